@@ -1,0 +1,121 @@
+/* msckf_hip.h -- C-ABI of the MI355X-native batched MSCKF filter core (libmsckf_hip.so).
+ *
+ * Drop-in boundary for the EKF hot path of daniilidis-group/msckf_mono.  The reference has no FFI layer:
+ * its operator boundary is the public interface of the header-only class template
+ *     msckf_mono::MSCKF<_S>            (include/msckf_mono/msckf.h:66-848)
+ * instantiated as MSCKF<float> by src/ros_interface.cpp:80 and datasets/asl_msckf.cpp:57.  Each entry point
+ * below replaces one member function of that class for ONE trajectory `b` of a batch handle (the reference
+ * object is the B = 1 case); include/msckf_mono/msckf.h in this repository is the C++ shim that keeps the
+ * reference's class/member names on top of these calls.
+ *
+ * Conventions: plain pointers and sizes only; every scalar crosses the boundary as double (narrowed to
+ * the handle's dtype inside); matrices are column-major; quaternions are (w,x,y,z) in Eigen's Hamilton
+ * convention; return value 0 = success, negative = -errno style failure (never throws; the reference
+ * reports nothing at all, msckf.h:328,1405-1409).  A handle is bound to one HIP device and one stream; calls
+ * on one handle must not be concurrent (the reference object is not re-entrant either).
+ *
+ * Packed argument layouts
+ *   cam12    c_u c_v f_u f_v b | q_CI(w,x,y,z) | p_C_I(3)                               types.h:48-55
+ *   noise29  u_var_prime v_var_prime | diag(Q_imu)(12) | diag(initial_imu_covar)(15)   types.h:86-92
+ *            (every caller of the reference passes diagonal matrices: asl_msckf.cpp:86-108)
+ *   params8  max_gn_cost_norm min_rcond translation_threshold redundancy_angle_thresh
+ *            redundancy_distance_thresh min_track_length max_track_length max_cam_states types.h:94-99
+ *   imu29    q_IG(4) b_g(3) v_I_G(3) b_a(3) p_I_G(3) g(3) q_IG_null(4) v_I_G_null(3) p_I_G_null(3)
+ *                                                                                       types.h:69-76
+ *   reading7 omega(3) a(3) dT                                                           types.h:78-84
+ *   cam7     q_CG(4) p_C_G(3)                                                           types.h:57-67
+ *
+ * Scope of this build: isotropic pixel noise only (u_var_prime == v_var_prime, the configuration the
+ * throughput metric is quoted on); msckf_hip_initialize returns -ENOTSUP otherwise (with
+ * anisotropic noise the reference's own result depends on JacobiSVD's arbitrary null-space basis).
+ */
+#ifndef MSCKF_HIP_H
+#define MSCKF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct msckf_hip_batch* msckf_hip_handle;
+
+enum { MSCKF_HIP_F32 = 0, MSCKF_HIP_F64 = 1 };
+
+/* ---- lifecycle --------------------------------------------------------------------------------------- */
+/* B trajectories; capacity n_cap camera states (>= max(max_cam_states, max_track_length)+1),
+ * f_cap tracks per update, m_cap observations per track (<= 64).  replaces: MSCKF() ctor, msckf.h:69. */
+int msckf_hip_create(int B, int n_cap, int f_cap, int m_cap, int dtype, int device, msckf_hip_handle* out);
+int msckf_hip_destroy(msckf_hip_handle h);
+const char* msckf_hip_last_error(void);
+
+/* ---- the reference's public member functions, per trajectory b ---------------------------------------- */
+/* MSCKF::initialize(camera, noise_params, msckf_params, imu_state)                   msckf.h:72-97  */
+int msckf_hip_initialize(msckf_hip_handle h, int b, const double* cam12, const double* noise29,
+                         const double* params8, const double* imu29);
+/* MSCKF::propagate(imuReading&), K consecutive readings fused into one launch        msckf.h:101-145 */
+int msckf_hip_propagate(msckf_hip_handle h, int b, const double* readings7, int K);
+/* MSCKF::augmentState(state_id, time)                                                msckf.h:148-212 */
+int msckf_hip_augment_state(msckf_hip_handle h, int b, int state_id, double time);
+/* MSCKF::update(measurements, feature_ids)   (host-side track bookkeeping)           msckf.h:215-299 */
+int msckf_hip_update(msckf_hip_handle h, int b, const double* meas2, const uint64_t* ids, int n);
+/* MSCKF::addFeatures(features, feature_ids)  (host-side track bookkeeping)           msckf.h:302-332 */
+int msckf_hip_add_features(msckf_hip_handle h, int b, const double* meas2, const uint64_t* ids, int n);
+/* MSCKF::marginalize()                                                               msckf.h:336-449 */
+int msckf_hip_marginalize(msckf_hip_handle h, int b);
+/* MSCKF::pruneEmptyStates()                                                          msckf.h:685-761 */
+int msckf_hip_prune_empty_states(msckf_hip_handle h, int b);
+/* MSCKF::pruneRedundantStates() -- not built yet: returns -ENOSYS  msckf.h:453-682 */
+int msckf_hip_prune_redundant_states(msckf_hip_handle h, int b);
+/* MSCKF::finish()                                                                    msckf.h:765-807 */
+int msckf_hip_finish(msckf_hip_handle h, int b);
+/* getters, msckf.h:810-848 */
+int msckf_hip_get_num_cam_states(msckf_hip_handle h, int b);                 /* getNumCamStates :810 */
+int msckf_hip_get_imu_state(msckf_hip_handle h, int b, double* imu29);       /* getImuState     :815 */
+int msckf_hip_get_cam_states(msckf_hip_handle h, int b, double* cam7, int* state_ids, int cap); /* getCamStates :835 */
+int msckf_hip_get_map(msckf_hip_handle h, int b, double* xyz, int cap);      /* getMap :820; returns count */
+int msckf_hip_get_pruned_state_ids(msckf_hip_handle h, int b, int* ids, int cap);  /* getPrunedStates :840 */
+
+/* ---- additive accessors (the reference keeps these private, msckf.h:52-54; needed for parity tests) ---- */
+int msckf_hip_get_covariance(msckf_hip_handle h, int b, double* P, int ld);  /* D x D, D = 15 + 6 N */
+int msckf_hip_set_covariance(msckf_hip_handle h, int b, const double* P, int D);
+int msckf_hip_set_imu_state(msckf_hip_handle h, int b, const double* imu29);
+int msckf_hip_set_cam_pose(msckf_hip_handle h, int b, int slot, const double* cam7);
+int msckf_hip_get_num_residualized(msckf_hip_handle h, int b, long long* n);
+int msckf_hip_set_num_residualized(msckf_hip_handle h, int b, long long n);
+/* last marginalize: out[0..6] = n_tracks, motion-rejected, triangulation-rejected, gate-rejected, passed,
+ * stacked rows m, kept rows r */
+int msckf_hip_last_stats(msckf_hip_handle h, int b, int* out7);
+/* per track of the last marginalize: out[t*8 + ..] = motion_ok tri_valid gate_pass included gamma p_f_G(3) */
+int msckf_hip_last_tracks(msckf_hip_handle h, int b, double* out8, int cap);
+int msckf_hip_last_deltax(msckf_hip_handle h, int b, double* dx, int cap);
+
+/* ---- batched path: work-lists ("front-end track dump": positional camera slots + normalized coords) ---- */
+/* Replace trajectory b's work-list by F tracks; slots/obs are flattened over tracks (sum(M) entries).
+ * This is what MSCKF::update() hands to marginalize() as feature_tracks_to_residualize_ (msckf.h:249-262). */
+int msckf_hip_set_tracks(msckf_hip_handle h, int b, int F, const int* M, const int* slots, const double* obs2);
+/* propagate / augment / marginalize / prune for the trajectory range [b0, b0+nb) in single launches */
+int msckf_hip_propagate_range(msckf_hip_handle h, int b0, int nb, const double* readings7, int K); /* [nb][K][7] */
+int msckf_hip_augment_range(msckf_hip_handle h, int b0, int nb);
+int msckf_hip_marginalize_range(msckf_hip_handle h, int b0, int nb);
+int msckf_hip_drop_oldest_range(msckf_hip_handle h, int b0, int nb, int n_drop);
+
+/* ---- batched path: HBM-resident scenario (inputs uploaded once, then frames run without host syncs) ---- */
+int msckf_hip_scenario_alloc(msckf_hip_handle h, int n_frames, int K);
+/* stage one (frame, trajectory) cell on the host side of the handle */
+int msckf_hip_scenario_set(msckf_hip_handle h, int frame, int b, const double* readings7 /*[K][7]*/, int F,
+                           const int* M, const int* slots, const double* obs2, int n_drop);
+int msckf_hip_scenario_commit(msckf_hip_handle h);   /* H2D of everything staged */
+/* one filter update per trajectory per frame: K x propagate + augmentState + marginalize + prune, for
+ * frames [f0, f1), asynchronously on the handle's stream */
+int msckf_hip_run_frames(msckf_hip_handle h, int f0, int f1);
+int msckf_hip_sync(msckf_hip_handle h);
+/* HIP-event stage timing: enable, run, sync, then read accumulated milliseconds and launch counts for
+ * stages 0 propagate, 1 augment, 2 feature+select, 3 compress stage 1, 4 compress merge, 5 kalman, 6 prune */
+int msckf_hip_profile_enable(msckf_hip_handle h, int on);
+int msckf_hip_profile_read(msckf_hip_handle h, double* ms7, int* count7);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

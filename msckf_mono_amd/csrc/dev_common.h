@@ -1,0 +1,204 @@
+// dev_common.h -- shared device-side layout and math helpers for the gfx950 MSCKF filter core.
+//
+// Data layout in HBM (one `Dev<S>` per batch of B independent trajectories, S = float | double):
+//   imu  [B][IMU_STRIDE]           q_IG(w,x,y,z) b_g v_I_G b_a p_I_G g q_IG_null v_I_G_null p_I_G_null
+//                                  (reference: types.h:69-76 imuState)
+//   cam  [B][n_cap][CAM_STRIDE]    q_CG(w,x,y,z) p_C_G                       (types.h:57-67 camState)
+//   prm  [B][PRM_STRIDE]           Camera / noiseParams / MSCKFParams scalars (types.h:48-99)
+//   P    [B][ld*ld]                full symmetric covariance, column-major, IMU block first, camera
+//                                  slot s at rows/cols 15+6s..  (reference keeps three blocks,
+//                                  msckf.h:52-54, and re-assembles them on every use :166-174)
+// Error-state order (msckf.h:1376-1391): [dtheta(0:3) db_g(3:6) dv(6:9) db_a(9:12) dp(12:15) | per cam dtheta_C dp_C].
+#ifndef MSCKF_DEV_COMMON_H
+#define MSCKF_DEV_COMMON_H
+
+#include <hip/hip_runtime.h>
+
+namespace msckf {
+
+constexpr int IMU_STRIDE = 32;
+constexpr int CAM_STRIDE = 8;
+constexpr int PRM_STRIDE = 48;
+constexpr int RD_STRIDE = 7;  // imuReading: omega(3) a(3) dT   (types.h:78-84)
+
+enum {  // offsets into imu[]
+  IQ = 0, IBG = 4, IV = 7, IBA = 10, IP = 13, IG = 16, IQN = 19, IVN = 23, IPN = 26
+};
+enum {  // offsets into prm[]
+  PRM_CU = 0, PRM_CV = 1, PRM_FU = 2, PRM_FV = 3, PRM_B = 4, PRM_QCI = 5, PRM_PCI = 9,
+  PRM_UVAR = 12, PRM_VVAR = 13, PRM_Q = 14,  // 12 diagonal entries of Q_imu
+  PRM_GN = 26, PRM_RCOND = 27, PRM_TRANS = 28, PRM_RANG = 29, PRM_RDIST = 30,
+  PRM_MINTL = 31, PRM_MAXTL = 32, PRM_MAXCS = 33
+};
+enum {  // per-track status bits written by k_feature / k_select
+  ST_MOTION_OK = 1, ST_TRI_VALID = 2, ST_GATE_PASS = 4, ST_INCLUDED = 8, ST_MOTION_SKIPPED = 16
+};
+enum { STAT_NTRACKS = 0, STAT_MOTION_REJ, STAT_TRI_REJ, STAT_GATE_REJ, STAT_PASSED, STAT_MROWS, STAT_RROWS, STAT_ERR, STAT_STRIDE = 8 };
+
+template <class S>
+struct Dev {
+  int B, n_cap, f_cap, m_cap;
+  int ld;      // leading dimension of P and of every D x * work matrix (multiple of 16)
+  int n6cap;   // 6*n_cap
+  int ldR;     // row stride of the QR work matrices: 64*NC >= 6*n_cap + 1
+  int nchunk;  // TSQR chunks per trajectory
+  // filter state
+  S* imu; S* cam; S* prm; S* P; S* Ptmp; int* ncam; long long* n_resid;
+  // current work-list (may point into a resident scenario)
+  const int* trk_n; const int* trk_M; const int* trk_slots; const S* trk_obs;
+  long wl_stride_n;   // stride between trajectories in trk_n   (ints)
+  long wl_stride_f;   // stride between trajectories in trk_M   (ints)
+  long wl_stride_o;   // stride between trajectories in trk_slots (ints) / trk_obs (2 scalars each)
+  // per-track products of k_feature
+  int* trk_status; S* trk_pf; S* trk_gamma; S* trk_Hx; S* trk_V; S* trk_Z; S* trk_ro; signed char* trk_inv; int* trk_first;
+  // k_select
+  int* row_start; int* stats;
+  // TSQR
+  S* Rbuf;
+  // Kalman work matrices
+  S* PHt; S* Smat; S* Linv; S* W; S* K; S* A; S* AP; S* X; S* dx;
+  // prune
+  int* keep; int* nkeep;
+};
+
+// ---------------------------------------------------------------- small math (all S-templated)
+template <class S> struct V3 { S x, y, z; };
+template <class S> __device__ __forceinline__ V3<S> mk3(S x, S y, S z) { V3<S> r; r.x = x; r.y = y; r.z = z; return r; }
+template <class S> __device__ __forceinline__ V3<S> ld3(const S* p) { return mk3(p[0], p[1], p[2]); }
+template <class S> __device__ __forceinline__ void st3(S* p, V3<S> v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+template <class S> __device__ __forceinline__ V3<S> operator+(V3<S> a, V3<S> b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <class S> __device__ __forceinline__ V3<S> operator-(V3<S> a, V3<S> b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <class S> __device__ __forceinline__ V3<S> operator*(S s, V3<S> a) { return mk3(s * a.x, s * a.y, s * a.z); }
+template <class S> __device__ __forceinline__ S dot3(V3<S> a, V3<S> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class S> __device__ __forceinline__ V3<S> cross3(V3<S> a, V3<S> b) {
+  return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+template <class S> struct M3 { S m[3][3]; };
+template <class S> __device__ __forceinline__ V3<S> mulv(const M3<S>& a, V3<S> v) {
+  return mk3(a.m[0][0] * v.x + a.m[0][1] * v.y + a.m[0][2] * v.z,
+             a.m[1][0] * v.x + a.m[1][1] * v.y + a.m[1][2] * v.z,
+             a.m[2][0] * v.x + a.m[2][1] * v.y + a.m[2][2] * v.z);
+}
+template <class S> __device__ __forceinline__ V3<S> multv(const M3<S>& a, V3<S> v) {  // a^T v
+  return mk3(a.m[0][0] * v.x + a.m[1][0] * v.y + a.m[2][0] * v.z,
+             a.m[0][1] * v.x + a.m[1][1] * v.y + a.m[2][1] * v.z,
+             a.m[0][2] * v.x + a.m[1][2] * v.y + a.m[2][2] * v.z);
+}
+template <class S> __device__ __forceinline__ M3<S> mulm(const M3<S>& a, const M3<S>& b) {
+  M3<S> r;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j];
+  return r;
+}
+template <class S> __device__ __forceinline__ M3<S> mulmt(const M3<S>& a, const M3<S>& b) {  // a * b^T
+  M3<S> r;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) r.m[i][j] = a.m[i][0] * b.m[j][0] + a.m[i][1] * b.m[j][1] + a.m[i][2] * b.m[j][2];
+  return r;
+}
+template <class S> __device__ __forceinline__ M3<S> skew3(V3<S> v) {  // matrix_utils.h:8-17
+  M3<S> r;
+  r.m[0][0] = 0; r.m[0][1] = -v.z; r.m[0][2] = v.y;
+  r.m[1][0] = v.z; r.m[1][1] = 0; r.m[1][2] = -v.x;
+  r.m[2][0] = -v.y; r.m[2][1] = v.x; r.m[2][2] = 0;
+  return r;
+}
+template <class S> struct Q4 { S w, x, y, z; };
+template <class S> __device__ __forceinline__ Q4<S> ldq(const S* p) { Q4<S> q; q.w = p[0]; q.x = p[1]; q.y = p[2]; q.z = p[3]; return q; }
+template <class S> __device__ __forceinline__ void stq(S* p, Q4<S> q) { p[0] = q.w; p[1] = q.x; p[2] = q.y; p[3] = q.z; }
+template <class S> __device__ __forceinline__ M3<S> q2rot(Q4<S> q) {  // Eigen toRotationMatrix
+  const S tx = S(2) * q.x, ty = S(2) * q.y, tz = S(2) * q.z;
+  const S twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  const S txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  const S tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  M3<S> r;
+  r.m[0][0] = S(1) - (tyy + tzz); r.m[0][1] = txy - twz; r.m[0][2] = txz + twy;
+  r.m[1][0] = txy + twz; r.m[1][1] = S(1) - (txx + tzz); r.m[1][2] = tyz - twx;
+  r.m[2][0] = txz - twy; r.m[2][1] = tyz + twx; r.m[2][2] = S(1) - (txx + tyy);
+  return r;
+}
+template <class S> __device__ __forceinline__ Q4<S> qmul(Q4<S> a, Q4<S> b) {
+  Q4<S> r;
+  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+  r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+  return r;
+}
+template <class S> __device__ __forceinline__ S dsqrt(S x);
+template <> __device__ __forceinline__ float dsqrt<float>(float x) { return sqrtf(x); }
+template <> __device__ __forceinline__ double dsqrt<double>(double x) { return sqrt(x); }
+template <class S> __device__ __forceinline__ Q4<S> qnormalized(Q4<S> q) {
+  S n = dsqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  q.w /= n; q.x /= n; q.y /= n; q.z /= n;
+  return q;
+}
+template <class S> __device__ __forceinline__ Q4<S> qinverse(Q4<S> q) {  // Eigen: conj / squaredNorm
+  S n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+  Q4<S> r; r.w = q.w / n2; r.x = -q.x / n2; r.y = -q.y / n2; r.z = -q.z / n2;
+  return r;
+}
+template <class S> __device__ __forceinline__ V3<S> qrotate(Q4<S> q, V3<S> v) {  // Eigen _transformVector
+  V3<S> u = mk3(q.x, q.y, q.z);
+  V3<S> uv = cross3(u, v);
+  uv = uv + uv;
+  return v + (q.w * uv) + cross3(u, uv);
+}
+// buildUpdateQuat, msckf.h:851-872
+template <class S> __device__ __forceinline__ Q4<S> update_quat(V3<S> dtheta) {
+  V3<S> dq = S(0.5) * dtheta;
+  S cs = dot3(dq, dq);
+  Q4<S> q;
+  q.w = (cs > S(1)) ? S(1) : dsqrt(S(1) - cs);
+  q.x = -dq.x; q.y = -dq.y; q.z = -dq.z;
+  return qnormalized(q);
+}
+
+// ---------------------------------------------------------------- wave64 helpers
+__device__ __forceinline__ float wave_bcast(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ double wave_bcast(double v, int lane) {
+  long long b = __double_as_longlong(v);
+  int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
+  int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ int wave_bcast(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+template <class S> __device__ __forceinline__ S wave_sum(S v) {  // xor butterfly: every lane gets the same sum
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <class S> __device__ __forceinline__ S wave_max(S v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { S t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+  return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
+  return v;
+}
+
+template <class S> struct Lim;
+template <> struct Lim<float> { static __device__ __forceinline__ float tiny() { return 1.17549435e-38f; } };
+template <> struct Lim<double> { static __device__ __forceinline__ double tiny() { return 2.2250738585072014e-308; } };
+
+// ---------------------------------------------------------------- launch entry points (one per .hip file)
+template <class S> void launch_propagate(const Dev<S>& d, int b0, int nb, const S* readings, long rd_stride, int K, hipStream_t st);
+template <class S> void launch_augment(const Dev<S>& d, int b0, int nb, hipStream_t st);
+template <class S> void launch_prune(const Dev<S>& d, int b0, int nb, hipStream_t st);
+template <class S> void launch_feature(const Dev<S>& d, int b0, int nb, hipStream_t st);
+template <class S> void launch_select(const Dev<S>& d, int b0, int nb, hipStream_t st);
+// phase: 0 = stage 1 + merges, 1 = stage 1 only (chunk-local QR updates), 2 = merge tree only
+template <class S> void launch_compress(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase);
+template <class S> void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st);
+size_t feature_lds_bytes(int m_cap, size_t scalar);
+
+}  // namespace msckf
+#endif

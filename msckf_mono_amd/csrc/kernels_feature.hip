@@ -1,0 +1,476 @@
+// kernels_feature.hip -- per-track stage of MSCKF::marginalize, one wavefront (64 lanes) per track.
+//
+//   checkMotion          msckf.h:980-1025      lane i holds observation i / camera state i of the track
+//   initializePosition   msckf.h:1147-1285     (+ generateInitialGuess :1126-1145, jacobian :1287-1323, cost :1027-1047)
+//   calcResidual         msckf.h:960-978
+//   calcMeasJacobian     msckf.h:905-958       2x6 blocks with the observability projection
+//   null-space           msckf.h:954-957       3 Householder reflectors of H_f_j (the reference takes the
+//                                              last 2M-3 columns of JacobiSVD's U; only the span matters)
+//   gatingTest           msckf.h:1103-1124     5% quantile of chi2(M+1), sigma^2 = u_var'
+//
+// What is NOT done the reference's way: H_o_j = A_j^T H_x_j is never formed.  With
+// Q = I - V T V^T (compact WY of the 3 reflectors) the projected block is
+//     H_o_j = (H_x_j)[3:, :] - V[3:, :] * Z,     Z = T^T V^T H_x_j   (3 x 6M, block-local per lane)
+// so a track is handed to the compression stage as {H_x blocks, V, Z, r_o}: 40*M scalars instead of
+// (2M-3)*(15+6N).  The gate uses G = H_x P_cc H_x^T assembled from 6x6 blocks of P (192 M^2 flop instead of
+// the dense 2 rho D^2) and S = (Q^T G Q)[3:,3:] + sigma^2 I as a rank-6 correction of G, factored by an
+// in-LDS Cholesky with r_o riding along as an extra row (gamma = |L^-1 r_o|^2).
+#include "chi2_table.h"
+#include "dev_common.h"
+
+namespace msckf {
+
+__constant__ double c_chi2[99];
+static bool g_chi2_uploaded[16] = {false};
+
+template <class S> struct Pose { M3<S> R; V3<S> t; };
+
+template <class S>
+__device__ __forceinline__ S tri_cost(const Pose<S>& T, S a, S b, S rho, S zx, S zy) {  // :1027-1047
+  const V3<S> h = mulv(T.R, mk3(a, b, S(1))) + (rho * T.t);
+  const S dx = h.x / h.z - zx, dy = h.y / h.z - zy;
+  return dx * dx + dy * dy;
+}
+
+// 3x3 LDL^T solve without pivoting (restates Eigen's .ldlt().solve() for the SPD system of :1222)
+template <class S>
+__device__ __forceinline__ void ldlt3(const S A[6], S lam, const S b[3], S x[3]) {
+  // A packed: a00 a01 a02 a11 a12 a22
+  const S a00 = A[0] + lam, a01 = A[1], a02 = A[2], a11 = A[3] + lam, a12 = A[4], a22 = A[5] + lam;
+  const S d0 = a00;
+  const S l10 = a01 / d0, l20 = a02 / d0;
+  const S d1 = a11 - l10 * l10 * d0;
+  const S l21 = (a12 - l20 * l10 * d0) / d1;
+  const S d2 = a22 - l20 * l20 * d0 - l21 * l21 * d1;
+  S y0 = b[0], y1 = b[1] - l10 * y0, y2 = b[2] - l20 * y0 - l21 * y1;
+  y0 /= d0; y1 /= d1; y2 /= d2;
+  x[2] = y2; x[1] = y1 - l21 * x[2]; x[0] = y0 - l10 * x[1] - l20 * x[2];
+}
+
+template <class S>
+__global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
+  const int b = b0 + blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
+  const int F = d.trk_n[(long)(b - b0) * d.wl_stride_n];
+  if (t >= F) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int m_cap = d.m_cap;
+  const int ldg = 2 * m_cap + 1;
+  S* sG = reinterpret_cast<S*>(smem_raw);              // [(2 m_cap + 1)][ldg]
+  S* sHx = sG + (2 * m_cap + 1) * ldg;                 // [m_cap][12]
+  S* sV = sHx + m_cap * 12;                            // [2 m_cap][3]
+  S* sE = sV + 2 * m_cap * 3;                          // [2 m_cap][3]
+  int* sSlot = reinterpret_cast<int*>(sE + 2 * m_cap * 3);
+
+  const long tb = (long)b * d.f_cap + t;               // per-track output index
+  const int M = d.trk_M[(long)(b - b0) * d.wl_stride_f + t];
+  const long wo = (long)(b - b0) * d.wl_stride_o + (long)t * m_cap;
+  const S* prm = d.prm + (long)b * PRM_STRIDE;
+  const S* imu = d.imu + (long)b * IMU_STRIDE;
+  const int ld = d.ld;
+  const bool act = lane < M;
+  int status = 0;
+  if (M < 2 || M > m_cap || M > 64) {                  // cannot be residualized (checkMotion :982 returns false)
+    if (lane == 0) { d.trk_status[tb] = 0; d.trk_gamma[tb] = 0; d.trk_first[tb] = 0; }
+    return;
+  }
+  // ---- load this lane's camera state and observation
+  const int slot = act ? d.trk_slots[wo + lane] : 0;
+  const S* cs = d.cam + ((long)b * d.n_cap + slot) * CAM_STRIDE;
+  const Q4<S> qc = ldq(cs);
+  const V3<S> pcg = ld3(cs + 4);
+  const S zx = act ? d.trk_obs[2 * (wo + lane)] : S(0), zy = act ? d.trk_obs[2 * (wo + lane) + 1] : S(0);
+  const M3<S> C = q2rot(qc);
+  const V3<S> g = ld3(imu + IG);
+  if (lane < m_cap) sSlot[lane] = act ? slot : -1;
+  // first camera of the track (lane 0) broadcast
+  M3<S> C0; V3<S> p0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C0.m[i][j] = wave_bcast(C.m[i][j], 0);
+  p0 = mk3(wave_bcast(pcg.x, 0), wave_bcast(pcg.y, 0), wave_bcast(pcg.z, 0));
+  const S z0x = wave_bcast(zx, 0), z0y = wave_bcast(zy, 0);
+
+  // ---- checkMotion :980-1025
+  {
+    V3<S> dir = mk3(z0x, z0y, S(1));
+    dir = (S(1) / dsqrt(dot3(dir, dir))) * dir;
+    dir = multv(C0, dir);
+    const V3<S> tr = pcg - p0;
+    const S par = dot3(tr, dir);
+    const V3<S> orth = tr - (par * dir);
+    S nrm = (act && lane > 0) ? dsqrt(dot3(orth, orth)) : S(0);
+    nrm = wave_max(nrm);
+    if (nrm > prm[PRM_TRANS]) status |= ST_MOTION_OK;
+  }
+
+  // ---- initializePosition :1147-1285 (Levenberg-Marquardt on inverse depth, wave-reduced sums)
+  Pose<S> T;
+  T.R = mulmt(C, C0);
+  T.t = mulv(C, p0 - pcg);
+  S sa, sb, srho;   // solution (alpha, beta, rho)
+  {
+    // generateInitialGuess with the LAST camera and the first/last observations :1172-1176
+    const int L = M - 1;
+    S depth;
+    {
+      const V3<S> m = mulv(T.R, mk3(z0x, z0y, S(1)));
+      const S A0 = m.x - zx * m.z, A1 = m.y - zy * m.z;
+      const S b0v = zx * T.t.z - T.t.x, b1v = zy * T.t.z - T.t.y;
+      depth = (S(1) / (A0 * A0 + A1 * A1)) * (A0 * b0v + A1 * b1v);
+      depth = wave_bcast(depth, L);
+    }
+    const S ix = z0x * depth, iy = z0y * depth, iz = depth;
+    sa = ix / iz; sb = iy / iz; srho = S(1) / iz;
+  }
+  S lambda = S(1e-3), delta_norm = 0;
+  S total_cost = wave_sum(act ? tri_cost(T, sa, sb, srho, zx, zy) : S(0));
+  bool reduced = false;
+  int inner = 0, outer = 0;
+  do {
+    S Ab[9];  // a00 a01 a02 a11 a12 a22 b0 b1 b2
+    {
+      const V3<S> h = mulv(T.R, mk3(sa, sb, S(1))) + (srho * T.t);
+      S W[3][3];
+      for (int i = 0; i < 3; ++i) { W[i][0] = T.R.m[i][0]; W[i][1] = T.R.m[i][1]; }
+      W[0][2] = T.t.x; W[1][2] = T.t.y; W[2][2] = T.t.z;
+      S J[2][3];
+      for (int j = 0; j < 3; ++j) {
+        J[0][j] = S(1) / h.z * W[0][j] - h.x / (h.z * h.z) * W[2][j];
+        J[1][j] = S(1) / h.z * W[1][j] - h.y / (h.z * h.z) * W[2][j];
+      }
+      const S r0 = h.x / h.z - zx, r1 = h.y / h.z - zy;
+      const S e = dsqrt(r0 * r0 + r1 * r1);
+      const S w = (e <= S(0.01)) ? S(1) : S(0.01) / (S(2) * e);
+      const S w2 = (w == S(1)) ? S(1) : w * w;
+      const S m = act ? w2 : S(0);
+      Ab[0] = m * (J[0][0] * J[0][0] + J[1][0] * J[1][0]);
+      Ab[1] = m * (J[0][0] * J[0][1] + J[1][0] * J[1][1]);
+      Ab[2] = m * (J[0][0] * J[0][2] + J[1][0] * J[1][2]);
+      Ab[3] = m * (J[0][1] * J[0][1] + J[1][1] * J[1][1]);
+      Ab[4] = m * (J[0][1] * J[0][2] + J[1][1] * J[1][2]);
+      Ab[5] = m * (J[0][2] * J[0][2] + J[1][2] * J[1][2]);
+      Ab[6] = m * (J[0][0] * r0 + J[1][0] * r1);
+      Ab[7] = m * (J[0][1] * r0 + J[1][1] * r1);
+      Ab[8] = m * (J[0][2] * r0 + J[1][2] * r1);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Ab[i] = wave_sum(Ab[i]);
+    do {
+      S dl[3];
+      ldlt3(Ab, lambda, Ab + 6, dl);
+      const S na = sa - dl[0], nb = sb - dl[1], nr = srho - dl[2];
+      delta_norm = dsqrt(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
+      const S new_cost = wave_sum(act ? tri_cost(T, na, nb, nr, zx, zy) : S(0));
+      if (new_cost < total_cost) {
+        reduced = true; sa = na; sb = nb; srho = nr; total_cost = new_cost;
+        lambda = lambda / 10 > S(1e-10) ? lambda / 10 : S(1e-10);
+      } else {
+        reduced = false;
+        lambda = lambda * 10 < S(1e12) ? lambda * 10 : S(1e12);
+      }
+    } while (inner++ < 10 && !reduced);
+    inner = 0;
+  } while (outer++ < 10 && delta_norm > S(5e-7));
+  const V3<S> fin = mk3(sa / srho, sb / srho, S(1) / srho);
+  {
+    const V3<S> pos = mulv(T.R, fin) + T.t;
+    const int bad = (act && pos.z <= S(0)) ? 1 : 0;
+    const bool any_bad = __any(bad);
+    const S ncost = total_cost / (S(2) * S(M) * S(M));
+    if (!any_bad && !(ncost > prm[PRM_GN])) status |= ST_TRI_VALID;
+  }
+  const V3<S> pf = multv(C0, fin) + p0;   // :1282
+
+  // ---- calcResidual :960-978 and calcMeasJacobian :915-950 for this lane's observation
+  S hx[2][6], hf[2][3], r[2];
+  {
+    const V3<S> pc = mulv(C, pf - pcg);
+    const S X = pc.x, Y = pc.y, Z = pc.z;
+    r[0] = zx - X / Z; r[1] = zy - Y / Z;
+    S Ji[2][3];
+    Ji[0][0] = S(1) * (S(1) / Z); Ji[0][1] = 0; Ji[0][2] = (-X / Z) * (S(1) / Z);
+    Ji[1][0] = 0; Ji[1][1] = S(1) * (S(1) / Z); Ji[1][2] = (-Y / Z) * (S(1) / Z);
+    const M3<S> sk = skew3(pc);
+    S A[2][6];
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 3; ++j) {
+        S a = 0, bb = 0;
+        for (int k = 0; k < 3; ++k) { a += Ji[i][k] * sk.m[k][j]; bb += Ji[i][k] * C.m[k][j]; }
+        A[i][j] = a; A[i][3 + j] = -bb;
+      }
+    const V3<S> uh = mulv(C, g);
+    const V3<S> ut = mulv(skew3(pf - pcg), g);
+    const S u[6] = {uh.x, uh.y, uh.z, ut.x, ut.y, ut.z};
+    S uu = 0;
+    for (int k = 0; k < 6; ++k) uu += u[k] * u[k];
+    for (int i = 0; i < 2; ++i) {
+      S Au = 0;
+      for (int k = 0; k < 6; ++k) Au += A[i][k] * u[k];
+      for (int k = 0; k < 6; ++k) {
+        const S h = act ? A[i][k] - Au * (S(1) / uu) * u[k] : S(0);
+        hx[i][k] = h;
+        if (k >= 3) hf[i][k - 3] = -h;
+      }
+    }
+    if (!act) { r[0] = 0; r[1] = 0; }
+  }
+
+  // ---- Householder QR of H_f_j (2M x 3): rows 2*lane, 2*lane+1 live in this lane
+  S v[2][3];      // V (unit lower trapezoidal), row-local
+  S tau[3];
+  const int row0 = 2 * lane;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    S t2 = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) if (row0 + s2 > k) t2 += hf[s2][k] * hf[s2][k];
+    t2 = wave_sum(t2);
+    const S c0 = wave_bcast(hf[k & 1][k], k >> 1);
+    S inv = 0;
+    if (t2 <= Lim<S>::tiny()) { tau[k] = 0; }
+    else {
+      S beta = dsqrt(c0 * c0 + t2);
+      if (c0 >= S(0)) beta = -beta;
+      inv = S(1) / (c0 - beta);
+      tau[k] = (beta - c0) / beta;
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int row = row0 + s2;
+      v[s2][k] = row > k ? hf[s2][k] * inv : (row == k ? S(1) : S(0));
+    }
+    // apply to the remaining columns of H_f
+#pragma unroll
+    for (int j = k + 1; j < 3; ++j) {
+      S s = v[0][k] * hf[0][j] + v[1][k] * hf[1][j];
+      s = wave_sum(s) * tau[k];
+      hf[0][j] -= s * v[0][k];
+      hf[1][j] -= s * v[1][k];
+    }
+  }
+  // compact WY: Q = I - V T V^T, T upper triangular (forward, columnwise)
+  const S d01 = wave_sum(v[0][0] * v[0][1] + v[1][0] * v[1][1]);
+  const S d02 = wave_sum(v[0][0] * v[0][2] + v[1][0] * v[1][2]);
+  const S d12 = wave_sum(v[0][1] * v[0][2] + v[1][1] * v[1][2]);
+  S Tm[3][3] = {{tau[0], 0, 0}, {0, tau[1], 0}, {0, 0, tau[2]}};
+  Tm[0][1] = -tau[1] * Tm[0][0] * d01;
+  Tm[0][2] = -tau[2] * (Tm[0][0] * d02 + Tm[0][1] * d12);
+  Tm[1][2] = -tau[2] * Tm[1][1] * d12;
+  // Z_c = T^T (V_rows^T Hx_c)  (3 x 6), local to the lane
+  S Zc[3][6];
+  {
+    S Wc[3][6];
+    for (int q = 0; q < 3; ++q) for (int k = 0; k < 6; ++k) Wc[q][k] = v[0][q] * hx[0][k] + v[1][q] * hx[1][k];
+    for (int q = 0; q < 3; ++q) for (int k = 0; k < 6; ++k) {
+      S s = 0;
+      for (int p = 0; p <= q; ++p) s += Tm[p][q] * Wc[p][k];
+      Zc[q][k] = s;
+    }
+  }
+  // Q^T r = r - V (T^T (V^T r))
+  S qr[2];
+  {
+    S wr[3], y[3];
+    for (int q = 0; q < 3; ++q) wr[q] = wave_sum(v[0][q] * r[0] + v[1][q] * r[1]);
+    for (int q = 0; q < 3; ++q) { S s = 0; for (int p = 0; p <= q; ++p) s += Tm[p][q] * wr[p]; y[q] = s; }
+    for (int s2 = 0; s2 < 2; ++s2) qr[s2] = r[s2] - (v[s2][0] * y[0] + v[s2][1] * y[1] + v[s2][2] * y[2]);
+  }
+
+  // ---- stage H_x, V in LDS; G = H_x P_cc H_x^T from 6x6 blocks of P (upper block-triangle + mirror)
+  if (lane < m_cap) {
+    for (int i = 0; i < 2; ++i) for (int k = 0; k < 6; ++k) sHx[lane * 12 + i * 6 + k] = hx[i][k];
+    for (int s2 = 0; s2 < 2; ++s2) for (int q = 0; q < 3; ++q) sV[(row0 + s2) * 3 + q] = v[s2][q];
+  }
+  __syncthreads();
+  const int R2 = 2 * M, rho = R2 - 3;
+  const S* P = d.P + (long)b * ld * ld;
+  {
+    const int npair = M * (M + 1) / 2;
+    for (int p = lane; p < npair; p += 64) {
+      // row-major upper-triangular index -> (a, bq), a <= bq
+      int a = (int)((S(2 * M + 1) - dsqrt(S((2 * M + 1) * (2 * M + 1) - 8 * p))) * S(0.5));
+      while (a > 0 && a * (2 * M - a + 1) / 2 > p) --a;
+      while ((a + 1) * (2 * M - a) / 2 <= p) ++a;
+      const int bq = a + (p - a * (2 * M - a + 1) / 2);
+      const int sa2 = sSlot[a], sb2 = sSlot[bq];
+      const S* Pab = P + (long)(15 + 6 * sb2) * ld + 15 + 6 * sa2;   // element (i,j) at Pab[j*ld + i]
+      S Tt[2][6];
+      for (int j = 0; j < 6; ++j) {
+        S s0 = 0, s1 = 0;
+        for (int i = 0; i < 6; ++i) { const S pv = Pab[(long)j * ld + i]; s0 += sHx[a * 12 + i] * pv; s1 += sHx[a * 12 + 6 + i] * pv; }
+        Tt[0][j] = s0; Tt[1][j] = s1;
+      }
+      for (int rr = 0; rr < 2; ++rr) for (int cc = 0; cc < 2; ++cc) {
+        S s = 0;
+        for (int j = 0; j < 6; ++j) s += Tt[rr][j] * sHx[bq * 12 + cc * 6 + j];
+        sG[(2 * a + rr) * ldg + 2 * bq + cc] = s;
+        if (a != bq) sG[(2 * bq + cc) * ldg + 2 * a + rr] = s;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- E = (G V) T - 1/2 V (T^T V^T G V T)
+  {
+    S gv[2][3];
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int row = row0 + s2;
+      S a0 = 0, a1 = 0, a2 = 0;
+      if (row < R2) for (int c = 0; c < R2; ++c) { const S gval = sG[row * ldg + c]; a0 += gval * sV[c * 3]; a1 += gval * sV[c * 3 + 1]; a2 += gval * sV[c * 3 + 2]; }
+      gv[s2][0] = a0; gv[s2][1] = a1; gv[s2][2] = a2;
+    }
+    S vgv[3][3];
+    for (int p = 0; p < 3; ++p) for (int q = 0; q < 3; ++q) vgv[p][q] = wave_sum(v[0][p] * gv[0][q] + v[1][p] * gv[1][q]);
+    S tmp[3][3], C3[3][3];
+    for (int p = 0; p < 3; ++p) for (int q = 0; q < 3; ++q) { S s = 0; for (int k = 0; k < 3; ++k) s += vgv[p][k] * Tm[k][q]; tmp[p][q] = s; }
+    for (int p = 0; p < 3; ++p) for (int q = 0; q < 3; ++q) { S s = 0; for (int k = 0; k < 3; ++k) s += Tm[k][p] * tmp[k][q]; C3[p][q] = s; }
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int row = row0 + s2;
+      if (row < R2)
+        for (int q = 0; q < 3; ++q) {
+          S y1 = 0, vc = 0;
+          for (int k = 0; k < 3; ++k) { y1 += gv[s2][k] * Tm[k][q]; vc += v[s2][k] * C3[k][q]; }
+          sE[row * 3 + q] = y1 - S(0.5) * vc;
+        }
+    }
+    // r_o rides along as the extra row 2M of the factorisation
+    for (int s2 = 0; s2 < 2; ++s2) { const int row = row0 + s2; if (row >= 3 && row < R2) sG[R2 * ldg + row] = qr[s2]; }
+  }
+  __syncthreads();
+  // ---- S = (Q^T G Q)[3:,3:] + sigma^2 I (lower triangle, in place)
+  const S sig2 = prm[PRM_UVAR];
+  for (int i = 3 + lane; i < R2; i += 64) {
+    const S vi0 = sV[i * 3], vi1 = sV[i * 3 + 1], vi2 = sV[i * 3 + 2];
+    const S ei0 = sE[i * 3], ei1 = sE[i * 3 + 1], ei2 = sE[i * 3 + 2];
+    for (int j = 3; j <= i; ++j) {
+      S s = sG[i * ldg + j] - (vi0 * sE[j * 3] + vi1 * sE[j * 3 + 1] + vi2 * sE[j * 3 + 2])
+            - (ei0 * sV[j * 3] + ei1 * sV[j * 3 + 1] + ei2 * sV[j * 3 + 2]);
+      if (i == j) s += sig2;
+      sG[i * ldg + j] = s;
+    }
+  }
+  __syncthreads();
+  // ---- Cholesky of S with the r_o row appended; gamma = sum y_k^2
+  bool spd = true;
+  for (int k = 3; k < R2; ++k) {
+    const S dkk = sG[k * ldg + k];
+    if (!(dkk > S(0))) { spd = false; break; }
+    const S dinv = S(1) / dsqrt(dkk);
+    for (int i = k + 1 + lane; i <= R2; i += 64) sG[i * ldg + k] *= dinv;
+    __syncthreads();
+    for (int i = k + 1 + lane; i <= R2; i += 64) {
+      const S lik = sG[i * ldg + k];
+      const int jmax = i < R2 ? i : R2 - 1;
+      for (int j = k + 1; j <= jmax; ++j) sG[i * ldg + j] -= lik * sG[j * ldg + k];
+    }
+    __syncthreads();
+  }
+  S gamma = 0;
+  for (int k = 3 + lane; k < R2; k += 64) { const S y = sG[R2 * ldg + k]; gamma += y * y; }
+  gamma = wave_sum(gamma);
+  const S thresh = S(c_chi2[M < 98 ? M : 98]);   // table[dof+1], dof = M-1   (:433, :1117)
+  if (spd && gamma < thresh) status |= ST_GATE_PASS;
+
+  // ---- publish the compact representation of the projected block
+  {
+    S* oHx = d.trk_Hx + (tb * m_cap) * 12;
+    S* oV = d.trk_V + (tb * 2 * m_cap) * 4;
+    S* oZ = d.trk_Z + (tb * m_cap) * 18;
+    S* oR = d.trk_ro + tb * 2 * m_cap;
+    if (act) {
+      for (int i = 0; i < 2; ++i) for (int k = 0; k < 6; ++k) oHx[lane * 12 + i * 6 + k] = hx[i][k];
+      for (int q = 0; q < 3; ++q) for (int k = 0; k < 6; ++k) oZ[lane * 18 + q * 6 + k] = Zc[q][k];
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int row = row0 + s2;
+        oV[row * 4 + 0] = v[s2][0]; oV[row * 4 + 1] = v[s2][1]; oV[row * 4 + 2] = v[s2][2]; oV[row * 4 + 3] = 0;
+        oR[row] = qr[s2];   // (Q^T r)[row]; rows >= 3 are r_o
+      }
+    }
+    signed char* inv = d.trk_inv + tb * d.n_cap;
+    for (int s = lane; s < d.n_cap; s += 64) inv[s] = -1;
+    __syncthreads();
+    if (act) inv[slot] = (signed char)lane;
+    int fs = act ? slot : 0x7fffffff;
+    fs = wave_min_i(fs);
+    if (lane == 0) {
+      d.trk_status[tb] = status;
+      d.trk_gamma[tb] = gamma;
+      d.trk_first[tb] = fs;
+      S* opf = d.trk_pf + tb * 4;
+      opf[0] = pf.x; opf[1] = pf.y; opf[2] = pf.z; opf[3] = 0;
+    }
+  }
+}
+
+// One thread per trajectory: resolves the order-dependent part of marginalize (:352-399) -- checkMotion is
+// skipped while fewer than 4 tracks have ever been residualized (Q4) -- and lays the gated-in tracks' rows
+// out contiguously (prefix sums) for the compression stage.
+template <class S>
+__global__ void k_select(Dev<S> d, int b0, int nb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nb) return;
+  const int b = b0 + i;
+  const int F = d.trk_n[(long)i * d.wl_stride_n];
+  long long nres = d.n_resid[b];
+  int* st = d.stats + (long)b * STAT_STRIDE;
+  int mrej = 0, trej = 0, grej = 0, pass = 0, rows = 0;
+  int* rs = d.row_start + (long)b * (d.f_cap + 1);
+  for (int t = 0; t < F; ++t) {
+    const long tb = (long)b * d.f_cap + t;
+    int s = d.trk_status[tb];
+    const int M = d.trk_M[(long)i * d.wl_stride_f + t];
+    rs[t] = rows;
+    bool valid = false;
+    if (M < 2) { if (nres > 3) mrej++; else trej++; s = 0; }
+    else if (nres > 3 && !(s & ST_MOTION_OK)) { mrej++; s &= ~(ST_TRI_VALID | ST_GATE_PASS); }
+    else {
+      if (nres <= 3) s |= ST_MOTION_SKIPPED;
+      if (s & ST_TRI_VALID) { valid = true; nres++; } else { trej++; s &= ~ST_GATE_PASS; }
+    }
+    if (valid) {
+      if (s & ST_GATE_PASS) { s |= ST_INCLUDED; pass++; rows += 2 * M - 3; }
+      else grej++;
+    }
+    d.trk_status[tb] = s;
+  }
+  rs[F] = rows;
+  d.n_resid[b] = nres;
+  st[STAT_NTRACKS] = F; st[STAT_MOTION_REJ] = mrej; st[STAT_TRI_REJ] = trej; st[STAT_GATE_REJ] = grej;
+  st[STAT_PASSED] = pass; st[STAT_MROWS] = rows; st[STAT_RROWS] = rows > 0 ? 6 * d.ncam[b] : 0;
+}
+
+size_t feature_lds_bytes(int m_cap, size_t scalar) {
+  const size_t ldg = 2 * (size_t)m_cap + 1;
+  return ((2 * (size_t)m_cap + 1) * ldg + (size_t)m_cap * 12 + 2 * (size_t)m_cap * 3 * 2) * scalar + (size_t)m_cap * sizeof(int) + 16;
+}
+
+template <class S>
+void launch_feature(const Dev<S>& d, int b0, int nb, hipStream_t st) {
+  if (nb <= 0) return;
+  int dev = 0;
+  hipGetDevice(&dev);
+  if (dev < 16 && !g_chi2_uploaded[dev]) {
+    hipMemcpyToSymbol(HIP_SYMBOL(c_chi2), kChi2Q05, sizeof(double) * 99);
+    g_chi2_uploaded[dev] = true;
+  }
+  const size_t lds = feature_lds_bytes(d.m_cap, sizeof(S));
+  static bool attr_set[2] = {false, false};
+  const int ti = sizeof(S) == 4 ? 0 : 1;
+  if (!attr_set[ti]) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature<S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set[ti] = true;
+  }
+  hipLaunchKernelGGL(k_feature<S>, dim3(d.f_cap, nb), dim3(64), lds, st, d, b0);
+}
+template <class S>
+void launch_select(const Dev<S>& d, int b0, int nb, hipStream_t st) {
+  if (nb <= 0) return;
+  hipLaunchKernelGGL(k_select<S>, dim3((nb + 63) / 64), dim3(64), 0, st, d, b0, nb);
+}
+
+template void launch_feature<float>(const Dev<float>&, int, int, hipStream_t);
+template void launch_feature<double>(const Dev<double>&, int, int, hipStream_t);
+template void launch_select<float>(const Dev<float>&, int, int, hipStream_t);
+template void launch_select<double>(const Dev<double>&, int, int, hipStream_t);
+
+}  // namespace msckf

@@ -1,0 +1,263 @@
+// kernels_kalman.hip -- Kalman gain, state correction and Joseph-form covariance update (gfx950).
+//
+// Reference: MSCKF::measurementUpdate, msckf.h:1368-1418 (+ buildUpdateQuat :851-872).  Inputs are the
+// compressed measurement [T | r_n] left by the TSQR stage in Rbuf[b][0] (T upper triangular n x n over
+// the camera columns, n = 6N; the IMU columns of T_H are zero, msckf.h:949) and R_n = sigma^2 I.
+//   PHt = P[:,15:] T^T                      (D x n)
+//   S   = T PHt[15:,:] + sigma^2 I          (n x n)     :1369
+//   S^-1 via Cholesky S = L L^T, Linv = L^-1 (the reference calls .inverse(), :1370; S is SPD)
+//   K   = (PHt Linv^T) Linv                 (D x n)     :1370
+//   dx  = K r_n, injected into the IMU and every camera state   :1373-1391
+//   A   = I - K T_H ;  P <- sym(A P A^T + sigma^2 K K^T)         :1394-1403
+// Every product is a batched tile GEMM (64x64 tile, 4x4 micro-tile per thread, LDS-staged); trajectories
+// with no gated-in rows are skipped.
+#include "dev_common.h"
+
+namespace msckf {
+
+enum { OP_PHT = 0, OP_S, OP_W, OP_K, OP_A, OP_AP, OP_X };
+
+template <class S>
+struct KView {
+  int D, n, ld, ldn, ldR;
+  S sig2;
+  const S* P; const S* R0;
+  S* PHt; S* Sm; S* Linv; S* W; S* K; S* A; S* AP; S* X;
+};
+template <class S>
+__device__ __forceinline__ KView<S> make_view(const Dev<S>& d, int b) {
+  KView<S> v;
+  v.n = 6 * d.ncam[b]; v.D = 15 + v.n; v.ld = d.ld; v.ldn = d.n6cap; v.ldR = d.ldR;
+  v.sig2 = d.prm[(long)b * PRM_STRIDE + PRM_UVAR];
+  const long pl = (long)d.ld * d.ld, nl = (long)d.n6cap * d.n6cap, dn = (long)d.ld * d.n6cap;
+  v.P = d.P + b * pl;
+  v.R0 = d.Rbuf + ((long)b * d.nchunk) * (long)d.n6cap * d.ldR;
+  v.PHt = d.PHt + b * dn; v.Sm = d.Smat + b * nl; v.Linv = d.Linv + b * nl;
+  v.W = d.W + b * dn; v.K = d.K + b * dn; v.A = d.A + b * pl; v.AP = d.AP + b * pl; v.X = d.X + b * pl;
+  return v;
+}
+
+template <class S, int OP> __device__ __forceinline__ void op_dims(const KView<S>& v, int& M, int& N, int& K) {
+  if (OP == OP_PHT) { M = v.D; N = v.n; K = v.n; }
+  else if (OP == OP_S) { M = v.n; N = v.n; K = v.n; }
+  else if (OP == OP_W || OP == OP_K) { M = v.D; N = v.n; K = v.n; }
+  else if (OP == OP_A) { M = v.D; N = v.D; K = v.n; }
+  else if (OP == OP_AP) { M = v.D; N = v.D; K = v.D; }
+  else { M = v.D; N = v.D; K = v.D + v.n; }
+}
+template <class S, int OP> __device__ __forceinline__ S op_a(const KView<S>& v, int i, int k) {
+  if (OP == OP_PHT) return v.P[(long)(15 + k) * v.ld + i];
+  if (OP == OP_S) return k >= i ? v.R0[(long)i * v.ldR + k] : S(0);
+  if (OP == OP_W) return v.PHt[(long)k * v.ld + i];
+  if (OP == OP_K) return v.W[(long)k * v.ld + i];
+  if (OP == OP_A) return v.K[(long)k * v.ld + i];
+  if (OP == OP_AP) return v.A[(long)k * v.ld + i];
+  return k < v.D ? v.AP[(long)k * v.ld + i] : v.sig2 * v.K[(long)(k - v.D) * v.ld + i];
+}
+template <class S, int OP> __device__ __forceinline__ S op_b(const KView<S>& v, int k, int j) {
+  if (OP == OP_PHT) return k >= j ? v.R0[(long)j * v.ldR + k] : S(0);            // T[j][k]
+  if (OP == OP_S) return v.PHt[(long)j * v.ld + 15 + k];
+  if (OP == OP_W) return k <= j ? v.Linv[(long)k * v.ldn + j] : S(0);             // Linv(j,k)
+  if (OP == OP_K) return j <= k ? v.Linv[(long)j * v.ldn + k] : S(0);             // Linv(k,j)
+  if (OP == OP_A) return (j >= 15 && j - 15 >= k) ? v.R0[(long)k * v.ldR + (j - 15)] : S(0);   // T_H[k][j]
+  if (OP == OP_AP) return v.P[(long)j * v.ld + k];
+  return k < v.D ? v.A[(long)k * v.ld + j] : v.K[(long)(k - v.D) * v.ld + j];
+}
+template <class S, int OP> __device__ __forceinline__ void op_store(const KView<S>& v, int i, int j, S acc) {
+  if (OP == OP_PHT) v.PHt[(long)j * v.ld + i] = acc;
+  else if (OP == OP_S) v.Sm[(long)j * v.ldn + i] = acc + (i == j ? v.sig2 : S(0));
+  else if (OP == OP_W) v.W[(long)j * v.ld + i] = acc;
+  else if (OP == OP_K) v.K[(long)j * v.ld + i] = acc;
+  else if (OP == OP_A) v.A[(long)j * v.ld + i] = (i == j ? S(1) : S(0)) - acc;
+  else if (OP == OP_AP) v.AP[(long)j * v.ld + i] = acc;
+  else v.X[(long)j * v.ld + i] = acc;
+}
+
+template <class S, int OP>
+__global__ __launch_bounds__(256) void k_gemm(Dev<S> d, int b0) {
+  const int b = b0 + blockIdx.z;
+  if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
+  const KView<S> v = make_view(d, b);
+  int M, N, K;
+  op_dims<S, OP>(v, M, N, K);
+  const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+  if (i0 >= M || j0 >= N) return;
+  __shared__ S sA[16][65];
+  __shared__ S sB[16][65];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  S acc[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = 0;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ii = tid & 63, kk = (tid >> 6) + 4 * q;
+      const int gi = i0 + ii, gk = k0 + kk;
+      sA[kk][ii] = (gi < M && gk < K) ? op_a<S, OP>(v, gi, gk) : S(0);
+      const int kb = tid & 15, jj = (tid >> 4) + 16 * q;
+      const int gj = j0 + jj, gk2 = k0 + kb;
+      sB[kb][jj] = (gj < N && gk2 < K) ? op_b<S, OP>(v, gk2, gj) : S(0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      S a[4], bb[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[r] = sA[kk][4 * ty + r];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bb[c] = sB[kk][4 * tx + c];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] += a[r] * bb[c];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int gi = i0 + 4 * ty + r, gj = j0 + 4 * tx + c;
+      if (gi < M && gj < N) op_store<S, OP>(v, gi, gj, acc[r][c]);
+    }
+}
+
+// Cholesky S = L L^T and in-place triangular inverse, one workgroup per trajectory.  The matrix is staged
+// in LDS when it fits (n*(n+1) scalars), otherwise it is factored in place in global memory.
+template <class S, bool LDS>
+__global__ __launch_bounds__(256) void k_chol_inv(Dev<S> d, int b0) {
+  const int b = b0 + blockIdx.x, tid = threadIdx.x;
+  if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
+  const KView<S> v = make_view(d, b);
+  const int n = v.n;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  S* L; int ldl;
+  if (LDS) {
+    L = reinterpret_cast<S*>(smem_raw); ldl = n + 1;
+    for (int e = tid; e < n * n; e += 256) { const int i = e % n, j = e / n; L[(long)j * ldl + i] = v.Sm[(long)j * v.ldn + i]; }
+  } else { L = v.Sm; ldl = v.ldn; }
+  __syncthreads();
+  // right-looking Cholesky on the lower triangle (column-major: element (i,j) at L[j*ldl + i])
+  for (int k = 0; k < n; ++k) {
+    const S dkk = L[(long)k * ldl + k];
+    const S dd = dsqrt(dkk > S(0) ? dkk : Lim<S>::tiny());
+    __syncthreads();
+    const S dinv = S(1) / dd;
+    for (int i = k + tid; i < n; i += 256) L[(long)k * ldl + i] = (i == k) ? dd : L[(long)k * ldl + i] * dinv;
+    __syncthreads();
+    // trailing update: columns j = k+1.., rows i >= j
+    const int rem = n - k - 1;
+    for (int e = tid; e < rem * rem; e += 256) {
+      const int jj = e / rem, ii = e % rem;
+      if (ii >= jj) {
+        const int i = k + 1 + ii, j = k + 1 + jj;
+        L[(long)j * ldl + i] -= L[(long)k * ldl + i] * L[(long)k * ldl + j];
+      }
+    }
+    __syncthreads();
+  }
+  // in-place inverse of the lower-triangular L (unblocked trtri, columns right to left)
+  for (int j = n - 1; j >= 0; --j) {
+    const S ljj = S(1) / L[(long)j * ldl + j];
+    __syncthreads();
+    // x = -Linv[j+1:, j+1:] * L[j+1:, j] * ljj ; rows processed in parallel, reading the original column j
+    S xs[4]; int cnt = 0;
+    for (int i = j + 1 + tid; i < n; i += 256) {   // n <= 1024: at most four rows per thread
+      S s = 0;
+      for (int k = j + 1; k <= i; ++k) s += L[(long)k * ldl + i] * L[(long)j * ldl + k];
+      xs[cnt++] = -s * ljj;
+    }
+    __syncthreads();
+    cnt = 0;
+    for (int i = j + 1 + tid; i < n; i += 256) L[(long)j * ldl + i] = xs[cnt++];
+    if (tid == 0) L[(long)j * ldl + j] = ljj;
+    __syncthreads();
+  }
+  // publish Linv (lower triangle, zeros above)
+  for (int e = tid; e < n * n; e += 256) {
+    const int i = e % n, j = e / n;
+    v.Linv[(long)j * v.ldn + i] = (i >= j) ? L[(long)j * ldl + i] : S(0);
+  }
+}
+
+// dx = K r_n and state injection (msckf.h:1373-1391); one workgroup per trajectory.
+template <class S>
+__global__ __launch_bounds__(256) void k_inject(Dev<S> d, int b0) {
+  const int b = b0 + blockIdx.x, tid = threadIdx.x;
+  if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
+  const KView<S> v = make_view(d, b);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  S* sdx = reinterpret_cast<S*>(smem_raw);
+  for (int i = tid; i < v.D; i += 256) {
+    S s = 0;
+    for (int a = 0; a < v.n; ++a) s += v.K[(long)a * v.ld + i] * v.R0[(long)a * v.ldR + v.n];
+    sdx[i] = s;
+    d.dx[(long)b * d.ld + i] = s;
+  }
+  __syncthreads();
+  S* imu = d.imu + (long)b * IMU_STRIDE;
+  if (tid == 0) {
+    const Q4<S> q = qmul(update_quat(mk3(sdx[0], sdx[1], sdx[2])), ldq(imu + IQ));   // not re-normalised (:1376-1378)
+    stq(imu + IQ, q);
+    for (int k = 0; k < 3; ++k) { imu[IBG + k] += sdx[3 + k]; imu[IV + k] += sdx[6 + k]; imu[IBA + k] += sdx[9 + k]; imu[IP + k] += sdx[12 + k]; }
+  }
+  const int N = d.ncam[b];
+  for (int c = tid; c < N; c += 256) {
+    S* cs = d.cam + ((long)b * d.n_cap + c) * CAM_STRIDE;
+    const Q4<S> q = qnormalized(qmul(update_quat(mk3(sdx[15 + 6 * c], sdx[16 + 6 * c], sdx[17 + 6 * c])), ldq(cs)));
+    stq(cs, q);
+    for (int k = 0; k < 3; ++k) cs[4 + k] += sdx[18 + 6 * c + k];
+  }
+}
+
+template <class S>
+__global__ __launch_bounds__(256) void k_symmetrize(Dev<S> d, int b0) {
+  const int b = b0 + blockIdx.y;
+  if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
+  const int D = 15 + 6 * d.ncam[b], ld = d.ld;
+  const S* X = d.X + (long)b * ld * ld;
+  S* P = d.P + (long)b * ld * ld;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)D * D; e += (long)gridDim.x * 256) {
+    const int i = (int)(e % D), j = (int)(e / D);
+    P[(long)j * ld + i] = (X[(long)j * ld + i] + X[(long)i * ld + j]) / S(2);
+  }
+}
+
+template <class S, int OP>
+static void gemm(const Dev<S>& d, int b0, int nb, int Mmax, int Nmax, hipStream_t st) {
+  hipLaunchKernelGGL((k_gemm<S, OP>), dim3((Mmax + 63) / 64, (Nmax + 63) / 64, nb), dim3(256), 0, st, d, b0);
+}
+
+template <class S>
+void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st) {
+  if (nb <= 0) return;
+  const int n = d.n6cap, D = 15 + n;
+  gemm<S, OP_PHT>(d, b0, nb, D, n, st);
+  gemm<S, OP_S>(d, b0, nb, n, n, st);
+  const size_t lds = (size_t)n * (n + 1) * sizeof(S);
+  if (lds <= 150 * 1024) {
+    static bool attr_set[2] = {false, false};
+    const int ti = sizeof(S) == 4 ? 0 : 1;
+    if (!attr_set[ti]) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_inv<S, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set[ti] = true;
+    }
+    hipLaunchKernelGGL((k_chol_inv<S, true>), dim3(nb), dim3(256), lds, st, d, b0);
+  } else {
+    hipLaunchKernelGGL((k_chol_inv<S, false>), dim3(nb), dim3(256), 0, st, d, b0);
+  }
+  gemm<S, OP_W>(d, b0, nb, D, n, st);
+  gemm<S, OP_K>(d, b0, nb, D, n, st);
+  hipLaunchKernelGGL(k_inject<S>, dim3(nb), dim3(256), (size_t)d.ld * sizeof(S), st, d, b0);
+  gemm<S, OP_A>(d, b0, nb, D, D, st);
+  gemm<S, OP_AP>(d, b0, nb, D, D, st);
+  gemm<S, OP_X>(d, b0, nb, D, D, st);
+  hipLaunchKernelGGL(k_symmetrize<S>, dim3(16, nb), dim3(256), 0, st, d, b0);
+}
+
+template void launch_kalman<float>(const Dev<float>&, int, int, hipStream_t);
+template void launch_kalman<double>(const Dev<double>&, int, int, hipStream_t);
+
+}  // namespace msckf

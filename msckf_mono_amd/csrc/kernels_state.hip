@@ -1,0 +1,323 @@
+// kernels_state.hip -- covariance propagation, state augmentation and camera-state pruning (gfx950).
+//
+//   k_propagate  <- MSCKF::propagate            msckf.h:101-145 (+ calcF :874-890, calcG :892-903,
+//                                                propogateImuStateRK :1425-1467, OC patch :116-132)
+//   k_augment    <- MSCKF::augmentState         msckf.h:148-212
+//   k_prune      <- pruneEmptyStates' gather    msckf.h:719-757, matrix_utils.h:58-87
+//
+// Design (not a translation): K queued IMU samples are fused into one launch; the 15x15 blocks live in
+// LDS, Phi_total = Phi_K...Phi_1 is accumulated so the only O(N) part, P_IC <- Phi P_IC, touches HBM once
+// per image instead of once per IMU sample; G Q G^T is applied in its closed block-diagonal form;
+// augmentation uses the 6 non-zero 3x3 blocks of J instead of two dense (D+6) x D GEMMs and never
+// computes the unused determinant of msckf.h:176.
+#include "dev_common.h"
+
+namespace msckf {
+
+template <class S> struct ExpOrder;
+template <> struct ExpOrder<float> { static constexpr int value = 8; };
+template <> struct ExpOrder<double> { static constexpr int value = 13; };
+
+// C = A*B for 15x15 row-major LDS matrices, 64 lanes cooperatively (no aliasing between C and A/B)
+template <class S>
+__device__ __forceinline__ void mm15(S* C, const S* A, const S* B, int lane) {
+  for (int e = lane; e < 225; e += 64) {
+    const int i = e / 15, j = e % 15;
+    S s = 0;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) s += A[i * 15 + k] * B[k * 15 + j];
+    C[e] = s;
+  }
+}
+template <class S>
+__device__ __forceinline__ void mm15_abt(S* C, const S* A, const S* B, int lane) {  // C = A*B^T
+  for (int e = lane; e < 225; e += 64) {
+    const int i = e / 15, j = e % 15;
+    S s = 0;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) s += A[i * 15 + k] * B[j * 15 + k];
+    C[e] = s;
+  }
+}
+
+template <class S>
+__global__ __launch_bounds__(64) void k_propagate(Dev<S> d, int b0, const S* readings, long rd_stride, int K) {
+  const int b = b0 + blockIdx.x, lane = threadIdx.x;
+  __shared__ S sF[225], sPhi[225], sT1[225], sT2[225], sTot[225], sPii[225], sSt[IMU_STRIDE];
+  S* imu = d.imu + (long)b * IMU_STRIDE;
+  const S* prm = d.prm + (long)b * PRM_STRIDE;
+  S* P = d.P + (long)b * d.ld * d.ld;
+  const int ld = d.ld;
+  const int n = 6 * d.ncam[b];
+  if (lane < IMU_STRIDE) sSt[lane] = imu[lane];
+  for (int e = lane; e < 225; e += 64) {
+    const int i = e / 15, j = e % 15;
+    sPii[e] = P[(long)j * ld + i];
+    sTot[e] = (i == j) ? S(1) : S(0);
+  }
+  __syncthreads();
+  const S* rd = readings + (long)(b - b0) * rd_stride;
+  for (int k = 0; k < K; ++k) {
+    const V3<S> om = ld3(rd + k * RD_STRIDE), ac = ld3(rd + k * RD_STRIDE + 3);
+    const S dT = rd[k * RD_STRIDE + 6];
+    // ---- every lane evaluates the (tiny) state propagation redundantly; lane 0 commits it
+    const Q4<S> q = ldq(sSt + IQ);
+    const V3<S> bg = ld3(sSt + IBG), v = ld3(sSt + IV), ba = ld3(sSt + IBA), p = ld3(sSt + IP), g = ld3(sSt + IG);
+    const Q4<S> qn0 = ldq(sSt + IQN);
+    const V3<S> vn0 = ld3(sSt + IVN), pn0 = ld3(sSt + IPN);
+    const V3<S> wh = om - bg, ah = ac - ba;
+    const M3<S> C = q2rot(q);
+    // RK on the JPL-ordered quaternion (-x,-y,-z,w) with 0.5*Omega(w)   msckf.h:1430-1456
+    S y0[4] = {-q.x, -q.y, -q.z, q.w};
+    auto omul = [&](const S* y, S* o) {  // o = 0.5*omegaMat(wh) * y   (matrix_utils.h:20-30)
+      o[0] = S(0.5) * (wh.z * y[1] - wh.y * y[2] + wh.x * y[3]);
+      o[1] = S(0.5) * (-wh.z * y[0] + wh.x * y[2] + wh.y * y[3]);
+      o[2] = S(0.5) * (wh.y * y[0] - wh.x * y[1] + wh.z * y[3]);
+      o[3] = S(0.5) * (-wh.x * y[0] - wh.y * y[1] - wh.z * y[2]);
+    };
+    S k0[4], k1[4], k2[4], k3[4], k4[4], k5[4], t[4];
+    omul(y0, k0);
+    for (int i = 0; i < 4; ++i) t[i] = y0[i] + (k0[i] / S(4)) * dT;
+    omul(t, k1);
+    for (int i = 0; i < 4; ++i) t[i] = y0[i] + (k0[i] / S(8) + k1[i] / S(8)) * dT;
+    omul(t, k2);
+    for (int i = 0; i < 4; ++i) t[i] = y0[i] + (-k1[i] / S(2) + k2[i]) * dT;
+    omul(t, k3);
+    for (int i = 0; i < 4; ++i) t[i] = y0[i] + (k0[i] * S(3) / S(16) + k3[i] * S(9) / S(16)) * dT;
+    omul(t, k4);
+    for (int i = 0; i < 4; ++i)
+      t[i] = y0[i] + (-k0[i] * S(3) / S(7) + k1[i] * S(2) / S(7) + k2[i] * S(12) / S(7) - k3[i] * S(12) / S(7) + k4[i] * S(8) / S(7)) * dT;
+    omul(t, k5);
+    S yt[4];
+    for (int i = 0; i < 4; ++i) yt[i] = y0[i] + (S(7) * k0[i] + S(32) * k2[i] + S(12) * k3[i] + S(32) * k4[i] + S(7) * k5[i]) * dT / S(90);
+    Q4<S> qn; qn.w = yt[3]; qn.x = -yt[0]; qn.y = -yt[1]; qn.z = -yt[2];
+    qn = qnormalized(qn);
+    const V3<S> vn = v + (dT * (multv(C, ah) + g));
+    const V3<S> pn = p + (dT * v);
+    // ---- F*dT (calcF :885-889) into LDS
+    const M3<S> sw = skew3(wh), sa = skew3(ah);
+    for (int e = lane; e < 225; e += 64) sF[e] = 0;
+    __syncthreads();
+    if (lane < 9) {
+      const int i = lane / 3, j = lane % 3;
+      sF[i * 15 + j] = -sw.m[i][j] * dT;
+      sF[i * 15 + 3 + j] = (i == j) ? -dT : S(0);
+      S s = 0;
+      for (int kk = 0; kk < 3; ++kk) s += C.m[kk][i] * sa.m[kk][j];  // (C^T [a x])_ij
+      sF[(6 + i) * 15 + j] = -s * dT;
+      sF[(6 + i) * 15 + 9 + j] = -C.m[j][i] * dT;
+      sF[(12 + i) * 15 + 6 + j] = (i == j) ? dT : S(0);
+    }
+    __syncthreads();
+    // ---- Phi = expm(F dT): scaling & squaring Taylor (replaces Eigen's Pade, msckf.h:111; equal to
+    //      working precision: ||A/2^s||_1 <= 0.25, truncation < 0.25^(order+1)/(order+1)!)
+    S colsum = 0;
+    if (lane < 15) for (int i = 0; i < 15; ++i) colsum += sF[i * 15 + lane] < 0 ? -sF[i * 15 + lane] : sF[i * 15 + lane];
+    const S l1 = wave_max(colsum);
+    int sq = 0;
+    { S x = l1; while (x > S(0.25) && sq < 30) { x *= S(0.5); ++sq; } }
+    const S scale = S(1) / S(1 << sq);
+    for (int e = lane; e < 225; e += 64) {
+      sF[e] *= scale;
+      sT1[e] = sF[e];                                   // term_1 = A
+      sPhi[e] = sF[e] + ((e / 15 == e % 15) ? S(1) : S(0));
+    }
+    __syncthreads();
+    S* tcur = sT1; S* tnxt = sT2;
+    for (int o = 2; o <= ExpOrder<S>::value; ++o) {
+      mm15(tnxt, tcur, sF, lane);
+      __syncthreads();
+      const S inv = S(1) / S(o);
+      for (int e = lane; e < 225; e += 64) { tnxt[e] *= inv; sPhi[e] += tnxt[e]; }
+      __syncthreads();
+      S* sw2 = tcur; tcur = tnxt; tnxt = sw2;
+    }
+    for (int s2 = 0; s2 < sq; ++s2) {
+      mm15(sT1, sPhi, sPhi, lane);
+      __syncthreads();
+      for (int e = lane; e < 225; e += 64) sPhi[e] = sT1[e];
+      __syncthreads();
+    }
+    // ---- observability-constraint patch of Phi blocks (0,0),(6,0),(12,0)   msckf.h:116-132
+    if (lane == 0) {
+      const M3<S> Rk = q2rot(qn0);
+      const M3<S> R00 = mulmt(q2rot(qn), Rk);
+      const V3<S> u = mulv(Rk, g);
+      const V3<S> sv = (S(1) / dot3(u, u)) * u;
+      M3<S> A1, A2;
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { A1.m[i][j] = sPhi[(6 + i) * 15 + j]; A2.m[i][j] = sPhi[(12 + i) * 15 + j]; }
+      const V3<S> w1 = mulv(skew3(vn0 - vn), g);
+      const V3<S> w2 = mulv(skew3((dT * vn0) + pn0 - pn), g);
+      const V3<S> e1 = mulv(A1, u) - w1, e2 = mulv(A2, u) - w2;
+      const S e1v[3] = {e1.x, e1.y, e1.z}, e2v[3] = {e2.x, e2.y, e2.z}, s3[3] = {sv.x, sv.y, sv.z};
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        sPhi[i * 15 + j] = R00.m[i][j];
+        sPhi[(6 + i) * 15 + j] = A1.m[i][j] - e1v[i] * s3[j];
+        sPhi[(12 + i) * 15 + j] = A2.m[i][j] - e2v[i] * s3[j];
+      }
+      // commit the propagated state and re-anchor the null-space states   :138-141
+      stq(sSt + IQ, qn); st3(sSt + IV, vn); st3(sSt + IP, pn);
+      stq(sSt + IQN, qn); st3(sSt + IVN, vn); st3(sSt + IPN, pn);
+    }
+    // ---- P_II + G Q G^T dT : diag(Qw, Qbg, C^T Qa C, Qba, 0)   (calcG :899-902, Q diagonal)
+    if (lane < 9) {
+      const int i = lane / 3, j = lane % 3;
+      if (i == j) {
+        sPii[i * 15 + i] += prm[PRM_Q + i] * dT;
+        sPii[(3 + i) * 15 + 3 + i] += prm[PRM_Q + 3 + i] * dT;
+        sPii[(9 + i) * 15 + 9 + i] += prm[PRM_Q + 9 + i] * dT;
+      }
+      S s = 0;
+      for (int kk = 0; kk < 3; ++kk) s += C.m[kk][i] * prm[PRM_Q + 6 + kk] * C.m[kk][j];
+      sPii[(6 + i) * 15 + 6 + j] += s * dT;
+    }
+    __syncthreads();
+    mm15(sT1, sPhi, sPii, lane);       // Phi * inner
+    __syncthreads();
+    mm15_abt(sT2, sT1, sPhi, lane);    // (Phi*inner) * Phi^T    :134
+    __syncthreads();
+    for (int e = lane; e < 225; e += 64) {  // symmetrise :143
+      const int i = e / 15, j = e % 15;
+      sPii[e] = (sT2[i * 15 + j] + sT2[j * 15 + i]) / S(2);
+    }
+    mm15(sT1, sPhi, sTot, lane);       // Phi_total <- Phi_k * Phi_total
+    __syncthreads();
+    for (int e = lane; e < 225; e += 64) sTot[e] = sT1[e];
+    __syncthreads();
+  }
+  // ---- write back state, P_II, and P_IC <- Phi_total P_IC (both halves of the symmetric storage) :144
+  if (lane < IMU_STRIDE) imu[lane] = sSt[lane];
+  for (int e = lane; e < 225; e += 64) { const int i = e / 15, j = e % 15; P[(long)j * ld + i] = sPii[e]; }
+  for (int c = lane; c < n; c += 64) {
+    S col[15], out[15];
+    S* pc = P + (long)(15 + c) * ld;
+#pragma unroll
+    for (int i = 0; i < 15; ++i) col[i] = pc[i];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) {
+      S s = 0;
+#pragma unroll
+      for (int kk = 0; kk < 15; ++kk) s += sTot[i * 15 + kk] * col[kk];
+      out[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < 15; ++i) { pc[i] = out[i]; P[(long)i * ld + 15 + c] = out[i]; }
+  }
+}
+
+template <class S>
+__global__ __launch_bounds__(256) void k_augment(Dev<S> d, int b0) {
+  const int b = b0 + blockIdx.x, tid = threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  S* sJP = reinterpret_cast<S*>(smem_raw);  // [6][ld]
+  const int n = d.ncam[b];
+  if (n >= d.n_cap) { if (tid == 0) d.stats[(long)b * STAT_STRIDE + STAT_ERR] = 1; return; }
+  const int D = 15 + 6 * n, ld = d.ld;
+  const S* imu = d.imu + (long)b * IMU_STRIDE;
+  const S* prm = d.prm + (long)b * PRM_STRIDE;
+  S* P = d.P + (long)b * ld * ld;
+  const Q4<S> q = ldq(imu + IQ), qci = ldq(prm + PRM_QCI);
+  const V3<S> pci = ld3(prm + PRM_PCI);
+  const V3<S> lever = qrotate(qinverse(q), pci);   // q_IG^-1 * p_C_I   :160,183
+  const M3<S> Jtt = q2rot(qci), Jpt = skew3(lever);
+  if (tid == 0) {
+    S* cs = d.cam + ((long)b * d.n_cap + n) * CAM_STRIDE;
+    stq(cs, qnormalized(qmul(qci, q)));             // :152-154
+    st3(cs + 4, ld3(imu + IP) + lever);             // :159-160
+  }
+  for (int c = tid; c < D; c += 256) {              // J P, J non-zero only in cols 0-2 and 12-14 (:180-184)
+    const S* pc = P + (long)c * ld;
+    const V3<S> th = mk3(pc[0], pc[1], pc[2]);
+    const V3<S> a = mulv(Jtt, th), bb = mulv(Jpt, th);
+    const S jp[6] = {a.x, a.y, a.z, bb.x + pc[12], bb.y + pc[13], bb.z + pc[14]};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { sJP[i * ld + c] = jp[i]; P[(long)c * ld + D + i] = jp[i]; P[(long)(D + i) * ld + c] = jp[i]; }
+  }
+  __syncthreads();
+  if (tid < 36) {                                   // corner J P J^T, symmetrised (:195-197)
+    const int i = tid / 6, j = tid % 6;
+    auto corner = [&](int r, int cc) {
+      const S* jp = sJP + r * ld;
+      if (cc < 3) return jp[0] * Jtt.m[cc][0] + jp[1] * Jtt.m[cc][1] + jp[2] * Jtt.m[cc][2];
+      const int c3 = cc - 3;
+      return jp[0] * Jpt.m[c3][0] + jp[1] * Jpt.m[c3][1] + jp[2] * Jpt.m[c3][2] + jp[12 + c3];
+    };
+    P[(long)(D + j) * ld + D + i] = (corner(i, j) + corner(j, i)) / S(2);
+  }
+  if (tid == 0) d.ncam[b] = n + 1;
+}
+
+// Gather the kept camera slots (keep[] ascending) of P into Ptmp, then copy back and compact cam[].
+template <class S>
+__global__ __launch_bounds__(256) void k_prune_gather(Dev<S> d, int b0) {
+  const int b = b0 + blockIdx.y;
+  const int nk = d.nkeep[b], n = d.ncam[b];
+  if (nk >= n) return;
+  const int Dn = 15 + 6 * nk, ld = d.ld;
+  const int* keep = d.keep + (long)b * d.n_cap;
+  const S* P = d.P + (long)b * ld * ld;
+  S* T = d.Ptmp + (long)b * ld * ld;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)Dn * Dn; e += (long)gridDim.x * 256) {
+    const int i = (int)(e % Dn), j = (int)(e / Dn);
+    const int si = i < 15 ? i : 15 + 6 * keep[(i - 15) / 6] + (i - 15) % 6;
+    const int sj = j < 15 ? j : 15 + 6 * keep[(j - 15) / 6] + (j - 15) % 6;
+    T[(long)j * ld + i] = P[(long)sj * ld + si];
+  }
+}
+template <class S>
+__global__ __launch_bounds__(256) void k_prune_commit(Dev<S> d, int b0) {
+  const int b = b0 + blockIdx.y;
+  const int nk = d.nkeep[b], n = d.ncam[b];
+  if (nk >= n) return;
+  const int Dn = 15 + 6 * nk, ld = d.ld;
+  S* P = d.P + (long)b * ld * ld;
+  const S* T = d.Ptmp + (long)b * ld * ld;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)Dn * Dn; e += (long)gridDim.x * 256) {
+    const int i = (int)(e % Dn), j = (int)(e / Dn);
+    P[(long)j * ld + i] = T[(long)j * ld + i];
+  }
+}
+template <class S>
+__global__ __launch_bounds__(64) void k_prune_cams(Dev<S> d, int b0) {
+  const int b = b0 + blockIdx.x, lane = threadIdx.x;
+  const int nk = d.nkeep[b], n = d.ncam[b];
+  if (nk >= n) return;
+  const int* keep = d.keep + (long)b * d.n_cap;
+  S* cam = d.cam + (long)b * d.n_cap * CAM_STRIDE;
+  for (int base = 0; base < nk; base += 64) {   // keep[] ascending => source slot >= destination slot
+    const int i = base + lane;
+    S v[CAM_STRIDE];
+    if (i < nk) for (int k = 0; k < CAM_STRIDE; ++k) v[k] = cam[(long)keep[i] * CAM_STRIDE + k];
+    __syncthreads();
+    if (i < nk) for (int k = 0; k < CAM_STRIDE; ++k) cam[(long)i * CAM_STRIDE + k] = v[k];
+    __syncthreads();
+  }
+  if (lane == 0) d.ncam[b] = nk;
+}
+
+template <class S>
+void launch_propagate(const Dev<S>& d, int b0, int nb, const S* readings, long rd_stride, int K, hipStream_t st) {
+  if (nb <= 0 || K <= 0) return;
+  hipLaunchKernelGGL(k_propagate<S>, dim3(nb), dim3(64), 0, st, d, b0, readings, rd_stride, K);
+}
+template <class S>
+void launch_augment(const Dev<S>& d, int b0, int nb, hipStream_t st) {
+  if (nb <= 0) return;
+  hipLaunchKernelGGL(k_augment<S>, dim3(nb), dim3(256), (size_t)6 * d.ld * sizeof(S), st, d, b0);
+}
+template <class S>
+void launch_prune(const Dev<S>& d, int b0, int nb, hipStream_t st) {
+  if (nb <= 0) return;
+  hipLaunchKernelGGL(k_prune_gather<S>, dim3(16, nb), dim3(256), 0, st, d, b0);
+  hipLaunchKernelGGL(k_prune_commit<S>, dim3(16, nb), dim3(256), 0, st, d, b0);
+  hipLaunchKernelGGL(k_prune_cams<S>, dim3(nb), dim3(64), 0, st, d, b0);
+}
+
+template void launch_propagate<float>(const Dev<float>&, int, int, const float*, long, int, hipStream_t);
+template void launch_propagate<double>(const Dev<double>&, int, int, const double*, long, int, hipStream_t);
+template void launch_augment<float>(const Dev<float>&, int, int, hipStream_t);
+template void launch_augment<double>(const Dev<double>&, int, int, hipStream_t);
+template void launch_prune<float>(const Dev<float>&, int, int, hipStream_t);
+template void launch_prune<double>(const Dev<double>&, int, int, hipStream_t);
+
+}  // namespace msckf

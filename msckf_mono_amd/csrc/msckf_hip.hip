@@ -1,0 +1,769 @@
+// msckf_hip.hip -- host side of libmsckf_hip.so: batch handle, track bookkeeping, C-ABI (include/msckf_hip.h).
+//
+// The host keeps exactly what the reference keeps on the host side of its hot loop -- the integer /
+// std::find bookkeeping of MSCKF::update / addFeatures / removeTrackedFeature / pruneEmptyStates
+// (msckf.h:215-332, 685-717, 1469-1485) -- and turns it into positional work-lists for the device.
+// Everything numerical (msckf.h:101-212, 336-449, 905-1423) runs in the HIP kernels of kernels_*.hip; there
+// is no CPU fallback: if no HIP device is usable msckf_hip_create fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/msckf_hip.h"
+#include "dev_common.h"
+
+namespace {
+using namespace msckf;
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) return fail(-EIO, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+struct CamMeta { int state_id; double time; int last_correlated_id; std::vector<uint64_t> tracked; };
+struct Track { uint64_t id; std::vector<double> obs; std::vector<int> cam_ids; };
+struct TrackToResid { uint64_t id; std::vector<double> obs; std::vector<int> slots; };
+struct HostTraj {
+  bool initialized = false;
+  int max_cam_states = 0, min_track_length = 0, max_track_length = 0;
+  std::vector<CamMeta> cams;
+  std::vector<Track> tracks;
+  std::vector<uint64_t> tracked_ids;
+  std::vector<TrackToResid> to_resid;
+  std::vector<int> pruned_ids;
+  std::vector<double> map;   // xyz triples of the last marginalize
+  int wl_F = 0;              // tracks in the device work-list of this trajectory
+};
+
+struct BatchBase {
+  virtual ~BatchBase() {}
+  int B = 0, n_cap = 0, f_cap = 0, m_cap = 0, dtype = 0, device = 0;
+  std::vector<HostTraj> traj;
+  virtual int init(int b, const double* cam, const double* noise, const double* params, const double* imu) = 0;
+  virtual int propagate(int b0, int nb, const double* rd, int K) = 0;
+  virtual int augment(int b0, int nb) = 0;
+  virtual int set_tracks(int b, int F, const int* M, const int* slots, const double* obs) = 0;
+  virtual int marginalize(int b0, int nb) = 0;
+  virtual int prune_keep(int b, const std::vector<int>& keep) = 0;
+  virtual int drop_oldest(int b0, int nb, int n) = 0;
+  virtual int get_ncam(int b, int* n) = 0;
+  virtual int get_imu(int b, double* o) = 0;
+  virtual int set_imu(int b, const double* in) = 0;
+  virtual int get_cams(int b, double* o, int cap, int* n) = 0;
+  virtual int set_cam(int b, int slot, const double* in) = 0;
+  virtual int get_cov(int b, double* P, int ldo) = 0;
+  virtual int set_cov(int b, const double* P, int D) = 0;
+  virtual int get_nres(int b, long long* n) = 0;
+  virtual int set_nres(int b, long long n) = 0;
+  virtual int stats(int b, int* out) = 0;
+  virtual int track_info(int b, double* out, int cap) = 0;
+  virtual int deltax(int b, double* out, int cap) = 0;
+  virtual int scen_alloc(int n_frames, int K) = 0;
+  virtual int scen_set(int f, int b, const double* rd, int F, const int* M, const int* slots, const double* obs, int n_drop) = 0;
+  virtual int scen_commit() = 0;
+  virtual int run_frames(int f0, int f1) = 0;
+  virtual int sync() = 0;
+  virtual int prof_enable(int on) = 0;
+  virtual int prof_read(double* ms, int* cnt) = 0;
+};
+
+constexpr int NSTAGE = 7;
+
+template <class S>
+struct Batch : BatchBase {
+  Dev<S> d{};
+  hipStream_t st = nullptr;
+  std::vector<void*> allocs;
+  // single-call staging on device
+  S* d_rd = nullptr; int rd_cap = 0;               // [B][rd_cap][7]
+  int* wl_n = nullptr; int* wl_M = nullptr; int* wl_slots = nullptr; S* wl_obs = nullptr;  // [B]...[B][f_cap][m_cap]
+  // scenario
+  int sc_frames = 0, sc_K = 0;
+  S* sc_rd = nullptr; int* sc_n = nullptr; int* sc_M = nullptr; int* sc_slots = nullptr; S* sc_obs = nullptr; int* sc_drop = nullptr;
+  std::vector<S> h_rd, h_obs; std::vector<int> h_n, h_M, h_slots, h_drop;
+  // profiling
+  bool prof = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool[NSTAGE];
+  size_t ev_used[NSTAGE] = {0};
+  double prof_ms[NSTAGE] = {0}; int prof_cnt[NSTAGE] = {0};
+
+  template <class T> int dalloc(T** p, size_t count) {
+    void* q = nullptr;
+    HIPCHK(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+    HIPCHK(hipMemsetAsync(q, 0, std::max<size_t>(count, 1) * sizeof(T), st));
+    allocs.push_back(q);
+    *p = (T*)q;
+    return 0;
+  }
+  int create() {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    d.B = B; d.n_cap = n_cap; d.f_cap = f_cap; d.m_cap = m_cap;
+    d.n6cap = 6 * n_cap;
+    d.ld = ((15 + 6 * n_cap + 15) / 16) * 16;
+    d.ldR = ((6 * n_cap + 1 + 63) / 64) * 64;
+    if (d.ldR / 64 > 6) return fail(-EINVAL, "n_cap too large for the QR kernel (6*n_cap+1 must be <= 384)");
+    int nch = 1;
+    while (nch < 8 && (long)B * nch * 2 <= 1024) nch *= 2;   // enough workgroups to cover 256 CUs
+    d.nchunk = nch;
+    const size_t Bz = B, pl = (size_t)d.ld * d.ld, nl = (size_t)d.n6cap * d.n6cap, dn = (size_t)d.ld * d.n6cap;
+    const size_t TF = Bz * f_cap;
+    int rc = 0;
+    rc |= dalloc(&d.imu, Bz * IMU_STRIDE); rc |= dalloc(&d.cam, Bz * n_cap * CAM_STRIDE); rc |= dalloc(&d.prm, Bz * PRM_STRIDE);
+    rc |= dalloc(&d.P, Bz * pl); rc |= dalloc(&d.Ptmp, Bz * pl); rc |= dalloc(&d.ncam, Bz); rc |= dalloc(&d.n_resid, Bz);
+    rc |= dalloc(&d.trk_status, TF); rc |= dalloc(&d.trk_pf, TF * 4); rc |= dalloc(&d.trk_gamma, TF);
+    rc |= dalloc(&d.trk_Hx, TF * m_cap * 12); rc |= dalloc(&d.trk_V, TF * 2 * m_cap * 4); rc |= dalloc(&d.trk_Z, TF * m_cap * 18);
+    rc |= dalloc(&d.trk_ro, TF * 2 * m_cap); rc |= dalloc(&d.trk_inv, TF * n_cap); rc |= dalloc(&d.trk_first, TF);
+    rc |= dalloc(&d.row_start, Bz * (f_cap + 1)); rc |= dalloc(&d.stats, Bz * STAT_STRIDE);
+    rc |= dalloc(&d.Rbuf, Bz * d.nchunk * (size_t)d.n6cap * d.ldR);
+    rc |= dalloc(&d.PHt, Bz * dn); rc |= dalloc(&d.Smat, Bz * nl); rc |= dalloc(&d.Linv, Bz * nl); rc |= dalloc(&d.W, Bz * dn);
+    rc |= dalloc(&d.K, Bz * dn); rc |= dalloc(&d.A, Bz * pl); rc |= dalloc(&d.AP, Bz * pl); rc |= dalloc(&d.X, Bz * pl); rc |= dalloc(&d.dx, Bz * d.ld);
+    rc |= dalloc(&d.keep, Bz * n_cap); rc |= dalloc(&d.nkeep, Bz);
+    rd_cap = 64;
+    rc |= dalloc(&d_rd, Bz * rd_cap * RD_STRIDE);
+    rc |= dalloc(&wl_n, Bz); rc |= dalloc(&wl_M, TF); rc |= dalloc(&wl_slots, TF * m_cap); rc |= dalloc(&wl_obs, TF * m_cap * 2);
+    if (rc) return rc;
+    use_single_worklists();
+    if (feature_lds_bytes(m_cap, sizeof(S)) > 160 * 1024) return fail(-EINVAL, "m_cap too large for the feature kernel's LDS budget");
+    traj.assign(B, HostTraj());
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+  }
+  ~Batch() override {
+    hipSetDevice(device);
+    if (st) hipStreamSynchronize(st);
+    for (void* p : allocs) hipFree(p);
+    for (int s = 0; s < NSTAGE; ++s) for (auto& e : ev_pool[s]) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    if (st) hipStreamDestroy(st);
+  }
+  void use_single_worklists() {
+    d.trk_n = wl_n; d.trk_M = wl_M; d.trk_slots = wl_slots; d.trk_obs = wl_obs;
+    d.wl_stride_n = 1; d.wl_stride_f = f_cap; d.wl_stride_o = (long)f_cap * m_cap;
+  }
+  // Dev view whose work-list pointers start at trajectory b0 (kernels index work-lists by b - b0)
+  Dev<S> view(int b0) const {
+    Dev<S> v = d;
+    v.trk_n += (long)b0 * d.wl_stride_n; v.trk_M += (long)b0 * d.wl_stride_f;
+    v.trk_slots += (long)b0 * d.wl_stride_o; v.trk_obs += 2 * (long)b0 * d.wl_stride_o;
+    return v;
+  }
+  // ---- profiling helpers
+  void stage_begin(int s) {
+    if (!prof) return;
+    if (ev_used[s] == ev_pool[s].size()) {
+      hipEvent_t a, b2; hipEventCreate(&a); hipEventCreate(&b2);
+      ev_pool[s].push_back({a, b2});
+    }
+    hipEventRecord(ev_pool[s][ev_used[s]].first, st);
+  }
+  void stage_end(int s) {
+    if (!prof) return;
+    hipEventRecord(ev_pool[s][ev_used[s]].second, st);
+    ev_used[s]++;
+  }
+
+  int chk(int b) const { return (b < 0 || b >= B) ? -EINVAL : 0; }
+  int chk_range(int b0, int nb) const { return (b0 < 0 || nb < 0 || b0 + nb > B) ? -EINVAL : 0; }
+
+  int init(int b, const double* cam, const double* noise, const double* params, const double* imu) override {
+    if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
+    if (noise[0] != noise[1]) return fail(-ENOTSUP, "anisotropic pixel noise (u_var_prime != v_var_prime) is not supported by this build");
+    HIPCHK(hipSetDevice(device));
+    S prm[PRM_STRIDE] = {0}, st_imu[IMU_STRIDE] = {0};
+    for (int i = 0; i < 12; ++i) prm[i] = (S)cam[i];
+    prm[PRM_UVAR] = (S)noise[0]; prm[PRM_VVAR] = (S)noise[1];
+    for (int i = 0; i < 12; ++i) prm[PRM_Q + i] = (S)noise[2 + i];
+    for (int i = 0; i < 8; ++i) prm[PRM_GN + i] = (S)params[i];
+    for (int i = 0; i < 29; ++i) st_imu[i] = (S)imu[i];
+    for (int i = 0; i < 4; ++i) st_imu[IQN + i] = st_imu[IQ + i];        // msckf.h:83-85
+    for (int i = 0; i < 3; ++i) { st_imu[IVN + i] = st_imu[IV + i]; st_imu[IPN + i] = st_imu[IP + i]; }
+    std::vector<S> P((size_t)d.ld * d.ld, S(0));
+    for (int i = 0; i < 15; ++i) P[(size_t)i * d.ld + i] = (S)noise[14 + i];
+    HIPCHK(hipMemcpyAsync(d.prm + (size_t)b * PRM_STRIDE, prm, sizeof(prm), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d.imu + (size_t)b * IMU_STRIDE, st_imu, sizeof(st_imu), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d.P + (size_t)b * d.ld * d.ld, P.data(), P.size() * sizeof(S), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(d.ncam + b, 0, sizeof(int), st));
+    HIPCHK(hipMemsetAsync(d.n_resid + b, 0, sizeof(long long), st));
+    HIPCHK(hipMemsetAsync(d.stats + (size_t)b * STAT_STRIDE, 0, sizeof(int) * STAT_STRIDE, st));
+    HIPCHK(hipMemsetAsync(wl_n + b, 0, sizeof(int), st));
+    HIPCHK(hipStreamSynchronize(st));
+    HostTraj& t = traj[b];
+    t = HostTraj();
+    t.initialized = true;
+    t.min_track_length = (int)params[5]; t.max_track_length = (int)params[6]; t.max_cam_states = (int)params[7];
+    return 0;
+  }
+  int propagate(int b0, int nb, const double* rd, int K) override {
+    if (chk_range(b0, nb)) return fail(-EINVAL, "trajectory range out of bounds");
+    HIPCHK(hipSetDevice(device));
+    for (int k0 = 0; k0 < K; k0 += rd_cap) {
+      const int kk = std::min(rd_cap, K - k0);
+      std::vector<S> tmp((size_t)nb * kk * RD_STRIDE);
+      for (int i = 0; i < nb; ++i)
+        for (int k = 0; k < kk; ++k)
+          for (int c = 0; c < RD_STRIDE; ++c) tmp[((size_t)i * kk + k) * RD_STRIDE + c] = (S)rd[((size_t)i * K + k0 + k) * RD_STRIDE + c];
+      HIPCHK(hipMemcpyAsync(d_rd, tmp.data(), tmp.size() * sizeof(S), hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));
+      launch_propagate<S>(d, b0, nb, d_rd, (long)kk * RD_STRIDE, kk, st);
+      HIPCHK(hipGetLastError());
+    }
+    return 0;
+  }
+  int augment(int b0, int nb) override {
+    if (chk_range(b0, nb)) return fail(-EINVAL, "trajectory range out of bounds");
+    HIPCHK(hipSetDevice(device));
+    launch_augment<S>(d, b0, nb, st);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  int set_tracks(int b, int F, const int* M, const int* slots, const double* obs) override {
+    if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
+    if (F < 0 || F > f_cap) return fail(-E2BIG, "more tracks than f_cap");
+    HIPCHK(hipSetDevice(device));
+    std::vector<int> hM(f_cap, 0), hS((size_t)f_cap * m_cap, 0);
+    std::vector<S> hO((size_t)f_cap * m_cap * 2, S(0));
+    size_t o = 0;
+    for (int t = 0; t < F; ++t) {
+      if (M[t] > m_cap || M[t] < 0) return fail(-E2BIG, "track longer than m_cap");
+      hM[t] = M[t];
+      for (int k = 0; k < M[t]; ++k) {
+        if (slots[o + k] < 0 || slots[o + k] >= n_cap) return fail(-EINVAL, "camera slot out of range");
+        hS[(size_t)t * m_cap + k] = slots[o + k];
+        hO[((size_t)t * m_cap + k) * 2] = (S)obs[2 * (o + k)];
+        hO[((size_t)t * m_cap + k) * 2 + 1] = (S)obs[2 * (o + k) + 1];
+      }
+      o += M[t];
+    }
+    HIPCHK(hipMemcpyAsync(wl_n + b, &F, sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(wl_M + (size_t)b * f_cap, hM.data(), hM.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(wl_slots + (size_t)b * f_cap * m_cap, hS.data(), hS.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(wl_obs + (size_t)b * f_cap * m_cap * 2, hO.data(), hO.size() * sizeof(S), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    traj[b].wl_F = F;
+    return 0;
+  }
+  void launch_update(const Dev<S>& v, int b0, int nb) {
+    stage_begin(2); launch_feature<S>(v, b0, nb, st); launch_select<S>(v, b0, nb, st); stage_end(2);
+    launch_compress_profiled(v, b0, nb);
+    stage_begin(5); launch_kalman<S>(v, b0, nb, st); stage_end(5);
+  }
+  void launch_compress_profiled(const Dev<S>& v, int b0, int nb) {
+    stage_begin(3); launch_compress<S>(v, b0, nb, st, 1); stage_end(3);
+    stage_begin(4); launch_compress<S>(v, b0, nb, st, 2); stage_end(4);
+  }
+  int marginalize(int b0, int nb) override {
+    if (chk_range(b0, nb)) return fail(-EINVAL, "trajectory range out of bounds");
+    HIPCHK(hipSetDevice(device));
+    use_single_worklists();
+    launch_update(view(b0), b0, nb);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  int prune_keep(int b, const std::vector<int>& keep) override {
+    HIPCHK(hipSetDevice(device));
+    const int nk = (int)keep.size();
+    if (nk) HIPCHK(hipMemcpyAsync(d.keep + (size_t)b * n_cap, keep.data(), nk * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d.nkeep + b, &nk, sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    launch_prune<S>(d, b, 1, st);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  int drop_oldest(int b0, int nb, int n) override;
+  int get_ncam(int b, int* n) override {
+    if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemcpyAsync(n, d.ncam + b, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+  }
+  int get_imu(int b, double* o) override {
+    if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
+    HIPCHK(hipSetDevice(device));
+    S tmp[IMU_STRIDE];
+    HIPCHK(hipMemcpyAsync(tmp, d.imu + (size_t)b * IMU_STRIDE, sizeof(tmp), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < 29; ++i) o[i] = (double)tmp[i];
+    return 0;
+  }
+  int set_imu(int b, const double* in) override {
+    if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
+    HIPCHK(hipSetDevice(device));
+    S tmp[IMU_STRIDE] = {0};
+    for (int i = 0; i < 29; ++i) tmp[i] = (S)in[i];
+    HIPCHK(hipMemcpyAsync(d.imu + (size_t)b * IMU_STRIDE, tmp, sizeof(tmp), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+  }
+  int get_cams(int b, double* o, int cap, int* nout) override {
+    int n = 0;
+    int rc = get_ncam(b, &n);
+    if (rc) return rc;
+    *nout = n;
+    if (n > cap) return fail(-E2BIG, "output buffer too small");
+    std::vector<S> tmp((size_t)std::max(n, 1) * CAM_STRIDE);
+    if (n) HIPCHK(hipMemcpyAsync(tmp.data(), d.cam + (size_t)b * n_cap * CAM_STRIDE, (size_t)n * CAM_STRIDE * sizeof(S), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < n; ++i) for (int k = 0; k < 7; ++k) o[7 * i + k] = (double)tmp[(size_t)i * CAM_STRIDE + k];
+    return 0;
+  }
+  int set_cam(int b, int slot, const double* in) override {
+    if (chk(b) || slot < 0 || slot >= n_cap) return fail(-EINVAL, "index out of range");
+    HIPCHK(hipSetDevice(device));
+    S tmp[CAM_STRIDE] = {0};
+    for (int k = 0; k < 7; ++k) tmp[k] = (S)in[k];
+    HIPCHK(hipMemcpyAsync(d.cam + ((size_t)b * n_cap + slot) * CAM_STRIDE, tmp, sizeof(tmp), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+  }
+  int get_cov(int b, double* P, int ldo) override {
+    int n = 0;
+    int rc = get_ncam(b, &n);
+    if (rc) return rc;
+    const int D = 15 + 6 * n;
+    if (ldo < D) return fail(-EINVAL, "ld smaller than D");
+    std::vector<S> tmp((size_t)d.ld * d.ld);
+    HIPCHK(hipMemcpyAsync(tmp.data(), d.P + (size_t)b * d.ld * d.ld, tmp.size() * sizeof(S), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int j = 0; j < D; ++j) for (int i = 0; i < D; ++i) P[(size_t)j * ldo + i] = (double)tmp[(size_t)j * d.ld + i];
+    return 0;
+  }
+  int set_cov(int b, const double* P, int D) override {
+    if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
+    if (D < 15 || (D - 15) % 6 || (D - 15) / 6 > n_cap) return fail(-EINVAL, "bad covariance dimension");
+    HIPCHK(hipSetDevice(device));
+    std::vector<S> tmp((size_t)d.ld * d.ld, S(0));
+    for (int j = 0; j < D; ++j) for (int i = 0; i < D; ++i) tmp[(size_t)j * d.ld + i] = (S)P[(size_t)j * D + i];
+    const int n = (D - 15) / 6;
+    HIPCHK(hipMemcpyAsync(d.P + (size_t)b * d.ld * d.ld, tmp.data(), tmp.size() * sizeof(S), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d.ncam + b, &n, sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+  }
+  int get_nres(int b, long long* n) override {
+    if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemcpyAsync(n, d.n_resid + b, sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+  }
+  int set_nres(int b, long long n) override {
+    if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemcpyAsync(d.n_resid + b, &n, sizeof(long long), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+  }
+  int stats(int b, int* out) override {
+    if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
+    HIPCHK(hipSetDevice(device));
+    int tmp[STAT_STRIDE];
+    HIPCHK(hipMemcpyAsync(tmp, d.stats + (size_t)b * STAT_STRIDE, sizeof(tmp), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < 7; ++i) out[i] = tmp[i];
+    return tmp[STAT_ERR] ? fail(-EOVERFLOW, "camera-state capacity n_cap exceeded in augmentState") : 0;
+  }
+  int track_info(int b, double* out, int cap) override {
+    if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
+    HIPCHK(hipSetDevice(device));
+    int tmp[STAT_STRIDE];
+    HIPCHK(hipMemcpyAsync(tmp, d.stats + (size_t)b * STAT_STRIDE, sizeof(tmp), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const int F = tmp[STAT_NTRACKS];
+    if (F > cap) return fail(-E2BIG, "output buffer too small");
+    std::vector<int> stt(std::max(F, 1)); std::vector<S> gm(std::max(F, 1)), pf((size_t)std::max(F, 1) * 4);
+    if (F) {
+      HIPCHK(hipMemcpyAsync(stt.data(), d.trk_status + (size_t)b * f_cap, F * sizeof(int), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(gm.data(), d.trk_gamma + (size_t)b * f_cap, F * sizeof(S), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipMemcpyAsync(pf.data(), d.trk_pf + (size_t)b * f_cap * 4, (size_t)F * 4 * sizeof(S), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+    }
+    for (int t = 0; t < F; ++t) {
+      double* o = out + 8 * t;
+      const bool skipped = stt[t] & ST_MOTION_SKIPPED;
+      o[0] = (skipped || (stt[t] & ST_MOTION_OK)) ? 1 : 0;
+      o[1] = (stt[t] & ST_TRI_VALID) ? 1 : 0; o[2] = (stt[t] & ST_GATE_PASS) ? 1 : 0; o[3] = (stt[t] & ST_INCLUDED) ? 1 : 0;
+      o[4] = (double)gm[t]; o[5] = (double)pf[4 * t]; o[6] = (double)pf[4 * t + 1]; o[7] = (double)pf[4 * t + 2];
+    }
+    return F;
+  }
+  int deltax(int b, double* out, int cap) override {
+    int n = 0;
+    int rc = get_ncam(b, &n);
+    if (rc) return rc;
+    const int D = 15 + 6 * n;
+    if (D > cap) return fail(-E2BIG, "output buffer too small");
+    std::vector<S> tmp(D);
+    HIPCHK(hipMemcpyAsync(tmp.data(), d.dx + (size_t)b * d.ld, D * sizeof(S), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < D; ++i) out[i] = (double)tmp[i];
+    return D;
+  }
+  // ---- scenario
+  int scen_alloc(int n_frames, int K) override {
+    if (n_frames <= 0 || K <= 0) return fail(-EINVAL, "bad scenario size");
+    HIPCHK(hipSetDevice(device));
+    sc_frames = n_frames; sc_K = K;
+    const size_t Bz = B, FB = (size_t)n_frames * Bz;
+    h_rd.assign(FB * K * RD_STRIDE, S(0)); h_n.assign(FB, 0); h_M.assign(FB * f_cap, 0);
+    h_slots.assign(FB * f_cap * m_cap, 0); h_obs.assign(FB * f_cap * m_cap * 2, S(0)); h_drop.assign(FB, 0);
+    int rc = 0;
+    rc |= dalloc(&sc_rd, h_rd.size()); rc |= dalloc(&sc_n, h_n.size()); rc |= dalloc(&sc_M, h_M.size());
+    rc |= dalloc(&sc_slots, h_slots.size()); rc |= dalloc(&sc_obs, h_obs.size()); rc |= dalloc(&sc_drop, h_drop.size());
+    return rc;
+  }
+  int scen_set(int f, int b, const double* rd, int F, const int* M, const int* slots, const double* obs, int n_drop) override {
+    if (f < 0 || f >= sc_frames || chk(b)) return fail(-EINVAL, "scenario cell out of range");
+    if (F < 0 || F > f_cap) return fail(-E2BIG, "more tracks than f_cap");
+    const size_t cell = (size_t)f * B + b;
+    for (int k = 0; k < sc_K; ++k) for (int c = 0; c < RD_STRIDE; ++c) h_rd[(cell * sc_K + k) * RD_STRIDE + c] = (S)rd[k * RD_STRIDE + c];
+    h_n[cell] = F; h_drop[cell] = n_drop;
+    size_t o = 0;
+    for (int t = 0; t < F; ++t) {
+      if (M[t] > m_cap) return fail(-E2BIG, "track longer than m_cap");
+      h_M[cell * f_cap + t] = M[t];
+      for (int k = 0; k < M[t]; ++k) {
+        h_slots[(cell * f_cap + t) * m_cap + k] = slots[o + k];
+        h_obs[((cell * f_cap + t) * m_cap + k) * 2] = (S)obs[2 * (o + k)];
+        h_obs[((cell * f_cap + t) * m_cap + k) * 2 + 1] = (S)obs[2 * (o + k) + 1];
+      }
+      o += M[t];
+    }
+    return 0;
+  }
+  int scen_commit() override {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemcpyAsync(sc_rd, h_rd.data(), h_rd.size() * sizeof(S), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(sc_n, h_n.data(), h_n.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(sc_M, h_M.data(), h_M.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(sc_slots, h_slots.data(), h_slots.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(sc_obs, h_obs.data(), h_obs.size() * sizeof(S), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(sc_drop, h_drop.data(), h_drop.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<S>().swap(h_rd); std::vector<S>().swap(h_obs); std::vector<int>().swap(h_slots); std::vector<int>().swap(h_M);
+    return 0;
+  }
+  int run_frames(int f0, int f1) override;
+  int sync() override {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+  }
+  int prof_enable(int on) override {
+    prof = on != 0;
+    for (int s = 0; s < NSTAGE; ++s) { ev_used[s] = 0; prof_ms[s] = 0; prof_cnt[s] = 0; }
+    return 0;
+  }
+  int prof_read(double* ms, int* cnt) override {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int s = 0; s < NSTAGE; ++s) {
+      for (size_t i = 0; i < ev_used[s]; ++i) {
+        float t = 0;
+        HIPCHK(hipEventElapsedTime(&t, ev_pool[s][i].first, ev_pool[s][i].second));
+        prof_ms[s] += t; prof_cnt[s]++;
+      }
+      ev_used[s] = 0;
+      ms[s] = prof_ms[s]; cnt[s] = prof_cnt[s];
+    }
+    return 0;
+  }
+};
+
+// keep[] = [n_drop(b) .. ncam-1] for a trajectory range; n_drop from a device array (scenario) or a constant
+__global__ void k_make_keep(int* keep, int* nkeep, const int* ncam, const int* drop, int drop_const, int n_cap, int b0, int nb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nb) return;
+  const int b = b0 + i;
+  const int n = ncam[b];
+  int nd = drop ? drop[i] : drop_const;
+  nd = nd < 0 ? 0 : (nd > n ? n : nd);
+  for (int k = nd; k < n; ++k) keep[(long)b * n_cap + (k - nd)] = k;
+  nkeep[b] = n - nd;
+}
+
+template <class S>
+int Batch<S>::drop_oldest(int b0, int nb, int n) {
+  if (chk_range(b0, nb)) return fail(-EINVAL, "trajectory range out of bounds");
+  HIPCHK(hipSetDevice(device));
+  hipLaunchKernelGGL(k_make_keep, dim3((nb + 63) / 64), dim3(64), 0, st, d.keep, d.nkeep, d.ncam, (const int*)nullptr, n, n_cap, b0, nb);
+  launch_prune<S>(d, b0, nb, st);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+template <class S>
+int Batch<S>::run_frames(int f0, int f1) {
+  if (f0 < 0 || f1 > sc_frames || f0 > f1) return fail(-EINVAL, "frame range out of bounds");
+  HIPCHK(hipSetDevice(device));
+  for (int f = f0; f < f1; ++f) {
+    const size_t cell0 = (size_t)f * B;
+    Dev<S> v = d;
+    v.trk_n = sc_n + cell0; v.trk_M = sc_M + cell0 * f_cap; v.trk_slots = sc_slots + cell0 * f_cap * m_cap; v.trk_obs = sc_obs + cell0 * f_cap * m_cap * 2;
+    v.wl_stride_n = 1; v.wl_stride_f = f_cap; v.wl_stride_o = (long)f_cap * m_cap;
+    stage_begin(0); launch_propagate<S>(v, 0, B, sc_rd + cell0 * sc_K * RD_STRIDE, (long)sc_K * RD_STRIDE, sc_K, st); stage_end(0);
+    stage_begin(1); launch_augment<S>(v, 0, B, st); stage_end(1);
+    launch_update(v, 0, B);
+    stage_begin(6);
+    hipLaunchKernelGGL(k_make_keep, dim3((B + 63) / 64), dim3(64), 0, st, d.keep, d.nkeep, d.ncam, (const int*)(sc_drop + cell0), 0, n_cap, 0, B);
+    launch_prune<S>(v, 0, B, st);
+    stage_end(6);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// host bookkeeping shared by both dtypes (restates msckf.h:215-332, 685-717, 765-807, 1469-1485)
+// -------------------------------------------------------------------------------------------------
+void remove_tracked_feature(HostTraj& t, uint64_t fid, std::vector<int>& slots) {
+  slots.clear();
+  for (size_t c = 0; c < t.cams.size(); ++c) {
+    auto& ids = t.cams[c].tracked;
+    auto it = std::find(ids.begin(), ids.end(), fid);
+    if (it != ids.end()) { ids.erase(it); slots.push_back((int)c); }
+  }
+}
+
+int host_update(BatchBase* B, int b, const double* meas, const uint64_t* ids, int n) {
+  HostTraj& t = B->traj[b];
+  if (!t.initialized) return fail(-EINVAL, "trajectory not initialized");
+  if (t.cams.empty()) return fail(-EINVAL, "update() before augmentState() (msckf.h:238 dereferences cam_states_.end()-1)");
+  t.to_resid.clear();
+  std::vector<uint64_t> to_remove;
+  size_t id_iter = 0;
+  for (uint64_t fid : t.tracked_ids) {
+    const uint64_t* it = std::find(ids, ids + n, fid);
+    const bool valid = it != ids + n;
+    Track& tr = t.tracks[id_iter];
+    if (valid) {
+      const size_t k = (size_t)(it - ids);
+      tr.obs.push_back(meas[2 * k]); tr.obs.push_back(meas[2 * k + 1]);
+      t.cams.back().tracked.push_back(fid);
+      tr.cam_ids.push_back(t.cams.back().state_id);
+    }
+    if (!valid || tr.obs.size() / 2 >= (size_t)t.max_track_length) {
+      TrackToResid r;
+      remove_tracked_feature(t, fid, r.slots);
+      if (r.slots.size() >= (size_t)t.min_track_length) {
+        r.id = tr.id; r.obs = tr.obs;
+        t.to_resid.push_back(r);
+      }
+      to_remove.push_back(fid);
+    }
+    id_iter++;
+  }
+  for (uint64_t fid : to_remove) {
+    for (size_t i = 0; i < t.tracks.size(); ++i)
+      if (t.tracks[i].id == fid) {
+        const int last_id = t.tracks[i].cam_ids.back();
+        for (int idx : t.tracks[i].cam_ids)
+          for (auto& cs : t.cams)
+            if (cs.tracked.empty() && cs.state_id == idx) cs.last_correlated_id = last_id;
+        t.tracks.erase(t.tracks.begin() + i);
+        break;
+      }
+    auto c = std::find(t.tracked_ids.begin(), t.tracked_ids.end(), fid);
+    if (c != t.tracked_ids.end()) t.tracked_ids.erase(c);
+  }
+  return 0;
+}
+
+int host_add_features(BatchBase* B, int b, const double* meas, const uint64_t* ids, int n) {
+  HostTraj& t = B->traj[b];
+  if (!t.initialized) return fail(-EINVAL, "trajectory not initialized");
+  if (t.cams.empty()) return fail(-EINVAL, "addFeatures() before augmentState() (msckf.h:320)");
+  for (int i = 0; i < n; ++i) {
+    if (std::find(t.tracked_ids.begin(), t.tracked_ids.end(), ids[i]) != t.tracked_ids.end())
+      return fail(-EEXIST, "added new feature that was already being tracked");   // msckf.h:328-329 prints and returns
+    Track tr; tr.id = ids[i];
+    tr.obs.push_back(meas[2 * i]); tr.obs.push_back(meas[2 * i + 1]);
+    t.cams.back().tracked.push_back(ids[i]);
+    tr.cam_ids.push_back(t.cams.back().state_id);
+    t.tracks.push_back(tr);
+    t.tracked_ids.push_back(ids[i]);
+  }
+  return 0;
+}
+
+int host_marginalize(BatchBase* B, int b) {
+  HostTraj& t = B->traj[b];
+  t.map.clear();
+  if (t.to_resid.empty()) { int z = 0; return B->set_tracks(b, 0, &z, &z, nullptr) ; }
+  const int F = (int)t.to_resid.size();
+  std::vector<int> M(F), slots; std::vector<double> obs;
+  for (int i = 0; i < F; ++i) {
+    M[i] = (int)t.to_resid[i].slots.size();
+    slots.insert(slots.end(), t.to_resid[i].slots.begin(), t.to_resid[i].slots.end());
+    obs.insert(obs.end(), t.to_resid[i].obs.begin(), t.to_resid[i].obs.end());
+  }
+  int rc = B->set_tracks(b, F, M.data(), slots.data(), obs.data());
+  if (rc) return rc;
+  rc = B->marginalize(b, 1);
+  if (rc) return rc;
+  std::vector<double> info((size_t)F * 8);
+  rc = B->track_info(b, info.data(), F);
+  if (rc < 0) return rc;
+  for (int i = 0; i < F; ++i)
+    if (info[8 * i] != 0 && info[8 * i + 1] != 0) { t.map.push_back(info[8 * i + 5]); t.map.push_back(info[8 * i + 6]); t.map.push_back(info[8 * i + 7]); }
+  t.to_resid.clear();   // consumed (the reference clears it at the next update(), msckf.h:218)
+  return 0;
+}
+
+int host_prune_empty(BatchBase* B, int b) {
+  HostTraj& t = B->traj[b];
+  const int max_states = t.max_cam_states, num = (int)t.cams.size();
+  if (num < max_states) return 0;
+  if (!t.cams.front().tracked.empty()) return 0;
+  int last_to_remove = num - max_states - 1;
+  for (int i = 1; i < num - max_states; i++)
+    if (!t.cams[i].tracked.empty()) { last_to_remove = i - 1; break; }
+  if (last_to_remove < 0) return 0;
+  std::vector<int> keep;
+  for (int i = 0; i <= last_to_remove; ++i) t.pruned_ids.push_back(t.cams[i].state_id);
+  for (int i = last_to_remove + 1; i < num; ++i) keep.push_back(i);
+  int rc = B->prune_keep(b, keep);
+  if (rc) return rc;
+  t.cams.erase(t.cams.begin(), t.cams.begin() + last_to_remove + 1);
+  return 0;
+}
+
+int host_finish(BatchBase* B, int b) {
+  HostTraj& t = B->traj[b];
+  for (size_t i = 0; i < t.tracked_ids.size(); i++) {
+    TrackToResid r;
+    remove_tracked_feature(t, t.tracked_ids[i], r.slots);
+    if (r.slots.size() >= (size_t)t.min_track_length) {
+      for (auto& tr : t.tracks) if (tr.id == t.tracked_ids[i]) { r.id = tr.id; r.obs = tr.obs; break; }
+      t.to_resid.push_back(r);
+    }
+  }
+  return host_marginalize(B, b);
+}
+
+BatchBase* H(msckf_hip_handle h) { return reinterpret_cast<BatchBase*>(h); }
+}  // namespace
+
+extern "C" {
+
+const char* msckf_hip_last_error(void) { return g_err.c_str(); }
+
+int msckf_hip_create(int B, int n_cap, int f_cap, int m_cap, int dtype, int device, msckf_hip_handle* out) {
+  if (!out) return fail(-EINVAL, "null out pointer");
+  *out = nullptr;
+  if (B <= 0 || n_cap <= 0 || f_cap <= 0 || m_cap < 2 || m_cap > 64) return fail(-EINVAL, "bad capacities (need B,n_cap,f_cap > 0 and 2 <= m_cap <= 64)");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(-ENODEV, "no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(-ENODEV, "HIP device index out of range");
+  BatchBase* b = nullptr;
+  if (dtype == MSCKF_HIP_F32) b = new Batch<float>();
+  else if (dtype == MSCKF_HIP_F64) b = new Batch<double>();
+  else return fail(-EINVAL, "dtype must be MSCKF_HIP_F32 or MSCKF_HIP_F64");
+  b->B = B; b->n_cap = n_cap; b->f_cap = f_cap; b->m_cap = m_cap; b->dtype = dtype; b->device = device;
+  int rc = dtype == MSCKF_HIP_F32 ? static_cast<Batch<float>*>(b)->create() : static_cast<Batch<double>*>(b)->create();
+  if (rc) { delete b; return rc; }
+  *out = reinterpret_cast<msckf_hip_handle>(b);
+  return 0;
+}
+int msckf_hip_destroy(msckf_hip_handle h) { delete H(h); return 0; }
+
+int msckf_hip_initialize(msckf_hip_handle h, int b, const double* cam12, const double* noise29, const double* params8, const double* imu29) {
+  return H(h)->init(b, cam12, noise29, params8, imu29);
+}
+int msckf_hip_propagate(msckf_hip_handle h, int b, const double* readings7, int K) { return H(h)->propagate(b, 1, readings7, K); }
+int msckf_hip_augment_state(msckf_hip_handle h, int b, int state_id, double time) {
+  BatchBase* B = H(h);
+  if (b < 0 || b >= B->B) return fail(-EINVAL, "trajectory index out of range");
+  if ((int)B->traj[b].cams.size() >= B->n_cap) return fail(-EOVERFLOW, "camera-state capacity n_cap exceeded");
+  int rc = B->augment(b, 1);
+  if (rc) return rc;
+  B->traj[b].cams.push_back(CamMeta{state_id, time, -1, {}});
+  B->traj[b].map.clear();   // msckf.h:149
+  return 0;
+}
+int msckf_hip_update(msckf_hip_handle h, int b, const double* meas2, const uint64_t* ids, int n) {
+  if (b < 0 || b >= H(h)->B) return fail(-EINVAL, "trajectory index out of range");
+  return host_update(H(h), b, meas2, ids, n);
+}
+int msckf_hip_add_features(msckf_hip_handle h, int b, const double* meas2, const uint64_t* ids, int n) {
+  if (b < 0 || b >= H(h)->B) return fail(-EINVAL, "trajectory index out of range");
+  return host_add_features(H(h), b, meas2, ids, n);
+}
+int msckf_hip_marginalize(msckf_hip_handle h, int b) {
+  if (b < 0 || b >= H(h)->B) return fail(-EINVAL, "trajectory index out of range");
+  return host_marginalize(H(h), b);
+}
+int msckf_hip_prune_empty_states(msckf_hip_handle h, int b) {
+  if (b < 0 || b >= H(h)->B) return fail(-EINVAL, "trajectory index out of range");
+  return host_prune_empty(H(h), b);
+}
+int msckf_hip_prune_redundant_states(msckf_hip_handle, int) { return fail(-ENOSYS, "pruneRedundantStates is not built yet (SURVEY.md 8f item 2)"); }
+int msckf_hip_finish(msckf_hip_handle h, int b) {
+  if (b < 0 || b >= H(h)->B) return fail(-EINVAL, "trajectory index out of range");
+  return host_finish(H(h), b);
+}
+int msckf_hip_get_num_cam_states(msckf_hip_handle h, int b) { int n = 0; int rc = H(h)->get_ncam(b, &n); return rc ? rc : n; }
+int msckf_hip_get_imu_state(msckf_hip_handle h, int b, double* imu29) { return H(h)->get_imu(b, imu29); }
+int msckf_hip_get_cam_states(msckf_hip_handle h, int b, double* cam7, int* state_ids, int cap) {
+  int n = 0;
+  int rc = H(h)->get_cams(b, cam7, cap, &n);
+  if (rc) return rc;
+  if (state_ids) {
+    const auto& cams = H(h)->traj[b].cams;
+    for (int i = 0; i < n; ++i) state_ids[i] = i < (int)cams.size() ? cams[i].state_id : -1;
+  }
+  return n;
+}
+int msckf_hip_get_map(msckf_hip_handle h, int b, double* xyz, int cap) {
+  if (b < 0 || b >= H(h)->B) return fail(-EINVAL, "trajectory index out of range");
+  const auto& m = H(h)->traj[b].map;
+  const int n = (int)m.size() / 3;
+  if (n > cap) return fail(-E2BIG, "output buffer too small");
+  std::copy(m.begin(), m.end(), xyz);
+  return n;
+}
+int msckf_hip_get_pruned_state_ids(msckf_hip_handle h, int b, int* ids, int cap) {
+  if (b < 0 || b >= H(h)->B) return fail(-EINVAL, "trajectory index out of range");
+  std::vector<int> p = H(h)->traj[b].pruned_ids;
+  std::stable_sort(p.begin(), p.end());   // getPrunedStates sorts by state_id, msckf.h:842-846
+  if ((int)p.size() > cap) return fail(-E2BIG, "output buffer too small");
+  std::copy(p.begin(), p.end(), ids);
+  return (int)p.size();
+}
+int msckf_hip_get_covariance(msckf_hip_handle h, int b, double* P, int ld) { return H(h)->get_cov(b, P, ld); }
+int msckf_hip_set_covariance(msckf_hip_handle h, int b, const double* P, int D) { return H(h)->set_cov(b, P, D); }
+int msckf_hip_set_imu_state(msckf_hip_handle h, int b, const double* imu29) { return H(h)->set_imu(b, imu29); }
+int msckf_hip_set_cam_pose(msckf_hip_handle h, int b, int slot, const double* cam7) { return H(h)->set_cam(b, slot, cam7); }
+int msckf_hip_get_num_residualized(msckf_hip_handle h, int b, long long* n) { return H(h)->get_nres(b, n); }
+int msckf_hip_set_num_residualized(msckf_hip_handle h, int b, long long n) { return H(h)->set_nres(b, n); }
+int msckf_hip_last_stats(msckf_hip_handle h, int b, int* out7) { return H(h)->stats(b, out7); }
+int msckf_hip_last_tracks(msckf_hip_handle h, int b, double* out8, int cap) { return H(h)->track_info(b, out8, cap); }
+int msckf_hip_last_deltax(msckf_hip_handle h, int b, double* dx, int cap) { return H(h)->deltax(b, dx, cap); }
+
+int msckf_hip_set_tracks(msckf_hip_handle h, int b, int F, const int* M, const int* slots, const double* obs2) { return H(h)->set_tracks(b, F, M, slots, obs2); }
+int msckf_hip_propagate_range(msckf_hip_handle h, int b0, int nb, const double* readings7, int K) { return H(h)->propagate(b0, nb, readings7, K); }
+int msckf_hip_augment_range(msckf_hip_handle h, int b0, int nb) { return H(h)->augment(b0, nb); }
+int msckf_hip_marginalize_range(msckf_hip_handle h, int b0, int nb) { return H(h)->marginalize(b0, nb); }
+int msckf_hip_drop_oldest_range(msckf_hip_handle h, int b0, int nb, int n_drop) { return H(h)->drop_oldest(b0, nb, n_drop); }
+
+int msckf_hip_scenario_alloc(msckf_hip_handle h, int n_frames, int K) { return H(h)->scen_alloc(n_frames, K); }
+int msckf_hip_scenario_set(msckf_hip_handle h, int frame, int b, const double* readings7, int F, const int* M, const int* slots, const double* obs2, int n_drop) {
+  return H(h)->scen_set(frame, b, readings7, F, M, slots, obs2, n_drop);
+}
+int msckf_hip_scenario_commit(msckf_hip_handle h) { return H(h)->scen_commit(); }
+int msckf_hip_run_frames(msckf_hip_handle h, int f0, int f1) { return H(h)->run_frames(f0, f1); }
+int msckf_hip_sync(msckf_hip_handle h) { return H(h)->sync(); }
+int msckf_hip_profile_enable(msckf_hip_handle h, int on) { return H(h)->prof_enable(on); }
+int msckf_hip_profile_read(msckf_hip_handle h, double* ms7, int* count7) { return H(h)->prof_read(ms7, count7); }
+
+}  // extern "C"

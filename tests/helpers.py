@@ -1,0 +1,72 @@
+"""Shared helpers for the parity tests: drive the CPU oracle and the HIP path with the same seeded inputs
+and measure the parity metric of SURVEY.md section 8c."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def quat_angle(q, qref):
+    """rotation angle of q (x) qref^-1 for (w,x,y,z) quaternions"""
+    q = np.asarray(q) / np.linalg.norm(q)
+    r = np.asarray(qref) / np.linalg.norm(qref)
+    d = abs(float(np.dot(q, r)))
+    return 2 * np.arccos(min(1.0, d))
+
+
+def rel(x, ref, floor=1e-3):
+    return float(np.linalg.norm(np.asarray(x) - np.asarray(ref)) / max(np.linalg.norm(ref), floor))
+
+
+def state_errors(imu, imu_ref, cams, cams_ref, P, P_ref):
+    """dict of the parity metrics: relative L2 per vector field, rotation angle for attitudes, relative
+    Frobenius norm for the covariance (full and IMU block)."""
+    e = dict(
+        q=quat_angle(imu[0:4], imu_ref[0:4]), bg=rel(imu[4:7], imu_ref[4:7]), v=rel(imu[7:10], imu_ref[7:10]),
+        ba=rel(imu[10:13], imu_ref[10:13]), p=rel(imu[13:16], imu_ref[13:16]),
+        P=rel(P, P_ref, 1e-30), Pii=rel(P[:15, :15], P_ref[:15, :15], 1e-30))
+    if len(cams_ref):
+        e["cam_q"] = max(quat_angle(a[:4], b[:4]) for a, b in zip(cams, cams_ref))
+        e["cam_p"] = max(rel(a[4:7], b[4:7]) for a, b in zip(cams, cams_ref))
+    return e
+
+
+def worst(e):
+    return max(e.values())
+
+
+def oracle_frame(o, tr, k, N):
+    o.propagate(tr.imu_for_frame(k))
+    o.augmentState(k, tr.frame_times[k])
+    fr = tr.frames[k]
+    if len(fr["M"]):
+        o.setTracks(fr["M"], fr["slots"], fr["obs"])
+        o.marginalize()
+    if o.getNumCamStates() == N:
+        o.dropOldest(1)
+
+
+def device_frame(batch, b, tr, k, N):
+    batch.propagate_range(b, 1, tr.imu_for_frame(k))
+    batch.augment_range(b, 1)
+    fr = tr.frames[k]
+    batch.set_tracks(b, fr["M"], fr["slots"], fr["obs"])
+    if len(fr["M"]):
+        batch.marginalize_range(b, 1)
+    if batch.num_cam_states(b) == N:
+        batch.drop_oldest_range(b, 1, 1)
+
+
+def copy_oracle_to_device(o, batch, b):
+    """teacher forcing: device state + covariance <- oracle"""
+    cams, _ = o.getCamStates()
+    batch.set_covariance(b, o.getCovariance())
+    batch.set_imu_state(b, o.getImuState())
+    for i, c in enumerate(cams):
+        batch.set_cam_pose(b, i, c)
+    batch.set_num_residualized(b, o.numResidualized())
