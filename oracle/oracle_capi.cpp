@@ -41,6 +41,8 @@ struct Base {
   virtual int pruned_ids(int* out, int cap) = 0;
   virtual long num_residualized() = 0;
   virtual void set_num_residualized(long n) = 0;
+  virtual void set_mode(int m) = 0;
+  virtual Base* clone() = 0;
 };
 
 template <class S>
@@ -133,6 +135,8 @@ struct Impl : Base {
   int pruned_ids(int* out, int cap) override { auto p = f.getPrunedStates(); int n = (int)p.size(); for (int i = 0; i < n && i < cap; ++i) out[i] = p[i].state_id; return n; }
   long num_residualized() override { return (long)f.numResidualized(); }
   void set_num_residualized(long n) override { f.setNumResidualized((size_t)n); }
+  void set_mode(int m) override { f.mode = (Mode)m; }
+  Base* clone() override { return new Impl<S>(*this); }
 };
 }  // namespace
 
@@ -165,6 +169,8 @@ int oracle_map_points(void* h, double* out, int cap) { return ((Base*)h)->map_po
 int oracle_pruned_ids(void* h, int* out, int cap) { return ((Base*)h)->pruned_ids(out, cap); }
 long oracle_num_residualized(void* h) { return ((Base*)h)->num_residualized(); }
 void oracle_set_num_residualized(void* h, long n) { ((Base*)h)->set_num_residualized(n); }
+void oracle_set_mode(void* h, int mode) { ((Base*)h)->set_mode(mode); }
+void* oracle_clone(void* h) { return ((Base*)h)->clone(); }
 
 // Timed CPU baseline: run `n_filters` independent filters over the same pre-built per-frame call
 // sequence on `n_threads` std::threads (one filter per thread at a time, as the reference is

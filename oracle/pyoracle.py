@@ -34,6 +34,8 @@ def lib():
         L = C.CDLL(path)
         L.oracle_create.restype = C.c_void_p
         L.oracle_create.argtypes = [C.c_int, C.c_int]
+        L.oracle_clone.restype = C.c_void_p
+        L.oracle_clone.argtypes = [C.c_void_p]
         L.oracle_time_updates.restype = C.c_double
         L.oracle_num_residualized.restype = C.c_long
         for name in ("oracle_num_cam_states", "oracle_get_tracks", "oracle_last_tracks", "oracle_last_deltax",
@@ -168,6 +170,15 @@ class Oracle:
 
     def numResidualized(self):
         return self.L.oracle_num_residualized(self.h)
+
+    def clone(self):
+        c = Oracle.__new__(Oracle)
+        c.L, c.dtype = self.L, self.dtype
+        c.h = C.c_void_p(self.L.oracle_clone(self.h))
+        return c
+
+    def setMode(self, mode):
+        self.L.oracle_set_mode(self.h, int(mode))
 
     def setNumResidualized(self, n):
         self.L.oracle_set_num_residualized(self.h, C.c_long(int(n)))

@@ -12,11 +12,13 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 
 def quat_angle(q, qref):
-    """rotation angle of q (x) qref^-1 for (w,x,y,z) quaternions"""
-    q = np.asarray(q) / np.linalg.norm(q)
-    r = np.asarray(qref) / np.linalg.norm(qref)
-    d = abs(float(np.dot(q, r)))
-    return 2 * np.arccos(min(1.0, d))
+    """rotation angle of q (x) qref^-1 for (w,x,y,z) quaternions (atan2 form: accurate near zero)"""
+    q = np.asarray(q, dtype=np.float64) / np.linalg.norm(q)
+    r = np.asarray(qref, dtype=np.float64) / np.linalg.norm(qref)
+    rc = np.array([r[0], -r[1], -r[2], -r[3]])
+    w = q[0] * rc[0] - q[1:] @ rc[1:]
+    v = q[0] * rc[1:] + rc[0] * q[1:] + np.cross(q[1:], rc[1:])
+    return float(2 * np.arctan2(np.linalg.norm(v), abs(w)))
 
 
 def rel(x, ref, floor=1e-3):

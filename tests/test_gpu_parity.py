@@ -1,0 +1,353 @@
+"""GPU parity tests: the HIP path (through the C-ABI, msckf_mono_amd.capi) against the CPU oracle on the
+same seeded inputs, against the committed golden fixtures, and -- at BASELINE.json's full sizes -- through
+size-independent properties.  Tolerances are BASELINE.json's: 1e-6 relative in double, 1e-3 in float, on
+state AND covariance (metric of SURVEY.md section 8c, implemented in tests/helpers.py)."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from msckf_mono_amd import scenario as sc
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = {"f64": 1e-6, "f32": 1e-3}
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from msckf_mono_amd import capi as c
+    c.lib()
+    return c
+
+
+@pytest.fixture(scope="module")
+def po(oracle_lib):
+    return oracle_lib
+
+
+def _dt(capi, po, name):
+    return (capi.F64, po.F64) if name == "f64" else (capi.F32, po.F32)
+
+
+def _errs(bt, b, o):
+    return H.state_errors(bt.imu_state(b), o.getImuState(), bt.cam_states(b)[0], o.getCamStates()[0], bt.covariance(b), o.getCovariance())
+
+
+def _stagewise(capi, po, prec, N, F, nf, teacher, traj=0, config=2, m_cap=None, check_tracks=True):
+    cd, od = _dt(capi, po, prec)
+    tr = sc.Trajectory(config, traj, N, F, nf)
+    o = po.Oracle(od, po.LEAN)
+    o.initialize(tr.cfg, tr.imu0)
+    bt = capi.Batch(1, N, max(F, 1), m_cap or max(N, 4), cd)
+    bt.initialize(0, tr.cfg, tr.imu0)
+    tol = TOL[prec]
+    for k in range(nf):
+        if teacher and k:
+            H.copy_oracle_to_device(o, bt, 0)
+        o.propagate(tr.imu_for_frame(k)); bt.propagate_range(0, 1, tr.imu_for_frame(k))
+        assert H.worst(_errs(bt, 0, o)) < tol, ("propagate", k, _errs(bt, 0, o))
+        o.augmentState(k, 0.0); bt.augment_range(0, 1)
+        assert H.worst(_errs(bt, 0, o)) < tol, ("augment", k, _errs(bt, 0, o))
+        fr = tr.frames[k]
+        bt.set_tracks(0, fr["M"], fr["slots"], fr["obs"])
+        if len(fr["M"]):
+            o.setTracks(fr["M"], fr["slots"], fr["obs"]); o.marginalize()
+            bt.marginalize_range(0, 1)
+            so, sd = o.lastStats(), bt.last_stats(0)
+            if check_tracks:
+                for key in ("n_tracks", "n_motion_rejected", "n_tri_rejected", "n_gate_rejected", "n_passed", "m_rows"):
+                    assert so[key] == sd[key], (k, key, so, sd)
+                to, td = o.lastTracks(), bt.last_tracks(0)
+                ok = (to[:, 0] > 0) & (to[:, 1] > 0)
+                assert np.allclose(td[ok, 5:8], to[ok, 5:8], rtol=0, atol=(1e-6 if prec == "f64" else 5e-2)), k   # triangulated points
+                assert np.allclose(td[ok, 4], to[ok, 4], rtol=(1e-6 if prec == "f64" else 2e-2), atol=1e-9), k      # gate statistic
+            assert H.worst(_errs(bt, 0, o)) < tol, ("update", k, _errs(bt, 0, o))
+        if o.getNumCamStates() == N:
+            o.dropOldest(1); bt.drop_oldest_range(0, 1, 1)
+            assert H.worst(_errs(bt, 0, o)) < tol, ("prune", k, _errs(bt, 0, o))
+    return bt, o, tr
+
+
+def test_cfg2_double_teacher_forced(capi, po):
+    """BASELINE.json configs[1]: synthetic 10-cam window, 50 feats, double, single trajectory."""
+    _stagewise(capi, po, "f64", 10, 50, 26, teacher=True)
+
+
+def test_cfg2_double_free_running(capi, po):
+    _stagewise(capi, po, "f64", 10, 50, 30, teacher=False)
+
+
+def test_cfg2_float_teacher_forced(capi, po):
+    _stagewise(capi, po, "f32", 10, 50, 26, teacher=True)
+
+
+def test_cfg3_float_teacher_forced(capi, po):
+    """BASELINE.json configs[2] problem size (30-cam window, 200 feats, float), one trajectory vs oracle."""
+    _stagewise(capi, po, "f32", 30, 200, 36, teacher=True, config=3, m_cap=32)
+
+
+def test_small_window_double(capi, po):
+    _stagewise(capi, po, "f64", 5, 7, 12, teacher=False, traj=3)
+
+
+@pytest.mark.parametrize("name", ["worklist_n6_f10", "worklist_n10_f50"])
+def test_golden_fixtures(capi, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    N, F, nf = int(g["N"]), int(g["F"]), int(g["nf"])
+    tr = sc.Trajectory(int(g["config_id"]), int(g["traj"]), N, F, nf)
+    bt = capi.Batch(1, N, F, N, capi.F64)
+    bt.initialize(0, tr.cfg, tr.imu0)
+    for k in range(nf):
+        H.device_frame(bt, 0, tr, k, N)
+        nc = int(g["ncam"][k])
+        assert bt.num_cam_states(0) == nc
+        D = 15 + 6 * nc
+        e = H.state_errors(bt.imu_state(0), g["imu"][k], bt.cam_states(0)[0], g["cams"][k][:nc], bt.covariance(0), g["P"][k][:D, :D])
+        assert H.worst(e) < 1e-6, (k, e)
+
+
+def test_reference_api_path_vs_oracle_and_golden(capi, po):
+    """initialize / propagate / augmentState / update / addFeatures / marginalize / pruneEmptyStates in the
+    reference's call order (asl_msckf.cpp:269-294) through the MSCKF mirror class."""
+    g = np.load(os.path.join(GOLD, "stream_n6_f8.npz"))
+    N, F, nf = int(g["N"]), int(g["F"]), int(g["nf"])
+    tr = sc.Trajectory(int(g["config_id"]), int(g["traj"]), N, F, nf)
+    st = tr.stream()
+    f = capi.MSCKF(capi.F64, n_cap=16, f_cap=32, m_cap=16)
+    f.initialize(tr.cfg, tr.imu0)
+    o = po.Oracle(po.F64, po.LEAN)
+    o.initialize(tr.cfg, tr.imu0)
+    for k in range(nf):
+        for rd in tr.imu_for_frame(k):
+            f.propagate(rd)                      # one launch per IMU sample, as the reference is called
+        o.propagate(tr.imu_for_frame(k))
+        f.augmentState(k, tr.frame_times[k]); o.augmentState(k, tr.frame_times[k])
+        f.update(st[k]["cur"][0], st[k]["cur"][1]); o.update(st[k]["cur"][0], st[k]["cur"][1])
+        f.addFeatures(st[k]["new"][0], st[k]["new"][1]); o.addFeatures(st[k]["new"][0], st[k]["new"][1])
+        f.marginalize(); o.marginalize()
+        assert len(f.getMap()) == len(o.getMap())
+        f.pruneEmptyStates(); o.pruneEmptyStates()
+        assert f.getNumCamStates() == o.getNumCamStates() == int(g["ncam"][k])
+        assert H.rel(f.getImuState()[:16], g["imu"][k][:16]) < 1e-6
+        assert H.worst(_errs(f.batch, 0, o)) < 1e-6
+        assert np.array_equal(f.getCamStates()[1], o.getCamStates()[1])      # state ids
+    assert np.array_equal(f.getPrunedStates(), o.getPrunedIds())
+    assert H.rel(f.getCovariance(), g["P_final"], 1e-30) < 1e-6
+    f.finish(); o.finish()
+    assert H.worst(_errs(f.batch, 0, o)) < 1e-6
+
+
+def test_batched_range_equals_single(capi):
+    """B trajectories in one launch give bit-identical results to B separate single-trajectory batches of
+    the same geometry (same kernels, same chunking)."""
+    N, F, nf, B = 8, 20, 14, 5
+    trs = [sc.Trajectory(2, 40 + b, N, F, nf) for b in range(B)]
+    big = capi.Batch(B, N, F, N, capi.F32)
+    for b, tr in enumerate(trs):
+        big.initialize(b, tr.cfg, tr.imu0)
+    for k in range(nf):
+        big.propagate_range(0, B, np.stack([tr.imu_for_frame(k) for tr in trs]))
+        big.augment_range(0, B)
+        for b, tr in enumerate(trs):
+            fr = tr.frames[k]
+            big.set_tracks(b, fr["M"], fr["slots"], fr["obs"])
+        big.marginalize_range(0, B)
+        if big.num_cam_states(0) == N:
+            big.drop_oldest_range(0, B, 1)
+    for b, tr in enumerate(trs):
+        one = capi.Batch(B, N, F, N, capi.F32)      # same B => same TSQR chunking
+        one.initialize(b, tr.cfg, tr.imu0)
+        for k in range(nf):
+            H.device_frame(one, b, tr, k, N)
+        assert np.array_equal(one.covariance(b), big.covariance(b))
+        assert np.array_equal(one.imu_state(b), big.imu_state(b))
+
+
+def test_resident_scenario_equals_per_call(capi):
+    N, F, nf, B = 8, 16, 13, 3
+    trs = [sc.Trajectory(2, 60 + b, N, F, nf) for b in range(B)]
+    a, c = capi.Batch(B, N, F, N, capi.F32), capi.Batch(B, N, F, N, capi.F32)
+    c.scenario_alloc(nf, sc.IMU_PER_FRAME)
+    for b, tr in enumerate(trs):
+        a.initialize(b, tr.cfg, tr.imu0); c.initialize(b, tr.cfg, tr.imu0)
+        for k in range(nf):
+            fr = tr.frames[k]
+            c.scenario_set(k, b, tr.imu_for_frame(k), fr["M"], fr["slots"], fr["obs"], 1 if fr["Nw"] == N else 0)
+    c.scenario_commit()
+    c.run_frames(0, nf); c.sync()
+    for b, tr in enumerate(trs):
+        for k in range(nf):
+            H.device_frame(a, b, tr, k, N)
+        assert np.array_equal(a.covariance(b), c.covariance(b))
+        assert np.array_equal(a.imu_state(b), c.imu_state(b))
+        assert np.array_equal(a.cam_states(b)[0], c.cam_states(b)[0])
+
+
+# ----------------------------------------------------------------------------------- edge cases
+def _pair(capi, po, prec, N, F, nf, cfg=None, traj=0, **kw):
+    cd, od = _dt(capi, po, prec)
+    tr = sc.Trajectory(2, traj, N, F, nf, cfg=cfg, **kw)
+    o = po.Oracle(od, po.LEAN); o.initialize(tr.cfg, tr.imu0)
+    bt = capi.Batch(1, N + 2, max(F, 1), max(N, 4), cd); bt.initialize(0, tr.cfg, tr.imu0)
+    return tr, o, bt
+
+
+def test_empty_track_list_is_a_no_op(capi, po):
+    tr, o, bt = _pair(capi, po, "f64", 6, 0, 8)
+    for k in range(8):
+        H.oracle_frame(o, tr, k, 6); H.device_frame(bt, 0, tr, k, 6)
+    P0 = bt.covariance(0)
+    bt.set_tracks(0, [], [], np.zeros((0, 2))); bt.marginalize_range(0, 1)
+    assert np.array_equal(bt.covariance(0), P0)
+    assert bt.last_stats(0)["n_tracks"] == 0
+    assert H.worst(_errs(bt, 0, o)) < 1e-6
+
+
+def test_all_tracks_gated_out_leaves_state_untouched(capi, po):
+    """true pixel noise == assumed noise: the 5% quantile gate (Q3) rejects (nearly) everything."""
+    tr, o, bt = _pair(capi, po, "f64", 7, 30, 10, obs_noise_px=20.0)
+    for k in range(9):
+        H.oracle_frame(o, tr, k, 7); H.device_frame(bt, 0, tr, k, 7)
+    H.copy_oracle_to_device(o, bt, 0)
+    k = 9
+    o.propagate(tr.imu_for_frame(k)); bt.propagate_range(0, 1, tr.imu_for_frame(k))
+    o.augmentState(k, 0); bt.augment_range(0, 1)
+    fr = tr.frames[k]
+    P0 = bt.covariance(0)
+    o.setTracks(fr["M"], fr["slots"], fr["obs"]); o.marginalize()
+    bt.set_tracks(0, fr["M"], fr["slots"], fr["obs"]); bt.marginalize_range(0, 1)
+    so, sd = o.lastStats(), bt.last_stats(0)
+    assert so["n_passed"] == sd["n_passed"] and so["n_gate_rejected"] + so["n_tri_rejected"] == sd["n_gate_rejected"] + sd["n_tri_rejected"]
+    if sd["n_passed"] == 0:
+        assert np.array_equal(bt.covariance(0), P0)
+    assert H.worst(_errs(bt, 0, o)) < 1e-6
+
+
+def test_motion_rejection_and_first_four_rule(capi, po):
+    """Q4 (msckf.h:354) + D1: an absurd translation threshold rejects every track after the first four."""
+    cfg = sc.filter_config(6)
+    cfg["translation_threshold"] = 1e3
+    tr, o, bt = _pair(capi, po, "f64", 6, 7, 7, cfg=cfg)
+    for k in range(7):
+        H.oracle_frame(o, tr, k, 6); H.device_frame(bt, 0, tr, k, 6)
+        if len(tr.frames[k]["M"]):
+            assert o.lastStats() == {**bt.last_stats(0), "r_rows": o.lastStats()["r_rows"]}
+    assert bt.num_residualized(0) == o.numResidualized() == 4
+    assert H.worst(_errs(bt, 0, o)) < 1e-6
+
+
+def test_ragged_tracks_with_gaps_and_unseen_cameras(capi, po):
+    """tracks with non-contiguous camera slots and cameras in the MIDDLE of the window that no track sees
+    (zero columns inside the stacked Jacobian) -- isotropic noise, so any compression agrees."""
+    N = 9
+    tr, o, bt = _pair(capi, po, "f64", N, 12, 12)
+    for k in range(11):
+        H.oracle_frame(o, tr, k, N); H.device_frame(bt, 0, tr, k, N)
+    H.copy_oracle_to_device(o, bt, 0)
+    k = 11
+    o.propagate(tr.imu_for_frame(k)); bt.propagate_range(0, 1, tr.imu_for_frame(k))
+    o.augmentState(k, 0); bt.augment_range(0, 1)
+    fr = tr.frames[k]
+    # drop every observation made from slots 3 and 4, and the odd observations of long tracks
+    M2, sl2, ob2, off = [], [], [], 0
+    for M in fr["M"]:
+        s, ob = fr["slots"][off:off + M], fr["obs"][off:off + M]
+        keep = [i for i in range(M) if s[i] not in (3, 4) and not (M > 6 and i % 2 == 1)]
+        off += M
+        if len(keep) >= 3:
+            M2.append(len(keep)); sl2 += [int(s[i]) for i in keep]; ob2 += [ob[i] for i in keep]
+    o.setTracks(M2, sl2, np.array(ob2)); o.marginalize()
+    bt.set_tracks(0, M2, sl2, np.array(ob2)); bt.marginalize_range(0, 1)
+    assert o.lastStats()["n_passed"] == bt.last_stats(0)["n_passed"] > 0
+    assert H.worst(_errs(bt, 0, o)) < 1e-6
+
+
+def test_maximum_track_length_equals_m_cap(capi, po):
+    """dense tracks: every track spans the whole window (M = N-1 = m_cap)."""
+    N = 17
+    cd, od = capi.F64, po.F64
+    tr = sc.Trajectory(2, 8, N, 10, N + 2, dense_tracks=True)
+    o = po.Oracle(od, po.LEAN); o.initialize(tr.cfg, tr.imu0)
+    bt = capi.Batch(1, N, 10, N - 1, cd); bt.initialize(0, tr.cfg, tr.imu0)
+    for k in range(N + 2):
+        H.oracle_frame(o, tr, k, N); H.device_frame(bt, 0, tr, k, N)
+    assert bt.last_stats(0)["m_rows"] == 10 * (2 * (N - 1) - 3)
+    assert H.worst(_errs(bt, 0, o)) < 1e-6
+
+
+def test_error_behaviour(capi):
+    import ctypes as C
+    cfg = sc.filter_config(6, isotropic=False)
+    tr = sc.Trajectory(2, 0, 6, 4, 3)
+    bt = capi.Batch(1, 3, 4, 6, capi.F32)
+    with pytest.raises(capi.HipError, match="anisotropic"):
+        bt.initialize(0, cfg, tr.imu0)                      # -ENOTSUP, documented scope
+    bt.initialize(0, tr.cfg, tr.imu0)
+    with pytest.raises(capi.HipError):
+        bt.set_tracks(0, [3] * 5, [0, 1, 2] * 5, np.zeros((15, 2)))   # more tracks than f_cap
+    with pytest.raises(capi.HipError):
+        bt.set_tracks(0, [7], list(range(7)), np.zeros((7, 2)))       # longer than m_cap
+    with pytest.raises(capi.HipError):
+        bt.initialize(5, tr.cfg, tr.imu0)                   # trajectory index out of range
+    for k in range(3):
+        bt.augment_state(0, k, 0.0)
+    with pytest.raises(capi.HipError, match="capacity"):
+        bt.augment_state(0, 3, 0.0)                         # n_cap exceeded
+    assert bt.L.msckf_hip_prune_redundant_states(bt.h, 0) == -38      # ENOSYS
+    with pytest.raises(capi.HipError):
+        capi.MSCKF(capi.F32, n_cap=4, f_cap=4, m_cap=4).update([[0, 0]], [1])   # update before initialize
+
+
+# ----------------------------------------------------------------------------------- full-size properties
+def test_cfg3_batch_properties(capi):
+    """64 trajectories x (30-cam window, 200 feats), float: the bench configuration.  Size-independent
+    properties: exact symmetry of P after every stage, positive diagonal, PSD up to float rounding, gate
+    pass-rate > 95 %, finite states, small position error against ground truth."""
+    N, F, B, nf = 30, 200, 64, 34
+    trs = [sc.Trajectory(3, b, N, F, nf) for b in range(B)]
+    bt = capi.Batch(B, N, F, N, capi.F32)
+    bt.scenario_alloc(nf, sc.IMU_PER_FRAME)
+    for b, tr in enumerate(trs):
+        bt.initialize(b, tr.cfg, tr.imu0)
+        for k in range(nf):
+            fr = tr.frames[k]
+            bt.scenario_set(k, b, tr.imu_for_frame(k), fr["M"], fr["slots"], fr["obs"], 1 if fr["Nw"] == N else 0)
+    bt.scenario_commit()
+    bt.run_frames(0, nf); bt.sync()
+    rates = []
+    for b in range(0, B, 7):
+        P = bt.covariance(b)
+        assert P.shape == (15 + 6 * (N - 1),) * 2 and np.all(np.isfinite(P))
+        assert np.array_equal(P, P.T)
+        assert np.all(np.diag(P) > 0)
+        w = np.linalg.eigvalsh(P)
+        assert w.min() > -1e-6 * w.max()
+        s = bt.last_stats(b)
+        rates.append(s["n_passed"] / s["n_tracks"])
+        assert s["m_rows"] > 4000
+        e = np.linalg.norm(bt.imu_state(b)[13:16] - trs[b].gt_frames["p"][nf - 1])
+        assert e < 0.05, e
+    assert np.mean(rates) > 0.95
+
+
+def test_cfg5_geometry_runs_and_stays_consistent(capi):
+    """60-camera window (BASELINE.json configs[4] geometry, fewer tracks): exercises NC = 6 QR tiles and the
+    global-memory Cholesky path; float."""
+    N, F, B, nf = 60, 60, 2, 64
+    trs = [sc.Trajectory(5, b, N, F, nf) for b in range(B)]
+    bt = capi.Batch(B, N, F, 64, capi.F32)
+    bt.scenario_alloc(nf, sc.IMU_PER_FRAME)
+    for b, tr in enumerate(trs):
+        bt.initialize(b, tr.cfg, tr.imu0)
+        for k in range(nf):
+            fr = tr.frames[k]
+            bt.scenario_set(k, b, tr.imu_for_frame(k), fr["M"], fr["slots"], fr["obs"], 1 if fr["Nw"] == N else 0)
+    bt.scenario_commit()
+    bt.run_frames(0, nf); bt.sync()
+    for b in range(B):
+        P = bt.covariance(b)
+        assert np.all(np.isfinite(P)) and np.array_equal(P, P.T) and np.all(np.diag(P) > 0)
+        assert np.linalg.norm(bt.imu_state(b)[13:16] - trs[b].gt_frames["p"][nf - 1]) < 0.1
+        assert bt.last_stats(b)["n_passed"] > 0.9 * F

@@ -1,0 +1,93 @@
+"""Known-answer and invariant tests of the oracle's linear-algebra kit and of the filter invariants
+(SURVEY.md section 4): chi2 table, covariance symmetry after every call, float-vs-double agreement."""
+import numpy as np
+import pytest
+from scipy.stats import chi2
+
+import helpers as H
+from msckf_mono_amd import scenario as sc
+
+
+def test_chi2_table_pinned():
+    """msckf.h:91-95: table[i-1] = quantile(chi2(i), 0.05); values pinned in SURVEY.md section 8c."""
+    import re
+    txt = open(H.ROOT + "/oracle/chi2_table.h").read()
+    vals = [float(x) for x in re.findall(r"^\s+([0-9.eE+-]+),?$", txt, flags=re.M)]
+    assert len(vals) == 99
+    for k, v in {1: 0.003932140000019522, 2: 0.10258658877510106, 3: 0.35184631774927144, 31: 19.280568559129293,
+                 32: 20.071913464548288, 99: 77.04633186376029}.items():
+        assert abs(vals[k - 1] - v) < 1e-13 * max(1, v)
+    assert np.allclose(vals, chi2.ppf(0.05, np.arange(1, 100)), rtol=1e-13)
+    dev = open(H.ROOT + "/msckf_mono_amd/csrc/chi2_table.h").read()
+    assert [float(x) for x in re.findall(r"^\s+([0-9.eE+-]+),?$", dev, flags=re.M)] == vals
+
+
+def test_covariance_symmetric_and_psd(oracle_lib):
+    po = oracle_lib
+    tr = sc.Trajectory(2, 4, 8, 25, 18)
+    o = po.Oracle(po.F64, po.LEAN)
+    o.initialize(tr.cfg, tr.imu0)
+    for k in range(18):
+        o.propagate(tr.imu_for_frame(k))
+        P = o.getCovariance(); assert np.array_equal(P, P.T)
+        o.augmentState(k, 0)
+        P = o.getCovariance(); assert np.array_equal(P, P.T)
+        fr = tr.frames[k]
+        if len(fr["M"]):
+            o.setTracks(fr["M"], fr["slots"], fr["obs"]); o.marginalize()
+            P = o.getCovariance(); assert np.array_equal(P, P.T)
+            assert np.linalg.eigvalsh(P).min() > -1e-12
+        if o.getNumCamStates() == 8:
+            o.dropOldest(1)
+            P = o.getCovariance(); assert np.array_equal(P, P.T)
+
+
+def test_float_oracle_tracks_double(oracle_lib):
+    """teacher-forced float vs double oracle: within the 1e-3 float bar of BASELINE.json"""
+    po = oracle_lib
+    N, F, nf = 10, 40, 16
+    tr = sc.Trajectory(2, 9, N, F, nf)
+    d, f = po.Oracle(po.F64, po.LEAN), po.Oracle(po.F32, po.LEAN)
+    d.initialize(tr.cfg, tr.imu0); f.initialize(tr.cfg, tr.imu0)
+    for k in range(nf):
+        if k:
+            f.setCovariance(d.getCovariance()); f.setImuState(d.getImuState())
+            for i, c in enumerate(d.getCamStates()[0]):
+                f.setCamPose(i, c)
+            f.setNumResidualized(d.numResidualized())
+        H.oracle_frame(d, tr, k, N); H.oracle_frame(f, tr, k, N)
+        e = H.state_errors(f.getImuState(), d.getImuState(), f.getCamStates()[0], d.getCamStates()[0], f.getCovariance(), d.getCovariance())
+        assert H.worst(e) < 1e-3, (k, e)
+
+
+def test_gate_uses_5pct_quantile_of_chi2_M_plus_1(oracle_lib):
+    """Q3: with true pixel noise == assumed noise virtually every track is rejected; with the scenario's
+    0.5 px vs 7 px the pass rate is > 95 %."""
+    po = oracle_lib
+    N, F, nf = 8, 40, 12
+    for obs_px, lo, hi in ((0.5, 0.95, 1.01), (7.0, -0.01, 0.2)):
+        tr = sc.Trajectory(2, 2, N, F, nf, obs_noise_px=obs_px)
+        o = po.Oracle(po.F64, po.LEAN)
+        o.initialize(tr.cfg, tr.imu0)
+        for k in range(nf):
+            H.oracle_frame(o, tr, k, N)
+        s = o.lastStats()
+        tri_ok = s["n_tracks"] - s["n_motion_rejected"] - s["n_tri_rejected"]
+        rate = s["n_passed"] / max(tri_ok, 1)
+        assert lo < rate < hi, (obs_px, s)
+
+
+def test_first_four_tracks_skip_check_motion(oracle_lib):
+    """Q4: num_feature_tracks_residualized_ > 3 gates checkMotion (msckf.h:354)."""
+    po = oracle_lib
+    N, F = 6, 6
+    cfg = sc.filter_config(N)
+    cfg["translation_threshold"] = 1e3        # every track fails checkMotion
+    tr = sc.Trajectory(2, 5, N, F, 6, cfg=cfg)
+    o = po.Oracle(po.F64, po.LEAN)
+    o.initialize(tr.cfg, tr.imu0)
+    for k in range(4):
+        H.oracle_frame(o, tr, k, N)
+    s = o.lastStats()
+    assert s["n_tracks"] == F and s["n_passed"] + s["n_gate_rejected"] + s["n_tri_rejected"] == 4 and s["n_motion_rejected"] == F - 4
+    assert o.numResidualized() == 4 - s["n_tri_rejected"]
