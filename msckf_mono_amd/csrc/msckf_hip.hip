@@ -616,7 +616,6 @@ int host_marginalize(BatchBase* B, int b) {
   if (rc < 0) return rc;
   for (int i = 0; i < F; ++i)
     if (info[8 * i] != 0 && info[8 * i + 1] != 0) { t.map.push_back(info[8 * i + 5]); t.map.push_back(info[8 * i + 6]); t.map.push_back(info[8 * i + 7]); }
-  t.to_resid.clear();   // consumed (the reference clears it at the next update(), msckf.h:218)
   return 0;
 }
 
@@ -640,6 +639,10 @@ int host_prune_empty(BatchBase* B, int b) {
 
 int host_finish(BatchBase* B, int b) {
   HostTraj& t = B->traj[b];
+  // D6: the reference appends to the stale feature_tracks_to_residualize_ of the previous update() (cleared only
+  // at msckf.h:218), whose positional indices and pose copies are invalid once states were corrected/pruned;
+  // the stale list is dropped here (oracle/msckf_oracle.hpp does the same).
+  t.to_resid.clear();
   for (size_t i = 0; i < t.tracked_ids.size(); i++) {
     TrackToResid r;
     remove_tracked_feature(t, t.tracked_ids[i], r.slots);

@@ -225,7 +225,7 @@ class Trajectory:
         pts = np.zeros((F, 3))
         todo = np.arange(F)
         spread = 0.6
-        for attempt in range(40):
+        for attempt in range(400):
             n = len(todo)
             u = rng.uniform(3 * n).reshape(n, 3)
             mid = k - 1 - (M[todo] // 2)
@@ -245,7 +245,12 @@ class Trajectory:
             if len(todo) == 0:
                 break
             if attempt % 8 == 7:
-                spread *= 0.7
+                spread = max(0.7 * spread, 0.05)
+            if attempt % 40 == 39:
+                # the camera sweeps ~23 deg/s: a landmark cannot stay inside a 90 deg field of view for much
+                # more than ~2 s, so over-long tracks (windows > 40 frames) are shortened (in place)
+                M[todo] = np.maximum(3, (3 * M[todo]) // 4)
+                spread = 0.6
         if len(todo):
             raise RuntimeError("landmark sampling failed")
         return pts

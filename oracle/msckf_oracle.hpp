@@ -23,6 +23,8 @@
 //   D1   the second loop of marginalize uses track.p_f_G (msckf.h:370) instead of p_f_G_vec[iter]
 //        (msckf.h:419), which is mis-indexed after a motion-rejected track.
 //   D3   observation erased at the index computed *before* erasing the cam_state index (msckf.h:601-604).
+//   D6   finish() (msckf.h:765-807) drops the stale feature_tracks_to_residualize_ left by the previous update()
+//        instead of re-residualizing it with out-of-date positional indices (the list is only cleared at :218).
 #ifndef ORACLE_MSCKF_ORACLE_HPP
 #define ORACLE_MSCKF_ORACLE_HPP
 
@@ -406,6 +408,7 @@ class MSCKF {
 
   // ---------------------------------------------------------------- msckf.h:765-807
   void finish() {
+    feature_tracks_to_residualize_.clear();   // D6
     for (size_t i = 0; i < tracked_feature_ids_.size(); i++) {
       std::vector<size_t> idx; std::vector<CamState<S>> cs;
       removeTrackedFeature(tracked_feature_ids_[i], cs, idx);
