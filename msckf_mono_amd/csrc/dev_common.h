@@ -50,9 +50,9 @@ struct Dev {
   long wl_stride_f;   // stride between trajectories in trk_M   (ints)
   long wl_stride_o;   // stride between trajectories in trk_slots (ints) / trk_obs (2 scalars each)
   // per-track products of k_feature
-  int* trk_status; S* trk_pf; S* trk_gamma; S* trk_Hx; S* trk_V; S* trk_Z; S* trk_ro; signed char* trk_inv; int* trk_first;
+  int* trk_status; S* trk_pf; S* trk_gamma; S* trk_Hx; S* trk_V; S* trk_Zf; S* trk_ro; int* trk_first;
   // k_select
-  int* row_start; int* stats;
+  int* row_start; int* trk_order; int* stats;
   // TSQR
   S* Rbuf;
   // Kalman work matrices

@@ -11,7 +11,7 @@
 // What is NOT done the reference's way: H_o_j = A_j^T H_x_j is never formed.  With
 // Q = I - V T V^T (compact WY of the 3 reflectors) the projected block is
 //     H_o_j = (H_x_j)[3:, :] - V[3:, :] * Z,     Z = T^T V^T H_x_j   (3 x 6M, block-local per lane)
-// so a track is handed to the compression stage as {H_x blocks, V, Z, r_o}: 40*M scalars instead of
+// so a track is handed to the compression stage as {H_x blocks, V, Z scattered to state columns, r_o} instead of
 // (2M-3)*(15+6N).  The gate uses G = H_x P_cc H_x^T assembled from 6x6 blocks of P (192 M^2 flop instead of
 // the dense 2 rho D^2) and S = (Q^T G Q)[3:,3:] + sigma^2 I as a rank-6 correction of G, factored by an
 // in-LDS Cholesky with r_o riding along as an extra row (gamma = |L^-1 r_o|^2).
@@ -375,21 +375,20 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
   {
     S* oHx = d.trk_Hx + (tb * m_cap) * 12;
     S* oV = d.trk_V + (tb * 2 * m_cap) * 4;
-    S* oZ = d.trk_Z + (tb * m_cap) * 18;
+    S* oZ = d.trk_Zf + tb * 3 * (long)d.ldR;   // Z scattered to state columns: [3][ldR], zero where unobserved
     S* oR = d.trk_ro + tb * 2 * m_cap;
     if (act) {
       for (int i = 0; i < 2; ++i) for (int k = 0; k < 6; ++k) oHx[lane * 12 + i * 6 + k] = hx[i][k];
-      for (int q = 0; q < 3; ++q) for (int k = 0; k < 6; ++k) oZ[lane * 18 + q * 6 + k] = Zc[q][k];
       for (int s2 = 0; s2 < 2; ++s2) {
         const int row = row0 + s2;
         oV[row * 4 + 0] = v[s2][0]; oV[row * 4 + 1] = v[s2][1]; oV[row * 4 + 2] = v[s2][2]; oV[row * 4 + 3] = 0;
         oR[row] = qr[s2];   // (Q^T r)[row]; rows >= 3 are r_o
       }
     }
-    signed char* inv = d.trk_inv + tb * d.n_cap;
-    for (int s = lane; s < d.n_cap; s += 64) inv[s] = -1;
+    for (int e = lane; e < 3 * d.ldR; e += 64) oZ[e] = 0;
     __syncthreads();
-    if (act) inv[slot] = (signed char)lane;
+    if (act)
+      for (int q = 0; q < 3; ++q) for (int k = 0; k < 6; ++k) oZ[(long)q * d.ldR + 6 * slot + k] = Zc[q][k];
     int fs = act ? slot : 0x7fffffff;
     fs = wave_min_i(fs);
     if (lane == 0) {
@@ -402,41 +401,114 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
   }
 }
 
-// One thread per trajectory: resolves the order-dependent part of marginalize (:352-399) -- checkMotion is
-// skipped while fewer than 4 tracks have ever been residualized (Q4) -- and lays the gated-in tracks' rows
-// out contiguously (prefix sums) for the compression stage.
+// One wavefront per trajectory: resolves the order-dependent part of marginalize (:352-399) -- checkMotion is
+// skipped while fewer than 4 tracks have ever been residualized (Q4, msckf.h:354) -- and lays the gated-in
+// tracks' rows out for the compression stage: tracks are counting-sorted by their first camera slot (stable,
+// deterministic), so that consecutive row blocks of the TSQR share their leading zero columns and can start
+// their elimination late.  order[p] = track id of sorted position p, row_start[p] = first stacked row.
+// Once more than 3 tracks have been residualized the decisions are independent per track and run
+// lane-parallel; the first few frames of a run take the serial path.
 template <class S>
-__global__ void k_select(Dev<S> d, int b0, int nb) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64) void k_select(Dev<S> d, int b0, int nb) {
+  const int i = blockIdx.x, lane = threadIdx.x;
   if (i >= nb) return;
   const int b = b0 + i;
   const int F = d.trk_n[(long)i * d.wl_stride_n];
   long long nres = d.n_resid[b];
   int* st = d.stats + (long)b * STAT_STRIDE;
-  int mrej = 0, trej = 0, grej = 0, pass = 0, rows = 0;
+  int mrej = 0, trej = 0, grej = 0, pass = 0;
   int* rs = d.row_start + (long)b * (d.f_cap + 1);
-  for (int t = 0; t < F; ++t) {
-    const long tb = (long)b * d.f_cap + t;
-    int s = d.trk_status[tb];
-    const int M = d.trk_M[(long)i * d.wl_stride_f + t];
-    rs[t] = rows;
-    bool valid = false;
-    if (M < 2) { if (nres > 3) mrej++; else trej++; s = 0; }
-    else if (nres > 3 && !(s & ST_MOTION_OK)) { mrej++; s &= ~(ST_TRI_VALID | ST_GATE_PASS); }
-    else {
-      if (nres <= 3) s |= ST_MOTION_SKIPPED;
-      if (s & ST_TRI_VALID) { valid = true; nres++; } else { trej++; s &= ~ST_GATE_PASS; }
+  int* order = d.trk_order + (long)b * d.f_cap;
+  __shared__ int sCnt[64], sBase[64], sRows[64];
+  sCnt[lane] = 0; sRows[lane] = 0;
+  __syncthreads();
+  // ---- pass 1: decisions (status bits), per-bin counts
+  if (nres <= 3) {
+    if (lane == 0) {
+      for (int t = 0; t < F; ++t) {
+        const long tb = (long)b * d.f_cap + t;
+        int s = d.trk_status[tb];
+        const int M = d.trk_M[(long)i * d.wl_stride_f + t];
+        bool valid = false;
+        if (M < 2) { if (nres > 3) mrej++; else trej++; s = 0; }
+        else if (nres > 3 && !(s & ST_MOTION_OK)) { mrej++; s &= ~(ST_TRI_VALID | ST_GATE_PASS); }
+        else {
+          if (nres <= 3) s |= ST_MOTION_SKIPPED;
+          if (s & ST_TRI_VALID) { valid = true; nres++; } else { trej++; s &= ~ST_GATE_PASS; }
+        }
+        if (valid) {
+          if (s & ST_GATE_PASS) { s |= ST_INCLUDED; pass++; const int f0 = d.trk_first[tb] & 63; sCnt[f0]++; sRows[f0] += 2 * M - 3; }
+          else grej++;
+        }
+        d.trk_status[tb] = s;
+      }
     }
-    if (valid) {
-      if (s & ST_GATE_PASS) { s |= ST_INCLUDED; pass++; rows += 2 * M - 3; }
-      else grej++;
+    mrej = __shfl(mrej, 0, 64); trej = __shfl(trej, 0, 64); grej = __shfl(grej, 0, 64); pass = __shfl(pass, 0, 64);
+    nres = __shfl((int)nres, 0, 64);
+  } else {
+    for (int t0 = 0; t0 < F; t0 += 64) {
+      const int t = t0 + lane;
+      const bool in = t < F;
+      const long tb = (long)b * d.f_cap + t;
+      int s = in ? d.trk_status[tb] : 0;
+      const int M = in ? d.trk_M[(long)i * d.wl_stride_f + t] : 0;
+      bool m_rej = false, t_rej = false, g_rej = false, valid = false, incl = false;
+      if (in) {
+        if (M < 2 || !(s & ST_MOTION_OK)) { m_rej = true; s = (M < 2) ? 0 : (s & ~(ST_TRI_VALID | ST_GATE_PASS)); }
+        else if (s & ST_TRI_VALID) valid = true;
+        else { t_rej = true; s &= ~ST_GATE_PASS; }
+        if (valid) { if (s & ST_GATE_PASS) { incl = true; s |= ST_INCLUDED; } else g_rej = true; }
+        d.trk_status[tb] = s;
+      }
+      if (incl) { const int f0 = d.trk_first[tb] & 63; atomicAdd(&sCnt[f0], 1); atomicAdd(&sRows[f0], 2 * M - 3); }
+      mrej += __popcll(__ballot(m_rej)); trej += __popcll(__ballot(t_rej)); grej += __popcll(__ballot(g_rej));
+      pass += __popcll(__ballot(incl)); nres += __popcll(__ballot(valid));
     }
-    d.trk_status[tb] = s;
   }
-  rs[F] = rows;
-  d.n_resid[b] = nres;
-  st[STAT_NTRACKS] = F; st[STAT_MOTION_REJ] = mrej; st[STAT_TRI_REJ] = trej; st[STAT_GATE_REJ] = grej;
-  st[STAT_PASSED] = pass; st[STAT_MROWS] = rows; st[STAT_RROWS] = rows > 0 ? 6 * d.ncam[b] : 0;
+  __syncthreads();
+  // ---- exclusive prefix of the per-bin track counts (bins = first camera slot, ascending)
+  {
+    const int c = sCnt[lane];
+    int scan = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(scan, o, 64); if (lane >= o) scan += up; }
+    sBase[lane] = scan - c;
+  }
+  __syncthreads();
+  // ---- pass 2: stable placement (track index order inside a bin), then row prefix over sorted positions
+  for (int t0 = 0; t0 < F; t0 += 64) {
+    const int t = t0 + lane;
+    const long tb = (long)b * d.f_cap + t;
+    const bool incl = (t < F) && (d.trk_status[tb] & ST_INCLUDED);
+    const int bin = incl ? (d.trk_first[tb] & 63) : -1;
+    int pos = -1;
+    for (int sbin = 0; sbin < d.n_cap && sbin < 64; ++sbin) {
+      const unsigned long long m = __ballot(bin == sbin);
+      if (bin == sbin) pos = sBase[sbin] + __popcll(m & ((1ull << lane) - 1ull));
+      __syncthreads();
+      if (lane == 0) sBase[sbin] += __popcll(m);
+      __syncthreads();
+    }
+    if (incl) order[pos] = t;
+  }
+  __syncthreads();
+  int rows = 0;
+  for (int p0 = 0; p0 < pass; p0 += 64) {
+    const int p = p0 + lane;
+    int r = 0;
+    if (p < pass) { const int t = order[p]; r = 2 * d.trk_M[(long)i * d.wl_stride_f + t] - 3; }
+    int scan = r;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(scan, o, 64); if (lane >= o) scan += up; }
+    if (p < pass) rs[p] = rows + scan - r;
+    rows += __shfl(scan, 63, 64);
+  }
+  if (lane == 0) {
+    rs[pass] = rows;
+    d.n_resid[b] = nres;
+    st[STAT_NTRACKS] = F; st[STAT_MOTION_REJ] = mrej; st[STAT_TRI_REJ] = trej; st[STAT_GATE_REJ] = grej;
+    st[STAT_PASSED] = pass; st[STAT_MROWS] = rows; st[STAT_RROWS] = rows > 0 ? 6 * d.ncam[b] : 0;
+  }
 }
 
 size_t feature_lds_bytes(int m_cap, size_t scalar) {
@@ -465,7 +537,7 @@ void launch_feature(const Dev<S>& d, int b0, int nb, hipStream_t st) {
 template <class S>
 void launch_select(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0) return;
-  hipLaunchKernelGGL(k_select<S>, dim3((nb + 63) / 64), dim3(64), 0, st, d, b0, nb);
+  hipLaunchKernelGGL(k_select<S>, dim3(nb), dim3(64), 0, st, d, b0, nb);
 }
 
 template void launch_feature<float>(const Dev<float>&, int, int, hipStream_t);

@@ -182,6 +182,121 @@ __global__ __launch_bounds__(256) void k_chol_inv(Dev<S> d, int b0) {
   }
 }
 
+// K = PHt S^-1 with S and PHt resident in REGISTERS of one workgroup (256 threads as a 16 x 16 grid, 2-D
+// block-cyclic: thread (tx,ty) owns S(16a+tx, 16b+ty) and PHt(16a+tx, 16b+ty)).
+//   phase 1: right-looking Cholesky S = L L^T; PHt rides along as appended rows, so the same rank-1
+//            eliminations turn it into W = PHt L^-T (the explicit S^-1 of msckf.h:1370 is never formed);
+//   phase 2: K = W L^-1 by a backward column sweep (K[:,c] = W[:,c]/L[c][c]; W[:,j<c] -= K[:,c] L[c][j]).
+// Per step one LDS exchange (pivot column / pivot row) + one barrier; all FMAs run on registers.
+template <class S, int NBN>
+__global__ __launch_bounds__(256) void k_gain(Dev<S> d, int b0) {
+  constexpr int G = 16, NBD = NBN + 1;
+  const int b = b0 + blockIdx.x, tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
+  const KView<S> v = make_view(d, b);
+  const int n = v.n, D = v.D;
+  __shared__ S sCol[2][G * NBN];     // pivot column of S (phase 1) / pivot row of L (phase 2)
+  __shared__ S sW[2][G * NBD];       // pivot column of the appended block
+  S A[NBN][NBN], Wm[NBD][NBN];
+#pragma unroll
+  for (int a = 0; a < NBN; ++a)
+#pragma unroll
+    for (int bb = 0; bb < NBN; ++bb) {
+      const int i = G * a + tx, j = G * bb + ty;
+      A[a][bb] = (a >= bb && i < n && j < n) ? v.Sm[(long)j * v.ldn + i] : S(0);
+    }
+#pragma unroll
+  for (int a = 0; a < NBD; ++a)
+#pragma unroll
+    for (int bb = 0; bb < NBN; ++bb) {
+      const int i = G * a + tx, j = G * bb + ty;
+      Wm[a][bb] = (i < D && j < n) ? v.PHt[(long)j * v.ld + i] : S(0);
+    }
+  int buf = 0;
+  // ---------------- phase 1
+#pragma unroll
+  for (int kb = 0; kb < NBN; ++kb) {
+    const int kk_hi = min(G, n - G * kb);
+    for (int kk = 0; kk < kk_hi; ++kk) {
+      const int k = G * kb + kk;
+      if (ty == kk) {
+#pragma unroll
+        for (int a = kb; a < NBN; ++a) sCol[buf][G * a + tx] = A[a][kb];
+#pragma unroll
+        for (int a = 0; a < NBD; ++a) sW[buf][G * a + tx] = Wm[a][kb];
+      }
+      __syncthreads();
+      const S dkk = sCol[buf][k];
+      const S dd = dsqrt(dkk > S(0) ? dkk : Lim<S>::tiny());
+      const S dinv = S(1) / dd;
+      S li[NBN], lj[NBN], wi[NBD];
+#pragma unroll
+      for (int a = kb; a < NBN; ++a) li[a] = (a > kb || tx > kk) ? sCol[buf][G * a + tx] * dinv : S(0);
+#pragma unroll
+      for (int bb = kb; bb < NBN; ++bb) lj[bb] = (bb > kb || ty > kk) ? sCol[buf][G * bb + ty] * dinv : S(0);
+#pragma unroll
+      for (int a = 0; a < NBD; ++a) wi[a] = sW[buf][G * a + tx] * dinv;
+#pragma unroll
+      for (int a = kb; a < NBN; ++a)
+#pragma unroll
+        for (int bb = kb; bb <= a; ++bb) A[a][bb] -= li[a] * lj[bb];
+#pragma unroll
+      for (int a = 0; a < NBD; ++a)
+#pragma unroll
+        for (int bb = kb; bb < NBN; ++bb) Wm[a][bb] -= wi[a] * lj[bb];
+      if (ty == kk) {   // finalise column k of L and of W
+#pragma unroll
+        for (int a = kb; a < NBN; ++a) {
+          if (a > kb || tx > kk) A[a][kb] = li[a];
+          else if (a == kb && tx == kk) A[a][kb] = dd;
+        }
+#pragma unroll
+        for (int a = 0; a < NBD; ++a) Wm[a][kb] = wi[a];
+      }
+      buf ^= 1;
+    }
+  }
+  // ---------------- phase 2
+#pragma unroll
+  for (int cb = NBN - 1; cb >= 0; --cb) {
+    const int cc_hi = min(G, n - G * cb);
+    for (int cc = cc_hi - 1; cc >= 0; --cc) {
+      const int c = G * cb + cc;
+      if (tx == cc) {   // row c of L: L(c, j) lives in A[cb][b] of the threads with tx == cc
+#pragma unroll
+        for (int bb = 0; bb <= cb; ++bb) sCol[buf][G * bb + ty] = A[cb][bb];
+      }
+      if (ty == cc) {
+#pragma unroll
+        for (int a = 0; a < NBD; ++a) sW[buf][G * a + tx] = Wm[a][cb];
+      }
+      __syncthreads();
+      const S dinv = S(1) / sCol[buf][c];
+      S kc[NBD], lr[NBN];
+#pragma unroll
+      for (int a = 0; a < NBD; ++a) kc[a] = sW[buf][G * a + tx] * dinv;
+#pragma unroll
+      for (int bb = 0; bb <= cb; ++bb) lr[bb] = (bb < cb || ty < cc) ? sCol[buf][G * bb + ty] : S(0);
+#pragma unroll
+      for (int a = 0; a < NBD; ++a)
+#pragma unroll
+        for (int bb = 0; bb <= cb; ++bb) Wm[a][bb] -= kc[a] * lr[bb];
+      if (ty == cc) {
+#pragma unroll
+        for (int a = 0; a < NBD; ++a) Wm[a][cb] = kc[a];
+      }
+      buf ^= 1;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < NBD; ++a)
+#pragma unroll
+    for (int bb = 0; bb < NBN; ++bb) {
+      const int i = G * a + tx, j = G * bb + ty;
+      if (i < D && j < n) v.K[(long)j * v.ld + i] = Wm[a][bb];
+    }
+}
+
 // dx = K r_n and state injection (msckf.h:1373-1391); one workgroup per trajectory.
 template <class S>
 __global__ __launch_bounds__(256) void k_inject(Dev<S> d, int b0) {
@@ -236,20 +351,30 @@ void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   const int n = d.n6cap, D = 15 + n;
   gemm<S, OP_PHT>(d, b0, nb, D, n, st);
   gemm<S, OP_S>(d, b0, nb, n, n, st);
-  const size_t lds = (size_t)n * (n + 1) * sizeof(S);
-  if (lds <= 150 * 1024) {
-    static bool attr_set[2] = {false, false};
-    const int ti = sizeof(S) == 4 ? 0 : 1;
-    if (!attr_set[ti]) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_inv<S, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set[ti] = true;
-    }
-    hipLaunchKernelGGL((k_chol_inv<S, true>), dim3(nb), dim3(256), lds, st, d, b0);
+  // K = PHt S^-1: register-resident factor/solve when the window fits the 16x16 thread grid, otherwise
+  // Cholesky + triangular inverse (LDS or global) followed by two GEMMs.
+  const int nbn = (n + 15) / 16;
+  const int nbn_max = sizeof(S) == 4 ? 12 : 8;
+  if (nbn <= nbn_max) {
+    if (nbn <= 4) hipLaunchKernelGGL((k_gain<S, 4>), dim3(nb), dim3(256), 0, st, d, b0);
+    else if (nbn <= 8) hipLaunchKernelGGL((k_gain<S, 8>), dim3(nb), dim3(256), 0, st, d, b0);
+    else hipLaunchKernelGGL((k_gain<S, 12>), dim3(nb), dim3(256), 0, st, d, b0);
   } else {
-    hipLaunchKernelGGL((k_chol_inv<S, false>), dim3(nb), dim3(256), 0, st, d, b0);
+    const size_t lds = (size_t)n * (n + 1) * sizeof(S);
+    if (lds <= 150 * 1024) {
+      static bool attr_set[2] = {false, false};
+      const int ti = sizeof(S) == 4 ? 0 : 1;
+      if (!attr_set[ti]) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_inv<S, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set[ti] = true;
+      }
+      hipLaunchKernelGGL((k_chol_inv<S, true>), dim3(nb), dim3(256), lds, st, d, b0);
+    } else {
+      hipLaunchKernelGGL((k_chol_inv<S, false>), dim3(nb), dim3(256), 0, st, d, b0);
+    }
+    gemm<S, OP_W>(d, b0, nb, D, n, st);
+    gemm<S, OP_K>(d, b0, nb, D, n, st);
   }
-  gemm<S, OP_W>(d, b0, nb, D, n, st);
-  gemm<S, OP_K>(d, b0, nb, D, n, st);
   hipLaunchKernelGGL(k_inject<S>, dim3(nb), dim3(256), (size_t)d.ld * sizeof(S), st, d, b0);
   gemm<S, OP_A>(d, b0, nb, D, D, st);
   gemm<S, OP_AP>(d, b0, nb, D, D, st);

@@ -7,7 +7,7 @@
 // (n = 6 N camera columns -- the 15 IMU columns of H_o are identically zero, msckf.h:949) and folds blocks
 // of 4*RW rows into it with structured Householder reflectors ("QR update" of [R; B]).  Rows are
 // regenerated on the fly from the per-track compact form written by k_feature:
-//       H_o_j[i, 6c+d] = [row 3+i belongs to obs c] Hx_c[(3+i)&1][d] - V[3+i,:] . Z_c[:, d]
+//       H_o_j[i, col] = [col in the 6 columns of obs (3+i)/2] Hx[(3+i)&1][.] - V[3+i,:] . Zf[:, col]
 // Block layout inside a workgroup (256 threads = 4 wavefronts):
 //   wave h owns rows h*RW .. h*RW+RW-1 of the block, lane l owns columns l, l+64, ... (NC per lane);
 //   the block lives in registers (RW*NC per lane).  Step k: the wave that needs column k reads it from
@@ -24,96 +24,154 @@
 
 namespace msckf {
 
-template <class S, int NC, int RW>
-__global__ __launch_bounds__(256) void k_qr_update(Dev<S> d, int b0, int stage, int level) {
+__device__ int g_qr_dbg[4] = {0, 0, 0, 0};   // experiment knobs (msckf_hip_debug_set); all zero in production
+
+template <class S> __device__ __forceinline__ S fast_rcp(S x) { return S(1) / x; }
+
+// Work triangle access: packed upper triangle in LDS (row k holds columns k..n) or ldR-strided rows in global.
+template <class S, bool RLDS>
+struct Tri {
+  S* base; int n, ldR;
+  __device__ __forceinline__ S get(int k, int col) const {
+    if (RLDS) return (col >= k && col <= n) ? base[k * (n + 1) - k * (k - 1) / 2 + col - k] : S(0);
+    return base[(long)k * ldR + col];
+  }
+  __device__ __forceinline__ void put(int k, int col, S v) const {
+    if (RLDS) { if (col >= k && col <= n) base[k * (n + 1) - k * (k - 1) / 2 + col - k] = v; }
+    else if (col >= k) base[(long)k * ldR + col] = v;
+  }
+};
+
+// One workgroup = 4 wavefronts working as a software pipeline over the rows of R: wavefront h owns the
+// row blocks h, h+4, h+8, ... of its chunk (RW rows x all columns in registers, lane l = columns l, l+64, ..),
+// and block q may run Householder step k as soon as block q-1 has finished step k (R's row k is handed
+// from wave to wave through LDS with a release/acquire progress word).  Inside a wavefront a step needs no
+// LDS exchange and no barrier: the pivot column is read from its owner lane with v_readlane, the dot
+// products are complete within the wave, the column norm is the pivot column's self product.
+constexpr int QR_NW = 12;   // wavefronts per workgroup = depth of the software pipeline
+
+template <class S, int NC, int RW, bool RLDS>
+__global__ __launch_bounds__(64 * QR_NW) void k_qr_update(Dev<S> d, int b0, int stage, int level) {
   const int b = b0 + blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
-  __shared__ S sPart[2][4][64 * NC];
-  __shared__ int sKmin[4];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  int* sProg = reinterpret_cast<int*>(smem_raw);          // [QR_NW] progress words (block * 1024 + steps done)
+  S* sR = reinterpret_cast<S*>(smem_raw + 64);            // packed triangle (RLDS)
   const int n = 6 * d.ncam[b];
   const int ldR = d.ldR;
   const int m_cap = d.m_cap, f_cap = d.f_cap;
   const int* rs = d.row_start + (long)b * (f_cap + 1);
-  const int F = d.stats[(long)b * STAT_STRIDE + STAT_NTRACKS];
+  const int* order = d.trk_order + (long)b * f_cap;
+  const int P = d.stats[(long)b * STAT_STRIDE + STAT_PASSED];     // gated-in tracks (sorted positions)
   const int m_total = d.stats[(long)b * STAT_STRIDE + STAT_MROWS];
   if (m_total == 0) return;
 
-  S* Rt;            // target triangle
+  S* Rt;                  // target triangle (global)
   const S* Rs = nullptr;  // stage 2: source triangle
   int row_begin, row_end;
   if (stage == 1) {
     const int c = blockIdx.x;
     Rt = d.Rbuf + ((long)b * d.nchunk + c) * (long)d.n6cap * ldR;
-    row_begin = (int)((long)m_total * c / d.nchunk);
-    row_end = (int)((long)m_total * (c + 1) / d.nchunk);
-    for (int e = tid; e < n * ldR; e += 256) Rt[e] = 0;   // fresh triangle
-    __syncthreads();
+    row_begin = 0; row_end = m_total;   // blocks of RW rows are dealt round-robin to the chunks (see below)
+    if (RLDS) { for (int e = tid; e < (n + 1) * (n + 2) / 2; e += 64 * QR_NW) sR[e] = 0; }
+    else { for (int e = tid; e < n * ldR; e += 64 * QR_NW) Rt[e] = 0; }   // fresh triangle
   } else {
     const int tgt = (2 * blockIdx.x) << level, src = tgt + (1 << level);
     if (src >= d.nchunk) return;
     Rt = d.Rbuf + ((long)b * d.nchunk + tgt) * (long)d.n6cap * ldR;
     Rs = d.Rbuf + ((long)b * d.nchunk + src) * (long)d.n6cap * ldR;
     row_begin = 0; row_end = n;
+    if (RLDS) {
+      for (int e = tid; e < n * (n + 1); e += 64 * QR_NW) {
+        const int k = e / (n + 1), col = e - k * (n + 1);
+        if (col >= k) sR[k * (n + 1) - k * (k - 1) / 2 + col - k] = Rt[(long)k * ldR + col];
+      }
+    }
   }
-  const int BR = 4 * RW;
-  int buf = 0;
-  for (int blk0 = row_begin; blk0 < row_end; blk0 += BR) {
-    // ---------------- load the block: RW rows x NC columns per lane
+  if (tid < QR_NW) sProg[tid] = 0;
+  __syncthreads();
+  Tri<S, RLDS> R;
+  R.base = RLDS ? sR : Rt; R.n = n; R.ldR = ldR;
+  const int pred = (h + QR_NW - 1) % QR_NW;
+  // Stage 1: the sorted stack is cut into blocks of RW rows; global block g belongs to chunk g % nchunk (so
+  // every chunk gets the same mix of long and short tracks) and is that chunk's block q = g / nchunk.
+  const int cstride = (stage == 1) ? d.nchunk : 1, coff = (stage == 1) ? (int)blockIdx.x : 0;
+  const int gblk = (row_end - row_begin + RW - 1) / RW;
+  const int nblk = (gblk - coff + cstride - 1) / cstride;
+  const int dbg = g_qr_dbg[0];
+  for (int q = h; q < nblk; q += QR_NW) {
+    const int blk0 = row_begin + (q * cstride + coff) * RW;
+    // ---------------- load this wave's block: RW rows x NC columns per lane
+    // lane r resolves stacked row blk0+r to (track, row-in-track) -- one parallel binary search per block
+    // instead of RW serial ones -- and the results are handed out with v_readlane
     S Bv[RW][NC];
     int kmin = n;
+    int my_t = -1, my_row = 0;
+    if (dbg & 2) {   // ablation: skip the loader
+#pragma unroll
+      for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int j = 0; j < NC; ++j) Bv[r][j] = S(0.001) * S((lane * 7 + r * 13 + j * 5 + q) % 17 - 8);
+      kmin = 0;
+    } else {
+    if (stage == 1) {
+      const int gr = blk0 + lane;
+      if (lane < RW && gr < row_end) {
+        int lo = 0, hi = P;   // invariant rs[lo] <= gr < rs[hi]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rs[mid] <= gr) lo = mid; else hi = mid; }
+        my_t = order[lo];
+        my_row = 3 + (gr - rs[lo]);               // row of Q^T [H_x | r]
+        kmin = 6 * d.trk_first[(long)b * f_cap + my_t];
+      }
+      kmin = wave_min_i(kmin);
+    } else {
+      kmin = blk0 < n ? blk0 : n;
+    }
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
-      const int gr = blk0 + h * RW + r;
-      if (gr >= row_end) {
-#pragma unroll
-        for (int j = 0; j < NC; ++j) Bv[r][j] = 0;
-        continue;
-      }
+      const int gr = blk0 + r;
       if (stage == 1) {
-        // track owning stacked row gr: last t with rs[t] <= gr
-        int lo = 0, hi = F;   // invariant rs[lo] <= gr < rs[hi]
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rs[mid] <= gr) lo = mid; else hi = mid; }
-        const int t = lo;
+        const int t_raw = wave_bcast(my_t, r);
+        const bool live = t_raw >= 0;               // false past the end of the chunk (last block only)
+        const int t = live ? t_raw : 0;             // branch-free: every load below stays in bounds
+        const int row = wave_bcast(my_row, r);
         const long tb = (long)b * f_cap + t;
-        const int row = 3 + (gr - rs[t]);            // row of Q^T [H_x | r]
         const int cobs = row >> 1, sub = row & 1;
         const S* Vr = d.trk_V + (tb * 2 * m_cap + row) * 4;
         const S v0 = Vr[0], v1 = Vr[1], v2 = Vr[2];
-        const signed char* inv = d.trk_inv + tb * d.n_cap;
-        const S* Hx = d.trk_Hx + (tb * m_cap) * 12;
-        const S* Z = d.trk_Z + (tb * m_cap) * 18;
-        const int first = 6 * d.trk_first[tb];
-        kmin = first < kmin ? first : kmin;
+        const S* Zf = d.trk_Zf + tb * 3 * (long)ldR;                        // [3][ldR], coalesced over columns
+        const int c0 = 6 * d.trk_slots[(long)(b - b0) * d.wl_stride_o + (long)t * m_cap + cobs];
+        const S* Hx = d.trk_Hx + (tb * m_cap + cobs) * 12 + sub * 6;
+        const S ro = d.trk_ro[tb * 2 * m_cap + row];
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
           const int col = lane + 64 * j;
-          S val = 0;
-          if (col < n) {
-            const int s = col / 6, dd = col - 6 * s;
-            const int c = inv[s];
-            if (c >= 0) {
-              const S* z = Z + c * 18 + dd;
-              val = -(v0 * z[0] + v1 * z[6] + v2 * z[12]);
-              if (c == cobs) val += Hx[c * 12 + sub * 6 + dd];
-            }
-          } else if (col == n) {
-            val = d.trk_ro[tb * 2 * m_cap + row];
-          }
-          Bv[r][j] = val;
+          S val = -(v0 * Zf[col] + v1 * Zf[ldR + col] + v2 * Zf[2 * ldR + col]);
+          const unsigned dcol = (unsigned)(col - c0);
+          if (dcol < 6u) val += Hx[dcol];
+          if (col == n) val = ro;
+          Bv[r][j] = live ? val : S(0);
         }
       } else {
-        kmin = gr < kmin ? gr : kmin;
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
           const int col = lane + 64 * j;
-          Bv[r][j] = (col <= n) ? Rs[(long)gr * ldR + col] : S(0);
+          Bv[r][j] = (gr < row_end && col <= n) ? Rs[(long)gr * ldR + col] : S(0);
         }
       }
     }
-    if (lane == 0) sKmin[h] = kmin;
-    __syncthreads();
-    kmin = min(min(sKmin[0], sKmin[1]), min(sKmin[2], sKmin[3]));
-    __syncthreads();
+    }
+    if (dbg & 1) kmin = n;   // ablation: skip the elimination steps
+    if (dbg & 4) kmin = 0;   // ablation: no leading-zero skipping
+    if (dbg & 8) {           // ablation: keep the loader's timing but eliminate dense pseudo-random data
+#pragma unroll
+      for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int j = 0; j < NC; ++j) Bv[r][j] = Bv[r][j] * S(1e-30) + S(0.001) * S((lane * 7 + r * 13 + j * 5 + q) % 17 - 8);
+    }
+    kmin = __builtin_amdgcn_readfirstlane(kmin);
+    // steps below kmin are no-ops for this block
+    if (lane == 0) __hip_atomic_store(&sProg[h], q * 1024 + kmin, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 
     // ---------------- fold the block into R: Householder steps k = kmin .. n-1
 #pragma unroll
@@ -122,76 +180,86 @@ __global__ __launch_bounds__(256) void k_qr_update(Dev<S> d, int b0, int stage, 
       const int l_hi = min(64, n - 64 * jk);
       for (int lk = l_lo; lk < l_hi; ++lk) {
         const int k = 64 * jk + lk;
-        // R row k (coalesced; only slots >= jk can hold columns >= k)
+        if (q > 0) {   // wait until block q-1 has finished step k (its R row k is final for us)
+          const int need = (q - 1) * 1024 + k + 1;
+          while (__hip_atomic_load(&sProg[pred], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+        }
         S rk[NC];
 #pragma unroll
-        for (int j = jk; j < NC; ++j) rk[j] = Rt[(long)k * ldR + lane + 64 * j];
-        // pivot column of this wave's rows, from the owner lane
+        for (int j = jk; j < NC; ++j) rk[j] = R.get(k, lane + 64 * j);
+        // pivot column of this block, from the owner lane
         S xr[RW];
 #pragma unroll
         for (int r = 0; r < RW; ++r) xr[r] = wave_bcast(Bv[r][jk], lk);
-        // partial dot products x'^T b_j over this wave's rows
-        S part[NC];
-#pragma unroll
-        for (int j = jk; j < NC; ++j) {
-          S s = 0;
-#pragma unroll
-          for (int r = 0; r < RW; ++r) s += xr[r] * Bv[r][j];
-          part[j] = s;
-          sPart[buf][h][64 * j + lane] = s;
-        }
-        __syncthreads();
         S tot[NC];
 #pragma unroll
-        for (int j = jk; j < NC; ++j)
-          tot[j] = (sPart[buf][0][64 * j + lane] + sPart[buf][1][64 * j + lane]) + (sPart[buf][2][64 * j + lane] + sPart[buf][3][64 * j + lane]);
-        const S sigma = (sPart[buf][0][k] + sPart[buf][1][k]) + (sPart[buf][2][k] + sPart[buf][3][k]);
-        buf ^= 1;
-        if (sigma <= Lim<S>::tiny()) continue;          // zero tail: the step is the identity
-        const S x0 = wave_bcast(rk[jk], lk);
-        S beta = dsqrt(x0 * x0 + sigma);
-        if (x0 >= S(0)) beta = -beta;
-        const S inv = S(1) / (x0 - beta);
-        const S tau = (beta - x0) / beta;
-#pragma unroll
         for (int j = jk; j < NC; ++j) {
-          const int col = lane + 64 * j;
-          if (col > k) {
-            const S w = rk[j] + tot[j] * inv;
-            const S tw = tau * w;
-            rk[j] -= tw;
-            const S cj = tw * inv;
+          S s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
-            for (int r = 0; r < RW; ++r) Bv[r][j] -= cj * xr[r];
-          } else if (col == k) {
-            rk[j] = beta;
-#pragma unroll
-            for (int r = 0; r < RW; ++r) Bv[r][j] = 0;
-          }
+          for (int r = 0; r < RW; r += 4) { s0 += xr[r] * Bv[r][j]; s1 += xr[r + 1] * Bv[r + 1][j]; s2 += xr[r + 2] * Bv[r + 2][j]; s3 += xr[r + 3] * Bv[r + 3][j]; }
+          tot[j] = (s0 + s1) + (s2 + s3);
         }
-        if (h == 0) {
+        const S sigma = wave_bcast(tot[jk], lk);
+        if (sigma > Lim<S>::tiny()) {
+          // reflector H = I - tau v v^T, v = [1; x'/u], u = x0 - beta, tau = -u/beta.  With g = 1/(beta u):
+          //   R[k][j] += e_j g u,   B[:,j] += e_j g x',   e_j = u R[k][j] + x'^T b_j      (one reciprocal per step)
+          const S x0 = wave_bcast(rk[jk], lk);
+          S beta = dsqrt(x0 * x0 + sigma);
+          if (x0 >= S(0)) beta = -beta;
+          const S u = x0 - beta;
+          const S g = fast_rcp(beta * u);
+          const S gu = g * u;
 #pragma unroll
           for (int j = jk; j < NC; ++j) {
             const int col = lane + 64 * j;
-            if (col >= k) Rt[(long)k * ldR + col] = rk[j];
+            if (col > k) {
+              const S e = u * rk[j] + tot[j];
+              rk[j] += e * gu;
+              const S cj = e * g;
+#pragma unroll
+              for (int r = 0; r < RW; ++r) Bv[r][j] += cj * xr[r];
+            } else if (col == k) {
+              rk[j] = beta;
+#pragma unroll
+              for (int r = 0; r < RW; ++r) Bv[r][j] = 0;
+            }
           }
+#pragma unroll
+          for (int j = jk; j < NC; ++j) R.put(k, lane + 64 * j, rk[j]);
         }
-        (void)part;
+        if (lane == 0) __hip_atomic_store(&sProg[h], q * 1024 + k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
-    __syncthreads();   // R rows written by wave 0 must be visible to every wave before the next block
+    if (lane == 0) __hip_atomic_store(&sProg[h], q * 1024 + 1023, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __syncthreads();
+  if (RLDS) {   // publish the triangle (zeros below the diagonal and in the padding columns)
+    for (int e = tid; e < n * ldR; e += 64 * QR_NW) {
+      const int k = e / ldR, col = e - k * ldR;
+      Rt[e] = (col >= k && col <= n) ? sR[k * (n + 1) - k * (k - 1) / 2 + col - k] : S(0);
+    }
   }
 }
 
-template <class S, int NC>
-static void launch_compress_nc(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase) {
-  constexpr int RW = 16;
-  if (phase != 2) hipLaunchKernelGGL((k_qr_update<S, NC, RW>), dim3(d.nchunk, nb), dim3(256), 0, st, d, b0, 1, 0);
+template <class S, int NC, bool RLDS>
+static void launch_compress_impl(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase, size_t lds) {
+  constexpr int RW = (sizeof(S) == 4 && NC <= 3) ? 32 : 16;
+  auto kern = k_qr_update<S, NC, RW, RLDS>;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  if (phase != 2) hipLaunchKernelGGL(kern, dim3(d.nchunk, nb), dim3(64 * QR_NW), lds, st, d, b0, 1, 0);
   if (phase == 1) return;
   for (int level = 0; (1 << level) < d.nchunk; ++level) {
     const int pairs = (d.nchunk + (2 << level) - 1) / (2 << level);
-    hipLaunchKernelGGL((k_qr_update<S, NC, RW>), dim3(pairs, nb), dim3(256), 0, st, d, b0, 2, level);
+    hipLaunchKernelGGL(kern, dim3(pairs, nb), dim3(64 * QR_NW), lds, st, d, b0, 2, level);
   }
+}
+template <class S, int NC>
+static void launch_compress_nc(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase) {
+  const size_t base = 64;
+  const size_t tri = sizeof(S) * (size_t)(d.n6cap + 1) * (d.n6cap + 2) / 2;
+  if (base + tri <= 150 * 1024) launch_compress_impl<S, NC, true>(d, b0, nb, st, phase, base + tri);
+  else launch_compress_impl<S, NC, false>(d, b0, nb, st, phase, base);
 }
 
 template <class S>
@@ -207,6 +275,8 @@ void launch_compress(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase)
     default: launch_compress_nc<S, 6>(d, b0, nb, st, phase); break;
   }
 }
+
+void qr_debug_set(int idx, int val) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_qr_dbg), &val, sizeof(int), idx * sizeof(int)); }
 
 template void launch_compress<float>(const Dev<float>&, int, int, hipStream_t, int);
 template void launch_compress<double>(const Dev<double>&, int, int, hipStream_t, int);

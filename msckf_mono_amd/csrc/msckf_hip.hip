@@ -114,7 +114,7 @@ struct Batch : BatchBase {
     d.ldR = ((6 * n_cap + 1 + 63) / 64) * 64;
     if (d.ldR / 64 > 6) return fail(-EINVAL, "n_cap too large for the QR kernel (6*n_cap+1 must be <= 384)");
     int nch = 1;
-    while (nch < 8 && (long)B * nch * 2 <= 1024) nch *= 2;   // enough workgroups to cover 256 CUs
+    while (nch < 8 && (long)B * nch * 2 <= 256) nch *= 2;    // one 8-wave workgroup per CU covers 256 CUs
     d.nchunk = nch;
     const size_t Bz = B, pl = (size_t)d.ld * d.ld, nl = (size_t)d.n6cap * d.n6cap, dn = (size_t)d.ld * d.n6cap;
     const size_t TF = Bz * f_cap;
@@ -122,9 +122,9 @@ struct Batch : BatchBase {
     rc |= dalloc(&d.imu, Bz * IMU_STRIDE); rc |= dalloc(&d.cam, Bz * n_cap * CAM_STRIDE); rc |= dalloc(&d.prm, Bz * PRM_STRIDE);
     rc |= dalloc(&d.P, Bz * pl); rc |= dalloc(&d.Ptmp, Bz * pl); rc |= dalloc(&d.ncam, Bz); rc |= dalloc(&d.n_resid, Bz);
     rc |= dalloc(&d.trk_status, TF); rc |= dalloc(&d.trk_pf, TF * 4); rc |= dalloc(&d.trk_gamma, TF);
-    rc |= dalloc(&d.trk_Hx, TF * m_cap * 12); rc |= dalloc(&d.trk_V, TF * 2 * m_cap * 4); rc |= dalloc(&d.trk_Z, TF * m_cap * 18);
-    rc |= dalloc(&d.trk_ro, TF * 2 * m_cap); rc |= dalloc(&d.trk_inv, TF * n_cap); rc |= dalloc(&d.trk_first, TF);
-    rc |= dalloc(&d.row_start, Bz * (f_cap + 1)); rc |= dalloc(&d.stats, Bz * STAT_STRIDE);
+    rc |= dalloc(&d.trk_Hx, TF * m_cap * 12); rc |= dalloc(&d.trk_V, TF * 2 * m_cap * 4); rc |= dalloc(&d.trk_Zf, TF * 3 * (size_t)d.ldR);
+    rc |= dalloc(&d.trk_ro, TF * 2 * m_cap); rc |= dalloc(&d.trk_first, TF);
+    rc |= dalloc(&d.row_start, Bz * (f_cap + 1)); rc |= dalloc(&d.trk_order, TF); rc |= dalloc(&d.stats, Bz * STAT_STRIDE);
     rc |= dalloc(&d.Rbuf, Bz * d.nchunk * (size_t)d.n6cap * d.ldR);
     rc |= dalloc(&d.PHt, Bz * dn); rc |= dalloc(&d.Smat, Bz * nl); rc |= dalloc(&d.Linv, Bz * nl); rc |= dalloc(&d.W, Bz * dn);
     rc |= dalloc(&d.K, Bz * dn); rc |= dalloc(&d.A, Bz * pl); rc |= dalloc(&d.AP, Bz * pl); rc |= dalloc(&d.X, Bz * pl); rc |= dalloc(&d.dx, Bz * d.ld);
@@ -657,7 +657,12 @@ int host_finish(BatchBase* B, int b) {
 BatchBase* H(msckf_hip_handle h) { return reinterpret_cast<BatchBase*>(h); }
 }  // namespace
 
+namespace msckf { void qr_debug_set(int idx, int val); }
+
 extern "C" {
+
+// experiment knob, not part of the ABI (include/msckf_hip.h does not declare it)
+void msckf_hip_debug_set(int idx, int val) { msckf::qr_debug_set(idx, val); }
 
 const char* msckf_hip_last_error(void) { return g_err.c_str(); }
 
