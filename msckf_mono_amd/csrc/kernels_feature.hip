@@ -337,37 +337,107 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
     for (int s2 = 0; s2 < 2; ++s2) { const int row = row0 + s2; if (row >= 3 && row < R2) sG[R2 * ldg + row] = qr[s2]; }
   }
   __syncthreads();
-  // ---- S = (Q^T G Q)[3:,3:] + sigma^2 I (lower triangle, in place)
+  // ---- S = (Q^T G Q)[3:,3:] + sigma^2 I, Cholesky with the r_o row appended, gamma = |L^-1 r_o|^2
   const S sig2 = prm[PRM_UVAR];
-  for (int i = 3 + lane; i < R2; i += 64) {
-    const S vi0 = sV[i * 3], vi1 = sV[i * 3 + 1], vi2 = sV[i * 3 + 2];
-    const S ei0 = sE[i * 3], ei1 = sE[i * 3 + 1], ei2 = sE[i * 3 + 2];
-    for (int j = 3; j <= i; ++j) {
-      S s = sG[i * ldg + j] - (vi0 * sE[j * 3] + vi1 * sE[j * 3 + 1] + vi2 * sE[j * 3 + 2])
-            - (ei0 * sV[j * 3] + ei1 * sV[j * 3 + 1] + ei2 * sV[j * 3 + 2]);
-      if (i == j) s += sig2;
-      sG[i * ldg + j] = s;
-    }
-  }
-  __syncthreads();
-  // ---- Cholesky of S with the r_o row appended; gamma = sum y_k^2
   bool spd = true;
-  for (int k = 3; k < R2; ++k) {
-    const S dkk = sG[k * ldg + k];
-    if (!(dkk > S(0))) { spd = false; break; }
-    const S dinv = S(1) / dsqrt(dkk);
-    for (int i = k + 1 + lane; i <= R2; i += 64) sG[i * ldg + k] *= dinv;
-    __syncthreads();
-    for (int i = k + 1 + lane; i <= R2; i += 64) {
-      const S lik = sG[i * ldg + k];
-      const int jmax = i < R2 ? i : R2 - 1;
-      for (int j = k + 1; j <= jmax; ++j) sG[i * ldg + j] -= lik * sG[j * ldg + k];
+  S gamma = 0;
+  (void)0;
+  if (rho + 1 <= 64) {
+    // register-resident: the wavefront is an 8 x 8 grid, lane (tx,ty) owns elements (8a+tx, 8b+ty) of the
+    // (rho+1) x rho lower trapezoid; one LDS exchange of the pivot column per step, no workgroup barrier
+    constexpr int NB = 8;
+    const int tx = lane & 7, ty = lane >> 3;
+    S A[NB][NB];
+    S vr[NB][3], er[NB][3];
+#pragma unroll
+    for (int a2 = 0; a2 < NB; ++a2) {
+      const int i = 8 * a2 + tx;
+      const bool ok = i < rho;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { vr[a2][q] = ok ? sV[(3 + i) * 3 + q] : S(0); er[a2][q] = ok ? sE[(3 + i) * 3 + q] : S(0); }
+    }
+#pragma unroll
+    for (int b2 = 0; b2 < NB; ++b2) {
+      const int j = 8 * b2 + ty;
+      const bool okj = j < rho;
+      S vc[3], ec[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { vc[q] = okj ? sV[(3 + j) * 3 + q] : S(0); ec[q] = okj ? sE[(3 + j) * 3 + q] : S(0); }
+#pragma unroll
+      for (int a2 = b2; a2 < NB; ++a2) {
+        const int i = 8 * a2 + tx;
+        S val = 0;
+        if (okj && i < rho) {
+          val = sG[(3 + i) * ldg + 3 + j] - (vr[a2][0] * ec[0] + vr[a2][1] * ec[1] + vr[a2][2] * ec[2])
+                - (er[a2][0] * vc[0] + er[a2][1] * vc[1] + er[a2][2] * vc[2]);
+          if (i == j) val += sig2;
+        } else if (okj && i == rho) {
+          val = sG[R2 * ldg + 3 + j];            // appended row: r_o
+        }
+        A[a2][b2] = val;
+      }
     }
     __syncthreads();
+    S* sC = sG;    // reuse: pivot column exchange, 2 x 64 entries laid out [buf][tx*8 + a]
+    int bufc = 0;
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+      const int kk_hi = min(8, rho - 8 * kb);
+      for (int kk = 0; kk < kk_hi; ++kk) {
+        const int k = 8 * kb + kk;
+        if (ty == kk) {
+#pragma unroll
+          for (int a2 = kb; a2 < NB; ++a2) sC[bufc * 64 + tx * 8 + a2] = A[a2][kb];
+        }
+        __syncthreads();
+        const S dkk = sC[bufc * 64 + kk * 8 + kb];
+        if (!(dkk > S(0))) { spd = false; break; }
+        const S dinv = S(1) / dsqrt(dkk);
+        S li[NB], lj[NB];
+#pragma unroll
+        for (int a2 = kb; a2 < NB; ++a2) li[a2] = (a2 > kb || tx > kk) ? sC[bufc * 64 + tx * 8 + a2] * dinv : S(0);
+#pragma unroll
+        for (int b2 = kb; b2 < NB; ++b2) lj[b2] = (b2 > kb || ty > kk) ? sC[bufc * 64 + ty * 8 + b2] * dinv : S(0);
+        {   // y_k = (r_o row)[k] / d  ->  gamma
+          const S y = sC[bufc * 64 + (rho & 7) * 8 + (rho >> 3)] * dinv;
+          gamma += y * y;
+        }
+#pragma unroll
+        for (int a2 = kb; a2 < NB; ++a2)
+#pragma unroll
+          for (int b2 = kb; b2 <= a2; ++b2) A[a2][b2] -= li[a2] * lj[b2];
+        bufc ^= 1;
+      }
+      if (!spd) break;
+    }
+  } else {
+    for (int i = 3 + lane; i < R2; i += 64) {
+      const S vi0 = sV[i * 3], vi1 = sV[i * 3 + 1], vi2 = sV[i * 3 + 2];
+      const S ei0 = sE[i * 3], ei1 = sE[i * 3 + 1], ei2 = sE[i * 3 + 2];
+      for (int j = 3; j <= i; ++j) {
+        S sv = sG[i * ldg + j] - (vi0 * sE[j * 3] + vi1 * sE[j * 3 + 1] + vi2 * sE[j * 3 + 2])
+               - (ei0 * sV[j * 3] + ei1 * sV[j * 3 + 1] + ei2 * sV[j * 3 + 2]);
+        if (i == j) sv += sig2;
+        sG[i * ldg + j] = sv;
+      }
+    }
+    __syncthreads();
+    for (int k = 3; k < R2; ++k) {
+      const S dkk = sG[k * ldg + k];
+      if (!(dkk > S(0))) { spd = false; break; }
+      const S dinv = S(1) / dsqrt(dkk);
+      for (int i = k + 1 + lane; i <= R2; i += 64) sG[i * ldg + k] *= dinv;
+      __syncthreads();
+      for (int i = k + 1 + lane; i <= R2; i += 64) {
+        const S lik = sG[i * ldg + k];
+        const int jmax = i < R2 ? i : R2 - 1;
+        for (int j = k + 1; j <= jmax; ++j) sG[i * ldg + j] -= lik * sG[j * ldg + k];
+      }
+      __syncthreads();
+    }
+    for (int k = 3 + lane; k < R2; k += 64) { const S y = sG[R2 * ldg + k]; gamma += y * y; }
+    gamma = wave_sum(gamma);
   }
-  S gamma = 0;
-  for (int k = 3 + lane; k < R2; k += 64) { const S y = sG[R2 * ldg + k]; gamma += y * y; }
-  gamma = wave_sum(gamma);
   const S thresh = S(c_chi2[M < 98 ? M : 98]);   // table[dof+1], dof = M-1   (:433, :1117)
   if (spd && gamma < thresh) status |= ST_GATE_PASS;
 

@@ -14,11 +14,7 @@
 
 namespace msckf {
 
-template <class S> struct ExpOrder;
-template <> struct ExpOrder<float> { static constexpr int value = 8; };
-template <> struct ExpOrder<double> { static constexpr int value = 13; };
-
-// C = A*B for 15x15 row-major LDS matrices, 64 lanes cooperatively (no aliasing between C and A/B)
+// One wavefront multiplies two 15x15 row-major LDS matrices (no aliasing between C and A/B)
 template <class S>
 __device__ __forceinline__ void mm15(S* C, const S* A, const S* B, int lane) {
   for (int e = lane; e < 225; e += 64) {
@@ -39,169 +35,225 @@ __device__ __forceinline__ void mm15_abt(S* C, const S* A, const S* B, int lane)
     C[e] = s;
   }
 }
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 
+constexpr int PG = 16;      // IMU samples per group
+constexpr int SST = 20;     // LDS stride of one IMU state: q(4) b_g(3) v(3) b_a(3) p(3) dT(1) pad
+
+// propogateImuStateRK, msckf.h:1425-1467: RK on the JPL-ordered quaternion (-x,-y,-z,w) with 0.5*Omega(w),
+// Euler on v and p.  `st` holds q b_g v b_a p; returns the propagated q, v, p in `out`.
 template <class S>
-__global__ __launch_bounds__(64) void k_propagate(Dev<S> d, int b0, const S* readings, long rd_stride, int K) {
-  const int b = b0 + blockIdx.x, lane = threadIdx.x;
-  __shared__ S sF[225], sPhi[225], sT1[225], sT2[225], sTot[225], sPii[225], sSt[IMU_STRIDE];
+__device__ __forceinline__ void imu_rk(const S* st, V3<S> g, V3<S> om, V3<S> ac, S dT, S* out) {
+  const Q4<S> q = ldq(st);
+  const V3<S> bg = ld3(st + 4), v = ld3(st + 7), ba = ld3(st + 10), p = ld3(st + 13);
+  const V3<S> wh = om - bg, ah = ac - ba;
+  const M3<S> C = q2rot(q);
+  S y0[4] = {-q.x, -q.y, -q.z, q.w};
+  auto omul = [&](const S* y, S* o) {  // o = 0.5*omegaMat(wh) * y   (matrix_utils.h:20-30)
+    o[0] = S(0.5) * (wh.z * y[1] - wh.y * y[2] + wh.x * y[3]);
+    o[1] = S(0.5) * (-wh.z * y[0] + wh.x * y[2] + wh.y * y[3]);
+    o[2] = S(0.5) * (wh.y * y[0] - wh.x * y[1] + wh.z * y[3]);
+    o[3] = S(0.5) * (-wh.x * y[0] - wh.y * y[1] - wh.z * y[2]);
+  };
+  S k0[4], k1[4], k2[4], k3[4], k4[4], k5[4], t[4];
+  omul(y0, k0);
+  for (int i = 0; i < 4; ++i) t[i] = y0[i] + (k0[i] / S(4)) * dT;
+  omul(t, k1);
+  for (int i = 0; i < 4; ++i) t[i] = y0[i] + (k0[i] / S(8) + k1[i] / S(8)) * dT;
+  omul(t, k2);
+  for (int i = 0; i < 4; ++i) t[i] = y0[i] + (-k1[i] / S(2) + k2[i]) * dT;
+  omul(t, k3);
+  for (int i = 0; i < 4; ++i) t[i] = y0[i] + (k0[i] * S(3) / S(16) + k3[i] * S(9) / S(16)) * dT;
+  omul(t, k4);
+  for (int i = 0; i < 4; ++i)
+    t[i] = y0[i] + (-k0[i] * S(3) / S(7) + k1[i] * S(2) / S(7) + k2[i] * S(12) / S(7) - k3[i] * S(12) / S(7) + k4[i] * S(8) / S(7)) * dT;
+  omul(t, k5);
+  S yt[4];
+  for (int i = 0; i < 4; ++i) yt[i] = y0[i] + (S(7) * k0[i] + S(32) * k2[i] + S(12) * k3[i] + S(32) * k4[i] + S(7) * k5[i]) * dT / S(90);
+  Q4<S> qn; qn.w = yt[3]; qn.x = -yt[0]; qn.y = -yt[1]; qn.z = -yt[2];
+  qn = qnormalized(qn);
+  stq(out, qn);
+  st3(out + 4, bg);
+  st3(out + 7, v + (dT * (multv(C, ah) + g)));
+  st3(out + 10, ba);
+  st3(out + 13, p + (dT * v));
+}
+
+// K queued IMU samples in one launch, one workgroup (4 wavefronts) per trajectory, samples in groups of PG:
+//   A  one lane integrates the IMU *state* chain of the group (cheap, sequential)           :105, :1425-1467
+//   B  the Phi_k = expm(F_k dT) of the group are built in parallel, one wavefront per sample: F dT is
+//      assembled from its five 3x3 blocks (calcF :885-889), summed as a Taylor series until the terms vanish
+//      (replaces Eigen's Pade, :111 -- equal to working precision), then OC-patched (:116-132)
+//   C  wavefront 0 runs the sequential covariance chain P_II <- sym(Phi (P_II + G Q G^T dT) Phi^T) (:134,143),
+//      wavefront 1 accumulates Phi_total = Phi_K ... Phi_1 alongside
+//   D  P_IC <- Phi_total P_IC for all camera columns, both halves of the symmetric storage    (:144)
+template <class S>
+__global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* readings, long rd_stride, int K) {
+  const int b = b0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  __shared__ S sState[(PG + 1) * SST];
+  __shared__ S sPhi[PG * 225];
+  __shared__ S sScr[4][3 * 225];
+  __shared__ S sTot[2][225];
+  __shared__ S sPii[225];
+  __shared__ S sNull[12];          // q_null v_null p_null used by the next sample
+  __shared__ S sG[4];
   S* imu = d.imu + (long)b * IMU_STRIDE;
   const S* prm = d.prm + (long)b * PRM_STRIDE;
   S* P = d.P + (long)b * d.ld * d.ld;
   const int ld = d.ld;
   const int n = 6 * d.ncam[b];
-  if (lane < IMU_STRIDE) sSt[lane] = imu[lane];
-  for (int e = lane; e < 225; e += 64) {
+  const S* rd = readings + (long)(b - b0) * rd_stride;
+  if (tid < 16) sState[tid] = imu[tid];                 // q b_g v b_a p
+  if (tid < 3) sG[tid] = imu[IG + tid];
+  if (tid >= 32 && tid < 32 + 10) sNull[tid - 32] = imu[IQN + (tid - 32)];
+  for (int e = tid; e < 225; e += 256) {
     const int i = e / 15, j = e % 15;
     sPii[e] = P[(long)j * ld + i];
-    sTot[e] = (i == j) ? S(1) : S(0);
+    sTot[0][e] = (i == j) ? S(1) : S(0);
   }
   __syncthreads();
-  const S* rd = readings + (long)(b - b0) * rd_stride;
-  for (int k = 0; k < K; ++k) {
-    const V3<S> om = ld3(rd + k * RD_STRIDE), ac = ld3(rd + k * RD_STRIDE + 3);
-    const S dT = rd[k * RD_STRIDE + 6];
-    // ---- every lane evaluates the (tiny) state propagation redundantly; lane 0 commits it
-    const Q4<S> q = ldq(sSt + IQ);
-    const V3<S> bg = ld3(sSt + IBG), v = ld3(sSt + IV), ba = ld3(sSt + IBA), p = ld3(sSt + IP), g = ld3(sSt + IG);
-    const Q4<S> qn0 = ldq(sSt + IQN);
-    const V3<S> vn0 = ld3(sSt + IVN), pn0 = ld3(sSt + IPN);
-    const V3<S> wh = om - bg, ah = ac - ba;
-    const M3<S> C = q2rot(q);
-    // RK on the JPL-ordered quaternion (-x,-y,-z,w) with 0.5*Omega(w)   msckf.h:1430-1456
-    S y0[4] = {-q.x, -q.y, -q.z, q.w};
-    auto omul = [&](const S* y, S* o) {  // o = 0.5*omegaMat(wh) * y   (matrix_utils.h:20-30)
-      o[0] = S(0.5) * (wh.z * y[1] - wh.y * y[2] + wh.x * y[3]);
-      o[1] = S(0.5) * (-wh.z * y[0] + wh.x * y[2] + wh.y * y[3]);
-      o[2] = S(0.5) * (wh.y * y[0] - wh.x * y[1] + wh.z * y[3]);
-      o[3] = S(0.5) * (-wh.x * y[0] - wh.y * y[1] - wh.z * y[2]);
-    };
-    S k0[4], k1[4], k2[4], k3[4], k4[4], k5[4], t[4];
-    omul(y0, k0);
-    for (int i = 0; i < 4; ++i) t[i] = y0[i] + (k0[i] / S(4)) * dT;
-    omul(t, k1);
-    for (int i = 0; i < 4; ++i) t[i] = y0[i] + (k0[i] / S(8) + k1[i] / S(8)) * dT;
-    omul(t, k2);
-    for (int i = 0; i < 4; ++i) t[i] = y0[i] + (-k1[i] / S(2) + k2[i]) * dT;
-    omul(t, k3);
-    for (int i = 0; i < 4; ++i) t[i] = y0[i] + (k0[i] * S(3) / S(16) + k3[i] * S(9) / S(16)) * dT;
-    omul(t, k4);
-    for (int i = 0; i < 4; ++i)
-      t[i] = y0[i] + (-k0[i] * S(3) / S(7) + k1[i] * S(2) / S(7) + k2[i] * S(12) / S(7) - k3[i] * S(12) / S(7) + k4[i] * S(8) / S(7)) * dT;
-    omul(t, k5);
-    S yt[4];
-    for (int i = 0; i < 4; ++i) yt[i] = y0[i] + (S(7) * k0[i] + S(32) * k2[i] + S(12) * k3[i] + S(32) * k4[i] + S(7) * k5[i]) * dT / S(90);
-    Q4<S> qn; qn.w = yt[3]; qn.x = -yt[0]; qn.y = -yt[1]; qn.z = -yt[2];
-    qn = qnormalized(qn);
-    const V3<S> vn = v + (dT * (multv(C, ah) + g));
-    const V3<S> pn = p + (dT * v);
-    // ---- F*dT (calcF :885-889) into LDS
-    const M3<S> sw = skew3(wh), sa = skew3(ah);
-    for (int e = lane; e < 225; e += 64) sF[e] = 0;
-    __syncthreads();
-    if (lane < 9) {
-      const int i = lane / 3, j = lane % 3;
-      sF[i * 15 + j] = -sw.m[i][j] * dT;
-      sF[i * 15 + 3 + j] = (i == j) ? -dT : S(0);
-      S s = 0;
-      for (int kk = 0; kk < 3; ++kk) s += C.m[kk][i] * sa.m[kk][j];  // (C^T [a x])_ij
-      sF[(6 + i) * 15 + j] = -s * dT;
-      sF[(6 + i) * 15 + 9 + j] = -C.m[j][i] * dT;
-      sF[(12 + i) * 15 + 6 + j] = (i == j) ? dT : S(0);
-    }
-    __syncthreads();
-    // ---- Phi = expm(F dT): scaling & squaring Taylor (replaces Eigen's Pade, msckf.h:111; equal to
-    //      working precision: ||A/2^s||_1 <= 0.25, truncation < 0.25^(order+1)/(order+1)!)
-    S colsum = 0;
-    if (lane < 15) for (int i = 0; i < 15; ++i) colsum += sF[i * 15 + lane] < 0 ? -sF[i * 15 + lane] : sF[i * 15 + lane];
-    const S l1 = wave_max(colsum);
-    int sq = 0;
-    { S x = l1; while (x > S(0.25) && sq < 30) { x *= S(0.5); ++sq; } }
-    const S scale = S(1) / S(1 << sq);
-    for (int e = lane; e < 225; e += 64) {
-      sF[e] *= scale;
-      sT1[e] = sF[e];                                   // term_1 = A
-      sPhi[e] = sF[e] + ((e / 15 == e % 15) ? S(1) : S(0));
-    }
-    __syncthreads();
-    S* tcur = sT1; S* tnxt = sT2;
-    for (int o = 2; o <= ExpOrder<S>::value; ++o) {
-      mm15(tnxt, tcur, sF, lane);
-      __syncthreads();
-      const S inv = S(1) / S(o);
-      for (int e = lane; e < 225; e += 64) { tnxt[e] *= inv; sPhi[e] += tnxt[e]; }
-      __syncthreads();
-      S* sw2 = tcur; tcur = tnxt; tnxt = sw2;
-    }
-    for (int s2 = 0; s2 < sq; ++s2) {
-      mm15(sT1, sPhi, sPhi, lane);
-      __syncthreads();
-      for (int e = lane; e < 225; e += 64) sPhi[e] = sT1[e];
-      __syncthreads();
-    }
-    // ---- observability-constraint patch of Phi blocks (0,0),(6,0),(12,0)   msckf.h:116-132
-    if (lane == 0) {
-      const M3<S> Rk = q2rot(qn0);
-      const M3<S> R00 = mulmt(q2rot(qn), Rk);
-      const V3<S> u = mulv(Rk, g);
-      const V3<S> sv = (S(1) / dot3(u, u)) * u;
-      M3<S> A1, A2;
-      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { A1.m[i][j] = sPhi[(6 + i) * 15 + j]; A2.m[i][j] = sPhi[(12 + i) * 15 + j]; }
-      const V3<S> w1 = mulv(skew3(vn0 - vn), g);
-      const V3<S> w2 = mulv(skew3((dT * vn0) + pn0 - pn), g);
-      const V3<S> e1 = mulv(A1, u) - w1, e2 = mulv(A2, u) - w2;
-      const S e1v[3] = {e1.x, e1.y, e1.z}, e2v[3] = {e2.x, e2.y, e2.z}, s3[3] = {sv.x, sv.y, sv.z};
-      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
-        sPhi[i * 15 + j] = R00.m[i][j];
-        sPhi[(6 + i) * 15 + j] = A1.m[i][j] - e1v[i] * s3[j];
-        sPhi[(12 + i) * 15 + j] = A2.m[i][j] - e2v[i] * s3[j];
+  int cur = 0;   // which sTot buffer is current
+  for (int k0 = 0; k0 < K; k0 += PG) {
+    const int G = min(PG, K - k0);
+    const V3<S> g = mk3(sG[0], sG[1], sG[2]);
+    // ---- A: state chain
+    if (tid == 0) {
+      for (int s = 0; s < G; ++s) {
+        const S* r = rd + (long)(k0 + s) * RD_STRIDE;
+        imu_rk(sState + s * SST, g, ld3(r), ld3(r + 3), r[6], sState + (s + 1) * SST);
       }
-      // commit the propagated state and re-anchor the null-space states   :138-141
-      stq(sSt + IQ, qn); st3(sSt + IV, vn); st3(sSt + IP, pn);
-      stq(sSt + IQN, qn); st3(sSt + IVN, vn); st3(sSt + IPN, pn);
     }
-    // ---- P_II + G Q G^T dT : diag(Qw, Qbg, C^T Qa C, Qba, 0)   (calcG :899-902, Q diagonal)
-    if (lane < 9) {
-      const int i = lane / 3, j = lane % 3;
-      if (i == j) {
-        sPii[i * 15 + i] += prm[PRM_Q + i] * dT;
-        sPii[(3 + i) * 15 + 3 + i] += prm[PRM_Q + 3 + i] * dT;
-        sPii[(9 + i) * 15 + 9 + i] += prm[PRM_Q + 9 + i] * dT;
+    __syncthreads();
+    // ---- B: Phi of every sample of the group, one wavefront per sample
+    for (int s = w; s < G; s += 4) {
+      S* A = sScr[w]; S* T1 = A + 225; S* T2 = A + 450;
+      S* Phi = sPhi + s * 225;
+      const S* st = sState + s * SST;
+      const S* r = rd + (long)(k0 + s) * RD_STRIDE;
+      const S dT = r[6];
+      const V3<S> wh = ld3(r) - ld3(st + 4), ah = ld3(r + 3) - ld3(st + 10);
+      const M3<S> C = q2rot(ldq(st));
+      const M3<S> sw = skew3(wh), sa = skew3(ah);
+      for (int e = lane; e < 225; e += 64) A[e] = 0;
+      wave_sync();
+      if (lane < 9) {
+        const int i = lane / 3, j = lane % 3;
+        A[i * 15 + j] = -sw.m[i][j] * dT;
+        A[i * 15 + 3 + j] = (i == j) ? -dT : S(0);
+        S sm = 0;
+        for (int kk = 0; kk < 3; ++kk) sm += C.m[kk][i] * sa.m[kk][j];  // (C^T [a x])_ij
+        A[(6 + i) * 15 + j] = -sm * dT;
+        A[(6 + i) * 15 + 9 + j] = -C.m[j][i] * dT;
+        A[(12 + i) * 15 + 6 + j] = (i == j) ? dT : S(0);
       }
-      S s = 0;
-      for (int kk = 0; kk < 3; ++kk) s += C.m[kk][i] * prm[PRM_Q + 6 + kk] * C.m[kk][j];
-      sPii[(6 + i) * 15 + 6 + j] += s * dT;
+      wave_sync();
+      for (int e = lane; e < 225; e += 64) { T1[e] = A[e]; Phi[e] = A[e] + ((e / 15 == e % 15) ? S(1) : S(0)); }
+      wave_sync();
+      S* tc = T1; S* tn = T2;
+      for (int o = 2; o <= 40; ++o) {
+        const S inv = S(1) / S(o);
+        S mx = 0;
+        for (int e = lane; e < 225; e += 64) {
+          const int i = e / 15, j = e % 15;
+          S sm = 0;
+#pragma unroll
+          for (int kk = 0; kk < 15; ++kk) sm += tc[i * 15 + kk] * A[kk * 15 + j];
+          sm *= inv;
+          tn[e] = sm; Phi[e] += sm;
+          const S am = sm < 0 ? -sm : sm;
+          mx = am > mx ? am : mx;
+        }
+        mx = wave_max(mx);
+        wave_sync();
+        S* t2 = tc; tc = tn; tn = t2;
+        if (mx < (sizeof(S) == 4 ? S(1e-11) : S(1e-21))) break;     // remaining terms are far below eps
+      }
+      // observability-constraint patch of Phi blocks (0,0),(6,0),(12,0)   msckf.h:116-132
+      if (lane == 0) {
+        const S* nx = sState + (s + 1) * SST;
+        const Q4<S> qn = ldq(nx);
+        const V3<S> vn = ld3(nx + 7), pn = ld3(nx + 13);
+        Q4<S> qn0; V3<S> vn0, pn0;
+        if (k0 + s == 0) { qn0 = ldq(sNull); vn0 = ld3(sNull + 4); pn0 = ld3(sNull + 7); }
+        else { qn0 = ldq(st); vn0 = ld3(st + 7); pn0 = ld3(st + 13); }   // re-anchored after every propagate :139-141
+        const M3<S> Rk = q2rot(qn0);
+        const M3<S> R00 = mulmt(q2rot(qn), Rk);
+        const V3<S> u = mulv(Rk, g);
+        const V3<S> sv = (S(1) / dot3(u, u)) * u;
+        M3<S> A1, A2;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { A1.m[i][j] = Phi[(6 + i) * 15 + j]; A2.m[i][j] = Phi[(12 + i) * 15 + j]; }
+        const V3<S> w1 = mulv(skew3(vn0 - vn), g);
+        const V3<S> w2 = mulv(skew3((dT * vn0) + pn0 - pn), g);
+        const V3<S> e1 = mulv(A1, u) - w1, e2 = mulv(A2, u) - w2;
+        const S e1v[3] = {e1.x, e1.y, e1.z}, e2v[3] = {e2.x, e2.y, e2.z}, s3[3] = {sv.x, sv.y, sv.z};
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+          Phi[i * 15 + j] = R00.m[i][j];
+          Phi[(6 + i) * 15 + j] = A1.m[i][j] - e1v[i] * s3[j];
+          Phi[(12 + i) * 15 + j] = A2.m[i][j] - e2v[i] * s3[j];
+        }
+      }
+      wave_sync();
     }
     __syncthreads();
-    mm15(sT1, sPhi, sPii, lane);       // Phi * inner
-    __syncthreads();
-    mm15_abt(sT2, sT1, sPhi, lane);    // (Phi*inner) * Phi^T    :134
-    __syncthreads();
-    for (int e = lane; e < 225; e += 64) {  // symmetrise :143
-      const int i = e / 15, j = e % 15;
-      sPii[e] = (sT2[i * 15 + j] + sT2[j * 15 + i]) / S(2);
+    // ---- C: sequential chains over the group (wave 0: P_II, wave 1: Phi_total)
+    if (w == 0) {
+      S* T1 = sScr[0]; S* T2 = sScr[0] + 225;
+      for (int s = 0; s < G; ++s) {
+        const S* st = sState + s * SST;
+        const S dT = rd[(long)(k0 + s) * RD_STRIDE + 6];
+        const M3<S> C = q2rot(ldq(st));
+        S* Pi = sPii;
+        if (lane < 9) {   // + G Q G^T dT = diag(Qw, Qbg, C^T Qa C, Qba, 0) dT   (calcG :899-902, Q diagonal)
+          const int i = lane / 3, j = lane % 3;
+          if (i == j) {
+            Pi[i * 15 + i] += prm[PRM_Q + i] * dT;
+            Pi[(3 + i) * 15 + 3 + i] += prm[PRM_Q + 3 + i] * dT;
+            Pi[(9 + i) * 15 + 9 + i] += prm[PRM_Q + 9 + i] * dT;
+          }
+          S sm = 0;
+          for (int kk = 0; kk < 3; ++kk) sm += C.m[kk][i] * prm[PRM_Q + 6 + kk] * C.m[kk][j];
+          Pi[(6 + i) * 15 + 6 + j] += sm * dT;
+        }
+        wave_sync();
+        mm15(T1, sPhi + s * 225, Pi, lane);
+        wave_sync();
+        mm15_abt(T2, T1, sPhi + s * 225, lane);
+        wave_sync();
+        for (int e = lane; e < 225; e += 64) { const int i = e / 15, j = e % 15; Pi[e] = (T2[i * 15 + j] + T2[j * 15 + i]) / S(2); }
+        wave_sync();
+      }
+    } else if (w == 1) {
+      int c2 = cur;
+      for (int s = 0; s < G; ++s) {
+        mm15(sTot[c2 ^ 1], sPhi + s * 225, sTot[c2], lane);
+        wave_sync();
+        c2 ^= 1;
+      }
     }
-    mm15(sT1, sPhi, sTot, lane);       // Phi_total <- Phi_k * Phi_total
+    if (G & 1) cur ^= 1;      // wave 1 flipped the Phi_total buffer G times
     __syncthreads();
-    for (int e = lane; e < 225; e += 64) sTot[e] = sT1[e];
+    if (tid < 16) sState[tid] = sState[G * SST + tid];   // carry the last state of the group to slot 0
     __syncthreads();
   }
-  // ---- write back state, P_II, and P_IC <- Phi_total P_IC (both halves of the symmetric storage) :144
-  if (lane < IMU_STRIDE) imu[lane] = sSt[lane];
-  for (int e = lane; e < 225; e += 64) { const int i = e / 15, j = e % 15; P[(long)j * ld + i] = sPii[e]; }
-  for (int c = lane; c < n; c += 64) {
-    S col[15], out[15];
+  // ---- write back: state, nulls (re-anchored to the final state), P_II, P_IC
+  if (tid < 16) imu[tid] = sState[tid];
+  if (tid < 4) imu[IQN + tid] = sState[tid];
+  if (tid >= 4 && tid < 7) imu[IVN + tid - 4] = sState[7 + tid - 4];
+  if (tid >= 8 && tid < 11) imu[IPN + tid - 8] = sState[13 + tid - 8];
+  for (int e = tid; e < 225; e += 256) { const int i = e / 15, j = e % 15; P[(long)j * ld + i] = sPii[e]; }
+  const S* Tot = sTot[cur];
+  for (int c = tid; c < n; c += 256) {
+    S col[15];
     S* pc = P + (long)(15 + c) * ld;
 #pragma unroll
     for (int i = 0; i < 15; ++i) col[i] = pc[i];
 #pragma unroll
     for (int i = 0; i < 15; ++i) {
-      S s = 0;
+      S sm = 0;
 #pragma unroll
-      for (int kk = 0; kk < 15; ++kk) s += sTot[i * 15 + kk] * col[kk];
-      out[i] = s;
+      for (int kk = 0; kk < 15; ++kk) sm += Tot[i * 15 + kk] * col[kk];
+      pc[i] = sm; P[(long)i * ld + 15 + c] = sm;
     }
-#pragma unroll
-    for (int i = 0; i < 15; ++i) { pc[i] = out[i]; P[(long)i * ld + 15 + c] = out[i]; }
   }
 }
 
@@ -298,7 +350,7 @@ __global__ __launch_bounds__(64) void k_prune_cams(Dev<S> d, int b0) {
 template <class S>
 void launch_propagate(const Dev<S>& d, int b0, int nb, const S* readings, long rd_stride, int K, hipStream_t st) {
   if (nb <= 0 || K <= 0) return;
-  hipLaunchKernelGGL(k_propagate<S>, dim3(nb), dim3(64), 0, st, d, b0, readings, rd_stride, K);
+  hipLaunchKernelGGL(k_propagate<S>, dim3(nb), dim3(256), 0, st, d, b0, readings, rd_stride, K);
 }
 template <class S>
 void launch_augment(const Dev<S>& d, int b0, int nb, hipStream_t st) {
