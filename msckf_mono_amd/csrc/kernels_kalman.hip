@@ -9,8 +9,8 @@
 //   K   = (PHt Linv^T) Linv                 (D x n)     :1370
 //   dx  = K r_n, injected into the IMU and every camera state   :1373-1391
 //   A   = I - K T_H ;  P <- sym(A P A^T + sigma^2 K K^T)         :1394-1403
-// Every product is a batched tile GEMM (64x64 tile, 4x4 micro-tile per thread, LDS-staged); trajectories
-// with no gated-in rows are skipped.
+// Every product is a batched 64x64-tile GEMM, LDS-staged: on the matrix cores (v_mfma_f32_32x32x2_f32) in
+// float, 4x4 VALU micro-tiles in double; trajectories with no gated-in rows are skipped.
 #include "dev_common.h"
 
 namespace msckf {
@@ -122,6 +122,56 @@ __global__ __launch_bounds__(256) void k_gemm(Dev<S> d, int b0) {
       const int gi = i0 + 4 * ty + r, gj = j0 + 4 * tx + c;
       if (gi < M && gj < N) op_store<S, OP>(v, gi, gj, acc[r][c]);
     }
+}
+
+// f32 tile GEMM on the matrix cores: v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate -- bit-identical to an fmaf
+// chain, MI355X_MICROARCH.md).  64 x 64 output tile per workgroup, one 32 x 32 accumulator per wavefront.  The
+// product is formed transposed (MFMA "A" operand = B-tile, "B" operand = A-tile) so that the accumulator's
+// lane index runs along the output ROW index i: stores to the column-major work matrices are coalesced.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0) {
+  using S = float;
+  const int b = b0 + blockIdx.z;
+  if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
+  const KView<S> v = make_view(d, b);
+  int M, N, K;
+  op_dims<S, OP>(v, M, N, K);
+  const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+  if (i0 >= M || j0 >= N) return;
+  __shared__ S sA[16][65];
+  __shared__ S sB[16][65];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w & 1, wn = w >> 1;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ii = tid & 63, kk = (tid >> 6) + 4 * q;
+      const int gi = i0 + ii, gk = k0 + kk;
+      sA[kk][ii] = (gi < M && gk < K) ? op_a<S, OP>(v, gi, gk) : S(0);
+      const int kb = tid & 15, jj = (tid >> 4) + 16 * q;
+      const int gj = j0 + jj, gk2 = k0 + kb;
+      sB[kb][jj] = (gj < N && gk2 < K) ? op_b<S, OP>(v, gk2, gj) : S(0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; kk += 2) {
+      const S bj = sB[kk + (lane >> 5)][32 * wn + (lane & 31)];   // MFMA A operand: rows of the result = j
+      const S ai = sA[kk + (lane >> 5)][32 * wm + (lane & 31)];   // MFMA B operand: cols of the result = i
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bj, ai, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int gi = i0 + 32 * wm + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int gj = j0 + 32 * wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (gi < M && gj < N) op_store<S, OP>(v, gi, gj, acc[r]);
+  }
 }
 
 // Cholesky S = L L^T and in-place triangular inverse, one workgroup per trajectory.  The matrix is staged
@@ -340,9 +390,17 @@ __global__ __launch_bounds__(256) void k_symmetrize(Dev<S> d, int b0) {
   }
 }
 
+template <int OP>
+static void gemm_launch(const Dev<float>& d, int b0, int nb, int Mmax, int Nmax, hipStream_t st) {
+  hipLaunchKernelGGL((k_gemm_mfma<OP>), dim3((Mmax + 63) / 64, (Nmax + 63) / 64, nb), dim3(256), 0, st, d, b0);
+}
+template <int OP>
+static void gemm_launch(const Dev<double>& d, int b0, int nb, int Mmax, int Nmax, hipStream_t st) {
+  hipLaunchKernelGGL((k_gemm<double, OP>), dim3((Mmax + 63) / 64, (Nmax + 63) / 64, nb), dim3(256), 0, st, d, b0);
+}
 template <class S, int OP>
 static void gemm(const Dev<S>& d, int b0, int nb, int Mmax, int Nmax, hipStream_t st) {
-  hipLaunchKernelGGL((k_gemm<S, OP>), dim3((Mmax + 63) / 64, (Nmax + 63) / 64, nb), dim3(256), 0, st, d, b0);
+  gemm_launch<OP>(d, b0, nb, Mmax, Nmax, st);
 }
 
 template <class S>

@@ -15,8 +15,8 @@
 //   LDS exchange + one barrier combines them (the norm of column k comes out of the same exchange as
 //   its self-product), then R's row k and the block are updated.  R's row k is only touched in step k, so
 //   it is streamed from/to L2 with coalesced row accesses.
-// TSQR: stage 1 = nchunk independent row chunks per trajectory, stage 2 = binary-tree merge of the chunk
-// triangles (same kernel, rows sourced from another chunk's R).  With isotropic pixel noise
+// TSQR: stage 1 = nchunk independent row chunks per trajectory, stage 2 = one merge of all chunk triangles
+// into chunk 0 (same kernel, rows sourced from the other chunks' R, interleaved by row index).  With isotropic pixel noise
 // (u_var' == v_var', the configuration BASELINE.json is quoted on) the Kalman update depends on the
 // stack only through H_o^T H_o and H_o^T r_o, so any orthogonal compression gives the reference's result;
 // R_n = sigma^2 I exactly.
@@ -76,11 +76,13 @@ __global__ __launch_bounds__(64 * QR_NW) void k_qr_update(Dev<S> d, int b0, int 
     if (RLDS) { for (int e = tid; e < (n + 1) * (n + 2) / 2; e += 64 * QR_NW) sR[e] = 0; }
     else { for (int e = tid; e < n * ldR; e += 64 * QR_NW) Rt[e] = 0; }   // fresh triangle
   } else {
-    const int tgt = (2 * blockIdx.x) << level, src = tgt + (1 << level);
-    if (src >= d.nchunk) return;
-    Rt = d.Rbuf + ((long)b * d.nchunk + tgt) * (long)d.n6cap * ldR;
-    Rs = d.Rbuf + ((long)b * d.nchunk + src) * (long)d.n6cap * ldR;
-    row_begin = 0; row_end = n;
+    // stage 2: ONE workgroup per trajectory folds the triangles of chunks 1..C-1 into chunk 0.  The source
+    // rows are interleaved by row index (row i of every source before row i+1 of any), so the blocks'
+    // leading-zero counts ascend and the pipeline never waits on a later block.
+    if (d.nchunk < 2) return;
+    Rt = d.Rbuf + ((long)b * d.nchunk) * (long)d.n6cap * ldR;
+    Rs = Rt;   // source c lives at Rs + c * n6cap * ldR
+    row_begin = 0; row_end = n * (d.nchunk - 1);
     if (RLDS) {
       for (int e = tid; e < n * (n + 1); e += 64 * QR_NW) {
         const int k = e / (n + 1), col = e - k * (n + 1);
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(64 * QR_NW) void k_qr_update(Dev<S> d, int b0, int 
       }
       kmin = wave_min_i(kmin);
     } else {
-      kmin = blk0 < n ? blk0 : n;
+      kmin = min(blk0 / (d.nchunk - 1), n);
     }
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
@@ -156,7 +158,8 @@ __global__ __launch_bounds__(64 * QR_NW) void k_qr_update(Dev<S> d, int b0, int 
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
           const int col = lane + 64 * j;
-          Bv[r][j] = (gr < row_end && col <= n) ? Rs[(long)gr * ldR + col] : S(0);
+          const int si = gr / (d.nchunk - 1), sc = 1 + gr % (d.nchunk - 1);
+          Bv[r][j] = (gr < row_end && col <= n) ? Rs[((long)sc * d.n6cap + si) * ldR + col] : S(0);
         }
       }
     }
@@ -249,10 +252,7 @@ static void launch_compress_impl(const Dev<S>& d, int b0, int nb, hipStream_t st
   if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
   if (phase != 2) hipLaunchKernelGGL(kern, dim3(d.nchunk, nb), dim3(64 * QR_NW), lds, st, d, b0, 1, 0);
   if (phase == 1) return;
-  for (int level = 0; (1 << level) < d.nchunk; ++level) {
-    const int pairs = (d.nchunk + (2 << level) - 1) / (2 << level);
-    hipLaunchKernelGGL(kern, dim3(pairs, nb), dim3(64 * QR_NW), lds, st, d, b0, 2, level);
-  }
+  if (d.nchunk > 1) hipLaunchKernelGGL(kern, dim3(1, nb), dim3(64 * QR_NW), lds, st, d, b0, 2, 0);
 }
 template <class S, int NC>
 static void launch_compress_nc(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase) {
