@@ -115,54 +115,70 @@ __global__ __launch_bounds__(64 * QR_NW) void k_qr_update(Dev<S> d, int b0, int 
 #pragma unroll
         for (int j = 0; j < NC; ++j) Bv[r][j] = S(0.001) * S((lane * 7 + r * 13 + j * 5 + q) % 17 - 8);
       kmin = 0;
-    } else {
-    if (stage == 1) {
-      const int gr = blk0 + lane;
-      if (lane < RW && gr < row_end) {
-        int lo = 0, hi = P;   // invariant rs[lo] <= gr < rs[hi]
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rs[mid] <= gr) lo = mid; else hi = mid; }
+    } else if (stage == 1) {
+      // lane r resolves stacked row blk0+r to (track, row-in-track) with one parallel binary search and
+      // fetches that row's scalars (V row, r_o, first column of its own observation); the per-row values
+      // are then handed out with v_readlane, so the coalesced Z / H_x loads of all rows issue back to back
+      S my_v0 = 0, my_v1 = 0, my_v2 = 0, my_ro = 0;
+      int my_c0 = 0;
+      const int grl = blk0 + lane;
+      if (lane < RW && grl < row_end) {
+        int lo = 0, hi = P;   // invariant rs[lo] <= grl < rs[hi]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rs[mid] <= grl) lo = mid; else hi = mid; }
         my_t = order[lo];
-        my_row = 3 + (gr - rs[lo]);               // row of Q^T [H_x | r]
-        kmin = 6 * d.trk_first[(long)b * f_cap + my_t];
+        my_row = 3 + (grl - rs[lo]);              // row of Q^T [H_x | r]
+        const long tb = (long)b * f_cap + my_t;
+        kmin = 6 * d.trk_first[tb];
+        const S* Vr = d.trk_V + (tb * 2 * m_cap + my_row) * 4;
+        my_v0 = Vr[0]; my_v1 = Vr[1]; my_v2 = Vr[2];
+        my_ro = d.trk_ro[tb * 2 * m_cap + my_row];
+        my_c0 = 6 * d.trk_slots[(long)(b - b0) * d.wl_stride_o + (long)my_t * m_cap + (my_row >> 1)];
       }
       kmin = wave_min_i(kmin);
-    } else {
-      kmin = min(blk0 / (d.nchunk - 1), n);
-    }
+      S zf[3][NC];                                   // Z of the current track at this lane's columns
+      int t_prev = -2;
 #pragma unroll
-    for (int r = 0; r < RW; ++r) {
-      const int gr = blk0 + r;
-      if (stage == 1) {
+      for (int r = 0; r < RW; ++r) {
         const int t_raw = wave_bcast(my_t, r);
-        const bool live = t_raw >= 0;               // false past the end of the chunk (last block only)
-        const int t = live ? t_raw : 0;             // branch-free: every load below stays in bounds
+        const bool live = t_raw >= 0;               // false past the end of the stack (last block only)
+        const int t = live ? t_raw : 0;             // every load below stays in bounds
         const int row = wave_bcast(my_row, r);
+        const S v0 = wave_bcast(my_v0, r), v1 = wave_bcast(my_v1, r), v2 = wave_bcast(my_v2, r);
+        const S ro = wave_bcast(my_ro, r);
+        const int c0 = wave_bcast(my_c0, r);
         const long tb = (long)b * f_cap + t;
-        const int cobs = row >> 1, sub = row & 1;
-        const S* Vr = d.trk_V + (tb * 2 * m_cap + row) * 4;
-        const S v0 = Vr[0], v1 = Vr[1], v2 = Vr[2];
-        const S* Zf = d.trk_Zf + tb * 3 * (long)ldR;                        // [3][ldR], coalesced over columns
-        const int c0 = 6 * d.trk_slots[(long)(b - b0) * d.wl_stride_o + (long)t * m_cap + cobs];
-        const S* Hx = d.trk_Hx + (tb * m_cap + cobs) * 12 + sub * 6;
-        const S ro = d.trk_ro[tb * 2 * m_cap + row];
+        if (t != t_prev) {                          // wave-uniform: consecutive rows mostly share their track
+          const S* Zf = d.trk_Zf + tb * 3 * (long)ldR;                      // [3][ldR], coalesced over columns
+#pragma unroll
+          for (int j = 0; j < NC; ++j) {
+            const int col = lane + 64 * j;
+            zf[0][j] = Zf[col]; zf[1][j] = Zf[ldR + col]; zf[2][j] = Zf[2 * ldR + col];
+          }
+          t_prev = t;
+        }
+        const S* Hx = d.trk_Hx + (tb * m_cap + (row >> 1)) * 12 + (row & 1) * 6;
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
           const int col = lane + 64 * j;
-          S val = -(v0 * Zf[col] + v1 * Zf[ldR + col] + v2 * Zf[2 * ldR + col]);
+          S val = -(v0 * zf[0][j] + v1 * zf[1][j] + v2 * zf[2][j]);
           const unsigned dcol = (unsigned)(col - c0);
           if (dcol < 6u) val += Hx[dcol];
           if (col == n) val = ro;
           Bv[r][j] = live ? val : S(0);
         }
-      } else {
+      }
+    } else {
+      kmin = min(blk0 / (d.nchunk - 1), n);
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        const int gr = blk0 + r;
+        const int si = gr / (d.nchunk - 1), sc = 1 + gr % (d.nchunk - 1);
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
           const int col = lane + 64 * j;
-          const int si = gr / (d.nchunk - 1), sc = 1 + gr % (d.nchunk - 1);
           Bv[r][j] = (gr < row_end && col <= n) ? Rs[((long)sc * d.n6cap + si) * ldR + col] : S(0);
         }
       }
-    }
     }
     if (dbg & 1) kmin = n;   // ablation: skip the elimination steps
     if (dbg & 4) kmin = 0;   // ablation: no leading-zero skipping
