@@ -28,7 +28,10 @@ enum {  // offsets into prm[]
   PRM_CU = 0, PRM_CV = 1, PRM_FU = 2, PRM_FV = 3, PRM_B = 4, PRM_QCI = 5, PRM_PCI = 9,
   PRM_UVAR = 12, PRM_VVAR = 13, PRM_Q = 14,  // 12 diagonal entries of Q_imu
   PRM_GN = 26, PRM_RCOND = 27, PRM_TRANS = 28, PRM_RANG = 29, PRM_RDIST = 30,
-  PRM_MINTL = 31, PRM_MAXTL = 32, PRM_MAXCS = 33
+  PRM_MINTL = 31, PRM_MAXTL = 32, PRM_MAXCS = 33,
+  // derived at initialize: row weights and the noise variance the kernels run with.  Isotropic noise: (1, 1, u_var');
+  // anisotropic noise: rows are pre-whitened by (1/sigma_u, 1/sigma_v) and the filter runs with unit variance.
+  PRM_WU = 34, PRM_WV = 35, PRM_SIG2 = 36
 };
 enum {  // per-track status bits written by k_feature / k_select
   ST_MOTION_OK = 1, ST_TRI_VALID = 2, ST_GATE_PASS = 4, ST_INCLUDED = 8, ST_MOTION_SKIPPED = 16

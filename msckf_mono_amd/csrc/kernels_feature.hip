@@ -214,6 +214,11 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
       }
     }
     if (!act) { r[0] = 0; r[1] = 0; }
+    // row weights: (1,1) for isotropic noise, (1/sigma_u, 1/sigma_v) pre-whitening for anisotropic noise
+    const S wu = prm[PRM_WU], wv = prm[PRM_WV];
+    r[0] *= wu; r[1] *= wv;
+    for (int k = 0; k < 6; ++k) { hx[0][k] *= wu; hx[1][k] *= wv; }
+    for (int k = 0; k < 3; ++k) { hf[0][k] *= wu; hf[1][k] *= wv; }
   }
 
   // ---- Householder QR of H_f_j (2M x 3): rows 2*lane, 2*lane+1 live in this lane
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
   }
   __syncthreads();
   // ---- S = (Q^T G Q)[3:,3:] + sigma^2 I, Cholesky with the r_o row appended, gamma = |L^-1 r_o|^2
-  const S sig2 = prm[PRM_UVAR];
+  const S sig2 = prm[PRM_SIG2];
   bool spd = true;
   S gamma = 0;
   (void)0;

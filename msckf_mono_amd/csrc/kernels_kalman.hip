@@ -28,7 +28,7 @@ template <class S>
 __device__ __forceinline__ KView<S> make_view(const Dev<S>& d, int b) {
   KView<S> v;
   v.n = 6 * d.ncam[b]; v.D = 15 + v.n; v.ld = d.ld; v.ldn = d.n6cap; v.ldR = d.ldR;
-  v.sig2 = d.prm[(long)b * PRM_STRIDE + PRM_UVAR];
+  v.sig2 = d.prm[(long)b * PRM_STRIDE + PRM_SIG2];
   const long pl = (long)d.ld * d.ld, nl = (long)d.n6cap * d.n6cap, dn = (long)d.ld * d.n6cap;
   v.P = d.P + b * pl;
   v.R0 = d.Rbuf + ((long)b * d.nchunk) * (long)d.n6cap * d.ldR;

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -177,13 +178,15 @@ struct Batch : BatchBase {
 
   int init(int b, const double* cam, const double* noise, const double* params, const double* imu) override {
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
-    if (noise[0] != noise[1]) return fail(-ENOTSUP, "anisotropic pixel noise (u_var_prime != v_var_prime) is not supported by this build");
+    if (!(noise[0] > 0) || !(noise[1] > 0)) return fail(-EINVAL, "u_var_prime / v_var_prime must be positive");
     HIPCHK(hipSetDevice(device));
     S prm[PRM_STRIDE] = {0}, st_imu[IMU_STRIDE] = {0};
     for (int i = 0; i < 12; ++i) prm[i] = (S)cam[i];
     prm[PRM_UVAR] = (S)noise[0]; prm[PRM_VVAR] = (S)noise[1];
     for (int i = 0; i < 12; ++i) prm[PRM_Q + i] = (S)noise[2 + i];
     for (int i = 0; i < 8; ++i) prm[PRM_GN + i] = (S)params[i];
+    if (noise[0] == noise[1]) { prm[PRM_WU] = 1; prm[PRM_WV] = 1; prm[PRM_SIG2] = (S)noise[0]; }
+    else { prm[PRM_WU] = (S)(1.0 / std::sqrt(noise[0])); prm[PRM_WV] = (S)(1.0 / std::sqrt(noise[1])); prm[PRM_SIG2] = 1; }
     for (int i = 0; i < 29; ++i) st_imu[i] = (S)imu[i];
     for (int i = 0; i < 4; ++i) st_imu[IQN + i] = st_imu[IQ + i];        // msckf.h:83-85
     for (int i = 0; i < 3; ++i) { st_imu[IVN + i] = st_imu[IV + i]; st_imu[IPN + i] = st_imu[IP + i]; }

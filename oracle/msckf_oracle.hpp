@@ -88,6 +88,10 @@ template <class S>
 class MSCKF {
  public:
   Mode mode = LEAN;
+  // Anisotropic pixel noise (u_var' != v_var'): when set, every observation row is pre-whitened by 1/sigma_u resp.
+  // 1/sigma_v and the filter then runs with unit isotropic noise -- the construction the HIP path uses (DESIGN.md
+  // section 3).  When clear the reference's A_j^T R_j A_j / Q_1^T R_o Q_1 construction is restated literally.
+  bool whiten = false;
   UpdateStats last_stats;
   std::vector<TrackDebug> last_tracks;
   Mat<S> last_deltaX;
@@ -292,6 +296,7 @@ class MSCKF {
       FeatureTrackToResidualize<S>& track = feature_tracks_to_residualize_[iter];
       const V3<S> p_f_G = track.p_f_G;            // D1
       Mat<S> r_j = calcResidual(p_f_G, track.cam_states, track.observations);
+      whitenRows(r_j);
       const int nObs = (int)track.observations.size();
       Mat<S> H_o_j, A_j;
       calcMeasJacobian(p_f_G, track.cam_state_indices, H_o_j, A_j);
@@ -365,6 +370,7 @@ class MSCKF {
         pos++;
       }
       Mat<S> r_j = calcResidual(feature.p_f_G, involved_cs, involved_obs);
+      whitenRows(r_j);
       Mat<S> H_x_j, A_j;
       calcMeasJacobian(feature.p_f_G, pos_idx, H_x_j, A_j);
       Mat<S> r_x_j = mul_atb(A_j, r_j);
@@ -478,6 +484,12 @@ class MSCKF {
   Mat<S> imu_covar_{15, 15}, cam_covar_, imu_cam_covar_{15, 0};
   std::vector<S> chi_squared_test_table;
   Mat<S> F_{15, 15}, Phi_{15, 15}, G_{15, 12};
+
+  bool whitening() const { return whiten && noise_params_.u_var_prime != noise_params_.v_var_prime; }
+  S uvar() const { return whitening() ? S(1) : noise_params_.u_var_prime; }
+  S vvar() const { return whitening() ? S(1) : noise_params_.v_var_prime; }
+  S roww(int i) const { return whitening() ? S(1) / std::sqrt((i % 2 == 0) ? noise_params_.u_var_prime : noise_params_.v_var_prime) : S(1); }
+  void whitenRows(Mat<S>& r) const { if (whitening()) for (int i = 0; i < r.r; ++i) for (int j = 0; j < r.c; ++j) r(i, j) *= roww(i); }
 
   static void set3(Mat<S>& M, int i0, int j0, const M3<S>& b) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) M(i0 + i, j0 + j) = b.m[i][j]; }
   static M3<S> get3(const Mat<S>& M, int i0, int j0) { M3<S> b; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) b.m[i][j] = M(i0 + i, j0 + j); return b; }
@@ -739,6 +751,7 @@ class MSCKF {
         }
       }
     }
+    whitenRows(H_f); whitenRows(H_x);
     const int rows = 2 * M;
     Mat<S> QR = H_f; std::vector<S> tau;
     householder_qr_inplace(QR, tau);
@@ -755,7 +768,7 @@ class MSCKF {
   // R_o_j = A_j^T diag(u',v',u',v',...) A_j   (:423,:431)
   Mat<S> projectedNoise(const Mat<S>& A_j, int nObs) const {
     Mat<S> RA = A_j;
-    for (int j = 0; j < RA.c; ++j) for (int i = 0; i < 2 * nObs; ++i) RA(i, j) *= (i % 2 == 0) ? noise_params_.u_var_prime : noise_params_.v_var_prime;
+    for (int j = 0; j < RA.c; ++j) for (int i = 0; i < 2 * nObs; ++i) RA(i, j) *= (i % 2 == 0) ? uvar() : vvar();
     return mul_atb(A_j, RA);
   }
   // ---- :1103-1124
@@ -767,7 +780,7 @@ class MSCKF {
       Mat<S> Hc = H.block(0, 15, H.r, n);
       P1 = mul_abt(mul(Hc, cam_covar_), Hc);
     }
-    for (int i = 0; i < P1.r; ++i) P1(i, i) += noise_params_.u_var_prime;
+    for (int i = 0; i < P1.r; ++i) P1(i, i) += uvar();
     std::vector<S> rv(r.r); for (int i = 0; i < r.r; ++i) rv[i] = r(i, 0);
     std::vector<S> x = ldlt_solve(P1, rv);
     S gamma = 0; for (int i = 0; i < r.r; ++i) gamma += rv[i] * x[i];
@@ -819,7 +832,7 @@ class MSCKF {
     last_stats.r_rows = nr;
     Mat<S> T_H(nr, D), r_n(nr, 1), R_n(nr, nr);
     for (int k = 0; k < nr; ++k) for (int c = kept[k]; c < D; ++c) T_H(k, c) = QR(kept[k], c);
-    const bool iso = (noise_params_.u_var_prime == noise_params_.v_var_prime);
+    const bool iso = (uvar() == vvar());
     if (mode == FAITHFUL) {
       Mat<S> Q = form_q_cols(QR, tau, 0, m);      // full m x m Q :1344
       Mat<S> Q1(m, nr);
@@ -829,7 +842,7 @@ class MSCKF {
     } else {
       Mat<S> qtr = r_o; apply_qt(QR, tau, qtr);
       for (int k = 0; k < nr; ++k) r_n(k, 0) = qtr(kept[k], 0);
-      if (iso) { for (int k = 0; k < nr; ++k) R_n(k, k) = noise_params_.u_var_prime; }
+      if (iso) { for (int k = 0; k < nr; ++k) R_n(k, k) = uvar(); }
       else {
         Mat<S> Qs = form_q_cols(QR, tau, 0, steps);
         Mat<S> Q1(m, nr);

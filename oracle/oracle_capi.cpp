@@ -43,6 +43,7 @@ struct Base {
   virtual void set_num_residualized(long n) = 0;
   virtual void set_mode(int m) = 0;
   virtual Base* clone() = 0;
+  virtual void set_whiten(int w) = 0;
 };
 
 template <class S>
@@ -137,6 +138,7 @@ struct Impl : Base {
   void set_num_residualized(long n) override { f.setNumResidualized((size_t)n); }
   void set_mode(int m) override { f.mode = (Mode)m; }
   Base* clone() override { return new Impl<S>(*this); }
+  void set_whiten(int w) override { f.whiten = w != 0; }
 };
 }  // namespace
 
@@ -171,6 +173,7 @@ long oracle_num_residualized(void* h) { return ((Base*)h)->num_residualized(); }
 void oracle_set_num_residualized(void* h, long n) { ((Base*)h)->set_num_residualized(n); }
 void oracle_set_mode(void* h, int mode) { ((Base*)h)->set_mode(mode); }
 void* oracle_clone(void* h) { return ((Base*)h)->clone(); }
+void oracle_set_whiten(void* h, int w) { ((Base*)h)->set_whiten(w); }
 
 // Timed CPU baseline: run `n_filters` independent filters over the same pre-built per-frame call
 // sequence on `n_threads` std::threads (one filter per thread at a time, as the reference is

@@ -177,6 +177,9 @@ class Oracle:
         c.h = C.c_void_p(self.L.oracle_clone(self.h))
         return c
 
+    def setWhiten(self, on=True):
+        self.L.oracle_set_whiten(self.h, 1 if on else 0)
+
     def setMode(self, mode):
         self.L.oracle_set_mode(self.h, int(mode))
 

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Per-kernel PMC summary from rocprofv3 rocpd databases (one --pmc pass per database).
+Usage: rocpd_pmc.py out.md db1 [db2 ...]
+FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; on gfx950 FETCH_SIZE under-reports wide coalesced
+reads by 2x (MI355X_MICROARCH.md, HBM section) -- both the raw and the x2-corrected numbers are printed."""
+import re
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def main():
+    out = sys.argv[1]
+    rows = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> per-dispatch values (steady-state = upper half)
+    for dbp in sys.argv[2:]:
+        db = sqlite3.connect(dbp)
+        for name, disp, cname, val in db.execute("select kernel_name, dispatch_id, counter_name, value from counters_collection"):
+            name = re.sub(r"\(.*$", "", name); name = re.sub(r"^void ", "", name)
+            rows[name][cname].append((disp, val))
+    lines = ["| kernel | counter | dispatches | mean per dispatch (steady state) | max |", "|---|---|---|---|---|"]
+    res = {}
+    for k in sorted(rows):
+        for c in sorted(rows[k]):
+            by_disp = defaultdict(float)
+            for disp, val in rows[k][c]:
+                by_disp[disp] += val          # sum over XCDs / shader engines
+            vals = [by_disp[d] for d in sorted(by_disp)]
+            ss = vals[len(vals) // 2:]        # second half of the run = steady-state window
+            mean = sum(ss) / len(ss)
+            lines.append("| %s | %s | %d | %.4g | %.4g |" % (k, c, len(vals), mean, max(vals)))
+            res[(k, c)] = mean
+    txt = "\n".join(lines)
+    print(txt)
+    open(out, "a").write(txt + "\n")
+
+
+if __name__ == "__main__":
+    main()
