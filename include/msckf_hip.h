@@ -68,7 +68,8 @@ int msckf_hip_add_features(msckf_hip_handle h, int b, const double* meas2, const
 int msckf_hip_marginalize(msckf_hip_handle h, int b);
 /* MSCKF::pruneEmptyStates()                                                          msckf.h:685-761 */
 int msckf_hip_prune_empty_states(msckf_hip_handle h, int b);
-/* MSCKF::pruneRedundantStates() -- not built yet: returns -ENOSYS  msckf.h:453-682 */
+/* MSCKF::pruneRedundantStates(): keyframe selection + observation surgery on the host, triangulation of
+ * not-yet-initialized features and the second update on the device                   msckf.h:453-682 */
 int msckf_hip_prune_redundant_states(msckf_hip_handle h, int b);
 /* MSCKF::finish()                                                                    msckf.h:765-807 */
 int msckf_hip_finish(msckf_hip_handle h, int b);

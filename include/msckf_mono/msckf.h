@@ -13,7 +13,6 @@
 //     MSCKF_SHIM_N_CAP / MSCKF_SHIM_F_CAP / MSCKF_SHIM_M_CAP);
 //   * Q_imu / initial_imu_covar are read through their diagonals (every caller passes .asDiagonal());
 //   * u_var_prime must equal v_var_prime in this build (msckf_hip_initialize returns -ENOTSUP otherwise);
-//   * pruneRedundantStates() is a no-op that reports -ENOSYS on stderr once (not built yet);
 //   * additive: getCovariance(), lastError().
 #ifndef MSCKF_MONO_SHIM_MSCKF_H_
 #define MSCKF_MONO_SHIM_MSCKF_H_
@@ -122,7 +121,7 @@ class MSCKF {
     report("addFeatures");
   }
   void marginalize() { rc_ = msckf_hip_marginalize(h_, 0); report("marginalize"); }                       // :336
-  void pruneRedundantStates() { rc_ = msckf_hip_prune_redundant_states(h_, 0); if (!warned_) { warned_ = true; report("pruneRedundantStates"); } }  // :453
+  void pruneRedundantStates() { rc_ = msckf_hip_prune_redundant_states(h_, 0); report("pruneRedundantStates"); }                 // :453
   void pruneEmptyStates() { rc_ = msckf_hip_prune_empty_states(h_, 0); report("pruneEmptyStates"); }      // :685
   void finish() { rc_ = msckf_hip_finish(h_, 0); report("finish"); }                                      // :765
 
@@ -177,7 +176,6 @@ class MSCKF {
   msckf_hip_handle h_ = nullptr;
   Camera<_S> camera_;
   int rc_ = 0;
-  bool warned_ = false;
   std::vector<double> buf_;
   std::vector<uint64_t> ids_;
 

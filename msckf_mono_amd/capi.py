@@ -129,6 +129,9 @@ class Batch:
     def prune_empty_states(self, b):
         _chk(self.L.msckf_hip_prune_empty_states(self.h, b))
 
+    def prune_redundant_states(self, b):
+        _chk(self.L.msckf_hip_prune_redundant_states(self.h, b))
+
     def finish(self, b):
         _chk(self.L.msckf_hip_finish(self.h, b))
 
@@ -251,6 +254,9 @@ class MSCKF:
 
     def marginalize(self):
         self.batch.marginalize(0)
+
+    def pruneRedundantStates(self):
+        self.batch.prune_redundant_states(0)
 
     def pruneEmptyStates(self):
         self.batch.prune_empty_states(0)

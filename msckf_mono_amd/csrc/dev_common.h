@@ -52,6 +52,9 @@ struct Dev {
   long wl_stride_n;   // stride between trajectories in trk_n   (ints)
   long wl_stride_f;   // stride between trajectories in trk_M   (ints)
   long wl_stride_o;   // stride between trajectories in trk_slots (ints) / trk_obs (2 scalars each)
+  // mode 1 (second update of pruneRedundantStates, msckf.h:545-614): every track comes with its stored feature
+  // position trk_pfin[b*f_cap+t][4] -- no checkMotion / triangulation, no Q4 bookkeeping
+  int mode; const S* trk_pfin;
   // per-track products of k_feature
   int* trk_status; S* trk_pf; S* trk_gamma; S* trk_Hx; S* trk_V; S* trk_Zf; S* trk_ro; int* trk_first;
   // k_select

@@ -123,11 +123,12 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
     const S ix = z0x * depth, iy = z0y * depth, iz = depth;
     sa = ix / iz; sb = iy / iz; srho = S(1) / iz;
   }
+  const bool given = d.mode == 1;   // stored feature position supplied by the host (pruneRedundantStates)
   S lambda = S(1e-3), delta_norm = 0;
   S total_cost = wave_sum(act ? tri_cost(T, sa, sb, srho, zx, zy) : S(0));
   bool reduced = false;
   int inner = 0, outer = 0;
-  do {
+  if (!given) do {
     S Ab[9];  // a00 a01 a02 a11 a12 a22 b0 b1 b2
     {
       const V3<S> h = mulv(T.R, mk3(sa, sb, S(1))) + (srho * T.t);
@@ -180,7 +181,11 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
     const S ncost = total_cost / (S(2) * S(M) * S(M));
     if (!any_bad && !(ncost > prm[PRM_GN])) status |= ST_TRI_VALID;
   }
-  const V3<S> pf = multv(C0, fin) + p0;   // :1282
+  V3<S> pf = multv(C0, fin) + p0;   // :1282
+  if (given) {
+    pf = ld3(d.trk_pfin + tb * 4);
+    status |= ST_MOTION_OK | ST_TRI_VALID;
+  }
 
   // ---- calcResidual :960-978 and calcMeasJacobian :915-950 for this lane's observation
   S hx[2][6], hf[2][3], r[2];
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(64) void k_select(Dev<S> d, int b0, int nb) {
   sCnt[lane] = 0; sRows[lane] = 0;
   __syncthreads();
   // ---- pass 1: decisions (status bits), per-bin counts
-  if (nres <= 3) {
+  if (nres <= 3 && d.mode == 0) {
     if (lane == 0) {
       for (int t = 0; t < F; ++t) {
         const long tb = (long)b * d.f_cap + t;
@@ -537,7 +542,7 @@ __global__ __launch_bounds__(64) void k_select(Dev<S> d, int b0, int nb) {
       }
       if (incl) { const int f0 = d.trk_first[tb] & 63; atomicAdd(&sCnt[f0], 1); atomicAdd(&sRows[f0], 2 * M - 3); }
       mrej += __popcll(__ballot(m_rej)); trej += __popcll(__ballot(t_rej)); grej += __popcll(__ballot(g_rej));
-      pass += __popcll(__ballot(incl)); nres += __popcll(__ballot(valid));
+      pass += __popcll(__ballot(incl)); if (d.mode == 0) nres += __popcll(__ballot(valid));
     }
   }
   __syncthreads();

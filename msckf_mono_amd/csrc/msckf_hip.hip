@@ -32,11 +32,12 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
   } while (0)
 
 struct CamMeta { int state_id; double time; int last_correlated_id; std::vector<uint64_t> tracked; };
-struct Track { uint64_t id; std::vector<double> obs; std::vector<int> cam_ids; };
+struct Track { uint64_t id; std::vector<double> obs; std::vector<int> cam_ids; bool initialized = false; double p_f_G[3] = {0, 0, 0}; };
 struct TrackToResid { uint64_t id; std::vector<double> obs; std::vector<int> slots; };
 struct HostTraj {
   bool initialized = false;
   int max_cam_states = 0, min_track_length = 0, max_track_length = 0;
+  double redundancy_angle_thresh = 0, redundancy_distance_thresh = 0;
   std::vector<CamMeta> cams;
   std::vector<Track> tracks;
   std::vector<uint64_t> tracked_ids;
@@ -55,6 +56,9 @@ struct BatchBase {
   virtual int augment(int b0, int nb) = 0;
   virtual int set_tracks(int b, int F, const int* M, const int* slots, const double* obs) = 0;
   virtual int marginalize(int b0, int nb) = 0;
+  virtual int set_given_positions(int b, int F, const double* pf3) = 0;   // mode-1 work-list: stored p_f_G per track
+  virtual int feature_only(int b, int* status, double* pf3, int cap) = 0;  // checkMotion + triangulation of the work-list
+  virtual int marginalize_given(int b) = 0;                               // second update of pruneRedundantStates
   virtual int prune_keep(int b, const std::vector<int>& keep) = 0;
   virtual int drop_oldest(int b0, int nb, int n) = 0;
   virtual int get_ncam(int b, int* n) = 0;
@@ -87,6 +91,7 @@ struct Batch : BatchBase {
   std::vector<void*> allocs;
   // single-call staging on device
   S* d_rd = nullptr; int rd_cap = 0;               // [B][rd_cap][7]
+  S* d_pfin = nullptr;                              // [B][f_cap][4] stored feature positions (mode 1)
   int* wl_n = nullptr; int* wl_M = nullptr; int* wl_slots = nullptr; S* wl_obs = nullptr;  // [B]...[B][f_cap][m_cap]
   // scenario
   int sc_frames = 0, sc_K = 0;
@@ -130,6 +135,7 @@ struct Batch : BatchBase {
     rc |= dalloc(&d.PHt, Bz * dn); rc |= dalloc(&d.Smat, Bz * nl); rc |= dalloc(&d.Linv, Bz * nl); rc |= dalloc(&d.W, Bz * dn);
     rc |= dalloc(&d.K, Bz * dn); rc |= dalloc(&d.A, Bz * pl); rc |= dalloc(&d.AP, Bz * pl); rc |= dalloc(&d.X, Bz * pl); rc |= dalloc(&d.dx, Bz * d.ld);
     rc |= dalloc(&d.keep, Bz * n_cap); rc |= dalloc(&d.nkeep, Bz);
+    rc |= dalloc(&d_pfin, TF * 4); d.trk_pfin = d_pfin; d.mode = 0;
     rd_cap = 64;
     rc |= dalloc(&d_rd, Bz * rd_cap * RD_STRIDE);
     rc |= dalloc(&wl_n, Bz); rc |= dalloc(&wl_M, TF); rc |= dalloc(&wl_slots, TF * m_cap); rc |= dalloc(&wl_obs, TF * m_cap * 2);
@@ -204,6 +210,7 @@ struct Batch : BatchBase {
     t = HostTraj();
     t.initialized = true;
     t.min_track_length = (int)params[5]; t.max_track_length = (int)params[6]; t.max_cam_states = (int)params[7];
+    t.redundancy_angle_thresh = params[3]; t.redundancy_distance_thresh = params[4];
     return 0;
   }
   int propagate(int b0, int nb, const double* rd, int K) override {
@@ -269,6 +276,41 @@ struct Batch : BatchBase {
     HIPCHK(hipSetDevice(device));
     use_single_worklists();
     launch_update(view(b0), b0, nb);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  int set_given_positions(int b, int F, const double* pf3) override {
+    if (chk(b) || F > f_cap) return fail(-EINVAL, "bad arguments");
+    HIPCHK(hipSetDevice(device));
+    std::vector<S> tmp((size_t)std::max(F, 1) * 4, S(0));
+    for (int t = 0; t < F; ++t) for (int k = 0; k < 3; ++k) tmp[4 * t + k] = (S)pf3[3 * t + k];
+    HIPCHK(hipMemcpyAsync(d_pfin + (size_t)b * f_cap * 4, tmp.data(), tmp.size() * sizeof(S), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+  }
+  int feature_only(int b, int* status, double* pf3, int cap) override {
+    if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
+    HIPCHK(hipSetDevice(device));
+    use_single_worklists();
+    const int F = traj[b].wl_F;
+    if (F > cap) return fail(-E2BIG, "output buffer too small");
+    if (F == 0) return 0;
+    launch_feature<S>(view(b), b, 1, st);
+    HIPCHK(hipGetLastError());
+    std::vector<int> stt(F); std::vector<S> pf((size_t)F * 4);
+    HIPCHK(hipMemcpyAsync(stt.data(), d.trk_status + (size_t)b * f_cap, F * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(pf.data(), d.trk_pf + (size_t)b * f_cap * 4, (size_t)F * 4 * sizeof(S), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int t = 0; t < F; ++t) { status[t] = stt[t]; for (int k = 0; k < 3; ++k) pf3[3 * t + k] = (double)pf[4 * t + k]; }
+    return F;
+  }
+  int marginalize_given(int b) override {
+    if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
+    HIPCHK(hipSetDevice(device));
+    use_single_worklists();
+    Dev<S> v = view(b);
+    v.mode = 1;
+    launch_update(v, b, 1);
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -640,6 +682,143 @@ int host_prune_empty(BatchBase* B, int b) {
   return 0;
 }
 
+// findRedundantCamStates, msckf.h:1049-1098 (poses: n x 7 = q_CG(w,x,y,z) p_C_G)
+static void find_redundant(const HostTraj& t, const std::vector<double>& poses, std::vector<int>& rm) {
+  const int n = (int)t.cams.size();
+  if (n < 5) return;
+  auto qp = [&](int i) { return &poses[7 * i]; };
+  int kf = 0;
+  const int prot = n - 3;
+  int next = 1;
+  while (next != prot) {
+    const double* a = qp(kf); const double* c = qp(next);
+    const double dx = c[4] - a[4], dy = c[5] - a[5], dz = c[6] - a[6];
+    const double distance = std::sqrt(dx * dx + dy * dy + dz * dz);
+    // Eigen angularDistance: d = kf_q * conj(cam_q); 2*atan2(|vec(d)|, |d.w|)
+    const double aw = a[0], ax = a[1], ay = a[2], az = a[3], bw = c[0], bx = -c[1], by = -c[2], bz = -c[3];
+    const double dw = aw * bw - ax * bx - ay * by - az * bz;
+    const double vx = aw * bx + ax * bw + ay * bz - az * by, vy = aw * by + ay * bw + az * bx - ax * bz, vz = aw * bz + az * bw + ax * by - ay * bx;
+    const double angle = 2 * std::atan2(std::sqrt(vx * vx + vy * vy + vz * vz), std::fabs(dw));
+    if (distance < t.redundancy_distance_thresh && angle < t.redundancy_angle_thresh) rm.push_back(t.cams[next].state_id);
+    else kf = next;
+    ++next;
+    if (n - (int)rm.size() <= t.max_cam_states) break;
+  }
+  const int over = (n - (int)rm.size()) - t.max_cam_states;
+  for (int i = 0; i < over; i++)
+    if (std::find(rm.begin(), rm.end(), t.cams[i].state_id) == rm.end()) rm.push_back(t.cams[i].state_id);
+  if (rm.size() < 2) rm.clear();
+  std::sort(rm.begin(), rm.end());
+}
+
+static void erase_involved(Track& tr, const std::vector<int>& involved) {
+  for (int cam_id : involved) {
+    auto it = std::find(tr.cam_ids.begin(), tr.cam_ids.end(), cam_id);
+    if (it != tr.cam_ids.end()) {
+      const size_t idx = (size_t)(it - tr.cam_ids.begin());
+      tr.cam_ids.erase(it);
+      tr.obs.erase(tr.obs.begin() + 2 * idx, tr.obs.begin() + 2 * idx + 2);
+    }
+  }
+}
+
+// MSCKF::pruneRedundantStates, msckf.h:453-682: keyframe selection and observation surgery on the host, the
+// triangulation of not-yet-initialized features and the second measurement update on the device.
+int host_prune_redundant(BatchBase* B, int b) {
+  HostTraj& t = B->traj[b];
+  if (!t.initialized) return fail(-EINVAL, "trajectory not initialized");
+  if (t.cams.size() < 20) return 0;                                           // :455
+  const int n = (int)t.cams.size();
+  std::vector<double> poses((size_t)n * 7);
+  int ngot = 0;
+  int rc = B->get_cams(b, poses.data(), n, &ngot);
+  if (rc) return rc;
+  std::vector<int> rm;
+  find_redundant(t, poses, rm);
+  auto involved_of = [&](const Track& tr) {
+    std::vector<int> inv;
+    for (int cam_id : rm) if (std::find(tr.cam_ids.begin(), tr.cam_ids.end(), cam_id) != tr.cam_ids.end()) inv.push_back(cam_id);
+    return inv;
+  };
+  auto slot_of = [&](int cam_id) { for (int i = 0; i < n; ++i) if (t.cams[i].state_id == cam_id) return i; return -1; };
+  // ---- first loop :466-534
+  std::vector<size_t> cand;   // not-yet-initialized features with >= 2 involved states: need motion check + triangulation
+  for (size_t i = 0; i < t.tracks.size(); ++i) {
+    Track& tr = t.tracks[i];
+    std::vector<int> inv = involved_of(tr);
+    if (inv.empty()) continue;
+    if (inv.size() == 1) { erase_involved(tr, inv); continue; }
+    if (!tr.initialized) cand.push_back(i);
+  }
+  if (!cand.empty()) {
+    if ((int)cand.size() > B->f_cap) return fail(-E2BIG, "more candidate features than f_cap");
+    std::vector<int> M, slots; std::vector<double> obs;
+    for (size_t ci : cand) {
+      const Track& tr = t.tracks[ci];
+      int m = 0;
+      for (int p = 0; p < n; ++p) {                                           // feature_associated_cam_states in cam order (:490-495)
+        auto it = std::find(tr.cam_ids.begin(), tr.cam_ids.end(), t.cams[p].state_id);
+        if (it == tr.cam_ids.end()) continue;
+        const size_t k = (size_t)(it - tr.cam_ids.begin());
+        slots.push_back(p); obs.push_back(tr.obs[2 * k]); obs.push_back(tr.obs[2 * k + 1]); ++m;
+      }
+      M.push_back(m);
+    }
+    rc = B->set_tracks(b, (int)cand.size(), M.data(), slots.data(), obs.data());
+    if (rc) return rc;
+    std::vector<int> status(cand.size()); std::vector<double> pf(3 * cand.size());
+    rc = B->feature_only(b, status.data(), pf.data(), (int)cand.size());
+    if (rc < 0) return rc;
+    for (size_t c = 0; c < cand.size(); ++c) {
+      Track& tr = t.tracks[cand[c]];
+      const bool ok = (status[c] & ST_MOTION_OK) && (status[c] & ST_TRI_VALID);
+      if (!ok) erase_involved(tr, involved_of(tr));                           // :496-524
+      else { tr.initialized = true; for (int k = 0; k < 3; ++k) tr.p_f_G[k] = pf[3 * c + k]; t.map.insert(t.map.end(), &pf[3 * c], &pf[3 * c] + 3); }
+    }
+  }
+  // ---- second loop :545-607
+  {
+    std::vector<int> M, slots; std::vector<double> obs, pf;
+    std::vector<size_t> used;
+    for (size_t i = 0; i < t.tracks.size(); ++i) {
+      Track& tr = t.tracks[i];
+      std::vector<int> inv = involved_of(tr);
+      if (inv.empty()) continue;
+      for (int cam_id : inv) {
+        const size_t k = (size_t)(std::find(tr.cam_ids.begin(), tr.cam_ids.end(), cam_id) - tr.cam_ids.begin());
+        slots.push_back(slot_of(cam_id)); obs.push_back(tr.obs[2 * k]); obs.push_back(tr.obs[2 * k + 1]);
+      }
+      M.push_back((int)inv.size());
+      for (int k = 0; k < 3; ++k) pf.push_back(tr.p_f_G[k]);
+      used.push_back(i);
+    }
+    const int F = (int)M.size();
+    if (F > B->f_cap) return fail(-E2BIG, "more features than f_cap");
+    if (F > 0) {
+      rc = B->set_tracks(b, F, M.data(), slots.data(), obs.data());
+      if (rc) return rc;
+      rc = B->set_given_positions(b, F, pf.data());
+      if (rc) return rc;
+      rc = B->marginalize_given(b);
+      if (rc) return rc;
+    }
+    for (size_t i : used) erase_involved(t.tracks[i], involved_of(t.tracks[i]));
+  }
+  // ---- prune the removed camera states :616-681
+  std::vector<int> keep;
+  std::vector<CamMeta> kept;
+  for (int i = 0; i < n; ++i) {
+    if (std::find(rm.begin(), rm.end(), t.cams[i].state_id) != rm.end()) t.pruned_ids.push_back(t.cams[i].state_id);
+    else { keep.push_back(i); kept.push_back(t.cams[i]); }
+  }
+  if ((int)keep.size() != n) {
+    rc = B->prune_keep(b, keep);
+    if (rc) return rc;
+    t.cams = kept;
+  }
+  return 0;
+}
+
 int host_finish(BatchBase* B, int b) {
   HostTraj& t = B->traj[b];
   // D6: the reference appends to the stale feature_tracks_to_residualize_ of the previous update() (cleared only
@@ -718,7 +897,10 @@ int msckf_hip_prune_empty_states(msckf_hip_handle h, int b) {
   if (b < 0 || b >= H(h)->B) return fail(-EINVAL, "trajectory index out of range");
   return host_prune_empty(H(h), b);
 }
-int msckf_hip_prune_redundant_states(msckf_hip_handle, int) { return fail(-ENOSYS, "pruneRedundantStates is not built yet (SURVEY.md 8f item 2)"); }
+int msckf_hip_prune_redundant_states(msckf_hip_handle h, int b) {
+  if (b < 0 || b >= H(h)->B) return fail(-EINVAL, "trajectory index out of range");
+  return host_prune_redundant(H(h), b);
+}
 int msckf_hip_finish(msckf_hip_handle h, int b) {
   if (b < 0 || b >= H(h)->B) return fail(-EINVAL, "trajectory index out of range");
   return host_finish(H(h), b);
