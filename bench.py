@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams for the timed region (halves of the batch run concurrently)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,6 +95,7 @@ def main():
         torch.cuda.synchronize()
         bt.sync()
 
+    bt.set_streams(args.streams)
     bt.run_frames(0, fill + W)       # window fill + warm-up (untimed)
     barrier()
     t0 = time.perf_counter()

@@ -26,7 +26,20 @@ namespace msckf {
 
 __device__ int g_qr_dbg[4] = {0, 0, 0, 0};   // experiment knobs (msckf_hip_debug_set); all zero in production
 
+// Reflector scalars: beta = sqrt(s), g = 1/(beta*u).  Double: IEEE sqrt / divide.  Float: hardware rsq / rcp
+// (~1 ulp) refined by one Newton step each -- within 1 ulp of the correctly rounded values at a third of the
+// instructions of the IEEE expansions, which sit on the per-step critical path of the elimination.
 template <class S> __device__ __forceinline__ S fast_rcp(S x) { return S(1) / x; }
+template <> __device__ __forceinline__ float fast_rcp<float>(float x) {
+  const float g0 = __builtin_amdgcn_rcpf(x);
+  return g0 * (2.0f - x * g0);
+}
+template <class S> __device__ __forceinline__ S fast_sqrt(S s) { return dsqrt(s); }
+template <> __device__ __forceinline__ float fast_sqrt<float>(float s) {
+  const float rs = __builtin_amdgcn_rsqf(s);
+  const float b0 = s * rs;
+  return b0 + 0.5f * rs * (s - b0 * b0);
+}
 
 // Work triangle access: packed upper triangle in LDS (row k holds columns k..n) or ldR-strided rows in global.
 template <class S, bool RLDS>
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(64 * QR_NW) void k_qr_update(Dev<S> d, int b0, int 
           // reflector H = I - tau v v^T, v = [1; x'/u], u = x0 - beta, tau = -u/beta.  With g = 1/(beta u):
           //   R[k][j] += e_j g u,   B[:,j] += e_j g x',   e_j = u R[k][j] + x'^T b_j      (one reciprocal per step)
           const S x0 = wave_bcast(rk[jk], lk);
-          S beta = dsqrt(x0 * x0 + sigma);
+          S beta = fast_sqrt(x0 * x0 + sigma);
           if (x0 >= S(0)) beta = -beta;
           const S u = x0 - beta;
           const S g = fast_rcp(beta * u);
@@ -238,9 +251,7 @@ __global__ __launch_bounds__(64 * QR_NW) void k_qr_update(Dev<S> d, int b0, int 
 #pragma unroll
               for (int r = 0; r < RW; ++r) Bv[r][j] += cj * xr[r];
             } else if (col == k) {
-              rk[j] = beta;
-#pragma unroll
-              for (int r = 0; r < RW; ++r) Bv[r][j] = 0;
+              rk[j] = beta;      // the eliminated column of B is never read again (its lane is masked from now on)
             }
           }
 #pragma unroll

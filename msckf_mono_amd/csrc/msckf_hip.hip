@@ -80,6 +80,7 @@ struct BatchBase {
   virtual int sync() = 0;
   virtual int prof_enable(int on) = 0;
   virtual int prof_read(double* ms, int* cnt) = 0;
+  virtual int set_streams(int n) = 0;
 };
 
 constexpr int NSTAGE = 7;
@@ -88,6 +89,9 @@ template <class S>
 struct Batch : BatchBase {
   Dev<S> d{};
   hipStream_t st = nullptr;
+  hipStream_t st2 = nullptr;        // second stream: run_frames can run the two halves of the batch concurrently
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int nstreams = 1;
   std::vector<void*> allocs;
   // single-call staging on device
   S* d_rd = nullptr; int rd_cap = 0;               // [B][rd_cap][7]
@@ -114,6 +118,9 @@ struct Batch : BatchBase {
   int create() {
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     d.B = B; d.n_cap = n_cap; d.f_cap = f_cap; d.m_cap = m_cap;
     d.n6cap = 6 * n_cap;
     d.ld = ((15 + 6 * n_cap + 15) / 16) * 16;
@@ -151,6 +158,9 @@ struct Batch : BatchBase {
     if (st) hipStreamSynchronize(st);
     for (void* p : allocs) hipFree(p);
     for (int s = 0; s < NSTAGE; ++s) for (auto& e : ev_pool[s]) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    if (st2) hipStreamDestroy(st2);
+    if (ev_fork) hipEventDestroy(ev_fork);
+    if (ev_join) hipEventDestroy(ev_join);
     if (st) hipStreamDestroy(st);
   }
   void use_single_worklists() {
@@ -509,6 +519,11 @@ struct Batch : BatchBase {
     for (int s = 0; s < NSTAGE; ++s) { ev_used[s] = 0; prof_ms[s] = 0; prof_cnt[s] = 0; }
     return 0;
   }
+  int set_streams(int n) override {
+    if (n < 1 || n > 2) return fail(-EINVAL, "1 or 2 streams");
+    nstreams = n;
+    return 0;
+  }
   int prof_read(double* ms, int* cnt) override {
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamSynchronize(st));
@@ -551,19 +566,34 @@ template <class S>
 int Batch<S>::run_frames(int f0, int f1) {
   if (f0 < 0 || f1 > sc_frames || f0 > f1) return fail(-EINVAL, "frame range out of bounds");
   HIPCHK(hipSetDevice(device));
+  // Trajectories are independent, so the batch may be cut into two halves that run the same kernel sequence on
+  // two streams: the latency-bound stages of one half (gain solve, TSQR merge, propagate: one workgroup per
+  // trajectory) overlap with the chip-filling stages of the other.  Stage profiling forces a single stream.
+  const int nh = (nstreams == 2 && !prof && B >= 2) ? 2 : 1;
+  hipStream_t streams[2] = {st, st2};
+  if (nh == 2) { HIPCHK(hipEventRecord(ev_fork, st)); HIPCHK(hipStreamWaitEvent(st2, ev_fork, 0)); }
+  hipStream_t saved = st;
   for (int f = f0; f < f1; ++f) {
     const size_t cell0 = (size_t)f * B;
-    Dev<S> v = d;
-    v.trk_n = sc_n + cell0; v.trk_M = sc_M + cell0 * f_cap; v.trk_slots = sc_slots + cell0 * f_cap * m_cap; v.trk_obs = sc_obs + cell0 * f_cap * m_cap * 2;
-    v.wl_stride_n = 1; v.wl_stride_f = f_cap; v.wl_stride_o = (long)f_cap * m_cap;
-    stage_begin(0); launch_propagate<S>(v, 0, B, sc_rd + cell0 * sc_K * RD_STRIDE, (long)sc_K * RD_STRIDE, sc_K, st); stage_end(0);
-    stage_begin(1); launch_augment<S>(v, 0, B, st); stage_end(1);
-    launch_update(v, 0, B);
-    stage_begin(6);
-    hipLaunchKernelGGL(k_make_keep, dim3((B + 63) / 64), dim3(64), 0, st, d.keep, d.nkeep, d.ncam, (const int*)(sc_drop + cell0), 0, n_cap, 0, B);
-    launch_prune<S>(v, 0, B, st);
-    stage_end(6);
+    for (int hh = 0; hh < nh; ++hh) {
+      const int b0 = hh == 0 ? 0 : B / 2;
+      const int nb = nh == 1 ? B : (hh == 0 ? B / 2 : B - B / 2);
+      st = streams[hh];
+      Dev<S> v = d;
+      v.trk_n = sc_n + cell0 + b0; v.trk_M = sc_M + (cell0 + b0) * f_cap; v.trk_slots = sc_slots + (cell0 + b0) * f_cap * m_cap;
+      v.trk_obs = sc_obs + (cell0 + b0) * f_cap * m_cap * 2;
+      v.wl_stride_n = 1; v.wl_stride_f = f_cap; v.wl_stride_o = (long)f_cap * m_cap;
+      stage_begin(0); launch_propagate<S>(v, b0, nb, sc_rd + (cell0 + b0) * sc_K * RD_STRIDE, (long)sc_K * RD_STRIDE, sc_K, st); stage_end(0);
+      stage_begin(1); launch_augment<S>(v, b0, nb, st); stage_end(1);
+      launch_update(v, b0, nb);
+      stage_begin(6);
+      hipLaunchKernelGGL(k_make_keep, dim3((nb + 63) / 64), dim3(64), 0, st, d.keep, d.nkeep, d.ncam, (const int*)(sc_drop + cell0 + b0), 0, n_cap, b0, nb);
+      launch_prune<S>(v, b0, nb, st);
+      stage_end(6);
+    }
   }
+  st = saved;
+  if (nh == 2) { HIPCHK(hipEventRecord(ev_join, st2)); HIPCHK(hipStreamWaitEvent(st, ev_join, 0)); }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -958,5 +988,6 @@ int msckf_hip_run_frames(msckf_hip_handle h, int f0, int f1) { return H(h)->run_
 int msckf_hip_sync(msckf_hip_handle h) { return H(h)->sync(); }
 int msckf_hip_profile_enable(msckf_hip_handle h, int on) { return H(h)->prof_enable(on); }
 int msckf_hip_profile_read(msckf_hip_handle h, double* ms7, int* count7) { return H(h)->prof_read(ms7, count7); }
+int msckf_hip_set_streams(msckf_hip_handle h, int n) { return H(h)->set_streams(n); }
 
 }  // extern "C"
