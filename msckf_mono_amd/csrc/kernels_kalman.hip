@@ -345,10 +345,33 @@ __global__ __launch_bounds__(256) void k_gain(Dev<S> d, int b0) {
       const int i = G * a + tx, j = G * bb + ty;
       if (i < D && j < n) v.K[(long)j * v.ld + i] = Wm[a][bb];
     }
+  // dx = K r_n (msckf.h:1373) while K is still in registers: per-thread partial sums over this thread's columns,
+  // combined over the 16 column residues in a fixed order (deterministic)
+  __shared__ S sDx[G][G * NBD + 1];
+  {
+    S rn[NBN];
+#pragma unroll
+    for (int bb = 0; bb < NBN; ++bb) { const int j = G * bb + ty; rn[bb] = j < n ? v.R0[(long)j * v.ldR + n] : S(0); }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < NBD; ++a) {
+      S p = 0;
+#pragma unroll
+      for (int bb = 0; bb < NBN; ++bb) p += Wm[a][bb] * rn[bb];
+      sDx[ty][G * a + tx] = p;
+    }
+    __syncthreads();
+    for (int i = tid; i < D; i += 256) {
+      S sm = 0;
+#pragma unroll
+      for (int y = 0; y < G; ++y) sm += sDx[y][i];
+      d.dx[(long)b * d.ld + i] = sm;
+    }
+  }
 }
 
 // dx = K r_n and state injection (msckf.h:1373-1391); one workgroup per trajectory.
-template <class S>
+template <class S, bool HAVE_DX>
 __global__ __launch_bounds__(256) void k_inject(Dev<S> d, int b0) {
   const int b = b0 + blockIdx.x, tid = threadIdx.x;
   if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
@@ -357,9 +380,12 @@ __global__ __launch_bounds__(256) void k_inject(Dev<S> d, int b0) {
   S* sdx = reinterpret_cast<S*>(smem_raw);
   for (int i = tid; i < v.D; i += 256) {
     S s = 0;
-    for (int a = 0; a < v.n; ++a) s += v.K[(long)a * v.ld + i] * v.R0[(long)a * v.ldR + v.n];
+    if (HAVE_DX) s = d.dx[(long)b * d.ld + i];
+    else {
+      for (int a = 0; a < v.n; ++a) s += v.K[(long)a * v.ld + i] * v.R0[(long)a * v.ldR + v.n];
+      d.dx[(long)b * d.ld + i] = s;
+    }
     sdx[i] = s;
-    d.dx[(long)b * d.ld + i] = s;
   }
   __syncthreads();
   S* imu = d.imu + (long)b * IMU_STRIDE;
@@ -433,7 +459,8 @@ void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st) {
     gemm<S, OP_W>(d, b0, nb, D, n, st);
     gemm<S, OP_K>(d, b0, nb, D, n, st);
   }
-  hipLaunchKernelGGL(k_inject<S>, dim3(nb), dim3(256), (size_t)d.ld * sizeof(S), st, d, b0);
+  if (nbn <= nbn_max) hipLaunchKernelGGL((k_inject<S, true>), dim3(nb), dim3(256), (size_t)d.ld * sizeof(S), st, d, b0);
+  else hipLaunchKernelGGL((k_inject<S, false>), dim3(nb), dim3(256), (size_t)d.ld * sizeof(S), st, d, b0);
   gemm<S, OP_A>(d, b0, nb, D, D, st);
   gemm<S, OP_AP>(d, b0, nb, D, D, st);
   gemm<S, OP_X>(d, b0, nb, D, D, st);
