@@ -157,7 +157,7 @@ def main():
                        "cam_window": N_WIN, "tracks_per_update": F_TRK, "trajectories_per_gpu": B_TRAJ, "imu_per_update": K_IMU,
                        "parallelism": "replicated trajectories, %d per rank" % B_TRAJ, "noise": "isotropic (f_u = f_v)"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_TFLOPS, "traffic": pmc_traffic(dom),
                          "alg_flops_per_update": f_update, "alg_bytes_per_update": by,
                          "whole_update_tflops": f_update * value / 1e12 / world,
                          "whole_update_frac": f_update * value / 1e12 / world / PEAK_F32_TFLOPS,
@@ -171,6 +171,20 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs of this same command, profiles/pmc_traffic.json, written by
+    scripts/rocpd_pmc.py); FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.  None if absent."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        t = json.load(open(path)).get(kernel)
+        return None if t is None else float(t["bytes_per_launch"])
+    except Exception:
+        return None
 
 
 def cpu_baseline(tr, frame, budget_s):

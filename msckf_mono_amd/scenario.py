@@ -166,6 +166,7 @@ class Trajectory:
     def __init__(self, config_id, traj_idx, N, F, n_frames, cfg=None, t0=0.0, imu_noise_scale=0.05,
                  obs_noise_px=0.5, dense_tracks=False, first_timed_window_only=False):
         self.N, self.F, self.n_frames = N, F, n_frames
+        self.t0 = t0
         self.cfg = cfg if cfg is not None else filter_config(N)
         self.seed = 0x5EED0000 + 1000 * config_id + traj_idx
         rng = SplitMix64(self.seed)

@@ -32,6 +32,24 @@ def main():
     txt = "\n".join(lines)
     print(txt)
     open(out, "a").write(txt + "\n")
+    # traffic of the TSQR stage-1 launches (the dominant kernel): the LARGEST dispatches of k_qr_update
+    import json, os
+    tr = {}
+    for k in rows:
+        if "k_qr_update" in k and "FETCH_SIZE" in rows[k] and "WRITE_SIZE" in rows[k]:
+            def top(c):
+                by = defaultdict(float)
+                for disp, val in rows[k][c]:
+                    by[disp] += val
+                v = sorted(by.values())
+                v = v[len(v) // 2:]                 # stage-1 launches carry more traffic than the merges
+                v = v[len(v) // 2:]
+                return sum(v) / len(v)
+            f, w = top("FETCH_SIZE"), top("WRITE_SIZE")
+            tr["compress_stage1"] = dict(kernel=k, fetch_kib=f, write_kib=w, bytes_per_launch=(2 * f + w) * 1024,
+                                         note="FETCH_SIZE doubled (gfx950 under-reports wide coalesced reads by 2x); WRITE_SIZE uncalibrated")
+    if tr:
+        json.dump(tr, open(os.path.join(os.path.dirname(out) or ".", "pmc_traffic.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,74 @@
+"""ASL (EuRoC mav0) layout: writer/reader round trip, the deterministic runner (asl_msckf.cpp:206-296 call order)
+against the scenario-driven loop, ATE; on the GPU the same runner drives the HIP path."""
+import numpy as np
+import pytest
+
+import helpers as H
+from msckf_mono_amd import asl, scenario as sc
+
+
+@pytest.fixture(scope="module")
+def dataset(tmp_path_factory):
+    N, F, nf = 7, 10, 16
+    tr = sc.Trajectory(1, 3, N, F, nf)
+    root = tmp_path_factory.mktemp("asl")
+    mav = asl.write_dataset(str(root), tr)
+    return tr, asl.read_dataset(mav)
+
+
+def test_round_trip(dataset):
+    tr, ds = dataset
+    assert np.array_equal(ds["readings"][:, :6], tr.readings[:, :6])
+    assert np.allclose(ds["readings"][:, 6], tr.dT)                        # Q6: dT = 1/rate_hz
+    assert np.allclose(ds["cam"]["q_CI"], tr.cfg["q_CI"], atol=1e-14) and np.allclose(ds["cam"]["p_C_I"], tr.cfg["p_C_I"], atol=1e-15)
+    assert len(ds["cam_t"]) == tr.n_frames
+    st = tr.stream()
+    for k, t in enumerate(ds["cam_t"]):
+        e = ds["tracks"].get(int(t), {"cur": ([], []), "new": ([], [])})
+        for key in ("cur", "new"):
+            assert e[key][1] == [int(i) for i in st[k][key][1]]
+            if len(e[key][1]):
+                assert np.array_equal(np.array(e[key][0]), np.array(st[k][key][0]))
+    s0 = asl.initial_state(ds)
+    assert np.allclose(s0[:19], tr.imu0[:19], atol=1e-12)
+
+
+def test_runner_equals_scenario_loop(dataset, oracle_lib):
+    po = oracle_lib
+    tr, ds = dataset
+    st = tr.stream()
+    a, b = po.Oracle(po.F64, po.LEAN), po.Oracle(po.F64, po.LEAN)
+    out = asl.run(ds, a, tr.cfg)
+    b.initialize(tr.cfg, asl.initial_state(ds))
+    sid = 0
+    for k in range(tr.n_frames):
+        b.propagate(ds["readings"][k * sc.IMU_PER_FRAME:(k + 1) * sc.IMU_PER_FRAME]); sid += sc.IMU_PER_FRAME
+        b.augmentState(sid, 0.0)
+        b.update(st[k]["cur"][0], st[k]["cur"][1]); b.addFeatures(st[k]["new"][0], st[k]["new"][1])
+        b.marginalize(); b.pruneEmptyStates()
+        assert np.array_equal(out[k][1], b.getImuState())
+    e, se, n = asl.ate(out, ds)
+    assert n == tr.n_frames and e < 0.02
+
+
+def test_default_parameters_match_the_reference_runner(dataset):
+    _, ds = dataset
+    cfg = asl.filter_config_from_dataset(ds)
+    f_u = ds["cam"]["intrinsics"][0]
+    assert cfg["u_var_prime"] == (7.0 / f_u) ** 2 and cfg["max_gn_cost_norm"] == (11.0 / f_u) ** 2   # asl_msckf.cpp:74-78,103-104
+    assert cfg["max_cam_states"] == 20 and cfg["min_track_length"] == 3 and cfg["max_track_length"] == 1000   # :116-118
+    assert cfg["Q_imu_diag"][0] == 1e-5 and cfg["Q_imu_diag"][3] == 3.6733e-5 and cfg["Q_imu_diag"][6] == 1e-3 and cfg["Q_imu_diag"][9] == 7e-4
+
+
+@pytest.mark.gpu
+def test_runner_on_the_hip_path(dataset, oracle_lib):
+    po = oracle_lib
+    from msckf_mono_amd import capi
+    tr, ds = dataset
+    o = po.Oracle(po.F64, po.LEAN)
+    ref = asl.run(ds, o, tr.cfg)
+    f = capi.MSCKF(capi.F64, n_cap=16, f_cap=64, m_cap=16)
+    got = asl.run(ds, f, tr.cfg)
+    for (t1, s1), (t2, s2) in zip(ref, got):
+        assert t1 == t2 and H.rel(s2[:16], s1[:16]) < 1e-6
+    assert abs(asl.ate(got, ds)[0] - asl.ate(ref, ds)[0]) < 1e-8
