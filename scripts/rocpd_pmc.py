@@ -46,8 +46,8 @@ def main():
                 v = v[len(v) // 2:]
                 return sum(v) / len(v)
             f, w = top("FETCH_SIZE"), top("WRITE_SIZE")
-            tr["compress_stage1"] = dict(kernel=k, fetch_kib=f, write_kib=w, bytes_per_launch=(2 * f + w) * 1024,
-                                         note="FETCH_SIZE doubled (gfx950 under-reports wide coalesced reads by 2x); WRITE_SIZE uncalibrated")
+            tr["k_qr_update"] = dict(kernel=k, fetch_kib=f, write_kib=w, bytes_per_launch=(2 * f + w) * 1024,
+                                         launches="stage-1 launches (the merge launch of the same kernel moves ~4x less)", note="FETCH_SIZE doubled (gfx950 under-reports wide coalesced reads by 2x); WRITE_SIZE uncalibrated")
     if tr:
         json.dump(tr, open(os.path.join(os.path.dirname(out) or ".", "pmc_traffic.json"), "w"), indent=1)
 
