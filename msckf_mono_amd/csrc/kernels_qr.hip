@@ -61,15 +61,16 @@ struct Tri {
 // from wave to wave through LDS with a release/acquire progress word).  Inside a wavefront a step needs no
 // LDS exchange and no barrier: the pivot column is read from its owner lane with v_readlane, the dot
 // products are complete within the wave, the column norm is the pivot column's self product.
-constexpr int QR_NW = 12;   // wavefronts per workgroup = depth of the software pipeline
+constexpr int QR_NW = 12;
+constexpr int QR_MAXBLK = 512;   // row blocks per workgroup (progress words in LDS)   // wavefronts per workgroup = depth of the software pipeline
 
 template <class S, int NC, int RW, bool RLDS>
 __global__ __launch_bounds__(64 * QR_NW) void k_qr_update(Dev<S> d, int b0, int stage, int level) {
   const int b = b0 + blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  int* sProg = reinterpret_cast<int*>(smem_raw);          // [QR_NW] progress words (block * 1024 + steps done)
-  S* sR = reinterpret_cast<S*>(smem_raw + 64);            // packed triangle (RLDS)
+  int* sProg = reinterpret_cast<int*>(smem_raw);          // [QR_MAXBLK] per-block progress (elimination steps done)
+  S* sR = reinterpret_cast<S*>(smem_raw + 4 * QR_MAXBLK); // packed triangle (RLDS)
   const int n = 6 * d.ncam[b];
   const int ldR = d.ldR;
   const int m_cap = d.m_cap, f_cap = d.f_cap;
@@ -103,17 +104,18 @@ __global__ __launch_bounds__(64 * QR_NW) void k_qr_update(Dev<S> d, int b0, int 
       }
     }
   }
-  if (tid < QR_NW) sProg[tid] = 0;
+  for (int e = tid; e < QR_MAXBLK; e += 64 * QR_NW) sProg[e] = -1;
   __syncthreads();
   Tri<S, RLDS> R;
   R.base = RLDS ? sR : Rt; R.n = n; R.ldR = ldR;
-  const int pred = (h + QR_NW - 1) % QR_NW;
   // Stage 1: the sorted stack is cut into blocks of RW rows; global block g belongs to chunk g % nchunk (so
   // every chunk gets the same mix of long and short tracks) and is that chunk's block q = g / nchunk.
   const int cstride = (stage == 1) ? d.nchunk : 1, coff = (stage == 1) ? (int)blockIdx.x : 0;
   const int gblk = (row_end - row_begin + RW - 1) / RW;
   const int nblk = (gblk - coff + cstride - 1) / cstride;
   const int dbg = g_qr_dbg[0];
+  // blocks are dealt to the wavefronts round-robin (a boustrophedon order balances the step totals better but
+  // stalls the pipeline at every turn: measured 9 % slower)
   for (int q = h; q < nblk; q += QR_NW) {
     const int blk0 = row_begin + (q * cstride + coff) * RW;
     // ---------------- load this wave's block: RW rows x NC columns per lane
@@ -203,7 +205,8 @@ __global__ __launch_bounds__(64 * QR_NW) void k_qr_update(Dev<S> d, int b0, int 
     }
     kmin = __builtin_amdgcn_readfirstlane(kmin);
     // steps below kmin are no-ops for this block
-    if (lane == 0) __hip_atomic_store(&sProg[h], q * 1024 + kmin, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // progress word of block q lives in ring slot q % QR_MAXBLK and carries the block index in its high bits
+    if (lane == 0) __hip_atomic_store(&sProg[q & (QR_MAXBLK - 1)], (q << 10) | kmin, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 
     // ---------------- fold the block into R: Householder steps k = kmin .. n-1
 #pragma unroll
@@ -213,8 +216,8 @@ __global__ __launch_bounds__(64 * QR_NW) void k_qr_update(Dev<S> d, int b0, int 
       for (int lk = l_lo; lk < l_hi; ++lk) {
         const int k = 64 * jk + lk;
         if (q > 0) {   // wait until block q-1 has finished step k (its R row k is final for us)
-          const int need = (q - 1) * 1024 + k + 1;
-          while (__hip_atomic_load(&sProg[pred], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+          const int need = ((q - 1) << 10) | (k + 1);
+          while (__hip_atomic_load(&sProg[(q - 1) & (QR_MAXBLK - 1)], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
         }
         S rk[NC];
 #pragma unroll
@@ -257,10 +260,10 @@ __global__ __launch_bounds__(64 * QR_NW) void k_qr_update(Dev<S> d, int b0, int 
 #pragma unroll
           for (int j = jk; j < NC; ++j) R.put(k, lane + 64 * j, rk[j]);
         }
-        if (lane == 0) __hip_atomic_store(&sProg[h], q * 1024 + k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_store(&sProg[q & (QR_MAXBLK - 1)], (q << 10) | (k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
-    if (lane == 0) __hip_atomic_store(&sProg[h], q * 1024 + 1023, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) __hip_atomic_store(&sProg[q & (QR_MAXBLK - 1)], (q << 10) | 1023, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   __syncthreads();
   if (RLDS) {   // publish the triangle (zeros below the diagonal and in the padding columns)
@@ -283,7 +286,7 @@ static void launch_compress_impl(const Dev<S>& d, int b0, int nb, hipStream_t st
 }
 template <class S, int NC>
 static void launch_compress_nc(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase) {
-  const size_t base = 64;
+  const size_t base = 4 * QR_MAXBLK;
   const size_t tri = sizeof(S) * (size_t)(d.n6cap + 1) * (d.n6cap + 2) / 2;
   if (base + tri <= 150 * 1024) launch_compress_impl<S, NC, true>(d, b0, nb, st, phase, base + tri);
   else launch_compress_impl<S, NC, false>(d, b0, nb, st, phase, base);
