@@ -15,7 +15,7 @@
 
 namespace msckf {
 
-enum { OP_PHT = 0, OP_S, OP_W, OP_K, OP_A, OP_AP, OP_X };
+enum { OP_PHT = 0, OP_S, OP_W, OP_K, OP_A, OP_AP, OP_X, OP_KE };
 
 template <class S>
 struct KView {
@@ -40,7 +40,7 @@ __device__ __forceinline__ KView<S> make_view(const Dev<S>& d, int b) {
 template <class S, int OP> __device__ __forceinline__ void op_dims(const KView<S>& v, int& M, int& N, int& K) {
   if (OP == OP_PHT) { M = v.D; N = v.n; K = v.n; }
   else if (OP == OP_S) { M = v.n; N = v.n; K = v.n; }
-  else if (OP == OP_W || OP == OP_K) { M = v.D; N = v.n; K = v.n; }
+  else if (OP == OP_W || OP == OP_K || OP == OP_KE) { M = v.D; N = v.n; K = v.n; }
   else if (OP == OP_A) { M = v.D; N = v.D; K = v.n; }
   else if (OP == OP_AP) { M = v.D; N = v.D; K = v.D; }
   else { M = v.D; N = v.D; K = v.D + v.n; }
@@ -49,7 +49,7 @@ template <class S, int OP> __device__ __forceinline__ S op_a(const KView<S>& v, 
   if (OP == OP_PHT) return v.P[(long)(15 + k) * v.ld + i];
   if (OP == OP_S) return k >= i ? v.R0[(long)i * v.ldR + k] : S(0);
   if (OP == OP_W) return v.PHt[(long)k * v.ld + i];
-  if (OP == OP_K) return v.W[(long)k * v.ld + i];
+  if (OP == OP_K || OP == OP_KE) return v.W[(long)k * v.ld + i];
   if (OP == OP_A) return v.K[(long)k * v.ld + i];
   if (OP == OP_AP) return v.A[(long)k * v.ld + i];
   return k < v.D ? v.AP[(long)k * v.ld + i] : v.sig2 * v.K[(long)(k - v.D) * v.ld + i];
@@ -59,6 +59,7 @@ template <class S, int OP> __device__ __forceinline__ S op_b(const KView<S>& v, 
   if (OP == OP_S) return v.PHt[(long)j * v.ld + 15 + k];
   if (OP == OP_W) return k <= j ? v.Linv[(long)k * v.ldn + j] : S(0);             // Linv(j,k)
   if (OP == OP_K) return j <= k ? v.Linv[(long)j * v.ldn + k] : S(0);             // Linv(k,j)
+  if (OP == OP_KE) return k >= j ? v.Linv[(long)k * v.ldn + j] : S(0);            // E(j,k), E = L^-T upper triangular
   if (OP == OP_A) return (j >= 15 && j - 15 >= k) ? v.R0[(long)k * v.ldR + (j - 15)] : S(0);   // T_H[k][j]
   if (OP == OP_AP) return v.P[(long)j * v.ld + k];
   return k < v.D ? v.A[(long)k * v.ld + j] : v.K[(long)(k - v.D) * v.ld + j];
@@ -67,7 +68,7 @@ template <class S, int OP> __device__ __forceinline__ void op_store(const KView<
   if (OP == OP_PHT) v.PHt[(long)j * v.ld + i] = acc;
   else if (OP == OP_S) v.Sm[(long)j * v.ldn + i] = acc + (i == j ? v.sig2 : S(0));
   else if (OP == OP_W) v.W[(long)j * v.ld + i] = acc;
-  else if (OP == OP_K) v.K[(long)j * v.ld + i] = acc;
+  else if (OP == OP_K || OP == OP_KE) v.K[(long)j * v.ld + i] = acc;
   else if (OP == OP_A) v.A[(long)j * v.ld + i] = (i == j ? S(1) : S(0)) - acc;
   else if (OP == OP_AP) v.AP[(long)j * v.ld + i] = acc;
   else v.X[(long)j * v.ld + i] = acc;
@@ -370,6 +371,95 @@ __global__ __launch_bounds__(256) void k_gain(Dev<S> d, int b0) {
   }
 }
 
+// Split variant of the gain solve: 4 workgroups per trajectory.  Every workgroup factors S = L L^T in registers
+// (redundantly, 78 blocks) and carries ONE QUARTER of the appended rows [PHt ; I] through the same eliminations,
+// which turns them into [W ; E] = [PHt L^-T ; L^-T].  K = PHt S^-1 = W E^T is then one MFMA GEMM (OP_KE) instead of
+// the backward sweep of k_gain: half the sequential steps, four times the workgroups.
+template <class S, int NBN>
+__global__ __launch_bounds__(256) void k_gain_split(Dev<S> d, int b0) {
+  constexpr int G = 16, NBD = NBN + 1, NBA = NBD + NBN, NBQ = (NBA + 3) / 4;
+  const int b = b0 + blockIdx.y, part = blockIdx.x, tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
+  const KView<S> v = make_view(d, b);
+  const int n = v.n, D = v.D;
+  __shared__ S sCol[2][G * NBN];
+  __shared__ S sW[2][G * NBQ];
+  S A[NBN][NBN], Wm[NBQ][NBN];
+#pragma unroll
+  for (int a = 0; a < NBN; ++a)
+#pragma unroll
+    for (int bb = 0; bb < NBN; ++bb) {
+      const int i = G * a + tx, j = G * bb + ty;
+      A[a][bb] = (a >= bb && i < n && j < n) ? v.Sm[(long)j * v.ldn + i] : S(0);
+    }
+#pragma unroll
+  for (int a = 0; a < NBQ; ++a) {
+    const int ab = part * NBQ + a;          // appended row block: [0,NBD) rows of PHt, [NBD,NBA) rows of I
+#pragma unroll
+    for (int bb = 0; bb < NBN; ++bb) {
+      const int j = G * bb + ty;
+      S val = 0;
+      if (ab < NBD) { const int i = G * ab + tx; if (i < D && j < n) val = v.PHt[(long)j * v.ld + i]; }
+      else if (ab < NBA) { const int r = G * (ab - NBD) + tx; if (r == j && r < n) val = S(1); }
+      Wm[a][bb] = val;
+    }
+  }
+  int buf = 0;
+#pragma unroll
+  for (int kb = 0; kb < NBN; ++kb) {
+    const int kk_hi = min(G, n - G * kb);
+    for (int kk = 0; kk < kk_hi; ++kk) {
+      const int k = G * kb + kk;
+      if (ty == kk) {
+#pragma unroll
+        for (int a = kb; a < NBN; ++a) sCol[buf][G * a + tx] = A[a][kb];
+#pragma unroll
+        for (int a = 0; a < NBQ; ++a) sW[buf][G * a + tx] = Wm[a][kb];
+      }
+      __syncthreads();
+      const S dkk = sCol[buf][k];
+      const S dd = dsqrt(dkk > S(0) ? dkk : Lim<S>::tiny());
+      const S dinv = S(1) / dd;
+      S li[NBN], lj[NBN], wi[NBQ];
+#pragma unroll
+      for (int a = kb; a < NBN; ++a) li[a] = (a > kb || tx > kk) ? sCol[buf][G * a + tx] * dinv : S(0);
+#pragma unroll
+      for (int bb = kb; bb < NBN; ++bb) lj[bb] = (bb > kb || ty > kk) ? sCol[buf][G * bb + ty] * dinv : S(0);
+#pragma unroll
+      for (int a = 0; a < NBQ; ++a) wi[a] = sW[buf][G * a + tx] * dinv;
+#pragma unroll
+      for (int a = kb; a < NBN; ++a)
+#pragma unroll
+        for (int bb = kb; bb <= a; ++bb) A[a][bb] -= li[a] * lj[bb];
+#pragma unroll
+      for (int a = 0; a < NBQ; ++a)
+#pragma unroll
+        for (int bb = kb; bb < NBN; ++bb) Wm[a][bb] -= wi[a] * lj[bb];
+      if (ty == kk) {
+#pragma unroll
+        for (int a = kb; a < NBN; ++a) {
+          if (a > kb || tx > kk) A[a][kb] = li[a];
+          else if (a == kb && tx == kk) A[a][kb] = dd;
+        }
+#pragma unroll
+        for (int a = 0; a < NBQ; ++a) Wm[a][kb] = wi[a];
+      }
+      buf ^= 1;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < NBQ; ++a) {
+    const int ab = part * NBQ + a;
+#pragma unroll
+    for (int bb = 0; bb < NBN; ++bb) {
+      const int j = G * bb + ty;
+      if (j >= n) continue;
+      if (ab < NBD) { const int i = G * ab + tx; if (i < D) v.W[(long)j * v.ld + i] = Wm[a][bb]; }
+      else if (ab < NBA) { const int r = G * (ab - NBD) + tx; if (r < n) v.Linv[(long)j * v.ldn + r] = Wm[a][bb]; }   // E(r,j), upper triangular
+    }
+  }
+}
+
 // dx = K r_n and state injection (msckf.h:1373-1391); one workgroup per trajectory.
 template <class S, bool HAVE_DX>
 __global__ __launch_bounds__(256) void k_inject(Dev<S> d, int b0) {
@@ -382,7 +472,16 @@ __global__ __launch_bounds__(256) void k_inject(Dev<S> d, int b0) {
     S s = 0;
     if (HAVE_DX) s = d.dx[(long)b * d.ld + i];
     else {
-      for (int a = 0; a < v.n; ++a) s += v.K[(long)a * v.ld + i] * v.R0[(long)a * v.ldR + v.n];
+      S s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+      int a = 0;
+      for (; a + 3 < v.n; a += 4) {
+        s0 += v.K[(long)a * v.ld + i] * v.R0[(long)a * v.ldR + v.n];
+        s1 += v.K[(long)(a + 1) * v.ld + i] * v.R0[(long)(a + 1) * v.ldR + v.n];
+        s2 += v.K[(long)(a + 2) * v.ld + i] * v.R0[(long)(a + 2) * v.ldR + v.n];
+        s3 += v.K[(long)(a + 3) * v.ld + i] * v.R0[(long)(a + 3) * v.ldR + v.n];
+      }
+      for (; a < v.n; ++a) s0 += v.K[(long)a * v.ld + i] * v.R0[(long)a * v.ldR + v.n];
+      s = (s0 + s1) + (s2 + s3);
       d.dx[(long)b * d.ld + i] = s;
     }
     sdx[i] = s;
@@ -439,9 +538,15 @@ void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   // Cholesky + triangular inverse (LDS or global) followed by two GEMMs.
   const int nbn = (n + 15) / 16;
   const int nbn_max = sizeof(S) == 4 ? 12 : 8;
+  bool split = false;
   if (nbn <= nbn_max) {
     if (nbn <= 4) hipLaunchKernelGGL((k_gain<S, 4>), dim3(nb), dim3(256), 0, st, d, b0);
     else if (nbn <= 8) hipLaunchKernelGGL((k_gain<S, 8>), dim3(nb), dim3(256), 0, st, d, b0);
+    else if (sizeof(S) == 4 && nb <= 128) {   // few trajectories: 4 workgroups each + one MFMA GEMM
+      hipLaunchKernelGGL((k_gain_split<S, 12>), dim3(4, nb), dim3(256), 0, st, d, b0);
+      gemm<S, OP_KE>(d, b0, nb, D, n, st);
+      split = true;
+    }
     else hipLaunchKernelGGL((k_gain<S, 12>), dim3(nb), dim3(256), 0, st, d, b0);
   } else {
     const size_t lds = (size_t)n * (n + 1) * sizeof(S);
@@ -459,7 +564,7 @@ void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st) {
     gemm<S, OP_W>(d, b0, nb, D, n, st);
     gemm<S, OP_K>(d, b0, nb, D, n, st);
   }
-  if (nbn <= nbn_max) hipLaunchKernelGGL((k_inject<S, true>), dim3(nb), dim3(256), (size_t)d.ld * sizeof(S), st, d, b0);
+  if (nbn <= nbn_max && !split) hipLaunchKernelGGL((k_inject<S, true>), dim3(nb), dim3(256), (size_t)d.ld * sizeof(S), st, d, b0);
   else hipLaunchKernelGGL((k_inject<S, false>), dim3(nb), dim3(256), (size_t)d.ld * sizeof(S), st, d, b0);
   gemm<S, OP_A>(d, b0, nb, D, D, st);
   gemm<S, OP_AP>(d, b0, nb, D, D, st);
