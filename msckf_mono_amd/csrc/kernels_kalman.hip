@@ -131,6 +131,10 @@ __global__ __launch_bounds__(256) void k_gemm(Dev<S> d, int b0) {
 // lane index runs along the output ROW index i: stores to the column-major work matrices are coalesced.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Operand-B staging order per product: true when the B element (k, j) is contiguous in j (then lanes run along j),
+// false when it is contiguous in k (lanes run along k) -- keeps the global loads of the tile coalesced.
+template <int OP> struct BContigJ { static constexpr bool value = (OP == OP_KE || OP == OP_A || OP == OP_X || OP == OP_W); };
+
 template <int OP>
 __global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0) {
   using S = float;
@@ -145,25 +149,45 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0) {
   __shared__ S sB[16][65];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w & 1, wn = w >> 1;
+  const bool wave_live = (i0 + 32 * wm < M) && (j0 + 32 * wn < N);   // edge tiles: whole wave sub-tile out of range
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int k0 = 0; k0 < K; k0 += 16) {
+  // register-staged software pipeline: the global loads of tile t+1 are in flight while tile t runs on the MFMAs
+  S ra[4], rb[4];
+  auto fetch = [&](int k0) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int ii = tid & 63, kk = (tid >> 6) + 4 * q;
       const int gi = i0 + ii, gk = k0 + kk;
-      sA[kk][ii] = (gi < M && gk < K) ? op_a<S, OP>(v, gi, gk) : S(0);
-      const int kb = tid & 15, jj = (tid >> 4) + 16 * q;
+      ra[q] = (gi < M && gk < K) ? op_a<S, OP>(v, gi, gk) : S(0);
+      int kb, jj;
+      if (BContigJ<OP>::value) { jj = tid & 63; kb = (tid >> 6) + 4 * q; }
+      else { kb = tid & 15; jj = (tid >> 4) + 16 * q; }
       const int gj = j0 + jj, gk2 = k0 + kb;
-      sB[kb][jj] = (gj < N && gk2 < K) ? op_b<S, OP>(v, gk2, gj) : S(0);
+      rb[q] = (gj < N && gk2 < K) ? op_b<S, OP>(v, gk2, gj) : S(0);
     }
-    __syncthreads();
+  };
+  auto stage = [&]() {
 #pragma unroll
-    for (int kk = 0; kk < 16; kk += 2) {
-      const S bj = sB[kk + (lane >> 5)][32 * wn + (lane & 31)];   // MFMA A operand: rows of the result = j
-      const S ai = sA[kk + (lane >> 5)][32 * wm + (lane & 31)];   // MFMA B operand: cols of the result = i
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bj, ai, acc, 0, 0, 0);
+    for (int q = 0; q < 4; ++q) {
+      sA[(tid >> 6) + 4 * q][tid & 63] = ra[q];
+      if (BContigJ<OP>::value) sB[(tid >> 6) + 4 * q][tid & 63] = rb[q];
+      else sB[tid & 15][(tid >> 4) + 16 * q] = rb[q];
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    stage();
+    __syncthreads();
+    if (k0 + 16 < K) fetch(k0 + 16);
+    if (wave_live) {
+#pragma unroll
+      for (int kk = 0; kk < 16; kk += 2) {
+        const S bj = sB[kk + (lane >> 5)][32 * wn + (lane & 31)];   // MFMA A operand: rows of the result = j
+        const S ai = sA[kk + (lane >> 5)][32 * wm + (lane & 31)];   // MFMA B operand: cols of the result = i
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bj, ai, acc, 0, 0, 0);
+      }
     }
     __syncthreads();
   }
