@@ -11,7 +11,7 @@ Launch: `python bench.py --gpus 1 --steps K --warmup W`, or one rank per GPU und
 (trajectories are independent: rank r runs its own 64 trajectories, weak scaling, no data-path
 collective; RCCL is used only for the timing reduction and the end-of-run ATE all-reduce).
 
-Prints ONE JSON line on rank 0; `roofline` is for the dominant kernel (the TSQR compression, stage 1),
+Prints ONE JSON line on rank 0; `roofline` is for the dominant kernel (k_qr_update, the TSQR compression),
 `cpu_baseline` is the CPU oracle (restatement of the reference; the reference itself cannot be built
 here -- see BASELINE.md) timed on this box's host cores on a bounded sample of the same workload.
 """
@@ -66,11 +66,19 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # test hooks (tests/test_bench_multirank.py): run the N>1 code path on a 1-GPU box with gloo
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if os.environ.get("BENCH_DEVICE_OVERRIDE") is not None:
+        local_rank = int(os.environ["BENCH_DEVICE_OVERRIDE"])
     torch.cuda.set_device(local_rank)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
     from msckf_mono_amd import capi, scenario as sc
 
     K, W = args.steps, args.warmup
@@ -105,7 +113,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         dist.barrier()
@@ -135,7 +143,7 @@ def main():
     for b, tr in enumerate(trajs):
         e = bt.imu_state(b)[13:16] - tr.gt_frames["p"][last]
         se += float(e @ e)
-    acc = torch.tensor([se, float(B_TRAJ)], device="cuda", dtype=torch.float64)
+    acc = torch.tensor([se, float(B_TRAJ)], device=red_dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
     ate = float(np.sqrt(acc[0].item() / acc[1].item()))
