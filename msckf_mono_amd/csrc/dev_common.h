@@ -19,6 +19,7 @@ namespace msckf {
 constexpr int IMU_STRIDE = 32;
 constexpr int CAM_STRIDE = 8;
 constexpr int PRM_STRIDE = 48;
+constexpr int DG_STRIDE = 28; // per-slot Gram block: 21 (upper 6x6) + 6 (h^T r) + pad
 constexpr int RD_STRIDE = 7;  // imuReading: omega(3) a(3) dT   (types.h:78-84)
 
 enum {  // offsets into imu[]
@@ -61,6 +62,13 @@ struct Dev {
   int* row_start; int* trk_order; int* stats;
   // TSQR
   S* Rbuf;
+  // information-form compression (compress == 1, kernels_gram.hip): [T | r_n] = chol(H_o^T H_o) accumulated in f64
+  //   trk_B  [B*f_cap][3][ldR]  f64   Q_f^T [H_x | r] of the track scattered to state columns (column n = Q_f^T r)
+  //   trk_rw [B*f_cap][2 m_cap]       whitened residual r of the track (before the null-space projection)
+  //   trk_inv[B*f_cap][n_cap]   i8    observation index of camera slot s in the track, -1 = not observed
+  //   Dg     [B][n_cap][28]     f64   per camera slot: upper triangle of sum h^T h (21) and sum h^T r (6)
+  //   Lam    [B][ldR][ldR]      f64   sum B^T B, upper 64x64 tiles
+  int compress; double* trk_B; S* trk_rw; signed char* trk_inv; double* Dg; double* Lam;
   // Kalman work matrices
   S* PHt; S* Smat; S* Linv; S* W; S* K; S* A; S* AP; S* X; S* dx;
   // prune
@@ -203,6 +211,8 @@ template <class S> void launch_feature(const Dev<S>& d, int b0, int nb, hipStrea
 template <class S> void launch_select(const Dev<S>& d, int b0, int nb, hipStream_t st);
 // phase: 0 = stage 1 + merges, 1 = stage 1 only (chunk-local QR updates), 2 = merge tree only
 template <class S> void launch_compress(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase);
+// phase: 0 = both, 1 = Gram accumulation only, 2 = Cholesky only
+template <class S> void launch_gram(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase);
 template <class S> void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st);
 size_t feature_lds_bytes(int m_cap, size_t scalar);
 

@@ -47,6 +47,54 @@ __device__ __forceinline__ void ldlt3(const S A[6], S lam, const S b[3], S x[3])
   x[2] = y2; x[1] = y1 - l21 * x[2]; x[0] = y0 - l10 * x[1] - l20 * x[2];
 }
 
+// Householder QR of the 2M x 3 block H_f (rows 2*lane, 2*lane+1 live in this lane) as compact WY:
+// Q = I - V T V^T, V unit lower trapezoidal (row-local), T upper triangular.  hf is overwritten.
+template <class T>
+__device__ __forceinline__ void house3(T hf[2][3], int lane, T v[2][3], T Tm[3][3]) {
+  T tau[3];
+  const int row0 = 2 * lane;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    T t2 = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) if (row0 + s2 > k) t2 += hf[s2][k] * hf[s2][k];
+    t2 = wave_sum(t2);
+    const T c0 = wave_bcast(hf[k & 1][k], k >> 1);
+    T inv = 0;
+    if (t2 <= Lim<T>::tiny()) { tau[k] = 0; }
+    else {
+      T beta = dsqrt(c0 * c0 + t2);
+      if (c0 >= T(0)) beta = -beta;
+      inv = T(1) / (c0 - beta);
+      tau[k] = (beta - c0) / beta;
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int row = row0 + s2;
+      v[s2][k] = row > k ? hf[s2][k] * inv : (row == k ? T(1) : T(0));
+    }
+    // apply to the remaining columns of H_f
+#pragma unroll
+    for (int j = k + 1; j < 3; ++j) {
+      T s = v[0][k] * hf[0][j] + v[1][k] * hf[1][j];
+      s = wave_sum(s) * tau[k];
+      hf[0][j] -= s * v[0][k];
+      hf[1][j] -= s * v[1][k];
+    }
+  }
+  const T d01 = wave_sum(v[0][0] * v[0][1] + v[1][0] * v[1][1]);
+  const T d02 = wave_sum(v[0][0] * v[0][2] + v[1][0] * v[1][2]);
+  const T d12 = wave_sum(v[0][1] * v[0][2] + v[1][1] * v[1][2]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Tm[i][j] = 0;
+  Tm[0][0] = tau[0]; Tm[1][1] = tau[1]; Tm[2][2] = tau[2];
+  Tm[0][1] = -tau[1] * Tm[0][0] * d01;
+  Tm[0][2] = -tau[2] * (Tm[0][0] * d02 + Tm[0][1] * d12);
+  Tm[1][2] = -tau[2] * Tm[1][1] * d12;
+}
+
 template <class S>
 __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
   const int b = b0 + blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
@@ -226,47 +274,56 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
     for (int k = 0; k < 3; ++k) { hf[0][k] *= wu; hf[1][k] *= wv; }
   }
 
-  // ---- Householder QR of H_f_j (2M x 3): rows 2*lane, 2*lane+1 live in this lane
-  S v[2][3];      // V (unit lower trapezoidal), row-local
-  S tau[3];
-  const int row0 = 2 * lane;
+  // ---- information-form compression (compress == 1): B = Q_f^T [H_x | r] in f64.  H_o^T H_o = H_x^T H_x - B^T B
+  // holds to f64 rounding only when Q_f is orthonormal to f64 rounding, so the three reflectors are redone in
+  // f64 on the (float-rounded) H_f; the gate below keeps the S-precision reflectors.
+  double Bq[3][6], cq[3];
+  if (d.compress) {
+    double hfd[2][3], vd[2][3], Td[3][3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    S t2 = 0;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) if (row0 + s2 > k) t2 += hf[s2][k] * hf[s2][k];
-    t2 = wave_sum(t2);
-    const S c0 = wave_bcast(hf[k & 1][k], k >> 1);
-    S inv = 0;
-    if (t2 <= Lim<S>::tiny()) { tau[k] = 0; }
-    else {
-      S beta = dsqrt(c0 * c0 + t2);
-      if (c0 >= S(0)) beta = -beta;
-      inv = S(1) / (c0 - beta);
-      tau[k] = (beta - c0) / beta;
+      for (int k = 0; k < 3; ++k) hfd[i][k] = (double)hf[i][k];
+    house3<double>(hfd, lane, vd, Td);
+    double Zd[3][6], yd[3];
+    {
+      double Wc[3][6], wr[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Wc[q][k] = vd[0][q] * (double)hx[0][k] + vd[1][q] * (double)hx[1][k];
+        wr[q] = wave_sum(vd[0][q] * (double)r[0] + vd[1][q] * (double)r[1]);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { double a2 = 0; for (int p2 = 0; p2 <= q; ++p2) a2 += Td[p2][q] * Wc[p2][k]; Zd[q][k] = a2; }
+        double a3 = 0;
+        for (int p2 = 0; p2 <= q; ++p2) a3 += Td[p2][q] * wr[p2];
+        yd[q] = a3;
+      }
     }
+    // rows 0..2 of Q^T [H_x | r]: row i lives in lane i>>1 (row 0,1 -> lane 0, row 2 -> lane 1)
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const int row = row0 + s2;
-      v[s2][k] = row > k ? hf[s2][k] * inv : (row == k ? S(1) : S(0));
-    }
-    // apply to the remaining columns of H_f
+    for (int i = 0; i < 3; ++i) {
+      const int src = i >> 1, sr = i & 1;
+      double vi[3];
 #pragma unroll
-    for (int j = k + 1; j < 3; ++j) {
-      S s = v[0][k] * hf[0][j] + v[1][k] * hf[1][j];
-      s = wave_sum(s) * tau[k];
-      hf[0][j] -= s * v[0][k];
-      hf[1][j] -= s * v[1][k];
+      for (int q = 0; q < 3; ++q) vi[q] = wave_bcast(vd[sr][q], src);
+      const double ri = wave_bcast((double)r[sr], src);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const double own = (lane == src) ? (double)hx[sr][k] : 0.0;
+        Bq[i][k] = own - (vi[0] * Zd[0][k] + vi[1] * Zd[1][k] + vi[2] * Zd[2][k]);
+      }
+      cq[i] = ri - (vi[0] * yd[0] + vi[1] * yd[1] + vi[2] * yd[2]);
     }
   }
-  // compact WY: Q = I - V T V^T, T upper triangular (forward, columnwise)
-  const S d01 = wave_sum(v[0][0] * v[0][1] + v[1][0] * v[1][1]);
-  const S d02 = wave_sum(v[0][0] * v[0][2] + v[1][0] * v[1][2]);
-  const S d12 = wave_sum(v[0][1] * v[0][2] + v[1][1] * v[1][2]);
-  S Tm[3][3] = {{tau[0], 0, 0}, {0, tau[1], 0}, {0, 0, tau[2]}};
-  Tm[0][1] = -tau[1] * Tm[0][0] * d01;
-  Tm[0][2] = -tau[2] * (Tm[0][0] * d02 + Tm[0][1] * d12);
-  Tm[1][2] = -tau[2] * Tm[1][1] * d12;
+
+  // ---- Householder QR of H_f_j (2M x 3) in working precision: compact WY for the gate (and the QR compression)
+  S v[2][3], Tm[3][3];
+  const int row0 = 2 * lane;
+  house3<S>(hf, lane, v, Tm);
   // Z_c = T^T (V_rows^T Hx_c)  (3 x 6), local to the lane
   S Zc[3][6];
   {
@@ -454,21 +511,38 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
   // ---- publish the compact representation of the projected block
   {
     S* oHx = d.trk_Hx + (tb * m_cap) * 12;
-    S* oV = d.trk_V + (tb * 2 * m_cap) * 4;
-    S* oZ = d.trk_Zf + tb * 3 * (long)d.ldR;   // Z scattered to state columns: [3][ldR], zero where unobserved
-    S* oR = d.trk_ro + tb * 2 * m_cap;
-    if (act) {
-      for (int i = 0; i < 2; ++i) for (int k = 0; k < 6; ++k) oHx[lane * 12 + i * 6 + k] = hx[i][k];
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int row = row0 + s2;
-        oV[row * 4 + 0] = v[s2][0]; oV[row * 4 + 1] = v[s2][1]; oV[row * 4 + 2] = v[s2][2]; oV[row * 4 + 3] = 0;
-        oR[row] = qr[s2];   // (Q^T r)[row]; rows >= 3 are r_o
-      }
-    }
-    for (int e = lane; e < 3 * d.ldR; e += 64) oZ[e] = 0;
-    __syncthreads();
     if (act)
-      for (int q = 0; q < 3; ++q) for (int k = 0; k < 6; ++k) oZ[(long)q * d.ldR + 6 * slot + k] = Zc[q][k];
+      for (int i = 0; i < 2; ++i) for (int k = 0; k < 6; ++k) oHx[lane * 12 + i * 6 + k] = hx[i][k];
+    if (d.compress) {
+      // B scattered to state columns ([3][ldR] f64, zero where unobserved, column n = Q_f^T r), the whitened
+      // residual and the slot -> observation map for the block-diagonal part of the Gram matrix
+      double* oB = d.trk_B + tb * 3 * (long)d.ldR;
+      signed char* oI = d.trk_inv + tb * d.n_cap;
+      for (int e = lane; e < 3 * d.ldR; e += 64) oB[e] = 0.0;
+      for (int e = lane; e < d.n_cap; e += 64) oI[e] = -1;
+      __syncthreads();
+      if (act) {
+        for (int q = 0; q < 3; ++q) for (int k = 0; k < 6; ++k) oB[(long)q * d.ldR + 6 * slot + k] = Bq[q][k];
+        oI[slot] = (signed char)lane;
+        d.trk_rw[tb * 2 * m_cap + row0] = r[0]; d.trk_rw[tb * 2 * m_cap + row0 + 1] = r[1];
+      }
+      if (lane < 3) oB[(long)lane * d.ldR + 6 * d.ncam[b]] = lane == 0 ? cq[0] : (lane == 1 ? cq[1] : cq[2]);
+    } else {
+      S* oV = d.trk_V + (tb * 2 * m_cap) * 4;
+      S* oZ = d.trk_Zf + tb * 3 * (long)d.ldR;   // Z scattered to state columns: [3][ldR], zero where unobserved
+      S* oR = d.trk_ro + tb * 2 * m_cap;
+      if (act) {
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int row = row0 + s2;
+          oV[row * 4 + 0] = v[s2][0]; oV[row * 4 + 1] = v[s2][1]; oV[row * 4 + 2] = v[s2][2]; oV[row * 4 + 3] = 0;
+          oR[row] = qr[s2];   // (Q^T r)[row]; rows >= 3 are r_o
+        }
+      }
+      for (int e = lane; e < 3 * d.ldR; e += 64) oZ[e] = 0;
+      __syncthreads();
+      if (act)
+        for (int q = 0; q < 3; ++q) for (int k = 0; k < 6; ++k) oZ[(long)q * d.ldR + 6 * slot + k] = Zc[q][k];
+    }
     int fs = act ? slot : 0x7fffffff;
     fs = wave_min_i(fs);
     if (lane == 0) {

@@ -1,0 +1,235 @@
+// Information-form compression of the stacked, null-space-projected Jacobian.
+//
+// The reference stacks H_o (m x D, m ~ 5 800 at a 30-camera window) and reduces it with a Householder QR to
+// T_H (n x n), r_n = Q_1^T r_o  (msckf.h:1338-1366).  The update that follows depends on the stack only
+// through  H_o^T H_o  and  H_o^T r_o  (T_H^T T_H and T_H^T r_n), and for one track
+//     H_o_j^T H_o_j = H_x_j^T (I - Q_f Q_f^T) H_x_j = H_x_j^T H_x_j - B_j^T B_j ,   B_j = Q_f^T H_x_j  (3 x 6 M_j)
+// where H_x_j^T H_x_j is block diagonal (one 6 x 6 block per observing camera).  So
+//     Lam^ = [H_o | r_o]^T [H_o | r_o] = blockdiag(sum h^T h | sum h^T r) - sum_j [B_j | c_j]^T [B_j | c_j]
+// costs 3 n^2 flop per track instead of 2 rho_j n^2, and [T_H | r_n] is its Cholesky factor (R of the QR up to
+// the signs of its rows; rows of unobservable directions come out as zero rows, as they do in the QR up to rounding).
+// The subtraction cancels, so everything in this file runs in f64 whatever the filter's scalar type is: with the
+// reflectors of k_feature orthonormal to f64 rounding Lam^ is positive semi-definite to f64 rounding, and the float
+// filter loses nothing against the float QR (scripts/experiments/gram_vs_qr.py: same error vs the f64 result).
+//
+//   k_gram    SYRK sum B^T B on the f64 matrix cores (v_mfma_f64_16x16x4_f64), 64 x 64 upper tiles, tracks
+//             staged through LDS 8 at a time; extra workgroups reduce the block-diagonal part (one wavefront
+//             per camera slot, lanes over tracks)
+//   k_chol_T  register-resident right-looking Cholesky (16 x 16 thread grid, 2-D block-cyclic, one LDS exchange
+//             and one barrier per step) with semi-definite pivot skipping; writes [T | r_n] in the layout the
+//             Kalman stage reads
+#include "dev_common.h"
+
+namespace msckf {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int GK = 24;   // rows of B per staged chunk = 8 tracks
+
+template <class S>
+__global__ __launch_bounds__(256) void k_gram(Dev<S> d, int b0, int npairs) {
+  const int b = b0 + blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int* st = d.stats + (long)b * STAT_STRIDE;
+  if (st[STAT_MROWS] == 0) return;
+  const int P = st[STAT_PASSED];
+  const int N = d.ncam[b], n = 6 * N, ldL = d.ldR, f_cap = d.f_cap, m_cap = d.m_cap;
+  const int* order = d.trk_order + (long)b * f_cap;
+
+  if ((int)blockIdx.x >= npairs) {
+    // ---- block-diagonal part: wavefront = camera slot s, lanes over the gated-in tracks
+    const int s = 4 * ((int)blockIdx.x - npairs) + w;
+    if (s >= N) return;
+    double acc[27];
+#pragma unroll
+    for (int e = 0; e < 27; ++e) acc[e] = 0.0;
+    for (int p = lane; p < P; p += 64) {
+      const long tb = (long)b * f_cap + order[p];
+      const int i = d.trk_inv[tb * d.n_cap + s];
+      if (i < 0) continue;
+      const S* h = d.trk_Hx + (tb * m_cap + i) * 12;
+      const S* rw = d.trk_rw + tb * 2 * m_cap + 2 * i;
+      double h0[6], h1[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { h0[k] = (double)h[k]; h1[k] = (double)h[6 + k]; }
+      const double r0 = (double)rw[0], r1 = (double)rw[1];
+      int e = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = a; c < 6; ++c) acc[e++] += h0[a] * h0[c] + h1[a] * h1[c];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) acc[21 + a] += h0[a] * r0 + h1[a] * r1;
+    }
+    double* out = d.Dg + ((long)b * d.n_cap + s) * DG_STRIDE;
+#pragma unroll
+    for (int e = 0; e < 27; ++e) {
+      const double v = wave_sum(acc[e]);
+      if (lane == 0) out[e] = v;
+    }
+    return;
+  }
+
+  // ---- SYRK tile (ti <= tj)
+  int ti = 0, tj = 0;
+  {
+    int e = blockIdx.x;
+    const int nt = ldL / 64;
+    for (ti = 0; ti < nt; ++ti) { const int cnt = nt - ti; if (e < cnt) { tj = ti + e; break; } e -= cnt; }
+  }
+  if (64 * tj > n) return;
+  __shared__ double sA[GK][64], sB[GK][64];
+  const int KT = 3 * P;
+  const int lr = tid >> 6, lc = tid & 63;
+  const int wi = w & 1, wj = w >> 1;
+  double ra[GK / 4], rb[GK / 4];
+  auto fetch = [&](int kc) {
+#pragma unroll
+    for (int it = 0; it < GK / 4; ++it) {
+      const int kk = kc + lr + 4 * it;
+      double a = 0.0, bb = 0.0;
+      if (kk < KT) {
+        const int p = kk / 3, q = kk - 3 * p;
+        const double* row = d.trk_B + (((long)b * f_cap + order[p]) * 3 + q) * (long)ldL;
+        a = row[64 * ti + lc];
+        bb = row[64 * tj + lc];
+      }
+      ra[it] = a; rb[it] = bb;
+    }
+  };
+  v4d acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
+  fetch(0);
+  for (int kc = 0; kc < KT; kc += GK) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < GK / 4; ++it) { sA[lr + 4 * it][lc] = ra[it]; sB[lr + 4 * it][lc] = rb[it]; }
+    __syncthreads();
+    if (kc + GK < KT) fetch(kc + GK);
+#pragma unroll
+    for (int k4 = 0; k4 < GK; k4 += 4) {
+      const int kr = k4 + (lane >> 4), cc = lane & 15;
+      const double a0 = sA[kr][wi * 32 + cc], a1 = sA[kr][wi * 32 + 16 + cc];
+      const double c0 = sB[kr][wj * 32 + cc], c1 = sB[kr][wj * 32 + 16 + cc];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, c0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, c1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, c0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, c1, acc[1][1], 0, 0, 0);
+    }
+  }
+  double* Lam = d.Lam + (long)b * ldL * ldL;
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 64 * ti + wi * 32 + ib * 16 + (lane >> 4) + 4 * r;
+        const int j = 64 * tj + wj * 32 + jb * 16 + (lane & 15);
+        Lam[(long)i * ldL + j] = acc[ib][jb][r];
+      }
+}
+
+// [T | r_n] = chol(Lam^) with Lam^ = Dg - sum B^T B; element (i, j), i >= j, of the lower factor lives in thread
+// (i % 16, j % 16).  A pivot below 64 eps times its original diagonal belongs to a direction the stack carries no
+// information about (the gauge freedoms of the window): its row of T is set to zero.
+template <class S, int NBN>
+__global__ __launch_bounds__(256) void k_chol_T(Dev<S> d, int b0) {
+  constexpr int G = 16;
+  const int b = b0 + blockIdx.x, tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  int* st = d.stats + (long)b * STAT_STRIDE;
+  if (st[STAT_MROWS] == 0) return;
+  const int N = d.ncam[b], n = 6 * N, ldL = d.ldR;
+  const double* Lam = d.Lam + (long)b * ldL * ldL;
+  const double* Dg = d.Dg + (long)b * d.n_cap * DG_STRIDE;
+  __shared__ double sCol[2][G * NBN];
+  __shared__ double sD0[G * NBN];
+  double A[NBN][NBN];
+#pragma unroll
+  for (int a = 0; a < NBN; ++a)
+#pragma unroll
+    for (int bb = 0; bb < NBN; ++bb) {
+      if (a < bb) continue;
+      const int i = G * a + tx, j = G * bb + ty;
+      double val = 0.0;
+      if (i >= j && i <= n && j < n) {
+        val = -Lam[(long)j * ldL + i];
+        if (i == n) val += Dg[(j / 6) * DG_STRIDE + 21 + j % 6];
+        else if (i / 6 == j / 6) {
+          const int ii = i % 6, jj = j % 6;   // jj <= ii: upper-triangle index (jj, ii)
+          val += Dg[(i / 6) * DG_STRIDE + jj * 6 - jj * (jj - 1) / 2 + (ii - jj)];
+        }
+        if (i == j) sD0[i] = val;
+      }
+      A[a][bb] = val;
+    }
+  __syncthreads();
+  const double tol = 64.0 * 2.220446049250313e-16;
+  int nskip = 0, buf = 0;
+#pragma unroll
+  for (int kb = 0; kb < NBN; ++kb) {
+    const int kk_hi = min(G, n - G * kb);
+    for (int kk = 0; kk < kk_hi; ++kk) {
+      const int k = G * kb + kk;
+      if (ty == kk) {
+#pragma unroll
+        for (int a = kb; a < NBN; ++a) sCol[buf][G * a + tx] = A[a][kb];
+      }
+      __syncthreads();
+      const double dkk = sCol[buf][k];
+      const bool skip = !(dkk > tol * sD0[k]);
+      const double dd = skip ? 0.0 : sqrt(dkk);
+      const double dinv = skip ? 0.0 : 1.0 / dd;
+      nskip += skip ? 1 : 0;
+      double li[NBN], lj[NBN];
+#pragma unroll
+      for (int a = kb; a < NBN; ++a) li[a] = (a > kb || tx > kk) ? sCol[buf][G * a + tx] * dinv : 0.0;
+#pragma unroll
+      for (int bb = kb; bb < NBN; ++bb) lj[bb] = (bb > kb || ty > kk) ? sCol[buf][G * bb + ty] * dinv : 0.0;
+#pragma unroll
+      for (int a = kb; a < NBN; ++a)
+#pragma unroll
+        for (int bb = kb; bb <= a; ++bb) A[a][bb] -= li[a] * lj[bb];
+      if (ty == kk) {
+#pragma unroll
+        for (int a = kb; a < NBN; ++a) {
+          if (a > kb || tx > kk) A[a][kb] = li[a];
+          else if (a == kb && tx == kk) A[a][kb] = dd;
+        }
+      }
+      buf ^= 1;
+    }
+  }
+  // T[k][c] = L[c][k]: rows k < n, columns c <= n; zeros below the diagonal and in the padding columns
+  S* Rt = d.Rbuf + ((long)b * d.nchunk) * (long)d.n6cap * d.ldR;
+#pragma unroll
+  for (int a = 0; a < NBN; ++a)
+#pragma unroll
+    for (int bb = 0; bb < NBN; ++bb) {
+      const int i = G * a + tx, j = G * bb + ty;
+      if (j >= n || i >= d.ldR) continue;
+      double val = 0.0;
+      if (a >= bb) { if (i >= j && i <= n) val = A[a][bb]; }
+      Rt[(long)j * d.ldR + i] = (S)val;
+    }
+  if (tid == 0) st[STAT_RROWS] = n - nskip;
+}
+
+template <class S>
+void launch_gram(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase) {
+  if (nb <= 0) return;
+  const int nt = d.ldR / 64, npairs = nt * (nt + 1) / 2, ndiag = (d.n_cap + 3) / 4;
+  if (phase != 2) hipLaunchKernelGGL(k_gram<S>, dim3(npairs + ndiag, nb), dim3(256), 0, st, d, b0, npairs);
+  if (phase == 1) return;
+  switch (d.ldR / 16) {
+    case 4: hipLaunchKernelGGL((k_chol_T<S, 4>), dim3(nb), dim3(256), 0, st, d, b0); break;
+    case 8: hipLaunchKernelGGL((k_chol_T<S, 8>), dim3(nb), dim3(256), 0, st, d, b0); break;
+    default: hipLaunchKernelGGL((k_chol_T<S, 12>), dim3(nb), dim3(256), 0, st, d, b0); break;
+  }
+}
+
+template void launch_gram<float>(const Dev<float>&, int, int, hipStream_t, int);
+template void launch_gram<double>(const Dev<double>&, int, int, hipStream_t, int);
+
+}  // namespace msckf

@@ -19,6 +19,8 @@
 #include "../../include/msckf_hip.h"
 #include "dev_common.h"
 
+namespace msckf { int g_compress_override = -1; }   // experiment knob (msckf_hip_debug_set(100, .))
+
 namespace {
 using namespace msckf;
 
@@ -139,6 +141,12 @@ struct Batch : BatchBase {
     rc |= dalloc(&d.trk_ro, TF * 2 * m_cap); rc |= dalloc(&d.trk_first, TF);
     rc |= dalloc(&d.row_start, Bz * (f_cap + 1)); rc |= dalloc(&d.trk_order, TF); rc |= dalloc(&d.stats, Bz * STAT_STRIDE);
     rc |= dalloc(&d.Rbuf, Bz * d.nchunk * (size_t)d.n6cap * d.ldR);
+    // information-form compression (kernels_gram.hip): the register-resident Cholesky covers n + 1 <= 192
+    d.compress = d.ldR <= 192 ? 1 : 0;
+    if (d.compress) {
+      rc |= dalloc(&d.trk_B, TF * 3 * (size_t)d.ldR); rc |= dalloc(&d.trk_rw, TF * 2 * m_cap); rc |= dalloc(&d.trk_inv, TF * n_cap);
+      rc |= dalloc(&d.Dg, Bz * n_cap * DG_STRIDE); rc |= dalloc(&d.Lam, Bz * (size_t)d.ldR * d.ldR);
+    }
     rc |= dalloc(&d.PHt, Bz * dn); rc |= dalloc(&d.Smat, Bz * nl); rc |= dalloc(&d.Linv, Bz * nl); rc |= dalloc(&d.W, Bz * dn);
     rc |= dalloc(&d.K, Bz * dn); rc |= dalloc(&d.A, Bz * pl); rc |= dalloc(&d.AP, Bz * pl); rc |= dalloc(&d.X, Bz * pl); rc |= dalloc(&d.dx, Bz * d.ld);
     rc |= dalloc(&d.keep, Bz * n_cap); rc |= dalloc(&d.nkeep, Bz);
@@ -272,12 +280,19 @@ struct Batch : BatchBase {
     traj[b].wl_F = F;
     return 0;
   }
-  void launch_update(const Dev<S>& v, int b0, int nb) {
+  void launch_update(const Dev<S>& vin, int b0, int nb) {
+    Dev<S> v = vin;
+    if (g_compress_override >= 0) v.compress = (g_compress_override && d.trk_B) ? 1 : 0;
     stage_begin(2); launch_feature<S>(v, b0, nb, st); launch_select<S>(v, b0, nb, st); stage_end(2);
     launch_compress_profiled(v, b0, nb);
     stage_begin(5); launch_kalman<S>(v, b0, nb, st); stage_end(5);
   }
   void launch_compress_profiled(const Dev<S>& v, int b0, int nb) {
+    if (v.compress) {
+      stage_begin(3); launch_gram<S>(v, b0, nb, st, 1); stage_end(3);
+      stage_begin(4); launch_gram<S>(v, b0, nb, st, 2); stage_end(4);
+      return;
+    }
     stage_begin(3); launch_compress<S>(v, b0, nb, st, 1); stage_end(3);
     stage_begin(4); launch_compress<S>(v, b0, nb, st, 2); stage_end(4);
   }
@@ -874,7 +889,11 @@ namespace msckf { void qr_debug_set(int idx, int val); }
 extern "C" {
 
 // experiment knob, not part of the ABI (include/msckf_hip.h does not declare it)
-void msckf_hip_debug_set(int idx, int val) { msckf::qr_debug_set(idx, val); }
+// idx 100: compression route (0 = Householder TSQR, 1 = information form, -1 = default); others: QR ablations
+void msckf_hip_debug_set(int idx, int val) {
+  if (idx == 100) { msckf::g_compress_override = val; return; }
+  msckf::qr_debug_set(idx, val);
+}
 
 const char* msckf_hip_last_error(void) { return g_err.c_str(); }
 
