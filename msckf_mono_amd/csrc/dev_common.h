@@ -183,20 +183,51 @@ __device__ __forceinline__ double wave_bcast(double v, int lane) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 __device__ __forceinline__ int wave_bcast(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-template <class S> __device__ __forceinline__ S wave_sum(S v) {  // xor butterfly: every lane gets the same sum
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// Wave-wide reductions on the DPP network instead of ds_bpermute shuffles: a reduction is four DPP steps inside the
+// rows of 16 lanes (quad swaps, half-row mirror, row mirror: every lane of a row ends up with the row's result)
+// plus one v_readlane per row.  A dependent chain of 6 LDS-crossbar round trips becomes ~10 short VALU ops; the
+// summation order is fixed, every lane gets the same value.
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <int CTRL> __device__ __forceinline__ float dpp_x(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
+template <int CTRL> __device__ __forceinline__ double dpp_x(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = dpp_i<CTRL>((int)(b & 0xffffffffLL)), hi = dpp_i<CTRL>((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int CTRL> __device__ __forceinline__ int dpp_x(int v) { return dpp_i<CTRL>(v); }
+constexpr int DPP_QUAD_X1 = 0xB1, DPP_QUAD_X2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+
+template <class S> __device__ __forceinline__ S wave_sum(S v) {
+  v += dpp_x<DPP_QUAD_X1>(v); v += dpp_x<DPP_QUAD_X2>(v); v += dpp_x<DPP_HALF_MIRROR>(v); v += dpp_x<DPP_ROW_MIRROR>(v);
+  return (wave_bcast(v, 0) + wave_bcast(v, 16)) + (wave_bcast(v, 32) + wave_bcast(v, 48));
 }
 template <class S> __device__ __forceinline__ S wave_max(S v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { S t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
-  return v;
+  S t;
+  t = dpp_x<DPP_QUAD_X1>(v); v = t > v ? t : v; t = dpp_x<DPP_QUAD_X2>(v); v = t > v ? t : v;
+  t = dpp_x<DPP_HALF_MIRROR>(v); v = t > v ? t : v; t = dpp_x<DPP_ROW_MIRROR>(v); v = t > v ? t : v;
+  const S a = wave_bcast(v, 0), b = wave_bcast(v, 16), c = wave_bcast(v, 32), e = wave_bcast(v, 48);
+  const S ab = a > b ? a : b, ce = c > e ? c : e;
+  return ab > ce ? ab : ce;
 }
 __device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
-  return v;
+  int t;
+  t = dpp_x<DPP_QUAD_X1>(v); v = t < v ? t : v; t = dpp_x<DPP_QUAD_X2>(v); v = t < v ? t : v;
+  t = dpp_x<DPP_HALF_MIRROR>(v); v = t < v ? t : v; t = dpp_x<DPP_ROW_MIRROR>(v); v = t < v ? t : v;
+  return min(min(wave_bcast(v, 0), wave_bcast(v, 16)), min(wave_bcast(v, 32), wave_bcast(v, 48)));
+}
+
+// 1/sqrt(x) for the pivots of the register-resident factorizations: hardware rsq seed + Newton steps instead of the
+// IEEE sqrt and division sequences (the pivot sits on the critical path of every elimination step)
+template <class S> __device__ __forceinline__ S fast_rsqrt(S x);
+template <> __device__ __forceinline__ float fast_rsqrt<float>(float x) {
+  const float r = __builtin_amdgcn_rsqf(x);
+  return r * (1.5f - 0.5f * x * r * r);
+}
+template <> __device__ __forceinline__ double fast_rsqrt<double>(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r + 0.5 * r * (1.0 - x * r * r);
+  r = r + 0.5 * r * (1.0 - x * r * r);
+  return r;
 }
 
 template <class S> struct Lim;

@@ -22,6 +22,7 @@ namespace msckf {
 
 __constant__ double c_chi2[99];
 static bool g_chi2_uploaded[16] = {false};
+__device__ int g_feat_dbg = 0;   // ablation knob (msckf_hip_debug_set(200, .)); zero in production
 
 template <class S> struct Pose { M3<S> R; V3<S> t; };
 
@@ -102,9 +103,12 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
   if (t >= F) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int m_cap = d.m_cap;
-  const int ldg = 2 * m_cap + 1;
-  S* sG = reinterpret_cast<S*>(smem_raw);              // [(2 m_cap + 1)][ldg]
-  S* sHx = sG + (2 * m_cap + 1) * ldg;                 // [m_cap][12]
+  // G (symmetric, 2M x 2M) plus the appended r_o row 2M as a packed lower triangle: element (i, j), j <= i, at TRI(i, j)
+#define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
+#define SYM(i, j) ((i) >= (j) ? TRI(i, j) : TRI(j, i))
+  S* sC = reinterpret_cast<S*>(smem_raw);              // [2][64] pivot-column exchange of the register Cholesky
+  S* sG = sC + 128;                                    // [(2 m_cap + 1)(2 m_cap + 2) / 2]
+  S* sHx = sG + (2 * m_cap + 1) * (2 * m_cap + 2) / 2; // [m_cap][12]
   S* sV = sHx + m_cap * 12;                            // [2 m_cap][3]
   S* sE = sV + 2 * m_cap * 3;                          // [2 m_cap][3]
   int* sSlot = reinterpret_cast<int*>(sE + 2 * m_cap * 3);
@@ -176,7 +180,8 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
   S total_cost = wave_sum(act ? tri_cost(T, sa, sb, srho, zx, zy) : S(0));
   bool reduced = false;
   int inner = 0, outer = 0;
-  if (!given) do {
+  const int fdbg = g_feat_dbg;
+  if (!given && !(fdbg & 1)) do {
     S Ab[9];  // a00 a01 a02 a11 a12 a22 b0 b1 b2
     {
       const V3<S> h = mulv(T.R, mk3(sa, sb, S(1))) + (srho * T.t);
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
   // holds to f64 rounding only when Q_f is orthonormal to f64 rounding, so the three reflectors are redone in
   // f64 on the (float-rounded) H_f; the gate below keeps the S-precision reflectors.
   double Bq[3][6], cq[3];
-  if (d.compress) {
+  if (d.compress && !(fdbg & 8)) {
     double hfd[2][3], vd[2][3], Td[3][3];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -365,14 +370,13 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
       S Tt[2][6];
       for (int j = 0; j < 6; ++j) {
         S s0 = 0, s1 = 0;
-        for (int i = 0; i < 6; ++i) { const S pv = Pab[(long)j * ld + i]; s0 += sHx[a * 12 + i] * pv; s1 += sHx[a * 12 + 6 + i] * pv; }
+        for (int i = 0; i < 6; ++i) { const S pv = (fdbg & 2) ? S(i == j ? 1e-4 : 0) : Pab[(long)j * ld + i]; s0 += sHx[a * 12 + i] * pv; s1 += sHx[a * 12 + 6 + i] * pv; }
         Tt[0][j] = s0; Tt[1][j] = s1;
       }
       for (int rr = 0; rr < 2; ++rr) for (int cc = 0; cc < 2; ++cc) {
         S s = 0;
         for (int j = 0; j < 6; ++j) s += Tt[rr][j] * sHx[bq * 12 + cc * 6 + j];
-        sG[(2 * a + rr) * ldg + 2 * bq + cc] = s;
-        if (a != bq) sG[(2 * bq + cc) * ldg + 2 * a + rr] = s;
+        if (a != bq || rr <= cc) sG[TRI(2 * bq + cc, 2 * a + rr)] = s;     // a <= bq: row 2bq+cc >= column 2a+rr
       }
     }
   }
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
     for (int s2 = 0; s2 < 2; ++s2) {
       const int row = row0 + s2;
       S a0 = 0, a1 = 0, a2 = 0;
-      if (row < R2) for (int c = 0; c < R2; ++c) { const S gval = sG[row * ldg + c]; a0 += gval * sV[c * 3]; a1 += gval * sV[c * 3 + 1]; a2 += gval * sV[c * 3 + 2]; }
+      if (row < R2) for (int c = 0; c < R2; ++c) { const S gval = sG[SYM(row, c)]; a0 += gval * sV[c * 3]; a1 += gval * sV[c * 3 + 1]; a2 += gval * sV[c * 3 + 2]; }
       gv[s2][0] = a0; gv[s2][1] = a1; gv[s2][2] = a2;
     }
     S vgv[3][3];
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
         }
     }
     // r_o rides along as the extra row 2M of the factorisation
-    for (int s2 = 0; s2 < 2; ++s2) { const int row = row0 + s2; if (row >= 3 && row < R2) sG[R2 * ldg + row] = qr[s2]; }
+    for (int s2 = 0; s2 < 2; ++s2) { const int row = row0 + s2; if (row >= 3 && row < R2) sG[TRI(R2, row)] = qr[s2]; }
   }
   __syncthreads();
   // ---- S = (Q^T G Q)[3:,3:] + sigma^2 I, Cholesky with the r_o row appended, gamma = |L^-1 r_o|^2
@@ -409,7 +413,8 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
   bool spd = true;
   S gamma = 0;
   (void)0;
-  if (rho + 1 <= 64) {
+  if (fdbg & 4) { gamma = 0; }
+  else if (rho + 1 <= 64) {
     // register-resident: the wavefront is an 8 x 8 grid, lane (tx,ty) owns elements (8a+tx, 8b+ty) of the
     // (rho+1) x rho lower trapezoid; one LDS exchange of the pivot column per step, no workgroup barrier
     constexpr int NB = 8;
@@ -435,17 +440,17 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
         const int i = 8 * a2 + tx;
         S val = 0;
         if (okj && i < rho) {
-          val = sG[(3 + i) * ldg + 3 + j] - (vr[a2][0] * ec[0] + vr[a2][1] * ec[1] + vr[a2][2] * ec[2])
+          val = sG[SYM(3 + i, 3 + j)] - (vr[a2][0] * ec[0] + vr[a2][1] * ec[1] + vr[a2][2] * ec[2])
                 - (er[a2][0] * vc[0] + er[a2][1] * vc[1] + er[a2][2] * vc[2]);
           if (i == j) val += sig2;
         } else if (okj && i == rho) {
-          val = sG[R2 * ldg + 3 + j];            // appended row: r_o
+          val = sG[TRI(R2, 3 + j)];            // appended row: r_o
         }
         A[a2][b2] = val;
       }
     }
     __syncthreads();
-    S* sC = sG;    // reuse: pivot column exchange, 2 x 64 entries laid out [buf][tx*8 + a]
+    // pivot column exchange through sC, 2 x 64 entries laid out [buf][tx*8 + a]
     int bufc = 0;
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
         __syncthreads();
         const S dkk = sC[bufc * 64 + kk * 8 + kb];
         if (!(dkk > S(0))) { spd = false; break; }
-        const S dinv = S(1) / dsqrt(dkk);
+        const S dinv = fast_rsqrt(dkk);
         S li[NB], lj[NB];
 #pragma unroll
         for (int a2 = kb; a2 < NB; ++a2) li[a2] = (a2 > kb || tx > kk) ? sC[bufc * 64 + tx * 8 + a2] * dinv : S(0);
@@ -482,27 +487,27 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
       const S vi0 = sV[i * 3], vi1 = sV[i * 3 + 1], vi2 = sV[i * 3 + 2];
       const S ei0 = sE[i * 3], ei1 = sE[i * 3 + 1], ei2 = sE[i * 3 + 2];
       for (int j = 3; j <= i; ++j) {
-        S sv = sG[i * ldg + j] - (vi0 * sE[j * 3] + vi1 * sE[j * 3 + 1] + vi2 * sE[j * 3 + 2])
+        S sv = sG[TRI(i, j)] - (vi0 * sE[j * 3] + vi1 * sE[j * 3 + 1] + vi2 * sE[j * 3 + 2])
                - (ei0 * sV[j * 3] + ei1 * sV[j * 3 + 1] + ei2 * sV[j * 3 + 2]);
         if (i == j) sv += sig2;
-        sG[i * ldg + j] = sv;
+        sG[TRI(i, j)] = sv;
       }
     }
     __syncthreads();
     for (int k = 3; k < R2; ++k) {
-      const S dkk = sG[k * ldg + k];
+      const S dkk = sG[TRI(k, k)];
       if (!(dkk > S(0))) { spd = false; break; }
       const S dinv = S(1) / dsqrt(dkk);
-      for (int i = k + 1 + lane; i <= R2; i += 64) sG[i * ldg + k] *= dinv;
+      for (int i = k + 1 + lane; i <= R2; i += 64) sG[TRI(i, k)] *= dinv;
       __syncthreads();
       for (int i = k + 1 + lane; i <= R2; i += 64) {
-        const S lik = sG[i * ldg + k];
+        const S lik = sG[TRI(i, k)];
         const int jmax = i < R2 ? i : R2 - 1;
-        for (int j = k + 1; j <= jmax; ++j) sG[i * ldg + j] -= lik * sG[j * ldg + k];
+        for (int j = k + 1; j <= jmax; ++j) sG[TRI(i, j)] -= lik * sG[TRI(j, k)];
       }
       __syncthreads();
     }
-    for (int k = 3 + lane; k < R2; k += 64) { const S y = sG[R2 * ldg + k]; gamma += y * y; }
+    for (int k = 3 + lane; k < R2; k += 64) { const S y = sG[TRI(R2, k)]; gamma += y * y; }
     gamma = wave_sum(gamma);
   }
   const S thresh = S(c_chi2[M < 98 ? M : 98]);   // table[dof+1], dof = M-1   (:433, :1117)
@@ -666,8 +671,8 @@ __global__ __launch_bounds__(64) void k_select(Dev<S> d, int b0, int nb) {
 }
 
 size_t feature_lds_bytes(int m_cap, size_t scalar) {
-  const size_t ldg = 2 * (size_t)m_cap + 1;
-  return ((2 * (size_t)m_cap + 1) * ldg + (size_t)m_cap * 12 + 2 * (size_t)m_cap * 3 * 2) * scalar + (size_t)m_cap * sizeof(int) + 16;
+  const size_t r2 = 2 * (size_t)m_cap + 1;
+  return (128 + r2 * (r2 + 1) / 2 + (size_t)m_cap * 12 + 2 * (size_t)m_cap * 3 * 2) * scalar + (size_t)m_cap * sizeof(int) + 16;
 }
 
 template <class S>
@@ -688,6 +693,8 @@ void launch_feature(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   }
   hipLaunchKernelGGL(k_feature<S>, dim3(d.f_cap, nb), dim3(64), lds, st, d, b0);
 }
+void feat_debug_set(int val) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_feat_dbg), &val, sizeof(int)); }
+
 template <class S>
 void launch_select(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0) return;

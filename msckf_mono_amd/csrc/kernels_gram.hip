@@ -22,11 +22,14 @@
 
 namespace msckf {
 
+int g_gram_dbg = 0;   // ablation knob (msckf_hip_debug_set(300, .)); zero in production
+
 typedef double v4d __attribute__((ext_vector_type(4)));
-constexpr int GK = 24;   // rows of B per staged chunk = 8 tracks
+constexpr int GK = 48;   // rows of B per staged chunk = 16 tracks
+constexpr int GORD = 1024; // track order staged in LDS (f_cap <= GORD on this route)
 
 template <class S>
-__global__ __launch_bounds__(256) void k_gram(Dev<S> d, int b0, int npairs) {
+__global__ __launch_bounds__(256) void k_gram(Dev<S> d, int b0, int npairs, int dbg) {
   const int b = b0 + blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int* st = d.stats + (long)b * STAT_STRIDE;
   if (st[STAT_MROWS] == 0) return;
@@ -37,7 +40,7 @@ __global__ __launch_bounds__(256) void k_gram(Dev<S> d, int b0, int npairs) {
   if ((int)blockIdx.x >= npairs) {
     // ---- block-diagonal part: wavefront = camera slot s, lanes over the gated-in tracks
     const int s = 4 * ((int)blockIdx.x - npairs) + w;
-    if (s >= N) return;
+    if (s >= N || (dbg & 1)) return;
     double acc[27];
 #pragma unroll
     for (int e = 0; e < 27; ++e) acc[e] = 0.0;
@@ -77,22 +80,27 @@ __global__ __launch_bounds__(256) void k_gram(Dev<S> d, int b0, int npairs) {
   }
   if (64 * tj > n) return;
   __shared__ double sA[GK][64], sB[GK][64];
+  __shared__ int sOrd[GORD];
+  for (int e = tid; e < P && e < GORD; e += 256) sOrd[e] = order[e];
+  __syncthreads();
   const int KT = 3 * P;
   const int lr = tid >> 6, lc = tid & 63;
   const int wi = w & 1, wj = w >> 1;
   double ra[GK / 4], rb[GK / 4];
+  // branch-free: rows past the end are clamped to the last row and masked, so that all 2*GK/4 loads of a chunk
+  // are in flight together (a conditional per row makes the compiler drain vmcnt between them)
   auto fetch = [&](int kc) {
+    const double* rows[GK / 4];
 #pragma unroll
     for (int it = 0; it < GK / 4; ++it) {
-      const int kk = kc + lr + 4 * it;
-      double a = 0.0, bb = 0.0;
-      if (kk < KT) {
-        const int p = kk / 3, q = kk - 3 * p;
-        const double* row = d.trk_B + (((long)b * f_cap + order[p]) * 3 + q) * (long)ldL;
-        a = row[64 * ti + lc];
-        bb = row[64 * tj + lc];
-      }
-      ra[it] = a; rb[it] = bb;
+      const int kk = min(kc + lr + 4 * it, KT - 1);
+      const int p = kk / 3, q = kk - 3 * p;
+      const int t = sOrd[min(p, GORD - 1)];
+      rows[it] = d.trk_B + (((long)b * f_cap + t) * 3 + q) * (long)ldL;
+    }
+#pragma unroll
+    for (int it = 0; it < GK / 4; ++it) {
+      ra[it] = rows[it][64 * ti + lc]; rb[it] = rows[it][64 * tj + lc];   // masked when stored to LDS
     }
   };
   v4d acc[2][2];
@@ -104,9 +112,13 @@ __global__ __launch_bounds__(256) void k_gram(Dev<S> d, int b0, int npairs) {
   for (int kc = 0; kc < KT; kc += GK) {
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < GK / 4; ++it) { sA[lr + 4 * it][lc] = ra[it]; sB[lr + 4 * it][lc] = rb[it]; }
+    for (int it = 0; it < GK / 4; ++it) {
+      const bool ok = kc + lr + 4 * it < KT;
+      sA[lr + 4 * it][lc] = ok ? ra[it] : 0.0; sB[lr + 4 * it][lc] = ok ? rb[it] : 0.0;
+    }
     __syncthreads();
-    if (kc + GK < KT) fetch(kc + GK);
+    if (kc + GK < KT && !(dbg & 2)) fetch(kc + GK);
+    if (!(dbg & 4))
 #pragma unroll
     for (int k4 = 0; k4 < GK; k4 += 4) {
       const int kr = k4 + (lane >> 4), cc = lane & 15;
@@ -179,8 +191,8 @@ __global__ __launch_bounds__(256) void k_chol_T(Dev<S> d, int b0) {
       __syncthreads();
       const double dkk = sCol[buf][k];
       const bool skip = !(dkk > tol * sD0[k]);
-      const double dd = skip ? 0.0 : sqrt(dkk);
-      const double dinv = skip ? 0.0 : 1.0 / dd;
+      const double dinv = skip ? 0.0 : fast_rsqrt(dkk);
+      const double dd = dkk * dinv;
       nskip += skip ? 1 : 0;
       double li[NBN], lj[NBN];
 #pragma unroll
@@ -220,7 +232,7 @@ template <class S>
 void launch_gram(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase) {
   if (nb <= 0) return;
   const int nt = d.ldR / 64, npairs = nt * (nt + 1) / 2, ndiag = (d.n_cap + 3) / 4;
-  if (phase != 2) hipLaunchKernelGGL(k_gram<S>, dim3(npairs + ndiag, nb), dim3(256), 0, st, d, b0, npairs);
+  if (phase != 2) hipLaunchKernelGGL(k_gram<S>, dim3(npairs + ndiag, nb), dim3(256), 0, st, d, b0, npairs, g_gram_dbg);
   if (phase == 1) return;
   switch (d.ldR / 16) {
     case 4: hipLaunchKernelGGL((k_chol_T<S, 4>), dim3(nb), dim3(256), 0, st, d, b0); break;

@@ -302,8 +302,9 @@ __global__ __launch_bounds__(256) void k_gain(Dev<S> d, int b0) {
       }
       __syncthreads();
       const S dkk = sCol[buf][k];
-      const S dd = dsqrt(dkk > S(0) ? dkk : Lim<S>::tiny());
-      const S dinv = S(1) / dd;
+      const S dpos = dkk > S(0) ? dkk : Lim<S>::tiny();
+      const S dinv = fast_rsqrt(dpos);
+      const S dd = dpos * dinv;
       S li[NBN], lj[NBN], wi[NBD];
 #pragma unroll
       for (int a = kb; a < NBN; ++a) li[a] = (a > kb || tx > kk) ? sCol[buf][G * a + tx] * dinv : S(0);
@@ -442,8 +443,9 @@ __global__ __launch_bounds__(256) void k_gain_split(Dev<S> d, int b0) {
       }
       __syncthreads();
       const S dkk = sCol[buf][k];
-      const S dd = dsqrt(dkk > S(0) ? dkk : Lim<S>::tiny());
-      const S dinv = S(1) / dd;
+      const S dpos = dkk > S(0) ? dkk : Lim<S>::tiny();
+      const S dinv = fast_rsqrt(dpos);
+      const S dd = dpos * dinv;
       S li[NBN], lj[NBN], wi[NBQ];
 #pragma unroll
       for (int a = kb; a < NBN; ++a) li[a] = (a > kb || tx > kk) ? sCol[buf][G * a + tx] * dinv : S(0);

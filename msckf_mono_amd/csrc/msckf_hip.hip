@@ -142,7 +142,7 @@ struct Batch : BatchBase {
     rc |= dalloc(&d.row_start, Bz * (f_cap + 1)); rc |= dalloc(&d.trk_order, TF); rc |= dalloc(&d.stats, Bz * STAT_STRIDE);
     rc |= dalloc(&d.Rbuf, Bz * d.nchunk * (size_t)d.n6cap * d.ldR);
     // information-form compression (kernels_gram.hip): the register-resident Cholesky covers n + 1 <= 192
-    d.compress = d.ldR <= 192 ? 1 : 0;
+    d.compress = (d.ldR <= 192 && f_cap <= 1024) ? 1 : 0;
     if (d.compress) {
       rc |= dalloc(&d.trk_B, TF * 3 * (size_t)d.ldR); rc |= dalloc(&d.trk_rw, TF * 2 * m_cap); rc |= dalloc(&d.trk_inv, TF * n_cap);
       rc |= dalloc(&d.Dg, Bz * n_cap * DG_STRIDE); rc |= dalloc(&d.Lam, Bz * (size_t)d.ldR * d.ldR);
@@ -884,7 +884,7 @@ int host_finish(BatchBase* B, int b) {
 BatchBase* H(msckf_hip_handle h) { return reinterpret_cast<BatchBase*>(h); }
 }  // namespace
 
-namespace msckf { void qr_debug_set(int idx, int val); }
+namespace msckf { void qr_debug_set(int idx, int val); void feat_debug_set(int val); extern int g_gram_dbg; }
 
 extern "C" {
 
@@ -892,6 +892,8 @@ extern "C" {
 // idx 100: compression route (0 = Householder TSQR, 1 = information form, -1 = default); others: QR ablations
 void msckf_hip_debug_set(int idx, int val) {
   if (idx == 100) { msckf::g_compress_override = val; return; }
+  if (idx == 200) { msckf::feat_debug_set(val); return; }
+  if (idx == 300) { msckf::g_gram_dbg = val; return; }
   msckf::qr_debug_set(idx, val);
 }
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd SQLite database (kernel-trace) into a per-kernel table: calls, total / average
-/ min / max duration.  Usage: rocpd_summary.py results.db [out.md]"""
+/ min / max duration.  Usage: rocpd_summary.py results.db [out.md]
+With ROCPD_TAIL=K only the last K launches of every kernel are counted (the steady-state window of bench.py)."""
 import re
 import sqlite3
 import sys
@@ -10,11 +11,19 @@ def main():
     db = sqlite3.connect(sys.argv[1])
     cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
-    rows = db.execute("select %s, start, end from kernels" % name_col).fetchall()
+    import os
+    rows = db.execute("select %s, start, end from kernels order by start" % name_col).fetchall()
+    rows = [(re.sub(r"^void ", "", re.sub(r"\(.*$", "", nm)), s, e) for nm, s, e in rows]
+    tail = int(os.environ.get("ROCPD_TAIL", "0"))
+    if tail:
+        seen, keep = {}, []
+        for r in reversed(rows):
+            if seen.get(r[0], 0) < tail:
+                seen[r[0]] = seen.get(r[0], 0) + 1
+                keep.append(r)
+        rows = keep
     agg = {}
     for name, s, e in rows:
-        name = re.sub(r"\(.*$", "", name)
-        name = re.sub(r"^void ", "", name)
         a = agg.setdefault(name, [0, 0, 1 << 62, 0])
         d = e - s
         a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
