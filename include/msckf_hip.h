@@ -118,8 +118,8 @@ int msckf_hip_sync(msckf_hip_handle h);
  * stages 0 propagate, 1 augment, 2 feature+select, 3 compress stage 1, 4 compress merge, 5 kalman, 6 prune */
 int msckf_hip_profile_enable(msckf_hip_handle h, int on);
 int msckf_hip_profile_read(msckf_hip_handle h, double* ms7, int* count7);
-/* run_frames on n = 1 or 2 HIP streams: with 2, the two halves of the batch (independent trajectories) run the
- * same kernel sequence concurrently so that latency-bound stages overlap with chip-filling ones */
+/* run_frames on n = 1..8 HIP streams: the batch is cut into n slices of independent trajectories that run the
+ * same kernel sequence concurrently (latency-bound stages of one slice overlap chip-filling stages of another). */
 int msckf_hip_set_streams(msckf_hip_handle h, int n);
 
 #ifdef __cplusplus

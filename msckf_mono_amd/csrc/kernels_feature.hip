@@ -96,6 +96,88 @@ __device__ __forceinline__ void house3(T hf[2][3], int lane, T v[2][3], T Tm[3][
   Tm[1][2] = -tau[2] * Tm[1][1] * d12;
 }
 
+// packed lower triangle: element (i, j), j <= i
+#define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
+#define SYM(i, j) ((i) >= (j) ? TRI(i, j) : TRI(j, i))
+
+// Register-resident Cholesky of S = (Q^T G Q)[3:,3:] + sigma^2 I with the r_o row appended: the wavefront is an
+// 8 x 8 lane grid, lane (tx,ty) owns elements (8a+tx, 8b+ty) of the (rho+1) x rho lower trapezoid, NB = number of
+// 8 x 8 blocks in use (compile-time: a short track runs a proportionally shorter instruction stream).  One LDS
+// exchange of the pivot column per step.  Returns false when a pivot is not positive; gamma = |L^-1 r_o|^2.
+template <class S, int NB>
+__device__ __forceinline__ bool gate_chol(const S* sG, const S* sV, const S* sE, S* sC, int lane, int rho, int R2, S sig2, S& gamma) {
+  bool spd = true;
+  {
+    // register-resident: the wavefront is an 8 x 8 grid, lane (tx,ty) owns elements (8a+tx, 8b+ty) of the
+    // (rho+1) x rho lower trapezoid; one LDS exchange of the pivot column per step, no workgroup barrier
+    const int tx = lane & 7, ty = lane >> 3;
+    S A[NB][NB];
+    S vr[NB][3], er[NB][3];
+#pragma unroll
+    for (int a2 = 0; a2 < NB; ++a2) {
+      const int i = 8 * a2 + tx;
+      const bool ok = i < rho;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { vr[a2][q] = ok ? sV[(3 + i) * 3 + q] : S(0); er[a2][q] = ok ? sE[(3 + i) * 3 + q] : S(0); }
+    }
+#pragma unroll
+    for (int b2 = 0; b2 < NB; ++b2) {
+      const int j = 8 * b2 + ty;
+      const bool okj = j < rho;
+      S vc[3], ec[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { vc[q] = okj ? sV[(3 + j) * 3 + q] : S(0); ec[q] = okj ? sE[(3 + j) * 3 + q] : S(0); }
+#pragma unroll
+      for (int a2 = b2; a2 < NB; ++a2) {
+        const int i = 8 * a2 + tx;
+        S val = 0;
+        if (okj && i < rho) {
+          val = sG[SYM(3 + i, 3 + j)] - (vr[a2][0] * ec[0] + vr[a2][1] * ec[1] + vr[a2][2] * ec[2])
+                - (er[a2][0] * vc[0] + er[a2][1] * vc[1] + er[a2][2] * vc[2]);
+          if (i == j) val += sig2;
+        } else if (okj && i == rho) {
+          val = sG[TRI(R2, 3 + j)];            // appended row: r_o
+        }
+        A[a2][b2] = val;
+      }
+    }
+    __syncthreads();
+    // pivot column exchange through sC, 2 x 64 entries laid out [buf][tx*8 + a]
+    int bufc = 0;
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+      const int kk_hi = min(8, rho - 8 * kb);
+      for (int kk = 0; kk < kk_hi; ++kk) {
+        const int k = 8 * kb + kk;
+        if (ty == kk) {
+#pragma unroll
+          for (int a2 = kb; a2 < NB; ++a2) sC[bufc * 64 + tx * 8 + a2] = A[a2][kb];
+        }
+        __syncthreads();
+        const S dkk = sC[bufc * 64 + kk * 8 + kb];
+        if (!(dkk > S(0))) { spd = false; break; }
+        const S dinv = fast_rsqrt(dkk);
+        S li[NB], lj[NB];
+#pragma unroll
+        for (int a2 = kb; a2 < NB; ++a2) li[a2] = (a2 > kb || tx > kk) ? sC[bufc * 64 + tx * 8 + a2] * dinv : S(0);
+#pragma unroll
+        for (int b2 = kb; b2 < NB; ++b2) lj[b2] = (b2 > kb || ty > kk) ? sC[bufc * 64 + ty * 8 + b2] * dinv : S(0);
+        {   // y_k = (r_o row)[k] / d  ->  gamma
+          const S y = sC[bufc * 64 + (rho & 7) * 8 + (rho >> 3)] * dinv;
+          gamma += y * y;
+        }
+#pragma unroll
+        for (int a2 = kb; a2 < NB; ++a2)
+#pragma unroll
+          for (int b2 = kb; b2 <= a2; ++b2) A[a2][b2] -= li[a2] * lj[b2];
+        bufc ^= 1;
+      }
+      if (!spd) break;
+    }
+  }
+  return spd;
+}
+
 template <class S>
 __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
   const int b = b0 + blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
@@ -104,8 +186,6 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int m_cap = d.m_cap;
   // G (symmetric, 2M x 2M) plus the appended r_o row 2M as a packed lower triangle: element (i, j), j <= i, at TRI(i, j)
-#define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
-#define SYM(i, j) ((i) >= (j) ? TRI(i, j) : TRI(j, i))
   S* sC = reinterpret_cast<S*>(smem_raw);              // [2][64] pivot-column exchange of the register Cholesky
   S* sG = sC + 128;                                    // [(2 m_cap + 1)(2 m_cap + 2) / 2]
   S* sHx = sG + (2 * m_cap + 1) * (2 * m_cap + 2) / 2; // [m_cap][12]
@@ -415,72 +495,16 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
   (void)0;
   if (fdbg & 4) { gamma = 0; }
   else if (rho + 1 <= 64) {
-    // register-resident: the wavefront is an 8 x 8 grid, lane (tx,ty) owns elements (8a+tx, 8b+ty) of the
-    // (rho+1) x rho lower trapezoid; one LDS exchange of the pivot column per step, no workgroup barrier
-    constexpr int NB = 8;
-    const int tx = lane & 7, ty = lane >> 3;
-    S A[NB][NB];
-    S vr[NB][3], er[NB][3];
-#pragma unroll
-    for (int a2 = 0; a2 < NB; ++a2) {
-      const int i = 8 * a2 + tx;
-      const bool ok = i < rho;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) { vr[a2][q] = ok ? sV[(3 + i) * 3 + q] : S(0); er[a2][q] = ok ? sE[(3 + i) * 3 + q] : S(0); }
-    }
-#pragma unroll
-    for (int b2 = 0; b2 < NB; ++b2) {
-      const int j = 8 * b2 + ty;
-      const bool okj = j < rho;
-      S vc[3], ec[3];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) { vc[q] = okj ? sV[(3 + j) * 3 + q] : S(0); ec[q] = okj ? sE[(3 + j) * 3 + q] : S(0); }
-#pragma unroll
-      for (int a2 = b2; a2 < NB; ++a2) {
-        const int i = 8 * a2 + tx;
-        S val = 0;
-        if (okj && i < rho) {
-          val = sG[SYM(3 + i, 3 + j)] - (vr[a2][0] * ec[0] + vr[a2][1] * ec[1] + vr[a2][2] * ec[2])
-                - (er[a2][0] * vc[0] + er[a2][1] * vc[1] + er[a2][2] * vc[2]);
-          if (i == j) val += sig2;
-        } else if (okj && i == rho) {
-          val = sG[TRI(R2, 3 + j)];            // appended row: r_o
-        }
-        A[a2][b2] = val;
-      }
-    }
-    __syncthreads();
-    // pivot column exchange through sC, 2 x 64 entries laid out [buf][tx*8 + a]
-    int bufc = 0;
-#pragma unroll
-    for (int kb = 0; kb < NB; ++kb) {
-      const int kk_hi = min(8, rho - 8 * kb);
-      for (int kk = 0; kk < kk_hi; ++kk) {
-        const int k = 8 * kb + kk;
-        if (ty == kk) {
-#pragma unroll
-          for (int a2 = kb; a2 < NB; ++a2) sC[bufc * 64 + tx * 8 + a2] = A[a2][kb];
-        }
-        __syncthreads();
-        const S dkk = sC[bufc * 64 + kk * 8 + kb];
-        if (!(dkk > S(0))) { spd = false; break; }
-        const S dinv = fast_rsqrt(dkk);
-        S li[NB], lj[NB];
-#pragma unroll
-        for (int a2 = kb; a2 < NB; ++a2) li[a2] = (a2 > kb || tx > kk) ? sC[bufc * 64 + tx * 8 + a2] * dinv : S(0);
-#pragma unroll
-        for (int b2 = kb; b2 < NB; ++b2) lj[b2] = (b2 > kb || ty > kk) ? sC[bufc * 64 + ty * 8 + b2] * dinv : S(0);
-        {   // y_k = (r_o row)[k] / d  ->  gamma
-          const S y = sC[bufc * 64 + (rho & 7) * 8 + (rho >> 3)] * dinv;
-          gamma += y * y;
-        }
-#pragma unroll
-        for (int a2 = kb; a2 < NB; ++a2)
-#pragma unroll
-          for (int b2 = kb; b2 <= a2; ++b2) A[a2][b2] -= li[a2] * lj[b2];
-        bufc ^= 1;
-      }
-      if (!spd) break;
+    const int nbr = (rho >> 3) + 1;   // 8 x 8 blocks in use (wave-uniform)
+    switch (nbr) {
+      case 1: spd = gate_chol<S, 1>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma); break;
+      case 2: spd = gate_chol<S, 2>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma); break;
+      case 3: spd = gate_chol<S, 3>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma); break;
+      case 4: spd = gate_chol<S, 4>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma); break;
+      case 5: spd = gate_chol<S, 5>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma); break;
+      case 6: spd = gate_chol<S, 6>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma); break;
+      case 7: spd = gate_chol<S, 7>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma); break;
+      default: spd = gate_chol<S, 8>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma); break;
     }
   } else {
     for (int i = 3 + lane; i < R2; i += 64) {

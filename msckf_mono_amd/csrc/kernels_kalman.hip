@@ -135,18 +135,57 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // false when it is contiguous in k (lanes run along k) -- keeps the global loads of the tile coalesced.
 template <int OP> struct BContigJ { static constexpr bool value = (OP == OP_KE || OP == OP_A || OP == OP_X || OP == OP_W); };
 
+// Operand access split into {address, validity, scale} so that the prefetch is branch-free: every load of a
+// k-tile is issued unconditionally from a clamped address (all in flight together -- a conditional per element makes
+// the compiler drain vmcnt between them) and masked / scaled when it is staged to LDS.
+template <int OP> __device__ __forceinline__ const float* opa_ptr(const KView<float>& v, int i, int k) {
+  if (OP == OP_PHT) return v.P + (long)(15 + k) * v.ld + i;
+  if (OP == OP_S) return v.R0 + (long)i * v.ldR + k;
+  if (OP == OP_W) return v.PHt + (long)k * v.ld + i;
+  if (OP == OP_K || OP == OP_KE) return v.W + (long)k * v.ld + i;
+  if (OP == OP_A) return v.K + (long)k * v.ld + i;
+  if (OP == OP_AP) return v.A + (long)k * v.ld + i;
+  return k < v.D ? v.AP + (long)k * v.ld + i : v.K + (long)(k - v.D) * v.ld + i;
+}
+template <int OP> __device__ __forceinline__ float opa_fix(const KView<float>& v, int i, int k, float x) {
+  if (OP == OP_S) return k >= i ? x : 0.f;
+  if (OP == OP_X) return k < v.D ? x : v.sig2 * x;
+  return x;
+}
+template <int OP> __device__ __forceinline__ const float* opb_ptr(const KView<float>& v, int k, int j) {
+  if (OP == OP_PHT) return v.R0 + (long)j * v.ldR + k;
+  if (OP == OP_S) return v.PHt + (long)j * v.ld + 15 + k;
+  if (OP == OP_W) return v.Linv + (long)k * v.ldn + j;
+  if (OP == OP_K) return v.Linv + (long)j * v.ldn + k;
+  if (OP == OP_KE) return v.Linv + (long)k * v.ldn + j;
+  if (OP == OP_A) return v.R0 + (long)k * v.ldR + (j >= 15 ? j - 15 : 0);
+  if (OP == OP_AP) return v.P + (long)j * v.ld + k;
+  return k < v.D ? v.A + (long)k * v.ld + j : v.K + (long)(k - v.D) * v.ld + j;
+}
+template <int OP> __device__ __forceinline__ float opb_fix(const KView<float>& v, int k, int j, float x) {
+  if (OP == OP_PHT) return k >= j ? x : 0.f;
+  if (OP == OP_W) return k <= j ? x : 0.f;
+  if (OP == OP_K) return j <= k ? x : 0.f;
+  if (OP == OP_KE) return k >= j ? x : 0.f;
+  if (OP == OP_A) return (j >= 15 && j - 15 >= k) ? x : 0.f;
+  return x;
+}
+
+constexpr int GT = 32;   // k-tile of the MFMA GEMM
+
 template <int OP>
 __global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0) {
   using S = float;
   const int b = b0 + blockIdx.z;
   if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
+  if (OP == OP_X && blockIdx.x > blockIdx.y) return;   // X is symmetric: k_symmetrize mirrors the upper tiles
   const KView<S> v = make_view(d, b);
   int M, N, K;
   op_dims<S, OP>(v, M, N, K);
   const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
   if (i0 >= M || j0 >= N) return;
-  __shared__ S sA[16][65];
-  __shared__ S sB[16][65];
+  __shared__ S sA[GT][65];
+  __shared__ S sB[GT][65];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w & 1, wn = w >> 1;
   const bool wave_live = (i0 + 32 * wm < M) && (j0 + 32 * wn < N);   // edge tiles: whole wave sub-tile out of range
@@ -154,39 +193,46 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   // register-staged software pipeline: the global loads of tile t+1 are in flight while tile t runs on the MFMAs
-  S ra[4], rb[4];
+  constexpr int NQ = GT / 4;
+  S ra[NQ], rb[NQ];
+  const int a_i = i0 + (tid & 63), a_ic = min(a_i, M - 1);
   auto fetch = [&](int k0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int ii = tid & 63, kk = (tid >> 6) + 4 * q;
-      const int gi = i0 + ii, gk = k0 + kk;
-      ra[q] = (gi < M && gk < K) ? op_a<S, OP>(v, gi, gk) : S(0);
+    for (int q = 0; q < NQ; ++q) {
+      const int gk = min(k0 + (tid >> 6) + 4 * q, K - 1);
+      ra[q] = *opa_ptr<OP>(v, a_ic, gk);
       int kb, jj;
       if (BContigJ<OP>::value) { jj = tid & 63; kb = (tid >> 6) + 4 * q; }
-      else { kb = tid & 15; jj = (tid >> 4) + 16 * q; }
-      const int gj = j0 + jj, gk2 = k0 + kb;
-      rb[q] = (gj < N && gk2 < K) ? op_b<S, OP>(v, gk2, gj) : S(0);
+      else { kb = (tid & 15) + 16 * (q & 1); jj = (tid >> 4) + 16 * (q >> 1); }
+      rb[q] = *opb_ptr<OP>(v, min(k0 + kb, K - 1), min(j0 + jj, N - 1));
     }
   };
-  auto stage = [&]() {
+  auto stage = [&](int k0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      sA[(tid >> 6) + 4 * q][tid & 63] = ra[q];
-      if (BContigJ<OP>::value) sB[(tid >> 6) + 4 * q][tid & 63] = rb[q];
-      else sB[tid & 15][(tid >> 4) + 16 * q] = rb[q];
+    for (int q = 0; q < NQ; ++q) {
+      const int kk = (tid >> 6) + 4 * q, gk = k0 + kk;
+      sA[kk][tid & 63] = (a_i < M && gk < K) ? opa_fix<OP>(v, a_i, gk, ra[q]) : 0.f;
+      int kb, jj;
+      if (BContigJ<OP>::value) { jj = tid & 63; kb = kk; }
+      else { kb = (tid & 15) + 16 * (q & 1); jj = (tid >> 4) + 16 * (q >> 1); }
+      const int gj = j0 + jj, gk2 = k0 + kb;
+      sB[kb][jj] = (gj < N && gk2 < K) ? opb_fix<OP>(v, gk2, gj, rb[q]) : 0.f;
     }
   };
   fetch(0);
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    stage();
+  for (int k0 = 0; k0 < K; k0 += GT) {
+    stage(k0);
     __syncthreads();
-    if (k0 + 16 < K) fetch(k0 + 16);
+    if (k0 + GT < K) fetch(k0 + GT);
     if (wave_live) {
+      const int kend = min(GT, K - k0);
 #pragma unroll
-      for (int kk = 0; kk < 16; kk += 2) {
-        const S bj = sB[kk + (lane >> 5)][32 * wn + (lane & 31)];   // MFMA A operand: rows of the result = j
-        const S ai = sA[kk + (lane >> 5)][32 * wm + (lane & 31)];   // MFMA B operand: cols of the result = i
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bj, ai, acc, 0, 0, 0);
+      for (int kk = 0; kk < GT; kk += 2) {
+        if (kk < kend) {
+          const S bj = sB[kk + (lane >> 5)][32 * wn + (lane & 31)];   // MFMA A operand: rows of the result = j
+          const S ai = sA[kk + (lane >> 5)][32 * wm + (lane & 31)];   // MFMA B operand: cols of the result = i
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bj, ai, acc, 0, 0, 0);
+        }
       }
     }
     __syncthreads();
@@ -528,7 +574,9 @@ __global__ __launch_bounds__(256) void k_inject(Dev<S> d, int b0) {
   }
 }
 
-template <class S>
+// P <- (X + X^T)/2 (msckf.h:1418).  The MFMA path computes only the 64x64 tiles of X on or above the block diagonal
+// (TRI): below it the mirrored element is taken, inside a diagonal tile the two halves are averaged as the reference does.
+template <class S, bool TRI>
 __global__ __launch_bounds__(256) void k_symmetrize(Dev<S> d, int b0) {
   const int b = b0 + blockIdx.y;
   if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
@@ -537,7 +585,10 @@ __global__ __launch_bounds__(256) void k_symmetrize(Dev<S> d, int b0) {
   S* P = d.P + (long)b * ld * ld;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)D * D; e += (long)gridDim.x * 256) {
     const int i = (int)(e % D), j = (int)(e / D);
-    P[(long)j * ld + i] = (X[(long)j * ld + i] + X[(long)i * ld + j]) / S(2);
+    S val;
+    if (TRI && (i >> 6) != (j >> 6)) val = (i >> 6) < (j >> 6) ? X[(long)j * ld + i] : X[(long)i * ld + j];
+    else val = (X[(long)j * ld + i] + X[(long)i * ld + j]) / S(2);
+    P[(long)j * ld + i] = val;
   }
 }
 
@@ -595,7 +646,8 @@ void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   gemm<S, OP_A>(d, b0, nb, D, D, st);
   gemm<S, OP_AP>(d, b0, nb, D, D, st);
   gemm<S, OP_X>(d, b0, nb, D, D, st);
-  hipLaunchKernelGGL(k_symmetrize<S>, dim3(16, nb), dim3(256), 0, st, d, b0);
+  if (sizeof(S) == 4) hipLaunchKernelGGL((k_symmetrize<S, true>), dim3(16, nb), dim3(256), 0, st, d, b0);
+  else hipLaunchKernelGGL((k_symmetrize<S, false>), dim3(16, nb), dim3(256), 0, st, d, b0);
 }
 
 template void launch_kalman<float>(const Dev<float>&, int, int, hipStream_t);

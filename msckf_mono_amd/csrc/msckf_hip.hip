@@ -91,8 +91,9 @@ template <class S>
 struct Batch : BatchBase {
   Dev<S> d{};
   hipStream_t st = nullptr;
-  hipStream_t st2 = nullptr;        // second stream: run_frames can run the two halves of the batch concurrently
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  static constexpr int MAXS = 8;     // run_frames can run up to MAXS slices of the batch concurrently
+  hipStream_t stx[MAXS] = {nullptr}; // stx[0] == st
+  hipEvent_t ev_fork = nullptr, ev_join[MAXS] = {nullptr};
   int nstreams = 1;
   std::vector<void*> allocs;
   // single-call staging on device
@@ -120,9 +121,10 @@ struct Batch : BatchBase {
   int create() {
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+    stx[0] = st;
+    for (int i = 1; i < MAXS; ++i) HIPCHK(hipStreamCreateWithFlags(&stx[i], hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    for (int i = 1; i < MAXS; ++i) HIPCHK(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
     d.B = B; d.n_cap = n_cap; d.f_cap = f_cap; d.m_cap = m_cap;
     d.n6cap = 6 * n_cap;
     d.ld = ((15 + 6 * n_cap + 15) / 16) * 16;
@@ -166,9 +168,8 @@ struct Batch : BatchBase {
     if (st) hipStreamSynchronize(st);
     for (void* p : allocs) hipFree(p);
     for (int s = 0; s < NSTAGE; ++s) for (auto& e : ev_pool[s]) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    if (st2) hipStreamDestroy(st2);
+    for (int i = 1; i < MAXS; ++i) { if (stx[i]) hipStreamDestroy(stx[i]); if (ev_join[i]) hipEventDestroy(ev_join[i]); }
     if (ev_fork) hipEventDestroy(ev_fork);
-    if (ev_join) hipEventDestroy(ev_join);
     if (st) hipStreamDestroy(st);
   }
   void use_single_worklists() {
@@ -535,7 +536,7 @@ struct Batch : BatchBase {
     return 0;
   }
   int set_streams(int n) override {
-    if (n < 1 || n > 2) return fail(-EINVAL, "1 or 2 streams");
+    if (n < 1 || n > MAXS) return fail(-EINVAL, "1 to 8 streams");
     nstreams = n;
     return 0;
   }
@@ -581,19 +582,18 @@ template <class S>
 int Batch<S>::run_frames(int f0, int f1) {
   if (f0 < 0 || f1 > sc_frames || f0 > f1) return fail(-EINVAL, "frame range out of bounds");
   HIPCHK(hipSetDevice(device));
-  // Trajectories are independent, so the batch may be cut into two halves that run the same kernel sequence on
-  // two streams: the latency-bound stages of one half (gain solve, TSQR merge, propagate: one workgroup per
-  // trajectory) overlap with the chip-filling stages of the other.  Stage profiling forces a single stream.
-  const int nh = (nstreams == 2 && !prof && B >= 2) ? 2 : 1;
-  hipStream_t streams[2] = {st, st2};
-  if (nh == 2) { HIPCHK(hipEventRecord(ev_fork, st)); HIPCHK(hipStreamWaitEvent(st2, ev_fork, 0)); }
+  // Trajectories are independent, so the batch may be cut into slices that run the same kernel sequence on
+  // separate streams: the latency-bound stages of one slice (gain solve, Cholesky, propagate: one workgroup per
+  // trajectory) overlap with the chip-filling stages of the others.  Stage profiling forces a single stream.
+  const int nh = prof ? 1 : std::max(1, std::min(nstreams, B));
+  if (nh > 1) { HIPCHK(hipEventRecord(ev_fork, st)); for (int i = 1; i < nh; ++i) HIPCHK(hipStreamWaitEvent(stx[i], ev_fork, 0)); }
   hipStream_t saved = st;
   for (int f = f0; f < f1; ++f) {
     const size_t cell0 = (size_t)f * B;
     for (int hh = 0; hh < nh; ++hh) {
-      const int b0 = hh == 0 ? 0 : B / 2;
-      const int nb = nh == 1 ? B : (hh == 0 ? B / 2 : B - B / 2);
-      st = streams[hh];
+      const int b0 = (int)((long)B * hh / nh);
+      const int nb = (int)((long)B * (hh + 1) / nh) - b0;
+      st = stx[hh];
       Dev<S> v = d;
       v.trk_n = sc_n + cell0 + b0; v.trk_M = sc_M + (cell0 + b0) * f_cap; v.trk_slots = sc_slots + (cell0 + b0) * f_cap * m_cap;
       v.trk_obs = sc_obs + (cell0 + b0) * f_cap * m_cap * 2;
@@ -608,7 +608,7 @@ int Batch<S>::run_frames(int f0, int f1) {
     }
   }
   st = saved;
-  if (nh == 2) { HIPCHK(hipEventRecord(ev_join, st2)); HIPCHK(hipStreamWaitEvent(st, ev_join, 0)); }
+  for (int i = 1; i < nh; ++i) { HIPCHK(hipEventRecord(ev_join[i], stx[i])); HIPCHK(hipStreamWaitEvent(st, ev_join[i], 0)); }
   HIPCHK(hipGetLastError());
   return 0;
 }
