@@ -11,7 +11,8 @@ Launch: `python bench.py --gpus 1 --steps K --warmup W`, or one rank per GPU und
 (trajectories are independent: rank r runs its own 64 trajectories, weak scaling, no data-path
 collective; RCCL is used only for the timing reduction and the end-of-run ATE all-reduce).
 
-Prints ONE JSON line on rank 0; `roofline` is for the dominant kernel (k_qr_update, the TSQR compression),
+Prints ONE JSON line on rank 0; `roofline` is for the dominant kernel (the longest single kernel of a step,
+k_feature since the compression moved to the information form),
 `cpu_baseline` is the CPU oracle (restatement of the reference; the reference itself cannot be built
 here -- see BASELINE.md) timed on this box's host cores on a bounded sample of the same workload.
 """
@@ -153,13 +154,13 @@ def main():
         value = updates / elapsed
         ms_per_step = 1e3 * elapsed / K
         stage_ms = {k2: v[0] / max(v[1], 1) for k2, v in prof.items()}
-        # kernels: the TSQR compression is ONE kernel (k_qr_update) launched twice per step (stage 1 + merge)
-        kern_ms = {"k_qr_update (TSQR compression, stage-1 + merge launches)": stage_ms["compress_stage1"] + stage_ms["compress_merge"],
-                   "k_feature + k_select": stage_ms["feature"], "kalman (k_gemm_mfma x5, k_gain, k_inject, k_symmetrize)": stage_ms["kalman"],
-                   "k_propagate": stage_ms["propagate"], "k_augment": stage_ms["augment"], "k_prune_*": stage_ms["prune"]}
-        kern_fl = {"k_qr_update (TSQR compression, stage-1 + merge launches)": fl["compress"], "k_feature + k_select": fl["feature"],
-                   "kalman (k_gemm_mfma x5, k_gain, k_inject, k_symmetrize)": fl["kalman"], "k_propagate": fl["propagate"],
-                   "k_augment": fl["augment"], "k_prune_*": 0.0}
+        # single kernels with their own HIP-event pair; "kalman" is a launch SET (6 GEMMs + gain + inject + symmetrize)
+        # and is listed in stage_ms_per_step only.  Algorithmic FLOP = SURVEY.md section 8d per-unit figures of the
+        # REFERENCE's algorithm (dense gate products, Householder compression), not the instructions executed.
+        kern_ms = {"k_feature": stage_ms["feature"], "k_gram (compression A)": stage_ms["compress_stage1"],
+                   "k_chol_T (compression B)": stage_ms["compress_merge"], "k_propagate": stage_ms["propagate"]}
+        kern_fl = {"k_feature": fl["feature"], "k_gram (compression A)": fl["compress"], "k_chol_T (compression B)": 0.0,
+                   "k_propagate": fl["propagate"]}
         dom = max(kern_ms, key=kern_ms.get)
         dom_flops = kern_fl[dom] * B_TRAJ
         achieved = dom_flops / (kern_ms[dom] * 1e-3) / 1e12 if kern_ms[dom] > 0 else 0.0
@@ -171,8 +172,10 @@ def main():
                        "cam_window": N_WIN, "tracks_per_update": F_TRK, "trajectories_per_gpu": B_TRAJ, "imu_per_update": K_IMU,
                        "parallelism": "replicated trajectories, %d per rank" % B_TRAJ, "noise": "isotropic (f_u = f_v)"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_TFLOPS, "traffic": pmc_traffic("k_qr_update") if dom.startswith("k_qr_update") else None,
-                         "kernel_ms_per_step": kern_ms[dom], "alg_flops_per_launch_set": dom_flops,
+                         "frac": achieved / PEAK_F32_TFLOPS, "traffic": pmc_traffic(dom.split(" ")[0]),
+                         "kernel_ms_per_step": kern_ms[dom], "alg_flops_per_launch": dom_flops,
+                         "kalman_set": {"ms_per_step": stage_ms["kalman"], "alg_flops_per_step": fl["kalman"] * B_TRAJ,
+                                        "tflops": fl["kalman"] * B_TRAJ / (stage_ms["kalman"] * 1e-3) / 1e12 if stage_ms["kalman"] > 0 else 0.0},
                          "alg_flops_per_update": f_update, "alg_bytes_per_update": by,
                          "whole_update_tflops": f_update * value / 1e12 / world,
                          "whole_update_frac": f_update * value / 1e12 / world / PEAK_F32_TFLOPS,

@@ -115,9 +115,10 @@ int msckf_hip_scenario_commit(msckf_hip_handle h);   /* H2D of everything staged
 int msckf_hip_run_frames(msckf_hip_handle h, int f0, int f1);
 int msckf_hip_sync(msckf_hip_handle h);
 /* HIP-event stage timing: enable, run, sync, then read accumulated milliseconds and launch counts for
- * stages 0 propagate, 1 augment, 2 feature+select, 3 compress stage 1, 4 compress merge, 5 kalman, 6 prune */
+ * stages 0 propagate, 1 augment, 2 k_feature, 3 compression A (k_gram | TSQR stage 1), 4 compression B (k_chol_T |
+ * TSQR merge), 5 kalman, 6 prune, 7 k_select */
 int msckf_hip_profile_enable(msckf_hip_handle h, int on);
-int msckf_hip_profile_read(msckf_hip_handle h, double* ms7, int* count7);
+int msckf_hip_profile_read(msckf_hip_handle h, double* ms8, int* count8);
 /* run_frames on n = 1..8 HIP streams: the batch is cut into n slices of independent trajectories that run the
  * same kernel sequence concurrently (latency-bound stages of one slice overlap chip-filling stages of another). */
 int msckf_hip_set_streams(msckf_hip_handle h, int n);

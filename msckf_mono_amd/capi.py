@@ -227,9 +227,9 @@ class Batch:
         _chk(self.L.msckf_hip_profile_enable(self.h, 1 if on else 0))
 
     def profile_read(self):
-        ms = np.zeros(7); cnt = np.zeros(7, dtype=np.int32)
+        ms = np.zeros(8); cnt = np.zeros(8, dtype=np.int32)
         _chk(self.L.msckf_hip_profile_read(self.h, ms.ctypes.data_as(_dp), cnt.ctypes.data_as(_ip)))
-        names = ["propagate", "augment", "feature", "compress_stage1", "compress_merge", "kalman", "prune"]
+        names = ["propagate", "augment", "feature", "compress_stage1", "compress_merge", "kalman", "prune", "select"]
         return {n: (float(m), int(c)) for n, m, c in zip(names, ms, cnt)}
 
 

@@ -85,7 +85,7 @@ struct BatchBase {
   virtual int set_streams(int n) = 0;
 };
 
-constexpr int NSTAGE = 7;
+constexpr int NSTAGE = 8;
 
 template <class S>
 struct Batch : BatchBase {
@@ -284,7 +284,8 @@ struct Batch : BatchBase {
   void launch_update(const Dev<S>& vin, int b0, int nb) {
     Dev<S> v = vin;
     if (g_compress_override >= 0) v.compress = (g_compress_override && d.trk_B) ? 1 : 0;
-    stage_begin(2); launch_feature<S>(v, b0, nb, st); launch_select<S>(v, b0, nb, st); stage_end(2);
+    stage_begin(2); launch_feature<S>(v, b0, nb, st); stage_end(2);
+    stage_begin(7); launch_select<S>(v, b0, nb, st); stage_end(7);
     launch_compress_profiled(v, b0, nb);
     stage_begin(5); launch_kalman<S>(v, b0, nb, st); stage_end(5);
   }

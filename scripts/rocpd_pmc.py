@@ -32,22 +32,19 @@ def main():
     txt = "\n".join(lines)
     print(txt)
     open(out, "a").write(txt + "\n")
-    # traffic of the TSQR stage-1 launches (the dominant kernel): the LARGEST dispatches of k_qr_update
+    # HBM traffic per launch of every kernel that has both counters: mean over the steady-state (second half of the
+    # run) dispatches.  Keyed by the bare kernel name (k_feature, k_gram, ...), read by bench.py's roofline block.
     import json, os
     tr = {}
     for k in rows:
-        if "k_qr_update" in k and "FETCH_SIZE" in rows[k] and "WRITE_SIZE" in rows[k]:
-            def top(c):
-                by = defaultdict(float)
-                for disp, val in rows[k][c]:
-                    by[disp] += val
-                v = sorted(by.values())
-                v = v[len(v) // 2:]                 # stage-1 launches carry more traffic than the merges
-                v = v[len(v) // 2:]
-                return sum(v) / len(v)
-            f, w = top("FETCH_SIZE"), top("WRITE_SIZE")
-            tr["k_qr_update"] = dict(kernel=k, fetch_kib=f, write_kib=w, bytes_per_launch=(2 * f + w) * 1024,
-                                         launches="stage-1 launches (the merge launch of the same kernel moves ~4x less)", note="FETCH_SIZE doubled (gfx950 under-reports wide coalesced reads by 2x); WRITE_SIZE uncalibrated")
+        if "FETCH_SIZE" in rows[k] and "WRITE_SIZE" in rows[k]:
+            m = re.search(r"(k_[a-zA-Z_0-9]+)", k)
+            if not m:
+                continue
+            f, w = res[(k, "FETCH_SIZE")], res[(k, "WRITE_SIZE")]
+            key = m.group(1) + (re.search(r"<(\d+)>", k).group(0) if m.group(1) == "k_gemm_mfma" and re.search(r"<(\d+)>", k) else "")
+            tr[key] = dict(kernel=k, fetch_kib=f, write_kib=w, bytes_per_launch=(2 * f + w) * 1024,
+                           note="FETCH_SIZE doubled (gfx950 under-reports wide coalesced reads by 2x); WRITE_SIZE uncalibrated")
     if tr:
         json.dump(tr, open(os.path.join(os.path.dirname(out) or ".", "pmc_traffic.json"), "w"), indent=1)
 

@@ -197,6 +197,33 @@ def test_batched_range_equals_single(capi):
         assert np.array_equal(one.imu_state(b), big.imu_state(b))
 
 
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_information_form_equals_householder_route(capi, prec):
+    """The library has two compression routes for the stacked Jacobian: the information form (default: H_o^T H_o
+    accumulated in f64 + Cholesky, kernels_gram.hip) and the Householder TSQR (kernels_qr.hip, what the reference
+    does, msckf.h:1338-1366).  Free-running filters on the two routes stay together to rounding; the information
+    form reports the unobservable directions of the window as zero rows of T_H."""
+    N, F, nf = 12, 40, 20
+    tr = sc.Trajectory(2, 7, N, F, nf)
+    cd = capi.F64 if prec == "f64" else capi.F32
+    res = {}
+    try:
+        for route in (0, 1):
+            capi.lib().msckf_hip_debug_set(100, route)
+            bt = capi.Batch(1, N, F, N, cd)
+            bt.initialize(0, tr.cfg, tr.imu0)
+            for k in range(nf):
+                H.device_frame(bt, 0, tr, k, N)
+            res[route] = (bt.imu_state(0), bt.cam_states(0)[0], bt.covariance(0), bt.last_stats(0))
+            bt.close()
+    finally:
+        capi.lib().msckf_hip_debug_set(100, -1)
+    e = H.state_errors(res[1][0], res[0][0], res[1][1], res[0][1], res[1][2], res[0][2])
+    assert H.worst(e) < (1e-8 if prec == "f64" else 3e-4), e
+    assert res[1][3]["m_rows"] == res[0][3]["m_rows"] > 0
+    assert res[1][3]["r_rows"] < res[0][3]["r_rows"] == 6 * N            # gauge directions skipped
+
+
 def test_resident_scenario_equals_per_call(capi):
     N, F, nf, B = 8, 16, 13, 3
     trs = [sc.Trajectory(2, 60 + b, N, F, nf) for b in range(B)]
