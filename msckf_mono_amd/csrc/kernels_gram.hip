@@ -12,8 +12,8 @@
 // reflectors of k_feature orthonormal to f64 rounding Lam^ is positive semi-definite to f64 rounding, and the float
 // filter loses nothing against the float QR (scripts/experiments/gram_vs_qr.py: same error vs the f64 result).
 //
-//   k_gram    SYRK sum B^T B on the f64 matrix cores (v_mfma_f64_16x16x4_f64), 64 x 64 upper tiles, tracks
-//             staged through LDS 8 at a time; extra workgroups reduce the block-diagonal part (one wavefront
+//   k_gram    SYRK sum B^T B on the f64 matrix cores (v_mfma_f64_16x16x4_f64), one workgroup per 64-column panel
+//             (strip of upper 64 x 64 tiles) over the tracks that reach the panel, staged through LDS 8 at a time; extra workgroups reduce the block-diagonal part (one wavefront
 //             per camera slot, lanes over tracks)
 //   k_chol_T  register-resident right-looking Cholesky (16 x 16 thread grid, 2-D block-cyclic, one LDS exchange
 //             and one barrier per step) with semi-definite pivot skipping; writes [T | r_n] in the layout the
@@ -25,11 +25,12 @@ namespace msckf {
 int g_gram_dbg = 0;   // ablation knob (msckf_hip_debug_set(300, .)); zero in production
 
 typedef double v4d __attribute__((ext_vector_type(4)));
-constexpr int GK = 48;   // rows of B per staged chunk = 16 tracks
+constexpr int GK = 24;   // rows of B per staged chunk = 8 tracks
+constexpr int GT_MAX = 3; // 64-column panels: the route covers n + 1 <= 192
 constexpr int GORD = 1024; // track order staged in LDS (f_cap <= GORD on this route)
 
 template <class S>
-__global__ __launch_bounds__(256) void k_gram(Dev<S> d, int b0, int npairs, int dbg) {
+__global__ __launch_bounds__(256) void k_gram(Dev<S> d, int b0, int npairs, int dbg, int xoff) {
   const int b = b0 + blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int* st = d.stats + (long)b * STAT_STRIDE;
   if (st[STAT_MROWS] == 0) return;
@@ -37,9 +38,10 @@ __global__ __launch_bounds__(256) void k_gram(Dev<S> d, int b0, int npairs, int 
   const int N = d.ncam[b], n = 6 * N, ldL = d.ldR, f_cap = d.f_cap, m_cap = d.m_cap;
   const int* order = d.trk_order + (long)b * f_cap;
 
-  if ((int)blockIdx.x >= npairs) {
+  const int bx = (int)blockIdx.x + xoff;
+  if (bx >= npairs) {
     // ---- block-diagonal part: wavefront = camera slot s, lanes over the gated-in tracks
-    const int s = 4 * ((int)blockIdx.x - npairs) + w;
+    const int s = 4 * (bx - npairs) + w;
     if (s >= N || (dbg & 1)) return;
     double acc[27];
 #pragma unroll
@@ -71,25 +73,40 @@ __global__ __launch_bounds__(256) void k_gram(Dev<S> d, int b0, int npairs, int 
     return;
   }
 
-  // ---- SYRK tile (ti <= tj)
-  int ti = 0, tj = 0;
-  {
-    int e = blockIdx.x;
-    const int nt = ldL / 64;
-    for (ti = 0; ti < nt; ++ti) { const int cnt = nt - ti; if (e < cnt) { tj = ti + e; break; } e -= cnt; }
-  }
-  if (64 * tj > n) return;
-  __shared__ double sA[GK][64], sB[GK][64];
+  // ---- SYRK strip: workgroup ti owns the tiles (ti, ti..nt-1).  The A panel (columns 64 ti ..) is staged once for
+  // all of them, and only the tracks whose FIRST camera slot lies at or before the panel take part: the tracks are
+  // sorted by first slot (k_select), every column of the panel is zero for the others, so the K loop runs over a
+  // prefix of the sorted order (tracks end at the newest camera, so the stack is a staircase: ~35 % of the tracks
+  // reach the first panel, ~75 % the second at a 30-camera window).
+  const int ti = bx;
+  const int nt = min(GT_MAX, n / 64 + 1);            // tiles that hold a column <= n
+  if (ti >= nt) return;
+  __shared__ double sA[GK][64], sB[GT_MAX][GK][64];
   __shared__ int sOrd[GORD];
-  for (int e = tid; e < P && e < GORD; e += 256) sOrd[e] = order[e];
+  __shared__ int sCnt;
+  if (tid == 0) sCnt = 0;
   __syncthreads();
-  const int KT = 3 * P;
+  {
+    const int hi_slot = (64 * ti + 63) / 6;          // last slot with a column in the panel
+    int c = 0;
+    for (int e = tid; e < P && e < GORD; e += 256) {
+      const int t = order[e];
+      sOrd[e] = t;
+      c += (d.trk_first[(long)b * f_cap + t] <= hi_slot) ? 1 : 0;
+    }
+    c = (int)wave_sum((float)c);
+    if (lane == 0 && c) atomicAdd(&sCnt, c);
+  }
+  __syncthreads();
+  const int KT = 3 * sCnt;
   const int lr = tid >> 6, lc = tid & 63;
   const int wi = w & 1, wj = w >> 1;
-  double ra[GK / 4], rb[GK / 4];
-  // branch-free: rows past the end are clamped to the last row and masked, so that all 2*GK/4 loads of a chunk
-  // are in flight together (a conditional per row makes the compiler drain vmcnt between them)
-  auto fetch = [&](int kc) {
+  // two register stages: the loads of chunk c+2 are issued as soon as chunk c has been staged to LDS, so two
+  // chunks of global latency are in flight behind the MFMAs.  Branch-free: rows past the end are clamped to the
+  // last row and masked when staged (a conditional per row makes the compiler drain vmcnt between the loads).
+  struct Stage { double a[GK / 4]; double b[GT_MAX][GK / 4]; };
+  Stage r0, r1;
+  auto fetch = [&](Stage& r, int kc) {
     const double* rows[GK / 4];
 #pragma unroll
     for (int it = 0; it < GK / 4; ++it) {
@@ -100,47 +117,77 @@ __global__ __launch_bounds__(256) void k_gram(Dev<S> d, int b0, int npairs, int 
     }
 #pragma unroll
     for (int it = 0; it < GK / 4; ++it) {
-      ra[it] = rows[it][64 * ti + lc]; rb[it] = rows[it][64 * tj + lc];   // masked when stored to LDS
+      r.a[it] = rows[it][64 * ti + lc];
+#pragma unroll
+      for (int tj = 0; tj < GT_MAX; ++tj)
+        if (tj > ti && tj < nt) r.b[tj][it] = rows[it][64 * tj + lc];
     }
   };
-  v4d acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
-  fetch(0);
-  for (int kc = 0; kc < KT; kc += GK) {
-    __syncthreads();
+  auto stage = [&](const Stage& r, int kc) {
 #pragma unroll
     for (int it = 0; it < GK / 4; ++it) {
       const bool ok = kc + lr + 4 * it < KT;
-      sA[lr + 4 * it][lc] = ok ? ra[it] : 0.0; sB[lr + 4 * it][lc] = ok ? rb[it] : 0.0;
+      sA[lr + 4 * it][lc] = ok ? r.a[it] : 0.0;
+#pragma unroll
+      for (int tj = 0; tj < GT_MAX; ++tj)
+        if (tj > ti && tj < nt) sB[tj][lr + 4 * it][lc] = ok ? r.b[tj][it] : 0.0;
     }
-    __syncthreads();
-    if (kc + GK < KT && !(dbg & 2)) fetch(kc + GK);
-    if (!(dbg & 4))
+  };
+  v4d acc[GT_MAX][2][2];
+#pragma unroll
+  for (int tj = 0; tj < GT_MAX; ++tj)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[tj][i][j] = v4d{0.0, 0.0, 0.0, 0.0};
+  auto compute = [&]() {
 #pragma unroll
     for (int k4 = 0; k4 < GK; k4 += 4) {
       const int kr = k4 + (lane >> 4), cc = lane & 15;
       const double a0 = sA[kr][wi * 32 + cc], a1 = sA[kr][wi * 32 + 16 + cc];
-      const double c0 = sB[kr][wj * 32 + cc], c1 = sB[kr][wj * 32 + 16 + cc];
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, c0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, c1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, c0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, c1, acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int tj = 0; tj < GT_MAX; ++tj) {
+        if (tj < ti || tj >= nt) continue;
+        const double c0 = tj == ti ? sA[kr][wj * 32 + cc] : sB[tj][kr][wj * 32 + cc];
+        const double c1 = tj == ti ? sA[kr][wj * 32 + 16 + cc] : sB[tj][kr][wj * 32 + 16 + cc];
+        acc[tj][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, c0, acc[tj][0][0], 0, 0, 0);
+        acc[tj][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, c1, acc[tj][0][1], 0, 0, 0);
+        if (dbg & 8) continue;
+        acc[tj][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, c0, acc[tj][1][0], 0, 0, 0);
+        acc[tj][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, c1, acc[tj][1][1], 0, 0, 0);
+      }
     }
+  };
+  if (KT > 0) fetch(r0, 0);
+  if (KT > GK) fetch(r1, GK);
+  for (int kc = 0; kc < KT; kc += 2 * GK) {
+    __syncthreads();
+    stage(r0, kc);
+    __syncthreads();
+    if (kc + 2 * GK < KT && !(dbg & 2)) fetch(r0, kc + 2 * GK);
+    if (!(dbg & 4)) compute();
+    if (kc + GK >= KT) break;
+    __syncthreads();
+    stage(r1, kc + GK);
+    __syncthreads();
+    if (kc + 3 * GK < KT && !(dbg & 2)) fetch(r1, kc + 3 * GK);
+    if (!(dbg & 4)) compute();
   }
   double* Lam = d.Lam + (long)b * ldL * ldL;
 #pragma unroll
-  for (int ib = 0; ib < 2; ++ib)
+  for (int tj = 0; tj < GT_MAX; ++tj) {
+    if (tj < ti || tj >= nt) continue;
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
+    for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 64 * ti + wi * 32 + ib * 16 + (lane >> 4) + 4 * r;
-        const int j = 64 * tj + wj * 32 + jb * 16 + (lane & 15);
-        Lam[(long)i * ldL + j] = acc[ib][jb][r];
-      }
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 64 * ti + wi * 32 + ib * 16 + (lane >> 4) + 4 * r;
+          const int j = 64 * tj + wj * 32 + jb * 16 + (lane & 15);
+          Lam[(long)i * ldL + j] = acc[tj][ib][jb][r];
+        }
+  }
 }
 
 // [T | r_n] = chol(Lam^) with Lam^ = Dg - sum B^T B; element (i, j), i >= j, of the lower factor lives in thread
@@ -231,8 +278,14 @@ __global__ __launch_bounds__(256) void k_chol_T(Dev<S> d, int b0) {
 template <class S>
 void launch_gram(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase) {
   if (nb <= 0) return;
-  const int nt = d.ldR / 64, npairs = nt * (nt + 1) / 2, ndiag = (d.n_cap + 3) / 4;
-  if (phase != 2) hipLaunchKernelGGL(k_gram<S>, dim3(npairs + ndiag, nb), dim3(256), 0, st, d, b0, npairs, g_gram_dbg);
+  const int npairs = d.ldR / 64, ndiag = (d.n_cap + 3) / 4;   // one SYRK strip per 64-column panel
+  if (phase != 2) {
+    // two launches of the same kernel: the block-diagonal reduction (short, many small workgroups) and the SYRK strips
+    // (MFMA-bound, <= 192 workgroups).  In ONE launch the dispatcher packs strips two to a CU behind the reduction
+    // workgroups and they share the matrix cores (measured: MFMA phase 2x longer).
+    hipLaunchKernelGGL(k_gram<S>, dim3(ndiag, nb), dim3(256), 0, st, d, b0, npairs, g_gram_dbg, npairs);
+    hipLaunchKernelGGL(k_gram<S>, dim3(npairs, nb), dim3(256), 0, st, d, b0, npairs, g_gram_dbg, 0);
+  }
   if (phase == 1) return;
   switch (d.ldR / 16) {
     case 4: hipLaunchKernelGGL((k_chol_T<S, 4>), dim3(nb), dim3(256), 0, st, d, b0); break;
