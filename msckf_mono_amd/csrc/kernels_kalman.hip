@@ -178,14 +178,16 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0) {
   using S = float;
   const int b = b0 + blockIdx.z;
   if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
-  if (OP == OP_X && blockIdx.x > blockIdx.y) return;   // X is symmetric: k_symmetrize mirrors the upper tiles
+  if (OP == OP_X && blockIdx.x > blockIdx.y) return;   // X is symmetric: the epilogue mirrors the upper tiles into P
+  if (OP == OP_S && blockIdx.x < blockIdx.y) return;   // S is symmetric: the gain solve reads its lower triangle
   const KView<S> v = make_view(d, b);
   int M, N, K;
   op_dims<S, OP>(v, M, N, K);
   const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
   if (i0 >= M || j0 >= N) return;
-  __shared__ S sA[GT][65];
-  __shared__ S sB[GT][65];
+  __shared__ S sbuf[2 * GT * 65];
+  S (*sA)[65] = reinterpret_cast<S (*)[65]>(sbuf);
+  S (*sB)[65] = reinterpret_cast<S (*)[65]>(sbuf + GT * 65);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w & 1, wn = w >> 1;
   const bool wave_live = (i0 + 32 * wm < M) && (j0 + 32 * wn < N);   // edge tiles: whole wave sub-tile out of range
@@ -219,8 +221,13 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0) {
       sB[kb][jj] = (gj < N && gk2 < K) ? opb_fix<OP>(v, gk2, gj, rb[q]) : 0.f;
     }
   };
-  fetch(0);
-  for (int k0 = 0; k0 < K; k0 += GT) {
+  // triangular operands: T, E = L^-T are upper triangular, so whole k-tiles of the product are zero
+  int kbeg = 0;
+  if (OP == OP_PHT || OP == OP_KE) kbeg = (j0 / GT) * GT;            // B(k, j) = T[j][k] / E(j, k): zero for k < j
+  if (OP == OP_S) kbeg = (i0 / GT) * GT;                             // A(i, k) = T[i][k]: zero for k < i
+  if (OP == OP_A) K = min(K, max(j0 + 64 - 15, 0));                  // B(k, j) = T_H[k][j]: zero for k > j - 15
+  if (kbeg < K) fetch(kbeg);
+  for (int k0 = kbeg; k0 < K; k0 += GT) {
     stage(k0);
     __syncthreads();
     if (k0 + GT < K) fetch(k0 + GT);
@@ -238,6 +245,30 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0) {
     __syncthreads();
   }
   const int gi = i0 + 32 * wm + (lane & 31);
+  if (OP == OP_X) {
+    // P <- (X + X^T)/2 (msckf.h:1418) fused into the product: X is not materialised.  Tiles above the block diagonal
+    // write their values to both halves of P; a diagonal tile averages with its own transpose through LDS.
+    S* Pw = const_cast<S*>(v.P);
+    if (blockIdx.x != blockIdx.y) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gj = j0 + 32 * wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (gi < M && gj < N) { Pw[(long)gj * v.ld + gi] = acc[r]; Pw[(long)gi * v.ld + gj] = acc[r]; }
+      }
+    } else {
+      S (*sT)[65] = reinterpret_cast<S (*)[65]>(sbuf);   // [64][65]: the k-loop ended with a barrier
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sT[32 * wm + (lane & 31)][32 * wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = acc[r];
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lj = 32 * wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), li = 32 * wm + (lane & 31);
+        const int gj = j0 + lj;
+        if (gi < M && gj < N) Pw[(long)gj * v.ld + gi] = (sT[li][lj] + sT[lj][li]) * 0.5f;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int gj = j0 + 32 * wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -646,8 +677,7 @@ void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   gemm<S, OP_A>(d, b0, nb, D, D, st);
   gemm<S, OP_AP>(d, b0, nb, D, D, st);
   gemm<S, OP_X>(d, b0, nb, D, D, st);
-  if (sizeof(S) == 4) hipLaunchKernelGGL((k_symmetrize<S, true>), dim3(16, nb), dim3(256), 0, st, d, b0);
-  else hipLaunchKernelGGL((k_symmetrize<S, false>), dim3(16, nb), dim3(256), 0, st, d, b0);
+  if (sizeof(S) != 4) hipLaunchKernelGGL((k_symmetrize<S, false>), dim3(16, nb), dim3(256), 0, st, d, b0);   // float: fused into the X product
 }
 
 template void launch_kalman<float>(const Dev<float>&, int, int, hipStream_t);

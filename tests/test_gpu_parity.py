@@ -412,6 +412,34 @@ def test_cfg3_batch_properties(capi):
     assert np.mean(rates) > 0.95
 
 
+def test_float_long_run_stays_with_the_double_oracle(capi, po):
+    """300 free-running frames in float (information-form compression, Joseph update) against the double oracle
+    on the same inputs: the float filter must neither drift away nor lose the structure of P (symmetry, PSD up to
+    rounding) -- the failure modes a Gram-matrix compression would show first."""
+    N, F, nf = 10, 40, 300
+    tr = sc.Trajectory(2, 91, N, F, nf)
+    o = po.Oracle(po.F64, po.LEAN)
+    o.initialize(tr.cfg, tr.imu0)
+    bt = capi.Batch(1, N, F, N, capi.F32)
+    bt.scenario_alloc(nf, sc.IMU_PER_FRAME)
+    bt.initialize(0, tr.cfg, tr.imu0)
+    for k in range(nf):
+        fr = tr.frames[k]
+        bt.scenario_set(k, 0, tr.imu_for_frame(k), fr["M"], fr["slots"], fr["obs"], 1 if fr["Nw"] == N else 0)
+        H.oracle_frame(o, tr, k, N)
+    bt.scenario_commit()
+    bt.run_frames(0, nf); bt.sync()
+    xd, xo = bt.imu_state(0), o.getImuState()
+    P, Po = bt.covariance(0), o.getCovariance()
+    assert np.all(np.isfinite(xd)) and np.array_equal(P, P.T)
+    w = np.linalg.eigvalsh(P)
+    assert w.min() > -1e-6 * w.max()
+    assert np.linalg.norm(xd[13:16] - xo[13:16]) < 2e-3 * max(1.0, np.linalg.norm(xo[13:16]))   # position, metres
+    assert H.quat_angle(xd[0:4], xo[0:4]) < 1e-3
+    assert np.linalg.norm(P - Po) / np.linalg.norm(Po) < 2e-2
+    assert np.linalg.norm(xd[13:16] - tr.gt_frames["p"][nf - 1]) < 0.1
+
+
 def test_cfg5_geometry_runs_and_stays_consistent(capi):
     """60-camera window (BASELINE.json configs[4] geometry, fewer tracks): exercises NC = 6 QR tiles and the
     global-memory Cholesky path; float."""
