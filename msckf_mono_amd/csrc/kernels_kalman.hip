@@ -473,13 +473,13 @@ __global__ __launch_bounds__(256) void k_gain(Dev<S> d, int b0) {
   }
 }
 
-// Split variant of the gain solve: 4 workgroups per trajectory.  Every workgroup factors S = L L^T in registers
-// (redundantly, 78 blocks) and carries ONE QUARTER of the appended rows [PHt ; I] through the same eliminations,
+// Split variant of the gain solve: NPART (4 or 8) workgroups per trajectory.  Every workgroup factors S = L L^T in registers
+// (redundantly, 78 blocks) and carries 1/NPART of the appended rows [PHt ; I] through the same eliminations,
 // which turns them into [W ; E] = [PHt L^-T ; L^-T].  K = PHt S^-1 = W E^T is then one MFMA GEMM (OP_KE) instead of
 // the backward sweep of k_gain: half the sequential steps, four times the workgroups.
-template <class S, int NBN>
+template <class S, int NBN, int NPART>
 __global__ __launch_bounds__(256) void k_gain_split(Dev<S> d, int b0) {
-  constexpr int G = 16, NBD = NBN + 1, NBA = NBD + NBN, NBQ = (NBA + 3) / 4;
+  constexpr int G = 16, NBD = NBN + 1, NBA = NBD + NBN, NBQ = (NBA + NPART - 1) / NPART;
   const int b = b0 + blockIdx.y, part = blockIdx.x, tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
   const KView<S> v = make_view(d, b);
@@ -651,7 +651,8 @@ void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st) {
     if (nbn <= 4) hipLaunchKernelGGL((k_gain<S, 4>), dim3(nb), dim3(256), 0, st, d, b0);
     else if (nbn <= 8) hipLaunchKernelGGL((k_gain<S, 8>), dim3(nb), dim3(256), 0, st, d, b0);
     else if (sizeof(S) == 4 && nb <= 128) {   // few trajectories: 4 workgroups each + one MFMA GEMM
-      hipLaunchKernelGGL((k_gain_split<S, 12>), dim3(4, nb), dim3(256), 0, st, d, b0);
+      if (nb <= 64) hipLaunchKernelGGL((k_gain_split<S, 12, 8>), dim3(8, nb), dim3(256), 0, st, d, b0);
+      else hipLaunchKernelGGL((k_gain_split<S, 12, 4>), dim3(4, nb), dim3(256), 0, st, d, b0);
       gemm<S, OP_KE>(d, b0, nb, D, n, st);
       split = true;
     }
