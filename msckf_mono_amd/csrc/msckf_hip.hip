@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/msckf_hip.h"
+#include <thread>
 #include "dev_common.h"
 
 namespace msckf { int g_compress_override = -1; }   // experiment knob (msckf_hip_debug_set(100, .))
@@ -184,17 +185,17 @@ struct Batch : BatchBase {
     return v;
   }
   // ---- profiling helpers
-  void stage_begin(int s) {
+  void stage_begin(int s, hipStream_t q) {
     if (!prof) return;
     if (ev_used[s] == ev_pool[s].size()) {
       hipEvent_t a, b2; hipEventCreate(&a); hipEventCreate(&b2);
       ev_pool[s].push_back({a, b2});
     }
-    hipEventRecord(ev_pool[s][ev_used[s]].first, st);
+    hipEventRecord(ev_pool[s][ev_used[s]].first, q);
   }
-  void stage_end(int s) {
+  void stage_end(int s, hipStream_t q) {
     if (!prof) return;
-    hipEventRecord(ev_pool[s][ev_used[s]].second, st);
+    hipEventRecord(ev_pool[s][ev_used[s]].second, q);
     ev_used[s]++;
   }
 
@@ -281,28 +282,25 @@ struct Batch : BatchBase {
     traj[b].wl_F = F;
     return 0;
   }
-  void launch_update(const Dev<S>& vin, int b0, int nb) {
+  void launch_update(const Dev<S>& vin, int b0, int nb, hipStream_t q) {
     Dev<S> v = vin;
     if (g_compress_override >= 0) v.compress = (g_compress_override && d.trk_B) ? 1 : 0;
-    stage_begin(2); launch_feature<S>(v, b0, nb, st); stage_end(2);
-    stage_begin(7); launch_select<S>(v, b0, nb, st); stage_end(7);
-    launch_compress_profiled(v, b0, nb);
-    stage_begin(5); launch_kalman<S>(v, b0, nb, st); stage_end(5);
-  }
-  void launch_compress_profiled(const Dev<S>& v, int b0, int nb) {
+    stage_begin(2, q); launch_feature<S>(v, b0, nb, q); stage_end(2, q);
+    stage_begin(7, q); launch_select<S>(v, b0, nb, q); stage_end(7, q);
     if (v.compress) {
-      stage_begin(3); launch_gram<S>(v, b0, nb, st, 1); stage_end(3);
-      stage_begin(4); launch_gram<S>(v, b0, nb, st, 2); stage_end(4);
-      return;
+      stage_begin(3, q); launch_gram<S>(v, b0, nb, q, 1); stage_end(3, q);
+      stage_begin(4, q); launch_gram<S>(v, b0, nb, q, 2); stage_end(4, q);
+    } else {
+      stage_begin(3, q); launch_compress<S>(v, b0, nb, q, 1); stage_end(3, q);
+      stage_begin(4, q); launch_compress<S>(v, b0, nb, q, 2); stage_end(4, q);
     }
-    stage_begin(3); launch_compress<S>(v, b0, nb, st, 1); stage_end(3);
-    stage_begin(4); launch_compress<S>(v, b0, nb, st, 2); stage_end(4);
+    stage_begin(5, q); launch_kalman<S>(v, b0, nb, q); stage_end(5, q);
   }
   int marginalize(int b0, int nb) override {
     if (chk_range(b0, nb)) return fail(-EINVAL, "trajectory range out of bounds");
     HIPCHK(hipSetDevice(device));
     use_single_worklists();
-    launch_update(view(b0), b0, nb);
+    launch_update(view(b0), b0, nb, st);
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -337,7 +335,7 @@ struct Batch : BatchBase {
     use_single_worklists();
     Dev<S> v = view(b);
     v.mode = 1;
-    launch_update(v, b, 1);
+    launch_update(v, b, 1, st);
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -588,27 +586,35 @@ int Batch<S>::run_frames(int f0, int f1) {
   // trajectory) overlap with the chip-filling stages of the others.  Stage profiling forces a single stream.
   const int nh = prof ? 1 : std::max(1, std::min(nstreams, B));
   if (nh > 1) { HIPCHK(hipEventRecord(ev_fork, st)); for (int i = 1; i < nh; ++i) HIPCHK(hipStreamWaitEvent(stx[i], ev_fork, 0)); }
-  hipStream_t saved = st;
-  for (int f = f0; f < f1; ++f) {
-    const size_t cell0 = (size_t)f * B;
-    for (int hh = 0; hh < nh; ++hh) {
-      const int b0 = (int)((long)B * hh / nh);
-      const int nb = (int)((long)B * (hh + 1) / nh) - b0;
-      st = stx[hh];
+  // one host thread per slice enqueues that slice's kernels for all frames: ~25 launches per frame and slice would
+  // otherwise serialise on one thread and make more than two slices launch-bound
+  auto enqueue = [&](int hh) {
+    (void)hipSetDevice(device);
+    hipStream_t q = stx[hh];
+    const int b0 = (int)((long)B * hh / nh);
+    const int nb = (int)((long)B * (hh + 1) / nh) - b0;
+    for (int f = f0; f < f1; ++f) {
+      const size_t cell0 = (size_t)f * B;
       Dev<S> v = d;
       v.trk_n = sc_n + cell0 + b0; v.trk_M = sc_M + (cell0 + b0) * f_cap; v.trk_slots = sc_slots + (cell0 + b0) * f_cap * m_cap;
       v.trk_obs = sc_obs + (cell0 + b0) * f_cap * m_cap * 2;
       v.wl_stride_n = 1; v.wl_stride_f = f_cap; v.wl_stride_o = (long)f_cap * m_cap;
-      stage_begin(0); launch_propagate<S>(v, b0, nb, sc_rd + (cell0 + b0) * sc_K * RD_STRIDE, (long)sc_K * RD_STRIDE, sc_K, st); stage_end(0);
-      stage_begin(1); launch_augment<S>(v, b0, nb, st); stage_end(1);
-      launch_update(v, b0, nb);
-      stage_begin(6);
-      hipLaunchKernelGGL(k_make_keep, dim3((nb + 63) / 64), dim3(64), 0, st, d.keep, d.nkeep, d.ncam, (const int*)(sc_drop + cell0 + b0), 0, n_cap, b0, nb);
-      launch_prune<S>(v, b0, nb, st);
-      stage_end(6);
+      stage_begin(0, q); launch_propagate<S>(v, b0, nb, sc_rd + (cell0 + b0) * sc_K * RD_STRIDE, (long)sc_K * RD_STRIDE, sc_K, q); stage_end(0, q);
+      stage_begin(1, q); launch_augment<S>(v, b0, nb, q); stage_end(1, q);
+      launch_update(v, b0, nb, q);
+      stage_begin(6, q);
+      hipLaunchKernelGGL(k_make_keep, dim3((nb + 63) / 64), dim3(64), 0, q, d.keep, d.nkeep, d.ncam, (const int*)(sc_drop + cell0 + b0), 0, n_cap, b0, nb);
+      launch_prune<S>(v, b0, nb, q);
+      stage_end(6, q);
     }
+  };
+  if (nh == 1) enqueue(0);
+  else {
+    std::vector<std::thread> th;
+    for (int hh = 1; hh < nh; ++hh) th.emplace_back(enqueue, hh);
+    enqueue(0);
+    for (auto& t : th) t.join();
   }
-  st = saved;
   for (int i = 1; i < nh; ++i) { HIPCHK(hipEventRecord(ev_join[i], stx[i])); HIPCHK(hipStreamWaitEvent(st, ev_join[i], 0)); }
   HIPCHK(hipGetLastError());
   return 0;
