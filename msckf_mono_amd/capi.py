@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmsckf_hip.so")
+LIB_PATH = os.environ.get("MSCKF_HIP_LIB", os.path.join(_HERE, "libmsckf_hip.so"))   # override: A/B experiments only
 _LIB = None
 
 F32, F64 = 0, 1

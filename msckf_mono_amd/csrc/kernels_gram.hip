@@ -18,6 +18,8 @@
 //   k_chol_T  register-resident right-looking Cholesky (16 x 16 thread grid, 2-D block-cyclic, one LDS exchange
 //             and one barrier per step) with semi-definite pivot skipping; writes [T | r_n] in the layout the
 //             Kalman stage reads
+#include <cstdlib>
+#include <utility>
 #include "dev_common.h"
 
 namespace msckf {
@@ -186,8 +188,27 @@ __global__ __launch_bounds__(256) void k_gram(Dev<S> d, int b0, int npairs, int 
           const int i = 64 * ti + wi * 32 + ib * 16 + (lane >> 4) + 4 * r;
           const int j = 64 * tj + wj * 32 + jb * 16 + (lane & 15);
           Lam[(long)i * ldL + j] = acc[tj][ib][jb][r];
+          Lam[(long)j * ldL + i] = acc[tj][ib][jb][r];   // mirrored copy: k_chol_blk reads the lower triangle row-wise
         }
   }
+}
+
+// Lam^(I, J) = (block-diagonal part) - (sum B^T B)(I, J) for the lower triangle incl. row n (= H_o^T r_o); rows beyond
+// n and the (n, n) corner are not needed and read as zero.  Branch-free: both loads are issued unconditionally from
+// clamped addresses and masked afterwards, so that a thread's loads are all in flight together (with a conditional
+// per element the compiler drains vmcnt between them and the ~80 loads of a thread run back to back).
+// Lam holds both triangles; (hi, lo) addressing reads it row-wise.
+__device__ __forceinline__ double lam_hat(const double* Lam, const double* Dg, int ldL, int n, int n_cap, int I, int J) {
+  const int hi = I >= J ? I : J, lo = I >= J ? J : I;
+  const bool ok = hi <= n && lo < n;
+  const int hic = min(hi, ldL - 1), loc = min(lo, ldL - 1);
+  const double lv = Lam[(long)hic * ldL + loc];
+  const bool isy = hi == n, isd = !isy && (hi / 6 == lo / 6);
+  const int a6 = lo % 6, c6 = hi % 6;
+  const int idx = isy ? 21 + a6 : (isd ? a6 * 6 - a6 * (a6 - 1) / 2 + (c6 - a6) : 0);
+  const double dg = Dg[min(lo / 6, n_cap - 1) * DG_STRIDE + idx];
+  const double val = ((isy || isd) ? dg : 0.0) - lv;
+  return ok ? val : 0.0;
 }
 
 // [T | r_n] = chol(Lam^) with Lam^ = Dg - sum B^T B; element (i, j), i >= j, of the lower factor lives in thread
@@ -211,16 +232,9 @@ __global__ __launch_bounds__(256) void k_chol_T(Dev<S> d, int b0) {
     for (int bb = 0; bb < NBN; ++bb) {
       if (a < bb) continue;
       const int i = G * a + tx, j = G * bb + ty;
-      double val = 0.0;
-      if (i >= j && i <= n && j < n) {
-        val = -Lam[(long)j * ldL + i];
-        if (i == n) val += Dg[(j / 6) * DG_STRIDE + 21 + j % 6];
-        else if (i / 6 == j / 6) {
-          const int ii = i % 6, jj = j % 6;   // jj <= ii: upper-triangle index (jj, ii)
-          val += Dg[(i / 6) * DG_STRIDE + jj * 6 - jj * (jj - 1) / 2 + (ii - jj)];
-        }
-        if (i == j) sD0[i] = val;
-      }
+      const double lv = lam_hat(Lam, Dg, ldL, n, d.n_cap, i, j);
+      const double val = i >= j ? lv : 0.0;
+      if (i == j && i < n) sD0[i] = val;
       A[a][bb] = val;
     }
   __syncthreads();
@@ -275,18 +289,169 @@ __global__ __launch_bounds__(256) void k_chol_T(Dev<S> d, int b0) {
   if (tid == 0) st[STAT_RROWS] = n - nskip;
 }
 
+// Blocked right-looking Cholesky of Lam^ on the f64 matrix cores.  The trailing matrix lives in MFMA accumulator
+// registers: 16 x 16 blocks, 2 x 2 block-cyclic over the four wavefronts (block (i, j) belongs to wave 2 (i & 1) +
+// (j & 1), <= 21 blocks = 168 registers per lane).  Per panel of 16 columns: the owners drop the panel's blocks into
+// LDS, wave 0 factors the 16 x 16 diagonal block (lanes = rows, pivot/column broadcasts by v_readlane, semi-definite
+// pivot skipping as in k_chol_T), all threads solve their row of the panel against it (thread = matrix row), the
+// finished rows of T = L^T go to global memory, and every wave applies the rank-16 update to its blocks with
+// v_mfma_f64_16x16x4_f64 (operands straight from the LDS panel).  12 panels x 4 barriers instead of 180 x 1, and
+// the O(n^3) part runs at MFMA rate.
+template <class F, int... Ps>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Ps...>) { (f(std::integral_constant<int, Ps>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <class S, int NBLK>
+__global__ __launch_bounds__(256) void k_chol_blk(Dev<S> d, int b0, int dbg) {
+  constexpr int H = NBLK / 2, NR = 16 * NBLK, LP = 17;
+  const int b = b0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int pi = w >> 1, pj = w & 1;
+  int* st = d.stats + (long)b * STAT_STRIDE;
+  if (st[STAT_MROWS] == 0) return;
+  const int N = d.ncam[b], n = 6 * N, ldL = d.ldR;
+  const double* Lam = d.Lam + (long)b * ldL * ldL;
+  const double* Dg = d.Dg + (long)b * d.n_cap * DG_STRIDE;
+  S* Rt = d.Rbuf + ((long)b * d.nchunk) * (long)d.n6cap * d.ldR;
+  __shared__ double sP[NR][LP];     // current panel: rows 0 .. NR-1, 16 columns
+  __shared__ double sL[16][LP];     // factored diagonal block
+  __shared__ double sDinv[16];
+  __shared__ double sD0[NR];
+  v4d acc[H][H];
+#pragma unroll
+  for (int ii = 0; ii < H; ++ii)
+#pragma unroll
+    for (int jj = 0; jj <= ii; ++jj) {                 // jj > ii is never a lower block, whatever the wave's parity
+      acc[ii][jj] = v4d{0.0, 0.0, 0.0, 0.0};
+      const int i = 2 * ii + pi, j = 2 * jj + pj;
+      if (i < j || 16 * j >= n || 16 * i > n) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[ii][jj][r] = lam_hat(Lam, Dg, ldL, n, d.n_cap, 16 * i + (lane >> 4) + 4 * r, 16 * j + (lane & 15));
+    }
+  for (int t = tid; t < NR; t += 256) { const double dv = lam_hat(Lam, Dg, ldL, n, d.n_cap, t, t); sD0[t] = t < n ? dv : 0.0; }
+  const double tol = 64.0 * 2.220446049250313e-16;
+  int nskip = 0;
+  // the panel index must be a compile-time constant (it selects accumulator registers): static_for, not a loop
+  auto panel = [&](auto pc) __attribute__((always_inline)) {
+    constexpr int p = decltype(pc)::value;
+    if (16 * p < n) {
+    __syncthreads();                                    // previous panel's operands are no longer read
+    // ---- (a) the panel's blocks (i, p), i >= p, from the accumulators to LDS
+    if (pj == (p & 1)) {
+#pragma unroll
+      for (int ii = 0; ii < H; ++ii) {
+        const int i = 2 * ii + pi;
+        if (i < p || 16 * i > n || (p >> 1) > ii) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sP[16 * i + (lane >> 4) + 4 * r][lane & 15] = acc[ii][(p >> 1) <= ii ? (p >> 1) : 0][r];
+      }
+    }
+    __syncthreads();
+    // ---- (b) diagonal block: lanes 0..15 of wave 0 hold one row each
+    if (w == 0 && !(dbg & 32)) {
+      const int kcount = min(16, n - 16 * p);
+      const int lr = lane & 15;
+      double x[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) x[j] = sP[16 * p + lr][j];
+      const double d0 = sD0[16 * p + lr];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        // every lane takes the rsqrt of its own x[k]; lane k's is the pivot's
+        const bool skip_l = (k >= kcount) || !(x[k] > tol * d0);
+        const double dinv_l = skip_l ? 0.0 : fast_rsqrt(x[k]);
+        const double dinv = wave_bcast(dinv_l, k);
+        const double pv = wave_bcast(x[k], k);
+        if (k < kcount && dinv == 0.0) ++nskip;
+        x[k] = lr == k ? pv * dinv : (lr > k ? x[k] * dinv : 0.0);
+        if (lane == 0) sDinv[k] = dinv;
+#pragma unroll
+        for (int j = k + 1; j < 16; ++j) {
+          const double ljk = wave_bcast(x[k], j);       // L(j, k)
+          if (lr >= j) x[j] -= x[k] * ljk;
+        }
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { sL[lane][j] = x[j]; sP[16 * p + lane][j] = x[j]; }
+      }
+    }
+    __syncthreads();
+    // ---- (c) rows below the diagonal block: thread = matrix row, forward substitution against L_pp
+    {
+      const int R = 16 * p + 16 + tid;
+      if (tid < NR - 16 * p - 16 && R <= n && !(dbg & 64)) {
+        double x[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x[j] = sP[R][j];
+        // column-oriented: after x[k] is final the 15-k updates are independent (dependency depth 16, not 120)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          x[k] *= sDinv[k];
+#pragma unroll
+          for (int j = k + 1; j < 16; ++j) x[j] -= x[k] * sL[j][k];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sP[R][j] = x[j];
+      }
+    }
+    __syncthreads();
+    // ---- (d) rows 16p .. 16p+15 of T = L^T are final: T[k][c] = L(c, k), zero left of the diagonal and beyond column n
+    if (tid < NR && !(dbg & 128)) {
+      const int c = tid;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int k = 16 * p + j;
+        const double val = (c >= k && c <= n) ? sP[c][j] : 0.0;
+        if (k < n) Rt[(long)k * d.ldR + c] = (S)val;
+      }
+    }
+    // ---- (e) rank-16 update of the trailing blocks on the matrix cores: acc(i, j) -= L(i, p) L(j, p)^T
+#pragma unroll
+    for (int ii = 0; ii < H; ++ii)
+#pragma unroll
+      for (int jj = 0; jj <= ii; ++jj) {
+        const int i = 2 * ii + pi, j = 2 * jj + pj;
+        if (2 * jj + 1 <= p) continue;                  // compile-time: at or left of the panel for either parity
+        if (i < j || j <= p || 16 * i > n || 16 * j >= n || (dbg & 256)) continue;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const double a = -sP[16 * i + (lane & 15)][4 * s4 + (lane >> 4)];
+          const double bq = sP[16 * j + (lane & 15)][4 * s4 + (lane >> 4)];
+          acc[ii][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq, acc[ii][jj], 0, 0, 0);
+        }
+      }
+    }
+  };
+  static_for<NBLK>(panel);
+  if (tid == 0) st[STAT_RROWS] = n - nskip;
+}
+
 template <class S>
 void launch_gram(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase) {
   if (nb <= 0) return;
+  static const int env_dbg = getenv("MSCKF_GRAM_DBG") ? atoi(getenv("MSCKF_GRAM_DBG")) : 0;   // experiments
+  const int g_dbg = g_gram_dbg | env_dbg;
   const int npairs = d.ldR / 64, ndiag = (d.n_cap + 3) / 4;   // one SYRK strip per 64-column panel
   if (phase != 2) {
     // two launches of the same kernel: the block-diagonal reduction (short, many small workgroups) and the SYRK strips
     // (MFMA-bound, <= 192 workgroups).  In ONE launch the dispatcher packs strips two to a CU behind the reduction
     // workgroups and they share the matrix cores (measured: MFMA phase 2x longer).
-    hipLaunchKernelGGL(k_gram<S>, dim3(ndiag, nb), dim3(256), 0, st, d, b0, npairs, g_gram_dbg, npairs);
-    hipLaunchKernelGGL(k_gram<S>, dim3(npairs, nb), dim3(256), 0, st, d, b0, npairs, g_gram_dbg, 0);
+    hipLaunchKernelGGL(k_gram<S>, dim3(ndiag, nb), dim3(256), 0, st, d, b0, npairs, g_dbg, npairs);
+    hipLaunchKernelGGL(k_gram<S>, dim3(npairs, nb), dim3(256), 0, st, d, b0, npairs, g_dbg, 0);
   }
   if (phase == 1) return;
+  // k_chol_blk (blocked, trailing update on the f64 matrix cores) is 10 % faster than k_chol_T in isolation (104 vs
+  // 114 us) but holds the whole register file of its CU (256 VGPR + 188 AGPR), so nothing of the other slice's stream
+  // co-schedules with it: 3 % slower end to end with two streams.  Kept selectable (msckf_hip_debug_set(300, 16)).
+  if (g_dbg & 16) {
+    switch (d.ldR / 16) {
+      case 4: hipLaunchKernelGGL((k_chol_blk<S, 4>), dim3(nb), dim3(256), 0, st, d, b0, g_dbg); break;
+      case 8: hipLaunchKernelGGL((k_chol_blk<S, 8>), dim3(nb), dim3(256), 0, st, d, b0, g_dbg); break;
+      default: hipLaunchKernelGGL((k_chol_blk<S, 12>), dim3(nb), dim3(256), 0, st, d, b0, g_dbg); break;
+    }
+    return;
+  }
   switch (d.ldR / 16) {
     case 4: hipLaunchKernelGGL((k_chol_T<S, 4>), dim3(nb), dim3(256), 0, st, d, b0); break;
     case 8: hipLaunchKernelGGL((k_chol_T<S, 8>), dim3(nb), dim3(256), 0, st, d, b0); break;

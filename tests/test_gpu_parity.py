@@ -208,8 +208,9 @@ def test_information_form_equals_householder_route(capi, prec):
     cd = capi.F64 if prec == "f64" else capi.F32
     res = {}
     try:
-        for route in (0, 1):
-            capi.lib().msckf_hip_debug_set(100, route)
+        for route in (0, 1, 2):               # 2 = information form with the blocked MFMA Cholesky (k_chol_blk)
+            capi.lib().msckf_hip_debug_set(100, min(route, 1))
+            capi.lib().msckf_hip_debug_set(300, 16 if route == 2 else 0)
             bt = capi.Batch(1, N, F, N, cd)
             bt.initialize(0, tr.cfg, tr.imu0)
             for k in range(nf):
@@ -218,8 +219,12 @@ def test_information_form_equals_householder_route(capi, prec):
             bt.close()
     finally:
         capi.lib().msckf_hip_debug_set(100, -1)
+        capi.lib().msckf_hip_debug_set(300, 0)
     e = H.state_errors(res[1][0], res[0][0], res[1][1], res[0][1], res[1][2], res[0][2])
     assert H.worst(e) < (1e-8 if prec == "f64" else 3e-4), e
+    e2 = H.state_errors(res[2][0], res[1][0], res[2][1], res[1][1], res[2][2], res[1][2])
+    assert H.worst(e2) < (1e-9 if prec == "f64" else 3e-4), e2
+    assert res[2][3] == res[1][3]
     assert res[1][3]["m_rows"] == res[0][3]["m_rows"] > 0
     assert res[1][3]["r_rows"] < res[0][3]["r_rows"] == 6 * N            # gauge directions skipped
 
