@@ -605,6 +605,82 @@ __global__ __launch_bounds__(64) void k_select(Dev<S> d, int b0, int nb) {
   __shared__ int sCnt[64], sBase[64], sRows[64];
   sCnt[lane] = 0; sRows[lane] = 0;
   __syncthreads();
+  // ---- fast path (steady state, F <= 256): every per-track word is loaded ONCE, four tracks per lane, all loads in
+  // flight together; decisions, stable counting sort by first camera slot and the row prefix then run from registers
+  // and LDS.  (The generic path below re-reads per pass: ~12 dependent global round trips for a 64-thread kernel.)
+  if (!(nres <= 3 && d.mode == 0) && F <= 256) {
+    __shared__ short sMrow[256];
+    __shared__ short sOrd[256];
+    int sv[4], Mv[4], fv[4];
+    bool inc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int t = 64 * c + lane, tc = min(t, max(F - 1, 0));
+      const long tb = (long)b * d.f_cap + tc;
+      sv[c] = d.trk_status[tb]; Mv[c] = d.trk_M[(long)i * d.wl_stride_f + tc]; fv[c] = d.trk_first[tb] & 63;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int t = 64 * c + lane;
+      const bool in = t < F;
+      int sx = in ? sv[c] : 0;
+      const int M = in ? Mv[c] : 0;
+      bool m_rej = false, t_rej = false, g_rej = false, valid = false, incl = false;
+      if (in) {
+        if (M < 2 || !(sx & ST_MOTION_OK)) { m_rej = true; sx = (M < 2) ? 0 : (sx & ~(ST_TRI_VALID | ST_GATE_PASS)); }
+        else if (sx & ST_TRI_VALID) valid = true;
+        else { t_rej = true; sx &= ~ST_GATE_PASS; }
+        if (valid) { if (sx & ST_GATE_PASS) { incl = true; sx |= ST_INCLUDED; } else g_rej = true; }
+        d.trk_status[(long)b * d.f_cap + t] = sx;
+        sMrow[t] = (short)(2 * M - 3);
+      }
+      inc[c] = incl;
+      if (incl) { atomicAdd(&sCnt[fv[c]], 1); atomicAdd(&sRows[fv[c]], 2 * M - 3); }
+      mrej += __popcll(__ballot(m_rej)); trej += __popcll(__ballot(t_rej)); grej += __popcll(__ballot(g_rej));
+      pass += __popcll(__ballot(incl)); if (d.mode == 0) nres += __popcll(__ballot(valid));
+    }
+    __syncthreads();
+    {
+      const int c0 = sCnt[lane];
+      int scan = c0;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(scan, o, 64); if (lane >= o) scan += up; }
+      sBase[lane] = scan - c0;
+    }
+    __syncthreads();
+    const int nbin = min(d.n_cap, 64);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int bin = inc[c] ? fv[c] : -1;
+      int rank = 0, cnt = 0;
+      for (int sbin = 0; sbin < nbin; ++sbin) {
+        const unsigned long long m = __ballot(bin == sbin);
+        if (bin == sbin) { rank = __popcll(m & ((1ull << lane) - 1ull)); cnt = __popcll(m); }
+      }
+      int pos = 0;
+      if (inc[c]) { pos = sBase[bin] + rank; sOrd[pos] = (short)(64 * c + lane); order[pos] = 64 * c + lane; }
+      __syncthreads();
+      if (inc[c] && rank == 0) sBase[bin] += cnt;     // one writer per bin
+      __syncthreads();
+    }
+    int rows = 0;
+    for (int p0 = 0; p0 < pass; p0 += 64) {
+      const int p = p0 + lane;
+      const int r = p < pass ? (int)sMrow[sOrd[p]] : 0;
+      int scan = r;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(scan, o, 64); if (lane >= o) scan += up; }
+      if (p < pass) rs[p] = rows + scan - r;
+      rows += __shfl(scan, 63, 64);
+    }
+    if (lane == 0) {
+      rs[pass] = rows;
+      d.n_resid[b] = nres;
+      st[STAT_NTRACKS] = F; st[STAT_MOTION_REJ] = mrej; st[STAT_TRI_REJ] = trej; st[STAT_GATE_REJ] = grej;
+      st[STAT_PASSED] = pass; st[STAT_MROWS] = rows; st[STAT_RROWS] = rows > 0 ? 6 * d.ncam[b] : 0;
+    }
+    return;
+  }
   // ---- pass 1: decisions (status bits), per-bin counts
   if (nres <= 3 && d.mode == 0) {
     if (lane == 0) {
