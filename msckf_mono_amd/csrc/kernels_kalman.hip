@@ -571,20 +571,27 @@ __global__ __launch_bounds__(256) void k_inject(Dev<S> d, int b0) {
   const KView<S> v = make_view(d, b);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   S* sdx = reinterpret_cast<S*>(smem_raw);
+  // r_n (column n of [T | r_n]) once into LDS; dx = K r_n with 12 independent accumulators per row so that a dozen
+  // loads are in flight per thread (the product is pure latency: 140 KB per trajectory)
+  S* srn = sdx + d.ld;
+  if (!HAVE_DX) {
+    for (int a = tid; a < v.n; a += 256) srn[a] = v.R0[(long)a * v.ldR + v.n];
+    __syncthreads();
+  }
   for (int i = tid; i < v.D; i += 256) {
     S s = 0;
     if (HAVE_DX) s = d.dx[(long)b * d.ld + i];
     else {
-      S s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+      S acc[12];
+#pragma unroll
+      for (int u = 0; u < 12; ++u) acc[u] = 0;
       int a = 0;
-      for (; a + 3 < v.n; a += 4) {
-        s0 += v.K[(long)a * v.ld + i] * v.R0[(long)a * v.ldR + v.n];
-        s1 += v.K[(long)(a + 1) * v.ld + i] * v.R0[(long)(a + 1) * v.ldR + v.n];
-        s2 += v.K[(long)(a + 2) * v.ld + i] * v.R0[(long)(a + 2) * v.ldR + v.n];
-        s3 += v.K[(long)(a + 3) * v.ld + i] * v.R0[(long)(a + 3) * v.ldR + v.n];
+      for (; a + 11 < v.n; a += 12) {
+#pragma unroll
+        for (int u = 0; u < 12; ++u) acc[u] += v.K[(long)(a + u) * v.ld + i] * srn[a + u];
       }
-      for (; a < v.n; ++a) s0 += v.K[(long)a * v.ld + i] * v.R0[(long)a * v.ldR + v.n];
-      s = (s0 + s1) + (s2 + s3);
+      for (; a < v.n; ++a) acc[0] += v.K[(long)a * v.ld + i] * srn[a];
+      s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7])) + ((acc[8] + acc[9]) + (acc[10] + acc[11]));
       d.dx[(long)b * d.ld + i] = s;
     }
     sdx[i] = s;
@@ -674,7 +681,7 @@ void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st) {
     gemm<S, OP_K>(d, b0, nb, D, n, st);
   }
   if (nbn <= nbn_max && !split) hipLaunchKernelGGL((k_inject<S, true>), dim3(nb), dim3(256), (size_t)d.ld * sizeof(S), st, d, b0);
-  else hipLaunchKernelGGL((k_inject<S, false>), dim3(nb), dim3(256), (size_t)d.ld * sizeof(S), st, d, b0);
+  else hipLaunchKernelGGL((k_inject<S, false>), dim3(nb), dim3(256), (size_t)(d.ld + d.n6cap) * sizeof(S), st, d, b0);
   gemm<S, OP_A>(d, b0, nb, D, D, st);
   gemm<S, OP_AP>(d, b0, nb, D, D, st);
   gemm<S, OP_X>(d, b0, nb, D, D, st);

@@ -97,6 +97,9 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
   __shared__ S sPii[225];
   __shared__ S sNull[12];          // q_null v_null p_null used by the next sample
   __shared__ S sG[4];
+  __shared__ S sRd[PG * RD_STRIDE];  // the group's IMU samples, staged once (the state chain is one thread: a global
+                                      // read per sample would put a memory round trip on every step of the chain)
+  __shared__ S sQ[12];
   S* imu = d.imu + (long)b * IMU_STRIDE;
   const S* prm = d.prm + (long)b * PRM_STRIDE;
   S* P = d.P + (long)b * d.ld * d.ld;
@@ -105,6 +108,7 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
   const S* rd = readings + (long)(b - b0) * rd_stride;
   if (tid < 16) sState[tid] = imu[tid];                 // q b_g v b_a p
   if (tid < 3) sG[tid] = imu[IG + tid];
+  if (tid >= 64 && tid < 64 + 12) sQ[tid - 64] = prm[PRM_Q + tid - 64];
   if (tid >= 32 && tid < 32 + 10) sNull[tid - 32] = imu[IQN + (tid - 32)];
   for (int e = tid; e < 225; e += 256) {
     const int i = e / 15, j = e % 15;
@@ -115,11 +119,13 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
   int cur = 0;   // which sTot buffer is current
   for (int k0 = 0; k0 < K; k0 += PG) {
     const int G = min(PG, K - k0);
+    for (int e = tid; e < G * RD_STRIDE; e += 256) sRd[e] = rd[(long)k0 * RD_STRIDE + e];
+    __syncthreads();
     const V3<S> g = mk3(sG[0], sG[1], sG[2]);
     // ---- A: state chain
     if (tid == 0) {
       for (int s = 0; s < G; ++s) {
-        const S* r = rd + (long)(k0 + s) * RD_STRIDE;
+        const S* r = sRd + s * RD_STRIDE;
         imu_rk(sState + s * SST, g, ld3(r), ld3(r + 3), r[6], sState + (s + 1) * SST);
       }
     }
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
       S* A = sScr[w]; S* T1 = A + 225; S* T2 = A + 450;
       S* Phi = sPhi + s * 225;
       const S* st = sState + s * SST;
-      const S* r = rd + (long)(k0 + s) * RD_STRIDE;
+      const S* r = sRd + s * RD_STRIDE;
       const S dT = r[6];
       const V3<S> wh = ld3(r) - ld3(st + 4), ah = ld3(r + 3) - ld3(st + 10);
       const M3<S> C = q2rot(ldq(st));
@@ -200,18 +206,18 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
       S* T1 = sScr[0]; S* T2 = sScr[0] + 225;
       for (int s = 0; s < G; ++s) {
         const S* st = sState + s * SST;
-        const S dT = rd[(long)(k0 + s) * RD_STRIDE + 6];
+        const S dT = sRd[s * RD_STRIDE + 6];
         const M3<S> C = q2rot(ldq(st));
         S* Pi = sPii;
         if (lane < 9) {   // + G Q G^T dT = diag(Qw, Qbg, C^T Qa C, Qba, 0) dT   (calcG :899-902, Q diagonal)
           const int i = lane / 3, j = lane % 3;
           if (i == j) {
-            Pi[i * 15 + i] += prm[PRM_Q + i] * dT;
-            Pi[(3 + i) * 15 + 3 + i] += prm[PRM_Q + 3 + i] * dT;
-            Pi[(9 + i) * 15 + 9 + i] += prm[PRM_Q + 9 + i] * dT;
+            Pi[i * 15 + i] += sQ[i] * dT;
+            Pi[(3 + i) * 15 + 3 + i] += sQ[3 + i] * dT;
+            Pi[(9 + i) * 15 + 9 + i] += sQ[9 + i] * dT;
           }
           S sm = 0;
-          for (int kk = 0; kk < 3; ++kk) sm += C.m[kk][i] * prm[PRM_Q + 6 + kk] * C.m[kk][j];
+          for (int kk = 0; kk < 3; ++kk) sm += C.m[kk][i] * sQ[6 + kk] * C.m[kk][j];
           Pi[(6 + i) * 15 + 6 + j] += sm * dT;
         }
         wave_sync();
