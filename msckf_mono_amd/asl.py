@@ -156,9 +156,32 @@ def initial_state(ds, start_ns=None):
     return np.concatenate([q, gt["b_g"][i], v, gt["b_a"][i], p, sc.GRAVITY, q, v, p])
 
 
-def run(ds, flt, cfg, start_ns=None, prune_redundant=False, on_frame=None):
+# stage names of the reference's StageTiming message (msg/StageTiming.msg: string[] stages, float64[] times) as the
+# ASL runner records them, datasets/asl_msckf.cpp:207-212 (TSTART/TEND/TRECORD) and :229-296
+STAGES = ("imu_prop", "msckf_augment_state", "msckf_update", "msckf_add_features", "msckf_marginalize",
+          "msckf_prune_redundant", "msckf_prune_empty_states")
+
+
+def run(ds, flt, cfg, start_ns=None, prune_redundant=False, on_frame=None, stage_timing=None):
     """Drive `flt` (any object with the reference's member names: msckf_mono_amd.capi.MSCKF or the oracle) through the
-    dataset in the reference's call order.  Returns the list of (timestamp_ns, imu_state29) after every image."""
+    dataset in the reference's call order.  Returns the list of (timestamp_ns, imu_state29) after every image.
+    `stage_timing`: a list that receives one StageTiming record per image, {"stamp": ns, "stages": [...], "times":
+    [...]} with the reference's stage names and wall-clock seconds; device work is synchronised at the end of every
+    stage (`flt.sync()` when the filter has one) so that the numbers compare with the reference's synchronous CPU
+    calls.  Timing changes nothing in the results."""
+    import time
+    sync = getattr(flt, "sync", None) if stage_timing is not None else None
+
+    def timed(rec, name, fn, *a):
+        if rec is None:
+            return fn(*a)
+        t0 = time.perf_counter()
+        r = fn(*a)
+        if sync is not None:
+            sync()
+        rec["stages"].append(name); rec["times"].append(time.perf_counter() - t0)
+        return r
+
     flt.initialize(cfg, initial_state(ds, start_ns))
     cam_set = set(int(t) for t in ds["cam_t"])
     out = []
@@ -171,15 +194,18 @@ def run(ds, flt, cfg, start_ns=None, prune_redundant=False, on_frame=None):
         state_k += 1                                                     # asl_msckf.cpp:227
         pend.append(rd)
         if int(t) in cam_set:
-            flt.propagate(np.array(pend)); pend = []                     # :233
+            rec = {"stamp": int(t), "stages": [], "times": []} if stage_timing is not None else None
+            timed(rec, "imu_prop", flt.propagate, np.array(pend)); pend = []        # :229-238
             tr = ds["tracks"].get(int(t), {"cur": ([], []), "new": ([], [])})
-            flt.augmentState(state_k, t / 1e9)                           # :269
-            flt.update(np.array(tr["cur"][0]).reshape(-1, 2), tr["cur"][1])   # :274
-            flt.addFeatures(np.array(tr["new"][0]).reshape(-1, 2), tr["new"][1])   # :279
-            flt.marginalize()                                            # :284
+            timed(rec, "msckf_augment_state", flt.augmentState, state_k, t / 1e9)                         # :268-271
+            timed(rec, "msckf_update", flt.update, np.array(tr["cur"][0]).reshape(-1, 2), tr["cur"][1])   # :273-276
+            timed(rec, "msckf_add_features", flt.addFeatures, np.array(tr["new"][0]).reshape(-1, 2), tr["new"][1])   # :278-281
+            timed(rec, "msckf_marginalize", flt.marginalize)                                              # :283-286
             if prune_redundant:
-                flt.pruneRedundantStates()                               # :289
-            flt.pruneEmptyStates()                                       # :294
+                timed(rec, "msckf_prune_redundant", flt.pruneRedundantStates)                             # :288-291
+            timed(rec, "msckf_prune_empty_states", flt.pruneEmptyStates)                                  # :293-296
+            if rec is not None:
+                stage_timing.append(rec)
             s = np.array(flt.getImuState())
             out.append((int(t), s))
             if on_frame is not None:
@@ -187,6 +213,16 @@ def run(ds, flt, cfg, start_ns=None, prune_redundant=False, on_frame=None):
     if pend:
         flt.propagate(np.array(pend))
     return out
+
+
+def write_stage_timing(path, records):
+    """StageTiming records as CSV `stamp_ns,stage,seconds` -- one line per (image, stage), the content of the
+    reference's `stage_timing` topic (asl_msckf.cpp:193, :470)."""
+    with open(path, "w") as f:
+        f.write("#stamp [ns],stage,seconds\n")
+        for r in records:
+            for st, tm in zip(r["stages"], r["times"]):
+                f.write("%d,%s,%.9f\n" % (r["stamp"], st, tm))
 
 
 def ate(traj_out, ds):

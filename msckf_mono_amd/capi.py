@@ -261,6 +261,9 @@ class MSCKF:
     def pruneRedundantStates(self):
         self.batch.prune_redundant_states(0)
 
+    def sync(self):
+        self.batch.sync()
+
     def pruneEmptyStates(self):
         self.batch.prune_empty_states(0)
 

@@ -51,6 +51,26 @@ def test_runner_equals_scenario_loop(dataset, oracle_lib):
     assert n == tr.n_frames and e < 0.02
 
 
+def test_stage_timing_records_follow_the_reference_message(dataset, oracle_lib, tmp_path):
+    """StageTiming (msg/StageTiming.msg): one record per image with the stage names of asl_msckf.cpp:229-296, and the
+    timed run gives the same states as the untimed one."""
+    po = oracle_lib
+    tr, ds = dataset
+    cfg = tr.cfg
+    a, b = po.Oracle(po.F64, po.LEAN), po.Oracle(po.F64, po.LEAN)
+    rec = []
+    out_t = asl.run(ds, a, cfg, prune_redundant=True, stage_timing=rec)
+    out = asl.run(ds, b, cfg, prune_redundant=True)
+    assert len(rec) == len(out) == len(ds["cam_t"])
+    for r, (t, _) in zip(rec, out):
+        assert r["stamp"] == t and tuple(r["stages"]) == asl.STAGES and all(x >= 0 for x in r["times"])
+    assert all(np.array_equal(x[1], y[1]) for x, y in zip(out_t, out))
+    p = tmp_path / "stage_timing.csv"
+    asl.write_stage_timing(str(p), rec)
+    lines = p.read_text().splitlines()
+    assert len(lines) == 1 + len(rec) * len(asl.STAGES) and lines[1].split(",")[1] == "imu_prop"
+
+
 def test_default_parameters_match_the_reference_runner(dataset):
     _, ds = dataset
     cfg = asl.filter_config_from_dataset(ds)
