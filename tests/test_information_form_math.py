@@ -1,0 +1,110 @@
+"""The algebra behind the information-form compression of kernels_gram.hip, checked on the CPU with the numpy twin
+(no GPU): for the tracks of one marginalize call
+    H_o^T H_o = blockdiag(sum h^T h) - sum_j B_j^T B_j ,  B_j = Q_f^T H_x_j ,
+its Cholesky factor with semi-definite pivot skipping is R of the stacked QR up to row signs (T^T T = R^T R), the
+skipped pivots are the unobservable directions of the window, and the Kalman update computed from [T | r_n] equals the
+one computed from the QR's [R | Q^T r]."""
+import numpy as np
+import scipy.linalg as sla
+
+from msckf_mono_amd import scenario as sc
+import np_oracle
+
+
+def _capture(N=8, F=24, nf=13, seed_traj=5):
+    cfg = sc.filter_config(N)
+    tr = sc.Trajectory(2, seed_traj, N, F, nf, cfg)
+    flt = np_oracle.NpMSCKF(cfg, tr.imu0, nullspace="householder")
+    cap = {}
+    orig = flt.jac
+
+    def jac(p_f, slots, obs):          # same maths as NpMSCKF.jac, keeping the unprojected blocks
+        Ho, ro, A_j = orig(p_f, slots, obs)
+        M, D = len(slots), flt.P.shape[0]
+        Hf, Hx, r = np.zeros((2 * M, 3)), np.zeros((2 * M, D)), np.zeros(2 * M)
+        for c, s in enumerate(slots):
+            cam = flt.cams[s]
+            C = np_oracle.q2R(cam["q"]); pc = C @ (p_f - cam["p"]); X, Y, Z = pc
+            Ji = np.array([[1, 0, -X / Z], [0, 1, -Y / Z]]) / Z
+            A = np.hstack([Ji @ np_oracle.skew(pc), -Ji @ C])
+            u = np.concatenate([C @ flt.g, np_oracle.skew(p_f - cam["p"]) @ flt.g])
+            H = A - np.outer(A @ u, u) / (u @ u)
+            Hf[2 * c:2 * c + 2] = -H[:, 3:6]; Hx[2 * c:2 * c + 2, 15 + 6 * s:21 + 6 * s] = H
+            r[2 * c:2 * c + 2] = obs[c] - pc[:2] / Z
+        cap.setdefault("cur", []).append((Hx, Hf, r, Ho, ro))
+        return Ho, ro, A_j
+    flt.jac = jac
+    orig_mu = flt.measurement_update
+    out = {}
+
+    def mu(H, r, R):
+        out["H"], out["r"], out["P"], out["tracks"] = H.copy(), r.copy(), flt.P.copy(), cap.pop("cur")
+        orig_mu(H, r, R)
+    flt.measurement_update = mu
+    for k in range(nf):
+        for rd in tr.imu_for_frame(k):
+            flt.propagate(rd)
+        flt.augment(k)
+        fr = tr.frames[k]
+        cap.pop("cur", None)
+        if len(fr["M"]):
+            flt.set_tracks(fr["M"], fr["slots"], fr["obs"])
+            flt.marginalize()
+        if len(flt.cams) == N:
+            flt.drop_oldest(1)
+    return cfg, out
+
+
+def _chol_skip(Lam_hat, n, tol=64 * np.finfo(float).eps):
+    """lower Cholesky of the (n+1)x(n+1) matrix [H|r]^T[H|r] over the first n pivots, zero column for a skipped pivot"""
+    A = Lam_hat.copy()
+    L = np.zeros((n + 1, n))
+    d0 = np.diag(A).copy()
+    skipped = 0
+    for k in range(n):
+        if not A[k, k] > tol * d0[k]:
+            skipped += 1
+            continue
+        L[k:, k] = A[k:, k] / np.sqrt(A[k, k])
+        A[k:, k:] -= np.outer(L[k:, k], L[k:, k])
+    return L, skipped
+
+
+def test_gram_of_the_projected_stack_and_its_factor():
+    cfg, c = _capture()
+    H, r, P = c["H"], c["r"], c["P"]
+    n = H.shape[1] - 15
+    Hc = np.hstack([H[:, 15:], r[:, None]])
+    assert sum(t[3].shape[0] for t in c["tracks"]) == H.shape[0]     # every track of this frame passed the gate
+    # information form from the UNPROJECTED per-track blocks
+    Lam = np.zeros((n + 1, n + 1))
+    for Hx, Hf, rr, _, _ in c["tracks"]:
+        Hh = np.hstack([Hx[:, 15:], rr[:, None]])
+        Qf = np.linalg.qr(Hf, mode="reduced")[0]
+        B = Qf.T @ Hh
+        Lam += Hh.T @ Hh - B.T @ B
+    G = Hc.T @ Hc
+    assert np.linalg.norm(Lam - G) < 1e-12 * np.linalg.norm(G)
+    # its factor against the QR of the stack
+    L, skipped = _chol_skip(Lam, n)
+    T, rn = L[:n].T, L[n]
+    Rq = np.linalg.qr(Hc, mode="r")
+    R, Qtr = np.triu(Rq[:n, :n]), Rq[:n, n]
+    assert np.linalg.norm(T.T @ T - R.T @ R) < 1e-11 * np.linalg.norm(R.T @ R)
+    assert np.linalg.norm(T.T @ rn - R.T @ Qtr) < 1e-11 * np.linalg.norm(R.T @ Qtr)
+    # skipped pivots = rank deficiency of the stack (gauge freedoms + cameras no track of this frame sees)
+    sv = np.linalg.svd(H[:, 15:], compute_uv=False)
+    assert skipped == int(np.sum(sv < 1e-9 * sv[0])) > 0
+    # and the update is the same
+    sig2 = cfg["u_var_prime"]
+
+    def update(Tm, rv):
+        TH = np.zeros((Tm.shape[0], P.shape[0])); TH[:, 15:] = Tm
+        S = TH @ P @ TH.T + sig2 * np.eye(Tm.shape[0])
+        K = np.linalg.solve(S, TH @ P).T
+        A = np.eye(P.shape[0]) - K @ TH
+        return K @ rv, A @ P @ A.T + sig2 * K @ K.T
+    dx1, P1 = update(T, rn)
+    dx2, P2 = update(R, Qtr)
+    assert np.linalg.norm(dx1 - dx2) < 1e-9 * np.linalg.norm(dx2)
+    assert np.linalg.norm(P1 - P2) < 1e-10 * np.linalg.norm(P2)
