@@ -467,7 +467,7 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
     for (int s2 = 0; s2 < 2; ++s2) {
       const int row = row0 + s2;
       S a0 = 0, a1 = 0, a2 = 0;
-      if (row < R2) for (int c = 0; c < R2; ++c) { const S gval = sG[SYM(row, c)]; a0 += gval * sV[c * 3]; a1 += gval * sV[c * 3 + 1]; a2 += gval * sV[c * 3 + 2]; }
+      if (row < R2 && !(fdbg & 16)) for (int c = 0; c < R2; ++c) { const S gval = sG[SYM(row, c)]; a0 += gval * sV[c * 3]; a1 += gval * sV[c * 3 + 1]; a2 += gval * sV[c * 3 + 2]; }
       gv[s2][0] = a0; gv[s2][1] = a1; gv[s2][2] = a2;
     }
     S vgv[3][3];
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
   if (spd && gamma < thresh) status |= ST_GATE_PASS;
 
   // ---- publish the compact representation of the projected block
-  {
+  if (!(fdbg & 64)) {
     S* oHx = d.trk_Hx + (tb * m_cap) * 12;
     if (act)
       for (int i = 0; i < 2; ++i) for (int k = 0; k < 6; ++k) oHx[lane * 12 + i * 6 + k] = hx[i][k];
