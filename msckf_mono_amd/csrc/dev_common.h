@@ -197,9 +197,22 @@ template <int CTRL> __device__ __forceinline__ double dpp_x(double v) {
 template <int CTRL> __device__ __forceinline__ int dpp_x(int v) { return dpp_i<CTRL>(v); }
 constexpr int DPP_QUAD_X1 = 0xB1, DPP_QUAD_X2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
 
+// masked DPP move: lanes of the rows selected by ROWMASK receive the source lane's value, the others 0
+template <int CTRL, int ROWMASK> __device__ __forceinline__ int dppm_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWMASK, 0xF, false); }
+template <int CTRL, int ROWMASK> __device__ __forceinline__ float dppm_x(float v) { return __int_as_float(dppm_i<CTRL, ROWMASK>(__float_as_int(v))); }
+template <int CTRL, int ROWMASK> __device__ __forceinline__ double dppm_x(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = dppm_i<CTRL, ROWMASK>((int)(b & 0xffffffffLL)), hi = dppm_i<CTRL, ROWMASK>((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+
 template <class S> __device__ __forceinline__ S wave_sum(S v) {
   v += dpp_x<DPP_QUAD_X1>(v); v += dpp_x<DPP_QUAD_X2>(v); v += dpp_x<DPP_HALF_MIRROR>(v); v += dpp_x<DPP_ROW_MIRROR>(v);
-  return (wave_bcast(v, 0) + wave_bcast(v, 16)) + (wave_bcast(v, 32) + wave_bcast(v, 48));
+  // every lane holds its row's sum: fold row 0 into 1 and 2 into 3, then rows {0,1} into 3; lane 63 has the total
+  v += dppm_x<DPP_ROW_BCAST15, 0xA>(v);
+  v += dppm_x<DPP_ROW_BCAST31, 0xC>(v);
+  return wave_bcast(v, 63);
 }
 template <class S> __device__ __forceinline__ S wave_max(S v) {
   S t;
