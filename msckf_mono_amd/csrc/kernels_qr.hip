@@ -1,25 +1,26 @@
-// kernels_qr.hip -- QR compression of the stacked projected Jacobian (msckf.h:1338-1366) as a streaming
-// TSQR on gfx950.
+// kernels_qr.hip -- Householder compression of the stacked projected Jacobian (msckf.h:1338-1366) as a streaming
+// TSQR on gfx950.  Route (b) of DESIGN.md section 4.4: used for windows with n + 1 > 192 and as the A/B reference of
+// the information-form route (kernels_gram.hip), which is the default below that size.
 //
 // The reference stacks H_o (m x D, m ~ 5 600 for 200 tracks in a 30-camera window), runs a dense
 // HouseholderQR, forms the FULL m x m Q and a dense m x m R_o (msckf.h:1343-1366).  Here H_o is never
-// materialised: every workgroup owns an n x (n+1) upper-triangular work matrix [R | Q^T r] in HBM/L2
-// (n = 6 N camera columns -- the 15 IMU columns of H_o are identically zero, msckf.h:949) and folds blocks
-// of 4*RW rows into it with structured Householder reflectors ("QR update" of [R; B]).  Rows are
-// regenerated on the fly from the per-track compact form written by k_feature:
+// materialised: every workgroup owns an n x (n+1) upper-triangular work matrix [R | Q^T r], packed in LDS when it
+// fits (n = 6 N camera columns -- the 15 IMU columns of H_o are identically zero, msckf.h:949) and folds blocks of
+// RW rows into it with structured Householder reflectors ("QR update" of [R; B]).  Rows are regenerated on the fly
+// from the per-track compact form written by k_feature:
 //       H_o_j[i, col] = [col in the 6 columns of obs (3+i)/2] Hx[(3+i)&1][.] - V[3+i,:] . Zf[:, col]
-// Block layout inside a workgroup (256 threads = 4 wavefronts):
-//   wave h owns rows h*RW .. h*RW+RW-1 of the block, lane l owns columns l, l+64, ... (NC per lane);
-//   the block lives in registers (RW*NC per lane).  Step k: the wave that needs column k reads it from
-//   the owner lane with v_readlane (no LDS), every wave forms partial dot products over its rows, one
-//   LDS exchange + one barrier combines them (the norm of column k comes out of the same exchange as
-//   its self-product), then R's row k and the block are updated.  R's row k is only touched in step k, so
-//   it is streamed from/to L2 with coalesced row accesses.
-// TSQR: stage 1 = nchunk independent row chunks per trajectory, stage 2 = one merge of all chunk triangles
-// into chunk 0 (same kernel, rows sourced from the other chunks' R, interleaved by row index).  With isotropic pixel noise
-// (u_var' == v_var', the configuration BASELINE.json is quoted on) the Kalman update depends on the
-// stack only through H_o^T H_o and H_o^T r_o, so any orthogonal compression gives the reference's result;
-// R_n = sigma^2 I exactly.
+// Layout inside a workgroup (QR_NW = 12 wavefronts): ONE wavefront owns one block of RW rows at a time, lane l holds
+// columns l, l+64, ... (NC per lane) of all RW rows in registers.  Step k needs no LDS exchange and no barrier inside
+// the wave: the pivot column comes from its owner lane with v_readlane, the dot products are lane-local over the RW
+// rows, the column norm is the pivot column's self product.  The wavefronts form a software pipeline over R's rows:
+// block q may run step k as soon as block q-1 has finished step k; R's row k is handed from wave to wave through LDS
+// with a workgroup-scope release/acquire progress word per block.
+// TSQR: stage 1 = nchunk workgroups per trajectory (the sorted blocks are dealt round-robin, so every chunk sees the
+// same mix of leading-zero counts), stage 2 = one merge of all chunk triangles into chunk 0 (same kernel, rows sourced
+// from the other chunks' R, interleaved by row index).  With isotropic pixel noise (u_var' == v_var', the
+// configuration BASELINE.json is quoted on) the Kalman update depends on the stack only through H_o^T H_o and
+// H_o^T r_o, so any orthogonal compression gives the reference's result; R_n = sigma^2 I exactly (SURVEY.md 8a
+// Q1/Q1b/Q2); anisotropic noise is handled by pre-whitening the rows.
 #include "dev_common.h"
 
 namespace msckf {
@@ -55,14 +56,14 @@ struct Tri {
   }
 };
 
-// One workgroup = 4 wavefronts working as a software pipeline over the rows of R: wavefront h owns the
-// row blocks h, h+4, h+8, ... of its chunk (RW rows x all columns in registers, lane l = columns l, l+64, ..),
+// One workgroup = QR_NW wavefronts working as a software pipeline over the rows of R: wavefront h owns the
+// row blocks h, h+QR_NW, h+2 QR_NW, ... of its chunk (RW rows x all columns in registers, lane l = columns l, l+64, ..),
 // and block q may run Householder step k as soon as block q-1 has finished step k (R's row k is handed
 // from wave to wave through LDS with a release/acquire progress word).  Inside a wavefront a step needs no
 // LDS exchange and no barrier: the pivot column is read from its owner lane with v_readlane, the dot
 // products are complete within the wave, the column norm is the pivot column's self product.
-constexpr int QR_NW = 12;
-constexpr int QR_MAXBLK = 512;   // row blocks per workgroup (progress words in LDS)   // wavefronts per workgroup = depth of the software pipeline
+constexpr int QR_NW = 12;        // wavefronts per workgroup = depth of the software pipeline
+constexpr int QR_MAXBLK = 512;   // ring of per-block progress words in LDS
 
 template <class S, int NC, int RW, bool RLDS>
 __global__ __launch_bounds__(64 * QR_NW) void k_qr_update(Dev<S> d, int b0, int stage, int level) {

@@ -132,7 +132,7 @@ struct Batch : BatchBase {
     d.ldR = ((6 * n_cap + 1 + 63) / 64) * 64;
     if (d.ldR / 64 > 6) return fail(-EINVAL, "n_cap too large for the QR kernel (6*n_cap+1 must be <= 384)");
     int nch = 1;
-    while (nch < 8 && (long)B * nch * 2 <= 256) nch *= 2;    // one 8-wave workgroup per CU covers 256 CUs
+    while (nch < 8 && (long)B * nch * 2 <= 256) nch *= 2;    // TSQR route: chunks x trajectories ~ one workgroup per CU
     d.nchunk = nch;
     const size_t Bz = B, pl = (size_t)d.ld * d.ld, nl = (size_t)d.n6cap * d.n6cap, dn = (size_t)d.ld * d.n6cap;
     const size_t TF = Bz * f_cap;
