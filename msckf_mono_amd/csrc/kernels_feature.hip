@@ -11,10 +11,13 @@
 // What is NOT done the reference's way: H_o_j = A_j^T H_x_j is never formed.  With
 // Q = I - V T V^T (compact WY of the 3 reflectors) the projected block is
 //     H_o_j = (H_x_j)[3:, :] - V[3:, :] * Z,     Z = T^T V^T H_x_j   (3 x 6M, block-local per lane)
-// so a track is handed to the compression stage as {H_x blocks, V, Z scattered to state columns, r_o} instead of
-// (2M-3)*(15+6N).  The gate uses G = H_x P_cc H_x^T assembled from 6x6 blocks of P (192 M^2 flop instead of
-// the dense 2 rho D^2) and S = (Q^T G Q)[3:,3:] + sigma^2 I as a rank-6 correction of G, factored by an
-// in-LDS Cholesky with r_o riding along as an extra row (gamma = |L^-1 r_o|^2).
+// so a track is handed to the TSQR route as {H_x blocks, V, Z scattered to state columns, r_o} instead of
+// (2M-3)*(15+6N); for the information-form route (default, kernels_gram.hip) it publishes B = Q_f^T [H_x | r] in f64
+// (reflectors redone in f64 so that H_o^T H_o = H_x^T H_x - B^T B holds to f64 rounding), the whitened residual and
+// the slot -> observation map.  The gate uses G = H_x P_cc H_x^T assembled from 6x6 blocks of P (192 M^2 flop instead
+// of the dense 2 rho D^2) and S = (Q^T G Q)[3:,3:] + sigma^2 I as a rank-6 correction of G, factored by a
+// register-resident Cholesky (8 x 8 lane grid, specialised on the track length; LDS fallback for 2M-2 > 64) with r_o
+// riding along as an extra row (gamma = |L^-1 r_o|^2).
 #include "chi2_table.h"
 #include "dev_common.h"
 

@@ -1,16 +1,18 @@
 // kernels_kalman.hip -- Kalman gain, state correction and Joseph-form covariance update (gfx950).
 //
 // Reference: MSCKF::measurementUpdate, msckf.h:1368-1418 (+ buildUpdateQuat :851-872).  Inputs are the
-// compressed measurement [T | r_n] left by the TSQR stage in Rbuf[b][0] (T upper triangular n x n over
-// the camera columns, n = 6N; the IMU columns of T_H are zero, msckf.h:949) and R_n = sigma^2 I.
+// compressed measurement [T | r_n] left by the compression stage (kernels_gram.hip or kernels_qr.hip) in Rbuf[b][0]
+// (T upper triangular n x n over the camera columns, n = 6N, possibly with zero rows; the IMU columns of T_H are
+// zero, msckf.h:949) and R_n = sigma^2 I.
 //   PHt = P[:,15:] T^T                      (D x n)
 //   S   = T PHt[15:,:] + sigma^2 I          (n x n)     :1369
-//   S^-1 via Cholesky S = L L^T, Linv = L^-1 (the reference calls .inverse(), :1370; S is SPD)
-//   K   = (PHt Linv^T) Linv                 (D x n)     :1370
+//   K   = PHt S^-1 by a register-resident Cholesky S = L L^T that carries [PHt ; I] along:
+//         [W ; E] = [PHt L^-T ; L^-T],  K = W E^T          (the reference calls .inverse(), :1370; S is SPD)
 //   dx  = K r_n, injected into the IMU and every camera state   :1373-1391
 //   A   = I - K T_H ;  P <- sym(A P A^T + sigma^2 K K^T)         :1394-1403
 // Every product is a batched 64x64-tile GEMM, LDS-staged: on the matrix cores (v_mfma_f32_32x32x2_f32) in
-// float, 4x4 VALU micro-tiles in double; trajectories with no gated-in rows are skipped.
+// float (zero k-tiles of the triangular operands skipped, S / X symmetric, P <- sym(X) fused into the X product),
+// 4x4 VALU micro-tiles in double; trajectories with no gated-in rows are skipped.
 #include "dev_common.h"
 
 namespace msckf {
