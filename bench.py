@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--streams", type=int, default=2, help="HIP streams for the timed region (halves of the batch run concurrently)")
+    ap.add_argument("--gate-early-accept", action="store_true",
+                    help="exact early accept of the chi-square gate (msckf_hip_set_gate_early_accept); OFF for the headline number")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -105,6 +107,7 @@ def main():
         bt.sync()
 
     bt.set_streams(args.streams)
+    bt.set_gate_early_accept(args.gate_early_accept)
     bt.run_frames(0, fill + W)       # window fill + warm-up (untimed)
     barrier()
     t0 = time.perf_counter()
@@ -169,7 +172,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[2]: synthetic 30-cam window / 200 feats, float, 64 batched trajectories per GPU",
                        "cam_window": N_WIN, "tracks_per_update": F_TRK, "trajectories_per_gpu": B_TRAJ, "imu_per_update": K_IMU,
-                       "parallelism": "replicated trajectories, %d per rank" % B_TRAJ, "noise": "isotropic (f_u = f_v)"},
+                       "parallelism": "replicated trajectories, %d per rank" % B_TRAJ, "noise": "isotropic (f_u = f_v)",
+                       "gate_early_accept": bool(args.gate_early_accept)},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_TFLOPS, "traffic": pmc_traffic(dom.split(" ")[0]),
                          "kernel_ms_per_step": kern_ms[dom], "alg_flops_per_launch": dom_flops,

@@ -122,6 +122,10 @@ int msckf_hip_profile_read(msckf_hip_handle h, double* ms8, int* count8);
 /* run_frames on n = 1..8 HIP streams: the batch is cut into n slices of independent trajectories that run the
  * same kernel sequence concurrently (latency-bound stages of one slice overlap chip-filling stages of another). */
 int msckf_hip_set_streams(msckf_hip_handle h, int n);
+/* Exact early accept of the chi-square gate (gatingTest, msckf.h:1103-1124), OFF by default: S = H_o P H_o^T + sigma^2 I
+ * >= sigma^2 I, so gamma <= |r_o|^2 / sigma^2; when that bound is below half the threshold the track passes without
+ * forming S.  Same decisions as the reference; the reported gamma of such a track is the bound (status bit 32). */
+int msckf_hip_set_gate_early_accept(msckf_hip_handle h, int on);
 
 #ifdef __cplusplus
 }

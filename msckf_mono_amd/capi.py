@@ -30,7 +30,7 @@ SYMBOLS = [
     "msckf_hip_last_tracks", "msckf_hip_last_deltax", "msckf_hip_set_tracks", "msckf_hip_propagate_range",
     "msckf_hip_augment_range", "msckf_hip_marginalize_range", "msckf_hip_drop_oldest_range", "msckf_hip_scenario_alloc",
     "msckf_hip_scenario_set", "msckf_hip_scenario_commit", "msckf_hip_run_frames", "msckf_hip_sync",
-    "msckf_hip_profile_enable", "msckf_hip_profile_read", "msckf_hip_set_streams",
+    "msckf_hip_profile_enable", "msckf_hip_profile_read", "msckf_hip_set_streams", "msckf_hip_set_gate_early_accept",
 ]
 
 
@@ -222,6 +222,9 @@ class Batch:
 
     def set_streams(self, n):
         _chk(self.L.msckf_hip_set_streams(self.h, int(n)))
+
+    def set_gate_early_accept(self, on):
+        _chk(self.L.msckf_hip_set_gate_early_accept(self.h, 1 if on else 0))
 
     def profile_enable(self, on=True):
         _chk(self.L.msckf_hip_profile_enable(self.h, 1 if on else 0))

@@ -35,7 +35,7 @@ enum {  // offsets into prm[]
   PRM_WU = 34, PRM_WV = 35, PRM_SIG2 = 36
 };
 enum {  // per-track status bits written by k_feature / k_select
-  ST_MOTION_OK = 1, ST_TRI_VALID = 2, ST_GATE_PASS = 4, ST_INCLUDED = 8, ST_MOTION_SKIPPED = 16
+  ST_MOTION_OK = 1, ST_TRI_VALID = 2, ST_GATE_PASS = 4, ST_INCLUDED = 8, ST_MOTION_SKIPPED = 16, ST_GATE_BOUND = 32
 };
 enum { STAT_NTRACKS = 0, STAT_MOTION_REJ, STAT_TRI_REJ, STAT_GATE_REJ, STAT_PASSED, STAT_MROWS, STAT_RROWS, STAT_ERR, STAT_STRIDE = 8 };
 
@@ -56,6 +56,7 @@ struct Dev {
   // mode 1 (second update of pruneRedundantStates, msckf.h:545-614): every track comes with its stored feature
   // position trk_pfin[b*f_cap+t][4] -- no checkMotion / triangulation, no Q4 bookkeeping
   int mode; const S* trk_pfin;
+  int gate_early;   // exact early accept of the chi-square gate by the bound |r_o|^2 / sigma^2 (k_feature), off by default
   // per-track products of k_feature
   int* trk_status; S* trk_pf; S* trk_gamma; S* trk_Hx; S* trk_V; S* trk_Zf; S* trk_ro; int* trk_first;
   // k_select

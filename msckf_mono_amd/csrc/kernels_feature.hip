@@ -432,6 +432,22 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
     for (int s2 = 0; s2 < 2; ++s2) qr[s2] = r[s2] - (v[s2][0] * y[0] + v[s2][1] * y[1] + v[s2][2] * y[2]);
   }
 
+  // ---- optional exact early accept of the gate (msckf_hip_set_gate_early_accept, off by default): S >= sigma^2 I, so
+  // gamma = r_o^T S^-1 r_o <= |r_o|^2 / sigma^2.  If that bound is already below the chi-square threshold (with a
+  // factor 2 in hand for the rounding of P's smallest eigenvalues) the track passes whatever G is: no G, no E, no
+  // Cholesky.  The decision is the reference's; trk_gamma then holds the bound and the status carries ST_GATE_BOUND.
+  const S thresh = S(c_chi2[M < 98 ? M : 98]);   // table[dof+1], dof = M-1   (:433, :1117)
+  bool spd = true;
+  S gamma = 0;
+  bool early = false;
+  if (d.gate_early) {
+    S rr = 0;
+    for (int s2 = 0; s2 < 2; ++s2) { const int row = row0 + s2; if (row >= 3 && row < 2 * M) rr += qr[s2] * qr[s2]; }
+    rr = wave_sum(rr);
+    const S ub = rr / prm[PRM_SIG2];
+    if (ub < S(0.5) * thresh) { early = true; gamma = ub; status |= ST_GATE_BOUND; }
+  }
+  if (!early) {
   // ---- stage H_x, V in LDS; G = H_x P_cc H_x^T from 6x6 blocks of P (upper block-triangle + mirror)
   if (lane < m_cap) {
     for (int i = 0; i < 2; ++i) for (int k = 0; k < 6; ++k) sHx[lane * 12 + i * 6 + k] = hx[i][k];
@@ -493,8 +509,6 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
   __syncthreads();
   // ---- S = (Q^T G Q)[3:,3:] + sigma^2 I, Cholesky with the r_o row appended, gamma = |L^-1 r_o|^2
   const S sig2 = prm[PRM_SIG2];
-  bool spd = true;
-  S gamma = 0;
   (void)0;
   if (fdbg & 4) { gamma = 0; }
   else if (rho + 1 <= 64) {
@@ -537,7 +551,7 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
     for (int k = 3 + lane; k < R2; k += 64) { const S y = sG[TRI(R2, k)]; gamma += y * y; }
     gamma = wave_sum(gamma);
   }
-  const S thresh = S(c_chi2[M < 98 ? M : 98]);   // table[dof+1], dof = M-1   (:433, :1117)
+  }   // !early
   if (spd && gamma < thresh) status |= ST_GATE_PASS;
 
   // ---- publish the compact representation of the projected block

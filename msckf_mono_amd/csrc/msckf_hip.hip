@@ -84,6 +84,7 @@ struct BatchBase {
   virtual int prof_enable(int on) = 0;
   virtual int prof_read(double* ms, int* cnt) = 0;
   virtual int set_streams(int n) = 0;
+  virtual int set_gate_early(int on) = 0;
 };
 
 constexpr int NSTAGE = 8;
@@ -534,6 +535,7 @@ struct Batch : BatchBase {
     for (int s = 0; s < NSTAGE; ++s) { ev_used[s] = 0; prof_ms[s] = 0; prof_cnt[s] = 0; }
     return 0;
   }
+  int set_gate_early(int on) override { d.gate_early = on ? 1 : 0; return 0; }
   int set_streams(int n) override {
     if (n < 1 || n > MAXS) return fail(-EINVAL, "1 to 8 streams");
     nstreams = n;
@@ -1017,5 +1019,6 @@ int msckf_hip_sync(msckf_hip_handle h) { return H(h)->sync(); }
 int msckf_hip_profile_enable(msckf_hip_handle h, int on) { return H(h)->prof_enable(on); }
 int msckf_hip_profile_read(msckf_hip_handle h, double* ms7, int* count7) { return H(h)->prof_read(ms7, count7); }
 int msckf_hip_set_streams(msckf_hip_handle h, int n) { return H(h)->set_streams(n); }
+int msckf_hip_set_gate_early_accept(msckf_hip_handle h, int on) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_gate_early(on); }
 
 }  // extern "C"

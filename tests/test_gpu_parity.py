@@ -417,6 +417,28 @@ def test_cfg3_batch_properties(capi):
     assert np.mean(rates) > 0.95
 
 
+def test_gate_early_accept_changes_no_decision(capi):
+    """msckf_hip_set_gate_early_accept: tracks whose |r_o|^2 / sigma^2 is already below the chi-square threshold pass
+    without forming S.  Same gate decisions, hence bit-identical states and covariance; the bound is flagged."""
+    N, F, nf = 10, 40, 18
+    tr = sc.Trajectory(2, 23, N, F, nf)
+    res = {}
+    for on in (0, 1):
+        bt = capi.Batch(1, N, F, N, capi.F32)
+        bt.set_gate_early_accept(on)
+        bt.initialize(0, tr.cfg, tr.imu0)
+        for k in range(nf):
+            H.device_frame(bt, 0, tr, k, N)
+        res[on] = (bt.imu_state(0), bt.cam_states(0)[0], bt.covariance(0), bt.last_stats(0), bt.last_tracks(0))
+        bt.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    assert res[0][3] == res[1][3] and res[1][3]["n_passed"] > 0
+    t0, t1 = res[0][4], res[1][4]                      # columns: motion_ok, tri_valid, gate_pass, included, gamma, p_f
+    assert np.array_equal(t0[:, :4], t1[:, :4]) and np.array_equal(t0[:, 5:], t1[:, 5:])
+    g0, g1 = t0[:, 4], t1[:, 4]
+    assert np.all(g1 >= g0 * (1 - 1e-5)) and np.any(g1 > g0 * 1.001)   # early-accepted tracks report the upper bound
+
+
 def test_float_long_run_stays_with_the_double_oracle(capi, po):
     """300 free-running frames in float (information-form compression, Joseph update) against the double oracle
     on the same inputs: the float filter must neither drift away nor lose the structure of P (symmetry, PSD up to
