@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--streams", type=int, default=2, help="HIP streams for the timed region (halves of the batch run concurrently)")
+    ap.add_argument("--no-early-accept-pass", action="store_true", help="skip the extra measurement with the gate early accept (profiling runs)")
     ap.add_argument("--gate-early-accept", action="store_true",
                     help="exact early accept of the chi-square gate (msckf_hip_set_gate_early_accept); OFF for the headline number")
     args = ap.parse_args()
@@ -144,7 +145,7 @@ def main():
     # ---- the same K-frame measurement with the optional exact early accept of the chi-square gate (reported beside
     # the headline value, never as it: its gain depends on the ratio of residual noise to feature_cov)
     early_ms = None
-    if not args.gate_early_accept:
+    if not args.gate_early_accept and not args.no_early_accept_pass:
         bt.set_gate_early_accept(True)
         barrier()
         te0 = time.perf_counter()
