@@ -24,7 +24,10 @@
 
 namespace msckf {
 
-int g_gram_dbg = 0;   // ablation knob (msckf_hip_debug_set(300, .)); zero in production
+// Ablation knob (msckf_hip_debug_set(300, .) or MSCKF_GRAM_DBG; zero in production, results are garbage otherwise except
+// for bit 16): 1 no block-diagonal reduction, 2 no prefetch after the first chunks, 4 no MFMA, 8 half the MFMAs,
+// 16 use k_chol_blk instead of k_chol_T, 32/64/128/256 skip phase b/c/d/e of k_chol_blk (scripts/gram_ablate.py).
+int g_gram_dbg = 0;
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int GK = 24;   // rows of B per staged chunk = 8 tracks
