@@ -16,6 +16,10 @@
 //             P.determinant() in augmentState, full-U null space, dense per-feature gate, full m x m
 //             Householder Q and dense m x m R_o, explicit S^-1) -- this is the CPU baseline that is timed.
 //   LEAN      thin QR, block-diagonal R_o, no copies, no determinant.
+//   GRAM      as LEAN, but [T_H | r_n] is the Cholesky factor of [H_o | r_o]^T [H_o | r_o] accumulated in double with
+//             semi-definite pivot skipping -- the compression route of the HIP library (kernels_gram.hip) restated on
+//             the CPU, so that its long-run behaviour in float can be checked without a GPU.  Isotropic or whitened
+//             noise only (R_n = sigma^2 I); otherwise it behaves as LEAN.
 // Documented deviations from the reference:
 //   Q1b  A_j := last 2M-3 columns of the *Householder* Q of H_f_j (the reference takes them from
 //        JacobiSVD's full U, msckf.h:954-955; only the span is defined by the maths, and for
@@ -73,7 +77,7 @@ template <class S> struct FeatureTrack {
   V3<S> p_f_G;
 };
 
-enum Mode { FAITHFUL = 0, LEAN = 1 };
+enum Mode { FAITHFUL = 0, LEAN = 1, GRAM = 2 };
 
 struct TrackDebug {  // per residualized track, in input order (for kernel-level parity tests)
   int motion_ok = 1, tri_valid = 0, gate_pass = 0, rows = 0;
@@ -812,12 +816,73 @@ class MSCKF {
   }
 
   // ---- :1325-1423
+  // K = P T_H^T S^-1, state injection and the Joseph-form covariance update (msckf.h:1368-1418) for a compressed
+  // measurement (T_H, r_n, R_n)
+  void applyUpdate(const Mat<S>& T_H, const Mat<S>& r_n, const Mat<S>& R_n, const Mat<S>& P) {
+    const int D = T_H.c;
+    Mat<S> PHt = mul_abt(P, T_H);                 // D x nr
+    Mat<S> Smat = add(mul(T_H, PHt), R_n);        // :1369
+    Mat<S> K = mul(PHt, inverse(Smat));           // :1370
+    Mat<S> dX = mul(K, r_n);                      // :1373
+    last_deltaX = dX;
+    auto seg = [&](int o) { return V3<S>{dX(o, 0), dX(o + 1, 0), dX(o + 2, 0)}; };
+    imu_state_.q_IG = buildUpdateQuat(seg(0)) * imu_state_.q_IG;   // :1376-1383
+    imu_state_.b_g = imu_state_.b_g + seg(3);
+    imu_state_.b_a = imu_state_.b_a + seg(9);
+    imu_state_.v_I_G = imu_state_.v_I_G + seg(6);
+    imu_state_.p_I_G = imu_state_.p_I_G + seg(12);
+    for (size_t c = 0; c < cam_states_.size(); ++c) {              // :1386-1391
+      Quat<S> q = buildUpdateQuat(seg(15 + 6 * (int)c)) * cam_states_[c].q_CG;
+      cam_states_[c].q_CG = q.normalized();
+      cam_states_[c].p_C_G = cam_states_[c].p_C_G + seg(18 + 6 * (int)c);
+    }
+    Mat<S> tempMat = add(Mat<S>::identity(D), mul(K, T_H), S(-1));  // :1394-1396
+    Mat<S> Pc = add(mul_abt(mul(tempMat, P), tempMat), mul_abt(mul(K, R_n), K));  // :1399
+    symmetrize(Pc);                               // :1401-1403
+    splitP(Pc);
+  }
+
+  // GRAM mode: [T_H | r_n] = chol([H_o | r_o]^T [H_o | r_o]) over the camera columns, accumulated and factored in
+  // double whatever S is; a pivot below 64 eps of its original diagonal is an unobservable direction of the stack
+  // and gives a zero row.
+  void measurementUpdateGram(const Mat<S>& H_o, const Mat<S>& r_o) {
+    const int m = H_o.r, D = H_o.c, n = D - 15;
+    std::vector<double> A((size_t)(n + 1) * (n + 1), 0.0);
+    auto at = [&](int i, int j) -> double& { return A[(size_t)i * (n + 1) + j]; };
+    for (int row = 0; row < m; ++row) {
+      std::vector<double> x(n + 1);
+      for (int c = 0; c < n; ++c) x[c] = (double)H_o(row, 15 + c);
+      x[n] = (double)r_o(row, 0);
+      for (int i = 0; i <= n; ++i) { if (x[i] == 0.0) continue; for (int j = 0; j <= i; ++j) at(i, j) += x[i] * x[j]; }
+    }
+    std::vector<double> d0(n);
+    for (int k = 0; k < n; ++k) d0[k] = at(k, k);
+    Mat<S> T_H(n, D), r_n(n, 1), R_n(n, n);
+    int rank = 0;
+    const double tol = 64.0 * 2.220446049250313e-16;
+    for (int k = 0; k < n; ++k) {
+      const double p = at(k, k);
+      if (!(p > tol * d0[k])) continue;                       // zero row of T_H
+      ++rank;
+      const double dinv = 1.0 / std::sqrt(p);
+      std::vector<double> l(n + 1, 0.0);
+      for (int i = k; i <= n; ++i) l[i] = at(i, k) * dinv;
+      for (int i = k; i < n; ++i) T_H(k, 15 + i) = (S)l[i];
+      r_n(k, 0) = (S)l[n];
+      for (int i = k + 1; i <= n; ++i) for (int j = k + 1; j <= i; ++j) at(i, j) -= l[i] * l[j];
+    }
+    for (int k = 0; k < n; ++k) R_n(k, k) = uvar();
+    last_stats.r_rows = rank;
+    applyUpdate(T_H, r_n, R_n, fullP());
+  }
+
   void measurementUpdate(const Mat<S>& H_o, const Mat<S>& r_o, const Mat<S>* R_o_dense,
                          const std::vector<Mat<S>>* R_blocks, const std::vector<int>* R_off) {
     const int m = H_o.r;
     last_stats.m_rows = m;
     if (m == 0) return;
     const int D = H_o.c;
+    if (mode == GRAM && (uvar() == vvar())) { measurementUpdateGram(H_o, r_o); return; }
     Mat<S> P = fullP();
     Mat<S> QR = H_o; std::vector<S> tau;
     householder_qr_inplace(QR, tau);              // :1343
@@ -855,26 +920,7 @@ class MSCKF {
         R_n = mul_atb(Q1, RQ);
       }
     }
-    Mat<S> PHt = mul_abt(P, T_H);                 // D x nr
-    Mat<S> Smat = add(mul(T_H, PHt), R_n);        // :1369
-    Mat<S> K = mul(PHt, inverse(Smat));           // :1370
-    Mat<S> dX = mul(K, r_n);                      // :1373
-    last_deltaX = dX;
-    auto seg = [&](int o) { return V3<S>{dX(o, 0), dX(o + 1, 0), dX(o + 2, 0)}; };
-    imu_state_.q_IG = buildUpdateQuat(seg(0)) * imu_state_.q_IG;   // :1376-1383
-    imu_state_.b_g = imu_state_.b_g + seg(3);
-    imu_state_.b_a = imu_state_.b_a + seg(9);
-    imu_state_.v_I_G = imu_state_.v_I_G + seg(6);
-    imu_state_.p_I_G = imu_state_.p_I_G + seg(12);
-    for (size_t c = 0; c < cam_states_.size(); ++c) {              // :1386-1391
-      Quat<S> q = buildUpdateQuat(seg(15 + 6 * (int)c)) * cam_states_[c].q_CG;
-      cam_states_[c].q_CG = q.normalized();
-      cam_states_[c].p_C_G = cam_states_[c].p_C_G + seg(18 + 6 * (int)c);
-    }
-    Mat<S> tempMat = add(Mat<S>::identity(D), mul(K, T_H), S(-1));  // :1394-1396
-    Mat<S> Pc = add(mul_abt(mul(tempMat, P), tempMat), mul_abt(mul(K, R_n), K));  // :1399
-    symmetrize(Pc);                               // :1401-1403
-    splitP(Pc);
+    applyUpdate(T_H, r_n, R_n, P);
   }
 };
 

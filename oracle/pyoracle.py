@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 F32, F64 = 0, 1
-FAITHFUL, LEAN = 0, 1
+FAITHFUL, LEAN, GRAM = 0, 1, 2   # GRAM: compression route of the HIP library restated on the CPU (msckf_oracle.hpp)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)

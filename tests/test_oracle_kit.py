@@ -91,3 +91,24 @@ def test_first_four_tracks_skip_check_motion(oracle_lib):
     s = o.lastStats()
     assert s["n_tracks"] == F and s["n_passed"] + s["n_gate_rejected"] + s["n_tri_rejected"] == 4 and s["n_motion_rejected"] == F - 4
     assert o.numResidualized() == 4 - s["n_tri_rejected"]
+
+
+def test_gram_mode_follows_the_qr_modes_over_a_long_float_run(oracle_lib):
+    """GRAM mode = the HIP library's compression route on the CPU: [T_H | r_n] = chol([H_o|r_o]^T [H_o|r_o]) accumulated in
+    double with pivot skipping.  Free-running for 200 frames it stays with the Householder modes -- to rounding in double,
+    to float noise in float -- and reports the unobservable directions as missing rows."""
+    import numpy as np
+    import helpers as H
+    from msckf_mono_amd import scenario as sc
+    po = oracle_lib
+    N, F, nf = 8, 30, 200
+    tr = sc.Trajectory(2, 77, N, F, nf)
+    for dt, tol in ((po.F64, 1e-7), (po.F32, 2e-3)):
+        a, g = po.Oracle(dt, po.LEAN), po.Oracle(dt, po.GRAM)
+        a.initialize(tr.cfg, tr.imu0); g.initialize(tr.cfg, tr.imu0)
+        for k in range(nf):
+            H.oracle_frame(a, tr, k, N); H.oracle_frame(g, tr, k, N)
+        e = H.state_errors(g.getImuState(), a.getImuState(), g.getCamStates()[0], a.getCamStates()[0], g.getCovariance(), a.getCovariance())
+        assert H.worst(e) < tol, (dt, e)
+        assert 0 < g.lastStats()["r_rows"] < a.lastStats()["r_rows"]
+        assert g.lastStats()["m_rows"] == a.lastStats()["m_rows"]
