@@ -28,6 +28,8 @@ struct Base {
   virtual void get_imu_state(double* out) = 0;
   virtual void set_imu_state(const double* in) = 0;
   virtual void get_cam_states(double* out, int* ids) = 0;
+  virtual int get_cam_meta(double* time, int* ntracked, int* last_corr, int cap) = 0;
+  virtual int pruned_states(double* out9, int cap) = 0;
   virtual void set_cam_pose(int i, const double* qp) = 0;
   virtual void get_covariance(double* P) = 0;
   virtual void set_covariance(const double* P, int D) = 0;
@@ -96,6 +98,16 @@ struct Impl : Base {
     auto cs = f.getCamStates();
     for (size_t i = 0; i < cs.size(); ++i) { pack4(out + 7 * i, cs[i].q_CG); pack3(out + 7 * i + 4, cs[i].p_C_G); if (ids) ids[i] = cs[i].state_id; }
   }
+  int get_cam_meta(double* time, int* ntracked, int* last_corr, int cap) override {
+    auto cs = f.getCamStates();
+    for (size_t i = 0; i < cs.size() && (int)i < cap; ++i) { time[i] = cs[i].time; ntracked[i] = (int)cs[i].tracked_feature_ids.size(); last_corr[i] = cs[i].last_correlated_id; }
+    return (int)cs.size();
+  }
+  int pruned_states(double* out9, int cap) override {
+    auto p = f.getPrunedStates(); int n = (int)p.size();
+    for (int i = 0; i < n && i < cap; ++i) { double* o = out9 + 9 * i; pack4(o, p[i].q_CG); pack3(o + 4, p[i].p_C_G); o[7] = p[i].time; o[8] = p[i].state_id; }
+    return n;
+  }
   void set_cam_pose(int i, const double* qp) override { f.setCamPose((size_t)i, q4(qp), v3(qp + 4)); }
   void get_covariance(double* P) override { Mat<S> m = f.getCovariance(); for (size_t i = 0; i < m.a.size(); ++i) P[i] = m.a[i]; }
   void set_covariance(const double* P, int D) override { Mat<S> m(D, D); for (size_t i = 0; i < m.a.size(); ++i) m.a[i] = S(P[i]); f.setCovariance(m); }
@@ -158,6 +170,9 @@ int oracle_num_cam_states(void* h) { return ((Base*)h)->num_cam_states(); }
 void oracle_get_imu_state(void* h, double* out) { ((Base*)h)->get_imu_state(out); }
 void oracle_set_imu_state(void* h, const double* in) { ((Base*)h)->set_imu_state(in); }
 void oracle_get_cam_states(void* h, double* out, int* ids) { ((Base*)h)->get_cam_states(out, ids); }
+int oracle_is_reference(void) { return 0; }
+int oracle_get_cam_meta(void* h, double* time, int* ntracked, int* last_corr, int cap) { return ((Base*)h)->get_cam_meta(time, ntracked, last_corr, cap); }
+int oracle_pruned_states(void* h, double* out9, int cap) { return ((Base*)h)->pruned_states(out9, cap); }
 void oracle_set_cam_pose(void* h, int i, const double* qp) { ((Base*)h)->set_cam_pose(i, qp); }
 void oracle_get_covariance(void* h, double* P) { ((Base*)h)->get_covariance(P); }
 void oracle_set_covariance(void* h, const double* P, int D) { ((Base*)h)->set_covariance(P, D); }

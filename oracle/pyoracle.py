@@ -1,8 +1,12 @@
-"""ctypes front for oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+"""ctypes front for oracle/liboracle.so and oracle/_ref/lib_ref.so -- TEST INFRASTRUCTURE ONLY.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
-product path (msckf_mono_amd) must never do so.  The library restates
-/root/reference/include/msckf_mono/msckf.h on the CPU (see oracle/msckf_oracle.hpp).
+product path (msckf_mono_amd) must never do so.  Two checkers share one C-ABI and this one Python class:
+  impl="oracle": oracle/liboracle.so, the restatement of /root/reference/include/msckf_mono/msckf.h
+                 (oracle/msckf_oracle.hpp);
+  impl="ref":    oracle/_ref/lib_ref.so, the reference's OWN unmodified sources compiled against the minimal
+                 Eigen/Boost surface of oracle/ref_shim (oracle/ref_capi.cpp).  Built only where /root/reference
+                 exists; the prebuilt library travels to the GPU box with the snapshot.
 """
 import ctypes as C
 import os
@@ -11,7 +15,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = None
+_LIBS = {}
 
 F32, F64 = 0, 1
 FAITHFUL, LEAN, GRAM = 0, 1, 2   # GRAM: compression route of the HIP library restated on the CPU (msckf_oracle.hpp)
@@ -25,10 +29,13 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        path = os.path.join(_HERE, "liboracle.so")
+def ref_available():
+    return os.path.exists(os.path.join(_HERE, "_ref", "lib_ref.so"))
+
+
+def lib(impl="oracle"):
+    if impl not in _LIBS:
+        path = os.path.join(_HERE, "liboracle.so") if impl == "oracle" else os.path.join(_HERE, "_ref", "lib_ref.so")
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)
@@ -39,10 +46,11 @@ def lib():
         L.oracle_time_updates.restype = C.c_double
         L.oracle_num_residualized.restype = C.c_long
         for name in ("oracle_num_cam_states", "oracle_get_tracks", "oracle_last_tracks", "oracle_last_deltax",
-                     "oracle_map_points", "oracle_pruned_ids"):
+                     "oracle_map_points", "oracle_pruned_ids", "oracle_get_cam_meta", "oracle_pruned_states", "oracle_is_reference"):
             getattr(L, name).restype = C.c_int
-        _LIB = L
-    return _LIB
+        assert L.oracle_is_reference() == (1 if impl == "ref" else 0)
+        _LIBS[impl] = L
+    return _LIBS[impl]
 
 
 def _d(a):
@@ -68,8 +76,9 @@ def pack_config(cfg):
 class Oracle:
     """One CPU filter (float or double).  Method names follow the reference's public API (msckf.h:72-848)."""
 
-    def __init__(self, dtype=F64, mode=LEAN):
-        self.L = lib()
+    def __init__(self, dtype=F64, mode=LEAN, impl="oracle"):
+        self.L = lib(impl)
+        self.impl = impl
         self.h = C.c_void_p(self.L.oracle_create(dtype, mode))
         self.dtype = dtype
 
@@ -127,6 +136,21 @@ class Oracle:
             self.L.oracle_get_cam_states(self.h, o.ctypes.data_as(_dp), ids.ctypes.data_as(_ip))
         return o, ids
 
+    def getCamMeta(self):
+        """(time[n], len(tracked_feature_ids)[n], last_correlated_id[n]) of getCamStates() (types.h:57-67)"""
+        n = self.getNumCamStates()
+        t = np.zeros(max(n, 1)); k = np.zeros(max(n, 1), dtype=np.int32); lc = np.zeros(max(n, 1), dtype=np.int32)
+        self.L.oracle_get_cam_meta(self.h, t.ctypes.data_as(_dp), k.ctypes.data_as(_ip), lc.ctypes.data_as(_ip), n)
+        return t[:n], k[:n], lc[:n]
+
+    def getPrunedStates(self, cap=65536):
+        """rows of q_CG(4) p_C_G(3) time state_id, sorted by state_id (getPrunedStates, msckf.h:840-848)"""
+        o = np.zeros((cap, 9)); n = self.L.oracle_pruned_states(self.h, o.ctypes.data_as(_dp), cap); return o[:n]
+
+    def chi2Table(self):
+        """impl="ref" only: chi_squared_test_table as msckf.h:91-95 built it"""
+        o = np.zeros(128); n = self.L.oracle_chi2_table(self.h, o.ctypes.data_as(_dp), 128); return o[:n]
+
     def setCamPose(self, i, qp):
         a, p = _d(qp); self.L.oracle_set_cam_pose(self.h, int(i), p)
 
@@ -173,7 +197,7 @@ class Oracle:
 
     def clone(self):
         c = Oracle.__new__(Oracle)
-        c.L, c.dtype = self.L, self.dtype
+        c.L, c.dtype, c.impl = self.L, self.dtype, self.impl
         c.h = C.c_void_p(self.L.oracle_clone(self.h))
         return c
 
@@ -189,7 +213,7 @@ class Oracle:
 
 def time_updates(oracles, n_threads, reps, readings, state_id0, M, slots, obs, n_drop):
     """Wall seconds for every filter in `oracles` to run `reps` filter updates (oracle_time_updates)."""
-    L = lib()
+    L = oracles[0].L
     hs = (C.c_void_p * len(oracles))(*[o.h for o in oracles])
     r, pr = _d(np.asarray(readings).reshape(-1, 7)); Ma, pM = _i(M); s, ps = _i(slots); o, po = _d(obs)
     return L.oracle_time_updates(hs, len(oracles), int(n_threads), int(reps), pr, r.shape[0], int(state_id0), len(Ma), pM, ps, po, int(n_drop))
