@@ -224,6 +224,42 @@ void householder_qr_inplace(Mat<S>& A, std::vector<S>& tau) {
     }
   }
 }
+// Column-pivoted variant: before step k the remaining column (rows k..) of largest squared norm is swapped into
+// place.  This is the QR preconditioner Eigen's JacobiSVD runs on a tall matrix (ColPivHouseholderQR); the last
+// rows-cols columns of its full Q ARE the trailing columns of JacobiSVD::matrixU() that the reference reads as the
+// left null space (msckf.h:954-955).  Norms are recomputed per step (Eigen downdates them: same choice away from ties).
+template <class S>
+void householder_qr_colpiv_inplace(Mat<S>& A, std::vector<S>& tau) {
+  const int m = A.r, n = A.c, steps = std::min(m, n);
+  tau.assign(steps, S(0));
+  for (int k = 0; k < steps; ++k) {
+    int big = k; S best = S(-1);
+    for (int j = k; j < n; ++j) {
+      S s = 0; for (int i = k; i < m; ++i) s += A(i, j) * A(i, j);
+      if (s > best) { best = s; big = j; }
+    }
+    if (big != k) for (int i = 0; i < m; ++i) std::swap(A(i, k), A(i, big));
+    S* ck = &A.a[(size_t)k * m];
+    S tail2 = 0;
+    for (int i = k + 1; i < m; ++i) tail2 += ck[i] * ck[i];
+    const S c0 = ck[k];
+    if (tail2 <= std::numeric_limits<S>::min()) { tau[k] = 0; for (int i = k + 1; i < m; ++i) ck[i] = 0; continue; }
+    S beta = std::sqrt(c0 * c0 + tail2);
+    if (c0 >= S(0)) beta = -beta;
+    const S inv = S(1) / (c0 - beta);
+    for (int i = k + 1; i < m; ++i) ck[i] *= inv;
+    tau[k] = (beta - c0) / beta;
+    ck[k] = beta;
+    for (int j = k + 1; j < n; ++j) {
+      S* cj = &A.a[(size_t)j * m];
+      S s = cj[k];
+      for (int i = k + 1; i < m; ++i) s += ck[i] * cj[i];
+      s *= tau[k];
+      cj[k] -= s;
+      for (int i = k + 1; i < m; ++i) cj[i] -= s * ck[i];
+    }
+  }
+}
 // Apply Q^T = H_{s-1}...H_1 H_0 to the columns of X (m x p), reflectors stored in QR/tau.
 template <class S>
 void apply_qt(const Mat<S>& QR, const std::vector<S>& tau, Mat<S>& X) {

@@ -96,6 +96,13 @@ class MSCKF {
   // 1/sigma_v and the filter then runs with unit isotropic noise -- the construction the HIP path uses (DESIGN.md
   // section 3).  When clear the reference's A_j^T R_j A_j / Q_1^T R_o Q_1 construction is restated literally.
   bool whiten = false;
+  // null-space basis A_j: the reference takes the trailing columns of JacobiSVD's full U, i.e. of the Q of a
+  // column-pivoted Householder QR of H_f_j (true); false = unpivoted reflectors in column order.  With isotropic
+  // pixel noise the update does not depend on the choice.
+  bool colpiv_null = true;
+  // experiment: > 0 drops the rows of R whose entries are all below tiny_row_tol * max|R| (rounding-level rows of the
+  // gauge directions); 0 = the reference's rule (a row is kept if any entry is non-zero, msckf.h:1347)
+  double tiny_row_tol = 0;
   UpdateStats last_stats;
   std::vector<TrackDebug> last_tracks;
   Mat<S> last_deltaX;
@@ -758,7 +765,9 @@ class MSCKF {
     whitenRows(H_f); whitenRows(H_x);
     const int rows = 2 * M;
     Mat<S> QR = H_f; std::vector<S> tau;
-    householder_qr_inplace(QR, tau);
+    // JacobiSVD(ComputeFullU) of the tall H_f_j = column-pivoted Householder QR preconditioner; its trailing
+    // 2M-3 columns of Q are matrixU().rightCols(2M-3) (msckf.h:954-955).  colpiv_null = false: unpivoted reflectors.
+    if (colpiv_null) householder_qr_colpiv_inplace(QR, tau); else householder_qr_inplace(QR, tau);
     if (mode == FAITHFUL) {                       // full U, rightCols, dense A^T H_x  (:954-957)
       Mat<S> Q = form_q_cols(QR, tau, 0, rows);
       A_j = Q.block(0, 3, rows, rows - 3);
@@ -888,9 +897,11 @@ class MSCKF {
     householder_qr_inplace(QR, tau);              // :1343
     const int steps = std::min(m, D);
     std::vector<int> kept;                        // nonZeroRows of the upper-triangular view :1345-1348
+    S rmax = 0;
+    if (tiny_row_tol > 0) for (int r = 0; r < steps; ++r) for (int c = r; c < D; ++c) rmax = std::max(rmax, (S)std::fabs(QR(r, c)));
     for (int r = 0; r < steps; ++r) {
       bool any = false;
-      for (int c = r; c < D && !any; ++c) any = (QR(r, c) != S(0));
+      for (int c = r; c < D && !any; ++c) any = tiny_row_tol > 0 ? (std::fabs(QR(r, c)) > S(tiny_row_tol) * rmax) : (QR(r, c) != S(0));
       if (any) kept.push_back(r);
     }
     const int nr = (int)kept.size();

@@ -46,6 +46,8 @@ struct Base {
   virtual void set_mode(int m) = 0;
   virtual Base* clone() = 0;
   virtual void set_whiten(int w) = 0;
+  virtual void set_colpiv(int w) = 0;
+  virtual void set_tiny(double t) = 0;
 };
 
 template <class S>
@@ -151,6 +153,8 @@ struct Impl : Base {
   void set_mode(int m) override { f.mode = (Mode)m; }
   Base* clone() override { return new Impl<S>(*this); }
   void set_whiten(int w) override { f.whiten = w != 0; }
+  void set_colpiv(int w) override { f.colpiv_null = w != 0; }
+  void set_tiny(double t) override { f.tiny_row_tol = t; }
 };
 }  // namespace
 
@@ -189,6 +193,8 @@ void oracle_set_num_residualized(void* h, long n) { ((Base*)h)->set_num_residual
 void oracle_set_mode(void* h, int mode) { ((Base*)h)->set_mode(mode); }
 void* oracle_clone(void* h) { return ((Base*)h)->clone(); }
 void oracle_set_whiten(void* h, int w) { ((Base*)h)->set_whiten(w); }
+void oracle_set_colpiv_null(void* h, int w) { ((Base*)h)->set_colpiv(w); }
+void oracle_set_tiny_row_tol(void* h, double t) { ((Base*)h)->set_tiny(t); }
 
 // Timed CPU baseline: run `n_filters` independent filters over the same pre-built per-frame call
 // sequence on `n_threads` std::threads (one filter per thread at a time, as the reference is

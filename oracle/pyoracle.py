@@ -4,7 +4,7 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 product path (msckf_mono_amd) must never do so.  Two checkers share one C-ABI and this one Python class:
   impl="oracle": oracle/liboracle.so, the restatement of /root/reference/include/msckf_mono/msckf.h
                  (oracle/msckf_oracle.hpp);
-  impl="ref":    oracle/_ref/lib_ref.so, the reference's OWN unmodified sources compiled against the minimal
+  impl="ref" ("ref_alt": same, second rounding): oracle/_ref/lib_ref.so, the reference's OWN unmodified sources compiled against the minimal
                  Eigen/Boost surface of oracle/ref_shim (oracle/ref_capi.cpp).  Built only where /root/reference
                  exists; the prebuilt library travels to the GPU box with the snapshot.
 """
@@ -35,7 +35,8 @@ def ref_available():
 
 def lib(impl="oracle"):
     if impl not in _LIBS:
-        path = os.path.join(_HERE, "liboracle.so") if impl == "oracle" else os.path.join(_HERE, "_ref", "lib_ref.so")
+        path = {"oracle": os.path.join(_HERE, "liboracle.so"), "ref": os.path.join(_HERE, "_ref", "lib_ref.so"),
+                "ref_alt": os.path.join(_HERE, "_ref", "lib_ref_alt.so")}[impl]
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)
@@ -48,7 +49,7 @@ def lib(impl="oracle"):
         for name in ("oracle_num_cam_states", "oracle_get_tracks", "oracle_last_tracks", "oracle_last_deltax",
                      "oracle_map_points", "oracle_pruned_ids", "oracle_get_cam_meta", "oracle_pruned_states", "oracle_is_reference"):
             getattr(L, name).restype = C.c_int
-        assert L.oracle_is_reference() == (1 if impl == "ref" else 0)
+        assert L.oracle_is_reference() == (0 if impl == "oracle" else 1)
         _LIBS[impl] = L
     return _LIBS[impl]
 
@@ -203,6 +204,11 @@ class Oracle:
 
     def setWhiten(self, on=True):
         self.L.oracle_set_whiten(self.h, 1 if on else 0)
+
+    def setColPivNull(self, on=True):
+        """null-space basis of H_f_j: column-pivoted Householder Q (= JacobiSVD's trailing U columns, the reference;
+        default) or unpivoted reflectors"""
+        self.L.oracle_set_colpiv_null(self.h, 1 if on else 0)
 
     def setMode(self, mode):
         self.L.oracle_set_mode(self.h, int(mode))

@@ -221,6 +221,7 @@ void oracle_set_num_residualized(void* h, long n) { ((Base*)h)->set_num_residual
 void oracle_set_mode(void*, int) {}
 void* oracle_clone(void* h) { return ((Base*)h)->clone(); }
 void oracle_set_whiten(void*, int) {}
+void oracle_set_colpiv_null(void*, int) {}
 // chi_squared_test_table as the reference built it (msckf.h:91-95), for the table test
 int oracle_chi2_table(void* h, double* out, int cap) {
   Impl<double>* d = dynamic_cast<Impl<double>*>((Base*)h);
@@ -251,5 +252,41 @@ double oracle_time_updates(void** handles, int n_filters, int n_threads, int rep
     });
   for (auto& x : th) x.join();
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+}
+
+// ---- the shim's own linear algebra, exposed so that tests can hold it against numpy/scipy (all column-major) ----
+namespace {
+template <class S> Eigen::Matrix<S, Eigen::Dynamic, Eigen::Dynamic> load(const double* a, int m, int n) {
+  Eigen::Matrix<S, Eigen::Dynamic, Eigen::Dynamic> M(m, n);
+  for (int j = 0; j < n; ++j) for (int i = 0; i < m; ++i) M(i, j) = S(a[(size_t)j * m + i]);
+  return M;
+}
+template <class M> void store(const M& A, double* out) {
+  for (int j = 0; j < (int)A.cols(); ++j) for (int i = 0; i < (int)A.rows(); ++i) out[(size_t)j * A.rows() + i] = (double)A(i, j);
+}
+template <class S> void t_expm(int n, const double* A, double* out) { store(load<S>(A, n, n).exp(), out); }
+template <class S> void t_qr(int m, int n, const double* A, double* Q, double* R) {
+  Eigen::HouseholderQR<Eigen::Matrix<S, Eigen::Dynamic, Eigen::Dynamic>> qr(load<S>(A, m, n));
+  Eigen::Matrix<S, Eigen::Dynamic, Eigen::Dynamic> q = qr.householderQ();
+  Eigen::Matrix<S, Eigen::Dynamic, Eigen::Dynamic> r = qr.matrixQR().template triangularView<Eigen::Upper>();
+  store(q, Q); store(r, R);
+}
+template <class S> void t_svd(int m, int n, const double* A, double* U, double* V, double* sv) {
+  Eigen::JacobiSVD<Eigen::Matrix<S, Eigen::Dynamic, Eigen::Dynamic>> svd(load<S>(A, m, n), Eigen::ComputeFullU | Eigen::ComputeThinV);
+  store(svd.matrixU(), U); store(svd.matrixV(), V); store(svd.singularValues(), sv);
+}
+template <class S> void t_solve(int n, int nrhs, const double* A, const double* b, double* x_ldlt, double* inv, double* det) {
+  auto M = load<S>(A, n, n); auto B = load<S>(b, n, nrhs);
+  Eigen::Matrix<S, Eigen::Dynamic, Eigen::Dynamic> x = M.ldlt().solve(B);
+  store(x, x_ldlt); store(M.inverse(), inv); *det = (double)M.determinant();
+}
+}  // namespace
+extern "C" {
+void shim_expm(int dtype, int n, const double* A, double* out) { dtype == 0 ? t_expm<float>(n, A, out) : t_expm<double>(n, A, out); }
+void shim_qr(int dtype, int m, int n, const double* A, double* Q, double* R) { dtype == 0 ? t_qr<float>(m, n, A, Q, R) : t_qr<double>(m, n, A, Q, R); }
+void shim_svd(int dtype, int m, int n, const double* A, double* U, double* V, double* sv) { dtype == 0 ? t_svd<float>(m, n, A, U, V, sv) : t_svd<double>(m, n, A, U, V, sv); }
+void shim_solve(int dtype, int n, int nrhs, const double* A, const double* b, double* x_ldlt, double* inv, double* det) {
+  dtype == 0 ? t_solve<float>(n, nrhs, A, b, x_ldlt, inv, det) : t_solve<double>(n, nrhs, A, b, x_ldlt, inv, det);
 }
 }

@@ -480,8 +480,14 @@ template <class S> void apply_householder_left(S* c, Index ld, Index n, Index nc
   if (tau == S(0)) return;
   for (Index j = 0; j < nc; ++j) {
     S* col = c + j * ld;
+#ifdef MSCKF_REF_SHIM_ALT_ROUNDING   // same arithmetic, dot product summed from the bottom up: a second, equally valid rounding
+    S t = 0;
+    for (Index i = n - 1; i >= 1; --i) t += ess[i - 1] * col[i];
+    t += col[0];
+#else
     S t = col[0];
     for (Index i = 1; i < n; ++i) t += ess[i - 1] * col[i];
+#endif
     t *= tau;
     col[0] -= t;
     for (Index i = 1; i < n; ++i) col[i] -= t * ess[i - 1];

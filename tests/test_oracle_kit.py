@@ -103,12 +103,19 @@ def test_gram_mode_follows_the_qr_modes_over_a_long_float_run(oracle_lib):
     po = oracle_lib
     N, F, nf = 8, 30, 200
     tr = sc.Trajectory(2, 77, N, F, nf)
-    for dt, tol in ((po.F64, 1e-7), (po.F32, 2e-3)):
-        a, g = po.Oracle(dt, po.LEAN), po.Oracle(dt, po.GRAM)
-        a.initialize(tr.cfg, tr.imu0); g.initialize(tr.cfg, tr.imu0)
-        for k in range(nf):
-            H.oracle_frame(a, tr, k, N); H.oracle_frame(g, tr, k, N)
-        e = H.state_errors(g.getImuState(), a.getImuState(), g.getCamStates()[0], a.getCamStates()[0], g.getCovariance(), a.getCovariance())
-        assert H.worst(e) < tol, (dt, e)
+    E = lambda x, y: H.state_errors(x.getImuState(), y.getImuState(), x.getCamStates()[0], y.getCamStates()[0], x.getCovariance(), y.getCovariance())
+    fs = dict(d=po.Oracle(po.F64, po.LEAN), gd=po.Oracle(po.F64, po.GRAM), a=po.Oracle(po.F32, po.LEAN), g=po.Oracle(po.F32, po.GRAM))
+    for f in fs.values():
+        f.initialize(tr.cfg, tr.imu0)
+    for k in range(nf):
+        for f in fs.values():
+            H.oracle_frame(f, tr, k, N)
+    assert H.worst(E(fs["gd"], fs["d"])) < 1e-7                        # double: to rounding
+    # float: 200 free-running frames wander by float noise (~1e-2 on the accelerometer bias for EITHER route); the
+    # information form must not wander further from the double filter than the Householder route does
+    e_qr, e_gram = E(fs["a"], fs["d"]), E(fs["g"], fs["d"])
+    assert H.worst(e_qr) < 3e-2 and H.worst(e_gram) < 3e-2, (e_qr, e_gram)
+    assert H.worst(e_gram) < 3 * H.worst(e_qr) + 1e-3, (e_qr, e_gram)
+    for a, g in ((fs["d"], fs["gd"]), (fs["a"], fs["g"])):
         assert 0 < g.lastStats()["r_rows"] < a.lastStats()["r_rows"]
         assert g.lastStats()["m_rows"] == a.lastStats()["m_rows"]
