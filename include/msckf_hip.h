@@ -27,10 +27,13 @@
  *
  * Pixel noise: with u_var_prime == v_var_prime (the configuration the throughput metric is quoted on) the update
  * is independent of the null-space basis and of the compression order and matches the reference to rounding.
- * With u_var_prime != v_var_prime (EuRoC intrinsics, asl_msckf.cpp:77-78) the reference's own result depends on
- * JacobiSVD's arbitrary null-space basis; this library pre-whitens every observation row by
- * 1/sigma_u resp. 1/sigma_v and runs the filter with unit noise -- a valid, basis-independent update that agrees
- * with the reference's construction at the level any two valid implementations can (~1e-3 in dx per update).
+ * With u_var_prime != v_var_prime (EuRoC intrinsics, asl_msckf.cpp:77-78) the reference's own result is not
+ * reproducible beyond ~1e-4 in the biases / ~1e-7 in attitude per update: msckf.h:1347 keeps the rounding-level rows of
+ * R that belong to the window's gauge directions, and their (rounding-noise) Q columns enter R_n = Q_1^T R_o Q_1 with
+ * O(1) weights (measured with the reference's own source under two roundings, tests/test_ref_vs_oracle.py).  This
+ * library pre-whitens every observation row by 1/sigma_u resp. 1/sigma_v and runs the filter with unit noise -- the
+ * basis-independent generalized-least-squares update -- which stays within a small multiple of that envelope
+ * (same test; < 2e-6 on attitude, position, velocity and covariance, < 2e-3 relative on the gyro bias).
  */
 #ifndef MSCKF_HIP_H
 #define MSCKF_HIP_H
@@ -79,6 +82,16 @@ int msckf_hip_get_imu_state(msckf_hip_handle h, int b, double* imu29);       /* 
 int msckf_hip_get_cam_states(msckf_hip_handle h, int b, double* cam7, int* state_ids, int cap); /* getCamStates :835 */
 int msckf_hip_get_map(msckf_hip_handle h, int b, double* xyz, int cap);      /* getMap :820; returns count */
 int msckf_hip_get_pruned_state_ids(msckf_hip_handle h, int b, int* ids, int cap);  /* getPrunedStates :840 */
+/* getPrunedStates() :840-848 in full: the camState of every pruned state as it was when pruned (pose after the
+ * last update that touched it, time, ids; types.h:57-67), sorted by state_id as the reference sorts them.  Any output
+ * pointer may be NULL.  Read by asl_msckf.cpp:409-424 (pruned-camera path).  Returns the count. */
+int msckf_hip_get_pruned_states(msckf_hip_handle h, int b, double* cam7, double* time, int* state_ids,
+                                int* last_correlated_ids, int cap);
+/* the non-pose members of getCamStates()[i] (types.h:57-67): time, tracked_feature_ids.size(), last_correlated_id
+ * (asl_msckf.cpp:384-388 publishes them); host-side bookkeeping, no device access.  Returns the count. */
+int msckf_hip_get_cam_meta(msckf_hip_handle h, int b, double* time, int* n_tracked, int* last_correlated_ids, int cap);
+/* getCamState(i).tracked_feature_ids :830 */
+int msckf_hip_get_tracked_feature_ids(msckf_hip_handle h, int b, int cam_index, uint64_t* ids, int cap);
 
 /* ---- additive accessors (the reference keeps these private, msckf.h:52-54; needed for parity tests) ---- */
 int msckf_hip_get_covariance(msckf_hip_handle h, int b, double* P, int ld);  /* D x D, D = 15 + 6 N */
@@ -126,6 +139,11 @@ int msckf_hip_set_streams(msckf_hip_handle h, int n);
  * >= sigma^2 I, so gamma <= |r_o|^2 / sigma^2; when that bound is below half the threshold the track passes without
  * forming S.  Same decisions as the reference; the reported gamma of such a track is the bound (status bit 32). */
 int msckf_hip_set_gate_early_accept(msckf_hip_handle h, int on);
+/* Compression of the stacked Jacobian (HouseholderQR + Q_1^T r_o of measurementUpdate, msckf.h:1338-1366):
+ * -1 default for the window size, 0 Householder TSQR (kernels_qr.hip), 1 information form [T | r_n] = chol(H_o^T H_o)
+ * accumulated in f64 (kernels_gram.hip), 2 the same with the blocked matrix-core Cholesky.  1 and 2 need
+ * 6 n_cap + 1 <= 192 (-ENOTSUP otherwise).  All routes give the reference's update (tests keep them together). */
+int msckf_hip_set_compression(msckf_hip_handle h, int route);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,9 @@
 //   * one filter = one batch handle with B = 1; capacities come from MSCKFParams (override with
 //     MSCKF_SHIM_N_CAP / MSCKF_SHIM_F_CAP / MSCKF_SHIM_M_CAP);
 //   * Q_imu / initial_imu_covar are read through their diagonals (every caller passes .asDiagonal());
-//   * u_var_prime must equal v_var_prime in this build (msckf_hip_initialize returns -ENOTSUP otherwise);
+//   * u_var_prime != v_var_prime (EuRoC intrinsics) is handled by row pre-whitening, see include/msckf_hip.h;
+//   * getCamStates()[i].tracked_feature_ids / getPrunedStates() carry the reference's payloads (time, poses, ids,
+//     last_correlated_id) -- asl_msckf.cpp:379-424 reads them;
 //   * additive: getCovariance(), lastError().
 #ifndef MSCKF_MONO_SHIM_MSCKF_H_
 #define MSCKF_MONO_SHIM_MSCKF_H_
@@ -144,23 +146,40 @@ class MSCKF {
   }
   inline Camera<_S> getCamera() { return camera_; }
   inline std::vector<camState<_S>> getCamStates() const {
-    std::vector<double> c(7 * 64); std::vector<int> ids(64);
-    int n = msckf_hip_get_cam_states(h_, 0, c.data(), ids.data(), 64);
+    const int cap = 64;
+    std::vector<double> c(7 * cap), tm(cap); std::vector<int> ids(cap), lc(cap), nt(cap);
+    const int n = msckf_hip_get_cam_states(h_, 0, c.data(), ids.data(), cap);
+    const int nm = msckf_hip_get_cam_meta(h_, 0, tm.data(), nt.data(), lc.data(), cap);
     std::vector<camState<_S>> out;
+    std::vector<uint64_t> fid;
     for (int i = 0; i < n; ++i) {
       camState<_S> s;
       setq(s.q_CG, c.data() + 7 * i); set3(s.p_C_G, c.data() + 7 * i + 4);
-      s.state_id = ids[i]; s.last_correlated_id = -1; s.time = 0;
+      s.state_id = ids[i];
+      s.time = i < nm ? (_S)tm[i] : (_S)0;
+      s.last_correlated_id = i < nm ? lc[i] : -1;
+      if (i < nm && nt[i] > 0) {                     // tracked_feature_ids (types.h:66), read at asl_msckf.cpp:388
+        fid.resize((size_t)nt[i]);
+        const int k = msckf_hip_get_tracked_feature_ids(h_, 0, i, fid.data(), nt[i]);
+        for (int j = 0; j < k; ++j) s.tracked_feature_ids.push_back((size_t)fid[(size_t)j]);
+      }
       out.push_back(s);
     }
     return out;
   }
   inline camState<_S> getCamState(size_t i) { return getCamStates()[i]; }
-  inline std::vector<camState<_S>> getPrunedStates() {   // ids only: poses of pruned states are not kept on the device
-    std::vector<int> ids(1 << 16);
-    int n = msckf_hip_get_pruned_state_ids(h_, 0, ids.data(), (int)ids.size());
+  inline std::vector<camState<_S>> getPrunedStates() {   // sorted by state_id, poses as they were when pruned (:840-848)
+    int n = msckf_hip_get_pruned_states(h_, 0, nullptr, nullptr, nullptr, nullptr, 1 << 30);
+    if (n < 0) n = 0;
+    std::vector<double> c(7 * (size_t)n + 1), tm((size_t)n + 1); std::vector<int> ids((size_t)n + 1), lc((size_t)n + 1);
+    n = msckf_hip_get_pruned_states(h_, 0, c.data(), tm.data(), ids.data(), lc.data(), n);
     std::vector<camState<_S>> out;
-    for (int i = 0; i < n; ++i) { camState<_S> s; s.state_id = ids[i]; out.push_back(s); }
+    for (int i = 0; i < n; ++i) {
+      camState<_S> s;
+      setq(s.q_CG, c.data() + 7 * i); set3(s.p_C_G, c.data() + 7 * i + 4);
+      s.state_id = ids[(size_t)i]; s.time = (_S)tm[(size_t)i]; s.last_correlated_id = lc[(size_t)i];
+      out.push_back(s);
+    }
     return out;
   }
   // additive accessors

@@ -31,6 +31,7 @@ SYMBOLS = [
     "msckf_hip_augment_range", "msckf_hip_marginalize_range", "msckf_hip_drop_oldest_range", "msckf_hip_scenario_alloc",
     "msckf_hip_scenario_set", "msckf_hip_scenario_commit", "msckf_hip_run_frames", "msckf_hip_sync",
     "msckf_hip_profile_enable", "msckf_hip_profile_read", "msckf_hip_set_streams", "msckf_hip_set_gate_early_accept",
+    "msckf_hip_set_compression", "msckf_hip_get_pruned_states", "msckf_hip_get_cam_meta", "msckf_hip_get_tracked_feature_ids",
 ]
 
 
@@ -152,6 +153,24 @@ class Batch:
     def pruned_state_ids(self, b, cap=65536):
         o = np.zeros(cap, dtype=np.int32); n = _chk(self.L.msckf_hip_get_pruned_state_ids(self.h, b, o.ctypes.data_as(_ip), cap)); return o[:n]
 
+    def pruned_states(self, b):
+        """getPrunedStates() in full: rows of q_CG(4) p_C_G(3) time state_id last_correlated_id, sorted by state_id"""
+        n = _chk(self.L.msckf_hip_get_pruned_states(self.h, b, None, None, None, None, 1 << 30))
+        c = np.zeros((max(n, 1), 7)); t = np.zeros(max(n, 1)); ids = np.zeros(max(n, 1), dtype=np.int32); lc = np.zeros(max(n, 1), dtype=np.int32)
+        n = _chk(self.L.msckf_hip_get_pruned_states(self.h, b, c.ctypes.data_as(_dp), t.ctypes.data_as(_dp), ids.ctypes.data_as(_ip), lc.ctypes.data_as(_ip), n))
+        return np.concatenate([c[:n], t[:n, None], ids[:n, None].astype(np.float64), lc[:n, None].astype(np.float64)], 1)
+
+    def cam_meta(self, b):
+        """(time, len(tracked_feature_ids), last_correlated_id) per entry of getCamStates() (types.h:57-67)"""
+        t = np.zeros(self.n_cap); k = np.zeros(self.n_cap, dtype=np.int32); lc = np.zeros(self.n_cap, dtype=np.int32)
+        n = _chk(self.L.msckf_hip_get_cam_meta(self.h, b, t.ctypes.data_as(_dp), k.ctypes.data_as(_ip), lc.ctypes.data_as(_ip), self.n_cap))
+        return t[:n], k[:n], lc[:n]
+
+    def tracked_feature_ids(self, b, cam_index, cap=4096):
+        o = np.zeros(cap, dtype=np.uint64)
+        n = _chk(self.L.msckf_hip_get_tracked_feature_ids(self.h, b, int(cam_index), o.ctypes.data_as(_up), cap))
+        return o[:n]
+
     # ---- additive accessors
     def covariance(self, b):
         D = 15 + 6 * self.num_cam_states(b)
@@ -223,6 +242,10 @@ class Batch:
     def set_streams(self, n):
         _chk(self.L.msckf_hip_set_streams(self.h, int(n)))
 
+    def set_compression(self, route):
+        """-1 default, 0 Householder TSQR, 1 information form, 2 information form + blocked Cholesky"""
+        _chk(self.L.msckf_hip_set_compression(self.h, int(route)))
+
     def set_gate_early_accept(self, on):
         _chk(self.L.msckf_hip_set_gate_early_accept(self.h, 1 if on else 0))
 
@@ -287,6 +310,12 @@ class MSCKF:
 
     def getPrunedStates(self):
         return self.batch.pruned_state_ids(0)
+
+    def getPrunedStatesFull(self):
+        return self.batch.pruned_states(0)
+
+    def getCamMeta(self):
+        return self.batch.cam_meta(0)
 
     def getCovariance(self):
         return self.batch.covariance(0)

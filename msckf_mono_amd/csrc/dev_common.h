@@ -69,7 +69,8 @@ struct Dev {
   //   trk_inv[B*f_cap][n_cap]   i8    observation index of camera slot s in the track, -1 = not observed
   //   Dg     [B][n_cap][28]     f64   per camera slot: upper triangle of sum h^T h (21) and sum h^T r (6)
   //   Lam    [B][ldR][ldR]      f64   sum B^T B, upper 64x64 tiles
-  int compress; double* trk_B; S* trk_rw; signed char* trk_inv; double* Dg; double* Lam;
+  int compress;   // 0 Householder TSQR, 1 information form (k_chol_T), 2 information form with the blocked Cholesky (k_chol_blk)
+  double* trk_B; S* trk_rw; signed char* trk_inv; double* Dg; double* Lam;
   // Kalman work matrices
   S* PHt; S* Smat; S* Linv; S* W; S* K; S* A; S* AP; S* X; S* dx;
   // prune
@@ -260,6 +261,10 @@ template <class S> void launch_compress(const Dev<S>& d, int b0, int nb, hipStre
 template <class S> void launch_gram(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase);
 template <class S> void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st);
 size_t feature_lds_bytes(int m_cap, size_t scalar);
+// one-time per-device setup of each kernel file (constant tables, dynamic-LDS limits); msckf_hip_create calls them
+void feature_device_setup();
+void qr_device_setup();
+void kalman_device_setup();
 
 }  // namespace msckf
 #endif

@@ -24,8 +24,9 @@
 namespace msckf {
 
 __constant__ double c_chi2[99];
-static bool g_chi2_uploaded[16] = {false};
-__device__ int g_feat_dbg = 0;   // ablation knob (msckf_hip_debug_set(200, .)); zero in production
+#ifdef MSCKF_ABLATE
+__device__ int g_feat_dbg = 0;   // ablation knob of the -DMSCKF_ABLATE build (scripts/feat_ablate.py); not in the product library
+#endif
 
 template <class S> struct Pose { M3<S> R; V3<S> t; };
 
@@ -263,7 +264,11 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
   S total_cost = wave_sum(act ? tri_cost(T, sa, sb, srho, zx, zy) : S(0));
   bool reduced = false;
   int inner = 0, outer = 0;
+#ifdef MSCKF_ABLATE
   const int fdbg = g_feat_dbg;
+#else
+  constexpr int fdbg = 0;
+#endif
   if (!given && !(fdbg & 1)) do {
     S Ab[9];  // a00 a01 a02 a11 a12 a22 b0 b1 b2
     {
@@ -792,25 +797,22 @@ size_t feature_lds_bytes(int m_cap, size_t scalar) {
   return (128 + r2 * (r2 + 1) / 2 + (size_t)m_cap * 12 + 2 * (size_t)m_cap * 3 * 2) * scalar + (size_t)m_cap * sizeof(int) + 16;
 }
 
+// one-time, per-device setup (called from msckf_hip_create after hipSetDevice): chi-square table, LDS limits
+void feature_device_setup() {
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(c_chi2), kChi2Q05, sizeof(double) * 99);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 template <class S>
 void launch_feature(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0) return;
-  int dev = 0;
-  hipGetDevice(&dev);
-  if (dev < 16 && !g_chi2_uploaded[dev]) {
-    hipMemcpyToSymbol(HIP_SYMBOL(c_chi2), kChi2Q05, sizeof(double) * 99);
-    g_chi2_uploaded[dev] = true;
-  }
   const size_t lds = feature_lds_bytes(d.m_cap, sizeof(S));
-  static bool attr_set[2] = {false, false};
-  const int ti = sizeof(S) == 4 ? 0 : 1;
-  if (!attr_set[ti]) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature<S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set[ti] = true;
-  }
   hipLaunchKernelGGL(k_feature<S>, dim3(d.f_cap, nb), dim3(64), lds, st, d, b0);
 }
+#ifdef MSCKF_ABLATE
 void feat_debug_set(int val) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_feat_dbg), &val, sizeof(int)); }
+#endif
 
 template <class S>
 void launch_select(const Dev<S>& d, int b0, int nb, hipStream_t st) {

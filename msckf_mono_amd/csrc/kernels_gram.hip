@@ -18,16 +18,17 @@
 //   k_chol_T  register-resident right-looking Cholesky (16 x 16 thread grid, 2-D block-cyclic, one LDS exchange
 //             and one barrier per step) with semi-definite pivot skipping; writes [T | r_n] in the layout the
 //             Kalman stage reads
-#include <cstdlib>
 #include <utility>
 #include "dev_common.h"
 
 namespace msckf {
 
-// Ablation knob (msckf_hip_debug_set(300, .) or MSCKF_GRAM_DBG; zero in production, results are garbage otherwise except
-// for bit 16): 1 no block-diagonal reduction, 2 no prefetch after the first chunks, 4 no MFMA, 8 half the MFMAs,
-// 16 use k_chol_blk instead of k_chol_T, 32/64/128/256 skip phase b/c/d/e of k_chol_blk (scripts/gram_ablate.py).
+// Ablation bits of the -DMSCKF_ABLATE build only (scripts/gram_ablate.py; the product library passes 0): 1 no
+// block-diagonal reduction, 2 no prefetch after the first chunks, 4 no MFMA, 8 half the MFMAs, 32/64/128/256 skip phase
+// b/c/d/e of k_chol_blk.  Results are garbage with any of them set.
+#ifdef MSCKF_ABLATE
 int g_gram_dbg = 0;
+#endif
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int GK = 24;   // rows of B per staged chunk = 8 tracks
@@ -433,8 +434,11 @@ __global__ __launch_bounds__(256) void k_chol_blk(Dev<S> d, int b0, int dbg) {
 template <class S>
 void launch_gram(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase) {
   if (nb <= 0) return;
-  static const int env_dbg = getenv("MSCKF_GRAM_DBG") ? atoi(getenv("MSCKF_GRAM_DBG")) : 0;   // experiments
-  const int g_dbg = g_gram_dbg | env_dbg;
+#ifdef MSCKF_ABLATE
+  const int g_dbg = g_gram_dbg;
+#else
+  const int g_dbg = 0;
+#endif
   const int npairs = d.ldR / 64, ndiag = (d.n_cap + 3) / 4;   // one SYRK strip per 64-column panel
   if (phase != 2) {
     // two launches of the same kernel: the block-diagonal reduction (short, many small workgroups) and the SYRK strips
@@ -446,8 +450,8 @@ void launch_gram(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase) {
   if (phase == 1) return;
   // k_chol_blk (blocked, trailing update on the f64 matrix cores) is 10 % faster than k_chol_T in isolation (104 vs
   // 114 us) but holds the whole register file of its CU (256 VGPR + 188 AGPR), so nothing of the other slice's stream
-  // co-schedules with it: 3 % slower end to end with two streams.  Kept selectable (msckf_hip_debug_set(300, 16)).
-  if (g_dbg & 16) {
+  // co-schedules with it: 3 % slower end to end with two streams.  Kept selectable (msckf_hip_set_compression(h, 2)).
+  if (d.compress == 2) {
     switch (d.ldR / 16) {
       case 4: hipLaunchKernelGGL((k_chol_blk<S, 4>), dim3(nb), dim3(256), 0, st, d, b0, g_dbg); break;
       case 8: hipLaunchKernelGGL((k_chol_blk<S, 8>), dim3(nb), dim3(256), 0, st, d, b0, g_dbg); break;

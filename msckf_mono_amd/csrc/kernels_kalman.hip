@@ -669,12 +669,6 @@ void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   } else {
     const size_t lds = (size_t)n * (n + 1) * sizeof(S);
     if (lds <= 150 * 1024) {
-      static bool attr_set[2] = {false, false};
-      const int ti = sizeof(S) == 4 ? 0 : 1;
-      if (!attr_set[ti]) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_inv<S, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set[ti] = true;
-      }
       hipLaunchKernelGGL((k_chol_inv<S, true>), dim3(nb), dim3(256), lds, st, d, b0);
     } else {
       hipLaunchKernelGGL((k_chol_inv<S, false>), dim3(nb), dim3(256), 0, st, d, b0);
@@ -688,6 +682,11 @@ void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   gemm<S, OP_AP>(d, b0, nb, D, D, st);
   gemm<S, OP_X>(d, b0, nb, D, D, st);
   if (sizeof(S) != 4) hipLaunchKernelGGL((k_symmetrize<S, false>), dim3(16, nb), dim3(256), 0, st, d, b0);   // float: fused into the X product
+}
+
+void kalman_device_setup() {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_inv<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_inv<double, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 template void launch_kalman<float>(const Dev<float>&, int, int, hipStream_t);

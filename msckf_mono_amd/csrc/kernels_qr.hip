@@ -25,7 +25,9 @@
 
 namespace msckf {
 
-__device__ int g_qr_dbg[4] = {0, 0, 0, 0};   // experiment knobs (msckf_hip_debug_set); all zero in production
+#ifdef MSCKF_ABLATE
+__device__ int g_qr_dbg[4] = {0, 0, 0, 0};   // ablation knobs of the -DMSCKF_ABLATE build (scripts/qr_ablate.py)
+#endif
 
 // Reflector scalars: beta = sqrt(s), g = 1/(beta*u).  Double: IEEE sqrt / divide.  Float: hardware rsq / rcp
 // (~1 ulp) refined by one Newton step each -- within 1 ulp of the correctly rounded values at a third of the
@@ -114,7 +116,11 @@ __global__ __launch_bounds__(64 * QR_NW) void k_qr_update(Dev<S> d, int b0, int 
   const int cstride = (stage == 1) ? d.nchunk : 1, coff = (stage == 1) ? (int)blockIdx.x : 0;
   const int gblk = (row_end - row_begin + RW - 1) / RW;
   const int nblk = (gblk - coff + cstride - 1) / cstride;
+#ifdef MSCKF_ABLATE
   const int dbg = g_qr_dbg[0];
+#else
+  constexpr int dbg = 0;
+#endif
   // blocks are dealt to the wavefronts round-robin (a boustrophedon order balances the step totals better but
   // stalls the pipeline at every turn: measured 9 % slower)
   for (int q = h; q < nblk; q += QR_NW) {
@@ -279,8 +285,6 @@ template <class S, int NC, bool RLDS>
 static void launch_compress_impl(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase, size_t lds) {
   constexpr int RW = (sizeof(S) == 4 && NC <= 3) ? 32 : 16;
   auto kern = k_qr_update<S, NC, RW, RLDS>;
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
   if (phase != 2) hipLaunchKernelGGL(kern, dim3(d.nchunk, nb), dim3(64 * QR_NW), lds, st, d, b0, 1, 0);
   if (phase == 1) return;
   if (d.nchunk > 1) hipLaunchKernelGGL(kern, dim3(1, nb), dim3(64 * QR_NW), lds, st, d, b0, 2, 0);
@@ -307,7 +311,18 @@ void launch_compress(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase)
   }
 }
 
+#ifdef MSCKF_ABLATE
 void qr_debug_set(int idx, int val) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_qr_dbg), &val, sizeof(int), idx * sizeof(int)); }
+#endif
+
+// one-time, per-device setup (called from msckf_hip_create after hipSetDevice): LDS limit of every instantiation
+template <class S, int NC> static void qr_setup_nc() {
+  constexpr int RW = (sizeof(S) == 4 && NC <= 3) ? 32 : 16;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_qr_update<S, NC, RW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_qr_update<S, NC, RW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+template <class S> static void qr_setup_s() { qr_setup_nc<S, 1>(); qr_setup_nc<S, 2>(); qr_setup_nc<S, 3>(); qr_setup_nc<S, 4>(); qr_setup_nc<S, 5>(); qr_setup_nc<S, 6>(); }
+void qr_device_setup() { qr_setup_s<float>(); qr_setup_s<double>(); }
 
 template void launch_compress<float>(const Dev<float>&, int, int, hipStream_t, int);
 template void launch_compress<double>(const Dev<double>&, int, int, hipStream_t, int);

@@ -20,7 +20,6 @@
 #include <thread>
 #include "dev_common.h"
 
-namespace msckf { int g_compress_override = -1; }   // experiment knob (msckf_hip_debug_set(100, .))
 
 namespace {
 using namespace msckf;
@@ -35,6 +34,7 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
   } while (0)
 
 struct CamMeta { int state_id; double time; int last_correlated_id; std::vector<uint64_t> tracked; };
+struct PrunedState { int state_id; double time; int last_correlated_id; double pose[7]; };   // camState at the moment it was pruned (msckf.h:631,714)
 struct Track { uint64_t id; std::vector<double> obs; std::vector<int> cam_ids; bool initialized = false; double p_f_G[3] = {0, 0, 0}; };
 struct TrackToResid { uint64_t id; std::vector<double> obs; std::vector<int> slots; };
 struct HostTraj {
@@ -45,7 +45,7 @@ struct HostTraj {
   std::vector<Track> tracks;
   std::vector<uint64_t> tracked_ids;
   std::vector<TrackToResid> to_resid;
-  std::vector<int> pruned_ids;
+  std::vector<PrunedState> pruned;
   std::vector<double> map;   // xyz triples of the last marginalize
   int wl_F = 0;              // tracks in the device work-list of this trajectory
 };
@@ -85,6 +85,8 @@ struct BatchBase {
   virtual int prof_read(double* ms, int* cnt) = 0;
   virtual int set_streams(int n) = 0;
   virtual int set_gate_early(int on) = 0;
+  virtual int set_compression(int route) = 0;
+  virtual int clear_stats(int b) = 0;
 };
 
 constexpr int NSTAGE = 8;
@@ -98,6 +100,10 @@ struct Batch : BatchBase {
   hipEvent_t ev_fork = nullptr, ev_join[MAXS] = {nullptr};
   int nstreams = 1;
   std::vector<void*> allocs;
+  // pinned host staging of the per-call inputs (single-filter API): filled, copied asynchronously, reused only after
+  // ev_stage says the previous copy has left it -- the calls themselves do not wait for the device
+  unsigned char* h_stage = nullptr; size_t h_stage_bytes = 0; hipEvent_t ev_stage = nullptr; bool stage_busy = false;
+  int compress_route = -1;   // -1 default, 0 Householder TSQR, 1 information form, 2 information form + blocked Cholesky
   // single-call staging on device
   S* d_rd = nullptr; int rd_cap = 0;               // [B][rd_cap][7]
   S* d_pfin = nullptr;                              // [B][f_cap][4] stored feature positions (mode 1)
@@ -106,6 +112,7 @@ struct Batch : BatchBase {
   int sc_frames = 0, sc_K = 0;
   S* sc_rd = nullptr; int* sc_n = nullptr; int* sc_M = nullptr; int* sc_slots = nullptr; S* sc_obs = nullptr; int* sc_drop = nullptr;
   std::vector<S> h_rd, h_obs; std::vector<int> h_n, h_M, h_slots, h_drop;
+  std::vector<void*> sc_allocs;
   // profiling
   bool prof = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool[NSTAGE];
@@ -122,7 +129,10 @@ struct Batch : BatchBase {
   }
   int create() {
     HIPCHK(hipSetDevice(device));
+    feature_device_setup(); qr_device_setup(); kalman_device_setup();   // per device: constant tables, dynamic-LDS limits
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ev_stage, hipEventDisableTiming));
     stx[0] = st;
     for (int i = 1; i < MAXS; ++i) HIPCHK(hipStreamCreateWithFlags(&stx[i], hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
@@ -172,8 +182,24 @@ struct Batch : BatchBase {
     for (int s = 0; s < NSTAGE; ++s) for (auto& e : ev_pool[s]) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (int i = 1; i < MAXS; ++i) { if (stx[i]) hipStreamDestroy(stx[i]); if (ev_join[i]) hipEventDestroy(ev_join[i]); }
     if (ev_fork) hipEventDestroy(ev_fork);
+    if (ev_stage) hipEventDestroy(ev_stage);
+    if (h_stage) hipHostFree(h_stage);
     if (st) hipStreamDestroy(st);
   }
+  // pinned staging area of at least `bytes`, safe to overwrite (the previous asynchronous copy out of it has finished)
+  int stage_acquire(size_t bytes, unsigned char** out) {
+    if (stage_busy) { HIPCHK(hipEventSynchronize(ev_stage)); stage_busy = false; }
+    if (bytes > h_stage_bytes) {
+      if (h_stage) HIPCHK(hipHostFree(h_stage));
+      h_stage = nullptr; h_stage_bytes = 0;
+      const size_t nb = std::max<size_t>(bytes, 1 << 16);
+      HIPCHK(hipHostMalloc((void**)&h_stage, nb, hipHostMallocDefault));
+      h_stage_bytes = nb;
+    }
+    *out = h_stage;
+    return 0;
+  }
+  int stage_release() { HIPCHK(hipEventRecord(ev_stage, st)); stage_busy = true; return 0; }
   void use_single_worklists() {
     d.trk_n = wl_n; d.trk_M = wl_M; d.trk_slots = wl_slots; d.trk_obs = wl_obs;
     d.wl_stride_n = 1; d.wl_stride_f = f_cap; d.wl_stride_o = (long)f_cap * m_cap;
@@ -236,15 +262,21 @@ struct Batch : BatchBase {
   }
   int propagate(int b0, int nb, const double* rd, int K) override {
     if (chk_range(b0, nb)) return fail(-EINVAL, "trajectory range out of bounds");
+    if (K < 0) return fail(-EINVAL, "negative sample count");
     HIPCHK(hipSetDevice(device));
     for (int k0 = 0; k0 < K; k0 += rd_cap) {
       const int kk = std::min(rd_cap, K - k0);
-      std::vector<S> tmp((size_t)nb * kk * RD_STRIDE);
+      const size_t cnt = (size_t)nb * kk * RD_STRIDE;
+      unsigned char* raw = nullptr;
+      int rc = stage_acquire(cnt * sizeof(S), &raw);
+      if (rc) return rc;
+      S* tmp = reinterpret_cast<S*>(raw);
       for (int i = 0; i < nb; ++i)
         for (int k = 0; k < kk; ++k)
           for (int c = 0; c < RD_STRIDE; ++c) tmp[((size_t)i * kk + k) * RD_STRIDE + c] = (S)rd[((size_t)i * K + k0 + k) * RD_STRIDE + c];
-      HIPCHK(hipMemcpyAsync(d_rd, tmp.data(), tmp.size() * sizeof(S), hipMemcpyHostToDevice, st));
-      HIPCHK(hipStreamSynchronize(st));
+      HIPCHK(hipMemcpyAsync(d_rd, tmp, cnt * sizeof(S), hipMemcpyHostToDevice, st));
+      rc = stage_release();
+      if (rc) return rc;
       launch_propagate<S>(d, b0, nb, d_rd, (long)kk * RD_STRIDE, kk, st);
       HIPCHK(hipGetLastError());
     }
@@ -261,11 +293,19 @@ struct Batch : BatchBase {
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
     if (F < 0 || F > f_cap) return fail(-E2BIG, "more tracks than f_cap");
     HIPCHK(hipSetDevice(device));
-    std::vector<int> hM(f_cap, 0), hS((size_t)f_cap * m_cap, 0);
-    std::vector<S> hO((size_t)f_cap * m_cap * 2, S(0));
+    for (int t = 0; t < F; ++t) if (M[t] > m_cap || M[t] < 0) return fail(-E2BIG, "track longer than m_cap");
+    // only the F rows in use travel: [F] lengths, [F][m_cap] slots, [F][m_cap][2] coordinates, one pinned block
+    const size_t nM = (size_t)F, nS = (size_t)F * m_cap, nO = (size_t)F * m_cap * 2;
+    const size_t offS = ((nM * sizeof(int) + 15) / 16) * 16, offO = offS + ((nS * sizeof(int) + 15) / 16) * 16;
+    unsigned char* raw = nullptr;
+    int rc = stage_acquire(offO + nO * sizeof(S) + sizeof(int), &raw);
+    if (rc) return rc;
+    int* hM = reinterpret_cast<int*>(raw); int* hS = reinterpret_cast<int*>(raw + offS); S* hO = reinterpret_cast<S*>(raw + offO);
+    int* hF = reinterpret_cast<int*>(raw + offO + nO * sizeof(S));
+    std::memset(raw, 0, offO + nO * sizeof(S));
+    *hF = F;
     size_t o = 0;
     for (int t = 0; t < F; ++t) {
-      if (M[t] > m_cap || M[t] < 0) return fail(-E2BIG, "track longer than m_cap");
       hM[t] = M[t];
       for (int k = 0; k < M[t]; ++k) {
         if (slots[o + k] < 0 || slots[o + k] >= n_cap) return fail(-EINVAL, "camera slot out of range");
@@ -275,17 +315,27 @@ struct Batch : BatchBase {
       }
       o += M[t];
     }
-    HIPCHK(hipMemcpyAsync(wl_n + b, &F, sizeof(int), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(wl_M + (size_t)b * f_cap, hM.data(), hM.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(wl_slots + (size_t)b * f_cap * m_cap, hS.data(), hS.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(wl_obs + (size_t)b * f_cap * m_cap * 2, hO.data(), hO.size() * sizeof(S), hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipMemcpyAsync(wl_n + b, hF, sizeof(int), hipMemcpyHostToDevice, st));
+    if (F) {
+      HIPCHK(hipMemcpyAsync(wl_M + (size_t)b * f_cap, hM, nM * sizeof(int), hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(wl_slots + (size_t)b * f_cap * m_cap, hS, nS * sizeof(int), hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(wl_obs + (size_t)b * f_cap * m_cap * 2, hO, nO * sizeof(S), hipMemcpyHostToDevice, st));
+    }
+    rc = stage_release();
+    if (rc) return rc;
     traj[b].wl_F = F;
+    return 0;
+  }
+  // last_stats of a marginalize() that had nothing to residualize (the reference returns early, msckf.h:337)
+  int clear_stats(int b) override {
+    if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemsetAsync(d.stats + (size_t)b * STAT_STRIDE, 0, sizeof(int) * STAT_ERR, st));
     return 0;
   }
   void launch_update(const Dev<S>& vin, int b0, int nb, hipStream_t q) {
     Dev<S> v = vin;
-    if (g_compress_override >= 0) v.compress = (g_compress_override && d.trk_B) ? 1 : 0;
+    if (compress_route >= 0) v.compress = (compress_route && d.trk_B) ? compress_route : 0;
     stage_begin(2, q); launch_feature<S>(v, b0, nb, q); stage_end(2, q);
     stage_begin(7, q); launch_select<S>(v, b0, nb, q); stage_end(7, q);
     if (v.compress) {
@@ -484,35 +534,57 @@ struct Batch : BatchBase {
   int scen_alloc(int n_frames, int K) override {
     if (n_frames <= 0 || K <= 0) return fail(-EINVAL, "bad scenario size");
     HIPCHK(hipSetDevice(device));
-    sc_frames = n_frames; sc_K = K;
+    HIPCHK(hipStreamSynchronize(st));
+    for (void* q : sc_allocs) {                                  // a previous scenario is replaced, not leaked
+      hipFree(q);
+      allocs.erase(std::remove(allocs.begin(), allocs.end(), q), allocs.end());
+    }
+    sc_allocs.clear();
+    sc_frames = 0;
     const size_t Bz = B, FB = (size_t)n_frames * Bz;
     h_rd.assign(FB * K * RD_STRIDE, S(0)); h_n.assign(FB, 0); h_M.assign(FB * f_cap, 0);
     h_slots.assign(FB * f_cap * m_cap, 0); h_obs.assign(FB * f_cap * m_cap * 2, S(0)); h_drop.assign(FB, 0);
+    const size_t mark = allocs.size();
     int rc = 0;
     rc |= dalloc(&sc_rd, h_rd.size()); rc |= dalloc(&sc_n, h_n.size()); rc |= dalloc(&sc_M, h_M.size());
     rc |= dalloc(&sc_slots, h_slots.size()); rc |= dalloc(&sc_obs, h_obs.size()); rc |= dalloc(&sc_drop, h_drop.size());
-    return rc;
+    sc_allocs.assign(allocs.begin() + mark, allocs.end());
+    if (rc) return rc;
+    sc_frames = n_frames; sc_K = K;
+    return 0;
   }
   int scen_set(int f, int b, const double* rd, int F, const int* M, const int* slots, const double* obs, int n_drop) override {
     if (f < 0 || f >= sc_frames || chk(b)) return fail(-EINVAL, "scenario cell out of range");
     if (F < 0 || F > f_cap) return fail(-E2BIG, "more tracks than f_cap");
+    if (n_drop < 0) return fail(-EINVAL, "negative n_drop");
     const size_t cell = (size_t)f * B + b;
+    {   // validate before touching the staged cell (same rules as set_tracks)
+      size_t o = 0;
+      for (int t = 0; t < F; ++t) {
+        if (M[t] > m_cap || M[t] < 0) return fail(-E2BIG, "track longer than m_cap");
+        for (int k = 0; k < M[t]; ++k) if (slots[o + k] < 0 || slots[o + k] >= n_cap) return fail(-EINVAL, "camera slot out of range");
+        o += M[t];
+      }
+    }
     for (int k = 0; k < sc_K; ++k) for (int c = 0; c < RD_STRIDE; ++c) h_rd[(cell * sc_K + k) * RD_STRIDE + c] = (S)rd[k * RD_STRIDE + c];
     h_n[cell] = F; h_drop[cell] = n_drop;
     size_t o = 0;
-    for (int t = 0; t < F; ++t) {
-      if (M[t] > m_cap) return fail(-E2BIG, "track longer than m_cap");
-      h_M[cell * f_cap + t] = M[t];
-      for (int k = 0; k < M[t]; ++k) {
-        h_slots[(cell * f_cap + t) * m_cap + k] = slots[o + k];
-        h_obs[((cell * f_cap + t) * m_cap + k) * 2] = (S)obs[2 * (o + k)];
-        h_obs[((cell * f_cap + t) * m_cap + k) * 2 + 1] = (S)obs[2 * (o + k) + 1];
+    for (int t = 0; t < f_cap; ++t) {
+      const int Mt = t < F ? M[t] : 0;
+      h_M[cell * f_cap + t] = Mt;
+      for (int k = 0; k < m_cap; ++k) {
+        const bool in = k < Mt;
+        h_slots[(cell * f_cap + t) * m_cap + k] = in ? slots[o + k] : 0;
+        h_obs[((cell * f_cap + t) * m_cap + k) * 2] = in ? (S)obs[2 * (o + k)] : S(0);
+        h_obs[((cell * f_cap + t) * m_cap + k) * 2 + 1] = in ? (S)obs[2 * (o + k) + 1] : S(0);
       }
-      o += M[t];
+      o += Mt;
     }
     return 0;
   }
+  // H2D of everything staged.  The host copy is kept, so cells may be patched with scenario_set and committed again.
   int scen_commit() override {
+    if (sc_frames <= 0) return fail(-EINVAL, "no scenario allocated");
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipMemcpyAsync(sc_rd, h_rd.data(), h_rd.size() * sizeof(S), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(sc_n, h_n.data(), h_n.size() * sizeof(int), hipMemcpyHostToDevice, st));
@@ -521,7 +593,6 @@ struct Batch : BatchBase {
     HIPCHK(hipMemcpyAsync(sc_obs, h_obs.data(), h_obs.size() * sizeof(S), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(sc_drop, h_drop.data(), h_drop.size() * sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
-    std::vector<S>().swap(h_rd); std::vector<S>().swap(h_obs); std::vector<int>().swap(h_slots); std::vector<int>().swap(h_M);
     return 0;
   }
   int run_frames(int f0, int f1) override;
@@ -536,6 +607,12 @@ struct Batch : BatchBase {
     return 0;
   }
   int set_gate_early(int on) override { d.gate_early = on ? 1 : 0; return 0; }
+  int set_compression(int route) override {
+    if (route < -1 || route > 2) return fail(-EINVAL, "route: -1 default, 0 Householder TSQR, 1 information form, 2 information form with the blocked Cholesky");
+    if (route >= 1 && !d.trk_B) return fail(-ENOTSUP, "information form not available for this window size (6 n_cap + 1 > 192)");
+    compress_route = route;
+    return 0;
+  }
   int set_streams(int n) override {
     if (n < 1 || n > MAXS) return fail(-EINVAL, "1 to 8 streams");
     nstreams = n;
@@ -590,8 +667,10 @@ int Batch<S>::run_frames(int f0, int f1) {
   if (nh > 1) { HIPCHK(hipEventRecord(ev_fork, st)); for (int i = 1; i < nh; ++i) HIPCHK(hipStreamWaitEvent(stx[i], ev_fork, 0)); }
   // one host thread per slice enqueues that slice's kernels for all frames: ~25 launches per frame and slice would
   // otherwise serialise on one thread and make more than two slices launch-bound
+  int slice_rc[MAXS] = {0};
   auto enqueue = [&](int hh) {
     (void)hipSetDevice(device);
+    (void)hipGetLastError();
     hipStream_t q = stx[hh];
     const int b0 = (int)((long)B * hh / nh);
     const int nb = (int)((long)B * (hh + 1) / nh) - b0;
@@ -609,6 +688,9 @@ int Batch<S>::run_frames(int f0, int f1) {
       launch_prune<S>(v, b0, nb, q);
       stage_end(6, q);
     }
+    // hipGetLastError is per host thread: a failed launch of this slice must not vanish with the thread
+    const hipError_t e = hipGetLastError();
+    slice_rc[hh] = (int)e;
   };
   if (nh == 1) enqueue(0);
   else {
@@ -618,7 +700,8 @@ int Batch<S>::run_frames(int f0, int f1) {
     for (auto& t : th) t.join();
   }
   for (int i = 1; i < nh; ++i) { HIPCHK(hipEventRecord(ev_join[i], stx[i])); HIPCHK(hipStreamWaitEvent(st, ev_join[i], 0)); }
-  HIPCHK(hipGetLastError());
+  for (int i = 0; i < nh; ++i)
+    if (slice_rc[i]) return fail(-EIO, std::string("kernel launch failed on slice ") + std::to_string(i) + ": " + hipGetErrorString((hipError_t)slice_rc[i]));
   return 0;
 }
 
@@ -698,7 +781,7 @@ int host_add_features(BatchBase* B, int b, const double* meas, const uint64_t* i
 int host_marginalize(BatchBase* B, int b) {
   HostTraj& t = B->traj[b];
   t.map.clear();
-  if (t.to_resid.empty()) { int z = 0; return B->set_tracks(b, 0, &z, &z, nullptr) ; }
+  if (t.to_resid.empty()) { int z = 0; int rc = B->set_tracks(b, 0, &z, &z, nullptr); return rc ? rc : B->clear_stats(b); }
   const int F = (int)t.to_resid.size();
   std::vector<int> M(F), slots; std::vector<double> obs;
   for (int i = 0; i < F; ++i) {
@@ -728,9 +811,18 @@ int host_prune_empty(BatchBase* B, int b) {
     if (!t.cams[i].tracked.empty()) { last_to_remove = i - 1; break; }
   if (last_to_remove < 0) return 0;
   std::vector<int> keep;
-  for (int i = 0; i <= last_to_remove; ++i) t.pruned_ids.push_back(t.cams[i].state_id);
+  // pruned_states_ keeps the whole camState (msckf.h:714; read by asl_msckf.cpp:409-424): poses come back once, here
+  std::vector<double> poses((size_t)num * 7);
+  int ngot = 0;
+  int rc = B->get_cams(b, poses.data(), num, &ngot);
+  if (rc) return rc;
+  for (int i = 0; i <= last_to_remove; ++i) {
+    PrunedState ps{t.cams[i].state_id, t.cams[i].time, t.cams[i].last_correlated_id, {0}};
+    std::copy(&poses[7 * (size_t)i], &poses[7 * (size_t)i] + 7, ps.pose);
+    t.pruned.push_back(ps);
+  }
   for (int i = last_to_remove + 1; i < num; ++i) keep.push_back(i);
-  int rc = B->prune_keep(b, keep);
+  rc = B->prune_keep(b, keep);
   if (rc) return rc;
   t.cams.erase(t.cams.begin(), t.cams.begin() + last_to_remove + 1);
   return 0;
@@ -861,8 +953,16 @@ int host_prune_redundant(BatchBase* B, int b) {
   // ---- prune the removed camera states :616-681
   std::vector<int> keep;
   std::vector<CamMeta> kept;
+  if (!rm.empty()) {                                  // poses as corrected by the second update (msckf.h:614 precedes :631)
+    rc = B->get_cams(b, poses.data(), n, &ngot);
+    if (rc) return rc;
+  }
   for (int i = 0; i < n; ++i) {
-    if (std::find(rm.begin(), rm.end(), t.cams[i].state_id) != rm.end()) t.pruned_ids.push_back(t.cams[i].state_id);
+    if (std::find(rm.begin(), rm.end(), t.cams[i].state_id) != rm.end()) {
+      PrunedState ps{t.cams[i].state_id, t.cams[i].time, t.cams[i].last_correlated_id, {0}};
+      std::copy(&poses[7 * (size_t)i], &poses[7 * (size_t)i] + 7, ps.pose);
+      t.pruned.push_back(ps);
+    }
     else { keep.push_back(i); kept.push_back(t.cams[i]); }
   }
   if ((int)keep.size() != n) {
@@ -893,18 +993,20 @@ int host_finish(BatchBase* B, int b) {
 BatchBase* H(msckf_hip_handle h) { return reinterpret_cast<BatchBase*>(h); }
 }  // namespace
 
+#ifdef MSCKF_ABLATE
 namespace msckf { void qr_debug_set(int idx, int val); void feat_debug_set(int val); extern int g_gram_dbg; }
+#endif
 
 extern "C" {
 
-// experiment knob, not part of the ABI (include/msckf_hip.h does not declare it)
-// idx 100: compression route (0 = Householder TSQR, 1 = information form, -1 = default); others: QR ablations
+#ifdef MSCKF_ABLATE
+// ablation knobs of the -DMSCKF_ABLATE build (scripts/*_ablate.py); the product library does not export this symbol
 void msckf_hip_debug_set(int idx, int val) {
-  if (idx == 100) { msckf::g_compress_override = val; return; }
   if (idx == 200) { msckf::feat_debug_set(val); return; }
   if (idx == 300) { msckf::g_gram_dbg = val; return; }
   msckf::qr_debug_set(idx, val);
 }
+#endif
 
 const char* msckf_hip_last_error(void) { return g_err.c_str(); }
 
@@ -985,13 +1087,49 @@ int msckf_hip_get_map(msckf_hip_handle h, int b, double* xyz, int cap) {
   std::copy(m.begin(), m.end(), xyz);
   return n;
 }
+static std::vector<PrunedState> sorted_pruned(const HostTraj& t) {
+  std::vector<PrunedState> p = t.pruned;
+  std::stable_sort(p.begin(), p.end(), [](const PrunedState& a, const PrunedState& c) { return a.state_id < c.state_id; });   // msckf.h:842-846
+  return p;
+}
 int msckf_hip_get_pruned_state_ids(msckf_hip_handle h, int b, int* ids, int cap) {
   if (b < 0 || b >= H(h)->B) return fail(-EINVAL, "trajectory index out of range");
-  std::vector<int> p = H(h)->traj[b].pruned_ids;
-  std::stable_sort(p.begin(), p.end());   // getPrunedStates sorts by state_id, msckf.h:842-846
+  const std::vector<PrunedState> p = sorted_pruned(H(h)->traj[b]);
   if ((int)p.size() > cap) return fail(-E2BIG, "output buffer too small");
-  std::copy(p.begin(), p.end(), ids);
+  for (size_t i = 0; i < p.size(); ++i) ids[i] = p[i].state_id;
   return (int)p.size();
+}
+int msckf_hip_get_pruned_states(msckf_hip_handle h, int b, double* cam7, double* time, int* state_ids, int* last_correlated_ids, int cap) {
+  if (b < 0 || b >= H(h)->B) return fail(-EINVAL, "trajectory index out of range");
+  const std::vector<PrunedState> p = sorted_pruned(H(h)->traj[b]);
+  if ((int)p.size() > cap) return fail(-E2BIG, "output buffer too small");
+  for (size_t i = 0; i < p.size(); ++i) {
+    if (cam7) std::copy(p[i].pose, p[i].pose + 7, cam7 + 7 * i);
+    if (time) time[i] = p[i].time;
+    if (state_ids) state_ids[i] = p[i].state_id;
+    if (last_correlated_ids) last_correlated_ids[i] = p[i].last_correlated_id;
+  }
+  return (int)p.size();
+}
+int msckf_hip_get_cam_meta(msckf_hip_handle h, int b, double* time, int* n_tracked, int* last_correlated_ids, int cap) {
+  if (b < 0 || b >= H(h)->B) return fail(-EINVAL, "trajectory index out of range");
+  const auto& cams = H(h)->traj[b].cams;
+  if ((int)cams.size() > cap) return fail(-E2BIG, "output buffer too small");
+  for (size_t i = 0; i < cams.size(); ++i) {
+    if (time) time[i] = cams[i].time;
+    if (n_tracked) n_tracked[i] = (int)cams[i].tracked.size();
+    if (last_correlated_ids) last_correlated_ids[i] = cams[i].last_correlated_id;
+  }
+  return (int)cams.size();
+}
+int msckf_hip_get_tracked_feature_ids(msckf_hip_handle h, int b, int cam_index, uint64_t* ids, int cap) {
+  if (b < 0 || b >= H(h)->B) return fail(-EINVAL, "trajectory index out of range");
+  const auto& cams = H(h)->traj[b].cams;
+  if (cam_index < 0 || cam_index >= (int)cams.size()) return fail(-EINVAL, "camera index out of range");
+  const auto& tr = cams[(size_t)cam_index].tracked;
+  if ((int)tr.size() > cap) return fail(-E2BIG, "output buffer too small");
+  std::copy(tr.begin(), tr.end(), ids);
+  return (int)tr.size();
 }
 int msckf_hip_get_covariance(msckf_hip_handle h, int b, double* P, int ld) { return H(h)->get_cov(b, P, ld); }
 int msckf_hip_set_covariance(msckf_hip_handle h, int b, const double* P, int D) { return H(h)->set_cov(b, P, D); }
@@ -1019,6 +1157,7 @@ int msckf_hip_sync(msckf_hip_handle h) { return H(h)->sync(); }
 int msckf_hip_profile_enable(msckf_hip_handle h, int on) { return H(h)->prof_enable(on); }
 int msckf_hip_profile_read(msckf_hip_handle h, double* ms7, int* count7) { return H(h)->prof_read(ms7, count7); }
 int msckf_hip_set_streams(msckf_hip_handle h, int n) { return H(h)->set_streams(n); }
+int msckf_hip_set_compression(msckf_hip_handle h, int route) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_compression(route); }
 int msckf_hip_set_gate_early_accept(msckf_hip_handle h, int on) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_gate_early(on); }
 
 }  // extern "C"

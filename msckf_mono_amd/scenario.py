@@ -164,8 +164,9 @@ class Trajectory:
     """One seeded trajectory: IMU stream + per-frame ending-track work-lists."""
 
     def __init__(self, config_id, traj_idx, N, F, n_frames, cfg=None, t0=0.0, imu_noise_scale=0.05,
-                 obs_noise_px=0.5, dense_tracks=False, first_timed_window_only=False):
+                 obs_noise_px=0.5, dense_tracks=False, first_timed_window_only=False, depth_range=(2.0, 10.0)):
         self.N, self.F, self.n_frames = N, F, n_frames
+        self.depth_range = depth_range   # landmark depth in the mid-track camera; (2, 10) m = SURVEY 8d, larger = low parallax
         self.t0 = t0
         self.cfg = cfg if cfg is not None else filter_config(N)
         self.seed = 0x5EED0000 + 1000 * config_id + traj_idx
@@ -221,7 +222,7 @@ class Trajectory:
             self.landmarks.append(pts)
 
     def _sample_landmarks(self, rng, k, M):
-        """One landmark per track, visible (90 deg FOV, in front) in frames k-M_j..k-1, 2-10 m deep."""
+        """One landmark per track, visible (90 deg FOV, in front) in frames k-M_j..k-1, depth_range (default 2-10 m) deep."""
         F = len(M)
         pts = np.zeros((F, 3))
         todo = np.arange(F)
@@ -231,7 +232,7 @@ class Trajectory:
             u = rng.uniform(3 * n).reshape(n, 3)
             mid = k - 1 - (M[todo] // 2)
             ax, ay = spread * (2 * u[:, 0] - 1), spread * (2 * u[:, 1] - 1)
-            d = 2.0 + 8.0 * u[:, 2]
+            d = self.depth_range[0] + (self.depth_range[1] - self.depth_range[0]) * u[:, 2]
             pc = np.stack([d * np.tan(ax), d * np.tan(ay), d], -1)
             pw = np.einsum("nji,nj->ni", self.C_CG[mid], pc) + self.p_C[mid]
             Mt = M[todo]

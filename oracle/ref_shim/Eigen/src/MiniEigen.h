@@ -147,6 +147,8 @@ template <class Derived> class MatrixBase {
   S operator()(Index i) const { return coeff(i); }
   S& operator()(Index i, Index j) { return derived().coeffRef(i, j); }
   S& operator()(Index i) { return cols() == 1 ? derived().coeffRef(i, 0) : derived().coeffRef(0, i); }
+  S operator[](Index i) const { return coeff(i); }
+  S& operator[](Index i) { return (*this)(i); }
 
   Plain eval() const { return Plain(*this); }
   Plain array() const { return Plain(*this); }

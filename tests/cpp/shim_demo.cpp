@@ -72,5 +72,16 @@ int main() {
   double tr = 0; const int D = 15 + 6 * (int)msckf.getNumCamStates();
   for (int i = 0; i < D; ++i) tr += P[(size_t)i * D + i];
   std::printf("%.17g\n", tr);
+  // what asl_msckf.cpp:379-424 reads from the getters: cam-state ids/times/tracked counts, pruned states' poses
+  std::vector<camState<S>> cs = msckf.getCamStates();
+  std::printf("%zu", cs.size());
+  for (const auto& c : cs) std::printf(" %d %.17g %zu %d", c.state_id, (double)c.time, c.tracked_feature_ids.size(), c.last_correlated_id);
+  std::printf("\n");
+  std::vector<camState<S>> ps = msckf.getPrunedStates();
+  std::printf("%zu", ps.size());
+  for (const auto& c : ps)
+    std::printf(" %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g", c.state_id, (double)c.time, (double)c.q_CG.w(), (double)c.q_CG.x(),
+                (double)c.q_CG.y(), (double)c.q_CG.z(), (double)c.p_C_G(0), (double)c.p_C_G(1), (double)c.p_C_G(2));
+  std::printf("\n");
   return 0;
 }

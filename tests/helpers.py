@@ -72,3 +72,50 @@ def copy_oracle_to_device(o, batch, b):
     for i, c in enumerate(cams):
         batch.set_cam_pose(b, i, c)
     batch.set_num_residualized(b, o.numResidualized())
+
+
+def check_tracks(td, to, ok, prec, tr, fr, o, k):
+    """Per-track parity of the triangulated point and of the gate statistic (rows of last_tracks: motion_ok tri_valid
+    gate_pass included gamma p_f_G).  Double: 1e-6 on both.  Float: the point is the result of an iterative solve whose
+    depth error scales with depth^2 / baseline, so it is held (i) through what the filter uses it for -- its
+    reprojection in every camera of the track agrees with the oracle's point to 1e-4 normalized units (0.05 px) -- and
+    (ii) directly to 2e-3 of its depth; gamma to 1e-3 relative + 1e-3 absolute."""
+    if prec == "f64":
+        assert np.allclose(td[ok, 5:8], to[ok, 5:8], rtol=0, atol=1e-6), k
+        assert np.allclose(td[ok, 4], to[ok, 4], rtol=1e-6, atol=1e-9), k
+        return
+    cams, _ = o.getCamStates()
+    off = np.concatenate([[0], np.cumsum(fr["M"])])
+    for t in np.nonzero(ok)[0]:
+        sl = fr["slots"][off[t]:off[t + 1]]
+        pd, pr = td[t, 5:8], to[t, 5:8]
+        worst_rp, depth = 0.0, 1e9
+        for s in sl:
+            R = q_to_rot(cams[s, :4])
+            a, b = R @ (pd - cams[s, 4:7]), R @ (pr - cams[s, 4:7])
+            worst_rp = max(worst_rp, float(np.abs(a[:2] / a[2] - b[:2] / b[2]).max()))
+            depth = min(depth, float(b[2]))
+        assert worst_rp < 1e-4, (k, t, worst_rp)
+        assert np.linalg.norm(pd - pr) < 2e-3 * max(depth, 1.0), (k, t, pd, pr, depth)
+    assert np.allclose(td[ok, 4], to[ok, 4], rtol=1e-3, atol=1e-3), (k, np.abs(td[ok, 4] - to[ok, 4]).max())
+
+
+def q_to_rot(q):
+    """Eigen toRotationMatrix of (w,x,y,z)"""
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def copy_device_to_oracle(batch, b, o):
+    """teacher forcing the other way: oracle state + covariance <- device trajectory b (the oracle's window is built by
+    replaying augmentState, then overwritten)"""
+    cams, ids = batch.cam_states(b)
+    while o.getNumCamStates() < len(cams):
+        o.augmentState(int(ids[o.getNumCamStates()]) if len(ids) else 0, 0.0)
+    o.setImuState(batch.imu_state(b))
+    for i, c in enumerate(cams):
+        o.setCamPose(i, c)
+    o.setCovariance(batch.covariance(b))
+    o.setNumResidualized(batch.num_residualized(b))

@@ -20,6 +20,18 @@ def test_shim_compiles_without_eigen(tmp_path):
     assert out.returncode == 0, out.stderr
 
 
+def test_shim_eigen_branch_compiles_against_the_reference_types():
+    """The branch a maintainer would build (with <Eigen/Dense> and the reference's own types.h): compile-only, against
+    the minimal Eigen surface of oracle/ref_shim (Eigen itself is not installed here)."""
+    ref_inc = "/root/reference/include"
+    if not os.path.exists(os.path.join(ref_inc, "msckf_mono", "types.h")):
+        pytest.skip("reference tree not present on this machine")
+    src = os.path.join(ROOT, "tests", "cpp", "shim_eigen_check.cpp")
+    out = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                          "-I" + os.path.join(ROOT, "oracle", "ref_shim"), "-I" + ref_inc, src], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+
+
 @pytest.mark.gpu
 def test_shim_runs_like_the_asl_runner(tmp_path, oracle_lib):
     po = oracle_lib
@@ -56,3 +68,18 @@ def test_shim_runs_like_the_asl_runner(tmp_path, oracle_lib):
     assert ncam == o.getNumCamStates() and nmap == len(o.getMap())
     assert H.rel(imu, o.getImuState()[:16]) < 1e-6
     assert abs(float(rows[2]) - np.trace(o.getCovariance())) / np.trace(o.getCovariance()) < 1e-6
+    # getCamStates(): ids, times, tracked_feature_ids.size(), last_correlated_id  (asl_msckf.cpp:384-388)
+    cs = rows[3].split()
+    assert int(cs[0]) == ncam
+    tm, nt, lc = o.getCamMeta()
+    ids = o.getCamStates()[1]
+    for i in range(ncam):
+        sid, t, k, l = int(cs[1 + 4 * i]), float(cs[2 + 4 * i]), int(cs[3 + 4 * i]), int(cs[4 + 4 * i])
+        assert (sid, k, l) == (int(ids[i]), int(nt[i]), int(lc[i])) and t == tm[i]
+    # getPrunedStates(): pose + time of every pruned state, sorted by id  (asl_msckf.cpp:409-424)
+    ps = rows[4].split()
+    ref = o.getPrunedStates()
+    assert int(ps[0]) == len(ref) > 0
+    got = np.array([float(x) for x in ps[1:]]).reshape(-1, 9)
+    assert np.array_equal(got[:, 0], ref[:, 8]) and np.array_equal(got[:, 1], ref[:, 7])
+    assert np.allclose(got[:, 2:9], ref[:, 0:7], atol=1e-8)

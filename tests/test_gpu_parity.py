@@ -61,8 +61,7 @@ def _stagewise(capi, po, prec, N, F, nf, teacher, traj=0, config=2, m_cap=None, 
                     assert so[key] == sd[key], (k, key, so, sd)
                 to, td = o.lastTracks(), bt.last_tracks(0)
                 ok = (to[:, 0] > 0) & (to[:, 1] > 0)
-                assert np.allclose(td[ok, 5:8], to[ok, 5:8], rtol=0, atol=(1e-6 if prec == "f64" else 5e-2)), k   # triangulated points
-                assert np.allclose(td[ok, 4], to[ok, 4], rtol=(1e-6 if prec == "f64" else 2e-2), atol=1e-9), k      # gate statistic
+                H.check_tracks(td, to, ok, prec, tr, fr, o, k)
             assert H.worst(_errs(bt, 0, o)) < tol, ("update", k, _errs(bt, 0, o))
         if o.getNumCamStates() == N:
             o.dropOldest(1); bt.drop_oldest_range(0, 1, 1)
@@ -133,7 +132,12 @@ def test_reference_api_path_vs_oracle_and_golden(capi, po):
         assert H.rel(f.getImuState()[:16], g["imu"][k][:16]) < 1e-6
         assert H.worst(_errs(f.batch, 0, o)) < 1e-6
         assert np.array_equal(f.getCamStates()[1], o.getCamStates()[1])      # state ids
+        for a, c in zip(f.getCamMeta(), o.getCamMeta()):                     # time, tracked_feature_ids.size(), last_correlated_id
+            assert np.array_equal(a, c), k
     assert np.array_equal(f.getPrunedStates(), o.getPrunedIds())
+    pf, pr = f.getPrunedStatesFull(), o.getPrunedStates()                    # poses and times of the pruned states (asl_msckf.cpp:409-424)
+    assert len(pr) and pf.shape[0] == pr.shape[0]
+    assert np.array_equal(pf[:, 7:9], pr[:, 7:9]) and np.allclose(pf[:, :7], pr[:, :7], atol=1e-8)
     assert H.rel(f.getCovariance(), g["P_final"], 1e-30) < 1e-6
     f.finish(); o.finish()
     assert H.worst(_errs(f.batch, 0, o)) < 1e-6
@@ -169,6 +173,8 @@ def test_prune_redundant_states_vs_oracle(capi, po):
         assert H.worst(_errs(f.batch, 0, o)) < 1e-6, (k, _errs(f.batch, 0, o))
     assert pruned_any
     assert np.array_equal(f.getPrunedStates(), o.getPrunedIds())
+    pf, pr = f.getPrunedStatesFull(), o.getPrunedStates()
+    assert np.array_equal(pf[:, 7:9], pr[:, 7:9]) and np.allclose(pf[:, :7], pr[:, :7], atol=1e-7)
 
 
 def test_batched_range_equals_single(capi):
@@ -207,19 +213,14 @@ def test_information_form_equals_householder_route(capi, prec):
     tr = sc.Trajectory(2, 7, N, F, nf)
     cd = capi.F64 if prec == "f64" else capi.F32
     res = {}
-    try:
-        for route in (0, 1, 2):               # 2 = information form with the blocked MFMA Cholesky (k_chol_blk)
-            capi.lib().msckf_hip_debug_set(100, min(route, 1))
-            capi.lib().msckf_hip_debug_set(300, 16 if route == 2 else 0)
-            bt = capi.Batch(1, N, F, N, cd)
-            bt.initialize(0, tr.cfg, tr.imu0)
-            for k in range(nf):
-                H.device_frame(bt, 0, tr, k, N)
-            res[route] = (bt.imu_state(0), bt.cam_states(0)[0], bt.covariance(0), bt.last_stats(0))
-            bt.close()
-    finally:
-        capi.lib().msckf_hip_debug_set(100, -1)
-        capi.lib().msckf_hip_debug_set(300, 0)
+    for route in (0, 1, 2):               # 2 = information form with the blocked MFMA Cholesky (k_chol_blk)
+        bt = capi.Batch(1, N, F, N, cd)
+        bt.set_compression(route)
+        bt.initialize(0, tr.cfg, tr.imu0)
+        for k in range(nf):
+            H.device_frame(bt, 0, tr, k, N)
+        res[route] = (bt.imu_state(0), bt.cam_states(0)[0], bt.covariance(0), bt.last_stats(0))
+        bt.close()
     e = H.state_errors(res[1][0], res[0][0], res[1][1], res[0][1], res[1][2], res[0][2])
     assert H.worst(e) < (1e-8 if prec == "f64" else 3e-4), e
     e2 = H.state_errors(res[2][0], res[1][0], res[2][1], res[1][1], res[2][2], res[1][2])
