@@ -144,6 +144,11 @@ int msckf_hip_set_gate_early_accept(msckf_hip_handle h, int on);
  * accumulated in f64 (kernels_gram.hip), 2 the same with the blocked matrix-core Cholesky.  1 and 2 need
  * 6 n_cap + 1 <= 192 (-ENOTSUP otherwise).  All routes give the reference's update (tests keep them together). */
 int msckf_hip_set_compression(msckf_hip_handle h, int route);
+/* Covariance update of measurementUpdate (msckf.h:1368-1418): 0 (default) the square-root gain form -- S = L L^T,
+ * W = P T_H^T L^-T, dx = W L^-1 r_n, P <- P - W W^T (= (I - K T_H) P, written symmetrically); 1 the reference's literal
+ * Joseph sequence K, (I - K T_H) P (I - K T_H)^T + K R_n K^T, symmetrise.  Identical in exact arithmetic, equal to
+ * rounding in the tests. */
+int msckf_hip_set_covariance_update(msckf_hip_handle h, int form);
 
 #ifdef __cplusplus
 }

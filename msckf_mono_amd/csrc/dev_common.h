@@ -71,6 +71,8 @@ struct Dev {
   //   Lam    [B][ldR][ldR]      f64   sum B^T B, upper 64x64 tiles
   int compress;   // 0 Householder TSQR, 1 information form (k_chol_T), 2 information form with the blocked Cholesky (k_chol_blk)
   double* trk_B; S* trk_rw; signed char* trk_inv; double* Dg; double* Lam;
+  // covariance update: 0 = square-root gain form P <- P - W W^T (default), 1 = the reference's Joseph sequence
+  int joseph;
   // Kalman work matrices
   S* PHt; S* Smat; S* Linv; S* W; S* K; S* A; S* AP; S* X; S* dx;
   // prune

@@ -6,18 +6,24 @@
 // zero, msckf.h:949) and R_n = sigma^2 I.
 //   PHt = P[:,15:] T^T                      (D x n)
 //   S   = T PHt[15:,:] + sigma^2 I          (n x n)     :1369
-//   K   = PHt S^-1 by a register-resident Cholesky S = L L^T that carries [PHt ; I] along:
-//         [W ; E] = [PHt L^-T ; L^-T],  K = W E^T          (the reference calls .inverse(), :1370; S is SPD)
-//   dx  = K r_n, injected into the IMU and every camera state   :1373-1391
-//   A   = I - K T_H ;  P <- sym(A P A^T + sigma^2 K K^T)         :1394-1403
-// Every product is a batched 64x64-tile GEMM, LDS-staged: on the matrix cores (v_mfma_f32_32x32x2_f32) in
-// float (zero k-tiles of the triangular operands skipped, S / X symmetric, P <- sym(X) fused into the X product),
-// 4x4 VALU micro-tiles in double; trajectories with no gated-in rows are skipped.
+// Default ("square-root gain") form -- the gain K = P T_H^T S^-1 (:1370, explicit .inverse()) is never formed:
+//   S = L L^T by a register-resident Cholesky that carries [PHt ; r_n^T] along as appended rows, which the same
+//   rank-1 eliminations turn into [W ; z^T] = [PHt L^-T ; (L^-1 r_n)^T]
+//   dx = K r_n = W z, injected into the IMU and every camera state          :1373-1391
+//   P <- P - W W^T  ( = (I - K T_H) P, BASELINE.json north_star's form; with K from this factorization it equals
+//        the Joseph form (I - K T_H) P (I - K T_H)^T + K R_n K^T of :1394-1403 identically in exact arithmetic:
+//        K PHt^T = K S K^T = W W^T), one symmetric rank-n downdate written to both triangles from the same values,
+//        so the symmetrisation of :1401-1403 is implicit
+// Joseph form (msckf_hip_set_covariance_update(h, 1); the reference's literal sequence, kept for A/B):
+//   [W ; E] = [PHt L^-T ; L^-T], K = W E^T, A = I - K T_H, P <- sym(A P A^T + sigma^2 K K^T)
+// Every product is a batched 64x64-tile GEMM, LDS-staged, on the matrix cores: v_mfma_f32_32x32x2_f32 in float
+// (zero k-tiles of the triangular operands skipped, symmetric results computed once), v_mfma_f64_16x16x4_f64 in
+// double; trajectories with no gated-in rows are skipped.
 #include "dev_common.h"
 
 namespace msckf {
 
-enum { OP_PHT = 0, OP_S, OP_W, OP_K, OP_A, OP_AP, OP_X, OP_KE };
+enum { OP_PHT = 0, OP_S, OP_W, OP_K, OP_A, OP_AP, OP_X, OP_KE, OP_DOWN };
 
 template <class S>
 struct KView {
@@ -45,6 +51,7 @@ template <class S, int OP> __device__ __forceinline__ void op_dims(const KView<S
   else if (OP == OP_W || OP == OP_K || OP == OP_KE) { M = v.D; N = v.n; K = v.n; }
   else if (OP == OP_A) { M = v.D; N = v.D; K = v.n; }
   else if (OP == OP_AP) { M = v.D; N = v.D; K = v.D; }
+  else if (OP == OP_DOWN) { M = v.D; N = v.D; K = v.n; }
   else { M = v.D; N = v.D; K = v.D + v.n; }
 }
 template <class S, int OP> __device__ __forceinline__ S op_a(const KView<S>& v, int i, int k) {
@@ -54,6 +61,7 @@ template <class S, int OP> __device__ __forceinline__ S op_a(const KView<S>& v, 
   if (OP == OP_K || OP == OP_KE) return v.W[(long)k * v.ld + i];
   if (OP == OP_A) return v.K[(long)k * v.ld + i];
   if (OP == OP_AP) return v.A[(long)k * v.ld + i];
+  if (OP == OP_DOWN) return v.W[(long)k * v.ld + i];
   return k < v.D ? v.AP[(long)k * v.ld + i] : v.sig2 * v.K[(long)(k - v.D) * v.ld + i];
 }
 template <class S, int OP> __device__ __forceinline__ S op_b(const KView<S>& v, int k, int j) {
@@ -64,6 +72,7 @@ template <class S, int OP> __device__ __forceinline__ S op_b(const KView<S>& v, 
   if (OP == OP_KE) return k >= j ? v.Linv[(long)k * v.ldn + j] : S(0);            // E(j,k), E = L^-T upper triangular
   if (OP == OP_A) return (j >= 15 && j - 15 >= k) ? v.R0[(long)k * v.ldR + (j - 15)] : S(0);   // T_H[k][j]
   if (OP == OP_AP) return v.P[(long)j * v.ld + k];
+  if (OP == OP_DOWN) return v.W[(long)k * v.ld + j];
   return k < v.D ? v.A[(long)k * v.ld + j] : v.K[(long)(k - v.D) * v.ld + j];
 }
 template <class S, int OP> __device__ __forceinline__ void op_store(const KView<S>& v, int i, int j, S acc) {
@@ -73,6 +82,11 @@ template <class S, int OP> __device__ __forceinline__ void op_store(const KView<
   else if (OP == OP_K || OP == OP_KE) v.K[(long)j * v.ld + i] = acc;
   else if (OP == OP_A) v.A[(long)j * v.ld + i] = (i == j ? S(1) : S(0)) - acc;
   else if (OP == OP_AP) v.AP[(long)j * v.ld + i] = acc;
+  else if (OP == OP_DOWN) {   // P <- P - W W^T, called for i <= j only: both triangles get the same value
+    S* Pw = const_cast<S*>(v.P);
+    const S val = Pw[(long)j * v.ld + i] - acc;
+    Pw[(long)j * v.ld + i] = val; Pw[(long)i * v.ld + j] = val;
+  }
   else v.X[(long)j * v.ld + i] = acc;
 }
 
@@ -135,7 +149,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Operand-B staging order per product: true when the B element (k, j) is contiguous in j (then lanes run along j),
 // false when it is contiguous in k (lanes run along k) -- keeps the global loads of the tile coalesced.
-template <int OP> struct BContigJ { static constexpr bool value = (OP == OP_KE || OP == OP_A || OP == OP_X || OP == OP_W); };
+template <int OP> struct BContigJ { static constexpr bool value = (OP == OP_KE || OP == OP_A || OP == OP_X || OP == OP_W || OP == OP_DOWN); };
 
 // Operand access split into {address, validity, scale} so that the prefetch is branch-free: every load of a
 // k-tile is issued unconditionally from a clamped address (all in flight together -- a conditional per element makes
@@ -147,6 +161,7 @@ template <int OP> __device__ __forceinline__ const float* opa_ptr(const KView<fl
   if (OP == OP_K || OP == OP_KE) return v.W + (long)k * v.ld + i;
   if (OP == OP_A) return v.K + (long)k * v.ld + i;
   if (OP == OP_AP) return v.A + (long)k * v.ld + i;
+  if (OP == OP_DOWN) return v.W + (long)k * v.ld + i;
   return k < v.D ? v.AP + (long)k * v.ld + i : v.K + (long)(k - v.D) * v.ld + i;
 }
 template <int OP> __device__ __forceinline__ float opa_fix(const KView<float>& v, int i, int k, float x) {
@@ -162,6 +177,7 @@ template <int OP> __device__ __forceinline__ const float* opb_ptr(const KView<fl
   if (OP == OP_KE) return v.Linv + (long)k * v.ldn + j;
   if (OP == OP_A) return v.R0 + (long)k * v.ldR + (j >= 15 ? j - 15 : 0);
   if (OP == OP_AP) return v.P + (long)j * v.ld + k;
+  if (OP == OP_DOWN) return v.W + (long)k * v.ld + j;
   return k < v.D ? v.A + (long)k * v.ld + j : v.K + (long)(k - v.D) * v.ld + j;
 }
 template <int OP> __device__ __forceinline__ float opb_fix(const KView<float>& v, int k, int j, float x) {
@@ -180,7 +196,7 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0) {
   using S = float;
   const int b = b0 + blockIdx.z;
   if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
-  if (OP == OP_X && blockIdx.x > blockIdx.y) return;   // X is symmetric: the epilogue mirrors the upper tiles into P
+  if ((OP == OP_X || OP == OP_DOWN) && blockIdx.x > blockIdx.y) return;   // symmetric: the epilogue mirrors the upper tiles into P
   if (OP == OP_S && blockIdx.x < blockIdx.y) return;   // S is symmetric: the gain solve reads its lower triangle
   const KView<S> v = make_view(d, b);
   int M, N, K;
@@ -274,8 +290,76 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int gj = j0 + 32 * wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (gi < M && gj < N) op_store<S, OP>(v, gi, gj, acc[r]);
+    if (OP == OP_DOWN) { if (gi <= gj && gj < N) op_store<S, OP>(v, gi, gj, acc[r]); }   // upper triangle of diagonal tiles, mirrored
+    else if (gi < M && gj < N) op_store<S, OP>(v, gi, gj, acc[r]);
   }
+}
+
+// f64 tile GEMM on the matrix cores: v_mfma_f64_16x16x4_f64, 64 x 64 output tile per workgroup, each wavefront a
+// 32 x 32 sub-tile as 2 x 2 accumulators.  As in the f32 kernel the product is formed transposed (MFMA "A" operand =
+// B-tile) so that the accumulator's lane index runs along the output row index i and the stores are coalesced.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+template <int OP>
+__global__ __launch_bounds__(256) void k_gemm_mfma64(Dev<double> d, int b0) {
+  using S = double;
+  const int b = b0 + blockIdx.z;
+  if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
+  if (OP == OP_DOWN && blockIdx.x > blockIdx.y) return;   // symmetric downdate: upper tiles, mirrored by the store
+  if (OP == OP_S && blockIdx.x < blockIdx.y) return;       // (X is needed in full: k_symmetrize averages X and X^T)
+  const KView<S> v = make_view(d, b);
+  int M, N, K;
+  op_dims<S, OP>(v, M, N, K);
+  const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+  if (i0 >= M || j0 >= N) return;
+  constexpr int KT = 16;
+  __shared__ S sA[KT][65];
+  __shared__ S sB[KT][65];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w & 1, wn = w >> 1;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc[a][c] = f64x4{0.0, 0.0, 0.0, 0.0};
+  int kbeg = 0;
+  if (OP == OP_PHT || OP == OP_KE) kbeg = (j0 / KT) * KT;
+  if (OP == OP_S) kbeg = (i0 / KT) * KT;
+  if (OP == OP_A) K = min(K, max(j0 + 64 - 15, 0));
+  for (int k0 = kbeg; k0 < K; k0 += KT) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ii = tid & 63, kk = (tid >> 6) + 4 * q;
+      const int gi = i0 + ii, gk = k0 + kk;
+      sA[kk][ii] = (gi < M && gk < K) ? op_a<S, OP>(v, gi, gk) : S(0);
+      int kb, jj;
+      if (BContigJ<OP>::value) { jj = tid & 63; kb = (tid >> 6) + 4 * q; }
+      else { kb = tid & 15; jj = (tid >> 4) + 16 * q; }
+      const int gj = j0 + jj, gk2 = k0 + kb;
+      sB[kb][jj] = (gj < N && gk2 < K) ? op_b<S, OP>(v, gk2, gj) : S(0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k4 = 0; k4 < KT; k4 += 4) {
+      const int kr = k4 + (lane >> 4), cc = lane & 15;
+      const S bj0 = sB[kr][32 * wn + cc], bj1 = sB[kr][32 * wn + 16 + cc];   // MFMA A operand: rows of the result = j
+      const S ai0 = sA[kr][32 * wm + cc], ai1 = sA[kr][32 * wm + 16 + cc];   // MFMA B operand: cols of the result = i
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bj0, ai0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(bj0, ai1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(bj1, ai0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(bj1, ai1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // acc[jb][ib][r] = C(i = i0 + 32 wm + 16 ib + (lane & 15), j = j0 + 32 wn + 16 jb + (lane >> 4) + 4 r)
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gi = i0 + 32 * wm + 16 * ib + (lane & 15), gj = j0 + 32 * wn + 16 * jb + (lane >> 4) + 4 * r;
+        if (OP == OP_DOWN) { if (gi <= gj && gj < N) op_store<S, OP>(v, gi, gj, acc[jb][ib][r]); }
+        else if (gi < M && gj < N) op_store<S, OP>(v, gi, gj, acc[jb][ib][r]);
+      }
 }
 
 // Cholesky S = L L^T and in-place triangular inverse, one workgroup per trajectory.  The matrix is staged
@@ -565,6 +649,150 @@ __global__ __launch_bounds__(256) void k_gain_split(Dev<S> d, int b0) {
   }
 }
 
+// Square-root gain: NPART workgroups per trajectory.  Every workgroup factors S = L L^T in registers (redundantly -- the
+// chip has idle CUs at these batch sizes) and carries 1/NPART of the rows of PHt plus the row r_n^T through the same
+// rank-1 eliminations, which turns them into W = PHt L^-T and z^T = (L^-1 r_n)^T.  Then dx = K r_n = W z for the
+// workgroup's rows, in a fixed summation order.  Neither S^-1 (msckf.h:1370) nor K is formed.
+template <class S, int NBN, int NPART>
+__global__ __launch_bounds__(256) void k_gain_w(Dev<S> d, int b0) {
+  constexpr int G = 16, NBD = NBN + 1, NBQ = (NBD + NPART - 1) / NPART, NBW = NBQ + 1;
+  const int b = b0 + blockIdx.y, part = blockIdx.x, tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
+  const KView<S> v = make_view(d, b);
+  const int n = v.n, D = v.D;
+  __shared__ S sCol[2][G * NBN];
+  __shared__ S sW[2][G * NBW];
+  S A[NBN][NBN], Wm[NBW][NBN];
+#pragma unroll
+  for (int a = 0; a < NBN; ++a)
+#pragma unroll
+    for (int bb = 0; bb < NBN; ++bb) {
+      const int i = G * a + tx, j = G * bb + ty;
+      A[a][bb] = (a >= bb && i < n && j < n) ? v.Sm[(long)j * v.ldn + i] : S(0);
+    }
+#pragma unroll
+  for (int a = 0; a < NBW; ++a) {
+    const int ab = part * NBQ + a;            // row block of PHt; a == NBQ: the block whose row 0 is r_n^T
+#pragma unroll
+    for (int bb = 0; bb < NBN; ++bb) {
+      const int j = G * bb + ty;
+      S val = 0;
+      if (a < NBQ) { const int i = G * ab + tx; if (ab < NBD && i < D && j < n) val = v.PHt[(long)j * v.ld + i]; }
+      else if (tx == 0 && j < n) val = v.R0[(long)j * v.ldR + n];
+      Wm[a][bb] = val;
+    }
+  }
+  int buf = 0;
+#pragma unroll
+  for (int kb = 0; kb < NBN; ++kb) {
+    const int kk_hi = min(G, n - G * kb);
+    for (int kk = 0; kk < kk_hi; ++kk) {
+      const int k = G * kb + kk;
+      if (ty == kk) {
+#pragma unroll
+        for (int a = kb; a < NBN; ++a) sCol[buf][G * a + tx] = A[a][kb];
+#pragma unroll
+        for (int a = 0; a < NBW; ++a) sW[buf][G * a + tx] = Wm[a][kb];
+      }
+      __syncthreads();
+      const S dkk = sCol[buf][k];
+      const S dpos = dkk > S(0) ? dkk : Lim<S>::tiny();
+      const S dinv = fast_rsqrt(dpos);
+      const S dd = dpos * dinv;
+      S li[NBN], lj[NBN], wi[NBW];
+#pragma unroll
+      for (int a = kb; a < NBN; ++a) li[a] = (a > kb || tx > kk) ? sCol[buf][G * a + tx] * dinv : S(0);
+#pragma unroll
+      for (int bb = kb; bb < NBN; ++bb) lj[bb] = (bb > kb || ty > kk) ? sCol[buf][G * bb + ty] * dinv : S(0);
+#pragma unroll
+      for (int a = 0; a < NBW; ++a) wi[a] = sW[buf][G * a + tx] * dinv;
+#pragma unroll
+      for (int a = kb; a < NBN; ++a)
+#pragma unroll
+        for (int bb = kb; bb <= a; ++bb) A[a][bb] -= li[a] * lj[bb];
+#pragma unroll
+      for (int a = 0; a < NBW; ++a)
+#pragma unroll
+        for (int bb = kb; bb < NBN; ++bb) Wm[a][bb] -= wi[a] * lj[bb];
+      if (ty == kk) {
+#pragma unroll
+        for (int a = kb; a < NBN; ++a) {
+          if (a > kb || tx > kk) A[a][kb] = li[a];
+          else if (a == kb && tx == kk) A[a][kb] = dd;
+        }
+#pragma unroll
+        for (int a = 0; a < NBW; ++a) Wm[a][kb] = wi[a];
+      }
+      buf ^= 1;
+    }
+  }
+  // W rows of this part
+#pragma unroll
+  for (int a = 0; a < NBQ; ++a) {
+    const int ab = part * NBQ + a, i = G * ab + tx;
+#pragma unroll
+    for (int bb = 0; bb < NBN; ++bb) {
+      const int j = G * bb + ty;
+      if (ab < NBD && i < D && j < n) v.W[(long)j * v.ld + i] = Wm[a][bb];
+    }
+  }
+  // z lives in row 0 of the last block: thread (0, ty) holds z[G bb + ty]
+  __shared__ S sZ[G * NBN];
+  __shared__ S sDx[G][G * NBQ + 1];
+  __syncthreads();
+  if (tx == 0) {
+#pragma unroll
+    for (int bb = 0; bb < NBN; ++bb) sZ[G * bb + ty] = Wm[NBQ][bb];
+  }
+  __syncthreads();
+  {
+    S zz[NBN];
+#pragma unroll
+    for (int bb = 0; bb < NBN; ++bb) zz[bb] = sZ[G * bb + ty];
+#pragma unroll
+    for (int a = 0; a < NBQ; ++a) {
+      S p = 0;
+#pragma unroll
+      for (int bb = 0; bb < NBN; ++bb) p += Wm[a][bb] * zz[bb];
+      sDx[ty][G * a + tx] = p;
+    }
+    __syncthreads();
+    for (int e = tid; e < G * NBQ; e += 256) {
+      const int i = G * NBQ * part + e;
+      if (i >= D) continue;
+      S sm = 0;
+#pragma unroll
+      for (int y = 0; y < G; ++y) sm += sDx[y][e];
+      d.dx[(long)b * d.ld + i] = sm;
+    }
+  }
+}
+
+// dx = W (L^-1 r_n) for the windows whose S does not fit the register grid (k_chol_inv left L^-1 in Linv, OP_W left
+// W = PHt L^-T); one workgroup per trajectory.
+template <class S>
+__global__ __launch_bounds__(256) void k_dx_w(Dev<S> d, int b0) {
+  const int b = b0 + blockIdx.x, tid = threadIdx.x;
+  if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
+  const KView<S> v = make_view(d, b);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  S* srn = reinterpret_cast<S*>(smem_raw);
+  S* sz = srn + v.ldn;
+  for (int a = tid; a < v.n; a += 256) srn[a] = v.R0[(long)a * v.ldR + v.n];
+  __syncthreads();
+  for (int j = tid; j < v.n; j += 256) {
+    S s = 0;
+    for (int k = 0; k <= j; ++k) s += v.Linv[(long)k * v.ldn + j] * srn[k];     // Linv(j, k), lower triangular
+    sz[j] = s;
+  }
+  __syncthreads();
+  for (int i = tid; i < v.D; i += 256) {
+    S s = 0;
+    for (int j = 0; j < v.n; ++j) s += v.W[(long)j * v.ld + i] * sz[j];
+    d.dx[(long)b * d.ld + i] = s;
+  }
+}
+
 // dx = K r_n and state injection (msckf.h:1373-1391); one workgroup per trajectory.
 template <class S, bool HAVE_DX>
 __global__ __launch_bounds__(256) void k_inject(Dev<S> d, int b0) {
@@ -638,11 +866,19 @@ static void gemm_launch(const Dev<float>& d, int b0, int nb, int Mmax, int Nmax,
 }
 template <int OP>
 static void gemm_launch(const Dev<double>& d, int b0, int nb, int Mmax, int Nmax, hipStream_t st) {
-  hipLaunchKernelGGL((k_gemm<double, OP>), dim3((Mmax + 63) / 64, (Nmax + 63) / 64, nb), dim3(256), 0, st, d, b0);
+  hipLaunchKernelGGL((k_gemm_mfma64<OP>), dim3((Mmax + 63) / 64, (Nmax + 63) / 64, nb), dim3(256), 0, st, d, b0);
 }
 template <class S, int OP>
 static void gemm(const Dev<S>& d, int b0, int nb, int Mmax, int Nmax, hipStream_t st) {
   gemm_launch<OP>(d, b0, nb, Mmax, Nmax, st);
+}
+
+template <class S, int NBN>
+static void launch_gain_w(const Dev<S>& d, int b0, int nb, hipStream_t st) {
+  // more workgroups per trajectory while the batch leaves CUs idle (the Cholesky of S is redone by each of them)
+  if (nb <= 64) hipLaunchKernelGGL((k_gain_w<S, NBN, 8>), dim3(8, nb), dim3(256), 0, st, d, b0);
+  else if (nb <= 128) hipLaunchKernelGGL((k_gain_w<S, NBN, 4>), dim3(4, nb), dim3(256), 0, st, d, b0);
+  else hipLaunchKernelGGL((k_gain_w<S, NBN, 2>), dim3(2, nb), dim3(256), 0, st, d, b0);
 }
 
 template <class S>
@@ -651,10 +887,30 @@ void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   const int n = d.n6cap, D = 15 + n;
   gemm<S, OP_PHT>(d, b0, nb, D, n, st);
   gemm<S, OP_S>(d, b0, nb, n, n, st);
-  // K = PHt S^-1: register-resident factor/solve when the window fits the 16x16 thread grid, otherwise
-  // Cholesky + triangular inverse (LDS or global) followed by two GEMMs.
   const int nbn = (n + 15) / 16;
   const int nbn_max = sizeof(S) == 4 ? 12 : 8;
+  const size_t lds_chol = (size_t)n * (n + 1) * sizeof(S);
+  auto chol_inv = [&]() {
+    if (lds_chol <= 150 * 1024) hipLaunchKernelGGL((k_chol_inv<S, true>), dim3(nb), dim3(256), lds_chol, st, d, b0);
+    else hipLaunchKernelGGL((k_chol_inv<S, false>), dim3(nb), dim3(256), 0, st, d, b0);
+  };
+  if (!d.joseph) {
+    // ---- square-root gain form: W = PHt L^-T, dx = W L^-1 r_n, P <- P - W W^T
+    if (nbn <= 4) launch_gain_w<S, 4>(d, b0, nb, st);
+    else if (nbn <= 8) launch_gain_w<S, 8>(d, b0, nb, st);
+    else if (nbn <= nbn_max) launch_gain_w<S, (sizeof(S) == 4 ? 12 : 8)>(d, b0, nb, st);
+    else {
+      chol_inv();
+      gemm<S, OP_W>(d, b0, nb, D, n, st);
+      hipLaunchKernelGGL((k_dx_w<S>), dim3(nb), dim3(256), (size_t)2 * d.n6cap * sizeof(S), st, d, b0);
+    }
+    hipLaunchKernelGGL((k_inject<S, true>), dim3(nb), dim3(256), (size_t)d.ld * sizeof(S), st, d, b0);
+    gemm<S, OP_DOWN>(d, b0, nb, D, D, st);
+    return;
+  }
+  // ---- Joseph form (the reference's literal sequence)
+  // K = PHt S^-1: register-resident factor/solve when the window fits the 16x16 thread grid, otherwise
+  // Cholesky + triangular inverse (LDS or global) followed by two GEMMs.
   bool split = false;
   if (nbn <= nbn_max) {
     if (nbn <= 4) hipLaunchKernelGGL((k_gain<S, 4>), dim3(nb), dim3(256), 0, st, d, b0);
@@ -667,12 +923,7 @@ void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st) {
     }
     else hipLaunchKernelGGL((k_gain<S, 12>), dim3(nb), dim3(256), 0, st, d, b0);
   } else {
-    const size_t lds = (size_t)n * (n + 1) * sizeof(S);
-    if (lds <= 150 * 1024) {
-      hipLaunchKernelGGL((k_chol_inv<S, true>), dim3(nb), dim3(256), lds, st, d, b0);
-    } else {
-      hipLaunchKernelGGL((k_chol_inv<S, false>), dim3(nb), dim3(256), 0, st, d, b0);
-    }
+    chol_inv();
     gemm<S, OP_W>(d, b0, nb, D, n, st);
     gemm<S, OP_K>(d, b0, nb, D, n, st);
   }

@@ -86,6 +86,7 @@ struct BatchBase {
   virtual int set_streams(int n) = 0;
   virtual int set_gate_early(int on) = 0;
   virtual int set_compression(int route) = 0;
+  virtual int set_cov_update(int form) = 0;
   virtual int clear_stats(int b) = 0;
 };
 
@@ -164,7 +165,7 @@ struct Batch : BatchBase {
     rc |= dalloc(&d.PHt, Bz * dn); rc |= dalloc(&d.Smat, Bz * nl); rc |= dalloc(&d.Linv, Bz * nl); rc |= dalloc(&d.W, Bz * dn);
     rc |= dalloc(&d.K, Bz * dn); rc |= dalloc(&d.A, Bz * pl); rc |= dalloc(&d.AP, Bz * pl); rc |= dalloc(&d.X, Bz * pl); rc |= dalloc(&d.dx, Bz * d.ld);
     rc |= dalloc(&d.keep, Bz * n_cap); rc |= dalloc(&d.nkeep, Bz);
-    rc |= dalloc(&d_pfin, TF * 4); d.trk_pfin = d_pfin; d.mode = 0;
+    rc |= dalloc(&d_pfin, TF * 4); d.trk_pfin = d_pfin; d.mode = 0; d.joseph = 0;
     rd_cap = 64;
     rc |= dalloc(&d_rd, Bz * rd_cap * RD_STRIDE);
     rc |= dalloc(&wl_n, Bz); rc |= dalloc(&wl_M, TF); rc |= dalloc(&wl_slots, TF * m_cap); rc |= dalloc(&wl_obs, TF * m_cap * 2);
@@ -607,6 +608,11 @@ struct Batch : BatchBase {
     return 0;
   }
   int set_gate_early(int on) override { d.gate_early = on ? 1 : 0; return 0; }
+  int set_cov_update(int form) override {
+    if (form != 0 && form != 1) return fail(-EINVAL, "form: 0 square-root gain (P - W W^T), 1 Joseph");
+    d.joseph = form;
+    return 0;
+  }
   int set_compression(int route) override {
     if (route < -1 || route > 2) return fail(-EINVAL, "route: -1 default, 0 Householder TSQR, 1 information form, 2 information form with the blocked Cholesky");
     if (route >= 1 && !d.trk_B) return fail(-ENOTSUP, "information form not available for this window size (6 n_cap + 1 > 192)");
@@ -1157,6 +1163,7 @@ int msckf_hip_sync(msckf_hip_handle h) { return H(h)->sync(); }
 int msckf_hip_profile_enable(msckf_hip_handle h, int on) { return H(h)->prof_enable(on); }
 int msckf_hip_profile_read(msckf_hip_handle h, double* ms7, int* count7) { return H(h)->prof_read(ms7, count7); }
 int msckf_hip_set_streams(msckf_hip_handle h, int n) { return H(h)->set_streams(n); }
+int msckf_hip_set_covariance_update(msckf_hip_handle h, int form) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_cov_update(form); }
 int msckf_hip_set_compression(msckf_hip_handle h, int route) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_compression(route); }
 int msckf_hip_set_gate_early_accept(msckf_hip_handle h, int on) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_gate_early(on); }
 

@@ -171,7 +171,7 @@ def test_low_parallax_double_both_routes_vs_oracle(capi, po):
         bt.close()
     # condition number of the stack (numpy twin on the same scenario, free-running for the first updates)
     tw = Capture(tr.cfg, tr.imu0)
-    for k in range(8):
+    for k in range(12):
         for rd in tr.imu_for_frame(k):
             tw.propagate(rd)
         tw.augment(k)

@@ -230,6 +230,32 @@ def test_information_form_equals_householder_route(capi, prec):
     assert res[1][3]["r_rows"] < res[0][3]["r_rows"] == 6 * N            # gauge directions skipped
 
 
+@pytest.mark.parametrize("prec,N,F", [("f64", 8, 24), ("f64", 26, 60), ("f32", 12, 40), ("f32", 30, 120)])
+def test_square_root_gain_form_equals_joseph_form(capi, prec, N, F):
+    """Covariance update of measurementUpdate (msckf.h:1368-1418): the default square-root gain form (W = P T_H^T L^-T,
+    P <- P - W W^T, dx = W L^-1 r_n; no gain matrix, no S^-1) against the reference's literal Joseph sequence, both on the
+    device, free-running over the same frames: equal to rounding.  Window sizes cover the register-resident solve
+    (n <= 128 double / 192 float) and the LDS Cholesky + f64 matrix-core path (26 cameras in double)."""
+    nf = N + 8
+    tr = sc.Trajectory(2, 9, N, F, nf)
+    cd = capi.F64 if prec == "f64" else capi.F32
+    res = {}
+    for form in (0, 1):
+        bt = capi.Batch(1, N, F, max(N, 4), cd)
+        bt.set_covariance_update(form)
+        bt.initialize(0, tr.cfg, tr.imu0)
+        for k in range(nf):
+            H.device_frame(bt, 0, tr, k, N)
+        P = bt.covariance(0)
+        assert np.array_equal(P, P.T)
+        res[form] = (bt.imu_state(0), bt.cam_states(0)[0], P, bt.last_stats(0))
+        bt.close()
+    e = H.state_errors(res[0][0], res[1][0], res[0][1], res[1][1], res[0][2], res[1][2])
+    assert H.worst(e) < (1e-9 if prec == "f64" else 1e-3), e           # float: two free-running float filters, ~40 frames
+    strip = lambda st: {k: v for k, v in st.items() if k != "r_rows"}   # r_rows: count of pivots above a rounding-level tolerance
+    assert strip(res[0][3]) == strip(res[1][3]) and res[0][3]["n_passed"] > 0
+
+
 def test_resident_scenario_equals_per_call(capi):
     N, F, nf, B = 8, 16, 13, 3
     trs = [sc.Trajectory(2, 60 + b, N, F, nf) for b in range(B)]
