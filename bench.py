@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--streams", type=int, default=2, help="HIP streams for the timed region (halves of the batch run concurrently)")
     ap.add_argument("--no-early-accept-pass", action="store_true", help="skip the extra measurement with the gate early accept (profiling runs)")
+    ap.add_argument("--compression", type=int, default=-1, help="msckf_hip_set_compression route (A/B runs; -1 = library default)")
+    ap.add_argument("--cov-form", type=int, default=0, help="msckf_hip_set_covariance_update form (A/B runs; 0 = library default)")
     ap.add_argument("--gate-early-accept", action="store_true",
                     help="exact early accept of the chi-square gate (msckf_hip_set_gate_early_accept); OFF for the headline number")
     args = ap.parse_args()
@@ -108,6 +110,9 @@ def main():
         bt.sync()
 
     bt.set_streams(args.streams)
+    if args.compression >= 0:
+        bt.set_compression(args.compression)
+    bt.set_covariance_update(args.cov_form)
     bt.set_gate_early_accept(args.gate_early_accept)
     bt.run_frames(0, fill + W)       # window fill + warm-up (untimed)
     barrier()

@@ -69,9 +69,10 @@ struct Dev {
   //   trk_inv[B*f_cap][n_cap]   i8    observation index of camera slot s in the track, -1 = not observed
   //   Dg     [B][n_cap][28]     f64   per camera slot: upper triangle of sum h^T h (21) and sum h^T r (6)
   //   Lam    [B][ldR][ldR]      f64   sum B^T B, upper 64x64 tiles
-  int compress;   // 0 Householder TSQR, 1 information form (k_chol_T), 2 information form with the blocked Cholesky (k_chol_blk)
+  int compress;   // 0 Householder TSQR; information form with 1 k_chol_T, 2 k_chol_blk, 3 k_chol_mfma (kernels_chol.hip)
   double* trk_B; S* trk_rw; signed char* trk_inv; double* Dg; double* Lam;
-  // covariance update: 0 = square-root gain form P <- P - W W^T (default), 1 = the reference's Joseph sequence
+  // covariance update: 0 = square-root gain form P <- P - W W^T, S factored by the blocked matrix-core Cholesky (float) /
+  // the register-resident one (double); 1 = the reference's Joseph sequence; 2 = square-root gain form, register-resident solve
   int joseph;
   // Kalman work matrices
   S* PHt; S* Smat; S* Linv; S* W; S* K; S* A; S* AP; S* X; S* dx;
@@ -251,6 +252,26 @@ template <class S> struct Lim;
 template <> struct Lim<float> { static __device__ __forceinline__ float tiny() { return 1.17549435e-38f; } };
 template <> struct Lim<double> { static __device__ __forceinline__ double tiny() { return 2.2250738585072014e-308; } };
 
+// Block-diagonal part of Lam^ = [H_o | r_o]^T [H_o | r_o] at (I, J): sum h^T h inside a camera's 6 x 6 block, sum h^T r
+// in row/column n, zero elsewhere (Dg: per camera slot 21 upper-triangle entries + 6 entries of h^T r).
+__device__ __forceinline__ double lam_diag_term(const double* Dg, int n, int n_cap, int I, int J) {
+  const int hi = I >= J ? I : J, lo = I >= J ? J : I;
+  const bool isy = hi == n && lo < n, isd = hi < n && (hi / 6 == lo / 6);
+  const int a6 = lo % 6, c6 = hi % 6;
+  const int idx = isy ? 21 + a6 : (isd ? a6 * 6 - a6 * (a6 - 1) / 2 + (c6 - a6) : 0);
+  const double dg = Dg[min(lo / 6, n_cap - 1) * DG_STRIDE + idx];
+  return (isy || isd) ? dg : 0.0;
+}
+// Lam^(I, J) as k_gram left it (block-diagonal part minus sum B^T B, both triangles stored): lower triangle incl. row n
+// (= H_o^T r_o); rows beyond n and the (n, n) corner read as zero.  Branch-free: the load is issued unconditionally from
+// a clamped address and masked afterwards, so that a thread's loads are all in flight together.
+__device__ __forceinline__ double lam_hat(const double* Lam, const double* /*Dg*/, int ldL, int n, int /*n_cap*/, int I, int J) {
+  const int hi = I >= J ? I : J, lo = I >= J ? J : I;
+  const bool ok = hi <= n && lo < n;
+  const double lv = Lam[(long)min(hi, ldL - 1) * ldL + min(lo, ldL - 1)];
+  return ok ? lv : 0.0;
+}
+
 // ---------------------------------------------------------------- launch entry points (one per .hip file)
 template <class S> void launch_propagate(const Dev<S>& d, int b0, int nb, const S* readings, long rd_stride, int K, hipStream_t st);
 template <class S> void launch_augment(const Dev<S>& d, int b0, int nb, hipStream_t st);
@@ -262,6 +283,10 @@ template <class S> void launch_compress(const Dev<S>& d, int b0, int nb, hipStre
 // phase: 0 = both, 1 = Gram accumulation only, 2 = Cholesky only
 template <class S> void launch_gram(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase);
 template <class S> void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st);
+// blocked matrix-core Cholesky (kernels_chol.hip): [T | r_n] = chol(Lam^) for the information form; S = L L^T with
+// [PHt ; r_n^T] appended (W, dx) for the float Kalman stage.  Return false when the window does not fit the kernel.
+template <class S> bool launch_chol_gram(const Dev<S>& d, int b0, int nb, hipStream_t st);
+bool launch_chol_gain(const Dev<float>& d, int b0, int nb, hipStream_t st);
 size_t feature_lds_bytes(int m_cap, size_t scalar);
 // one-time per-device setup of each kernel file (constant tables, dynamic-LDS limits); msckf_hip_create calls them
 void feature_device_setup();

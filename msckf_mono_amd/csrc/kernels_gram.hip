@@ -179,7 +179,10 @@ __global__ __launch_bounds__(256) void k_gram(Dev<S> d, int b0, int npairs, int 
     if (kc + 3 * GK < KT && !(dbg & 2)) fetch(r1, kc + 3 * GK);
     if (!(dbg & 4)) compute();
   }
+  // epilogue: Lam^ = (block-diagonal part, reduced by the launch that precedes this one on the stream) - sum B^T B, written
+  // to both triangles so that the Cholesky kernels read plain rows
   double* Lam = d.Lam + (long)b * ldL * ldL;
+  const double* Dgb = d.Dg + (long)b * d.n_cap * DG_STRIDE;
 #pragma unroll
   for (int tj = 0; tj < GT_MAX; ++tj) {
     if (tj < ti || tj >= nt) continue;
@@ -191,28 +194,11 @@ __global__ __launch_bounds__(256) void k_gram(Dev<S> d, int b0, int npairs, int 
         for (int r = 0; r < 4; ++r) {
           const int i = 64 * ti + wi * 32 + ib * 16 + (lane >> 4) + 4 * r;
           const int j = 64 * tj + wj * 32 + jb * 16 + (lane & 15);
-          Lam[(long)i * ldL + j] = acc[tj][ib][jb][r];
-          Lam[(long)j * ldL + i] = acc[tj][ib][jb][r];   // mirrored copy: k_chol_blk reads the lower triangle row-wise
+          const double val = lam_diag_term(Dgb, n, d.n_cap, i, j) - acc[tj][ib][jb][r];
+          Lam[(long)i * ldL + j] = val;
+          Lam[(long)j * ldL + i] = val;
         }
   }
-}
-
-// Lam^(I, J) = (block-diagonal part) - (sum B^T B)(I, J) for the lower triangle incl. row n (= H_o^T r_o); rows beyond
-// n and the (n, n) corner are not needed and read as zero.  Branch-free: both loads are issued unconditionally from
-// clamped addresses and masked afterwards, so that a thread's loads are all in flight together (with a conditional
-// per element the compiler drains vmcnt between them and the ~80 loads of a thread run back to back).
-// Lam holds both triangles; (hi, lo) addressing reads it row-wise.
-__device__ __forceinline__ double lam_hat(const double* Lam, const double* Dg, int ldL, int n, int n_cap, int I, int J) {
-  const int hi = I >= J ? I : J, lo = I >= J ? J : I;
-  const bool ok = hi <= n && lo < n;
-  const int hic = min(hi, ldL - 1), loc = min(lo, ldL - 1);
-  const double lv = Lam[(long)hic * ldL + loc];
-  const bool isy = hi == n, isd = !isy && (hi / 6 == lo / 6);
-  const int a6 = lo % 6, c6 = hi % 6;
-  const int idx = isy ? 21 + a6 : (isd ? a6 * 6 - a6 * (a6 - 1) / 2 + (c6 - a6) : 0);
-  const double dg = Dg[min(lo / 6, n_cap - 1) * DG_STRIDE + idx];
-  const double val = ((isy || isd) ? dg : 0.0) - lv;
-  return ok ? val : 0.0;
 }
 
 // [T | r_n] = chol(Lam^) with Lam^ = Dg - sum B^T B; element (i, j), i >= j, of the lower factor lives in thread
@@ -451,6 +437,7 @@ void launch_gram(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase) {
   // k_chol_blk (blocked, trailing update on the f64 matrix cores) is 10 % faster than k_chol_T in isolation (104 vs
   // 114 us) but holds the whole register file of its CU (256 VGPR + 188 AGPR), so nothing of the other slice's stream
   // co-schedules with it: 3 % slower end to end with two streams.  Kept selectable (msckf_hip_set_compression(h, 2)).
+  if (d.compress == 3 && launch_chol_gram<S>(d, b0, nb, st)) return;   // blocked matrix-core Cholesky, kernels_chol.hip
   if (d.compress == 2) {
     switch (d.ldR / 16) {
       case 4: hipLaunchKernelGGL((k_chol_blk<S, 4>), dim3(nb), dim3(256), 0, st, d, b0, g_dbg); break;

@@ -31,6 +31,7 @@ struct KView {
   S sig2;
   const S* P; const S* R0;
   S* PHt; S* Sm; S* Linv; S* W; S* K; S* A; S* AP; S* X;
+  S* PHtT;   // square-root gain form: row-major copy of PHt (D x n, row stride ldn) in the K buffer, for the blocked solve
 };
 template <class S>
 __device__ __forceinline__ KView<S> make_view(const Dev<S>& d, int b) {
@@ -42,6 +43,7 @@ __device__ __forceinline__ KView<S> make_view(const Dev<S>& d, int b) {
   v.R0 = d.Rbuf + ((long)b * d.nchunk) * (long)d.n6cap * d.ldR;
   v.PHt = d.PHt + b * dn; v.Sm = d.Smat + b * nl; v.Linv = d.Linv + b * nl;
   v.W = d.W + b * dn; v.K = d.K + b * dn; v.A = d.A + b * pl; v.AP = d.AP + b * pl; v.X = d.X + b * pl;
+  v.PHtT = d.joseph == 0 ? v.K : nullptr;
   return v;
 }
 
@@ -76,8 +78,13 @@ template <class S, int OP> __device__ __forceinline__ S op_b(const KView<S>& v, 
   return k < v.D ? v.A[(long)k * v.ld + j] : v.K[(long)(k - v.D) * v.ld + j];
 }
 template <class S, int OP> __device__ __forceinline__ void op_store(const KView<S>& v, int i, int j, S acc) {
-  if (OP == OP_PHT) v.PHt[(long)j * v.ld + i] = acc;
-  else if (OP == OP_S) v.Sm[(long)j * v.ldn + i] = acc + (i == j ? v.sig2 : S(0));
+  if (OP == OP_PHT) { v.PHt[(long)j * v.ld + i] = acc; if (v.PHtT) v.PHtT[(long)i * v.ldn + j] = acc; }
+  else if (OP == OP_S) {   // lower tiles are computed; the mirror image makes S readable row-wise
+    if (i >= j) {          // one writer per location: T (P T^T) is not symmetric to the last bit
+      const S val = acc + (i == j ? v.sig2 : S(0));
+      v.Sm[(long)j * v.ldn + i] = val; v.Sm[(long)i * v.ldn + j] = val;
+    }
+  }
   else if (OP == OP_W) v.W[(long)j * v.ld + i] = acc;
   else if (OP == OP_K || OP == OP_KE) v.K[(long)j * v.ld + i] = acc;
   else if (OP == OP_A) v.A[(long)j * v.ld + i] = (i == j ? S(1) : S(0)) - acc;
@@ -881,6 +888,9 @@ static void launch_gain_w(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   else hipLaunchKernelGGL((k_gain_w<S, NBN, 2>), dim3(2, nb), dim3(256), 0, st, d, b0);
 }
 
+static bool gain_blocked(const Dev<float>& d, int b0, int nb, hipStream_t st) { return launch_chol_gain(d, b0, nb, st); }
+static bool gain_blocked(const Dev<double>&, int, int, hipStream_t) { return false; }
+
 template <class S>
 void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0) return;
@@ -894,9 +904,10 @@ void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st) {
     if (lds_chol <= 150 * 1024) hipLaunchKernelGGL((k_chol_inv<S, true>), dim3(nb), dim3(256), lds_chol, st, d, b0);
     else hipLaunchKernelGGL((k_chol_inv<S, false>), dim3(nb), dim3(256), 0, st, d, b0);
   };
-  if (!d.joseph) {
+  if (d.joseph != 1) {
     // ---- square-root gain form: W = PHt L^-T, dx = W L^-1 r_n, P <- P - W W^T
-    if (nbn <= 4) launch_gain_w<S, 4>(d, b0, nb, st);
+    if (d.joseph == 0 && gain_blocked(d, b0, nb, st)) {}   // float: blocked matrix-core Cholesky with appended rows
+    else if (nbn <= 4) launch_gain_w<S, 4>(d, b0, nb, st);
     else if (nbn <= 8) launch_gain_w<S, 8>(d, b0, nb, st);
     else if (nbn <= nbn_max) launch_gain_w<S, (sizeof(S) == 4 ? 12 : 8)>(d, b0, nb, st);
     else {

@@ -157,7 +157,7 @@ struct Batch : BatchBase {
     rc |= dalloc(&d.row_start, Bz * (f_cap + 1)); rc |= dalloc(&d.trk_order, TF); rc |= dalloc(&d.stats, Bz * STAT_STRIDE);
     rc |= dalloc(&d.Rbuf, Bz * d.nchunk * (size_t)d.n6cap * d.ldR);
     // information-form compression (kernels_gram.hip): the register-resident Cholesky covers n + 1 <= 192
-    d.compress = (d.ldR <= 192 && f_cap <= 1024) ? 1 : 0;
+    d.compress = (d.ldR <= 192 && f_cap <= 1024) ? 3 : 0;   // blocked matrix-core Cholesky (kernels_chol.hip)
     if (d.compress) {
       rc |= dalloc(&d.trk_B, TF * 3 * (size_t)d.ldR); rc |= dalloc(&d.trk_rw, TF * 2 * m_cap); rc |= dalloc(&d.trk_inv, TF * n_cap);
       rc |= dalloc(&d.Dg, Bz * n_cap * DG_STRIDE); rc |= dalloc(&d.Lam, Bz * (size_t)d.ldR * d.ldR);
@@ -609,12 +609,12 @@ struct Batch : BatchBase {
   }
   int set_gate_early(int on) override { d.gate_early = on ? 1 : 0; return 0; }
   int set_cov_update(int form) override {
-    if (form != 0 && form != 1) return fail(-EINVAL, "form: 0 square-root gain (P - W W^T), 1 Joseph");
+    if (form < 0 || form > 2) return fail(-EINVAL, "form: 0 square-root gain (P - W W^T), 1 Joseph, 2 square-root gain with the register-resident solve");
     d.joseph = form;
     return 0;
   }
   int set_compression(int route) override {
-    if (route < -1 || route > 2) return fail(-EINVAL, "route: -1 default, 0 Householder TSQR, 1 information form, 2 information form with the blocked Cholesky");
+    if (route < -1 || route > 3) return fail(-EINVAL, "route: -1 default, 0 Householder TSQR, information form with 1 register / 2 blocked / 3 blocked + MFMA panel Cholesky");
     if (route >= 1 && !d.trk_B) return fail(-ENOTSUP, "information form not available for this window size (6 n_cap + 1 > 192)");
     compress_route = route;
     return 0;
@@ -1000,7 +1000,7 @@ BatchBase* H(msckf_hip_handle h) { return reinterpret_cast<BatchBase*>(h); }
 }  // namespace
 
 #ifdef MSCKF_ABLATE
-namespace msckf { void qr_debug_set(int idx, int val); void feat_debug_set(int val); extern int g_gram_dbg; }
+namespace msckf { void qr_debug_set(int idx, int val); void feat_debug_set(int val); extern int g_gram_dbg; void chol_cycles_read(unsigned long long* out16, int reset); }
 #endif
 
 extern "C" {
@@ -1012,6 +1012,7 @@ void msckf_hip_debug_set(int idx, int val) {
   if (idx == 300) { msckf::g_gram_dbg = val; return; }
   msckf::qr_debug_set(idx, val);
 }
+void msckf_hip_debug_chol_cycles(unsigned long long* out16, int reset) { msckf::chol_cycles_read(out16, reset); }
 #endif
 
 const char* msckf_hip_last_error(void) { return g_err.c_str(); }

@@ -1,0 +1,34 @@
+"""Phase breakdown of the blocked matrix-core Cholesky (kernels_chol.hip) on the GPU box, -DMSCKF_ABLATE build only:
+    make -C msckf_mono_amd/csrc ablate && MSCKF_HIP_LIB=msckf_mono_amd/lib_ab/libmsckf_hip_ablate.so python scripts/chol_phases.py
+Prints shader-clock cycles per launch and phase for the GRAM (f64) and GAIN (f32) instances at the cfg3 window."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from msckf_mono_amd import capi, scenario as sc  # noqa: E402
+
+N, F, B, nf = 30, 200, 8, 40
+trajs = [sc.Trajectory(3, b, N, F, nf) for b in range(B)]
+bt = capi.Batch(B, N, F, N, capi.F32)
+bt.set_compression(3); bt.set_covariance_update(0)
+for b, tr in enumerate(trajs):
+    bt.initialize(b, tr.cfg, tr.imu0)
+bt.scenario_alloc(nf, 10)
+for k in range(nf):
+    for b, tr in enumerate(trajs):
+        fr = tr.frames[k]
+        bt.scenario_set(k, b, tr.imu_for_frame(k), fr["M"], fr["slots"], fr["obs"], 1 if fr["Nw"] == N else 0)
+bt.scenario_commit()
+bt.run_frames(0, 32); bt.sync()
+out = (C.c_ulonglong * 16)()
+bt.L.msckf_hip_debug_chol_cycles(out, 1)
+bt.run_frames(32, nf); bt.sync()
+bt.L.msckf_hip_debug_chol_cycles(out, 1)
+names = ["load", "panel->LDS", "diag block", "L21", "outputs", "trailing"]
+for m, nm in enumerate(("GRAM f64", "GAIN f32")):
+    v = np.array(out[8 * m:8 * m + 8], dtype=np.float64)
+    n = max(v[6], 1)
+    print(nm, "launches", int(v[6]), {a: int(c / n) for a, c in zip(names, v[:6])}, "total cycles/launch", int(v[:6].sum() / n))

@@ -213,7 +213,7 @@ def test_information_form_equals_householder_route(capi, prec):
     tr = sc.Trajectory(2, 7, N, F, nf)
     cd = capi.F64 if prec == "f64" else capi.F32
     res = {}
-    for route in (0, 1, 2):               # 2 = information form with the blocked MFMA Cholesky (k_chol_blk)
+    for route in (0, 1, 2, 3):            # information form with 1 k_chol_T, 2 k_chol_blk, 3 k_chol_mfma (kernels_chol.hip)
         bt = capi.Batch(1, N, F, N, cd)
         bt.set_compression(route)
         bt.initialize(0, tr.cfg, tr.imu0)
@@ -226,6 +226,9 @@ def test_information_form_equals_householder_route(capi, prec):
     e2 = H.state_errors(res[2][0], res[1][0], res[2][1], res[1][1], res[2][2], res[1][2])
     assert H.worst(e2) < (1e-9 if prec == "f64" else 3e-4), e2
     assert res[2][3] == res[1][3]
+    e3 = H.state_errors(res[3][0], res[1][0], res[3][1], res[1][1], res[3][2], res[1][2])
+    assert H.worst(e3) < (1e-9 if prec == "f64" else 3e-4), e3
+    assert res[3][3] == res[1][3]
     assert res[1][3]["m_rows"] == res[0][3]["m_rows"] > 0
     assert res[1][3]["r_rows"] < res[0][3]["r_rows"] == 6 * N            # gauge directions skipped
 
@@ -240,7 +243,7 @@ def test_square_root_gain_form_equals_joseph_form(capi, prec, N, F):
     tr = sc.Trajectory(2, 9, N, F, nf)
     cd = capi.F64 if prec == "f64" else capi.F32
     res = {}
-    for form in (0, 1):
+    for form in (0, 1, 2):                 # 0 default (float: blocked matrix-core solve), 1 Joseph, 2 register-resident solve
         bt = capi.Batch(1, N, F, max(N, 4), cd)
         bt.set_covariance_update(form)
         bt.initialize(0, tr.cfg, tr.imu0)
@@ -254,6 +257,8 @@ def test_square_root_gain_form_equals_joseph_form(capi, prec, N, F):
     assert H.worst(e) < (1e-9 if prec == "f64" else 1e-3), e           # float: two free-running float filters, ~40 frames
     strip = lambda st: {k: v for k, v in st.items() if k != "r_rows"}   # r_rows: count of pivots above a rounding-level tolerance
     assert strip(res[0][3]) == strip(res[1][3]) and res[0][3]["n_passed"] > 0
+    e2 = H.state_errors(res[2][0], res[0][0], res[2][1], res[0][1], res[2][2], res[0][2])
+    assert H.worst(e2) < (1e-9 if prec == "f64" else 1e-3), e2
 
 
 def test_resident_scenario_equals_per_call(capi):
