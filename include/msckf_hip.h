@@ -126,6 +126,11 @@ int msckf_hip_scenario_commit(msckf_hip_handle h);   /* H2D of everything staged
 /* one filter update per trajectory per frame: K x propagate + augmentState + marginalize + prune, for
  * frames [f0, f1), asynchronously on the handle's stream */
 int msckf_hip_run_frames(msckf_hip_handle h, int f0, int f1);
+/* The same frames with the inputs handed over per frame, as the reference's callers do (IMU samples and the image's
+ * tracks arrive with the image, asl_msckf.cpp:227-284): frame f's IMU samples and work-list are copied from the
+ * page-locked host scenario to the device on a copy stream, double-buffered, while frame f-1 computes.  Results are
+ * bit-identical to msckf_hip_run_frames; the difference is the PCIe leg inside the timed region. */
+int msckf_hip_run_frames_streamed(msckf_hip_handle h, int f0, int f1);
 int msckf_hip_sync(msckf_hip_handle h);
 /* HIP-event stage timing: enable, run, sync, then read accumulated milliseconds and launch counts for
  * stages 0 propagate, 1 augment, 2 k_feature, 3 compression A (k_gram | TSQR stage 1), 4 compression B (k_chol_T |

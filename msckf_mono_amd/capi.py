@@ -29,7 +29,7 @@ SYMBOLS = [
     "msckf_hip_set_cam_pose", "msckf_hip_get_num_residualized", "msckf_hip_set_num_residualized", "msckf_hip_last_stats",
     "msckf_hip_last_tracks", "msckf_hip_last_deltax", "msckf_hip_set_tracks", "msckf_hip_propagate_range",
     "msckf_hip_augment_range", "msckf_hip_marginalize_range", "msckf_hip_drop_oldest_range", "msckf_hip_scenario_alloc",
-    "msckf_hip_scenario_set", "msckf_hip_scenario_commit", "msckf_hip_run_frames", "msckf_hip_sync",
+    "msckf_hip_scenario_set", "msckf_hip_scenario_commit", "msckf_hip_run_frames", "msckf_hip_run_frames_streamed", "msckf_hip_sync",
     "msckf_hip_profile_enable", "msckf_hip_profile_read", "msckf_hip_set_streams", "msckf_hip_set_gate_early_accept",
     "msckf_hip_set_compression", "msckf_hip_set_covariance_update", "msckf_hip_get_pruned_states", "msckf_hip_get_cam_meta", "msckf_hip_get_tracked_feature_ids",
 ]
@@ -235,6 +235,10 @@ class Batch:
 
     def run_frames(self, f0, f1):
         _chk(self.L.msckf_hip_run_frames(self.h, f0, f1))
+
+    def run_frames_streamed(self, f0, f1):
+        """run_frames with per-frame asynchronous H2D of the inputs (copy stream, double-buffered)"""
+        _chk(self.L.msckf_hip_run_frames_streamed(self.h, f0, f1))
 
     def sync(self):
         _chk(self.L.msckf_hip_sync(self.h))

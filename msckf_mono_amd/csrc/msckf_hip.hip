@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/msckf_hip.h"
+#include <atomic>
 #include <thread>
 #include "dev_common.h"
 
@@ -80,6 +81,7 @@ struct BatchBase {
   virtual int scen_set(int f, int b, const double* rd, int F, const int* M, const int* slots, const double* obs, int n_drop) = 0;
   virtual int scen_commit() = 0;
   virtual int run_frames(int f0, int f1) = 0;
+  virtual int run_frames_streamed(int f0, int f1) = 0;
   virtual int sync() = 0;
   virtual int prof_enable(int on) = 0;
   virtual int prof_read(double* ms, int* cnt) = 0;
@@ -114,6 +116,11 @@ struct Batch : BatchBase {
   S* sc_rd = nullptr; int* sc_n = nullptr; int* sc_M = nullptr; int* sc_slots = nullptr; S* sc_obs = nullptr; int* sc_drop = nullptr;
   std::vector<S> h_rd, h_obs; std::vector<int> h_n, h_M, h_slots, h_drop;
   std::vector<void*> sc_allocs;
+  // streamed inputs: per-frame H2D from the (page-locked) host copy into two device staging sets on a copy stream
+  bool host_pinned = false;
+  hipStream_t stc = nullptr; hipEvent_t ev_up[2] = {nullptr, nullptr}; hipEvent_t ev_use[2][MAXS] = {{nullptr}};
+  unsigned char* h_pack = nullptr; unsigned char* sg_blk[2] = {nullptr, nullptr};   // one packed block per frame: [rd | n | M | slots | obs | drop]
+  size_t pk_rd = 0, pk_n = 0, pk_M = 0, pk_slots = 0, pk_obs = 0, pk_drop = 0, pk_bytes = 0;
   // profiling
   bool prof = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool[NSTAGE];
@@ -184,6 +191,9 @@ struct Batch : BatchBase {
     for (int i = 1; i < MAXS; ++i) { if (stx[i]) hipStreamDestroy(stx[i]); if (ev_join[i]) hipEventDestroy(ev_join[i]); }
     if (ev_fork) hipEventDestroy(ev_fork);
     if (ev_stage) hipEventDestroy(ev_stage);
+    unpin_host();
+    for (int k = 0; k < 2; ++k) { if (ev_up[k]) hipEventDestroy(ev_up[k]); for (int i = 0; i < MAXS; ++i) if (ev_use[k][i]) hipEventDestroy(ev_use[k][i]); }
+    if (stc) hipStreamDestroy(stc);
     if (h_stage) hipHostFree(h_stage);
     if (st) hipStreamDestroy(st);
   }
@@ -542,6 +552,7 @@ struct Batch : BatchBase {
     }
     sc_allocs.clear();
     sc_frames = 0;
+    unpin_host();
     const size_t Bz = B, FB = (size_t)n_frames * Bz;
     h_rd.assign(FB * K * RD_STRIDE, S(0)); h_n.assign(FB, 0); h_M.assign(FB * f_cap, 0);
     h_slots.assign(FB * f_cap * m_cap, 0); h_obs.assign(FB * f_cap * m_cap * 2, S(0)); h_drop.assign(FB, 0);
@@ -549,6 +560,13 @@ struct Batch : BatchBase {
     int rc = 0;
     rc |= dalloc(&sc_rd, h_rd.size()); rc |= dalloc(&sc_n, h_n.size()); rc |= dalloc(&sc_M, h_M.size());
     rc |= dalloc(&sc_slots, h_slots.size()); rc |= dalloc(&sc_obs, h_obs.size()); rc |= dalloc(&sc_drop, h_drop.size());
+    {   // packed per-frame block of run_frames_streamed (sections 256-byte aligned) and its two device staging copies
+      auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+      pk_rd = 0; pk_n = al(pk_rd + Bz * K * RD_STRIDE * sizeof(S)); pk_M = al(pk_n + Bz * sizeof(int));
+      pk_slots = al(pk_M + Bz * f_cap * sizeof(int)); pk_obs = al(pk_slots + Bz * f_cap * m_cap * sizeof(int));
+      pk_drop = al(pk_obs + Bz * f_cap * m_cap * 2 * sizeof(S)); pk_bytes = al(pk_drop + Bz * sizeof(int));
+      for (int k = 0; k < 2; ++k) rc |= dalloc(&sg_blk[k], pk_bytes);
+    }
     sc_allocs.assign(allocs.begin() + mark, allocs.end());
     if (rc) return rc;
     sc_frames = n_frames; sc_K = K;
@@ -594,9 +612,31 @@ struct Batch : BatchBase {
     HIPCHK(hipMemcpyAsync(sc_obs, h_obs.data(), h_obs.size() * sizeof(S), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(sc_drop, h_drop.data(), h_drop.size() * sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
+    // page-locked, per-frame packed copy of the scenario for run_frames_streamed: ONE asynchronous H2D per frame
+    unpin_host();
+    HIPCHK(hipHostMalloc((void**)&h_pack, pk_bytes * (size_t)sc_frames, hipHostMallocDefault));
+    {
+      const size_t Bz = B;
+      for (int f = 0; f < sc_frames; ++f) {
+        unsigned char* blk = h_pack + (size_t)f * pk_bytes;
+        const size_t c0 = (size_t)f * Bz;
+        std::memcpy(blk + pk_rd, h_rd.data() + c0 * sc_K * RD_STRIDE, Bz * sc_K * RD_STRIDE * sizeof(S));
+        std::memcpy(blk + pk_n, h_n.data() + c0, Bz * sizeof(int));
+        std::memcpy(blk + pk_M, h_M.data() + c0 * f_cap, Bz * f_cap * sizeof(int));
+        std::memcpy(blk + pk_slots, h_slots.data() + c0 * f_cap * m_cap, Bz * f_cap * m_cap * sizeof(int));
+        std::memcpy(blk + pk_obs, h_obs.data() + c0 * f_cap * m_cap * 2, Bz * f_cap * m_cap * 2 * sizeof(S));
+        std::memcpy(blk + pk_drop, h_drop.data() + c0, Bz * sizeof(int));
+      }
+    }
+    host_pinned = true;
     return 0;
   }
   int run_frames(int f0, int f1) override;
+  int run_frames_streamed(int f0, int f1) override;
+  void unpin_host() {
+    if (h_pack) hipHostFree(h_pack);
+    h_pack = nullptr; host_pinned = false;
+  }
   int sync() override {
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamSynchronize(st));
@@ -706,6 +746,88 @@ int Batch<S>::run_frames(int f0, int f1) {
     for (auto& t : th) t.join();
   }
   for (int i = 1; i < nh; ++i) { HIPCHK(hipEventRecord(ev_join[i], stx[i])); HIPCHK(hipStreamWaitEvent(st, ev_join[i], 0)); }
+  for (int i = 0; i < nh; ++i)
+    if (slice_rc[i]) return fail(-EIO, std::string("kernel launch failed on slice ") + std::to_string(i) + ": " + hipGetErrorString((hipError_t)slice_rc[i]));
+  return 0;
+}
+
+// run_frames with the inputs handed over per frame, as the reference's callers do (asl_msckf.cpp:227-284: IMU samples and
+// the image's tracks arrive with the image): the IMU samples and the work-list of frame f are copied from the page-locked
+// host scenario into one of two device staging sets on a copy stream while frame f-1 computes; the slices' kernels wait for
+// the upload event of their frame, the upload of frame f+2 waits until every slice has consumed the set.
+template <class S>
+int Batch<S>::run_frames_streamed(int f0, int f1) {
+  if (f0 < 0 || f1 > sc_frames || f0 > f1) return fail(-EINVAL, "frame range out of bounds");
+  if (!host_pinned) return fail(-EINVAL, "scenario not committed");
+  HIPCHK(hipSetDevice(device));
+  if (!stc) {
+    HIPCHK(hipStreamCreateWithFlags(&stc, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+      HIPCHK(hipEventCreateWithFlags(&ev_up[k], hipEventDisableTiming));
+      for (int i = 0; i < MAXS; ++i) HIPCHK(hipEventCreateWithFlags(&ev_use[k][i], hipEventDisableTiming));
+    }
+  }
+  const int nh = prof ? 1 : std::max(1, std::min(nstreams, B));
+  HIPCHK(hipEventRecord(ev_fork, st));
+  HIPCHK(hipStreamWaitEvent(stc, ev_fork, 0));
+  for (int i = 1; i < nh; ++i) HIPCHK(hipStreamWaitEvent(stx[i], ev_fork, 0));
+  // One host thread per slice enqueues that slice's kernels (as run_frames does); this thread enqueues the uploads.  An
+  // event must be RECORDED (enqueued) before a wait on it is enqueued, so the threads hand frame numbers over through
+  // atomics: up_enq = frames whose upload + record are enqueued, use_enq[s] = frames whose consumption record is enqueued.
+  std::atomic<int> up_enq{f0};
+  std::atomic<int> use_enq[MAXS];
+  for (int i = 0; i < MAXS; ++i) use_enq[i].store(f0);
+  std::atomic<int> failed{0};
+  int slice_rc[MAXS] = {0};
+  auto slice = [&](int hh) {
+    (void)hipSetDevice(device);
+    (void)hipGetLastError();
+    hipStream_t q = stx[hh];
+    const int b0 = (int)((long)B * hh / nh);
+    const int nb = (int)((long)B * (hh + 1) / nh) - b0;
+    for (int f = f0; f < f1; ++f) {
+      while (up_enq.load(std::memory_order_acquire) <= f && !failed.load()) std::this_thread::yield();
+      if (failed.load()) break;
+      const int k = (f - f0) & 1;
+      unsigned char* blk = sg_blk[k];
+      (void)hipStreamWaitEvent(q, ev_up[k], 0);
+      Dev<S> v = d;
+      v.trk_n = reinterpret_cast<int*>(blk + pk_n) + b0; v.trk_M = reinterpret_cast<int*>(blk + pk_M) + (size_t)b0 * f_cap;
+      v.trk_slots = reinterpret_cast<int*>(blk + pk_slots) + (size_t)b0 * f_cap * m_cap;
+      v.trk_obs = reinterpret_cast<S*>(blk + pk_obs) + (size_t)b0 * f_cap * m_cap * 2;
+      v.wl_stride_n = 1; v.wl_stride_f = f_cap; v.wl_stride_o = (long)f_cap * m_cap;
+      stage_begin(0, q); launch_propagate<S>(v, b0, nb, reinterpret_cast<S*>(blk + pk_rd) + (size_t)b0 * sc_K * RD_STRIDE, (long)sc_K * RD_STRIDE, sc_K, q); stage_end(0, q);
+      stage_begin(1, q); launch_augment<S>(v, b0, nb, q); stage_end(1, q);
+      launch_update(v, b0, nb, q);
+      stage_begin(6, q);
+      hipLaunchKernelGGL(k_make_keep, dim3((nb + 63) / 64), dim3(64), 0, q, d.keep, d.nkeep, d.ncam, (const int*)(reinterpret_cast<int*>(blk + pk_drop) + b0), 0, n_cap, b0, nb);
+      launch_prune<S>(v, b0, nb, q);
+      stage_end(6, q);
+      (void)hipEventRecord(ev_use[k][hh], q);
+      use_enq[hh].store(f + 1, std::memory_order_release);
+    }
+    slice_rc[hh] = (int)hipGetLastError();
+  };
+  std::vector<std::thread> th;
+  for (int hh = 0; hh < nh; ++hh) th.emplace_back(slice, hh);
+  int rc_up = 0;
+  for (int f = f0; f < f1 && !rc_up; ++f) {
+    const int k = (f - f0) & 1;
+    if (f - f0 >= 2)
+      for (int i = 0; i < nh; ++i) {   // the set is free again once every slice has consumed frame f-2
+        while (use_enq[i].load(std::memory_order_acquire) <= f - 2) std::this_thread::yield();
+        if (hipStreamWaitEvent(stc, ev_use[k][i], 0) != hipSuccess) rc_up = -EIO;
+      }
+    if (hipMemcpyAsync(sg_blk[k], h_pack + (size_t)f * pk_bytes, pk_bytes, hipMemcpyHostToDevice, stc) != hipSuccess) rc_up = -EIO;
+    if (hipEventRecord(ev_up[k], stc) != hipSuccess) rc_up = -EIO;
+    if (rc_up) failed.store(1);
+    up_enq.store(f + 1, std::memory_order_release);
+  }
+  if (rc_up) failed.store(1);
+  for (auto& t : th) t.join();
+  if (rc_up) return fail(rc_up, "input upload failed");
+  for (int i = 1; i < nh; ++i) { HIPCHK(hipEventRecord(ev_join[i], stx[i])); HIPCHK(hipStreamWaitEvent(st, ev_join[i], 0)); }
+  HIPCHK(hipEventRecord(ev_join[1], stc)); HIPCHK(hipStreamWaitEvent(st, ev_join[1], 0));
   for (int i = 0; i < nh; ++i)
     if (slice_rc[i]) return fail(-EIO, std::string("kernel launch failed on slice ") + std::to_string(i) + ": " + hipGetErrorString((hipError_t)slice_rc[i]));
   return 0;
@@ -1160,6 +1282,7 @@ int msckf_hip_scenario_set(msckf_hip_handle h, int frame, int b, const double* r
 }
 int msckf_hip_scenario_commit(msckf_hip_handle h) { return H(h)->scen_commit(); }
 int msckf_hip_run_frames(msckf_hip_handle h, int f0, int f1) { return H(h)->run_frames(f0, f1); }
+int msckf_hip_run_frames_streamed(msckf_hip_handle h, int f0, int f1) { return H(h)->run_frames_streamed(f0, f1); }
 int msckf_hip_sync(msckf_hip_handle h) { return H(h)->sync(); }
 int msckf_hip_profile_enable(msckf_hip_handle h, int on) { return H(h)->prof_enable(on); }
 int msckf_hip_profile_read(msckf_hip_handle h, double* ms7, int* count7) { return H(h)->prof_read(ms7, count7); }

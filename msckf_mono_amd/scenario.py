@@ -117,38 +117,47 @@ def filter_config(N, isotropic=True, feature_px=7.0, gn_px=7.0):
 
 
 # ------------------------------------------------------------------ analytic trajectory
-def _path(t):
+# path_id -> (radius [m], turn rate [rad/s], vertical amplitude [m], vertical rate [rad/s], roll/pitch wobble [rad], wobble rate)
+# 0 is the SURVEY 8d path every config uses; 1..4 are the other "sequences" of the cfg4 Monte-Carlo stand-in
+# (BASELINE.json configs[3] names EuRoC MH_01..MH_05, which are not on disk).
+PATHS = [(3.0, 0.4, 0.5, 0.8, 0.10, 0.7), (4.0, 0.3, 0.8, 0.5, 0.08, 0.5), (2.5, 0.5, 0.3, 1.0, 0.12, 0.9),
+         (3.5, 0.35, 0.6, 0.7, 0.05, 0.6), (5.0, 0.25, 1.0, 0.4, 0.10, 0.8)]
+
+
+def _path(t, path_id=0):
+    R, w, Az, wz, _, _ = PATHS[path_id]
     t = np.asarray(t, dtype=np.float64)
-    p = np.stack([3 * np.cos(0.4 * t), 3 * np.sin(0.4 * t), 0.5 * np.sin(0.8 * t)], -1)
-    v = np.stack([-1.2 * np.sin(0.4 * t), 1.2 * np.cos(0.4 * t), 0.4 * np.cos(0.8 * t)], -1)
-    a = np.stack([-0.48 * np.cos(0.4 * t), -0.48 * np.sin(0.4 * t), -0.32 * np.sin(0.8 * t)], -1)
+    p = np.stack([R * np.cos(w * t), R * np.sin(w * t), Az * np.sin(wz * t)], -1)
+    v = np.stack([-R * w * np.sin(w * t), R * w * np.cos(w * t), Az * wz * np.cos(wz * t)], -1)
+    a = np.stack([-R * w * w * np.cos(w * t), -R * w * w * np.sin(w * t), -Az * wz * wz * np.sin(wz * t)], -1)
     return p, v, a
 
 
-def _attitude(t):
+def _attitude(t, path_id=0):
     """R_GI(t) [..,3,3] (IMU axes in world) and body angular rate omega(t)."""
+    _, w0, _, _, wob, wr = PATHS[path_id]
     t = np.asarray(t, dtype=np.float64)
-    th = 0.4 * t
+    th = w0 * t
     o = np.stack([np.cos(th), np.sin(th), np.zeros_like(th)], -1)       # outward  -> z_I (camera axis)
     up = np.broadcast_to(np.array([0.0, 0.0, 1.0]), o.shape)             # up       -> x_I
     tg = np.stack([-np.sin(th), np.cos(th), np.zeros_like(th)], -1)     # tangent  -> -y_I
     Rn = np.stack([up, -tg, o], -1)
-    al, dal = 0.1 * np.sin(0.7 * t), 0.07 * np.cos(0.7 * t)
-    be, dbe = 0.1 * np.sin(0.7 * t + 1.0), 0.07 * np.cos(0.7 * t + 1.0)
+    al, dal = wob * np.sin(wr * t), wob * wr * np.cos(wr * t)
+    be, dbe = wob * np.sin(wr * t + 1.0), wob * wr * np.cos(wr * t + 1.0)
     ca, sa, cb, sb = np.cos(al), np.sin(al), np.cos(be), np.sin(be)
     z, one = np.zeros_like(t), np.ones_like(t)
     Rx = np.stack([np.stack([one, z, z], -1), np.stack([z, ca, -sa], -1), np.stack([z, sa, ca], -1)], -2)
     Ry = np.stack([np.stack([cb, z, sb], -1), np.stack([z, one, z], -1), np.stack([-sb, z, cb], -1)], -2)
     R = Rn @ Rx @ Ry
-    w = 0.4 + dal
+    w = w0 + dal
     omega = np.stack([cb * w, dbe, sb * w], -1)
     return R, omega
 
 
-def ground_truth(t):
+def ground_truth(t, path_id=0):
     """dict of p, v, q_IG (w,x,y,z), R_GI at times t."""
-    p, v, a = _path(t)
-    R, om = _attitude(t)
+    p, v, a = _path(t, path_id)
+    R, om = _attitude(t, path_id)
     R2 = R.reshape(-1, 3, 3)
     q = np.stack([rot_to_quat(Ri.T) for Ri in R2]).reshape(np.shape(t) + (4,))
     return dict(p=p, v=v, a=a, R_GI=R, omega=om, q_IG=q)
@@ -164,7 +173,7 @@ class Trajectory:
     """One seeded trajectory: IMU stream + per-frame ending-track work-lists."""
 
     def __init__(self, config_id, traj_idx, N, F, n_frames, cfg=None, t0=0.0, imu_noise_scale=0.05,
-                 obs_noise_px=0.5, dense_tracks=False, first_timed_window_only=False, depth_range=(2.0, 10.0)):
+                 obs_noise_px=0.5, dense_tracks=False, first_timed_window_only=False, depth_range=(2.0, 10.0), path_id=0):
         self.N, self.F, self.n_frames = N, F, n_frames
         self.depth_range = depth_range   # landmark depth in the mid-track camera; (2, 10) m = SURVEY 8d, larger = low parallax
         self.t0 = t0
@@ -177,7 +186,8 @@ class Trajectory:
         # IMU sample i covers [t0 + i dT, t0 + (i+1) dT); frame k is taken after IMU samples [10(k-1)+... ]
         n_imu = n_frames * IMU_PER_FRAME
         ti = t0 + np.arange(n_imu) * self.dT
-        gt = ground_truth(ti + 0.5 * self.dT)            # mid-interval sampling
+        self.path_id = path_id
+        gt = ground_truth(ti + 0.5 * self.dT, path_id)            # mid-interval sampling
         q = self.cfg["Q_imu_diag"]
         sg = imu_noise_scale * np.sqrt(q[0] / self.dT)
         sa = imu_noise_scale * np.sqrt(q[6] / self.dT)
@@ -188,8 +198,8 @@ class Trajectory:
         self.readings = np.concatenate([om, ac, np.full((n_imu, 1), self.dT)], 1)   # [n_imu, 7]
         # frame k happens at time t0 + (k+1)*10*dT, i.e. after IMU samples [10k, 10k+10)
         self.frame_times = t0 + (np.arange(n_frames) + 1) * IMU_PER_FRAME * self.dT
-        self.gt_frames = ground_truth(self.frame_times)
-        self.gt0 = ground_truth(np.array(t0))
+        self.gt_frames = ground_truth(self.frame_times, path_id)
+        self.gt0 = ground_truth(np.array(t0), path_id)
         self.imu0 = imu29_from_gt(self.gt0, self.b_g, self.b_a)
         q_CI, p_C_I = self.cfg["q_CI"], self.cfg["p_C_I"]
         C_CI = quat_to_rot(q_CI)

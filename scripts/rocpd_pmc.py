@@ -45,6 +45,10 @@ def main():
             key = m.group(1) + (re.search(r"<(\d+)>", k).group(0) if m.group(1) == "k_gemm_mfma" and re.search(r"<(\d+)>", k) else "")
             tr[key] = dict(kernel=k, fetch_kib=f, write_kib=w, bytes_per_launch=(2 * f + w) * 1024,
                            note="FETCH_SIZE doubled (gfx950 under-reports wide coalesced reads by 2x); WRITE_SIZE uncalibrated")
+            ex = {c: res[(k, c)] for c in ("SQ_INSTS_VALU", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_VALU_MFMA_MOPS_F64",
+                                           "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES") if (k, c) in res}
+            if ex:   # executed work per launch (wave-level instruction counts summed over the chip), for roofline.executed
+                tr[key]["executed"] = ex
     if tr:
         json.dump(tr, open(os.path.join(os.path.dirname(out) or ".", "pmc_traffic.json"), "w"), indent=1)
 

@@ -22,5 +22,22 @@ def test_two_ranks_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 4
     assert abs(d["value"] - 2 * 64 * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 1e-6
-    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
-    assert d["ate_m"] < 0.05
+    assert d["roofline"]["bound"] in ("valu", "mfma", "hbm") and 0 < d["roofline"]["frac"] < 1
+    assert d["ate_m"] < 0.05 and len(d["ate_per_sequence_m"]) == 1
+    assert d["repeats"]["windows"] >= 3 and d["repeats"]["values"][0] == d["value"]
+    assert d["value_with_worklist_upload"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_cfg4_monte_carlo_mode_reports_per_sequence_ate():
+    """bench.py --config cfg4: 5 synthetic sequences x noise seeds, EuRoC intrinsics (anisotropic noise), per-sequence ATE
+    through shard.ate_local / ate_allreduce, the CPU oracle's ATE beside the HIP path's on sampled trajectories."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "cfg4", "--steps", "4", "--warmup", "1", "--repeats", "1",
+           "--no-early-accept-pass", "--no-upload-pass", "--cpu-seconds", "5"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["name"] == "cfg4" and d["config"]["sequences"] == 5 and d["config"]["trajectories_per_gpu"] == 128
+    assert len(d["ate_per_sequence_m"]) == 5 and max(d["ate_per_sequence_m"]) < 0.1
+    assert d["ate_vs_ref_m"] < 1e-2 and abs(d["ate_ref_m"] - d["ate_hip_sample_m"]) < 1e-2
+    assert d["cpu_baseline"]["kind"] in ("reference", "port")

@@ -71,6 +71,15 @@ def test_cfg3_streams_give_bit_identical_results(capi, cfg3_trajs):
         for b in range(c["B"]):
             for x, y in zip(snap[b], ref[b]):
                 assert np.array_equal(x, y), (ns, b)
+    # inputs uploaded per frame inside the run (msckf_hip_run_frames_streamed, copy stream + double buffering): same bits
+    for ns in (1, 2):
+        bt = _resident_batch(capi, cfg3_trajs, c["N"], c["F"], c["nf"], 32, capi.F32, streams=ns)
+        bt.run_frames_streamed(0, 11); bt.run_frames_streamed(11, c["nf"]); bt.sync()
+        snap = _snapshot(bt, c["B"])
+        bt.close()
+        for b in range(c["B"]):
+            for x, y in zip(snap[b], ref[b]):
+                assert np.array_equal(x, y), ("streamed", ns, b)
 
 
 def test_cfg3_batch_of_64_vs_oracle(capi, po, cfg3_trajs):
