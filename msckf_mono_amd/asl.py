@@ -156,17 +156,50 @@ def initial_state(ds, start_ns=None):
     return np.concatenate([q, gt["b_g"][i], v, gt["b_a"][i], p, sc.GRAVITY, q, v, p])
 
 
+def _from_two_vectors(a, b):
+    """Eigen::Quaternion::FromTwoVectors(a, b): the rotation that sends the direction of a onto the direction of b, (w,x,y,z)"""
+    v0 = np.asarray(a, float) / np.linalg.norm(a); v1 = np.asarray(b, float) / np.linalg.norm(b)
+    c = float(v1 @ v0)
+    if c < -1.0 + 1e-12:                       # opposite vectors: any axis orthogonal to v0 (Eigen takes it from an SVD)
+        axis = np.cross(v0, [1.0, 0.0, 0.0]) if abs(v0[0]) < 0.9 else np.cross(v0, [0.0, 1.0, 0.0])
+        axis /= np.linalg.norm(axis)
+        return np.array([0.0, axis[0], axis[1], axis[2]])
+    axis = np.cross(v0, v1)
+    sq = np.sqrt((1.0 + c) * 2.0)
+    return np.concatenate([[sq * 0.5], axis / sq])
+
+
+def standstill_initial_state(ds, calib_start_ns, calib_end_ns):
+    """First IMU state of the no-ground-truth runner (datasets/asl_msckf_no_ground_truth.cpp:136-173): gyro bias = mean
+    gyro reading over the stand-still interval, attitude from the mean accelerometer reading against gravity
+    (q_IG = FromTwoVectors(-g, a_mean)), accelerometer bias = q_IG g + a_mean, zero position and velocity."""
+    m = (ds["imu_t"] >= calib_start_ns) & (ds["imu_t"] < calib_end_ns)
+    if not np.any(m):
+        raise ValueError("no IMU samples inside the stand-still interval")
+    rd = np.asarray(ds["readings"])[m]
+    gyro_mean, accel_mean = rd[:, 0:3].mean(0), rd[:, 3:6].mean(0)
+    g = np.array(sc.GRAVITY, dtype=float)
+    q = _from_two_vectors(-g, accel_mean)
+    w, x, y, z = q
+    u = np.array([x, y, z]); uv = np.cross(u, g); uv = uv + uv
+    qg = g + w * uv + np.cross(u, uv)          # q_IG * g (Eigen _transformVector)
+    b_a = qg + accel_mean
+    zero = np.zeros(3)
+    return np.concatenate([q, gyro_mean, zero, b_a, zero, g, q, zero, zero])
+
+
 # stage names of the reference's StageTiming message (msg/StageTiming.msg: string[] stages, float64[] times) as the
 # ASL runner records them, datasets/asl_msckf.cpp:207-212 (TSTART/TEND/TRECORD) and :229-296
 STAGES = ("imu_prop", "msckf_augment_state", "msckf_update", "msckf_add_features", "msckf_marginalize",
           "msckf_prune_redundant", "msckf_prune_empty_states")
 
 
-def run(ds, flt, cfg, start_ns=None, prune_redundant=False, on_frame=None, stage_timing=None):
+def run(ds, flt, cfg, start_ns=None, prune_redundant=False, on_frame=None, stage_timing=None, standstill=None):
     """Drive `flt` (any object with the reference's member names: msckf_mono_amd.capi.MSCKF or the oracle) through the
     dataset in the reference's call order.  Returns the list of (timestamp_ns, imu_state29) after every image.
     `stage_timing`: a list that receives one StageTiming record per image, {"stamp": ns, "stages": [...], "times":
-    [...]} with the reference's stage names and wall-clock seconds; device work is synchronised at the end of every
+    [...]} with the reference's stage names and wall-clock seconds; `standstill` = (calib_start_ns, calib_end_ns) starts
+    from the stand-still initialisation of asl_msckf_no_ground_truth.cpp instead of ground truth, at calib_end_ns; device work is synchronised at the end of every
     stage (`flt.sync()` when the filter has one) so that the numbers compare with the reference's synchronous CPU
     calls.  Timing changes nothing in the results."""
     import time
@@ -182,7 +215,11 @@ def run(ds, flt, cfg, start_ns=None, prune_redundant=False, on_frame=None, stage
         rec["stages"].append(name); rec["times"].append(time.perf_counter() - t0)
         return r
 
-    flt.initialize(cfg, initial_state(ds, start_ns))
+    if standstill is not None:
+        flt.initialize(cfg, standstill_initial_state(ds, standstill[0], standstill[1]))
+        start_ns = standstill[1] if start_ns is None else start_ns
+    else:
+        flt.initialize(cfg, initial_state(ds, start_ns))
     cam_set = set(int(t) for t in ds["cam_t"])
     out = []
     state_k = 0

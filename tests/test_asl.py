@@ -80,6 +80,50 @@ def test_default_parameters_match_the_reference_runner(dataset):
     assert cfg["Q_imu_diag"][0] == 1e-5 and cfg["Q_imu_diag"][3] == 3.6733e-5 and cfg["Q_imu_diag"][6] == 1e-3 and cfg["Q_imu_diag"][9] == 7e-4
 
 
+def test_standstill_initialisation_of_the_no_ground_truth_runner():
+    """asl_msckf_no_ground_truth.cpp:136-173: biases and attitude from the mean IMU reading over a stand-still interval"""
+    rng = np.random.default_rng(1)
+    # a tilted, stationary IMU: specific force = C_IG (-g), plus biases and noise
+    ang = 0.2
+    C_IG = np.array([[np.cos(ang), 0, -np.sin(ang)], [0, 1, 0], [np.sin(ang), 0, np.cos(ang)]])
+    g = np.array([0.0, 0.0, -9.81])
+    bg, ba = np.array([0.002, -0.001, 0.003]), np.array([0.02, 0.01, -0.03])
+    n = 400
+    rd = np.zeros((n, 7)); rd[:, 0:3] = bg + 1e-4 * rng.standard_normal((n, 3)); rd[:, 3:6] = C_IG @ (-g) + ba + 1e-3 * rng.standard_normal((n, 3)); rd[:, 6] = 0.005
+    ds = dict(imu_t=np.arange(n, dtype=np.int64) * 5_000_000, readings=rd)
+    s = asl.standstill_initial_state(ds, 0, 300 * 5_000_000)
+    assert np.allclose(s[4:7], rd[:300, 0:3].mean(0)) and np.all(s[7:10] == 0) and np.all(s[13:16] == 0)   # b_g, v, p
+    q = s[0:4]; assert abs(np.linalg.norm(q) - 1) < 1e-12
+    R = H.q_to_rot(q)
+    am = rd[:300, 3:6].mean(0)
+    assert np.allclose(R @ (-g) / 9.81, am / np.linalg.norm(am), atol=1e-12)        # q_IG sends -g onto the measured specific force
+    assert np.allclose(s[10:13], R @ g + am) and np.linalg.norm(s[10:13]) < 0.1   # b_a = q_IG g + a_mean: |a_mean| - 9.81 along gravity
+    assert np.array_equal(s[19:23], q)                                               # null-space anchors start at the state
+    with pytest.raises(ValueError):
+        asl.standstill_initial_state(ds, 10**12, 2 * 10**12)
+
+
+@pytest.mark.gpu
+def test_stage_timing_on_the_hip_path(dataset, tmp_path):
+    """StageTiming (msg/StageTiming.msg, asl_msckf.cpp:207-212) recorded on the HIP path: one record per image, the
+    reference's stage names, a device sync per stage, and the timed run gives bit-identical states to the untimed one."""
+    from msckf_mono_amd import capi
+    tr, ds = dataset
+    rec = []
+    a = capi.MSCKF(capi.F32, n_cap=16, f_cap=64, m_cap=16)
+    b = capi.MSCKF(capi.F32, n_cap=16, f_cap=64, m_cap=16)
+    out_t = asl.run(ds, a, tr.cfg, prune_redundant=True, stage_timing=rec)
+    out = asl.run(ds, b, tr.cfg, prune_redundant=True)
+    assert len(rec) == len(out) == len(ds["cam_t"])
+    for r, (t, _) in zip(rec, out):
+        assert r["stamp"] == t and tuple(r["stages"]) == asl.STAGES and all(x > 0 for x in r["times"])
+    assert all(np.array_equal(x[1], y[1]) for x, y in zip(out_t, out))
+    per_stage = {st: float(np.median([r["times"][i] for r in rec])) for i, st in enumerate(asl.STAGES)}
+    assert per_stage["msckf_marginalize"] < 0.05 and per_stage["imu_prop"] < 0.05      # seconds per image, single filter
+    asl.write_stage_timing(str(tmp_path / "stage_timing.csv"), rec)
+    assert (tmp_path / "stage_timing.csv").read_text().count("\n") == 1 + len(rec) * len(asl.STAGES)
+
+
 @pytest.mark.gpu
 def test_runner_on_the_hip_path(dataset, oracle_lib):
     po = oracle_lib
