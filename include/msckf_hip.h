@@ -46,7 +46,9 @@ extern "C" {
 
 typedef struct msckf_hip_batch* msckf_hip_handle;
 
-enum { MSCKF_HIP_F32 = 0, MSCKF_HIP_F64 = 1 };
+/* MSCKF_HIP_F16H_F32P (BASELINE.json configs[4]): state, covariance and every accumulation in f32 (Gram matrix in f64),
+ * the 2 x 6 measurement Jacobian blocks H_x rounded to and stored as fp16. */
+enum { MSCKF_HIP_F32 = 0, MSCKF_HIP_F64 = 1, MSCKF_HIP_F16H_F32P = 2 };
 
 /* ---- lifecycle --------------------------------------------------------------------------------------- */
 /* B trajectories; capacity n_cap camera states (>= max(max_cam_states, max_track_length)+1),

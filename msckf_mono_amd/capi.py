@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MSCKF_HIP_LIB", os.path.join(_HERE, "libmsckf_hip.so"))   # override: A/B experiments only
 _LIB = None
 
-F32, F64 = 0, 1
+F32, F64, F16H = 0, 1, 2   # F16H: fp16 measurement Jacobian / f32 state + covariance (MSCKF_HIP_F16H_F32P)
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 _up = C.POINTER(C.c_uint64)

@@ -13,6 +13,7 @@
 #define MSCKF_DEV_COMMON_H
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 
 namespace msckf {
 
@@ -59,6 +60,10 @@ struct Dev {
   int gate_early;   // exact early accept of the chi-square gate by the bound |r_o|^2 / sigma^2 (k_feature), off by default
   // per-track products of k_feature
   int* trk_status; S* trk_pf; S* trk_gamma; S* trk_Hx; S* trk_V; S* trk_Zf; S* trk_ro; int* trk_first;
+  // dtype MSCKF_HIP_F16H_F32P (BASELINE.json configs[4]: fp16 Jacobian / fp32 covariance): the 2 x 6 measurement Jacobian
+  // blocks are rounded to fp16 where they are formed and stored as fp16 (trk_Hx16 replaces trk_Hx); every consumer sees
+  // the rounded values, all accumulation stays in f32 / f64
+  int h16; __half* trk_Hx16;
   // k_select
   int* row_start; int* trk_order; int* stats;
   // TSQR
@@ -79,6 +84,11 @@ struct Dev {
   // prune
   int* keep; int* nkeep;
 };
+
+// measurement Jacobian element idx of the per-track blocks [track][m_cap][12]
+template <class S> __device__ __forceinline__ S ld_hx(const Dev<S>& d, long idx) {
+  return d.h16 ? (S)__half2float(d.trk_Hx16[idx]) : d.trk_Hx[idx];
+}
 
 // ---------------------------------------------------------------- small math (all S-templated)
 template <class S> struct V3 { S x, y, z; };

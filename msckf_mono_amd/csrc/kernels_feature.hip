@@ -365,6 +365,10 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
     r[0] *= wu; r[1] *= wv;
     for (int k = 0; k < 6; ++k) { hx[0][k] *= wu; hx[1][k] *= wv; }
     for (int k = 0; k < 3; ++k) { hf[0][k] *= wu; hf[1][k] *= wv; }
+    if (d.h16) {   // fp16 Jacobian (dtype MSCKF_HIP_F16H_F32P): rounded here, every consumer below sees the rounded blocks
+      for (int i = 0; i < 2; ++i) for (int k = 0; k < 6; ++k) hx[i][k] = (S)__half2float(__float2half_rn((float)hx[i][k]));
+      for (int i = 0; i < 2; ++i) for (int k = 0; k < 3; ++k) hf[i][k] = -hx[i][3 + k];
+    }
   }
 
   // ---- information-form compression (compress == 1): B = Q_f^T [H_x | r] in f64.  H_o^T H_o = H_x^T H_x - B^T B
@@ -561,9 +565,10 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
 
   // ---- publish the compact representation of the projected block
   if (!(fdbg & 64)) {
-    S* oHx = d.trk_Hx + (tb * m_cap) * 12;
-    if (act)
-      for (int i = 0; i < 2; ++i) for (int k = 0; k < 6; ++k) oHx[lane * 12 + i * 6 + k] = hx[i][k];
+    if (act) {
+      if (d.h16) { __half* oH = d.trk_Hx16 + (tb * m_cap) * 12; for (int i = 0; i < 2; ++i) for (int k = 0; k < 6; ++k) oH[lane * 12 + i * 6 + k] = __float2half_rn((float)hx[i][k]); }
+      else { S* oHx = d.trk_Hx + (tb * m_cap) * 12; for (int i = 0; i < 2; ++i) for (int k = 0; k < 6; ++k) oHx[lane * 12 + i * 6 + k] = hx[i][k]; }
+    }
     if (d.compress) {
       // B scattered to state columns ([3][ldR] f64, zero where unobserved, column n = Q_f^T r), the whitened
       // residual and the slot -> observation map for the block-diagonal part of the Gram matrix

@@ -56,11 +56,11 @@ __global__ __launch_bounds__(256) void k_gram(Dev<S> d, int b0, int npairs, int 
       const long tb = (long)b * f_cap + order[p];
       const int i = d.trk_inv[tb * d.n_cap + s];
       if (i < 0) continue;
-      const S* h = d.trk_Hx + (tb * m_cap + i) * 12;
+      const long h0i = (tb * m_cap + i) * 12;
       const S* rw = d.trk_rw + tb * 2 * m_cap + 2 * i;
       double h0[6], h1[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { h0[k] = (double)h[k]; h1[k] = (double)h[6 + k]; }
+      for (int k = 0; k < 6; ++k) { h0[k] = (double)ld_hx(d, h0i + k); h1[k] = (double)ld_hx(d, h0i + 6 + k); }
       const double r0 = (double)rw[0], r1 = (double)rw[1];
       int e = 0;
 #pragma unroll

@@ -178,13 +178,13 @@ __global__ __launch_bounds__(64 * QR_NW) void k_qr_update(Dev<S> d, int b0, int 
           }
           t_prev = t;
         }
-        const S* Hx = d.trk_Hx + (tb * m_cap + (row >> 1)) * 12 + (row & 1) * 6;
+        const long hx0 = (tb * m_cap + (row >> 1)) * 12 + (row & 1) * 6;
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
           const int col = lane + 64 * j;
           S val = -(v0 * zf[0][j] + v1 * zf[1][j] + v2 * zf[2][j]);
           const unsigned dcol = (unsigned)(col - c0);
-          if (dcol < 6u) val += Hx[dcol];
+          if (dcol < 6u) val += ld_hx(d, hx0 + dcol);
           if (col == n) val = ro;
           Bv[r][j] = live ? val : S(0);
         }

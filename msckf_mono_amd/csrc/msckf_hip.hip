@@ -54,6 +54,7 @@ struct HostTraj {
 struct BatchBase {
   virtual ~BatchBase() {}
   int B = 0, n_cap = 0, f_cap = 0, m_cap = 0, dtype = 0, device = 0;
+  bool h16 = false;   // dtype MSCKF_HIP_F16H_F32P: fp16 measurement Jacobian, f32 state and covariance
   std::vector<HostTraj> traj;
   virtual int init(int b, const double* cam, const double* noise, const double* params, const double* imu) = 0;
   virtual int propagate(int b0, int nb, const double* rd, int K) = 0;
@@ -159,7 +160,9 @@ struct Batch : BatchBase {
     rc |= dalloc(&d.imu, Bz * IMU_STRIDE); rc |= dalloc(&d.cam, Bz * n_cap * CAM_STRIDE); rc |= dalloc(&d.prm, Bz * PRM_STRIDE);
     rc |= dalloc(&d.P, Bz * pl); rc |= dalloc(&d.Ptmp, Bz * pl); rc |= dalloc(&d.ncam, Bz); rc |= dalloc(&d.n_resid, Bz);
     rc |= dalloc(&d.trk_status, TF); rc |= dalloc(&d.trk_pf, TF * 4); rc |= dalloc(&d.trk_gamma, TF);
-    rc |= dalloc(&d.trk_Hx, TF * m_cap * 12); rc |= dalloc(&d.trk_V, TF * 2 * m_cap * 4); rc |= dalloc(&d.trk_Zf, TF * 3 * (size_t)d.ldR);
+    d.h16 = h16 ? 1 : 0; d.trk_Hx = nullptr; d.trk_Hx16 = nullptr;
+    if (h16) rc |= dalloc(&d.trk_Hx16, TF * m_cap * 12); else rc |= dalloc(&d.trk_Hx, TF * m_cap * 12);
+    rc |= dalloc(&d.trk_V, TF * 2 * m_cap * 4); rc |= dalloc(&d.trk_Zf, TF * 3 * (size_t)d.ldR);
     rc |= dalloc(&d.trk_ro, TF * 2 * m_cap); rc |= dalloc(&d.trk_first, TF);
     rc |= dalloc(&d.row_start, Bz * (f_cap + 1)); rc |= dalloc(&d.trk_order, TF); rc |= dalloc(&d.stats, Bz * STAT_STRIDE);
     rc |= dalloc(&d.Rbuf, Bz * d.nchunk * (size_t)d.n6cap * d.ldR);
@@ -1147,11 +1150,12 @@ int msckf_hip_create(int B, int n_cap, int f_cap, int m_cap, int dtype, int devi
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(-ENODEV, "no HIP device available (this library has no CPU fallback)");
   if (device < 0 || device >= ndev) return fail(-ENODEV, "HIP device index out of range");
   BatchBase* b = nullptr;
-  if (dtype == MSCKF_HIP_F32) b = new Batch<float>();
+  if (dtype == MSCKF_HIP_F32 || dtype == MSCKF_HIP_F16H_F32P) b = new Batch<float>();
   else if (dtype == MSCKF_HIP_F64) b = new Batch<double>();
-  else return fail(-EINVAL, "dtype must be MSCKF_HIP_F32 or MSCKF_HIP_F64");
+  else return fail(-EINVAL, "dtype must be MSCKF_HIP_F32, MSCKF_HIP_F64 or MSCKF_HIP_F16H_F32P");
   b->B = B; b->n_cap = n_cap; b->f_cap = f_cap; b->m_cap = m_cap; b->dtype = dtype; b->device = device;
-  int rc = dtype == MSCKF_HIP_F32 ? static_cast<Batch<float>*>(b)->create() : static_cast<Batch<double>*>(b)->create();
+  b->h16 = dtype == MSCKF_HIP_F16H_F32P;
+  int rc = dtype != MSCKF_HIP_F64 ? static_cast<Batch<float>*>(b)->create() : static_cast<Batch<double>*>(b)->create();
   if (rc) { delete b; return rc; }
   *out = reinterpret_cast<msckf_hip_handle>(b);
   return 0;

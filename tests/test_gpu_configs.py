@@ -140,6 +140,55 @@ def test_cfg5_geometry_vs_oracle(capi, po):
     bt.close()
 
 
+def test_fp16_jacobian_dtype(capi, po):
+    """MSCKF_HIP_F16H_F32P (BASELINE.json configs[4]: fp16 Jacobian / fp32 covariance): the measurement Jacobian blocks are
+    rounded to fp16 (11-bit significand: ~5e-4 relative per entry) where they are formed, everything else stays f32.
+    (1) the rounding is active and bounded: against the plain float filter on the same inputs, per update, attitude /
+    position / velocity move by < 1e-3, the covariance and the accelerometer bias by < 3e-2, the gyro bias by < 1e-1
+    (measured at the 10-camera window: 1e-4, 5e-5, 2e-4, 9e-4, 3e-3, 5e-2; at the 60-camera window P moves by 1.0e-2); (2) cfg5 geometry (60-camera window, 500 tracks): the same envelope
+    against the float oracle -- SURVEY 8d quotes 1e-2 for this configuration, "reported, not gated" -- with equal gate
+    decisions."""
+    def envelope(e):
+        assert max(e["q"], e["p"], e["v"], e["cam_q"], e["cam_p"]) < 1e-3 and max(e["P"], e["Pii"], e["ba"]) < 3e-2 and e["bg"] < 1e-1, e
+    N, F, nf = 10, 50, 20
+    tr = sc.Trajectory(2, 4, N, F, nf)
+    a, b = capi.Batch(1, N, F, N, capi.F32), capi.Batch(1, N, F, N, capi.F16H)
+    a.initialize(0, tr.cfg, tr.imu0); b.initialize(0, tr.cfg, tr.imu0)
+    worst = 0.0
+    for k in range(nf):
+        if k:   # teacher-forced from the float filter
+            b.set_covariance(0, a.covariance(0)); b.set_imu_state(0, a.imu_state(0))
+            for i, c in enumerate(a.cam_states(0)[0]):
+                b.set_cam_pose(0, i, c)
+            b.set_num_residualized(0, a.num_residualized(0))
+        H.device_frame(a, 0, tr, k, N); H.device_frame(b, 0, tr, k, N)
+        e = H.state_errors(b.imu_state(0), a.imu_state(0), b.cam_states(0)[0], a.cam_states(0)[0], b.covariance(0), a.covariance(0))
+        envelope(e)
+        worst = max(worst, H.worst(e))
+    assert worst > 1e-6, worst        # the rounding is really applied
+    a.close(); b.close()
+    N, F, nf, B = 60, 500, 63, 2
+    trajs = [sc.Trajectory(5, b2, N, F, nf) for b2 in range(B)]
+    bt = _resident_batch(capi, trajs, N, F, nf, 60, capi.F16H)
+    k0 = nf - 1
+    bt.run_frames(0, k0); bt.sync()
+    oracles = []
+    for b2 in range(B):
+        o = po.Oracle(po.F32, po.LEAN)
+        o.initialize(trajs[b2].cfg, trajs[b2].imu0)
+        H.copy_device_to_oracle(bt, b2, o)
+        oracles.append(o)
+    bt.run_frames(k0, k0 + 1); bt.sync()
+    for b2 in range(B):
+        o = oracles[b2]
+        H.oracle_frame(o, trajs[b2], k0, N)
+        so, sd = o.lastStats(), bt.last_stats(b2)
+        assert so["n_passed"] == sd["n_passed"] > 400, (so, sd)
+        e = H.state_errors(bt.imu_state(b2), o.getImuState(), bt.cam_states(b2)[0], o.getCamStates()[0], bt.covariance(b2), o.getCovariance())
+        envelope(e)
+    bt.close()
+
+
 # ------------------------------------------------------------------------------------------------ ill-conditioned stack
 def test_low_parallax_double_both_routes_vs_oracle(capi, po):
     """Landmarks 150-600 m away (sub-pixel parallax per frame): the stacked Jacobian is as ill-conditioned as tracks that
