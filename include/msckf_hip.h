@@ -156,6 +156,11 @@ int msckf_hip_set_compression(msckf_hip_handle h, int route);
  * Joseph sequence K, (I - K T_H) P (I - K T_H)^T + K R_n K^T, symmetrise.  Identical in exact arithmetic, equal to
  * rounding in the tests. */
 int msckf_hip_set_covariance_update(msckf_hip_handle h, int form);
+/* run_frames: launch a frame's per-track kernel on a side stream concurrently with the same frame's propagate + augmentState
+ * whenever no track of the frame observes the camera that augmentState adds (it then depends only on what the previous
+ * frame left behind).  Bit-identical results; OFF by default -- on MI355X at the benchmark configuration the per-track
+ * kernel starves the latency-bound propagate/augment workgroups of CUs (100 k -> 82 k updates/s). */
+int msckf_hip_set_feature_overlap(msckf_hip_handle h, int on);
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,7 @@ SYMBOLS = [
     "msckf_hip_augment_range", "msckf_hip_marginalize_range", "msckf_hip_drop_oldest_range", "msckf_hip_scenario_alloc",
     "msckf_hip_scenario_set", "msckf_hip_scenario_commit", "msckf_hip_run_frames", "msckf_hip_run_frames_streamed", "msckf_hip_sync",
     "msckf_hip_profile_enable", "msckf_hip_profile_read", "msckf_hip_set_streams", "msckf_hip_set_gate_early_accept",
-    "msckf_hip_set_compression", "msckf_hip_set_covariance_update", "msckf_hip_get_pruned_states", "msckf_hip_get_cam_meta", "msckf_hip_get_tracked_feature_ids",
+    "msckf_hip_set_compression", "msckf_hip_set_covariance_update", "msckf_hip_set_feature_overlap", "msckf_hip_get_pruned_states", "msckf_hip_get_cam_meta", "msckf_hip_get_tracked_feature_ids",
 ]
 
 
@@ -253,6 +253,9 @@ class Batch:
     def set_covariance_update(self, form):
         """0 square-root gain form P - W W^T (default), 1 the reference's Joseph sequence"""
         _chk(self.L.msckf_hip_set_covariance_update(self.h, int(form)))
+
+    def set_feature_overlap(self, on):
+        _chk(self.L.msckf_hip_set_feature_overlap(self.h, 1 if on else 0))
 
     def set_gate_early_accept(self, on):
         _chk(self.L.msckf_hip_set_gate_early_accept(self.h, 1 if on else 0))

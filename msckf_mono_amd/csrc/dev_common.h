@@ -57,6 +57,10 @@ struct Dev {
   // mode 1 (second update of pruneRedundantStates, msckf.h:545-614): every track comes with its stored feature
   // position trk_pfin[b*f_cap+t][4] -- no checkMotion / triangulation, no Q4 bookkeeping
   int mode; const S* trk_pfin;
+  // k_feature launched BEFORE this frame's augmentState on a side stream (run_frames overlaps it with propagate + augment
+  // when no track of the frame observes the newest camera): it then takes the window size from ncam_upd (left by the previous
+  // frame's prune: ncam after prune + 1) instead of ncam, which augmentState is incrementing meanwhile
+  int ncam_bias; int* ncam_upd;
   int gate_early;   // exact early accept of the chi-square gate by the bound |r_o|^2 / sigma^2 (k_feature), off by default
   // per-track products of k_feature
   int* trk_status; S* trk_pf; S* trk_gamma; S* trk_Hx; S* trk_V; S* trk_Zf; S* trk_ro; int* trk_first;

@@ -582,7 +582,7 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
         oI[slot] = (signed char)lane;
         d.trk_rw[tb * 2 * m_cap + row0] = r[0]; d.trk_rw[tb * 2 * m_cap + row0 + 1] = r[1];
       }
-      if (lane < 3) oB[(long)lane * d.ldR + 6 * d.ncam[b]] = lane == 0 ? cq[0] : (lane == 1 ? cq[1] : cq[2]);
+      if (lane < 3) oB[(long)lane * d.ldR + 6 * (d.ncam_bias ? d.ncam_upd[b] : d.ncam[b])] = lane == 0 ? cq[0] : (lane == 1 ? cq[1] : cq[2]);
     } else {
       S* oV = d.trk_V + (tb * 2 * m_cap) * 4;
       S* oZ = d.trk_Zf + tb * 3 * (long)d.ldR;   // Z scattered to state columns: [3][ldR], zero where unobserved

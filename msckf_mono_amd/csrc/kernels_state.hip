@@ -339,6 +339,9 @@ template <class S>
 __global__ __launch_bounds__(64) void k_prune_cams(Dev<S> d, int b0) {
   const int b = b0 + blockIdx.x, lane = threadIdx.x;
   const int nk = d.nkeep[b], n = d.ncam[b];
+  // window size of the NEXT update (after its augmentState): read by a k_feature that run_frames launches concurrently with
+  // that augmentState, when ncam itself is in flux
+  if (lane == 0) d.ncam_upd[b] = min(nk, n) + 1;
   if (nk >= n) return;
   const int* keep = d.keep + (long)b * d.n_cap;
   S* cam = d.cam + (long)b * d.n_cap * CAM_STRIDE;

@@ -281,6 +281,55 @@ def test_resident_scenario_equals_per_call(capi):
         assert np.array_equal(a.cam_states(b)[0], c.cam_states(b)[0])
 
 
+def test_resident_scenario_with_tracks_on_the_newest_camera(capi):
+    """With msckf_hip_set_feature_overlap run_frames launches k_feature concurrently with the frame's propagate +
+    augmentState when no track observes the camera that augmentState adds; a track terminated by max_track_length DOES observe it (msckf.h:246-262), and then
+    the frame must take the ordered path.  Frames of both kinds, resident run vs per-call API: bit-identical."""
+    N, F, nf, B = 8, 12, 14, 2
+    trs = [sc.Trajectory(2, 80 + b, N, F, nf) for b in range(B)]
+    frames = []
+    for b, tr in enumerate(trs):
+        fl = []
+        for k in range(nf):
+            fr = dict(tr.frames[k])
+            if len(fr["M"]) and k % 3 == b:       # extend track 0 by an observation in the newest camera (slot Nw - 1)
+                M = fr["M"].copy(); off = np.concatenate([[0], np.cumsum(M)])
+                pt = tr.landmarks[k][0]
+                pc = tr.C_CG[k] @ (pt - tr.p_C[k])
+                if pc[2] > 0.5 and M[0] < N - 1:
+                    z = pc[:2] / pc[2]
+                    slots = np.insert(fr["slots"], off[1], fr["Nw"] - 1).astype(np.int32)
+                    obs = np.insert(fr["obs"], off[1], z, axis=0)
+                    M[0] += 1
+                    fr = dict(Nw=fr["Nw"], M=M, slots=slots, obs=obs)
+            fl.append(fr)
+        frames.append(fl)
+    assert any(len(fr["M"]) and fr["slots"].max() == fr["Nw"] - 1 for fl in frames for fr in fl)
+    a, c = capi.Batch(B, N, F, N, capi.F64), capi.Batch(B, N, F, N, capi.F64)
+    c.scenario_alloc(nf, sc.IMU_PER_FRAME)
+    for b, tr in enumerate(trs):
+        a.initialize(b, tr.cfg, tr.imu0); c.initialize(b, tr.cfg, tr.imu0)
+        for k in range(nf):
+            fr = frames[b][k]
+            c.scenario_set(k, b, tr.imu_for_frame(k), fr["M"], fr["slots"], fr["obs"], 1 if fr["Nw"] == N else 0)
+    c.scenario_commit()
+    c.set_streams(2)
+    c.set_feature_overlap(True)
+    c.run_frames(0, 5); c.run_frames(5, nf); c.sync()
+    for b, tr in enumerate(trs):
+        for k in range(nf):
+            fr = frames[b][k]
+            a.propagate_range(b, 1, tr.imu_for_frame(k)); a.augment_range(b, 1)
+            a.set_tracks(b, fr["M"], fr["slots"], fr["obs"])
+            if len(fr["M"]):
+                a.marginalize_range(b, 1)
+            if a.num_cam_states(b) == N:
+                a.drop_oldest_range(b, 1, 1)
+        assert np.array_equal(a.covariance(b), c.covariance(b)), b
+        assert np.array_equal(a.imu_state(b), c.imu_state(b)), b
+        assert a.last_stats(b) == c.last_stats(b) and a.last_stats(b)["n_passed"] > 0
+
+
 # ----------------------------------------------------------------------------------- edge cases
 def _pair(capi, po, prec, N, F, nf, cfg=None, traj=0, **kw):
     cd, od = _dt(capi, po, prec)
