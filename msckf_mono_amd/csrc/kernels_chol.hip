@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void k_chol_mfma(Dev<SO> d, int b0) {
   const int b = b0 + (MODE == CH_GAIN ? blockIdx.y : blockIdx.x), part = MODE == CH_GAIN ? (int)blockIdx.x : 0;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int pi = w >> 1, pj = w & 1;
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: win instruction arbitration against co-resident throughput waves of the other slice
   int* st = d.stats + (long)b * STAT_STRIDE;
   if (st[STAT_MROWS] == 0) return;
   const int N = d.ncam[b], n = 6 * N, D = 15 + n;

@@ -208,6 +208,7 @@ template <class S, int NBN>
 __global__ __launch_bounds__(256) void k_chol_T(Dev<S> d, int b0) {
   constexpr int G = 16;
   const int b = b0 + blockIdx.x, tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: win instruction arbitration against co-resident throughput waves of the other slice
   int* st = d.stats + (long)b * STAT_STRIDE;
   if (st[STAT_MROWS] == 0) return;
   const int N = d.ncam[b], n = 6 * N, ldL = d.ldR;

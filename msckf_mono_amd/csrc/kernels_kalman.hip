@@ -664,6 +664,7 @@ template <class S, int NBN, int NPART>
 __global__ __launch_bounds__(256) void k_gain_w(Dev<S> d, int b0) {
   constexpr int G = 16, NBD = NBN + 1, NBQ = (NBD + NPART - 1) / NPART, NBW = NBQ + 1;
   const int b = b0 + blockIdx.y, part = blockIdx.x, tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: win instruction arbitration against co-resident throughput waves of the other slice
   if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
   const KView<S> v = make_view(d, b);
   const int n = v.n, D = v.D;

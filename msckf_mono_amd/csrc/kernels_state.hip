@@ -80,16 +80,35 @@ __device__ __forceinline__ void imu_rk(const S* st, V3<S> g, V3<S> om, V3<S> ac,
 }
 
 // K queued IMU samples in one launch, one workgroup (4 wavefronts) per trajectory, samples in groups of PG:
-//   A  one lane integrates the IMU *state* chain of the group (cheap, sequential)           :105, :1425-1467
-//   B  the Phi_k = expm(F_k dT) of the group are built in parallel, one wavefront per sample: F dT is
-//      assembled from its five 3x3 blocks (calcF :885-889), summed as a Taylor series until the terms vanish
-//      (replaces Eigen's Pade, :111 -- equal to working precision), then OC-patched (:116-132)
-//   C  wavefront 0 runs the sequential covariance chain P_II <- sym(Phi (P_II + G Q G^T dT) Phi^T) (:134,143),
-//      wavefront 1 accumulates Phi_total = Phi_K ... Phi_1 alongside
+//   A  IMU *state* chain (:105, :1425-1467): the RK step is a linear map of the quaternion that depends on the reading only
+//      (the biases are constant while propagating), so the maps M_s are built in parallel and one thread walks
+//      q_{s+1} = normalize(M_s q_s); velocity and position follow from the per-sample rotations
+//   B  Phi_s = expm(F_s dT), one thread per sample: F dT is assembled from its five 3x3 blocks (calcF :885-889) and its
+//      exponential reduces to three series in the 3x3 matrix -[w^ x] dT (replaces Eigen's Pade, :111 -- the same Taylor
+//      series, equal to working precision), then OC-patched (:116-132)
+//   C  the sequential chains P_II <- sym(Phi (P_II + G Q G^T dT) Phi^T) (:134,143) and Phi_total = Phi_K ... Phi_1 advance
+//      together, one 15 x 15 element per thread
 //   D  P_IC <- Phi_total P_IC for all camera columns, both halves of the symmetric storage    (:144)
+#ifdef MSCKF_ABLATE
+// phase timers of the -DMSCKF_ABLATE build (scripts/chol_phases.py): shader-clock cycles of workgroup 0, thread 0:
+// 0 load, 1 state chain, 2 Phi series, 3 P_II / Phi_total chains, 4 write back + P_IC, 5 launches
+__device__ unsigned long long g_prop_cycles[8];
+#define PR_TICK(slot) do { if (tid == 0) { const long long t_ = clock64(); pcyc[slot] += t_ - ptl; ptl = t_; } } while (0)
+void prop_cycles_read(unsigned long long* out8, int reset) {
+  (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_prop_cycles), sizeof(unsigned long long) * 8);
+  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prop_cycles), z, sizeof(z)); }
+}
+#else
+#define PR_TICK(slot) do {} while (0)
+#endif
+
 template <class S>
 __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* readings, long rd_stride, int K) {
   const int b = b0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: win instruction arbitration against co-resident throughput waves of the other slice
+#ifdef MSCKF_ABLATE
+  long long pcyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ptl = clock64();
+#endif
   __shared__ S sState[(PG + 1) * SST];
   __shared__ S sPhi[PG * 225];
   __shared__ S sScr[4][3 * 225];
@@ -100,6 +119,8 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
   __shared__ S sRd[PG * RD_STRIDE];  // the group's IMU samples, staged once (the state chain is one thread: a global
                                       // read per sample would put a memory round trip on every step of the chain)
   __shared__ S sQ[12];
+  __shared__ S sRk[PG * 16];         // RK maps M_s of the group's samples (column-major 4 x 4)
+  __shared__ S sDv[PG * 3];          // velocity increments of the group's samples
   S* imu = d.imu + (long)b * IMU_STRIDE;
   const S* prm = d.prm + (long)b * PRM_STRIDE;
   S* P = d.P + (long)b * d.ld * d.ld;
@@ -121,18 +142,86 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
     const int G = min(PG, K - k0);
     for (int e = tid; e < G * RD_STRIDE; e += 256) sRd[e] = rd[(long)k0 * RD_STRIDE + e];
     __syncthreads();
+    PR_TICK(0);
     const V3<S> g = mk3(sG[0], sG[1], sG[2]);
-    // ---- A: state chain
+    // ---- A: state chain.  The gyro bias does not change during propagation, so the RK step of sample s is a LINEAR map
+    // y -> M_s y of the (JPL-ordered) quaternion that depends on the reading only: thread (s, c) runs the reference's
+    // six stages (propogateImuStateRK, msckf.h:1437-1453) on the unit vector e_c and leaves column c of M_s in LDS; one
+    // thread then walks the chain q_{s+1} = normalize(M_s q_s) (16 FMAs + a normalisation per sample instead of ~300
+    // dependent operations), and the velocity / position chains follow from the per-sample rotations.
+    if (tid < 4 * G) {
+      const int s = tid >> 2, c = tid & 3;
+      const S* r = sRd + s * RD_STRIDE;
+      const S dT = r[6];
+      const V3<S> wh = ld3(r) - mk3(sState[4], sState[5], sState[6]);
+      auto omul = [&](const S* y, S* o) {  // o = 0.5*omegaMat(wh) * y   (matrix_utils.h:20-30)
+        o[0] = S(0.5) * (wh.z * y[1] - wh.y * y[2] + wh.x * y[3]);
+        o[1] = S(0.5) * (-wh.z * y[0] + wh.x * y[2] + wh.y * y[3]);
+        o[2] = S(0.5) * (wh.y * y[0] - wh.x * y[1] + wh.z * y[3]);
+        o[3] = S(0.5) * (-wh.x * y[0] - wh.y * y[1] - wh.z * y[2]);
+      };
+      S y0[4] = {c == 0 ? S(1) : S(0), c == 1 ? S(1) : S(0), c == 2 ? S(1) : S(0), c == 3 ? S(1) : S(0)};
+      S k0[4], k1[4], k2[4], k3[4], k4[4], k5[4], t[4];
+      omul(y0, k0);
+      for (int i = 0; i < 4; ++i) t[i] = y0[i] + (k0[i] / S(4)) * dT;
+      omul(t, k1);
+      for (int i = 0; i < 4; ++i) t[i] = y0[i] + (k0[i] / S(8) + k1[i] / S(8)) * dT;
+      omul(t, k2);
+      for (int i = 0; i < 4; ++i) t[i] = y0[i] + (-k1[i] / S(2) + k2[i]) * dT;
+      omul(t, k3);
+      for (int i = 0; i < 4; ++i) t[i] = y0[i] + (k0[i] * S(3) / S(16) + k3[i] * S(9) / S(16)) * dT;
+      omul(t, k4);
+      for (int i = 0; i < 4; ++i)
+        t[i] = y0[i] + (-k0[i] * S(3) / S(7) + k1[i] * S(2) / S(7) + k2[i] * S(12) / S(7) - k3[i] * S(12) / S(7) + k4[i] * S(8) / S(7)) * dT;
+      omul(t, k5);
+      for (int i = 0; i < 4; ++i) sRk[(s * 4 + c) * 4 + i] = y0[i] + (S(7) * k0[i] + S(32) * k2[i] + S(12) * k3[i] + S(32) * k4[i] + S(7) * k5[i]) * dT / S(90);
+    }
+    __syncthreads();
     if (tid == 0) {
+      Q4<S> q = ldq(sState);
       for (int s = 0; s < G; ++s) {
-        const S* r = sRd + s * RD_STRIDE;
-        imu_rk(sState + s * SST, g, ld3(r), ld3(r + 3), r[6], sState + (s + 1) * SST);
+        const S y0[4] = {-q.x, -q.y, -q.z, q.w};
+        const S* M = sRk + s * 16;                       // column c at M[c*4 ..]
+        S yt[4];
+        for (int i = 0; i < 4; ++i) yt[i] = M[i] * y0[0] + M[4 + i] * y0[1] + M[8 + i] * y0[2] + M[12 + i] * y0[3];
+        Q4<S> qn; qn.w = yt[3]; qn.x = -yt[0]; qn.y = -yt[1]; qn.z = -yt[2];
+        q = qnormalized(qn);
+        stq(sState + (s + 1) * SST, q);
       }
     }
     __syncthreads();
-    // ---- B: Phi of every sample of the group, one wavefront per sample
-    for (int s = w; s < G; s += 4) {
-      S* A = sScr[w]; S* T1 = A + 225; S* T2 = A + 450;
+    if (tid < G) {          // velocity increment of sample s from ITS rotation: (C_IG^T (a - b_a) + g) dT   (:1459-1461)
+      const int s = tid;
+      const S* r = sRd + s * RD_STRIDE;
+      const M3<S> C = q2rot(ldq(sState + s * SST));
+      const V3<S> ah = ld3(r + 3) - mk3(sState[10], sState[11], sState[12]);
+      st3(sDv + 3 * s, r[6] * (multv(C, ah) + g));
+    }
+    __syncthreads();
+    if (tid == 0) {
+      V3<S> v = ld3(sState + 7), p = ld3(sState + 13);
+      const V3<S> bg = ld3(sState + 4), ba = ld3(sState + 10);
+      for (int s = 0; s < G; ++s) {
+        const S dT = sRd[s * RD_STRIDE + 6];
+        const V3<S> vn = v + ld3(sDv + 3 * s), pn = p + (dT * v);      // p uses the OLD velocity (:1465)
+        S* o = sState + (s + 1) * SST;
+        st3(o + 4, bg); st3(o + 7, vn); st3(o + 10, ba); st3(o + 13, pn);
+        v = vn; p = pn;
+      }
+    }
+    __syncthreads();
+    PR_TICK(1);
+    // ---- B: Phi_s = expm(F_s dT) of every sample, one thread per sample.  F dT has five non-zero 3x3 blocks (calcF
+    // :885-889): W = -[w^ x] dT at (th,th), -I dT at (th,bg), X = -C^T [a^ x] dT at (v,th), -C^T dT at (v,ba), I dT at (p,v),
+    // and its powers reduce to powers of the 3x3 matrix W:  with E_m = sum_j W^j / (j+m)!
+    //   Phi(th,bg) = -dT E_1   Phi(v,th) = X E_1   Phi(v,bg) = -dT X E_2   Phi(v,ba) = -C^T dT
+    //   Phi(p,th) = dT X E_2   Phi(p,bg) = -dT^2 X E_3   Phi(p,v) = dT I    Phi(p,ba) = -C^T dT^2 / 2,   identity diagonal
+    // -- the same Taylor series as expm of the 15x15 matrix (Eigen's Pade, msckf.h:111, to working precision), summed until
+    // the terms vanish; Phi(th,th) is overwritten by the observability patch anyway (:117-118).
+    for (int e = tid; e < G * 225; e += 256) { const int q = e % 225; sPhi[e] = (q / 15 == q % 15) ? S(1) : S(0); }
+    __syncthreads();
+    if (tid < G) {
+      const int s = tid;
       S* Phi = sPhi + s * 225;
       const S* st = sState + s * SST;
       const S* r = sRd + s * RD_STRIDE;
@@ -140,42 +229,41 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
       const V3<S> wh = ld3(r) - ld3(st + 4), ah = ld3(r + 3) - ld3(st + 10);
       const M3<S> C = q2rot(ldq(st));
       const M3<S> sw = skew3(wh), sa = skew3(ah);
-      for (int e = lane; e < 225; e += 64) A[e] = 0;
-      wave_sync();
-      if (lane < 9) {
-        const int i = lane / 3, j = lane % 3;
-        A[i * 15 + j] = -sw.m[i][j] * dT;
-        A[i * 15 + 3 + j] = (i == j) ? -dT : S(0);
+      M3<S> W, X, Pw, E1, E2, E3;
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        W.m[i][j] = -sw.m[i][j] * dT;
         S sm = 0;
-        for (int kk = 0; kk < 3; ++kk) sm += C.m[kk][i] * sa.m[kk][j];  // (C^T [a x])_ij
-        A[(6 + i) * 15 + j] = -sm * dT;
-        A[(6 + i) * 15 + 9 + j] = -C.m[j][i] * dT;
-        A[(12 + i) * 15 + 6 + j] = (i == j) ? dT : S(0);
+        for (int kk = 0; kk < 3; ++kk) sm += C.m[kk][i] * sa.m[kk][j];
+        X.m[i][j] = -sm * dT;
+        const S id = (i == j) ? S(1) : S(0);
+        Pw.m[i][j] = id; E1.m[i][j] = id; E2.m[i][j] = id / S(2); E3.m[i][j] = id / S(6);
       }
-      wave_sync();
-      for (int e = lane; e < 225; e += 64) { T1[e] = A[e]; Phi[e] = A[e] + ((e / 15 == e % 15) ? S(1) : S(0)); }
-      wave_sync();
-      S* tc = T1; S* tn = T2;
-      for (int o = 2; o <= 40; ++o) {
-        const S inv = S(1) / S(o);
+      S r1 = 1, r2 = S(0.5), r3 = S(1) / S(6);        // 1/(j+1)!, 1/(j+2)!, 1/(j+3)! for j = 0
+      for (int j = 1; j <= 40; ++j) {
+        Pw = mulm(Pw, W);                              // W^j
+        r1 /= S(j + 1); r2 /= S(j + 2); r3 /= S(j + 3);
         S mx = 0;
-        for (int e = lane; e < 225; e += 64) {
-          const int i = e / 15, j = e % 15;
-          S sm = 0;
-#pragma unroll
-          for (int kk = 0; kk < 15; ++kk) sm += tc[i * 15 + kk] * A[kk * 15 + j];
-          sm *= inv;
-          tn[e] = sm; Phi[e] += sm;
-          const S am = sm < 0 ? -sm : sm;
+        for (int a2 = 0; a2 < 3; ++a2) for (int c2 = 0; c2 < 3; ++c2) {
+          const S t1 = Pw.m[a2][c2] * r1;
+          E1.m[a2][c2] += t1; E2.m[a2][c2] += Pw.m[a2][c2] * r2; E3.m[a2][c2] += Pw.m[a2][c2] * r3;
+          const S am = t1 < 0 ? -t1 : t1;
           mx = am > mx ? am : mx;
         }
-        mx = wave_max(mx);
-        wave_sync();
-        S* t2 = tc; tc = tn; tn = t2;
-        if (mx < (sizeof(S) == 4 ? S(1e-11) : S(1e-21))) break;     // remaining terms are far below eps
+        if (mx < (sizeof(S) == 4 ? S(1e-11) : S(1e-21))) break;
+      }
+      const M3<S> XE1 = mulm(X, E1), XE2 = mulm(X, E2), XE3 = mulm(X, E3);
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        Phi[i * 15 + 3 + j] = -dT * E1.m[i][j];
+        Phi[(6 + i) * 15 + j] = XE1.m[i][j];
+        Phi[(6 + i) * 15 + 3 + j] = -dT * XE2.m[i][j];
+        Phi[(6 + i) * 15 + 9 + j] = -C.m[j][i] * dT;
+        Phi[(12 + i) * 15 + j] = dT * XE2.m[i][j];
+        Phi[(12 + i) * 15 + 3 + j] = -dT * dT * XE3.m[i][j];
+        Phi[(12 + i) * 15 + 6 + j] = (i == j) ? dT : S(0);
+        Phi[(12 + i) * 15 + 9 + j] = -C.m[j][i] * dT * dT / S(2);
       }
       // observability-constraint patch of Phi blocks (0,0),(6,0),(12,0)   msckf.h:116-132
-      if (lane == 0) {
+      {
         const S* nx = sState + (s + 1) * SST;
         const Q4<S> qn = ldq(nx);
         const V3<S> vn = ld3(nx + 7), pn = ld3(nx + 13);
@@ -198,48 +286,58 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
           Phi[(12 + i) * 15 + j] = A2.m[i][j] - e2v[i] * s3[j];
         }
       }
-      wave_sync();
     }
     __syncthreads();
-    // ---- C: sequential chains over the group (wave 0: P_II, wave 1: Phi_total)
-    if (w == 0) {
-      S* T1 = sScr[0]; S* T2 = sScr[0] + 225;
-      for (int s = 0; s < G; ++s) {
-        const S* st = sState + s * SST;
+    PR_TICK(2);
+    // ---- C: sequential chains over the group with the whole workgroup: thread e < 225 owns element (ei, ej) of the 15 x 15
+    // results; P_II <- sym(Phi (P_II + G Q G^T dT) Phi^T) (:134,143) and Phi_total <- Phi Phi_total advance together, two
+    // barriers per sample: the thread forms both (Phi M Phi^T)(ei, ej) and (ej, ei), so the symmetrisation of :143 needs no
+    // exchange (and both halves get the same bits), and adds the next sample's process noise to its own element
+    {
+      S* T1 = sScr[0];
+      const int ei = tid / 15, ej = tid % 15;
+      // this thread's element of G Q G^T dT = diag(Qw, Qbg, C^T Qa C, Qba, 0) dT of sample s   (calcG :899-902, Q diagonal)
+      auto qterm = [&](int s) -> S {
+        if (tid >= 225) return S(0);
         const S dT = sRd[s * RD_STRIDE + 6];
-        const M3<S> C = q2rot(ldq(st));
-        S* Pi = sPii;
-        if (lane < 9) {   // + G Q G^T dT = diag(Qw, Qbg, C^T Qa C, Qba, 0) dT   (calcG :899-902, Q diagonal)
-          const int i = lane / 3, j = lane % 3;
-          if (i == j) {
-            Pi[i * 15 + i] += sQ[i] * dT;
-            Pi[(3 + i) * 15 + 3 + i] += sQ[3 + i] * dT;
-            Pi[(9 + i) * 15 + 9 + i] += sQ[9 + i] * dT;
-          }
+        const int bi = ei / 3, bj = ej / 3;
+        if (bi != bj || bi == 4) return S(0);
+        if (bi == 2) {
+          const M3<S> C = q2rot(ldq(sState + s * SST));
+          const int i = ei - 6, j = ej - 6;
           S sm = 0;
           for (int kk = 0; kk < 3; ++kk) sm += C.m[kk][i] * sQ[6 + kk] * C.m[kk][j];
-          Pi[(6 + i) * 15 + 6 + j] += sm * dT;
+          return sm * dT;
         }
-        wave_sync();
-        mm15(T1, sPhi + s * 225, Pi, lane);
-        wave_sync();
-        mm15_abt(T2, T1, sPhi + s * 225, lane);
-        wave_sync();
-        for (int e = lane; e < 225; e += 64) { const int i = e / 15, j = e % 15; Pi[e] = (T2[i * 15 + j] + T2[j * 15 + i]) / S(2); }
-        wave_sync();
-      }
-    } else if (w == 1) {
+        return ei == ej ? sQ[ei] * dT : S(0);
+      };
+      if (tid < 225) sPii[tid] += qterm(0);
       int c2 = cur;
       for (int s = 0; s < G; ++s) {
-        mm15(sTot[c2 ^ 1], sPhi + s * 225, sTot[c2], lane);
-        wave_sync();
+        const S* Ph = sPhi + s * 225;
+        __syncthreads();
+        if (tid < 225) {
+          S a1 = 0, a2 = 0;
+#pragma unroll
+          for (int k = 0; k < 15; ++k) { const S ph = Ph[ei * 15 + k]; a1 += ph * sPii[k * 15 + ej]; a2 += ph * sTot[c2][k * 15 + ej]; }
+          T1[tid] = a1; sTot[c2 ^ 1][tid] = a2;
+        }
+        __syncthreads();
+        if (tid < 225) {
+          S tij = 0, tji = 0;
+#pragma unroll
+          for (int k = 0; k < 15; ++k) { tij += T1[ei * 15 + k] * Ph[ej * 15 + k]; tji += T1[ej * 15 + k] * Ph[ei * 15 + k]; }
+          const S sym = ei <= ej ? (tij + tji) / S(2) : (tji + tij) / S(2);
+          sPii[tid] = sym + (s + 1 < G ? qterm(s + 1) : S(0));
+        }
         c2 ^= 1;
       }
     }
-    if (G & 1) cur ^= 1;      // wave 1 flipped the Phi_total buffer G times
+    if (G & 1) cur ^= 1;      // the Phi_total buffer flipped G times
     __syncthreads();
     if (tid < 16) sState[tid] = sState[G * SST + tid];   // carry the last state of the group to slot 0
     __syncthreads();
+    PR_TICK(3);
   }
   // ---- write back: state, nulls (re-anchored to the final state), P_II, P_IC
   if (tid < 16) imu[tid] = sState[tid];
@@ -261,11 +359,17 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
       pc[i] = sm; P[(long)i * ld + 15 + c] = sm;
     }
   }
+#ifdef MSCKF_ABLATE
+  __syncthreads();
+  PR_TICK(4);
+  if (tid == 0 && blockIdx.x == 0) { for (int q = 0; q < 5; ++q) atomicAdd(&g_prop_cycles[q], (unsigned long long)pcyc[q]); atomicAdd(&g_prop_cycles[5], 1ull); }
+#endif
 }
 
 template <class S>
 __global__ __launch_bounds__(256) void k_augment(Dev<S> d, int b0) {
   const int b = b0 + blockIdx.x, tid = threadIdx.x;
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: win instruction arbitration against co-resident throughput waves of the other slice
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   S* sJP = reinterpret_cast<S*>(smem_raw);  // [6][ld]
   const int n = d.ncam[b];
@@ -306,6 +410,9 @@ __global__ __launch_bounds__(256) void k_augment(Dev<S> d, int b0) {
 }
 
 // Gather the kept camera slots (keep[] ascending) of P into Ptmp, then copy back and compact cam[].
+// square_slice / column_slice of the covariance (matrix_utils.h:58-87) as two passes through Ptmp.  Workgroup = a set of
+// columns; the source row of every kept row is looked up once per workgroup (LDS table), threads run down a column
+// (coalesced) -- no integer division per element.
 template <class S>
 __global__ __launch_bounds__(256) void k_prune_gather(Dev<S> d, int b0) {
   const int b = b0 + blockIdx.y;
@@ -315,11 +422,13 @@ __global__ __launch_bounds__(256) void k_prune_gather(Dev<S> d, int b0) {
   const int* keep = d.keep + (long)b * d.n_cap;
   const S* P = d.P + (long)b * ld * ld;
   S* T = d.Ptmp + (long)b * ld * ld;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)Dn * Dn; e += (long)gridDim.x * 256) {
-    const int i = (int)(e % Dn), j = (int)(e / Dn);
-    const int si = i < 15 ? i : 15 + 6 * keep[(i - 15) / 6] + (i - 15) % 6;
-    const int sj = j < 15 ? j : 15 + 6 * keep[(j - 15) / 6] + (j - 15) % 6;
-    T[(long)j * ld + i] = P[(long)sj * ld + si];
+  __shared__ int sSrc[1024];
+  for (int i = threadIdx.x; i < Dn && i < 1024; i += 256) sSrc[i] = i < 15 ? i : 15 + 6 * keep[(i - 15) / 6] + (i - 15) % 6;
+  __syncthreads();
+  for (int j = blockIdx.x; j < Dn; j += gridDim.x) {
+    const S* src = P + (long)sSrc[j] * ld;
+    S* dst = T + (long)j * ld;
+    for (int i = threadIdx.x; i < Dn; i += 256) dst[i] = src[sSrc[i]];
   }
 }
 template <class S>
@@ -330,10 +439,8 @@ __global__ __launch_bounds__(256) void k_prune_commit(Dev<S> d, int b0) {
   const int Dn = 15 + 6 * nk, ld = d.ld;
   S* P = d.P + (long)b * ld * ld;
   const S* T = d.Ptmp + (long)b * ld * ld;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)Dn * Dn; e += (long)gridDim.x * 256) {
-    const int i = (int)(e % Dn), j = (int)(e / Dn);
-    P[(long)j * ld + i] = T[(long)j * ld + i];
-  }
+  for (int j = blockIdx.x; j < Dn; j += gridDim.x)
+    for (int i = threadIdx.x; i < Dn; i += 256) P[(long)j * ld + i] = T[(long)j * ld + i];
 }
 template <class S>
 __global__ __launch_bounds__(64) void k_prune_cams(Dev<S> d, int b0) {
@@ -369,8 +476,8 @@ void launch_augment(const Dev<S>& d, int b0, int nb, hipStream_t st) {
 template <class S>
 void launch_prune(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0) return;
-  hipLaunchKernelGGL(k_prune_gather<S>, dim3(16, nb), dim3(256), 0, st, d, b0);
-  hipLaunchKernelGGL(k_prune_commit<S>, dim3(16, nb), dim3(256), 0, st, d, b0);
+  hipLaunchKernelGGL(k_prune_gather<S>, dim3(32, nb), dim3(256), 0, st, d, b0);
+  hipLaunchKernelGGL(k_prune_commit<S>, dim3(32, nb), dim3(256), 0, st, d, b0);
   hipLaunchKernelGGL(k_prune_cams<S>, dim3(nb), dim3(64), 0, st, d, b0);
 }
 

@@ -25,6 +25,8 @@ bt.scenario_commit()
 bt.run_frames(0, 32); bt.sync()
 out = (C.c_ulonglong * 16)()
 bt.L.msckf_hip_debug_chol_cycles(out, 1)
+po8 = (C.c_ulonglong * 8)()
+bt.L.msckf_hip_debug_prop_cycles(po8, 1)
 bt.run_frames(32, nf); bt.sync()
 bt.L.msckf_hip_debug_chol_cycles(out, 1)
 names = ["load", "panel->LDS", "diag block", "L21", "outputs", "trailing"]
@@ -32,3 +34,6 @@ for m, nm in enumerate(("GRAM f64", "GAIN f32")):
     v = np.array(out[8 * m:8 * m + 8], dtype=np.float64)
     n = max(v[6], 1)
     print(nm, "launches", int(v[6]), {a: int(c / n) for a, c in zip(names, v[:6])}, "total cycles/launch", int(v[:6].sum() / n))
+bt.L.msckf_hip_debug_prop_cycles(po8, 1)
+v = np.array(po8, dtype=np.float64); n = max(v[5], 1)
+print("k_propagate launches", int(v[5]), {a: int(c / n) for a, c in zip(["load", "state chain", "Phi series", "P_II/Phi_tot chains", "write back + P_IC"], v[:5])}, "total", int(v[:5].sum() / n))
