@@ -1,15 +1,21 @@
+# Collect the round's evidence on the GPU box (run through gpurun from the repo root):
+#   GPU test-suite, bench.py JSON, rocprofv3 kernel trace of bench.py (single stream), three PMC passes.
+# Outputs land in gpurun_out/$TAG; the summaries to be judged are then copied into profiles/ by hand.
+TAG=${TAG:-r02}
+OUT=/root/repo/gpurun_out/$TAG
 set -x
-mkdir -p gpurun_out/r1f
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-python bench.py > gpurun_out/r1f/bench.json 2> gpurun_out/r1f/bench.err; tail -c 600 gpurun_out/r1f/bench.json
+mkdir -p $OUT
+python -m pytest tests -m gpu -q 2>&1 | tail -3 > $OUT/pytest_tail.txt
+python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; tail -c 600 $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d /tmp/p1 -o r -- python /root/repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-early-accept-pass --streams 1 > /tmp/b1.log 2>&1
-DB=$(find /tmp/p1 -name "*.db" | head -1); tail -1 /tmp/b1.log > /root/repo/gpurun_out/r1f/bench_profiled.json
-ROCPD_TAIL=10 python /root/repo/scripts/rocpd_summary.py $DB /root/repo/gpurun_out/r1f/kernel_stats_tail10.md > /dev/null
-python /root/repo/scripts/rocpd_summary.py $DB /root/repo/gpurun_out/r1f/kernel_stats_all.md > /dev/null
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p2 -o r -- python /root/repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-early-accept-pass --streams 1 > /tmp/b2.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p3 -o r -- python /root/repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-early-accept-pass --streams 1 > /tmp/b3.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace -d /tmp/p4 -o r -- python /root/repo/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-early-accept-pass --streams 1 > /tmp/b4.log 2>&1
+COMMON="--steps 10 --warmup 3 --no-cpu-baseline --no-early-accept-pass --no-upload-pass --repeats 1 --streams 1"
+rocprofv3 --kernel-trace --stats -d /tmp/p1 -o r -- python /root/repo/bench.py $COMMON > /tmp/b1.log 2>&1
+DB=$(find /tmp/p1 -name "*.db" | head -1); tail -1 /tmp/b1.log > $OUT/bench_profiled.json
+ROCPD_TAIL=20 python /root/repo/scripts/rocpd_summary.py $DB $OUT/kernel_stats_tail20.md > /dev/null
+python /root/repo/scripts/rocpd_summary.py $DB $OUT/kernel_stats_all.md > /dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p2 -o r -- python /root/repo/bench.py $COMMON > /tmp/b2.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p3 -o r -- python /root/repo/bench.py $COMMON > /tmp/b3.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace -d /tmp/p4 -o r -- python /root/repo/bench.py $COMMON > /tmp/b4.log 2>&1
 tail -2 /tmp/b4.log | cut -c1-300
-python /root/repo/scripts/rocpd_pmc.py /root/repo/gpurun_out/r1f/pmc.md $(find /tmp/p2 /tmp/p3 /tmp/p4 -name "*.db") > /dev/null
-ls -la /root/repo/gpurun_out/r1f
+python /root/repo/scripts/rocpd_pmc.py $OUT/pmc.md $(find /tmp/p2 /tmp/p3 /tmp/p4 -name "*.db") > /dev/null
+ls -la $OUT
