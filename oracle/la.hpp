@@ -12,7 +12,9 @@
 //   * PartialPivLU inverse / determinant                                   msckf.h:176,1370
 // Eigen/Boost are absent from the build image and un-pinned by the reference (CMakeLists.txt:22,39);
 // only the *values* of these operations matter for parity, so they are restated from their published
-// algorithms.  PARITY UNPINNED: the reference ships no golden vectors.
+// algorithms.  The reference ships no golden vectors; parity is PINNED by running the
+// reference's own unmodified msckf.h (oracle/_ref/lib_ref.so, built by oracle/Makefile against oracle/ref_shim)
+// on the same inputs: tests/test_ref_vs_oracle.py.
 #ifndef ORACLE_LA_HPP
 #define ORACLE_LA_HPP
 

@@ -6,10 +6,13 @@
 // used as the checker for the HIP path and as the `cpu_baseline` leg of bench.py.  Nothing in the
 // product (msckf_mono_amd/csrc, include/) may include or link this file.
 //
-// PARITY UNPINNED: the reference has no tests / golden vectors and cannot be compiled in this image
-// (Eigen, Boost.Math, ROS, OpenCV absent -- SURVEY.md section 8c).  The restatement is pinned instead by
-// an independent numpy/scipy implementation (oracle/np_oracle.py, tests/test_oracle_vs_numpy.py) and
-// by the invariants of SURVEY.md section 4.
+// PARITY PINNED TO REFERENCE SOURCE: the reference has no tests / golden vectors, and Eigen / Boost.Math are absent
+// from this image, but its three headers compile unmodified against the minimal Eigen/Boost shim of oracle/ref_shim
+// (oracle/Makefile target _ref -> oracle/_ref/lib_ref.so, wrapper oracle/ref_capi.cpp with this file's C-ABI).
+// tests/test_ref_vs_oracle.py holds this restatement against that library (1e-8 double / 1e-3 float, free-running,
+// public API path, golden fixtures, cfg3 window); an independent numpy/scipy implementation (oracle/np_oracle.py,
+// tests/test_oracle_vs_numpy.py) and the invariants of SURVEY.md section 4 pin it a second time.  Limit: the shim's
+// decompositions are this repository's code (checked against scipy), not Eigen's.
 //
 // Two modes, identical results up to rounding:
 //   FAITHFUL  same algorithmic steps and asymptotic costs as msckf.h (dense P re-assembly per use,

@@ -1,8 +1,9 @@
 """Independent numpy/scipy restatement of the reference filter -- TEST INFRASTRUCTURE ONLY.
 
 Second, deliberately different implementation of /root/reference/include/msckf_mono/msckf.h used to pin
-the C++ oracle (oracle/msckf_oracle.hpp), because the reference itself ships no tests or golden vectors
-and cannot be built in this image (PARITY UNPINNED).  Where the C++ oracle uses
+the C++ oracle (oracle/msckf_oracle.hpp) a second time: the reference itself ships no tests or golden vectors
+(SURVEY.md section 8c); the first pin is the reference's own msckf.h compiled against oracle/ref_shim
+(oracle/_ref/lib_ref.so, tests/test_ref_vs_oracle.py).  Where the C++ oracle uses
 hand-written Householder/LDLT/LU/Pade, this file uses scipy.linalg.expm / qr / svd / numpy solve, dense
 matrices everywhere, and scipy.stats.chi2.ppf for the gate table (msckf.h:91-95).  It also generates the
 golden fixtures in tests/golden (scripts/gen_golden.py).
