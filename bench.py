@@ -11,6 +11,10 @@ locked host memory inside the timed region (SURVEY.md 8d's definition of the met
 `--config cfg4`: BASELINE.json configs[3] stand-in (EuRoC MH_01..05 are not on disk): 5 synthetic sequences x noise seeds,
 EuRoC cam0 intrinsics (f_u != f_v), float, 128 trajectories per GPU, per-sequence ATE all-reduced over the ranks.
 
+`--config cfg5`: BASELINE.json configs[4] -- 60-camera window, 500 tracks, fp16 measurement Jacobian / fp32 covariance
+(dtype MSCKF_HIP_F16H_F32P), 512 trajectories per GPU (32 distinct scenarios, each run by 16 filters; `--trajectories`
+overrides); no CPU leg at this size (one update of the reference's algorithm builds a 28 000 x 28 000 Q).
+
 Launch: `python bench.py --gpus 1 --steps K --warmup W`, or one rank per GPU under torch.distributed.run (trajectories are
 independent: rank r runs its own block of trajectories, weak scaling, no data-path collective; RCCL is used only for the
 timing reduction and the end-of-run ATE all-reduce).
@@ -40,11 +44,14 @@ PEAK_F64_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
 CONFIGS = {
     # name: config id (seed family), window, tracks, trajectories per GPU, isotropic noise, sequences
-    "cfg3": dict(cid=3, N=30, F=200, B=64, iso=True, nseq=1,
+    "cfg3": dict(cid=3, N=30, F=200, B=64, iso=True, nseq=1, dtype="f32",
                  workload="BASELINE.json configs[2]: synthetic 30-cam window / 200 feats, float, 64 batched trajectories per GPU"),
-    "cfg4": dict(cid=4, N=30, F=200, B=128, iso=False, nseq=5,
+    "cfg4": dict(cid=4, N=30, F=200, B=128, iso=False, nseq=5, dtype="f32",
                  workload="BASELINE.json configs[3] stand-in: 5 synthetic sequences x noise seeds (EuRoC MH_01..05 not on disk), "
                           "EuRoC cam0 intrinsics f_u != f_v, float, 30-cam window / 200 feats, 128 trajectories per GPU"),
+    "cfg5": dict(cid=5, N=60, F=500, B=512, iso=True, nseq=1, dtype="f16h", uniq=32,
+                 workload="BASELINE.json configs[4]: synthetic 60-cam window / 500 feats, fp16 measurement Jacobian / fp32 covariance, "
+                          "512 batched trajectories per GPU (32 distinct scenarios, each run by 16 filters)"),
 }
 
 
@@ -80,12 +87,15 @@ def make_trajectories(c, rank, n_frames):
     """Scenario generation (host, numpy) for this rank's trajectories, spread over a process pool; runs BEFORE torch / HIP
     are initialised in this process (fork)."""
     from concurrent.futures import ProcessPoolExecutor
-    jobs = [(c["cid"], rank * c["B"] + b, c["N"], c["F"], n_frames, c["iso"], (rank * c["B"] + b) % c["nseq"]) for b in range(c["B"])]
+    nu = min(c.get("uniq", c["B"]), c["B"])            # distinct scenarios (cfg5: the batch repeats them)
+    jobs = [(c["cid"], rank * nu + b, c["N"], c["F"], n_frames, c["iso"], (rank * nu + b) % c["nseq"]) for b in range(nu)]
     nproc = max(1, min(32, (os.cpu_count() or 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))), len(jobs)))
     if nproc == 1:
-        return [_make_traj(j) for j in jobs]
-    with ProcessPoolExecutor(nproc) as ex:
-        return list(ex.map(_make_traj, jobs, chunksize=max(1, len(jobs) // (4 * nproc))))
+        out = [_make_traj(j) for j in jobs]
+    else:
+        with ProcessPoolExecutor(nproc) as ex:
+            out = list(ex.map(_make_traj, jobs, chunksize=max(1, len(jobs) // (4 * nproc))))
+    return [out[b % nu] for b in range(c["B"])]
 
 
 def main():
@@ -94,6 +104,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg3")
+    ap.add_argument("--trajectories", type=int, default=0, help="trajectories per GPU (default: the configuration's)")
     ap.add_argument("--repeats", type=int, default=-1, help="timed K-step windows in all (default: until >= 0.5 s of timed region, 3..12)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -105,7 +116,14 @@ def main():
     ap.add_argument("--gate-early-accept", action="store_true",
                     help="exact early accept of the chi-square gate (msckf_hip_set_gate_early_accept); OFF for the headline number")
     args = ap.parse_args()
-    c = CONFIGS[args.config]
+    c = dict(CONFIGS[args.config])
+    if args.trajectories > 0:
+        c["B"] = args.trajectories
+    if args.config == "cfg5":          # big windows: one repeat window by default, no CPU legs that take minutes
+        args.no_early_accept_pass = True
+        args.no_upload_pass = True
+        if args.repeats <= 0:
+            args.repeats = 2
     N_WIN, F_TRK, B_TRAJ = c["N"], c["F"], c["B"]
 
     rank = int(os.environ.get("RANK", "0"))
@@ -113,7 +131,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     K, W = args.steps, args.warmup
     fill = N_WIN                     # frames needed to reach the steady-state window
-    est_ms = 0.7 * B_TRAJ / 64.0     # rough step time, only used to size the number of repeat windows
+    est_ms = 0.7 * B_TRAJ / 64.0 * (N_WIN / 30.0) ** 2 * (F_TRK / 200.0)    # rough step time, only used to size the number of repeat windows
     R = args.repeats if args.repeats > 0 else int(min(12, max(3, np.ceil(500.0 / (K * est_ms)))))
     extra = (0 if args.no_upload_pass else 1) + 1 + (0 if (args.gate_early_accept or args.no_early_accept_pass) else 1)
     n_frames = fill + W + K * (R + extra)   # [fill | warmup | R timed windows | upload window | profiled | early-accept window]
@@ -140,7 +158,7 @@ def main():
     from msckf_mono_amd import capi, shard
 
     t_up = time.time()
-    bt = capi.Batch(B_TRAJ, N_WIN, F_TRK, N_WIN, capi.F32, local_rank)
+    bt = capi.Batch(B_TRAJ, N_WIN, F_TRK, N_WIN, capi.F16H if c["dtype"] == "f16h" else capi.F32, local_rank)
     bt.scenario_alloc(n_frames, K_IMU)
     for b, tr in enumerate(trajs):
         bt.initialize(b, tr.cfg, tr.imu0)
@@ -259,9 +277,9 @@ def main():
         achieved = dom_flops / (kd["ms"] * 1e-3) / 1e12 if kd["ms"] > 0 else 0.0
         pmc = pmc_block(dom)
         out = {
-            "metric": "filter updates/sec (30-cam window, 200 feats)", "value": value, "unit": "updates/s",
+            "metric": "filter updates/sec (%d-cam window, %d feats)" % (N_WIN, F_TRK), "value": value, "unit": "updates/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if c["dtype"] == "f32" else "f32 (measurement Jacobian stored as f16)", "data": "synthetic",
             "config": {"workload": c["workload"], "name": args.config,
                        "cam_window": N_WIN, "tracks_per_update": F_TRK, "trajectories_per_gpu": B_TRAJ, "imu_per_update": K_IMU,
                        "parallelism": "replicated trajectories, %d per rank" % B_TRAJ,
@@ -295,9 +313,13 @@ def main():
                 "value": world * B_TRAJ * K / (early_ms * 1e-3 * K), "ms_per_step": early_ms,
                 "note": "same K steps measured again with msckf_hip_set_gate_early_accept(1): exact bound gamma <= |r_o|^2/sigma^2, identical results; not the headline value"},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.config != "cfg5":
             out["cpu_baseline"] = cpu_baseline(trajs[0], fill + W, args.cpu_seconds, N_WIN)
             out.update(ate_vs_reference(trajs, sample, p_dev_sample, f_end_timed, N_WIN))
+        elif args.config == "cfg5":
+            out["cpu_baseline"] = None
+            out["cpu_baseline_note"] = ("not run at this size: one update of the reference's algorithm on a 60-camera / 500-track window builds a "
+                                        "~28 000 x 28 000 Q (minutes and > 3 GB per filter); parity at this geometry is held by the -m gpu tests")
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -80,6 +80,8 @@ struct Dev {
   //   Lam    [B][ldR][ldR]      f64   sum B^T B, upper 64x64 tiles
   int compress;   // 0 Householder TSQR; information form with 1 k_chol_T, 2 k_chol_blk, 3 k_chol_mfma (kernels_chol.hip)
   double* trk_B; S* trk_rw; signed char* trk_inv; double* Dg; double* Lam;
+  S* Mp2;       // [B][24][16][16] per-panel M of the two-level factorization of S (6 n_cap > 192), else null
+  double* Mp;   // [B][12][16][16] per-panel M of level A of the two-level Gram factorization (windows with 6 n_cap + 1 > 192), else null
   // covariance update: 0 = square-root gain form P <- P - W W^T, S factored by the blocked matrix-core Cholesky (float) /
   // the register-resident one (double); 1 = the reference's Joseph sequence; 2 = square-root gain form, register-resident solve
   int joseph;
@@ -301,6 +303,7 @@ template <class S> void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream
 // [PHt ; r_n^T] appended (W, dx) for the float Kalman stage.  Return false when the window does not fit the kernel.
 template <class S> bool launch_chol_gram(const Dev<S>& d, int b0, int nb, hipStream_t st);
 bool launch_chol_gain(const Dev<float>& d, int b0, int nb, hipStream_t st);
+template <class S> bool launch_chol_gain_large(const Dev<S>& d, int b0, int nb, hipStream_t st);
 size_t feature_lds_bytes(int m_cap, size_t scalar);
 // one-time per-device setup of each kernel file (constant tables, dynamic-LDS limits); msckf_hip_create calls them
 void feature_device_setup();

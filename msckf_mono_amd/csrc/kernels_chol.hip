@@ -46,7 +46,15 @@ __device__ __forceinline__ void cstatic_for_impl(F&& f, std::integer_sequence<in
 template <int N, class F>
 __device__ __forceinline__ void cstatic_for(F&& f) { cstatic_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-enum { CH_GRAM = 0, CH_GAIN = 1 };
+// CH_GRAM_A / CH_GRAM_B: the two levels of the factorization of a Gram matrix with more than 192 columns (windows of
+// more than 31 cameras): A factors the leading 192 x 192 block in place (f64 L11 and the per-panel M kept for k_trsm_l21),
+// k_trsm_l21 forms L21 = A21 L11^-T one 16-row block per wavefront, B applies L21 L21^T to its accumulators ("pre-panels")
+// and factors the Schur complement.
+// CH_S_A / CH_S_B: the same two levels for S = T_H P T_H^T + R_n of a window with more than 32 cameras (n > 192): L (in
+// place in Smat's lower triangle) and every panel's M are kept, and W = P T_H^T L^-T, z = L^-1 r_n follow from k_trsm_rows
+// over all the panels (rows are independent: one 16-row block per wavefront) instead of riding along as appended rows.
+enum { CH_GRAM = 0, CH_GAIN = 1, CH_GRAM_A = 2, CH_GRAM_B = 3, CH_S_A = 4, CH_S_B = 5 };
+constexpr int CH_SPLIT = 192;   // columns of level A
 
 #ifdef MSCKF_ABLATE
 // phase timers of the -DMSCKF_ABLATE build: shader-clock cycles of workgroup 0's thread 0 per phase, summed over launches
@@ -68,10 +76,18 @@ __global__ __launch_bounds__(256) void k_chol_mfma(Dev<SO> d, int b0) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound chain: win instruction arbitration against co-resident throughput waves of the other slice
   int* st = d.stats + (long)b * STAT_STRIDE;
   if (st[STAT_MROWS] == 0) return;
-  const int N = d.ncam[b], n = 6 * N, D = 15 + n;
-  // rows of the main block that exist: GRAM n + 1 (row n = H_o^T r_o), GAIN n; appended rows of this part (GAIN): a slice
-  // of the D rows of P T_H^T plus, as the LAST row of the slice's blocks, r_n^T
-  const int main_rows = MODE == CH_GRAM ? n + 1 : n;
+  constexpr bool GRAMLIKE = MODE == CH_GRAM || MODE == CH_GRAM_A || MODE == CH_GRAM_B;
+  constexpr bool SLIKE = MODE == CH_S_A || MODE == CH_S_B;
+  constexpr bool LEVEL_A = MODE == CH_GRAM_A || MODE == CH_S_A, LEVEL_B = MODE == CH_GRAM_B || MODE == CH_S_B;
+  constexpr int OFF = LEVEL_B ? CH_SPLIT : 0;                            // first row/column of this launch's block
+  const int N = d.ncam[b], nfull = 6 * N, D = 15 + nfull;
+  // n: columns this launch factors (local); main_rows: rows of the main block that exist: GRAM n + 1 (row n = H_o^T r_o),
+  // GAIN n; appended rows of this part (GAIN): a slice of the D rows of P T_H^T plus, as the LAST row of the slice's
+  // blocks, r_n^T
+  const int n = LEVEL_A ? min(nfull, CH_SPLIT) : nfull - OFF;
+  const int main_rows = !GRAMLIKE ? n : (LEVEL_A ? min(nfull + 1, CH_SPLIT) : nfull + 1 - OFF);
+  if (LEVEL_B && n <= 0) return;
+  const bool two_level = MODE == CH_GRAM_A && nfull + 1 > CH_SPLIT;      // level A of a two-level factorization
   const int app_per = MODE == CH_GAIN ? 16 * NA - 1 : 0;              // rows of PHt per part (the last appended row is r_n^T)
   const int app_lo = part * app_per, app_hi = min(D, app_lo + app_per);   // [app_lo, app_hi) rows of PHt
   const int zrow = 16 * NR - 1;                                          // panel row of r_n^T
@@ -81,13 +97,14 @@ __global__ __launch_bounds__(256) void k_chol_mfma(Dev<SO> d, int b0) {
 
   // ---- sources
   const double* Lam = nullptr; const double* Dg = nullptr;
-  const SO* Sm = nullptr; const SO* PHtT = nullptr; const SO* R0 = d.Rbuf + ((long)b * d.nchunk) * (long)d.n6cap * d.ldR;
-  if (MODE == CH_GRAM) { Lam = d.Lam + (long)b * d.ldR * d.ldR; Dg = d.Dg + (long)b * d.n_cap * DG_STRIDE; }
+  SO* Sm = nullptr; const SO* PHtT = nullptr; const SO* R0 = d.Rbuf + ((long)b * d.nchunk) * (long)d.n6cap * d.ldR;
+  if (GRAMLIKE) { Lam = d.Lam + (long)b * d.ldR * d.ldR; Dg = d.Dg + (long)b * d.n_cap * DG_STRIDE; }
   else { Sm = d.Smat + (long)b * d.n6cap * d.n6cap; PHtT = d.K + (long)b * d.ld * d.n6cap; }
   // Initial accumulators.  (Measured: hoisting the loads of all blocks into one basic block -- clamped addresses, masks --
   // runs the kernel out of registers next to 60 live accumulator blocks and is slower than one round trip per block.)
   auto element = [&](int row, int col) -> T {
-    if (MODE == CH_GRAM) return (T)lam_hat(Lam, Dg, d.ldR, n, d.n_cap, row, col);
+    if (GRAMLIKE) return (T)lam_hat(Lam, Dg, d.ldR, nfull, d.n_cap, OFF + row, OFF + col);
+    if (SLIKE) return (row < n && col < n) ? (T)Sm[(long)(OFF + row) * d.n6cap + OFF + col] : T(0);
     if (col >= n) return T(0);
     if (row < 16 * NB) return row < n ? (T)Sm[(long)row * d.n6cap + col] : T(0);   // S (OP_S wrote both triangles): lanes run along col
     if (row == zrow) return (T)R0[(long)col * d.ldR + n];   // r_n[col]
@@ -110,13 +127,48 @@ __global__ __launch_bounds__(256) void k_chol_mfma(Dev<SO> d, int b0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[ii][jj][r] = element(16 * i + Mf<T>::row(lane, r), 16 * j + (lane & 15));
     }
-  if (MODE == CH_GRAM)
-    for (int t = tid; t < 16 * NB; t += 256) { const double dv = lam_hat(Lam, Dg, d.ldR, n, d.n_cap, t, t); sD0[t] = t < n ? (T)dv : T(0); }
+  if (GRAMLIKE)
+    for (int t = tid; t < 16 * NB; t += 256) { const double dv = lam_hat(Lam, Dg, d.ldR, nfull, d.n_cap, OFF + t, OFF + t); sD0[t] = t < n ? (T)dv : T(0); }
   const T tol = T(64.0 * 2.220446049250313e-16);
   int nskip = 0;
   T dxacc = 0;   // GAIN: thread t < app rows accumulates dx[app_lo + t] = sum_k W(., k) z_k
   SO* Rt = d.Rbuf + ((long)b * d.nchunk) * (long)d.n6cap * d.ldR;
   SO* Wg = d.W + (long)b * d.ld * d.n6cap;
+
+  // ---- level B: acc -= L21 L21^T, the CH_SPLIT columns of L21 (left in Lam by k_trsm_l21) staged 16 at a time
+  if (LEVEL_B) {
+    for (int q = 0; q < CH_SPLIT / 16; ++q) {
+      __syncthreads();
+      for (int e = tid; e < 16 * NB * 16; e += 256) {
+        const int r = e >> 4, c = e & 15;
+        if (SLIKE) sP[r][c] = OFF + r < nfull ? (T)Sm[(long)(OFF + r) * d.n6cap + 16 * q + c] : T(0);
+        else {
+          const double lv = Lam[(long)min(OFF + r, d.ldR - 1) * d.ldR + 16 * q + c];
+          sP[r][c] = OFF + r <= nfull ? (T)lv : T(0);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int jj = 0; jj < HC; ++jj) {
+        const int j = 2 * jj + pj;
+        if (j >= NB || 16 * j >= n) continue;
+        T bq[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) bq[s4] = sP[16 * j + (lane & 15)][4 * s4 + (lane >> 4)];
+#pragma unroll
+        for (int ii = 0; ii < HR; ++ii) {
+          if (2 * ii + 1 < 2 * jj && 2 * ii + 1 < NB) continue;
+          const int i = 2 * ii + pi;
+          if (i >= NR || i < j || 16 * i >= main_rows) continue;
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const T a = -sP[16 * i + (lane & 15)][4 * s4 + (lane >> 4)];
+            acc[ii][jj] = Mf<T>::mma(a, bq[s4], acc[ii][jj]);
+          }
+        }
+      }
+    }
+  }
 
   auto panel = [&](auto pc) __attribute__((always_inline)) {
     constexpr int p = decltype(pc)::value;
@@ -145,19 +197,19 @@ __global__ __launch_bounds__(256) void k_chol_mfma(Dev<SO> d, int b0) {
         T x[4], v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) { x[q] = sP[16 * p + r][4 * q + g]; v[q] = (4 * q + g == r) ? T(1) : T(0); }
-        const T d0 = MODE == CH_GRAM ? sD0[16 * p + r] : T(0);
+        const T d0 = GRAMLIKE ? sD0[16 * p + r] : T(0);
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
           constexpr int dummy = 0; (void)dummy;
           const int gk = k & 3, qk = k >> 2, src = 16 * gk + k;     // pivot (k, k) lives in lane src, register x[qk]
           bool skip_l;
           T piv = x[qk];
-          if (MODE == CH_GRAM) skip_l = (k >= kcount) || !(piv > tol * d0);
+          if (GRAMLIKE) skip_l = (k >= kcount) || !(piv > tol * d0);
           else { skip_l = k >= kcount; piv = piv > T(0) ? piv : Lim<T>::tiny(); }
           const T dinv_l = skip_l ? T(0) : fast_rsqrt(piv);
           const T dinv = wave_bcast(dinv_l, src);
           const T pv = wave_bcast(piv, src);
-          if (MODE == CH_GRAM && k < kcount && dinv == T(0)) ++nskip;
+          if (GRAMLIKE && k < kcount && dinv == T(0)) ++nskip;
           // column k of L (valid in the lanes of group gk): L(r, k)
           const T c_own = (r == k) ? pv * dinv : (r > k ? x[qk] * dinv : T(0));
           const T vk_own = v[qk] * dinv;
@@ -200,7 +252,7 @@ __global__ __launch_bounds__(256) void k_chol_mfma(Dev<SO> d, int b0) {
       __syncthreads();
       CH_TICK(3);
       // ---- (4) results of this panel
-      if (MODE == CH_GRAM) {
+      if (GRAMLIKE) {
         // rows 16p .. 16p+15 of T = L^T: T[k][c] = L(c, k), zero left of the diagonal and beyond column n
         if (tid < 16 * NB) {
           const int c = tid;
@@ -208,9 +260,26 @@ __global__ __launch_bounds__(256) void k_chol_mfma(Dev<SO> d, int b0) {
           for (int j = 0; j < 16; ++j) {
             const int k = 16 * p + j;
             const T val = (c >= k && c <= n) ? sP[c][j] : T(0);
-            if (k < n && c < d.ldR) Rt[(long)k * d.ldR + c] = (SO)val;
+            if (k < n && OFF + c < d.ldR) Rt[(long)(OFF + k) * d.ldR + OFF + c] = (SO)val;
+            if (MODE == CH_GRAM_A && two_level && c >= k) d.Lam[(long)b * d.ldR * d.ldR + (long)c * d.ldR + k] = (double)sP[c][j];   // f64 L11 in place
           }
         }
+        if (MODE == CH_GRAM_B && tid < OFF) {          // columns left of this launch's block: zero
+#pragma unroll
+          for (int j = 0; j < 16; ++j) { const int k = 16 * p + j; if (k < n) Rt[(long)(OFF + k) * d.ldR + tid] = SO(0); }
+        }
+        if (MODE == CH_GRAM_A && two_level) d.Mp[((long)b * (CH_SPLIT / 16) + p) * 256 + tid] = (double)sM[tid >> 4][tid & 15];
+      } else if (SLIKE) {
+        // L in place (row-major lower triangle of Smat) and this panel's M, for k_trsm_rows
+        if (tid < 16 * NB) {
+          const int c = tid;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int k = 16 * p + j;
+            if (c >= k && c < n && k < n) Sm[(long)(OFF + c) * d.n6cap + OFF + k] = (SO)sP[c][j];
+          }
+        }
+        d.Mp2[((long)b * 24 + OFF / 16 + p) * 256 + tid] = (SO)sM[tid >> 4][tid & 15];
       } else {
         // columns 16p .. 16p+15 of W for this part's rows; dx += W(:, k) z_k
         if (tid < app_per) {
@@ -251,23 +320,168 @@ __global__ __launch_bounds__(256) void k_chol_mfma(Dev<SO> d, int b0) {
 #ifdef MSCKF_ABLATE
   CH_TICK(5);
   if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
-    for (int q = 0; q < 6; ++q) atomicAdd(&g_chol_cycles[MODE][q], (unsigned long long)cyc[q]);
-    atomicAdd(&g_chol_cycles[MODE][6], 1ull);
+    for (int q = 0; q < 6; ++q) atomicAdd(&g_chol_cycles[MODE == CH_GAIN ? 1 : 0][q], (unsigned long long)cyc[q]);
+    atomicAdd(&g_chol_cycles[MODE == CH_GAIN ? 1 : 0][6], 1ull);
   }
 #endif
-  if (MODE == CH_GRAM) { if (tid == 0) st[STAT_RROWS] = n - nskip; }
+  if (MODE == CH_GRAM || MODE == CH_GRAM_A) { if (tid == 0) st[STAT_RROWS] = nfull - nskip; }
+  else if (MODE == CH_GRAM_B) { if (tid == 0) st[STAT_RROWS] -= nskip; }
+  else if (SLIKE) {}
   else if (tid < app_per && app_lo + tid < app_hi) d.dx[(long)b * d.ld + app_lo + tid] = (SO)dxacc;
+}
+
+// Y = X L^-T for 16-row blocks X that do not take part in the factorization itself, one block per wavefront, independent
+// of every other block.  Per 16-column panel p of L: Y_p = X_p M_p on the matrix cores (M_p from the factorization:
+// y = x M solves y L_pp^T = x), then X_q -= Y_p L(q, p)^T for the panels right of it.
+//   TR_GRAM  X = rows CH_SPLIT .. n of Lam^ (the row n = H_o^T r_o included), columns < CH_SPLIT: L21 of the two-level
+//            Gram factorization; Y goes back to Lam (f64, read by level B) and, transposed, into T_H's columns CH_SPLIT..
+//   TR_S21   the same for S (rows CH_SPLIT .. n-1 of Smat), in place
+//   TR_W     X = [P T_H^T ; r_n^T] (D + 1 rows, all n columns): W = P T_H^T L^-T (msckf.h:1370 without the inverse) and
+//            z = L^-1 r_n, left in W and Linv[0..n)
+enum { TR_GRAM = 0, TR_S21 = 1, TR_W = 2 };
+template <class T, class SO, int NP, int TMODE>
+__global__ __launch_bounds__(256) void k_trsm_rows(Dev<SO> d, int b0) {
+  typedef typename Mf<T>::V V;
+  constexpr int LP = 17;
+  const int b = b0 + blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int* st = d.stats + (long)b * STAT_STRIDE;
+  if (st[STAT_MROWS] == 0) return;
+  const int i = 4 * (int)blockIdx.x + w;                 // 16-row block
+  const int nfull = 6 * d.ncam[b], D = 15 + nfull;
+  const int ncols = TMODE == TR_W ? nfull : min(nfull, CH_SPLIT);      // columns of L that exist
+  const int R0 = TMODE == TR_W ? 16 * i : CH_SPLIT + 16 * i;           // first row of the block (TR_W: row of [PHt ; r_n^T])
+  const int row_end = TMODE == TR_GRAM ? nfull + 1 : (TMODE == TR_S21 ? nfull : D + 1);   // rows that exist
+  if (TMODE == TR_GRAM) { if (R0 >= d.ldR) return; } else if (R0 >= row_end) return;
+  double* Lam = TMODE == TR_GRAM ? d.Lam + (long)b * d.ldR * d.ldR : nullptr;
+  SO* Sm = TMODE != TR_GRAM ? d.Smat + (long)b * d.n6cap * d.n6cap : nullptr;
+  SO* Rt = d.Rbuf + ((long)b * d.nchunk) * (long)d.n6cap * d.ldR;
+  __shared__ T sT[4][16][LP];
+  if (TMODE == TR_GRAM && R0 >= row_end) {               // nothing below the split in this block: zero columns of T_H
+    for (int e = lane; e < 16 * CH_SPLIT; e += 64) { const int k = e >> 4, c = e & 15; if (k < nfull) Rt[(long)k * d.ldR + R0 + c] = SO(0); }
+    return;
+  }
+  auto xin = [&](int row, int col) -> T {                // X(row, col), row = absolute row of this mode's operand
+    if (TMODE == TR_GRAM) return (T)lam_hat(Lam, nullptr, d.ldR, nfull, d.n_cap, row, col);
+    if (col >= ncols) return T(0);
+    if (TMODE == TR_S21) return row < nfull ? (T)Sm[(long)row * d.n6cap + col] : T(0);
+    if (row < D) return (T)d.K[(long)b * d.ld * d.n6cap + (long)row * d.n6cap + col];   // row-major copy of P T_H^T left by OP_PHT
+    return row == D ? (T)Rt[(long)col * d.ldR + nfull] : T(0);                           // r_n[col]
+  };
+  auto lblk = [&](int q, int p, int r, int c) -> T {     // L(16 q + r, 16 p + c)
+    if (TMODE == TR_GRAM) return (T)Lam[(long)(16 * q + r) * d.ldR + 16 * p + c];
+    return (T)Sm[(long)(16 * q + r) * d.n6cap + 16 * p + c];
+  };
+  V acc[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[q][r] = xin(R0 + Mf<T>::row(lane, r), 16 * q + (lane & 15));
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    if (16 * p >= ncols) continue;
+    // Y = X_p M_p
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sT[w][Mf<T>::row(lane, r)][lane & 15] = acc[p][r];
+    __builtin_amdgcn_wave_barrier();
+    V y = V{0, 0, 0, 0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const T a = sT[w][lane & 15][(lane >> 4) + 4 * s4];
+      const int mi = ((lane >> 4) + 4 * s4) * 16 + (lane & 15);
+      const T bq = TMODE == TR_GRAM ? (T)d.Mp[((long)b * (CH_SPLIT / 16) + p) * 256 + mi] : (T)d.Mp2[((long)b * 24 + p) * 256 + mi];
+      y = Mf<T>::mma(a, bq, y);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = Mf<T>::row(lane, r), col = lane & 15;
+      sT[w][row][col] = y[r];
+      if (TMODE == TR_GRAM) { if (R0 + row <= nfull) Lam[(long)(R0 + row) * d.ldR + 16 * p + col] = (double)y[r]; }
+      if (TMODE == TR_S21) { if (R0 + row < nfull && 16 * p + col < ncols) Sm[(long)(R0 + row) * d.n6cap + 16 * p + col] = (SO)y[r]; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // transposed outputs, lanes along the rows of the block
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 16 * p + (lane >> 4) + 4 * r, c = lane & 15;
+      const T yv = sT[w][c][(lane >> 4) + 4 * r];
+      if (TMODE == TR_GRAM) { if (k < nfull) Rt[(long)k * d.ldR + R0 + c] = (R0 + c <= nfull) ? (SO)yv : SO(0); }
+      if (TMODE == TR_W && k < nfull) {
+        if (R0 + c < D) d.W[(long)b * d.ld * d.n6cap + (long)k * d.ld + R0 + c] = (SO)yv;
+        else if (R0 + c == D) d.Linv[(long)b * d.n6cap * d.n6cap + k] = (SO)yv;       // z_k
+      }
+    }
+    // X_q -= Y L(q, p)^T, q > p
+    T a[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) a[s4] = -sT[w][lane & 15][4 * s4 + (lane >> 4)];
+#pragma unroll
+    for (int q = p + 1; q < NP; ++q) {
+      if (16 * q >= ncols) continue;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) acc[q] = Mf<T>::mma(a[s4], lblk(q, p, lane & 15, 4 * s4 + (lane >> 4)), acc[q]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);   // keep the next panels' loads of L out of this one (the scheduler otherwise hoists them all: spills)
+  }
+}
+
+// dx = W z (z = L^-1 r_n left in Linv[0..n) by k_trsm_rows<TR_W>); one workgroup per trajectory
+template <class SO>
+__global__ __launch_bounds__(256) void k_dx_wz(Dev<SO> d, int b0) {
+  const int b = b0 + blockIdx.x, tid = threadIdx.x;
+  if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
+  const int n = 6 * d.ncam[b], D = 15 + n;
+  __shared__ SO sz[384];
+  for (int j = tid; j < n; j += 256) sz[j] = d.Linv[(long)b * d.n6cap * d.n6cap + j];
+  __syncthreads();
+  const SO* W = d.W + (long)b * d.ld * d.n6cap;
+  for (int i = tid; i < D; i += 256) {
+    SO s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int j = 0;
+    for (; j + 3 < n; j += 4) { s0 += W[(long)j * d.ld + i] * sz[j]; s1 += W[(long)(j + 1) * d.ld + i] * sz[j + 1]; s2 += W[(long)(j + 2) * d.ld + i] * sz[j + 2]; s3 += W[(long)(j + 3) * d.ld + i] * sz[j + 3]; }
+    for (; j < n; ++j) s0 += W[(long)j * d.ld + i] * sz[j];
+    d.dx[(long)b * d.ld + i] = (s0 + s1) + (s2 + s3);
+  }
+}
+
+// S = L L^T in two levels, W = P T_H^T L^-T, z = L^-1 r_n, dx = W z for windows with n > 192 (6 n_cap in {256, 320, 384} padded)
+template <class S>
+bool launch_chol_gain_large(const Dev<S>& d, int b0, int nb, hipStream_t st) {
+  if (nb <= 0) return true;
+  const int nblk = (d.n6cap + 15) / 16;
+  if (!d.Mp2 || nblk <= 12 || nblk > 24) return false;
+  hipLaunchKernelGGL((k_chol_mfma<S, S, 12, 0, CH_S_A, 1>), dim3(nb), dim3(256), 0, st, d, b0);
+  hipLaunchKernelGGL((k_trsm_rows<S, S, 12, TR_S21>), dim3((nblk - 12 + 3) / 4, nb), dim3(256), 0, st, d, b0);
+  if (nblk <= 16) hipLaunchKernelGGL((k_chol_mfma<S, S, 4, 0, CH_S_B, 1>), dim3(nb), dim3(256), 0, st, d, b0);
+  else if (nblk <= 20) hipLaunchKernelGGL((k_chol_mfma<S, S, 8, 0, CH_S_B, 1>), dim3(nb), dim3(256), 0, st, d, b0);
+  else hipLaunchKernelGGL((k_chol_mfma<S, S, 12, 0, CH_S_B, 1>), dim3(nb), dim3(256), 0, st, d, b0);
+  const int rblk = (15 + d.n6cap + 1 + 15) / 16;          // 16-row blocks of [P T_H^T ; r_n^T]
+  if (nblk <= 16) hipLaunchKernelGGL((k_trsm_rows<S, S, 16, TR_W>), dim3((rblk + 3) / 4, nb), dim3(256), 0, st, d, b0);
+  else if (nblk <= 20) hipLaunchKernelGGL((k_trsm_rows<S, S, 20, TR_W>), dim3((rblk + 3) / 4, nb), dim3(256), 0, st, d, b0);
+  else hipLaunchKernelGGL((k_trsm_rows<S, S, 24, TR_W>), dim3((rblk + 3) / 4, nb), dim3(256), 0, st, d, b0);
+  hipLaunchKernelGGL((k_dx_wz<S>), dim3(nb), dim3(256), 0, st, d, b0);
+  return true;
 }
 
 template <class S>
 bool launch_chol_gram(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0) return true;
-  switch (d.ldR / 16) {
+  const int nblk = d.ldR / 16;
+  switch (nblk) {
     case 4: hipLaunchKernelGGL((k_chol_mfma<double, S, 4, 0, CH_GRAM, 1>), dim3(nb), dim3(256), 0, st, d, b0); return true;
     case 8: hipLaunchKernelGGL((k_chol_mfma<double, S, 8, 0, CH_GRAM, 1>), dim3(nb), dim3(256), 0, st, d, b0); return true;
     case 12: hipLaunchKernelGGL((k_chol_mfma<double, S, 12, 0, CH_GRAM, 1>), dim3(nb), dim3(256), 0, st, d, b0); return true;
-    default: return false;
+    default: break;
   }
+  if (!d.Mp || (nblk != 16 && nblk != 20 && nblk != 24)) return false;
+  // two levels: columns [0, 192), L21, Schur complement
+  hipLaunchKernelGGL((k_chol_mfma<double, S, 12, 0, CH_GRAM_A, 1>), dim3(nb), dim3(256), 0, st, d, b0);
+  hipLaunchKernelGGL((k_trsm_rows<double, S, 12, TR_GRAM>), dim3((nblk - 12 + 3) / 4, nb), dim3(256), 0, st, d, b0);
+  if (nblk == 16) hipLaunchKernelGGL((k_chol_mfma<double, S, 4, 0, CH_GRAM_B, 1>), dim3(nb), dim3(256), 0, st, d, b0);
+  else if (nblk == 20) hipLaunchKernelGGL((k_chol_mfma<double, S, 8, 0, CH_GRAM_B, 1>), dim3(nb), dim3(256), 0, st, d, b0);
+  else hipLaunchKernelGGL((k_chol_mfma<double, S, 12, 0, CH_GRAM_B, 1>), dim3(nb), dim3(256), 0, st, d, b0);
+  return true;
 }
 
 // GAIN: parts x NA blocks of 16 rows must cover the D + 1 appended rows (each part also carries r_n^T)
@@ -293,6 +507,8 @@ void chol_cycles_read(unsigned long long* out16, int reset) {
 #endif
 
 template bool launch_chol_gram<float>(const Dev<float>&, int, int, hipStream_t);
+template bool launch_chol_gain_large<float>(const Dev<float>&, int, int, hipStream_t);
+template bool launch_chol_gain_large<double>(const Dev<double>&, int, int, hipStream_t);
 template bool launch_chol_gram<double>(const Dev<double>&, int, int, hipStream_t);
 
 }  // namespace msckf

@@ -115,6 +115,7 @@ __device__ __forceinline__ bool gate_chol(const S* sG, const S* sV, const S* sE,
     // register-resident: the wavefront is an 8 x 8 grid, lane (tx,ty) owns elements (8a+tx, 8b+ty) of the
     // (rho+1) x rho lower trapezoid; one LDS exchange of the pivot column per step, no workgroup barrier
     const int tx = lane & 7, ty = lane >> 3;
+    constexpr int NBS = NB <= 8 ? 8 : 16, CB = 8 * NBS;   // exchange buffer: [2][8 tx][NBS block rows]
     S A[NB][NB];
     S vr[NB][3], er[NB][3];
 #pragma unroll
@@ -155,19 +156,19 @@ __device__ __forceinline__ bool gate_chol(const S* sG, const S* sV, const S* sE,
         const int k = 8 * kb + kk;
         if (ty == kk) {
 #pragma unroll
-          for (int a2 = kb; a2 < NB; ++a2) sC[bufc * 64 + tx * 8 + a2] = A[a2][kb];
+          for (int a2 = kb; a2 < NB; ++a2) sC[bufc * CB + tx * NBS + a2] = A[a2][kb];
         }
         __syncthreads();
-        const S dkk = sC[bufc * 64 + kk * 8 + kb];
+        const S dkk = sC[bufc * CB + kk * NBS + kb];
         if (!(dkk > S(0))) { spd = false; break; }
         const S dinv = fast_rsqrt(dkk);
         S li[NB], lj[NB];
 #pragma unroll
-        for (int a2 = kb; a2 < NB; ++a2) li[a2] = (a2 > kb || tx > kk) ? sC[bufc * 64 + tx * 8 + a2] * dinv : S(0);
+        for (int a2 = kb; a2 < NB; ++a2) li[a2] = (a2 > kb || tx > kk) ? sC[bufc * CB + tx * NBS + a2] * dinv : S(0);
 #pragma unroll
-        for (int b2 = kb; b2 < NB; ++b2) lj[b2] = (b2 > kb || ty > kk) ? sC[bufc * 64 + ty * 8 + b2] * dinv : S(0);
+        for (int b2 = kb; b2 < NB; ++b2) lj[b2] = (b2 > kb || ty > kk) ? sC[bufc * CB + ty * NBS + b2] * dinv : S(0);
         {   // y_k = (r_o row)[k] / d  ->  gamma
-          const S y = sC[bufc * 64 + (rho & 7) * 8 + (rho >> 3)] * dinv;
+          const S y = sC[bufc * CB + (rho & 7) * NBS + (rho >> 3)] * dinv;
           gamma += y * y;
         }
 #pragma unroll
@@ -182,7 +183,9 @@ __device__ __forceinline__ bool gate_chol(const S* sG, const S* sV, const S* sE,
   return spd;
 }
 
-template <class S>
+// LONG: tracks of more than 33 observations (2M - 2 > 64: windows beyond 33 cameras) keep the gate's Cholesky in registers
+// too (up to 16 x 16 blocks per lane); a separate instantiation, so that the short-track kernel keeps its register budget.
+template <class S, bool LONG>
 __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
   const int b = b0 + blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
   const int F = d.trk_n[(long)(b - b0) * d.wl_stride_n];
@@ -190,8 +193,8 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int m_cap = d.m_cap;
   // G (symmetric, 2M x 2M) plus the appended r_o row 2M as a packed lower triangle: element (i, j), j <= i, at TRI(i, j)
-  S* sC = reinterpret_cast<S*>(smem_raw);              // [2][64] pivot-column exchange of the register Cholesky
-  S* sG = sC + 128;                                    // [(2 m_cap + 1)(2 m_cap + 2) / 2]
+  S* sC = reinterpret_cast<S*>(smem_raw);              // [2][64] ([2][128] LONG) pivot-column exchange of the register Cholesky
+  S* sG = sC + 256;                                    // [(2 m_cap + 1)(2 m_cap + 2) / 2]
   S* sHx = sG + (2 * m_cap + 1) * (2 * m_cap + 2) / 2; // [m_cap][12]
   S* sV = sHx + m_cap * 12;                            // [2 m_cap][3]
   S* sE = sV + 2 * m_cap * 3;                          // [2 m_cap][3]
@@ -520,6 +523,13 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
   const S sig2 = prm[PRM_SIG2];
   (void)0;
   if (fdbg & 4) { gamma = 0; }
+  else if (LONG && rho + 1 > 64 && rho + 1 <= (sizeof(S) == 4 ? 128 : 96)) {   // double: 12 blocks fit the register file, longer tracks take the LDS path
+    const int nbr = (rho >> 3) + 1;
+    if (nbr <= 10) spd = gate_chol<S, LONG ? 10 : 1>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma);
+    else if (nbr <= 12) spd = gate_chol<S, LONG ? 12 : 1>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma);
+    else if (nbr <= 14) spd = gate_chol<S, (LONG && sizeof(S) == 4) ? 14 : 1>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma);
+    else spd = gate_chol<S, (LONG && sizeof(S) == 4) ? 16 : 1>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma);
+  }
   else if (rho + 1 <= 64) {
     const int nbr = (rho >> 3) + 1;   // 8 x 8 blocks in use (wave-uniform)
     switch (nbr) {
@@ -799,21 +809,24 @@ __global__ __launch_bounds__(64) void k_select(Dev<S> d, int b0, int nb) {
 
 size_t feature_lds_bytes(int m_cap, size_t scalar) {
   const size_t r2 = 2 * (size_t)m_cap + 1;
-  return (128 + r2 * (r2 + 1) / 2 + (size_t)m_cap * 12 + 2 * (size_t)m_cap * 3 * 2) * scalar + (size_t)m_cap * sizeof(int) + 16;
+  return (256 + r2 * (r2 + 1) / 2 + (size_t)m_cap * 12 + 2 * (size_t)m_cap * 3 * 2) * scalar + (size_t)m_cap * sizeof(int) + 16;
 }
 
 // one-time, per-device setup (called from msckf_hip_create after hipSetDevice): chi-square table, LDS limits
 void feature_device_setup() {
   (void)hipMemcpyToSymbol(HIP_SYMBOL(c_chi2), kChi2Q05, sizeof(double) * 99);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature<double, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature<double, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 template <class S>
 void launch_feature(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0) return;
   const size_t lds = feature_lds_bytes(d.m_cap, sizeof(S));
-  hipLaunchKernelGGL(k_feature<S>, dim3(d.f_cap, nb), dim3(64), lds, st, d, b0);
+  if (2 * d.m_cap - 2 > 64) hipLaunchKernelGGL((k_feature<S, true>), dim3(d.f_cap, nb), dim3(64), lds, st, d, b0);
+  else hipLaunchKernelGGL((k_feature<S, false>), dim3(d.f_cap, nb), dim3(64), lds, st, d, b0);
 }
 #ifdef MSCKF_ABLATE
 void feat_debug_set(int val) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_feat_dbg), &val, sizeof(int)); }

@@ -32,7 +32,7 @@ int g_gram_dbg = 0;
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int GK = 24;   // rows of B per staged chunk = 8 tracks
-constexpr int GT_MAX = 3; // 64-column panels: the route covers n + 1 <= 192
+constexpr int GT_MAX = 3; // 64 x 64 tiles of one block row held by one workgroup
 constexpr int GORD = 1024; // track order staged in LDS (f_cap <= GORD on this route)
 
 template <class S>
@@ -79,14 +79,25 @@ __global__ __launch_bounds__(256) void k_gram(Dev<S> d, int b0, int npairs, int 
     return;
   }
 
-  // ---- SYRK strip: workgroup ti owns the tiles (ti, ti..nt-1).  The A panel (columns 64 ti ..) is staged once for
+  // ---- SYRK strip: a workgroup owns up to GT_MAX tiles (ti, tj0 .. tj0+GT_MAX-1) of block row ti (windows with more
+  // than GT_MAX panels split a block row over several workgroups).  The A panel (columns 64 ti ..) is staged once for
   // all of them, and only the tracks whose FIRST camera slot lies at or before the panel take part: the tracks are
   // sorted by first slot (k_select), every column of the panel is zero for the others, so the K loop runs over a
   // prefix of the sorted order (tracks end at the newest camera, so the stack is a staircase: ~35 % of the tracks
   // reach the first panel, ~75 % the second at a 30-camera window).
-  const int ti = bx;
-  const int nt = min(GT_MAX, n / 64 + 1);            // tiles that hold a column <= n
-  if (ti >= nt) return;
+  const int np_cap = ldL / 64;                       // panels the buffers hold
+  int ti = 0, tj0 = 0;
+  {
+    int rem = bx;
+    for (ti = 0; ti < np_cap; ++ti) {
+      const int ng = (np_cap - ti + GT_MAX - 1) / GT_MAX;
+      if (rem < ng) { tj0 = ti + GT_MAX * rem; break; }
+      rem -= ng;
+    }
+  }
+  const int nt = min(np_cap, n / 64 + 1);            // tiles that hold a column <= n
+  if (ti >= nt || tj0 >= nt) return;
+  const bool has_diag = tj0 == ti;                   // local tile 0 is the diagonal tile (its B operand is the A panel)
   __shared__ double sA[GK][64], sB[GT_MAX][GK][64];
   __shared__ int sOrd[GORD];
   __shared__ int sCnt;
@@ -125,8 +136,8 @@ __global__ __launch_bounds__(256) void k_gram(Dev<S> d, int b0, int npairs, int 
     for (int it = 0; it < GK / 4; ++it) {
       r.a[it] = rows[it][64 * ti + lc];
 #pragma unroll
-      for (int tj = 0; tj < GT_MAX; ++tj)
-        if (tj > ti && tj < nt) r.b[tj][it] = rows[it][64 * tj + lc];
+      for (int u = 0; u < GT_MAX; ++u)
+        if (tj0 + u > ti && tj0 + u < nt) r.b[u][it] = rows[it][64 * (tj0 + u) + lc];
     }
   };
   auto stage = [&](const Stage& r, int kc) {
@@ -135,32 +146,33 @@ __global__ __launch_bounds__(256) void k_gram(Dev<S> d, int b0, int npairs, int 
       const bool ok = kc + lr + 4 * it < KT;
       sA[lr + 4 * it][lc] = ok ? r.a[it] : 0.0;
 #pragma unroll
-      for (int tj = 0; tj < GT_MAX; ++tj)
-        if (tj > ti && tj < nt) sB[tj][lr + 4 * it][lc] = ok ? r.b[tj][it] : 0.0;
+      for (int u = 0; u < GT_MAX; ++u)
+        if (tj0 + u > ti && tj0 + u < nt) sB[u][lr + 4 * it][lc] = ok ? r.b[u][it] : 0.0;
     }
   };
   v4d acc[GT_MAX][2][2];
 #pragma unroll
-  for (int tj = 0; tj < GT_MAX; ++tj)
+  for (int u = 0; u < GT_MAX; ++u)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[tj][i][j] = v4d{0.0, 0.0, 0.0, 0.0};
+      for (int j = 0; j < 2; ++j) acc[u][i][j] = v4d{0.0, 0.0, 0.0, 0.0};
   auto compute = [&]() {
 #pragma unroll
     for (int k4 = 0; k4 < GK; k4 += 4) {
       const int kr = k4 + (lane >> 4), cc = lane & 15;
       const double a0 = sA[kr][wi * 32 + cc], a1 = sA[kr][wi * 32 + 16 + cc];
 #pragma unroll
-      for (int tj = 0; tj < GT_MAX; ++tj) {
-        if (tj < ti || tj >= nt) continue;
-        const double c0 = tj == ti ? sA[kr][wj * 32 + cc] : sB[tj][kr][wj * 32 + cc];
-        const double c1 = tj == ti ? sA[kr][wj * 32 + 16 + cc] : sB[tj][kr][wj * 32 + 16 + cc];
-        acc[tj][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, c0, acc[tj][0][0], 0, 0, 0);
-        acc[tj][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, c1, acc[tj][0][1], 0, 0, 0);
+      for (int u = 0; u < GT_MAX; ++u) {
+        if (tj0 + u >= nt) continue;
+        const bool dg = has_diag && u == 0;
+        const double c0 = dg ? sA[kr][wj * 32 + cc] : sB[u][kr][wj * 32 + cc];
+        const double c1 = dg ? sA[kr][wj * 32 + 16 + cc] : sB[u][kr][wj * 32 + 16 + cc];
+        acc[u][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, c0, acc[u][0][0], 0, 0, 0);
+        acc[u][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, c1, acc[u][0][1], 0, 0, 0);
         if (dbg & 8) continue;
-        acc[tj][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, c0, acc[tj][1][0], 0, 0, 0);
-        acc[tj][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, c1, acc[tj][1][1], 0, 0, 0);
+        acc[u][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, c0, acc[u][1][0], 0, 0, 0);
+        acc[u][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, c1, acc[u][1][1], 0, 0, 0);
       }
     }
   };
@@ -184,8 +196,9 @@ __global__ __launch_bounds__(256) void k_gram(Dev<S> d, int b0, int npairs, int 
   double* Lam = d.Lam + (long)b * ldL * ldL;
   const double* Dgb = d.Dg + (long)b * d.n_cap * DG_STRIDE;
 #pragma unroll
-  for (int tj = 0; tj < GT_MAX; ++tj) {
-    if (tj < ti || tj >= nt) continue;
+  for (int u = 0; u < GT_MAX; ++u) {
+    const int tj = tj0 + u;
+    if (tj >= nt) continue;
 #pragma unroll
     for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
@@ -194,7 +207,7 @@ __global__ __launch_bounds__(256) void k_gram(Dev<S> d, int b0, int npairs, int 
         for (int r = 0; r < 4; ++r) {
           const int i = 64 * ti + wi * 32 + ib * 16 + (lane >> 4) + 4 * r;
           const int j = 64 * tj + wj * 32 + jb * 16 + (lane & 15);
-          const double val = lam_diag_term(Dgb, n, d.n_cap, i, j) - acc[tj][ib][jb][r];
+          const double val = lam_diag_term(Dgb, n, d.n_cap, i, j) - acc[u][ib][jb][r];
           Lam[(long)i * ldL + j] = val;
           Lam[(long)j * ldL + i] = val;
         }
@@ -426,7 +439,9 @@ void launch_gram(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase) {
 #else
   const int g_dbg = 0;
 #endif
-  const int npairs = d.ldR / 64, ndiag = (d.n_cap + 3) / 4;   // one SYRK strip per 64-column panel
+  int npairs = 0;                                             // SYRK workgroups: <= GT_MAX tiles of one block row each
+  for (int ti = 0; ti < d.ldR / 64; ++ti) npairs += (d.ldR / 64 - ti + GT_MAX - 1) / GT_MAX;
+  const int ndiag = (d.n_cap + 3) / 4;
   if (phase != 2) {
     // two launches of the same kernel: the block-diagonal reduction (short, many small workgroups) and the SYRK strips
     // (MFMA-bound, <= 192 workgroups).  In ONE launch the dispatcher packs strips two to a CU behind the reduction
@@ -438,7 +453,7 @@ void launch_gram(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase) {
   // k_chol_blk (blocked, trailing update on the f64 matrix cores) is 10 % faster than k_chol_T in isolation (104 vs
   // 114 us) but holds the whole register file of its CU (256 VGPR + 188 AGPR), so nothing of the other slice's stream
   // co-schedules with it: 3 % slower end to end with two streams.  Kept selectable (msckf_hip_set_compression(h, 2)).
-  if (d.compress == 3 && launch_chol_gram<S>(d, b0, nb, st)) return;   // blocked matrix-core Cholesky, kernels_chol.hip
+  if ((d.compress == 3 || d.ldR > 192) && launch_chol_gram<S>(d, b0, nb, st)) return;   // blocked matrix-core Cholesky, kernels_chol.hip (the only one for > 192 columns)
   if (d.compress == 2) {
     switch (d.ldR / 16) {
       case 4: hipLaunchKernelGGL((k_chol_blk<S, 4>), dim3(nb), dim3(256), 0, st, d, b0, g_dbg); break;

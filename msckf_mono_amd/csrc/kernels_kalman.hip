@@ -911,6 +911,7 @@ void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st) {
     else if (nbn <= 4) launch_gain_w<S, 4>(d, b0, nb, st);
     else if (nbn <= 8) launch_gain_w<S, 8>(d, b0, nb, st);
     else if (nbn <= nbn_max) launch_gain_w<S, (sizeof(S) == 4 ? 12 : 8)>(d, b0, nb, st);
+    else if (d.joseph == 0 && nbn > 12 && launch_chol_gain_large<S>(d, b0, nb, st)) {}   // two-level blocked factorization + row solves
     else {
       chol_inv();
       gemm<S, OP_W>(d, b0, nb, D, n, st);

@@ -178,9 +178,12 @@ struct Batch : BatchBase {
     rc |= dalloc(&d.trk_ro, TF * 2 * m_cap); rc |= dalloc(&d.trk_first, TF);
     rc |= dalloc(&d.row_start, Bz * (f_cap + 1)); rc |= dalloc(&d.trk_order, TF); rc |= dalloc(&d.stats, Bz * STAT_STRIDE);
     rc |= dalloc(&d.Rbuf, Bz * d.nchunk * (size_t)d.n6cap * d.ldR);
-    // information-form compression (kernels_gram.hip): the register-resident Cholesky covers n + 1 <= 192
-    d.compress = (d.ldR <= 192 && f_cap <= 1024) ? 3 : 0;   // blocked matrix-core Cholesky (kernels_chol.hip)
+    // information-form compression (kernels_gram.hip + kernels_chol.hip)
+    d.compress = (d.ldR <= 384 && f_cap <= 1024) ? 3 : 0;   // blocked matrix-core Cholesky (kernels_chol.hip), two levels beyond 192 columns
+    d.Mp = nullptr; d.Mp2 = nullptr;
+    if (d.n6cap > 192) rc |= dalloc(&d.Mp2, Bz * 24 * 256);
     if (d.compress) {
+      if (d.ldR > 192) rc |= dalloc(&d.Mp, Bz * 12 * 256);
       rc |= dalloc(&d.trk_B, TF * 3 * (size_t)d.ldR); rc |= dalloc(&d.trk_rw, TF * 2 * m_cap); rc |= dalloc(&d.trk_inv, TF * n_cap);
       rc |= dalloc(&d.Dg, Bz * n_cap * DG_STRIDE); rc |= dalloc(&d.Lam, Bz * (size_t)d.ldR * d.ldR);
     }

@@ -140,6 +140,48 @@ def test_cfg5_geometry_vs_oracle(capi, po):
     bt.close()
 
 
+@pytest.mark.parametrize("N,F", [(36, 80), (47, 100), (60, 140)])
+def test_two_level_information_form_equals_householder_route_large_windows(capi, N, F):
+    """Windows of more than 31 cameras (6N + 1 > 192): the information form factors the Gram matrix in two levels
+    (kernels_chol.hip: leading 192 columns, L21 on the matrix cores, Schur complement; 256 / 320 / 384 padded columns
+    here) and must stay with the Householder TSQR route (what the reference does, msckf.h:1338-1366) to rounding, in
+    double, free-running from the first frame -- the frames during which the window is still below 192 columns included."""
+    nf = N + 6
+    tr = sc.Trajectory(5, 11, N, F, nf)
+    res = {}
+    for route in (0, 3):
+        bt = capi.Batch(1, N, F, N, capi.F64)
+        bt.set_compression(route)
+        bt.initialize(0, tr.cfg, tr.imu0)
+        for k in range(nf):
+            H.device_frame(bt, 0, tr, k, N)
+        res[route] = (bt.imu_state(0), bt.cam_states(0)[0], bt.covariance(0), bt.last_stats(0))
+        bt.close()
+    e = H.state_errors(res[3][0], res[0][0], res[3][1], res[0][1], res[3][2], res[0][2])
+    assert H.worst(e) < 1e-8, e
+    assert res[3][3]["m_rows"] == res[0][3]["m_rows"] > 0
+    assert res[3][3]["r_rows"] < res[0][3]["r_rows"] == 6 * N            # gauge directions skipped
+
+
+def test_cfg5_geometry_householder_route_vs_information_form_float(capi):
+    """cfg5 geometry in float, B = 2, resident scenario: the default route (two-level information form) against the TSQR
+    route on the same frames; both are separately held against the oracle (test_cfg5_geometry_vs_oracle runs the default)."""
+    N, F, nf, B = 60, 300, 63, 2
+    trajs = [sc.Trajectory(5, 20 + b, N, F, nf) for b in range(B)]
+    res = {}
+    for route in (0, 3):
+        bt = _resident_batch(capi, trajs, N, F, nf, 60, capi.F32)
+        bt.set_compression(route)
+        bt.run_frames(0, nf); bt.sync()
+        res[route] = [(bt.imu_state(b), bt.cam_states(b)[0], bt.covariance(b), bt.last_stats(b)) for b in range(B)]
+        bt.close()
+    for b in range(B):
+        a, c = res[3][b], res[0][b]
+        e = H.state_errors(a[0], c[0], a[1], c[1], a[2], c[2])
+        assert H.worst(e) < 1e-3, (b, e)
+        assert a[3]["n_passed"] == c[3]["n_passed"] > 0.9 * F
+
+
 def test_fp16_jacobian_dtype(capi, po):
     """MSCKF_HIP_F16H_F32P (BASELINE.json configs[4]: fp16 Jacobian / fp32 covariance): the measurement Jacobian blocks are
     rounded to fp16 (11-bit significand: ~5e-4 relative per entry) where they are formed, everything else stays f32.

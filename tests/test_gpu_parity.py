@@ -233,12 +233,13 @@ def test_information_form_equals_householder_route(capi, prec):
     assert res[1][3]["r_rows"] < res[0][3]["r_rows"] == 6 * N            # gauge directions skipped
 
 
-@pytest.mark.parametrize("prec,N,F", [("f64", 8, 24), ("f64", 26, 60), ("f32", 12, 40), ("f32", 30, 120)])
+@pytest.mark.parametrize("prec,N,F", [("f64", 8, 24), ("f64", 26, 60), ("f32", 12, 40), ("f32", 30, 120), ("f64", 36, 80), ("f32", 44, 100), ("f64", 60, 120)])
 def test_square_root_gain_form_equals_joseph_form(capi, prec, N, F):
     """Covariance update of measurementUpdate (msckf.h:1368-1418): the default square-root gain form (W = P T_H^T L^-T,
     P <- P - W W^T, dx = W L^-1 r_n; no gain matrix, no S^-1) against the reference's literal Joseph sequence, both on the
     device, free-running over the same frames: equal to rounding.  Window sizes cover the register-resident solve
-    (n <= 128 double / 192 float) and the LDS Cholesky + f64 matrix-core path (26 cameras in double)."""
+    (n <= 128 double / 192 float), the LDS Cholesky + f64 matrix-core path (26 cameras in double) and, beyond 32 cameras,
+    the two-level blocked factorization of S with the row solves for W (kernels_chol.hip: 36, 44 and 60 cameras)."""
     nf = N + 8
     tr = sc.Trajectory(2, 9, N, F, nf)
     cd = capi.F64 if prec == "f64" else capi.F32
