@@ -30,9 +30,21 @@ __device__ int g_feat_dbg = 0;   // ablation knob of the -DMSCKF_ABLATE build (s
 
 template <class S> struct Pose { M3<S> R; V3<S> t; };
 
+// Reciprocal / square root inside the Levenberg-Marquardt iteration.  double: IEEE (the 1e-6 parity of the double filter
+// follows the reference's iterates).  float: hardware rcp + one Newton step (<= 1 ulp) instead of the ~10-instruction IEEE
+// division sequence -- the iteration is 28 % of the kernel's VALU instructions, half of them divisions; the float filter's
+// tolerances (tests/helpers.py:check_tracks) are four orders of magnitude above the difference.
+template <class S> __device__ __forceinline__ S lm_rcp(S x);
+template <> __device__ __forceinline__ double lm_rcp<double>(double x) { return 1.0 / x; }
+template <> __device__ __forceinline__ float lm_rcp<float>(float x) { const float r = __builtin_amdgcn_rcpf(x); return r * __builtin_fmaf(-x, r, 2.0f); }
+template <class S> __device__ __forceinline__ S lm_sqrt(S x);
+template <> __device__ __forceinline__ double lm_sqrt<double>(double x) { return sqrt(x); }
+template <> __device__ __forceinline__ float lm_sqrt<float>(float x) { return __builtin_amdgcn_sqrtf(x); }
+
 template <class S>
 __device__ __forceinline__ S tri_cost(const Pose<S>& T, S a, S b, S rho, S zx, S zy) {  // :1027-1047
   const V3<S> h = mulv(T.R, mk3(a, b, S(1))) + (rho * T.t);
+  if (sizeof(S) == 4) { const S iz = lm_rcp(h.z); const S dx = h.x * iz - zx, dy = h.y * iz - zy; return dx * dx + dy * dy; }
   const S dx = h.x / h.z - zx, dy = h.y / h.z - zy;
   return dx * dx + dy * dy;
 }
@@ -43,12 +55,23 @@ __device__ __forceinline__ void ldlt3(const S A[6], S lam, const S b[3], S x[3])
   // A packed: a00 a01 a02 a11 a12 a22
   const S a00 = A[0] + lam, a01 = A[1], a02 = A[2], a11 = A[3] + lam, a12 = A[4], a22 = A[5] + lam;
   const S d0 = a00;
-  const S l10 = a01 / d0, l20 = a02 / d0;
-  const S d1 = a11 - l10 * l10 * d0;
-  const S l21 = (a12 - l20 * l10 * d0) / d1;
-  const S d2 = a22 - l20 * l20 * d0 - l21 * l21 * d1;
-  S y0 = b[0], y1 = b[1] - l10 * y0, y2 = b[2] - l20 * y0 - l21 * y1;
-  y0 /= d0; y1 /= d1; y2 /= d2;
+  S y0, y1, y2, l10, l20, l21;
+  if (sizeof(S) == 4) {
+    const S i0 = lm_rcp(d0);
+    l10 = a01 * i0; l20 = a02 * i0;
+    const S d1 = a11 - l10 * l10 * d0, i1 = lm_rcp(d1);
+    l21 = (a12 - l20 * l10 * d0) * i1;
+    const S d2 = a22 - l20 * l20 * d0 - l21 * l21 * d1;
+    y0 = b[0]; y1 = b[1] - l10 * y0; y2 = b[2] - l20 * y0 - l21 * y1;
+    y0 *= i0; y1 *= i1; y2 *= lm_rcp(d2);
+  } else {
+    l10 = a01 / d0; l20 = a02 / d0;
+    const S d1 = a11 - l10 * l10 * d0;
+    l21 = (a12 - l20 * l10 * d0) / d1;
+    const S d2 = a22 - l20 * l20 * d0 - l21 * l21 * d1;
+    y0 = b[0]; y1 = b[1] - l10 * y0; y2 = b[2] - l20 * y0 - l21 * y1;
+    y0 /= d0; y1 /= d1; y2 /= d2;
+  }
   x[2] = y2; x[1] = y1 - l21 * x[2]; x[0] = y0 - l10 * x[1] - l20 * x[2];
 }
 
@@ -125,6 +148,9 @@ __device__ __forceinline__ bool gate_chol(const S* sG, const S* sV, const S* sE,
 #pragma unroll
       for (int q = 0; q < 3; ++q) { vr[a2][q] = ok ? sV[(3 + i) * 3 + q] : S(0); er[a2][q] = ok ? sE[(3 + i) * 3 + q] : S(0); }
     }
+    int rbase[NB];   // packed-triangle offset of row 3 + 8 a2 + tx (a block below the diagonal block never needs SYM's swap)
+#pragma unroll
+    for (int a2 = 0; a2 < NB; ++a2) rbase[a2] = TRI(3 + 8 * a2 + tx, 3);
 #pragma unroll
     for (int b2 = 0; b2 < NB; ++b2) {
       const int j = 8 * b2 + ty;
@@ -137,7 +163,7 @@ __device__ __forceinline__ bool gate_chol(const S* sG, const S* sV, const S* sE,
         const int i = 8 * a2 + tx;
         S val = 0;
         if (okj && i < rho) {
-          val = sG[SYM(3 + i, 3 + j)] - (vr[a2][0] * ec[0] + vr[a2][1] * ec[1] + vr[a2][2] * ec[2])
+          val = sG[a2 > b2 ? rbase[a2] + j : SYM(3 + i, 3 + j)] - (vr[a2][0] * ec[0] + vr[a2][1] * ec[1] + vr[a2][2] * ec[2])
                 - (er[a2][0] * vc[0] + er[a2][1] * vc[1] + er[a2][2] * vc[2]);
           if (i == j) val += sig2;
         } else if (okj && i == rho) {
@@ -186,7 +212,7 @@ __device__ __forceinline__ bool gate_chol(const S* sG, const S* sV, const S* sE,
 // LONG: tracks of more than 33 observations (2M - 2 > 64: windows beyond 33 cameras) keep the gate's Cholesky in registers
 // too (up to 16 x 16 blocks per lane); a separate instantiation, so that the short-track kernel keeps its register budget.
 template <class S, bool LONG>
-__global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (sizeof(S) == 4 ? 3 : 2), sizeof(S) == 4 && !LONG ? 3 : 2))) void k_feature(Dev<S> d, int b0) {
   const int b = b0 + blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
   const int F = d.trk_n[(long)(b - b0) * d.wl_stride_n];
   if (t >= F) return;
@@ -208,6 +234,11 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
   const int ld = d.ld;
   const bool act = lane < M;
   int status = 0;
+#ifdef MSCKF_ABLATE
+  const int fdbg = g_feat_dbg;
+#else
+  constexpr int fdbg = 0;
+#endif
   if (M < 2 || M > m_cap || M > 64) {                  // cannot be residualized (checkMotion :982 returns false)
     if (lane == 0) { d.trk_status[tb] = 0; d.trk_gamma[tb] = 0; d.trk_first[tb] = 0; }
     return;
@@ -231,7 +262,7 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
   const S z0x = wave_bcast(zx, 0), z0y = wave_bcast(zy, 0);
 
   // ---- checkMotion :980-1025
-  {
+  if (!(fdbg & 256)) {
     V3<S> dir = mk3(z0x, z0y, S(1));
     dir = (S(1) / dsqrt(dot3(dir, dir))) * dir;
     dir = multv(C0, dir);
@@ -267,11 +298,6 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
   S total_cost = wave_sum(act ? tri_cost(T, sa, sb, srho, zx, zy) : S(0));
   bool reduced = false;
   int inner = 0, outer = 0;
-#ifdef MSCKF_ABLATE
-  const int fdbg = g_feat_dbg;
-#else
-  constexpr int fdbg = 0;
-#endif
   if (!given && !(fdbg & 1)) do {
     S Ab[9];  // a00 a01 a02 a11 a12 a22 b0 b1 b2
     {
@@ -280,13 +306,25 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
       for (int i = 0; i < 3; ++i) { W[i][0] = T.R.m[i][0]; W[i][1] = T.R.m[i][1]; }
       W[0][2] = T.t.x; W[1][2] = T.t.y; W[2][2] = T.t.z;
       S J[2][3];
-      for (int j = 0; j < 3; ++j) {
-        J[0][j] = S(1) / h.z * W[0][j] - h.x / (h.z * h.z) * W[2][j];
-        J[1][j] = S(1) / h.z * W[1][j] - h.y / (h.z * h.z) * W[2][j];
+      S r0, r1, e, w;
+      if (sizeof(S) == 4) {
+        const S iz = lm_rcp(h.z), xz = h.x * iz, yz = h.y * iz;
+        for (int j = 0; j < 3; ++j) {
+          J[0][j] = iz * (W[0][j] - xz * W[2][j]);
+          J[1][j] = iz * (W[1][j] - yz * W[2][j]);
+        }
+        r0 = xz - zx; r1 = yz - zy;
+        e = lm_sqrt(r0 * r0 + r1 * r1);
+        w = (e <= S(0.01)) ? S(1) : S(0.005) * lm_rcp(e);
+      } else {
+        for (int j = 0; j < 3; ++j) {
+          J[0][j] = S(1) / h.z * W[0][j] - h.x / (h.z * h.z) * W[2][j];
+          J[1][j] = S(1) / h.z * W[1][j] - h.y / (h.z * h.z) * W[2][j];
+        }
+        r0 = h.x / h.z - zx; r1 = h.y / h.z - zy;
+        e = dsqrt(r0 * r0 + r1 * r1);
+        w = (e <= S(0.01)) ? S(1) : S(0.01) / (S(2) * e);
       }
-      const S r0 = h.x / h.z - zx, r1 = h.y / h.z - zy;
-      const S e = dsqrt(r0 * r0 + r1 * r1);
-      const S w = (e <= S(0.01)) ? S(1) : S(0.01) / (S(2) * e);
       const S w2 = (w == S(1)) ? S(1) : w * w;
       const S m = act ? w2 : S(0);
       Ab[0] = m * (J[0][0] * J[0][0] + J[1][0] * J[1][0]);
@@ -305,11 +343,12 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
       S dl[3];
       ldlt3(Ab, lambda, Ab + 6, dl);
       const S na = sa - dl[0], nb = sb - dl[1], nr = srho - dl[2];
-      delta_norm = dsqrt(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
+      delta_norm = lm_sqrt(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
       const S new_cost = wave_sum(act ? tri_cost(T, na, nb, nr, zx, zy) : S(0));
       if (new_cost < total_cost) {
         reduced = true; sa = na; sb = nb; srho = nr; total_cost = new_cost;
-        lambda = lambda / 10 > S(1e-10) ? lambda / 10 : S(1e-10);
+        const S l10th = sizeof(S) == 4 ? lambda * S(0.1) : lambda / 10;
+        lambda = l10th > S(1e-10) ? l10th : S(1e-10);
       } else {
         reduced = false;
         lambda = lambda * 10 < S(1e12) ? lambda * 10 : S(1e12);
@@ -469,37 +508,77 @@ __global__ __launch_bounds__(64) void k_feature(Dev<S> d, int b0) {
   const int R2 = 2 * M, rho = R2 - 3;
   const S* P = d.P + (long)b * ld * ld;
   {
-    const int npair = M * (M + 1) / 2;
+    // pairs (a, bq), a <= bq, enumerated as a rectangle of M/2 (rounded up) rows of width M | 1: row k of the rectangle
+    // holds row k of the triangle (M - k pairs) followed by row M - 1 - k (M even) or M - k (M odd) -- two integer
+    // operations per pair instead of a square root and a search
+    const int npair = (fdbg & 32) ? 0 : M * (M + 1) / 2;
+    const int Wd = M | 1;
+    const float invW = 1.0f / (float)Wd;
     for (int p = lane; p < npair; p += 64) {
-      // row-major upper-triangular index -> (a, bq), a <= bq
-      int a = (int)((S(2 * M + 1) - dsqrt(S((2 * M + 1) * (2 * M + 1) - 8 * p))) * S(0.5));
-      while (a > 0 && a * (2 * M - a + 1) / 2 > p) --a;
-      while ((a + 1) * (2 * M - a) / 2 <= p) ++a;
-      const int bq = a + (p - a * (2 * M - a + 1) / 2);
+      const int k = (int)(((float)p + 0.5f) * invW), c = p - k * Wd;
+      const bool first = c < M - k;
+      const int a = first ? k : ((M & 1) ? M - k : M - 1 - k);
+      const int bq = a + (first ? c : c - (M - k));
       const int sa2 = sSlot[a], sb2 = sSlot[bq];
       const S* Pab = P + (long)(15 + 6 * sb2) * ld + 15 + 6 * sa2;   // element (i,j) at Pab[j*ld + i]
-      S Tt[2][6];
-      for (int j = 0; j < 6; ++j) {
-        S s0 = 0, s1 = 0;
-        for (int i = 0; i < 6; ++i) { const S pv = (fdbg & 2) ? S(i == j ? 1e-4 : 0) : Pab[(long)j * ld + i]; s0 += sHx[a * 12 + i] * pv; s1 += sHx[a * 12 + 6 + i] * pv; }
-        Tt[0][j] = s0; Tt[1][j] = s1;
-      }
-      for (int rr = 0; rr < 2; ++rr) for (int cc = 0; cc < 2; ++cc) {
-        S s = 0;
-        for (int j = 0; j < 6; ++j) s += Tt[rr][j] * sHx[bq * 12 + cc * 6 + j];
-        if (a != bq || rr <= cc) sG[TRI(2 * bq + cc, 2 * a + rr)] = s;     // a <= bq: row 2bq+cc >= column 2a+rr
+      S pv[6][6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) pv[j][i] = (fdbg & 2) ? S(i == j ? 1e-4 : 0) : Pab[(long)j * ld + i];
+      if constexpr (sizeof(S) == 4) {
+        // both rows of the 2 x 6 block at once on the packed-f32 pipe: (T0j, T1j) += (h0i, h1i) * P(i, j)
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 ha[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ha[i] = f2{(float)sHx[a * 12 + i], (float)sHx[a * 12 + 6 + i]};
+        f2 Tt[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          f2 t = f2{0.0f, 0.0f};
+#pragma unroll
+          for (int i = 0; i < 6; ++i) t += ha[i] * (float)pv[j][i];
+          Tt[j] = t;
+        }
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          f2 g = f2{0.0f, 0.0f};
+#pragma unroll
+          for (int j = 0; j < 6; ++j) g += Tt[j] * (float)sHx[bq * 12 + cc * 6 + j];
+          if (a != bq || 0 <= cc) sG[TRI(2 * bq + cc, 2 * a)] = (S)g.x;          // a <= bq: row 2bq+cc >= column 2a+rr
+          if (a != bq || 1 <= cc) sG[TRI(2 * bq + cc, 2 * a + 1)] = (S)g.y;
+        }
+      } else {
+        S Tt[2][6];
+        for (int j = 0; j < 6; ++j) {
+          S s0 = 0, s1 = 0;
+          for (int i = 0; i < 6; ++i) { s0 += sHx[a * 12 + i] * pv[j][i]; s1 += sHx[a * 12 + 6 + i] * pv[j][i]; }
+          Tt[0][j] = s0; Tt[1][j] = s1;
+        }
+        for (int rr = 0; rr < 2; ++rr) for (int cc = 0; cc < 2; ++cc) {
+          S s = 0;
+          for (int j = 0; j < 6; ++j) s += Tt[rr][j] * sHx[bq * 12 + cc * 6 + j];
+          if (a != bq || rr <= cc) sG[TRI(2 * bq + cc, 2 * a + rr)] = s;     // a <= bq: row 2bq+cc >= column 2a+rr
+        }
       }
     }
   }
   __syncthreads();
   // ---- E = (G V) T - 1/2 V (T^T V^T G V T)
-  {
-    S gv[2][3];
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const int row = row0 + s2;
-      S a0 = 0, a1 = 0, a2 = 0;
-      if (row < R2 && !(fdbg & 16)) for (int c = 0; c < R2; ++c) { const S gval = sG[SYM(row, c)]; a0 += gval * sV[c * 3]; a1 += gval * sV[c * 3 + 1]; a2 += gval * sV[c * 3 + 2]; }
-      gv[s2][0] = a0; gv[s2][1] = a1; gv[s2][2] = a2;
+  if (!(fdbg & 128)) {
+    // rows row0, row0 + 1 of G V with G in its packed triangle: the address of G(row0, c) advances by 1 up to the diagonal
+    // and by c + 1 beyond it (running index instead of a triangular-number computation per element), row0 + 1 sits
+    // row0 + 1 entries further below the diagonal and 1 entry further beyond it
+    S gv[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    if (row0 < R2 && !(fdbg & 16)) {
+      int idx = TRI(row0, 0);
+      for (int c = 0; c < R2; ++c) {
+        const S g0 = sG[idx], g1 = sG[idx + (c <= row0 ? row0 + 1 : 1)];
+        const S v0 = sV[c * 3], v1 = sV[c * 3 + 1], v2 = sV[c * 3 + 2];
+        gv[0][0] += g0 * v0; gv[0][1] += g0 * v1; gv[0][2] += g0 * v2;
+        gv[1][0] += g1 * v0; gv[1][1] += g1 * v1; gv[1][2] += g1 * v2;
+        idx += c < row0 ? 1 : c + 1;
+      }
     }
     S vgv[3][3];
     for (int p = 0; p < 3; ++p) for (int q = 0; q < 3; ++q) vgv[p][q] = wave_sum(v[0][p] * gv[0][q] + v[1][p] * gv[1][q]);
