@@ -91,8 +91,8 @@ __global__ __launch_bounds__(256) void k_chol_mfma(Dev<SO> d, int b0) {
   const int app_per = MODE == CH_GAIN ? 16 * NA - 1 : 0;              // rows of PHt per part (the last appended row is r_n^T)
   const int app_lo = part * app_per, app_hi = min(D, app_lo + app_per);   // [app_lo, app_hi) rows of PHt
   const int zrow = 16 * NR - 1;                                          // panel row of r_n^T
-  __shared__ T sP[16 * NR][LP];   // current panel: every row, 16 columns
-  __shared__ T sM[16][LP];        // M: y = x M solves y L11^T = x (zero columns for skipped pivots)
+  __shared__ T sPP[2][16 * NR][LP];   // panels p & 1: every row, 16 columns (two, for the lookahead)
+  __shared__ T sMM[2][16][LP];        // M: y = x M solves y L11^T = x (zero columns for skipped pivots)
   __shared__ T sD0[16 * NB];      // GRAM: original diagonal (pivot tolerance)
 
   // ---- sources
@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256) void k_chol_mfma(Dev<SO> d, int b0) {
 
   // ---- level B: acc -= L21 L21^T, the CH_SPLIT columns of L21 (left in Lam by k_trsm_l21) staged 16 at a time
   if (LEVEL_B) {
+    T (*sP)[LP] = sPP[0];
     for (int q = 0; q < CH_SPLIT / 16; ++q) {
       __syncthreads();
       for (int e = tid; e < 16 * NB * 16; e += 256) {
@@ -170,150 +171,194 @@ __global__ __launch_bounds__(256) void k_chol_mfma(Dev<SO> d, int b0) {
     }
   }
 
+  // ---- the panel loop with one panel of lookahead: while the other wavefronts apply panel p to the trailing blocks right of
+  // column p + 1, wavefront 0 already factors the diagonal block of panel p + 1 (its column was updated and dropped into
+  // the second LDS panel first).  The 16-pivot chain of the diagonal block is the longest phase of a panel; it no longer
+  // waits for the matrix-core update, and the update no longer waits for it.
+  // (1) blocks (i, p), i >= p, from the accumulators to LDS panel p & 1
+  auto drop = [&](auto pc) __attribute__((always_inline)) {
+    constexpr int p = decltype(pc)::value;
+    T (*sP)[LP] = sPP[p & 1];
+    if (pj == (p & 1)) {
+#pragma unroll
+      for (int ii = 0; ii < HR; ++ii) {
+        if (2 * ii + 1 < p && 2 * ii + 1 < NB) continue;   // compile-time: block row above the panel
+        const int i = 2 * ii + pi;
+        if (i < p || i >= NR) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sP[16 * i + Mf<T>::row(lane, r)][lane & 15] = acc[ii][p >> 1][r];
+      }
+    }
+  };
+  // (2) diagonal block on ONE wavefront, all 64 lanes busy: lane (r = lane & 15, g = lane >> 4) holds row r, columns
+  // 4q + g of the block and of the identity image v.  Per pivot: rsqrt on the owner, dinv by v_readlane, the scaled pivot
+  // column and the multipliers L(j, k) reach the other lanes through the LDS crossbar (ds_bpermute), 4 + 4 FMAs/lane.
+  auto diag = [&](auto pc) __attribute__((always_inline)) {
+    constexpr int p = decltype(pc)::value;
+    T (*sP)[LP] = sPP[p & 1];
+    T (*sM)[LP] = sMM[p & 1];
+    if (w == 0) {
+      const int kcount = min(16, n - 16 * p);
+      const int r = lane & 15, g = lane >> 4;
+      T x[4], v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { x[q] = sP[16 * p + r][4 * q + g]; v[q] = (4 * q + g == r) ? T(1) : T(0); }
+      const T d0 = GRAMLIKE ? sD0[16 * p + r] : T(0);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int gk = k & 3, qk = k >> 2, src = 16 * gk + k;     // pivot (k, k) lives in lane src, register x[qk]
+        bool skip_l;
+        T piv = x[qk];
+        if (GRAMLIKE) skip_l = (k >= kcount) || !(piv > tol * d0);
+        else { skip_l = k >= kcount; piv = piv > T(0) ? piv : Lim<T>::tiny(); }
+        const T dinv_l = skip_l ? T(0) : fast_rsqrt(piv);
+        const T dinv = wave_bcast(dinv_l, src);
+        const T pv = wave_bcast(piv, src);
+        if (GRAMLIKE && k < kcount && dinv == T(0)) ++nskip;
+        // column k of L (valid in the lanes of group gk): L(r, k)
+        const T c_own = (r == k) ? pv * dinv : (r > k ? x[qk] * dinv : T(0));
+        const T vk_own = v[qk] * dinv;
+        if (g == gk) { x[qk] = c_own; v[qk] = vk_own; }
+        const T c = __shfl(c_own, 16 * gk + r, 64);     // L(r, k) for every group
+        const T vk = __shfl(vk_own, 16 * gk + r, 64);   // v(r, k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (4 * q + 3 <= k) continue;                 // compile-time: all of this register's columns are <= k
+          const int j = 4 * q + g;
+          const T ljk = __shfl(c_own, 16 * gk + (j & 15), 64);   // L(j, k)
+          if (j > k) {
+            if (r >= j) x[q] -= c * ljk;
+            v[q] -= vk * ljk;
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int j = 4 * q + g; sP[16 * p + r][j] = j <= r ? x[q] : T(0); sM[r][j] = v[q]; }
+    }
+  };
+  // (3) panel below the diagonal block: L21 = A21 M on the matrix cores, one 16-row block per wavefront at a time
+  auto l21 = [&](auto pc) __attribute__((always_inline)) {
+    constexpr int p = decltype(pc)::value;
+    T (*sP)[LP] = sPP[p & 1];
+    T (*sM)[LP] = sMM[p & 1];
+    T bq[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) bq[s4] = sM[(lane >> 4) + 4 * s4][lane & 15];
+    for (int i = p + 1 + w; i < NR; i += 4) {
+      if (i < NB && 16 * i >= main_rows) continue;
+      T a[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) a[s4] = sP[16 * i + (lane & 15)][(lane >> 4) + 4 * s4];
+      V y = V{0, 0, 0, 0};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) y = Mf<T>::mma(a[s4], bq[s4], y);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sP[16 * i + Mf<T>::row(lane, r)][lane & 15] = y[r];
+    }
+  };
+  // (4) results of panel p, written by wavefronts 1..3 (192 threads) while wavefront 0 factors the next diagonal block
+  auto outputs = [&](auto pc) __attribute__((always_inline)) {
+    constexpr int p = decltype(pc)::value;
+    T (*sP)[LP] = sPP[p & 1];
+    T (*sM)[LP] = sMM[p & 1];
+    if (w == 0) return;
+    const int t = tid - 64;                             // 0 .. 191
+    if (GRAMLIKE) {
+      // rows 16p .. 16p+15 of T = L^T: T[k][c] = L(c, k), zero left of the diagonal and beyond column n
+      for (int c = t; c < 16 * NB; c += 192) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int k = 16 * p + j;
+          const T val = (c >= k && c <= n) ? sP[c][j] : T(0);
+          if (k < n && OFF + c < d.ldR) Rt[(long)(OFF + k) * d.ldR + OFF + c] = (SO)val;
+          if (MODE == CH_GRAM_A && two_level && c >= k) d.Lam[(long)b * d.ldR * d.ldR + (long)c * d.ldR + k] = (double)sP[c][j];   // f64 L11 in place
+        }
+      }
+      if (MODE == CH_GRAM_B) {                          // columns left of this launch's block: zero
+        for (int c = t; c < OFF; c += 192) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) { const int k = 16 * p + j; if (k < n) Rt[(long)(OFF + k) * d.ldR + c] = SO(0); }
+        }
+      }
+      if (MODE == CH_GRAM_A && two_level)
+        for (int e = t; e < 256; e += 192) d.Mp[((long)b * (CH_SPLIT / 16) + p) * 256 + e] = (double)sM[e >> 4][e & 15];
+    } else if (SLIKE) {
+      // L in place (row-major lower triangle of Smat) and this panel's M, for k_trsm_rows
+      for (int c = t; c < 16 * NB; c += 192) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int k = 16 * p + j;
+          if (c >= k && c < n && k < n) Sm[(long)(OFF + c) * d.n6cap + OFF + k] = (SO)sP[c][j];
+        }
+      }
+      for (int e = t; e < 256; e += 192) d.Mp2[((long)b * 24 + OFF / 16 + p) * 256 + e] = (SO)sM[e >> 4][e & 15];
+    } else {
+      // columns 16p .. 16p+15 of W for this part's rows; dx += W(:, k) z_k (thread 64 + a owns appended row a)
+      if (t < app_per) {
+        const int ar = app_lo + t;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int k = 16 * p + j;
+          const T wv = sP[16 * NB + t][j];
+          if (k < n && ar < app_hi) { Wg[(long)k * d.ld + ar] = (SO)wv; dxacc += wv * sP[zrow][j]; }
+        }
+      }
+    }
+  };
+  // (5) rank-16 update of trailing blocks: acc(i, j) -= L(i, p) L(j, p)^T; NEXT: column p + 1 only, else the columns right of it
+  auto trail = [&](auto pc, auto nextc) __attribute__((always_inline)) {
+    constexpr int p = decltype(pc)::value;
+    constexpr bool NEXT = decltype(nextc)::value;
+    T (*sP)[LP] = sPP[p & 1];
+#pragma unroll
+    for (int jj = 0; jj < HC; ++jj) {
+      if (2 * jj + 1 <= p) continue;                    // compile-time: at or left of the panel for either parity
+      if (NEXT && 2 * jj > p + 1) continue;             // compile-time: right of column p + 1 for either parity
+      const int j = 2 * jj + pj;
+      if (j <= p || j >= NB || 16 * j >= n) continue;
+      if (NEXT ? j != p + 1 : j == p + 1) continue;
+      T bq[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) bq[s4] = sP[16 * j + (lane & 15)][4 * s4 + (lane >> 4)];
+#pragma unroll
+      for (int ii = 0; ii < HR; ++ii) {
+        if (2 * ii + 1 < 2 * jj && 2 * ii + 1 < NB) continue;   // compile-time: main block row above the column block
+        const int i = 2 * ii + pi;
+        if (i >= NR || (i < NB && (i < j || 16 * i >= main_rows))) continue;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const T a = -sP[16 * i + (lane & 15)][4 * s4 + (lane >> 4)];
+          acc[ii][jj] = Mf<T>::mma(a, bq[s4], acc[ii][jj]);
+        }
+      }
+    }
+  };
+  __syncthreads();
+  CH_TICK(0);
+  if (n > 0) {
+    drop(std::integral_constant<int, 0>{});
+    __syncthreads();
+    CH_TICK(1);
+    diag(std::integral_constant<int, 0>{});
+    __syncthreads();
+    CH_TICK(2);
+  }
   auto panel = [&](auto pc) __attribute__((always_inline)) {
     constexpr int p = decltype(pc)::value;
     if (16 * p < n) {
-      __syncthreads();                                   // the previous panel's operands are no longer read
-      CH_TICK(p == 0 ? 0 : 5);
-      // ---- (1) blocks (i, p), i >= p, from the accumulators to the LDS panel
-      if (pj == (p & 1)) {
-#pragma unroll
-        for (int ii = 0; ii < HR; ++ii) {
-          if (2 * ii + 1 < p && 2 * ii + 1 < NB) continue;   // compile-time: block row above the panel
-          const int i = 2 * ii + pi;
-          if (i < p || i >= NR) continue;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) sP[16 * i + Mf<T>::row(lane, r)][lane & 15] = acc[ii][p >> 1][r];
-        }
-      }
-      __syncthreads();
-      CH_TICK(1);
-      // ---- (2) diagonal block on ONE wavefront, all 64 lanes busy: lane (r = lane & 15, g = lane >> 4) holds row r,
-      // columns 4q + g of the block and of the identity image v.  Per pivot: rsqrt on the owner, dinv by v_readlane, the scaled
-      // pivot column and the multipliers L(j, k) reach the other lanes through the LDS crossbar (ds_bpermute), 4 + 4 FMAs/lane.
-      if (w == 0) {
-        const int kcount = min(16, n - 16 * p);
-        const int r = lane & 15, g = lane >> 4;
-        T x[4], v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { x[q] = sP[16 * p + r][4 * q + g]; v[q] = (4 * q + g == r) ? T(1) : T(0); }
-        const T d0 = GRAMLIKE ? sD0[16 * p + r] : T(0);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          constexpr int dummy = 0; (void)dummy;
-          const int gk = k & 3, qk = k >> 2, src = 16 * gk + k;     // pivot (k, k) lives in lane src, register x[qk]
-          bool skip_l;
-          T piv = x[qk];
-          if (GRAMLIKE) skip_l = (k >= kcount) || !(piv > tol * d0);
-          else { skip_l = k >= kcount; piv = piv > T(0) ? piv : Lim<T>::tiny(); }
-          const T dinv_l = skip_l ? T(0) : fast_rsqrt(piv);
-          const T dinv = wave_bcast(dinv_l, src);
-          const T pv = wave_bcast(piv, src);
-          if (GRAMLIKE && k < kcount && dinv == T(0)) ++nskip;
-          // column k of L (valid in the lanes of group gk): L(r, k)
-          const T c_own = (r == k) ? pv * dinv : (r > k ? x[qk] * dinv : T(0));
-          const T vk_own = v[qk] * dinv;
-          if (g == gk) { x[qk] = c_own; v[qk] = vk_own; }
-          const T c = __shfl(c_own, 16 * gk + r, 64);     // L(r, k) for every group
-          const T vk = __shfl(vk_own, 16 * gk + r, 64);   // v(r, k)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if (4 * q + 3 <= k) continue;                 // compile-time: all of this register's columns are <= k
-            const int j = 4 * q + g;
-            const T ljk = __shfl(c_own, 16 * gk + (j & 15), 64);   // L(j, k)
-            if (j > k) {
-              if (r >= j) x[q] -= c * ljk;
-              v[q] -= vk * ljk;
-            }
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const int j = 4 * q + g; sP[16 * p + r][j] = j <= r ? x[q] : T(0); sM[r][j] = v[q]; }
-      }
-      __syncthreads();
-      CH_TICK(2);
-      // ---- (3) panel below the diagonal block: L21 = A21 M on the matrix cores, one 16-row block per wavefront at a time
-      {
-        T bq[4];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) bq[s4] = sM[(lane >> 4) + 4 * s4][lane & 15];
-        for (int i = p + 1 + w; i < NR; i += 4) {
-          if (i < NB && 16 * i >= main_rows) continue;
-          T a[4];
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) a[s4] = sP[16 * i + (lane & 15)][(lane >> 4) + 4 * s4];
-          V y = V{0, 0, 0, 0};
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) y = Mf<T>::mma(a[s4], bq[s4], y);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) sP[16 * i + Mf<T>::row(lane, r)][lane & 15] = y[r];
-        }
-      }
+      const bool more = p + 1 < NB && 16 * (p + 1) < n;
+      l21(pc);
       __syncthreads();
       CH_TICK(3);
-      // ---- (4) results of this panel
-      if (GRAMLIKE) {
-        // rows 16p .. 16p+15 of T = L^T: T[k][c] = L(c, k), zero left of the diagonal and beyond column n
-        if (tid < 16 * NB) {
-          const int c = tid;
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const int k = 16 * p + j;
-            const T val = (c >= k && c <= n) ? sP[c][j] : T(0);
-            if (k < n && OFF + c < d.ldR) Rt[(long)(OFF + k) * d.ldR + OFF + c] = (SO)val;
-            if (MODE == CH_GRAM_A && two_level && c >= k) d.Lam[(long)b * d.ldR * d.ldR + (long)c * d.ldR + k] = (double)sP[c][j];   // f64 L11 in place
-          }
-        }
-        if (MODE == CH_GRAM_B && tid < OFF) {          // columns left of this launch's block: zero
-#pragma unroll
-          for (int j = 0; j < 16; ++j) { const int k = 16 * p + j; if (k < n) Rt[(long)(OFF + k) * d.ldR + tid] = SO(0); }
-        }
-        if (MODE == CH_GRAM_A && two_level) d.Mp[((long)b * (CH_SPLIT / 16) + p) * 256 + tid] = (double)sM[tid >> 4][tid & 15];
-      } else if (SLIKE) {
-        // L in place (row-major lower triangle of Smat) and this panel's M, for k_trsm_rows
-        if (tid < 16 * NB) {
-          const int c = tid;
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const int k = 16 * p + j;
-            if (c >= k && c < n && k < n) Sm[(long)(OFF + c) * d.n6cap + OFF + k] = (SO)sP[c][j];
-          }
-        }
-        d.Mp2[((long)b * 24 + OFF / 16 + p) * 256 + tid] = (SO)sM[tid >> 4][tid & 15];
-      } else {
-        // columns 16p .. 16p+15 of W for this part's rows; dx += W(:, k) z_k
-        if (tid < app_per) {
-          const int ar = app_lo + tid;
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const int k = 16 * p + j;
-            const T wv = sP[16 * NB + tid][j];
-            if (k < n && ar < app_hi) { Wg[(long)k * d.ld + ar] = (SO)wv; dxacc += wv * sP[zrow][j]; }
-          }
-        }
-      }
+      if (more) { trail(pc, std::true_type{}); drop(std::integral_constant<int, (p + 1 < NB ? p + 1 : p)>{}); }
+      __syncthreads();
       CH_TICK(4);
-      // ---- (5) rank-16 update of the trailing blocks: acc(i, j) -= L(i, p) L(j, p)^T
-#pragma unroll
-      for (int jj = 0; jj < HC; ++jj) {
-        if (2 * jj + 1 <= p) continue;                    // compile-time: at or left of the panel for either parity
-        const int j = 2 * jj + pj;
-        if (j <= p || j >= NB || 16 * j >= n) continue;
-        T bq[4];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) bq[s4] = sP[16 * j + (lane & 15)][4 * s4 + (lane >> 4)];
-#pragma unroll
-        for (int ii = 0; ii < HR; ++ii) {
-          if (2 * ii + 1 < 2 * jj && 2 * ii + 1 < NB) continue;   // compile-time: main block row above the column block
-          const int i = 2 * ii + pi;
-          if (i >= NR || (i < NB && (i < j || 16 * i >= main_rows))) continue;
-#pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) {
-            const T a = -sP[16 * i + (lane & 15)][4 * s4 + (lane >> 4)];
-            acc[ii][jj] = Mf<T>::mma(a, bq[s4], acc[ii][jj]);
-          }
-        }
-      }
+      if (more) diag(std::integral_constant<int, (p + 1 < NB ? p + 1 : p)>{});
+      CH_TICK(2);
+      outputs(pc);
+      trail(pc, std::false_type{});
+      __syncthreads();
+      CH_TICK(5);
     }
   };
   cstatic_for<NB>(panel);
@@ -327,7 +372,7 @@ __global__ __launch_bounds__(256) void k_chol_mfma(Dev<SO> d, int b0) {
   if (MODE == CH_GRAM || MODE == CH_GRAM_A) { if (tid == 0) st[STAT_RROWS] = nfull - nskip; }
   else if (MODE == CH_GRAM_B) { if (tid == 0) st[STAT_RROWS] -= nskip; }
   else if (SLIKE) {}
-  else if (tid < app_per && app_lo + tid < app_hi) d.dx[(long)b * d.ld + app_lo + tid] = (SO)dxacc;
+  else if (tid >= 64 && tid - 64 < app_per && app_lo + tid - 64 < app_hi) d.dx[(long)b * d.ld + app_lo + tid - 64] = (SO)dxacc;
 }
 
 // Y = X L^-T for 16-row blocks X that do not take part in the factorization itself, one block per wavefront, independent
