@@ -309,6 +309,7 @@ size_t feature_lds_bytes(int m_cap, size_t scalar);
 void feature_device_setup();
 void qr_device_setup();
 void kalman_device_setup();
+void gram_device_setup();
 
 }  // namespace msckf
 #endif

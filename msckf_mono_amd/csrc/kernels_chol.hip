@@ -75,12 +75,13 @@ __global__ __launch_bounds__(256) void k_chol_mfma(Dev<SO> d, int b0) {
   const int pi = w >> 1, pj = w & 1;
   __builtin_amdgcn_s_setprio(3);   // latency-bound chain: win instruction arbitration against co-resident throughput waves of the other slice
   int* st = d.stats + (long)b * STAT_STRIDE;
-  if (st[STAT_MROWS] == 0) return;
+  const int mrows_ = st[STAT_MROWS], ncam_ = d.ncam[b];   // independent scalar loads, one wait
+  if (mrows_ == 0) return;
   constexpr bool GRAMLIKE = MODE == CH_GRAM || MODE == CH_GRAM_A || MODE == CH_GRAM_B;
   constexpr bool SLIKE = MODE == CH_S_A || MODE == CH_S_B;
   constexpr bool LEVEL_A = MODE == CH_GRAM_A || MODE == CH_S_A, LEVEL_B = MODE == CH_GRAM_B || MODE == CH_S_B;
   constexpr int OFF = LEVEL_B ? CH_SPLIT : 0;                            // first row/column of this launch's block
-  const int N = d.ncam[b], nfull = 6 * N, D = 15 + nfull;
+  const int N = ncam_, nfull = 6 * N, D = 15 + nfull;
   // n: columns this launch factors (local); main_rows: rows of the main block that exist: GRAM n + 1 (row n = H_o^T r_o),
   // GAIN n; appended rows of this part (GAIN): a slice of the D rows of P T_H^T plus, as the LAST row of the slice's
   // blocks, r_n^T

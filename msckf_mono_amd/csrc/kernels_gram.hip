@@ -35,13 +35,17 @@ constexpr int GK = 24;   // rows of B per staged chunk = 8 tracks
 constexpr int GT_MAX = 3; // 64 x 64 tiles of one block row held by one workgroup
 constexpr int GORD = 1024; // track order staged in LDS (f_cap <= GORD on this route)
 
+// SYRK launch: 512 threads = two groups of four wavefronts; the groups take alternate chunks of the K loop (each with its
+// own accumulators, LDS stage and two-deep register prefetch, sharing the barriers) and are summed through LDS at the end:
+// twice the loads in flight and two wavefronts per SIMD on a loop that is bound by load latency, with a fixed summation
+// order.  The block-diagonal launch keeps 256 threads.
 template <class S>
-__global__ __launch_bounds__(256) void k_gram(Dev<S> d, int b0, int npairs, int dbg, int xoff) {
-  const int b = b0 + blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+__global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int npairs, int dbg, int xoff) {
+  const int b = b0 + blockIdx.y, grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, w = tid >> 6;
   const int* st = d.stats + (long)b * STAT_STRIDE;
-  if (st[STAT_MROWS] == 0) return;
-  const int P = st[STAT_PASSED];
-  const int N = d.ncam[b], n = 6 * N, ldL = d.ldR, f_cap = d.f_cap, m_cap = d.m_cap;
+  const int mrows_ = st[STAT_MROWS], P = st[STAT_PASSED], N = d.ncam[b];   // independent scalar loads, one wait
+  if (mrows_ == 0) return;
+  const int n = 6 * N, ldL = d.ldR, f_cap = d.f_cap, m_cap = d.m_cap;
   const int* order = d.trk_order + (long)b * f_cap;
 
   const int bx = (int)blockIdx.x + xoff;
@@ -98,15 +102,21 @@ __global__ __launch_bounds__(256) void k_gram(Dev<S> d, int b0, int npairs, int 
   const int nt = min(np_cap, n / 64 + 1);            // tiles that hold a column <= n
   if (ti >= nt || tj0 >= nt) return;
   const bool has_diag = tj0 == ti;                   // local tile 0 is the diagonal tile (its B operand is the A panel)
-  __shared__ double sA[GK][64], sB[GT_MAX][GK][64];
-  __shared__ int sOrd[GORD];
+  extern __shared__ __attribute__((aligned(16))) unsigned char gram_smem[];
+  typedef double (*PanelA)[64];
+  typedef double (*PanelB)[GK][64];
+  double* sbase = reinterpret_cast<double*>(gram_smem);
+  constexpr int GRP_DOUBLES = (1 + GT_MAX) * GK * 64;          // one group's stage: A panel + GT_MAX B panels
+  PanelA sA = reinterpret_cast<PanelA>(sbase + grp * GRP_DOUBLES);
+  PanelB sB = reinterpret_cast<PanelB>(sbase + grp * GRP_DOUBLES + GK * 64);
+  int* sOrd = reinterpret_cast<int*>(sbase + 2 * GRP_DOUBLES);
   __shared__ int sCnt;
-  if (tid == 0) sCnt = 0;
+  if (threadIdx.x == 0) sCnt = 0;
   __syncthreads();
   {
     const int hi_slot = (64 * ti + 63) / 6;          // last slot with a column in the panel
     int c = 0;
-    for (int e = tid; e < P && e < GORD; e += 256) {
+    for (int e = threadIdx.x; e < P && e < GORD; e += 512) {
       const int t = order[e];
       sOrd[e] = t;
       c += (d.trk_first[(long)b * f_cap + t] <= hi_slot) ? 1 : 0;
@@ -176,20 +186,48 @@ __global__ __launch_bounds__(256) void k_gram(Dev<S> d, int b0, int npairs, int 
       }
     }
   };
-  if (KT > 0) fetch(r0, 0);
-  if (KT > GK) fetch(r1, GK);
-  for (int kc = 0; kc < KT; kc += 2 * GK) {
+  // group g takes the chunks g, g + 2, g + 4, ... (chunk = GK rows); the loop control runs on group 0's chunk (uniform for
+  // the workgroup: both groups pass the same barriers), a group whose chunk lies past the end stages zeros and skips the MFMAs
+  const int goff = grp * GK;
+  if (goff < KT) fetch(r0, goff);
+  if (2 * GK + goff < KT) fetch(r1, 2 * GK + goff);
+  for (int kc = 0; kc < KT; kc += 4 * GK) {
     __syncthreads();
-    stage(r0, kc);
+    stage(r0, kc + goff);
     __syncthreads();
-    if (kc + 2 * GK < KT && !(dbg & 2)) fetch(r0, kc + 2 * GK);
-    if (!(dbg & 4)) compute();
-    if (kc + GK >= KT) break;
+    if (kc + 4 * GK + goff < KT && !(dbg & 2)) fetch(r0, kc + 4 * GK + goff);
+    if (!(dbg & 4) && kc + goff < KT) compute();
+    if (kc + 2 * GK >= KT) break;
     __syncthreads();
-    stage(r1, kc + GK);
+    stage(r1, kc + 2 * GK + goff);
     __syncthreads();
-    if (kc + 3 * GK < KT && !(dbg & 2)) fetch(r1, kc + 3 * GK);
-    if (!(dbg & 4)) compute();
+    if (kc + 6 * GK + goff < KT && !(dbg & 2)) fetch(r1, kc + 6 * GK + goff);
+    if (!(dbg & 4) && kc + 2 * GK + goff < KT) compute();
+  }
+  // sum of the two groups through the (now free) stage area: group 1 stores, group 0 adds in a fixed order
+  __syncthreads();
+  {
+    double* red = sbase;                                        // [GT_MAX][2][2][4][256]
+    if (grp == 1) {
+#pragma unroll
+      for (int u = 0; u < GT_MAX; ++u)
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+          for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(((u * 2 + ib) * 2 + jb) * 4 + r) * 256 + tid] = acc[u][ib][jb][r];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int u = 0; u < GT_MAX; ++u)
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[u][ib][jb][r] += red[(((u * 2 + ib) * 2 + jb) * 4 + r) * 256 + tid];
   }
   // epilogue: Lam^ = (block-diagonal part, reduced by the launch that precedes this one on the stream) - sum B^T B, written
   // to both triangles so that the Cholesky kernels read plain rows
@@ -431,6 +469,12 @@ __global__ __launch_bounds__(256) void k_chol_blk(Dev<S> d, int b0, int dbg) {
   if (tid == 0) st[STAT_RROWS] = n - nskip;
 }
 
+static size_t gram_lds_bytes() { return (size_t)2 * (1 + GT_MAX) * GK * 64 * sizeof(double) + GORD * sizeof(int); }
+void gram_device_setup() {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_lds_bytes());
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_lds_bytes());
+}
+
 template <class S>
 void launch_gram(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase) {
   if (nb <= 0) return;
@@ -447,7 +491,7 @@ void launch_gram(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase) {
     // (MFMA-bound, <= 192 workgroups).  In ONE launch the dispatcher packs strips two to a CU behind the reduction
     // workgroups and they share the matrix cores (measured: MFMA phase 2x longer).
     hipLaunchKernelGGL(k_gram<S>, dim3(ndiag, nb), dim3(256), 0, st, d, b0, npairs, g_dbg, npairs);
-    hipLaunchKernelGGL(k_gram<S>, dim3(npairs, nb), dim3(256), 0, st, d, b0, npairs, g_dbg, 0);
+    hipLaunchKernelGGL(k_gram<S>, dim3(npairs, nb), dim3(512), gram_lds_bytes(), st, d, b0, npairs, g_dbg, 0);
   }
   if (phase == 1) return;
   // k_chol_blk (blocked, trailing update on the f64 matrix cores) is 10 % faster than k_chol_T in isolation (104 vs

@@ -100,8 +100,9 @@ template <class S, int OP> __device__ __forceinline__ void op_store(const KView<
 template <class S, int OP>
 __global__ __launch_bounds__(256) void k_gemm(Dev<S> d, int b0) {
   const int b = b0 + blockIdx.z;
-  if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
+  const int mrows_ = d.stats[(long)b * STAT_STRIDE + STAT_MROWS];   // loaded together with the window size (independent scalar loads, one wait)
   const KView<S> v = make_view(d, b);
+  if (mrows_ == 0) return;
   int M, N, K;
   op_dims<S, OP>(v, M, N, K);
   const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
@@ -202,10 +203,11 @@ template <int OP>
 __global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0) {
   using S = float;
   const int b = b0 + blockIdx.z;
-  if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
   if ((OP == OP_X || OP == OP_DOWN) && blockIdx.x > blockIdx.y) return;   // symmetric: the epilogue mirrors the upper tiles into P
   if (OP == OP_S && blockIdx.x < blockIdx.y) return;   // S is symmetric: the gain solve reads its lower triangle
+  const int mrows_ = d.stats[(long)b * STAT_STRIDE + STAT_MROWS];   // loaded together with the window size (independent scalar loads, one wait)
   const KView<S> v = make_view(d, b);
+  if (mrows_ == 0) return;
   int M, N, K;
   op_dims<S, OP>(v, M, N, K);
   const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
@@ -310,10 +312,11 @@ template <int OP>
 __global__ __launch_bounds__(256) void k_gemm_mfma64(Dev<double> d, int b0) {
   using S = double;
   const int b = b0 + blockIdx.z;
-  if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
   if (OP == OP_DOWN && blockIdx.x > blockIdx.y) return;   // symmetric downdate: upper tiles, mirrored by the store
   if (OP == OP_S && blockIdx.x < blockIdx.y) return;       // (X is needed in full: k_symmetrize averages X and X^T)
+  const int mrows_ = d.stats[(long)b * STAT_STRIDE + STAT_MROWS];   // loaded together with the window size (independent scalar loads, one wait)
   const KView<S> v = make_view(d, b);
+  if (mrows_ == 0) return;
   int M, N, K;
   op_dims<S, OP>(v, M, N, K);
   const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
@@ -374,8 +377,9 @@ __global__ __launch_bounds__(256) void k_gemm_mfma64(Dev<double> d, int b0) {
 template <class S, bool LDS>
 __global__ __launch_bounds__(256) void k_chol_inv(Dev<S> d, int b0) {
   const int b = b0 + blockIdx.x, tid = threadIdx.x;
-  if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
+  const int mrows_ = d.stats[(long)b * STAT_STRIDE + STAT_MROWS];   // loaded together with the window size (independent scalar loads, one wait)
   const KView<S> v = make_view(d, b);
+  if (mrows_ == 0) return;
   const int n = v.n;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   S* L; int ldl;
@@ -437,8 +441,9 @@ template <class S, int NBN>
 __global__ __launch_bounds__(256) void k_gain(Dev<S> d, int b0) {
   constexpr int G = 16, NBD = NBN + 1;
   const int b = b0 + blockIdx.x, tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
+  const int mrows_ = d.stats[(long)b * STAT_STRIDE + STAT_MROWS];   // loaded together with the window size (independent scalar loads, one wait)
   const KView<S> v = make_view(d, b);
+  if (mrows_ == 0) return;
   const int n = v.n, D = v.D;
   __shared__ S sCol[2][G * NBN];     // pivot column of S (phase 1) / pivot row of L (phase 2)
   __shared__ S sW[2][G * NBD];       // pivot column of the appended block
@@ -574,8 +579,9 @@ template <class S, int NBN, int NPART>
 __global__ __launch_bounds__(256) void k_gain_split(Dev<S> d, int b0) {
   constexpr int G = 16, NBD = NBN + 1, NBA = NBD + NBN, NBQ = (NBA + NPART - 1) / NPART;
   const int b = b0 + blockIdx.y, part = blockIdx.x, tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
+  const int mrows_ = d.stats[(long)b * STAT_STRIDE + STAT_MROWS];   // loaded together with the window size (independent scalar loads, one wait)
   const KView<S> v = make_view(d, b);
+  if (mrows_ == 0) return;
   const int n = v.n, D = v.D;
   __shared__ S sCol[2][G * NBN];
   __shared__ S sW[2][G * NBQ];
@@ -665,8 +671,9 @@ __global__ __launch_bounds__(256) void k_gain_w(Dev<S> d, int b0) {
   constexpr int G = 16, NBD = NBN + 1, NBQ = (NBD + NPART - 1) / NPART, NBW = NBQ + 1;
   const int b = b0 + blockIdx.y, part = blockIdx.x, tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   __builtin_amdgcn_s_setprio(3);   // latency-bound chain: win instruction arbitration against co-resident throughput waves of the other slice
-  if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
+  const int mrows_ = d.stats[(long)b * STAT_STRIDE + STAT_MROWS];   // loaded together with the window size (independent scalar loads, one wait)
   const KView<S> v = make_view(d, b);
+  if (mrows_ == 0) return;
   const int n = v.n, D = v.D;
   __shared__ S sCol[2][G * NBN];
   __shared__ S sW[2][G * NBW];
@@ -781,8 +788,9 @@ __global__ __launch_bounds__(256) void k_gain_w(Dev<S> d, int b0) {
 template <class S>
 __global__ __launch_bounds__(256) void k_dx_w(Dev<S> d, int b0) {
   const int b = b0 + blockIdx.x, tid = threadIdx.x;
-  if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
+  const int mrows_ = d.stats[(long)b * STAT_STRIDE + STAT_MROWS];   // loaded together with the window size (independent scalar loads, one wait)
   const KView<S> v = make_view(d, b);
+  if (mrows_ == 0) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   S* srn = reinterpret_cast<S*>(smem_raw);
   S* sz = srn + v.ldn;
@@ -805,8 +813,9 @@ __global__ __launch_bounds__(256) void k_dx_w(Dev<S> d, int b0) {
 template <class S, bool HAVE_DX>
 __global__ __launch_bounds__(256) void k_inject(Dev<S> d, int b0) {
   const int b = b0 + blockIdx.x, tid = threadIdx.x;
-  if (d.stats[(long)b * STAT_STRIDE + STAT_MROWS] == 0) return;
+  const int mrows_ = d.stats[(long)b * STAT_STRIDE + STAT_MROWS];   // loaded together with the window size (independent scalar loads, one wait)
   const KView<S> v = make_view(d, b);
+  if (mrows_ == 0) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   S* sdx = reinterpret_cast<S*>(smem_raw);
   // r_n (column n of [T | r_n]) once into LDS; dx = K r_n with 12 independent accumulators per row so that a dozen

@@ -145,7 +145,7 @@ struct Batch : BatchBase {
   }
   int create() {
     HIPCHK(hipSetDevice(device));
-    feature_device_setup(); qr_device_setup(); kalman_device_setup();   // per device: constant tables, dynamic-LDS limits
+    feature_device_setup(); qr_device_setup(); kalman_device_setup(); gram_device_setup();   // per device: constant tables, dynamic-LDS limits
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ev_stage, hipEventDisableTiming));

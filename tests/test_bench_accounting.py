@@ -11,7 +11,7 @@ def _expected_Ms(N, F):
 
 def test_cfg3_flops_and_bytes_match_survey():
     fl = bench.alg_flops_update(_expected_Ms(30, 200), 30)
-    total = sum(fl.values())
+    total = sum(v for k, v in fl.items() if k != "gram")   # gram = the compression stage as built, not additive
     assert abs(total - 7.36e8) / 7.36e8 < 0.03, total
     assert abs(fl["compress"] - 3.65e8) / 3.65e8 < 0.03
     assert abs(fl["kalman"] - 1.21e8) / 1.21e8 < 0.03
@@ -22,4 +22,4 @@ def test_cfg3_flops_and_bytes_match_survey():
 
 def test_cfg2_flops():
     fl = bench.alg_flops_update(_expected_Ms(10, 50), 10)
-    assert abs(sum(fl.values()) - 1.31e7) / 1.31e7 < 0.05
+    assert abs(sum(v for k, v in fl.items() if k != "gram") - 1.31e7) / 1.31e7 < 0.05
