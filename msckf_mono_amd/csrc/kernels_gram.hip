@@ -28,11 +28,18 @@ namespace msckf {
 // b/c/d/e of k_chol_blk.  Results are garbage with any of them set.
 #ifdef MSCKF_ABLATE
 int g_gram_dbg = 0;
+// phase timers of the SYRK launch (shader-clock cycles of thread 0 of trajectory 0's workgroups): [strip][0 start-up + track
+// count, 1 K loop, 2 group sum, 3 epilogue, 4 launches]
+__device__ unsigned long long g_gram_cycles[8][5];
+#define GR_TICK(slot) do { if (threadIdx.x == 0 && blockIdx.y == 0) { const long long t_ = clock64(); atomicAdd(&g_gram_cycles[bx & 7][slot], (unsigned long long)(t_ - gr_t)); gr_t = t_; } } while (0)
+#else
+#define GR_TICK(slot) do {} while (0)
 #endif
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int GK = 24;   // rows of B per staged chunk = 8 tracks
-constexpr int GT_MAX = 3; // 64 x 64 tiles of one block row held by one workgroup
+constexpr int GT_MAX = 1; // 64 x 64 tiles of one block row held by one workgroup (1: every tile its own workgroup -- the MFMA work of a
+                          // trajectory spreads over 6 CUs instead of 3 at a 30-camera window; measured against 3)
 constexpr int GORD = 1024; // track order staged in LDS (f_cap <= GORD on this route)
 
 // SYRK launch: 512 threads = two groups of four wavefronts; the groups take alternate chunks of the K loop (each with its
@@ -49,6 +56,9 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int npairs, int 
   const int* order = d.trk_order + (long)b * f_cap;
 
   const int bx = (int)blockIdx.x + xoff;
+#ifdef MSCKF_ABLATE
+  long long gr_t = clock64();
+#endif
   if (bx >= npairs) {
     // ---- block-diagonal part: wavefront = camera slot s, lanes over the gated-in tracks
     const int s = 4 * (bx - npairs) + w;
@@ -126,6 +136,7 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int npairs, int 
   }
   __syncthreads();
   const int KT = 3 * sCnt;
+  GR_TICK(0);
   const int lr = tid >> 6, lc = tid & 63;
   const int wi = w & 1, wj = w >> 1;
   // two register stages: the loads of chunk c+2 are issued as soon as chunk c has been staged to LDS, so two
@@ -178,11 +189,13 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int npairs, int 
         const bool dg = has_diag && u == 0;
         const double c0 = dg ? sA[kr][wj * 32 + cc] : sB[u][kr][wj * 32 + cc];
         const double c1 = dg ? sA[kr][wj * 32 + 16 + cc] : sB[u][kr][wj * 32 + 16 + cc];
-        acc[u][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, c0, acc[u][0][0], 0, 0, 0);
-        acc[u][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, c1, acc[u][0][1], 0, 0, 0);
+        // operands swapped: the accumulator holds the TRANSPOSED block (rows = columns of the tj panel), which is the
+        // block's position in the lower triangle of Lam^ -- the epilogue stores it with the lanes along a row
+        acc[u][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, a0, acc[u][0][0], 0, 0, 0);
+        acc[u][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, a0, acc[u][0][1], 0, 0, 0);
         if (dbg & 8) continue;
-        acc[u][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, c0, acc[u][1][0], 0, 0, 0);
-        acc[u][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, c1, acc[u][1][1], 0, 0, 0);
+        acc[u][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, a1, acc[u][1][0], 0, 0, 0);
+        acc[u][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, a1, acc[u][1][1], 0, 0, 0);
       }
     }
   };
@@ -206,6 +219,7 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int npairs, int 
   }
   // sum of the two groups through the (now free) stage area: group 1 stores, group 0 adds in a fixed order
   __syncthreads();
+  GR_TICK(1);
   {
     double* red = sbase;                                        // [GT_MAX][2][2][4][256]
     if (grp == 1) {
@@ -229,8 +243,10 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int npairs, int 
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[u][ib][jb][r] += red[(((u * 2 + ib) * 2 + jb) * 4 + r) * 256 + tid];
   }
-  // epilogue: Lam^ = (block-diagonal part, reduced by the launch that precedes this one on the stream) - sum B^T B, written
-  // to both triangles so that the Cholesky kernels read plain rows
+  GR_TICK(2);
+  // epilogue: Lam^ = (block-diagonal part, reduced by the launch that precedes this one on the stream) - sum B^T B.  Only the
+  // lower triangle is read downstream (lam_hat): acc[u][ib][jb] holds rows 64 tj + 32 wj + 16 jb .., columns 64 ti + 32 wi +
+  // 16 ib .. (transposed accumulation), one coalesced store per element; a diagonal tile is stored whole
   double* Lam = d.Lam + (long)b * ldL * ldL;
   const double* Dgb = d.Dg + (long)b * d.n_cap * DG_STRIDE;
 #pragma unroll
@@ -243,13 +259,17 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int npairs, int 
       for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int i = 64 * ti + wi * 32 + ib * 16 + (lane >> 4) + 4 * r;
-          const int j = 64 * tj + wj * 32 + jb * 16 + (lane & 15);
+          const int j = 64 * tj + wj * 32 + jb * 16 + (lane >> 4) + 4 * r;     // row of Lam^ (>= the column, except inside a diagonal tile)
+          const int i = 64 * ti + wi * 32 + ib * 16 + (lane & 15);            // column
           const double val = lam_diag_term(Dgb, n, d.n_cap, i, j) - acc[u][ib][jb][r];
-          Lam[(long)i * ldL + j] = val;
           Lam[(long)j * ldL + i] = val;
         }
   }
+#ifdef MSCKF_ABLATE
+  __builtin_amdgcn_s_waitcnt(0);
+  GR_TICK(3);
+  if (threadIdx.x == 0 && blockIdx.y == 0) atomicAdd(&g_gram_cycles[bx & 7][4], 1ull);
+#endif
 }
 
 // [T | r_n] = chol(Lam^) with Lam^ = Dg - sum B^T B; element (i, j), i >= j, of the lower factor lives in thread
@@ -474,6 +494,13 @@ void gram_device_setup() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_lds_bytes());
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gram<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_lds_bytes());
 }
+
+#ifdef MSCKF_ABLATE
+void gram_cycles_read(unsigned long long* out40, int reset) {
+  (void)hipMemcpyFromSymbol(out40, HIP_SYMBOL(g_gram_cycles), sizeof(unsigned long long) * 40);
+  if (reset) { unsigned long long z[40] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gram_cycles), z, sizeof(z)); }
+}
+#endif
 
 template <class S>
 void launch_gram(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase) {

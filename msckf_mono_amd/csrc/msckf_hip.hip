@@ -1174,7 +1174,7 @@ BatchBase* H(msckf_hip_handle h) { return reinterpret_cast<BatchBase*>(h); }
 }  // namespace
 
 #ifdef MSCKF_ABLATE
-namespace msckf { void qr_debug_set(int idx, int val); void feat_debug_set(int val); extern int g_gram_dbg; void chol_cycles_read(unsigned long long* out16, int reset); void prop_cycles_read(unsigned long long* out8, int reset); }
+namespace msckf { void qr_debug_set(int idx, int val); void feat_debug_set(int val); extern int g_gram_dbg; void chol_cycles_read(unsigned long long* out16, int reset); void prop_cycles_read(unsigned long long* out8, int reset); void gram_cycles_read(unsigned long long* out40, int reset); }
 #endif
 
 extern "C" {
@@ -1188,6 +1188,7 @@ void msckf_hip_debug_set(int idx, int val) {
 }
 void msckf_hip_debug_chol_cycles(unsigned long long* out16, int reset) { msckf::chol_cycles_read(out16, reset); }
 void msckf_hip_debug_prop_cycles(unsigned long long* out8, int reset) { msckf::prop_cycles_read(out8, reset); }
+void msckf_hip_debug_gram_cycles(unsigned long long* out40, int reset) { msckf::gram_cycles_read(out40, reset); }
 #endif
 
 const char* msckf_hip_last_error(void) { return g_err.c_str(); }

@@ -27,6 +27,8 @@ out = (C.c_ulonglong * 16)()
 bt.L.msckf_hip_debug_chol_cycles(out, 1)
 po8 = (C.c_ulonglong * 8)()
 bt.L.msckf_hip_debug_prop_cycles(po8, 1)
+g40 = (C.c_ulonglong * 40)()
+bt.L.msckf_hip_debug_gram_cycles(g40, 1)
 bt.run_frames(32, nf); bt.sync()
 bt.L.msckf_hip_debug_chol_cycles(out, 1)
 names = ["load", "panel->LDS", "diag block", "L21", "outputs", "trailing"]
@@ -37,3 +39,8 @@ for m, nm in enumerate(("GRAM f64", "GAIN f32")):
 bt.L.msckf_hip_debug_prop_cycles(po8, 1)
 v = np.array(po8, dtype=np.float64); n = max(v[5], 1)
 print("k_propagate launches", int(v[5]), {a: int(c / n) for a, c in zip(["load", "state chain", "Phi series", "P_II/Phi_tot chains", "write back + P_IC"], v[:5])}, "total", int(v[:5].sum() / n))
+bt.L.msckf_hip_debug_gram_cycles(g40, 1)
+g = np.array(g40, dtype=np.float64).reshape(8, 5)
+for strip in range(8):
+    if g[strip, 4] > 0:
+        print("k_gram SYRK strip", strip, "launches", int(g[strip, 4]), {a: int(c / g[strip, 4]) for a, c in zip(["start-up + count", "K loop", "group sum", "epilogue"], g[strip, :4])}, "total", int(g[strip, :4].sum() / g[strip, 4]))
