@@ -61,6 +61,7 @@ struct Dev {
   // when no track of the frame observes the newest camera): it then takes the window size from ncam_upd (left by the previous
   // frame's prune: ncam after prune + 1) instead of ncam, which augmentState is incrementing meanwhile
   int ncam_bias; int* ncam_upd;
+  int* nprev;   // [B] window size before the prune in flight (k_prune_gather -> k_prune_commit)
   int gate_early;   // exact early accept of the chi-square gate by the bound |r_o|^2 / sigma^2 (k_feature), off by default
   // per-track products of k_feature
   int* trk_status; S* trk_pf; S* trk_gamma; S* trk_Hx; S* trk_V; S* trk_Zf; S* trk_ro; int* trk_first;
@@ -289,9 +290,9 @@ __device__ __forceinline__ double lam_hat(const double* Lam, const double* /*Dg*
 }
 
 // ---------------------------------------------------------------- launch entry points (one per .hip file)
-template <class S> void launch_propagate(const Dev<S>& d, int b0, int nb, const S* readings, long rd_stride, int K, hipStream_t st);
+template <class S> void launch_propagate(const Dev<S>& d, int b0, int nb, const S* readings, long rd_stride, int K, hipStream_t st, bool then_augment = false);
 template <class S> void launch_augment(const Dev<S>& d, int b0, int nb, hipStream_t st);
-template <class S> void launch_prune(const Dev<S>& d, int b0, int nb, hipStream_t st);
+template <class S> void launch_prune(const Dev<S>& d, int b0, int nb, hipStream_t st, const int* drop = nullptr, int drop_const = -1);
 template <class S> void launch_feature(const Dev<S>& d, int b0, int nb, hipStream_t st);
 template <class S> void launch_select(const Dev<S>& d, int b0, int nb, hipStream_t st);
 // phase: 0 = stage 1 + merges, 1 = stage 1 only (chunk-local QR updates), 2 = merge tree only

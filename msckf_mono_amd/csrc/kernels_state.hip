@@ -102,7 +102,56 @@ void prop_cycles_read(unsigned long long* out8, int reset) {
 #define PR_TICK(slot) do {} while (0)
 #endif
 
+// augmentState (msckf.h:148-212) for one trajectory by one workgroup of 256 threads; sJP: [6][ld] scratch in LDS.  Called by
+// k_augment and, fused, at the end of k_propagate (run_frames: the two are always back to back, one launch less per frame).
 template <class S>
+__device__ __forceinline__ void augment_body(const Dev<S>& d, int b, int tid, S* sJP) {
+  const int n = d.ncam[b];
+  if (n >= d.n_cap) { if (tid == 0) d.stats[(long)b * STAT_STRIDE + STAT_ERR] = 1; return; }
+  const int D = 15 + 6 * n, ld = d.ld;
+  const S* imu = d.imu + (long)b * IMU_STRIDE;
+  const S* prm = d.prm + (long)b * PRM_STRIDE;
+  S* P = d.P + (long)b * ld * ld;
+  const Q4<S> q = ldq(imu + IQ), qci = ldq(prm + PRM_QCI);
+  const V3<S> pci = ld3(prm + PRM_PCI);
+  const V3<S> lever = qrotate(qinverse(q), pci);   // q_IG^-1 * p_C_I   :160,183
+  const M3<S> Jtt = q2rot(qci), Jpt = skew3(lever);
+  if (tid == 0) {
+    S* cs = d.cam + ((long)b * d.n_cap + n) * CAM_STRIDE;
+    stq(cs, qnormalized(qmul(qci, q)));             // :152-154
+    st3(cs + 4, ld3(imu + IP) + lever);             // :159-160
+  }
+  for (int c = tid; c < D; c += 256) {              // J P, J non-zero only in cols 0-2 and 12-14 (:180-184)
+    const S* pc = P + (long)c * ld;
+    const V3<S> th = mk3(pc[0], pc[1], pc[2]);
+    const V3<S> a = mulv(Jtt, th), bb = mulv(Jpt, th);
+    const S jp[6] = {a.x, a.y, a.z, bb.x + pc[12], bb.y + pc[13], bb.z + pc[14]};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { sJP[i * ld + c] = jp[i]; P[(long)c * ld + D + i] = jp[i]; P[(long)(D + i) * ld + c] = jp[i]; }
+  }
+  __syncthreads();
+  if (tid < 36) {                                   // corner J P J^T, symmetrised (:195-197)
+    const int i = tid / 6, j = tid % 6;
+    auto corner = [&](int r, int cc) {
+      const S* jp = sJP + r * ld;
+      if (cc < 3) return jp[0] * Jtt.m[cc][0] + jp[1] * Jtt.m[cc][1] + jp[2] * Jtt.m[cc][2];
+      const int c3 = cc - 3;
+      return jp[0] * Jpt.m[c3][0] + jp[1] * Jpt.m[c3][1] + jp[2] * Jpt.m[c3][2] + jp[12 + c3];
+    };
+    P[(long)(D + j) * ld + D + i] = (corner(i, j) + corner(j, i)) / S(2);
+  }
+  if (tid == 0) d.ncam[b] = n + 1;
+}
+
+template <class S>
+__global__ __launch_bounds__(256) void k_augment(Dev<S> d, int b0) {
+  const int b = b0 + blockIdx.x, tid = threadIdx.x;
+  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: win instruction arbitration against co-resident throughput waves of the other slice
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  augment_body<S>(d, b, tid, reinterpret_cast<S*>(smem_raw));
+}
+
+template <class S, bool AUGMENT>
 __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* readings, long rd_stride, int K) {
   const int b = b0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   __builtin_amdgcn_s_setprio(3);   // latency-bound chain: win instruction arbitration against co-resident throughput waves of the other slice
@@ -364,128 +413,101 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
   PR_TICK(4);
   if (tid == 0 && blockIdx.x == 0) { for (int q = 0; q < 5; ++q) atomicAdd(&g_prop_cycles[q], (unsigned long long)pcyc[q]); atomicAdd(&g_prop_cycles[5], 1ull); }
 #endif
+  if (AUGMENT) {
+    // the state and the IMU rows of P just written by this workgroup are read back by other threads of it
+    __threadfence();
+    __syncthreads();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_aug[];
+    augment_body<S>(d, b, tid, reinterpret_cast<S*>(smem_aug));
+  }
 }
 
-template <class S>
-__global__ __launch_bounds__(256) void k_augment(Dev<S> d, int b0) {
-  const int b = b0 + blockIdx.x, tid = threadIdx.x;
-  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: win instruction arbitration against co-resident throughput waves of the other slice
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  S* sJP = reinterpret_cast<S*>(smem_raw);  // [6][ld]
-  const int n = d.ncam[b];
-  if (n >= d.n_cap) { if (tid == 0) d.stats[(long)b * STAT_STRIDE + STAT_ERR] = 1; return; }
-  const int D = 15 + 6 * n, ld = d.ld;
-  const S* imu = d.imu + (long)b * IMU_STRIDE;
-  const S* prm = d.prm + (long)b * PRM_STRIDE;
-  S* P = d.P + (long)b * ld * ld;
-  const Q4<S> q = ldq(imu + IQ), qci = ldq(prm + PRM_QCI);
-  const V3<S> pci = ld3(prm + PRM_PCI);
-  const V3<S> lever = qrotate(qinverse(q), pci);   // q_IG^-1 * p_C_I   :160,183
-  const M3<S> Jtt = q2rot(qci), Jpt = skew3(lever);
-  if (tid == 0) {
-    S* cs = d.cam + ((long)b * d.n_cap + n) * CAM_STRIDE;
-    stq(cs, qnormalized(qmul(qci, q)));             // :152-154
-    st3(cs + 4, ld3(imu + IP) + lever);             // :159-160
-  }
-  for (int c = tid; c < D; c += 256) {              // J P, J non-zero only in cols 0-2 and 12-14 (:180-184)
-    const S* pc = P + (long)c * ld;
-    const V3<S> th = mk3(pc[0], pc[1], pc[2]);
-    const V3<S> a = mulv(Jtt, th), bb = mulv(Jpt, th);
-    const S jp[6] = {a.x, a.y, a.z, bb.x + pc[12], bb.y + pc[13], bb.z + pc[14]};
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { sJP[i * ld + c] = jp[i]; P[(long)c * ld + D + i] = jp[i]; P[(long)(D + i) * ld + c] = jp[i]; }
-  }
-  __syncthreads();
-  if (tid < 36) {                                   // corner J P J^T, symmetrised (:195-197)
-    const int i = tid / 6, j = tid % 6;
-    auto corner = [&](int r, int cc) {
-      const S* jp = sJP + r * ld;
-      if (cc < 3) return jp[0] * Jtt.m[cc][0] + jp[1] * Jtt.m[cc][1] + jp[2] * Jtt.m[cc][2];
-      const int c3 = cc - 3;
-      return jp[0] * Jpt.m[c3][0] + jp[1] * Jpt.m[c3][1] + jp[2] * Jpt.m[c3][2] + jp[12 + c3];
-    };
-    P[(long)(D + j) * ld + D + i] = (corner(i, j) + corner(j, i)) / S(2);
-  }
-  if (tid == 0) d.ncam[b] = n + 1;
-}
-
-// Gather the kept camera slots (keep[] ascending) of P into Ptmp, then copy back and compact cam[].
-// square_slice / column_slice of the covariance (matrix_utils.h:58-87) as two passes through Ptmp.  Workgroup = a set of
+// Drop camera states: gather the kept camera slots (keep[] ascending) of P into Ptmp, then copy back
+// (square_slice / column_slice of the covariance, matrix_utils.h:58-87, as two passes through Ptmp).  Workgroup = a set of
 // columns; the source row of every kept row is looked up once per workgroup (LDS table), threads run down a column
-// (coalesced) -- no integer division per element.
+// (coalesced) -- no integer division per element.  The keep list is either the host's (d.keep / d.nkeep: pruneEmptyStates,
+// pruneRedundantStates) or "drop the n_drop oldest" (drop array of the resident scenario, or a constant), which every
+// workgroup derives itself; workgroup 0 of a trajectory also publishes it, compacts cam[] and leaves the old window size
+// for the commit pass, whose workgroup 0 finally sets ncam (no launch of the pass reads ncam any more at that point).
 template <class S>
-__global__ __launch_bounds__(256) void k_prune_gather(Dev<S> d, int b0) {
-  const int b = b0 + blockIdx.y;
-  const int nk = d.nkeep[b], n = d.ncam[b];
+__global__ __launch_bounds__(256) void k_prune_gather(Dev<S> d, int b0, const int* drop, int drop_const, int use_keep) {
+  const int b = b0 + blockIdx.y, tid = threadIdx.x;
+  const int n = d.ncam[b];
+  int nk, nd = 0;
+  if (use_keep) nk = d.nkeep[b];
+  else { nd = drop ? drop[blockIdx.y] : drop_const; nd = nd < 0 ? 0 : (nd > n ? n : nd); nk = n - nd; }
+  int* keep = d.keep + (long)b * d.n_cap;
+  if (blockIdx.x == 0) {
+    if (tid == 0) { d.nprev[b] = n; d.ncam_upd[b] = min(nk, n) + 1; if (!use_keep) d.nkeep[b] = nk; }
+    if (!use_keep) for (int k = tid; k < nk; k += 256) keep[k] = nd + k;
+    if (nk < n && tid < 64) {
+      // compact cam[]: keep[] ascending => source slot >= destination slot
+      S* cam = d.cam + (long)b * d.n_cap * CAM_STRIDE;
+      for (int base = 0; base < nk; base += 64) {
+        const int i = base + tid;
+        S v[CAM_STRIDE];
+        if (i < nk) { const int src = use_keep ? keep[i] : nd + i; for (int k = 0; k < CAM_STRIDE; ++k) v[k] = cam[(long)src * CAM_STRIDE + k]; }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        if (i < nk) for (int k = 0; k < CAM_STRIDE; ++k) cam[(long)i * CAM_STRIDE + k] = v[k];
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+      }
+    }
+  }
   if (nk >= n) return;
   const int Dn = 15 + 6 * nk, ld = d.ld;
-  const int* keep = d.keep + (long)b * d.n_cap;
   const S* P = d.P + (long)b * ld * ld;
   S* T = d.Ptmp + (long)b * ld * ld;
   __shared__ int sSrc[1024];
-  for (int i = threadIdx.x; i < Dn && i < 1024; i += 256) sSrc[i] = i < 15 ? i : 15 + 6 * keep[(i - 15) / 6] + (i - 15) % 6;
+  for (int i = tid; i < Dn && i < 1024; i += 256) sSrc[i] = i < 15 ? i : 15 + 6 * (use_keep ? keep[(i - 15) / 6] : nd + (i - 15) / 6) + (i - 15) % 6;
   __syncthreads();
   for (int j = blockIdx.x; j < Dn; j += gridDim.x) {
     const S* src = P + (long)sSrc[j] * ld;
     S* dst = T + (long)j * ld;
-    for (int i = threadIdx.x; i < Dn; i += 256) dst[i] = src[sSrc[i]];
+    for (int i = tid; i < Dn; i += 256) dst[i] = src[sSrc[i]];
   }
 }
 template <class S>
 __global__ __launch_bounds__(256) void k_prune_commit(Dev<S> d, int b0) {
   const int b = b0 + blockIdx.y;
-  const int nk = d.nkeep[b], n = d.ncam[b];
+  const int nk = d.nkeep[b], n = d.nprev[b];
   if (nk >= n) return;
   const int Dn = 15 + 6 * nk, ld = d.ld;
   S* P = d.P + (long)b * ld * ld;
   const S* T = d.Ptmp + (long)b * ld * ld;
   for (int j = blockIdx.x; j < Dn; j += gridDim.x)
     for (int i = threadIdx.x; i < Dn; i += 256) P[(long)j * ld + i] = T[(long)j * ld + i];
-}
-template <class S>
-__global__ __launch_bounds__(64) void k_prune_cams(Dev<S> d, int b0) {
-  const int b = b0 + blockIdx.x, lane = threadIdx.x;
-  const int nk = d.nkeep[b], n = d.ncam[b];
-  // window size of the NEXT update (after its augmentState): read by a k_feature that run_frames launches concurrently with
-  // that augmentState, when ncam itself is in flux
-  if (lane == 0) d.ncam_upd[b] = min(nk, n) + 1;
-  if (nk >= n) return;
-  const int* keep = d.keep + (long)b * d.n_cap;
-  S* cam = d.cam + (long)b * d.n_cap * CAM_STRIDE;
-  for (int base = 0; base < nk; base += 64) {   // keep[] ascending => source slot >= destination slot
-    const int i = base + lane;
-    S v[CAM_STRIDE];
-    if (i < nk) for (int k = 0; k < CAM_STRIDE; ++k) v[k] = cam[(long)keep[i] * CAM_STRIDE + k];
-    __syncthreads();
-    if (i < nk) for (int k = 0; k < CAM_STRIDE; ++k) cam[(long)i * CAM_STRIDE + k] = v[k];
-    __syncthreads();
-  }
-  if (lane == 0) d.ncam[b] = nk;
+  if (blockIdx.x == 0 && threadIdx.x == 0) d.ncam[b] = nk;
 }
 
 template <class S>
-void launch_propagate(const Dev<S>& d, int b0, int nb, const S* readings, long rd_stride, int K, hipStream_t st) {
-  if (nb <= 0 || K <= 0) return;
-  hipLaunchKernelGGL(k_propagate<S>, dim3(nb), dim3(256), 0, st, d, b0, readings, rd_stride, K);
+void launch_propagate(const Dev<S>& d, int b0, int nb, const S* readings, long rd_stride, int K, hipStream_t st, bool then_augment) {
+  if (nb <= 0) return;
+  if (K <= 0) { if (then_augment) launch_augment<S>(d, b0, nb, st); return; }
+  if (then_augment) hipLaunchKernelGGL((k_propagate<S, true>), dim3(nb), dim3(256), (size_t)6 * d.ld * sizeof(S), st, d, b0, readings, rd_stride, K);
+  else hipLaunchKernelGGL((k_propagate<S, false>), dim3(nb), dim3(256), 0, st, d, b0, readings, rd_stride, K);
 }
 template <class S>
 void launch_augment(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0) return;
   hipLaunchKernelGGL(k_augment<S>, dim3(nb), dim3(256), (size_t)6 * d.ld * sizeof(S), st, d, b0);
 }
+// drop == nullptr && drop_const < 0: the host's keep list (d.keep, d.nkeep); otherwise drop the oldest drop[i] (i = trajectory
+// index relative to b0) or drop_const camera states
 template <class S>
-void launch_prune(const Dev<S>& d, int b0, int nb, hipStream_t st) {
+void launch_prune(const Dev<S>& d, int b0, int nb, hipStream_t st, const int* drop, int drop_const) {
   if (nb <= 0) return;
-  hipLaunchKernelGGL(k_prune_gather<S>, dim3(32, nb), dim3(256), 0, st, d, b0);
+  const int use_keep = (!drop && drop_const < 0) ? 1 : 0;
+  hipLaunchKernelGGL(k_prune_gather<S>, dim3(32, nb), dim3(256), 0, st, d, b0, drop, drop_const, use_keep);
   hipLaunchKernelGGL(k_prune_commit<S>, dim3(32, nb), dim3(256), 0, st, d, b0);
-  hipLaunchKernelGGL(k_prune_cams<S>, dim3(nb), dim3(64), 0, st, d, b0);
 }
 
-template void launch_propagate<float>(const Dev<float>&, int, int, const float*, long, int, hipStream_t);
-template void launch_propagate<double>(const Dev<double>&, int, int, const double*, long, int, hipStream_t);
+template void launch_propagate<float>(const Dev<float>&, int, int, const float*, long, int, hipStream_t, bool);
+template void launch_propagate<double>(const Dev<double>&, int, int, const double*, long, int, hipStream_t, bool);
 template void launch_augment<float>(const Dev<float>&, int, int, hipStream_t);
 template void launch_augment<double>(const Dev<double>&, int, int, hipStream_t);
-template void launch_prune<float>(const Dev<float>&, int, int, hipStream_t);
-template void launch_prune<double>(const Dev<double>&, int, int, hipStream_t);
+template void launch_prune<float>(const Dev<float>&, int, int, hipStream_t, const int*, int);
+template void launch_prune<double>(const Dev<double>&, int, int, hipStream_t, const int*, int);
 
 }  // namespace msckf

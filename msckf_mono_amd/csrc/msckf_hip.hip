@@ -189,7 +189,7 @@ struct Batch : BatchBase {
     }
     rc |= dalloc(&d.PHt, Bz * dn); rc |= dalloc(&d.Smat, Bz * nl); rc |= dalloc(&d.Linv, Bz * nl); rc |= dalloc(&d.W, Bz * dn);
     rc |= dalloc(&d.K, Bz * dn); rc |= dalloc(&d.A, Bz * pl); rc |= dalloc(&d.AP, Bz * pl); rc |= dalloc(&d.X, Bz * pl); rc |= dalloc(&d.dx, Bz * d.ld);
-    rc |= dalloc(&d.keep, Bz * n_cap); rc |= dalloc(&d.nkeep, Bz); rc |= dalloc(&d.ncam_upd, Bz);
+    rc |= dalloc(&d.keep, Bz * n_cap); rc |= dalloc(&d.nkeep, Bz); rc |= dalloc(&d.ncam_upd, Bz); rc |= dalloc(&d.nprev, Bz);
     rc |= dalloc(&d_pfin, TF * 4); d.trk_pfin = d_pfin; d.mode = 0; d.joseph = 0; d.ncam_bias = 0;
     rd_cap = 64;
     rc |= dalloc(&d_rd, Bz * rd_cap * RD_STRIDE);
@@ -705,24 +705,11 @@ struct Batch : BatchBase {
   }
 };
 
-// keep[] = [n_drop(b) .. ncam-1] for a trajectory range; n_drop from a device array (scenario) or a constant
-__global__ void k_make_keep(int* keep, int* nkeep, const int* ncam, const int* drop, int drop_const, int n_cap, int b0, int nb) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nb) return;
-  const int b = b0 + i;
-  const int n = ncam[b];
-  int nd = drop ? drop[i] : drop_const;
-  nd = nd < 0 ? 0 : (nd > n ? n : nd);
-  for (int k = nd; k < n; ++k) keep[(long)b * n_cap + (k - nd)] = k;
-  nkeep[b] = n - nd;
-}
-
 template <class S>
 int Batch<S>::drop_oldest(int b0, int nb, int n) {
   if (chk_range(b0, nb)) return fail(-EINVAL, "trajectory range out of bounds");
   HIPCHK(hipSetDevice(device));
-  hipLaunchKernelGGL(k_make_keep, dim3((nb + 63) / 64), dim3(64), 0, st, d.keep, d.nkeep, d.ncam, (const int*)nullptr, n, n_cap, b0, nb);
-  launch_prune<S>(d, b0, nb, st);
+  launch_prune<S>(d, b0, nb, st, nullptr, std::max(n, 0));
   for (int b = b0; b < b0 + nb; ++b) h_ncam[b] -= std::max(0, std::min(n, h_ncam[b]));
   HIPCHK(hipGetLastError());
   return 0;
@@ -769,13 +756,13 @@ int Batch<S>::run_frames(int f0, int f1) {
         launch_feature<S>(v2, b0, nb, sty[hh]);
         (void)hipEventRecord(ev_fb[hh], sty[hh]);
       }
-      stage_begin(0, q); launch_propagate<S>(v, b0, nb, sc_rd + (cell0 + b0) * sc_K * RD_STRIDE, (long)sc_K * RD_STRIDE, sc_K, q); stage_end(0, q);
-      stage_begin(1, q); launch_augment<S>(v, b0, nb, q); stage_end(1, q);
+      // propagate and augmentState are always back to back here: one launch (the per-stage profile keeps them apart)
+      stage_begin(0, q); launch_propagate<S>(v, b0, nb, sc_rd + (cell0 + b0) * sc_K * RD_STRIDE, (long)sc_K * RD_STRIDE, sc_K, q, !prof); stage_end(0, q);
+      if (prof) { stage_begin(1, q); launch_augment<S>(v, b0, nb, q); stage_end(1, q); }
       if (early) (void)hipStreamWaitEvent(q, ev_fb[hh], 0);
       launch_update(v, b0, nb, q, early);
       stage_begin(6, q);
-      hipLaunchKernelGGL(k_make_keep, dim3((nb + 63) / 64), dim3(64), 0, q, d.keep, d.nkeep, d.ncam, (const int*)(sc_drop + cell0 + b0), 0, n_cap, b0, nb);
-      launch_prune<S>(v, b0, nb, q);
+      launch_prune<S>(v, b0, nb, q, (const int*)(sc_drop + cell0 + b0), 0);
       stage_end(6, q);
       for (int b = b0; b < b0 + nb; ++b) {   // host mirror of the window size: augment, then drop n_drop (clamped as k_make_keep does)
         if (h_ncam[b] < n_cap) h_ncam[b]++;
@@ -844,12 +831,11 @@ int Batch<S>::run_frames_streamed(int f0, int f1) {
       v.trk_slots = reinterpret_cast<int*>(blk + pk_slots) + (size_t)b0 * f_cap * m_cap;
       v.trk_obs = reinterpret_cast<S*>(blk + pk_obs) + (size_t)b0 * f_cap * m_cap * 2;
       v.wl_stride_n = 1; v.wl_stride_f = f_cap; v.wl_stride_o = (long)f_cap * m_cap;
-      stage_begin(0, q); launch_propagate<S>(v, b0, nb, reinterpret_cast<S*>(blk + pk_rd) + (size_t)b0 * sc_K * RD_STRIDE, (long)sc_K * RD_STRIDE, sc_K, q); stage_end(0, q);
-      stage_begin(1, q); launch_augment<S>(v, b0, nb, q); stage_end(1, q);
+      stage_begin(0, q); launch_propagate<S>(v, b0, nb, reinterpret_cast<S*>(blk + pk_rd) + (size_t)b0 * sc_K * RD_STRIDE, (long)sc_K * RD_STRIDE, sc_K, q, !prof); stage_end(0, q);
+      if (prof) { stage_begin(1, q); launch_augment<S>(v, b0, nb, q); stage_end(1, q); }
       launch_update(v, b0, nb, q);
       stage_begin(6, q);
-      hipLaunchKernelGGL(k_make_keep, dim3((nb + 63) / 64), dim3(64), 0, q, d.keep, d.nkeep, d.ncam, (const int*)(reinterpret_cast<int*>(blk + pk_drop) + b0), 0, n_cap, b0, nb);
-      launch_prune<S>(v, b0, nb, q);
+      launch_prune<S>(v, b0, nb, q, (const int*)(reinterpret_cast<int*>(blk + pk_drop) + b0), 0);
       stage_end(6, q);
       (void)hipEventRecord(ev_use[k][hh], q);
       for (int b = b0; b < b0 + nb; ++b) {   // host mirror of the window size
