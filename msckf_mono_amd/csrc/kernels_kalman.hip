@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256) void k_gemm(Dev<S> d, int b0) {
   const int mrows_ = d.stats[(long)b * STAT_STRIDE + STAT_MROWS];   // loaded together with the window size (independent scalar loads, one wait)
   const KView<S> v = make_view(d, b);
   if (mrows_ == 0) return;
+  if (OP == OP_DOWN && blockIdx.x == 0 && blockIdx.y == 0) inject_from_dx<S>(d, b, threadIdx.x, 256);
   int M, N, K;
   op_dims<S, OP>(v, M, N, K);
   const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
@@ -197,6 +198,26 @@ template <int OP> __device__ __forceinline__ float opb_fix(const KView<float>& v
   return x;
 }
 
+// State injection from a finished dx (msckf.h:1373-1391, buildUpdateQuat :851-872), for one trajectory, by the threads of one
+// workgroup: the square-root gain form runs it inside the first tile's workgroup of the covariance downdate (one launch less).
+template <class S>
+__device__ __forceinline__ void inject_from_dx(const Dev<S>& d, int b, int tid, int nthreads) {
+  const S* dx = d.dx + (long)b * d.ld;
+  S* imu = d.imu + (long)b * IMU_STRIDE;
+  if (tid == 0) {
+    const Q4<S> q = qmul(update_quat(mk3(dx[0], dx[1], dx[2])), ldq(imu + IQ));   // not re-normalised (:1376-1378)
+    stq(imu + IQ, q);
+    for (int k = 0; k < 3; ++k) { imu[IBG + k] += dx[3 + k]; imu[IV + k] += dx[6 + k]; imu[IBA + k] += dx[9 + k]; imu[IP + k] += dx[12 + k]; }
+  }
+  const int N = d.ncam[b];
+  for (int c = tid; c < N; c += nthreads) {
+    S* cs = d.cam + ((long)b * d.n_cap + c) * CAM_STRIDE;
+    const Q4<S> q = qnormalized(qmul(update_quat(mk3(dx[15 + 6 * c], dx[16 + 6 * c], dx[17 + 6 * c])), ldq(cs)));
+    stq(cs, q);
+    for (int k = 0; k < 3; ++k) cs[4 + k] += dx[18 + 6 * c + k];
+  }
+}
+
 constexpr int GT = 32;   // k-tile of the MFMA GEMM
 
 template <int OP>
@@ -208,6 +229,7 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0) {
   const int mrows_ = d.stats[(long)b * STAT_STRIDE + STAT_MROWS];   // loaded together with the window size (independent scalar loads, one wait)
   const KView<S> v = make_view(d, b);
   if (mrows_ == 0) return;
+  if (OP == OP_DOWN && blockIdx.x == 0 && blockIdx.y == 0) inject_from_dx<S>(d, b, threadIdx.x, 256);
   int M, N, K;
   op_dims<S, OP>(v, M, N, K);
   const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
@@ -317,6 +339,7 @@ __global__ __launch_bounds__(256) void k_gemm_mfma64(Dev<double> d, int b0) {
   const int mrows_ = d.stats[(long)b * STAT_STRIDE + STAT_MROWS];   // loaded together with the window size (independent scalar loads, one wait)
   const KView<S> v = make_view(d, b);
   if (mrows_ == 0) return;
+  if (OP == OP_DOWN && blockIdx.x == 0 && blockIdx.y == 0) inject_from_dx<S>(d, b, threadIdx.x, 256);
   int M, N, K;
   op_dims<S, OP>(v, M, N, K);
   const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
@@ -926,8 +949,7 @@ void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st) {
       gemm<S, OP_W>(d, b0, nb, D, n, st);
       hipLaunchKernelGGL((k_dx_w<S>), dim3(nb), dim3(256), (size_t)2 * d.n6cap * sizeof(S), st, d, b0);
     }
-    hipLaunchKernelGGL((k_inject<S, true>), dim3(nb), dim3(256), (size_t)d.ld * sizeof(S), st, d, b0);
-    gemm<S, OP_DOWN>(d, b0, nb, D, D, st);
+    gemm<S, OP_DOWN>(d, b0, nb, D, D, st);   // its first tile's workgroup also applies dx to the state (inject_from_dx)
     return;
   }
   // ---- Joseph form (the reference's literal sequence)
