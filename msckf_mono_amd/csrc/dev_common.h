@@ -265,6 +265,20 @@ template <> __device__ __forceinline__ double fast_rsqrt<double>(double x) {
   return r;
 }
 
+// 1/x from the hardware seed + Newton steps (full precision of the type to ~1 ulp): the IEEE division sequence is ~10 (f32)
+// / ~25 (f64) instructions
+template <class S> __device__ __forceinline__ S fast_rcp(S x);
+template <> __device__ __forceinline__ float fast_rcp<float>(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
+template <> __device__ __forceinline__ double fast_rcp<double>(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+}
+
 template <class S> struct Lim;
 template <> struct Lim<float> { static __device__ __forceinline__ float tiny() { return 1.17549435e-38f; } };
 template <> struct Lim<double> { static __device__ __forceinline__ double tiny() { return 2.2250738585072014e-308; } };

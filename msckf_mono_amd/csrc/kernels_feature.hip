@@ -91,10 +91,13 @@ __device__ __forceinline__ void house3(T hf[2][3], int lane, T v[2][3], T Tm[3][
     T inv = 0;
     if (t2 <= Lim<T>::tiny()) { tau[k] = 0; }
     else {
-      T beta = dsqrt(c0 * c0 + t2);
-      if (c0 >= T(0)) beta = -beta;
-      inv = T(1) / (c0 - beta);
-      tau[k] = (beta - c0) / beta;
+      // beta = -sign(c0) |x|, v = x / (c0 - beta), tau = (beta - c0) / beta with the hardware rsqrt / rcp seeds + Newton steps
+      // (~1 ulp; the IEEE sqrt and two divisions were 80 of the double instance's instructions per reflector)
+      const T nn = c0 * c0 + t2, rs = fast_rsqrt(nn);
+      T beta = nn * rs, ibeta = rs;
+      if (c0 >= T(0)) { beta = -beta; ibeta = -ibeta; }
+      inv = fast_rcp(c0 - beta);
+      tau[k] = (beta - c0) * ibeta;
     }
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
@@ -339,20 +342,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
     }
 #pragma unroll
     for (int i = 0; i < 9; ++i) Ab[i] = wave_sum(Ab[i]);
+    // The damping ladder lambda, 10 lambda, 100 lambda, ... (clamped at 1e12) of the inner loop is known before its first
+    // step is tried: lane c solves the 3 x 3 system for the c-th rung, all rungs at once, and the loop only evaluates the
+    // cost of one candidate per pass (in float the last outer iteration fails all 11 rungs: 11 solves become one).
+    S lam_c = lambda;
+#pragma unroll
+    for (int t2 = 0; t2 < 11; ++t2) { const S up = lam_c * 10 < S(1e12) ? lam_c * 10 : S(1e12); if (t2 < lane) lam_c = up; }
+    S dlc[3];
+    ldlt3(Ab, lam_c, Ab + 6, dlc);
+    int cand = 0;
     do {
-      S dl[3];
-      ldlt3(Ab, lambda, Ab + 6, dl);
+      const S dl[3] = {wave_bcast(dlc[0], cand), wave_bcast(dlc[1], cand), wave_bcast(dlc[2], cand)};
       const S na = sa - dl[0], nb = sb - dl[1], nr = srho - dl[2];
       delta_norm = lm_sqrt(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
       const S new_cost = wave_sum(act ? tri_cost(T, na, nb, nr, zx, zy) : S(0));
       if (new_cost < total_cost) {
         reduced = true; sa = na; sb = nb; srho = nr; total_cost = new_cost;
-        const S l10th = sizeof(S) == 4 ? lambda * S(0.1) : lambda / 10;
+        const S lam_now = wave_bcast(lam_c, cand);
+        const S l10th = sizeof(S) == 4 ? lam_now * S(0.1) : lam_now / 10;
         lambda = l10th > S(1e-10) ? l10th : S(1e-10);
       } else {
         reduced = false;
-        lambda = lambda * 10 < S(1e12) ? lambda * 10 : S(1e12);
+        lambda = wave_bcast(lam_c, cand + 1);       // = min(10 * rung, 1e12)
       }
+      ++cand;
     } while (inner++ < 10 && !reduced);
     inner = 0;
   } while (outer++ < 10 && delta_norm > S(5e-7));

@@ -32,8 +32,8 @@ __device__ int g_qr_dbg[4] = {0, 0, 0, 0};   // ablation knobs of the -DMSCKF_AB
 // Reflector scalars: beta = sqrt(s), g = 1/(beta*u).  Double: IEEE sqrt / divide.  Float: hardware rsq / rcp
 // (~1 ulp) refined by one Newton step each -- within 1 ulp of the correctly rounded values at a third of the
 // instructions of the IEEE expansions, which sit on the per-step critical path of the elimination.
-template <class S> __device__ __forceinline__ S fast_rcp(S x) { return S(1) / x; }
-template <> __device__ __forceinline__ float fast_rcp<float>(float x) {
+template <class S> __device__ __forceinline__ S qr_rcp(S x) { return S(1) / x; }
+template <> __device__ __forceinline__ float qr_rcp<float>(float x) {
   const float g0 = __builtin_amdgcn_rcpf(x);
   return g0 * (2.0f - x * g0);
 }
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64 * QR_NW) void k_qr_update(Dev<S> d, int b0, int 
           S beta = fast_sqrt(x0 * x0 + sigma);
           if (x0 >= S(0)) beta = -beta;
           const S u = x0 - beta;
-          const S g = fast_rcp(beta * u);
+          const S g = qr_rcp(beta * u);
           const S gu = g * u;
 #pragma unroll
           for (int j = jk; j < NC; ++j) {

@@ -414,8 +414,8 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
   if (tid == 0 && blockIdx.x == 0) { for (int q = 0; q < 5; ++q) atomicAdd(&g_prop_cycles[q], (unsigned long long)pcyc[q]); atomicAdd(&g_prop_cycles[5], 1ull); }
 #endif
   if (AUGMENT) {
-    // the state and the IMU rows of P just written by this workgroup are read back by other threads of it
-    __threadfence();
+    // the state and the IMU rows of P just written by this workgroup are read back by other threads of it: work-group scope
+    // (one CU, one vector L1: the barrier's fence is enough; a device-scope fence waits for the write-back of all of P_IC)
     __syncthreads();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_aug[];
     augment_body<S>(d, b, tid, reinterpret_cast<S*>(smem_aug));

@@ -203,6 +203,13 @@ def test_batched_range_equals_single(capi):
         assert np.array_equal(one.imu_state(b), big.imu_state(b))
 
 
+def _same_but_r_rows(a, b):
+    """r_rows counts the pivots of the Gram matrix above a rounding-level tolerance (64 eps of the original diagonal): a
+    gauge direction whose pivot is rounding noise can fall on either side of it in two factorization kernels."""
+    strip = lambda st: {k: v for k, v in st.items() if k != "r_rows"}
+    return strip(a) == strip(b) and abs(a["r_rows"] - b["r_rows"]) <= 1
+
+
 @pytest.mark.parametrize("prec", ["f64", "f32"])
 def test_information_form_equals_householder_route(capi, prec):
     """The library has two compression routes for the stacked Jacobian: the information form (default: H_o^T H_o
@@ -225,10 +232,10 @@ def test_information_form_equals_householder_route(capi, prec):
     assert H.worst(e) < (1e-8 if prec == "f64" else 3e-4), e
     e2 = H.state_errors(res[2][0], res[1][0], res[2][1], res[1][1], res[2][2], res[1][2])
     assert H.worst(e2) < (1e-9 if prec == "f64" else 3e-4), e2
-    assert res[2][3] == res[1][3]
+    assert _same_but_r_rows(res[2][3], res[1][3])
     e3 = H.state_errors(res[3][0], res[1][0], res[3][1], res[1][1], res[3][2], res[1][2])
     assert H.worst(e3) < (1e-9 if prec == "f64" else 3e-4), e3
-    assert res[3][3] == res[1][3]
+    assert _same_but_r_rows(res[3][3], res[1][3])
     assert res[1][3]["m_rows"] == res[0][3]["m_rows"] > 0
     assert res[1][3]["r_rows"] < res[0][3]["r_rows"] == 6 * N            # gauge directions skipped
 
