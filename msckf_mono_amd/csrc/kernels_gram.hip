@@ -42,10 +42,52 @@ constexpr int GT_MAX = 1; // 64 x 64 tiles of one block row held by one workgrou
                           // trajectory spreads over 6 CUs instead of 3 at a 30-camera window; measured against 3)
 constexpr int GORD = 1024; // track order staged in LDS (f_cap <= GORD on this route)
 
+// Block-diagonal part of Lam^ (sum h^T h per camera slot, sum h^T r): one wavefront per camera slot, lanes over the
+// gated-in tracks.  Its own kernel (it was a branch of the SYRK kernel: 3 us slower there).  Measured and rejected: four
+// tracks per lane with the three dependent loads batched (18.0 vs 16.2 us -- the 27 f64 wave reductions dominate).
+template <class S>
+__global__ __launch_bounds__(256) void k_gram_diag(Dev<S> d, int b0) {
+  const int b = b0 + blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int* st = d.stats + (long)b * STAT_STRIDE;
+  const int mrows_ = st[STAT_MROWS], P = st[STAT_PASSED], N = d.ncam[b];   // independent scalar loads, one wait
+  if (mrows_ == 0) return;
+  const int f_cap = d.f_cap, m_cap = d.m_cap;
+  const int* order = d.trk_order + (long)b * f_cap;
+  const int s = 4 * (int)blockIdx.x + w;
+  if (s >= N) return;
+  double acc[27];
+#pragma unroll
+  for (int e = 0; e < 27; ++e) acc[e] = 0.0;
+  for (int p = lane; p < P; p += 64) {
+    const long tb = (long)b * f_cap + order[p];
+    const int i = d.trk_inv[tb * d.n_cap + s];
+    if (i < 0) continue;
+    const long h0i = (tb * m_cap + i) * 12;
+    const S* rw = d.trk_rw + tb * 2 * m_cap + 2 * i;
+    double h0[6], h1[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { h0[k] = (double)ld_hx(d, h0i + k); h1[k] = (double)ld_hx(d, h0i + 6 + k); }
+    const double r0 = (double)rw[0], r1 = (double)rw[1];
+    int e = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int c = a; c < 6; ++c) acc[e++] += h0[a] * h0[c] + h1[a] * h1[c];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) acc[21 + a] += h0[a] * r0 + h1[a] * r1;
+  }
+  double* out = d.Dg + ((long)b * d.n_cap + s) * DG_STRIDE;
+#pragma unroll
+  for (int e = 0; e < 27; ++e) {
+    const double v = wave_sum(acc[e]);
+    if (lane == 0) out[e] = v;
+  }
+}
+
 // SYRK launch: 512 threads = two groups of four wavefronts; the groups take alternate chunks of the K loop (each with its
 // own accumulators, LDS stage and two-deep register prefetch, sharing the barriers) and are summed through LDS at the end:
 // twice the loads in flight and two wavefronts per SIMD on a loop that is bound by load latency, with a fixed summation
-// order.  The block-diagonal launch keeps 256 threads.
+// order.
 template <class S>
 __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int npairs, int dbg, int xoff) {
   const int b = b0 + blockIdx.y, grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, w = tid >> 6;
@@ -59,40 +101,6 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int npairs, int 
 #ifdef MSCKF_ABLATE
   long long gr_t = clock64();
 #endif
-  if (bx >= npairs) {
-    // ---- block-diagonal part: wavefront = camera slot s, lanes over the gated-in tracks
-    const int s = 4 * (bx - npairs) + w;
-    if (s >= N || (dbg & 1)) return;
-    double acc[27];
-#pragma unroll
-    for (int e = 0; e < 27; ++e) acc[e] = 0.0;
-    for (int p = lane; p < P; p += 64) {
-      const long tb = (long)b * f_cap + order[p];
-      const int i = d.trk_inv[tb * d.n_cap + s];
-      if (i < 0) continue;
-      const long h0i = (tb * m_cap + i) * 12;
-      const S* rw = d.trk_rw + tb * 2 * m_cap + 2 * i;
-      double h0[6], h1[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) { h0[k] = (double)ld_hx(d, h0i + k); h1[k] = (double)ld_hx(d, h0i + 6 + k); }
-      const double r0 = (double)rw[0], r1 = (double)rw[1];
-      int e = 0;
-#pragma unroll
-      for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int c = a; c < 6; ++c) acc[e++] += h0[a] * h0[c] + h1[a] * h1[c];
-#pragma unroll
-      for (int a = 0; a < 6; ++a) acc[21 + a] += h0[a] * r0 + h1[a] * r1;
-    }
-    double* out = d.Dg + ((long)b * d.n_cap + s) * DG_STRIDE;
-#pragma unroll
-    for (int e = 0; e < 27; ++e) {
-      const double v = wave_sum(acc[e]);
-      if (lane == 0) out[e] = v;
-    }
-    return;
-  }
-
   // ---- SYRK strip: a workgroup owns up to GT_MAX tiles (ti, tj0 .. tj0+GT_MAX-1) of block row ti (windows with more
   // than GT_MAX panels split a block row over several workgroups).  The A panel (columns 64 ti ..) is staged once for
   // all of them, and only the tracks whose FIRST camera slot lies at or before the panel take part: the tracks are
@@ -517,7 +525,7 @@ void launch_gram(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase) {
     // two launches of the same kernel: the block-diagonal reduction (short, many small workgroups) and the SYRK strips
     // (MFMA-bound, <= 192 workgroups).  In ONE launch the dispatcher packs strips two to a CU behind the reduction
     // workgroups and they share the matrix cores (measured: MFMA phase 2x longer).
-    hipLaunchKernelGGL(k_gram<S>, dim3(ndiag, nb), dim3(256), 0, st, d, b0, npairs, g_dbg, npairs);
+    if (!(g_dbg & 1)) hipLaunchKernelGGL(k_gram_diag<S>, dim3(ndiag, nb), dim3(256), 0, st, d, b0);
     hipLaunchKernelGGL(k_gram<S>, dim3(npairs, nb), dim3(512), gram_lds_bytes(), st, d, b0, npairs, g_dbg, 0);
   }
   if (phase == 1) return;
