@@ -190,15 +190,17 @@ __device__ __forceinline__ bool gate_chol(const S* sG, const S* sV, const S* sE,
         __syncthreads();
         const S dkk = sC[bufc * CB + kk * NBS + kb];
         if (!(dkk > S(0))) { spd = false; break; }
-        const S dinv = fast_rsqrt(dkk);
+        // L is never needed itself: the update is A(i, j) -= A(i, k) A(j, k) / d and gamma += r_k^2 / d -- one reciprocal
+        // (hardware seed; double: + Newton) and one scaled operand instead of rsqrt + Newton and two scaled operands
+        const S dinv2 = sizeof(S) == 4 ? (S)__builtin_amdgcn_rcpf((float)dkk) : fast_rcp(dkk);
         S li[NB], lj[NB];
 #pragma unroll
-        for (int a2 = kb; a2 < NB; ++a2) li[a2] = (a2 > kb || tx > kk) ? sC[bufc * CB + tx * NBS + a2] * dinv : S(0);
+        for (int a2 = kb; a2 < NB; ++a2) li[a2] = (a2 > kb || tx > kk) ? sC[bufc * CB + tx * NBS + a2] * dinv2 : S(0);
 #pragma unroll
-        for (int b2 = kb; b2 < NB; ++b2) lj[b2] = (b2 > kb || ty > kk) ? sC[bufc * CB + ty * NBS + b2] * dinv : S(0);
-        {   // y_k = (r_o row)[k] / d  ->  gamma
-          const S y = sC[bufc * CB + (rho & 7) * NBS + (rho >> 3)] * dinv;
-          gamma += y * y;
+        for (int b2 = kb; b2 < NB; ++b2) lj[b2] = (b2 > kb || ty > kk) ? sC[bufc * CB + ty * NBS + b2] : S(0);
+        {   // y_k^2 = (r_o row)[k]^2 / d  ->  gamma
+          const S y = sC[bufc * CB + (rho & 7) * NBS + (rho >> 3)];
+          gamma += y * y * dinv2;
         }
 #pragma unroll
         for (int a2 = kb; a2 < NB; ++a2)
