@@ -474,6 +474,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
     }
   }
 
+  // ---- publish H_x and, for the information form, B^ = Q_f^T [H_x | r] right away: nothing below changes them, and the 42
+  // registers of B^ (f64) would otherwise stay live through the whole gate (the kernel sits at its register budget)
+  if (!(fdbg & 64)) {
+    if (act) {
+      if (d.h16) { __half* oH = d.trk_Hx16 + (tb * m_cap) * 12; for (int i = 0; i < 2; ++i) for (int k = 0; k < 6; ++k) oH[lane * 12 + i * 6 + k] = __float2half_rn((float)hx[i][k]); }
+      else { S* oHx = d.trk_Hx + (tb * m_cap) * 12; for (int i = 0; i < 2; ++i) for (int k = 0; k < 6; ++k) oHx[lane * 12 + i * 6 + k] = hx[i][k]; }
+    }
+    if (d.compress) {
+      // B scattered to state columns ([3][ldR] f64, zero where unobserved, column n = Q_f^T r), the whitened
+      // residual and the slot -> observation map for the block-diagonal part of the Gram matrix
+      double* oB = d.trk_B + tb * 3 * (long)d.ldR;
+      signed char* oI = d.trk_inv + tb * d.n_cap;
+      for (int e = lane; e < 3 * d.ldR; e += 64) oB[e] = 0.0;
+      for (int e = lane; e < d.n_cap; e += 64) oI[e] = -1;
+      __syncthreads();
+      if (act) {
+        for (int q = 0; q < 3; ++q) for (int k = 0; k < 6; ++k) oB[(long)q * d.ldR + 6 * slot + k] = Bq[q][k];
+        oI[slot] = (signed char)lane;
+        d.trk_rw[tb * 2 * m_cap + 2 * lane] = r[0]; d.trk_rw[tb * 2 * m_cap + 2 * lane + 1] = r[1];
+      }
+      if (lane < 3) oB[(long)lane * d.ldR + 6 * (d.ncam_bias ? d.ncam_upd[b] : d.ncam[b])] = lane == 0 ? cq[0] : (lane == 1 ? cq[1] : cq[2]);
+    }
+  }
+
   // ---- Householder QR of H_f_j (2M x 3) in working precision: compact WY for the gate (and the QR compression)
   S v[2][3], Tm[3][3];
   const int row0 = 2 * lane;
@@ -669,25 +693,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
 
   // ---- publish the compact representation of the projected block
   if (!(fdbg & 64)) {
-    if (act) {
-      if (d.h16) { __half* oH = d.trk_Hx16 + (tb * m_cap) * 12; for (int i = 0; i < 2; ++i) for (int k = 0; k < 6; ++k) oH[lane * 12 + i * 6 + k] = __float2half_rn((float)hx[i][k]); }
-      else { S* oHx = d.trk_Hx + (tb * m_cap) * 12; for (int i = 0; i < 2; ++i) for (int k = 0; k < 6; ++k) oHx[lane * 12 + i * 6 + k] = hx[i][k]; }
-    }
-    if (d.compress) {
-      // B scattered to state columns ([3][ldR] f64, zero where unobserved, column n = Q_f^T r), the whitened
-      // residual and the slot -> observation map for the block-diagonal part of the Gram matrix
-      double* oB = d.trk_B + tb * 3 * (long)d.ldR;
-      signed char* oI = d.trk_inv + tb * d.n_cap;
-      for (int e = lane; e < 3 * d.ldR; e += 64) oB[e] = 0.0;
-      for (int e = lane; e < d.n_cap; e += 64) oI[e] = -1;
-      __syncthreads();
-      if (act) {
-        for (int q = 0; q < 3; ++q) for (int k = 0; k < 6; ++k) oB[(long)q * d.ldR + 6 * slot + k] = Bq[q][k];
-        oI[slot] = (signed char)lane;
-        d.trk_rw[tb * 2 * m_cap + row0] = r[0]; d.trk_rw[tb * 2 * m_cap + row0 + 1] = r[1];
-      }
-      if (lane < 3) oB[(long)lane * d.ldR + 6 * (d.ncam_bias ? d.ncam_upd[b] : d.ncam[b])] = lane == 0 ? cq[0] : (lane == 1 ? cq[1] : cq[2]);
-    } else {
+    if (!d.compress) {
       S* oV = d.trk_V + (tb * 2 * m_cap) * 4;
       S* oZ = d.trk_Zf + tb * 3 * (long)d.ldR;   // Z scattered to state columns: [3][ldR], zero where unobserved
       S* oR = d.trk_ro + tb * 2 * m_cap;
