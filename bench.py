@@ -206,9 +206,21 @@ def main():
     rep = [elapsed]
     for _ in range(R - 1):           # further windows of the same size: spread of the measurement
         rep.append(timed(f, f + K)); f += K
-    upload_el = None
+    upload_el, h2d_gbs = None, None
     if not args.no_upload_pass:      # the same K-step window with every frame's inputs uploaded inside the timed region
         upload_el = timed(f, f + K, streamed=True); f += K
+        try:                         # what the box's host-to-device path delivers from page-locked memory (64 MB copies)
+            hbuf = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
+            dbuf = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+            dbuf.copy_(hbuf, non_blocking=True); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                dbuf.copy_(hbuf, non_blocking=True)
+            torch.cuda.synchronize()
+            h2d_gbs = 4 * (64 << 20) / (time.perf_counter() - t0) / 1e9
+            del hbuf, dbuf
+        except Exception:
+            h2d_gbs = None
 
     # ---- profiled pass over K further frames: HIP events on the library's stream, per stage (single stream)
     bt.profile_enable(True)
@@ -293,6 +305,7 @@ def main():
             "value_with_worklist_upload": None if upload_el is None else {
                 "value": updates / upload_el, "ms_per_step": 1e3 * upload_el / K,
                 "bytes_per_step": int(B_TRAJ * (K_IMU * 7 * 4 + 8 + F_TRK * 4 + F_TRK * N_WIN * 12)),
+                "h2d_GBps_pinned_64MB": h2d_gbs,
                 "note": "same K steps with each frame's IMU samples + work-list copied from page-locked host memory on a copy stream inside "
                         "the timed region (msckf_hip_run_frames_streamed); SURVEY.md 8d's definition of the metric"},
             "roofline": {"bound": kd["bound"], "kernel": dom, "achieved": achieved, "peak": kd["peak"], "unit": "TFLOP/s",

@@ -680,7 +680,7 @@ struct Batch : BatchBase {
   }
   int set_compression(int route) override {
     if (route < -1 || route > 3) return fail(-EINVAL, "route: -1 default, 0 Householder TSQR, information form with 1 register / 2 blocked / 3 blocked + MFMA panel Cholesky");
-    if (route >= 1 && !d.trk_B) return fail(-ENOTSUP, "information form not available for this window size (6 n_cap + 1 > 192)");
+    if (route >= 1 && !d.trk_B) return fail(-ENOTSUP, "information form not available for this window size (6 n_cap + 1 > 384 or f_cap > 1024)");
     compress_route = route;
     return 0;
   }
