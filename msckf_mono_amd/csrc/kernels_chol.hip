@@ -202,8 +202,9 @@ __global__ __launch_bounds__(256) void k_chol_mfma(Dev<SO> d, int b0) {
   // the second LDS panel first).  The 16-pivot chain of the diagonal block is the longest phase of a panel; it no longer
   // waits for the matrix-core update, and the update no longer waits for it.
   // (1) blocks (i, p), i >= p, from the accumulators to LDS panel p & 1
-  auto drop = [&](auto pc) __attribute__((always_inline)) {
+  auto drop = [&](auto pc, auto whichc) __attribute__((always_inline)) {
     constexpr int p = decltype(pc)::value;
+    constexpr int WHICH = decltype(whichc)::value;        // 0 all blocks (i, p), i >= p; 1 the diagonal block only; 2 the blocks below it
     T (*sP)[LP] = sPP[p & 1];
     if (pj == (p & 1)) {
 #pragma unroll
@@ -211,6 +212,8 @@ __global__ __launch_bounds__(256) void k_chol_mfma(Dev<SO> d, int b0) {
         if (2 * ii + 1 < p && 2 * ii + 1 < NB) continue;   // compile-time: block row above the panel
         const int i = 2 * ii + pi;
         if (i < p || i >= NR) continue;
+        if (WHICH == 1 && i != p) continue;
+        if (WHICH == 2 && i == p) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) sP[16 * i + Mf<T>::row(lane, r)][lane & 15] = acc[ii][p >> 1][r];
       }
@@ -331,7 +334,8 @@ __global__ __launch_bounds__(256) void k_chol_mfma(Dev<SO> d, int b0) {
       }
     }
   };
-  // (5) rank-16 update of trailing blocks: acc(i, j) -= L(i, p) L(j, p)^T; NEXT: column p + 1 only, else the columns right of it
+  // (5) rank-16 update of trailing blocks: acc(i, j) -= L(i, p) L(j, p)^T; NEXT: the next diagonal block (p+1, p+1) only --
+  // all the next diagonal-block factorization waits for --, else everything but it
   auto trail = [&](auto pc, auto nextc) __attribute__((always_inline)) {
     constexpr int p = decltype(pc)::value;
     constexpr bool NEXT = decltype(nextc)::value;
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(256) void k_chol_mfma(Dev<SO> d, int b0) {
       if (NEXT && 2 * jj > p + 1) continue;             // compile-time: right of column p + 1 for either parity
       const int j = 2 * jj + pj;
       if (j <= p || j >= NB || 16 * j >= n) continue;
-      if (NEXT ? j != p + 1 : j == p + 1) continue;
+      if (NEXT && j != p + 1) continue;
       T bq[4];
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) bq[s4] = sP[16 * j + (lane & 15)][4 * s4 + (lane >> 4)];
@@ -351,6 +355,7 @@ __global__ __launch_bounds__(256) void k_chol_mfma(Dev<SO> d, int b0) {
         if (2 * ii + 1 < 2 * jj && 2 * ii + 1 < NB) continue;   // compile-time: main block row above the column block
         const int i = 2 * ii + pi;
         if (i >= NR || (i < NB && (i < j || 16 * i >= main_rows))) continue;
+        if (NEXT ? i != p + 1 : (i == p + 1 && j == p + 1)) continue;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
           const T a = -sP[16 * i + (lane & 15)][4 * s4 + (lane >> 4)];
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(256) void k_chol_mfma(Dev<SO> d, int b0) {
   __syncthreads();
   CH_TICK(0);
   if (n > 0) {
-    drop(std::integral_constant<int, 0>{});
+    drop(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     __syncthreads();
     CH_TICK(1);
     diag(std::integral_constant<int, 0>{});
@@ -376,13 +381,15 @@ __global__ __launch_bounds__(256) void k_chol_mfma(Dev<SO> d, int b0) {
       l21(pc);
       __syncthreads();
       CH_TICK(3);
-      if (more) { trail(pc, std::true_type{}); drop(std::integral_constant<int, (p + 1 < NB ? p + 1 : p)>{}); }
+      constexpr int pn = p + 1 < NB ? p + 1 : p;
+      if (more) { trail(pc, std::true_type{}); drop(std::integral_constant<int, pn>{}, std::integral_constant<int, 1>{}); }   // next diagonal block only
       __syncthreads();
       CH_TICK(4);
-      if (more) diag(std::integral_constant<int, (p + 1 < NB ? p + 1 : p)>{});
+      if (more) diag(std::integral_constant<int, pn>{});
       CH_TICK(2);
       outputs(pc);
       trail(pc, std::false_type{});
+      if (more) drop(std::integral_constant<int, pn>{}, std::integral_constant<int, 2>{});   // the rest of the next panel (rows disjoint from the diagonal block's)
       __syncthreads();
       CH_TICK(5);
     }
