@@ -417,6 +417,9 @@ __global__ __launch_bounds__(256) void k_chol_mfma(Dev<SO> d, int b0) {
 //   TR_W     X = [P T_H^T ; r_n^T] (D + 1 rows, all n columns): W = P T_H^T L^-T (msckf.h:1370 without the inverse) and
 //            z = L^-1 r_n, left in W and Linv[0..n)
 enum { TR_GRAM = 0, TR_S21 = 1, TR_W = 2 };
+// LDS hand-over between the lanes of ONE wavefront (write in one layout, read in another): no s_barrier needed, but the
+// compiler must not move the reads above the writes -- per-thread addresses differ, so only the fences order them
+#define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 template <class T, class SO, int NP, int TMODE>
 __global__ __launch_bounds__(256) void k_trsm_rows(Dev<SO> d, int b0) {
   typedef typename Mf<T>::V V;
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(256) void k_trsm_rows(Dev<SO> d, int b0) {
     // Y = X_p M_p
 #pragma unroll
     for (int r = 0; r < 4; ++r) sT[w][Mf<T>::row(lane, r)][lane & 15] = acc[p][r];
-    __builtin_amdgcn_wave_barrier();
+    WAVE_LDS_SYNC();
     V y = V{0, 0, 0, 0};
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(256) void k_trsm_rows(Dev<SO> d, int b0) {
       const T bq = TMODE == TR_GRAM ? (T)d.Mp[((long)b * (CH_SPLIT / 16) + p) * 256 + mi] : (T)d.Mp2[((long)b * 24 + p) * 256 + mi];
       y = Mf<T>::mma(a, bq, y);
     }
-    __builtin_amdgcn_wave_barrier();
+    WAVE_LDS_SYNC();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = Mf<T>::row(lane, r), col = lane & 15;
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(256) void k_trsm_rows(Dev<SO> d, int b0) {
       if (TMODE == TR_GRAM) { if (R0 + row <= nfull) Lam[(long)(R0 + row) * d.ldR + 16 * p + col] = (double)y[r]; }
       if (TMODE == TR_S21) { if (R0 + row < nfull && 16 * p + col < ncols) Sm[(long)(R0 + row) * d.n6cap + 16 * p + col] = (SO)y[r]; }
     }
-    __builtin_amdgcn_wave_barrier();
+    WAVE_LDS_SYNC();
     // transposed outputs, lanes along the rows of the block
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(256) void k_trsm_rows(Dev<SO> d, int b0) {
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) acc[q] = Mf<T>::mma(a[s4], lblk(q, p, lane & 15, 4 * s4 + (lane >> 4)), acc[q]);
     }
-    __builtin_amdgcn_wave_barrier();
+    WAVE_LDS_SYNC();
     __builtin_amdgcn_sched_barrier(0);   // keep the next panels' loads of L out of this one (the scheduler otherwise hoists them all: spills)
   }
 }
