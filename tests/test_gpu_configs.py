@@ -140,11 +140,11 @@ def test_cfg5_geometry_vs_oracle(capi, po):
     bt.close()
 
 
-@pytest.mark.parametrize("N,F", [(36, 80), (47, 100), (60, 140)])
+@pytest.mark.parametrize("N,F", [(32, 70), (33, 70), (36, 80), (47, 100), (60, 140)])
 def test_two_level_information_form_equals_householder_route_large_windows(capi, N, F):
     """Windows of more than 31 cameras (6N + 1 > 192): the information form factors the Gram matrix in two levels
     (kernels_chol.hip: leading 192 columns, L21 on the matrix cores, Schur complement; 256 / 320 / 384 padded columns
-    here) and must stay with the Householder TSQR route (what the reference does, msckf.h:1338-1366) to rounding, in
+    here; 32 cameras = 193 columns: only the H_o^T r_o row lies beyond the split, 33 = the first real second level) and must stay with the Householder TSQR route (what the reference does, msckf.h:1338-1366) to rounding, in
     double, free-running from the first frame -- the frames during which the window is still below 192 columns included."""
     nf = N + 6
     tr = sc.Trajectory(5, 11, N, F, nf)

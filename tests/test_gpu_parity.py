@@ -240,7 +240,7 @@ def test_information_form_equals_householder_route(capi, prec):
     assert res[1][3]["r_rows"] < res[0][3]["r_rows"] == 6 * N            # gauge directions skipped
 
 
-@pytest.mark.parametrize("prec,N,F", [("f64", 8, 24), ("f64", 26, 60), ("f32", 12, 40), ("f32", 30, 120), ("f64", 36, 80), ("f32", 44, 100), ("f64", 60, 120)])
+@pytest.mark.parametrize("prec,N,F", [("f64", 8, 24), ("f64", 26, 60), ("f32", 12, 40), ("f32", 30, 120), ("f64", 36, 80), ("f32", 44, 100), ("f64", 60, 120), ("f32", 32, 80), ("f32", 33, 80)])
 def test_square_root_gain_form_equals_joseph_form(capi, prec, N, F):
     """Covariance update of measurementUpdate (msckf.h:1368-1418): the default square-root gain form (W = P T_H^T L^-T,
     P <- P - W W^T, dx = W L^-1 r_n; no gain matrix, no S^-1) against the reference's literal Joseph sequence, both on the
