@@ -217,19 +217,22 @@ __device__ __forceinline__ bool gate_chol(const S* sG, const S* sV, const S* sE,
 // LONG: tracks of more than 33 observations (2M - 2 > 64: windows beyond 33 cameras) keep the gate's Cholesky in registers
 // too (up to 16 x 16 blocks per lane); a separate instantiation, so that the short-track kernel keeps its register budget.
 template <class S, bool LONG>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (sizeof(S) == 4 ? 3 : 2), sizeof(S) == 4 && !LONG ? 3 : 2))) void k_feature(Dev<S> d, int b0) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (sizeof(S) == 4 ? 4 : 2), sizeof(S) == 4 && !LONG ? 4 : 2))) void k_feature(Dev<S> d, int b0) {
   const int b = b0 + blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
   const int F = d.trk_n[(long)(b - b0) * d.wl_stride_n];
   if (t >= F) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int m_cap = d.m_cap;
   // G (symmetric, 2M x 2M) plus the appended r_o row 2M as a packed lower triangle: element (i, j), j <= i, at TRI(i, j)
-  S* sC = reinterpret_cast<S*>(smem_raw);              // [2][64] ([2][128] LONG) pivot-column exchange of the register Cholesky
-  S* sG = sC + 256;                                    // [(2 m_cap + 1)(2 m_cap + 2) / 2]
-  S* sHx = sG + (2 * m_cap + 1) * (2 * m_cap + 2) / 2; // [m_cap][12]
-  S* sV = sHx + m_cap * 12;                            // [2 m_cap][3]
-  S* sE = sV + 2 * m_cap * 3;                          // [2 m_cap][3]
-  int* sSlot = reinterpret_cast<int*>(sE + 2 * m_cap * 3);
+  // sHx (G stage only) shares its space with sC + sE (written after the G stage's closing barrier): 10 KB per wavefront at
+  // m_cap = 30, sixteen wavefronts per CU
+  S* sG = reinterpret_cast<S*>(smem_raw);              // [(2 m_cap + 1)(2 m_cap + 2) / 2]
+  S* sV = sG + (2 * m_cap + 1) * (2 * m_cap + 2) / 2;  // [2 m_cap][3]
+  S* sHx = sV + 2 * m_cap * 3;                         // [m_cap][12]
+  S* sC = sHx;                                         // [2][64] ([2][128] LONG) pivot-column exchange of the register Cholesky
+  S* sE = sC + 256;                                    // [2 m_cap][3]
+  const int xlen = (m_cap * 12 > 256 + 2 * m_cap * 3) ? m_cap * 12 : 256 + 2 * m_cap * 3;
+  int* sSlot = reinterpret_cast<int*>(sHx + xlen);
 
   const long tb = (long)b * d.f_cap + t;               // per-track output index
   const int M = d.trk_M[(long)(b - b0) * d.wl_stride_f + t];
@@ -909,7 +912,8 @@ __global__ __launch_bounds__(64) void k_select(Dev<S> d, int b0, int nb) {
 
 size_t feature_lds_bytes(int m_cap, size_t scalar) {
   const size_t r2 = 2 * (size_t)m_cap + 1;
-  return (256 + r2 * (r2 + 1) / 2 + (size_t)m_cap * 12 + 2 * (size_t)m_cap * 3 * 2) * scalar + (size_t)m_cap * sizeof(int) + 16;
+  const size_t x = std::max<size_t>((size_t)m_cap * 12, 256 + 2 * (size_t)m_cap * 3);
+  return (r2 * (r2 + 1) / 2 + 2 * (size_t)m_cap * 3 + x) * scalar + (size_t)m_cap * sizeof(int) + 16;
 }
 
 // one-time, per-device setup (called from msckf_hip_create after hipSetDevice): chi-square table, LDS limits
