@@ -135,8 +135,9 @@ int msckf_hip_run_frames(msckf_hip_handle h, int f0, int f1);
 int msckf_hip_run_frames_streamed(msckf_hip_handle h, int f0, int f1);
 int msckf_hip_sync(msckf_hip_handle h);
 /* HIP-event stage timing: enable, run, sync, then read accumulated milliseconds and launch counts for
- * stages 0 propagate, 1 augment, 2 k_feature, 3 compression A (k_gram | TSQR stage 1), 4 compression B (k_chol_T |
- * TSQR merge), 5 kalman, 6 prune, 7 k_select */
+ * stages 0 propagate, 1 augment, 2 k_feature, 3 compression A (k_gram_diag + k_gram | TSQR stage 1), 4 compression B
+ * (k_chol_mfma | TSQR merge), 5 kalman, 6 prune, 7 k_select.  (While profiling, run_frames launches propagate and
+ * augmentState separately; otherwise they share one launch.) */
 int msckf_hip_profile_enable(msckf_hip_handle h, int on);
 int msckf_hip_profile_read(msckf_hip_handle h, double* ms8, int* count8);
 /* run_frames on n = 1..8 HIP streams: the batch is cut into n slices of independent trajectories that run the
@@ -148,12 +149,15 @@ int msckf_hip_set_streams(msckf_hip_handle h, int n);
 int msckf_hip_set_gate_early_accept(msckf_hip_handle h, int on);
 /* Compression of the stacked Jacobian (HouseholderQR + Q_1^T r_o of measurementUpdate, msckf.h:1338-1366):
  * -1 default for the window size, 0 Householder TSQR (kernels_qr.hip), 1 information form [T | r_n] = chol(H_o^T H_o)
- * accumulated in f64 (kernels_gram.hip), 2 the same with the blocked matrix-core Cholesky.  1 and 2 need
- * 6 n_cap + 1 <= 192 (-ENOTSUP otherwise).  All routes give the reference's update (tests keep them together). */
+ * accumulated in f64 (kernels_gram.hip) with the register-resident Cholesky k_chol_T, 2 the same with k_chol_blk, 3 with
+ * the blocked matrix-core Cholesky k_chol_mfma (kernels_chol.hip; the default, and the only factorization for windows of
+ * more than 31 cameras, 6 n_cap + 1 > 192, where it runs in two levels).  The information form needs 6 n_cap + 1 <= 384 and
+ * f_cap <= 1024 (-ENOTSUP otherwise).  All routes give the reference's update (tests keep them together). */
 int msckf_hip_set_compression(msckf_hip_handle h, int route);
 /* Covariance update of measurementUpdate (msckf.h:1368-1418): 0 (default) the square-root gain form -- S = L L^T,
  * W = P T_H^T L^-T, dx = W L^-1 r_n, P <- P - W W^T (= (I - K T_H) P, written symmetrically); 1 the reference's literal
- * Joseph sequence K, (I - K T_H) P (I - K T_H)^T + K R_n K^T, symmetrise.  Identical in exact arithmetic, equal to
+ * Joseph sequence K, (I - K T_H) P (I - K T_H)^T + K R_n K^T, symmetrise; 2 the square-root gain form with the
+ * register-resident solve of round 1 instead of the blocked matrix-core one.  Identical in exact arithmetic, equal to
  * rounding in the tests. */
 int msckf_hip_set_covariance_update(msckf_hip_handle h, int form);
 /* run_frames: launch a frame's per-track kernel on a side stream concurrently with the same frame's propagate + augmentState
