@@ -330,7 +330,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1 and args.config != "cfg5":
             out["cpu_baseline"] = cpu_baseline(trajs[0], fill + W, args.cpu_seconds, N_WIN)
-            out.update(ate_vs_reference(trajs, sample, p_dev_sample, f_end_timed, N_WIN))
+            out.update(ate_vs_reference(trajs, sample, p_dev_sample, f_end_timed, N_WIN, anisotropic=not c["iso"]))
         elif args.config == "cfg5":
             out["cpu_baseline"] = None
             out["cpu_baseline_note"] = ("not run at this size: one update of the reference's algorithm on a 60-camera / 500-track window builds a "
@@ -367,22 +367,29 @@ def _oracle_window(o, tr, k, N):
         o.dropOldest(1)
 
 
-def ate_vs_reference(trajs, sample, p_dev, n_run, N):
+def ate_vs_reference(trajs, sample, p_dev, n_run, N, anisotropic=False):
     """'ATE vs ref' of BASELINE.json's metric: the CPU oracle (float, LEAN = same results as the reference's steps) runs
     the sampled trajectories free from frame 0 to the end of the timed window on host threads; reported: its ATE against
-    ground truth, the HIP path's ATE on the same trajectories, and the RMS position difference between the two."""
+    ground truth, the HIP path's ATE on the same trajectories, and the RMS position difference between the two.  With
+    anisotropic pixel noise (f_u != f_v) the reference's literal R_n construction is not reproducible beyond ~1e-4 per
+    update and the device runs the row-pre-whitened update: the difference to the oracle's whitened mode
+    (the same construction) is reported beside the one to the literal restatement."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
-    res = {}
+    res, resw = {}, {}
 
-    def run(b):
+    def run(b, whiten, out):
         tr = trajs[b]
         o = po.Oracle(po.F32, po.LEAN)
+        if whiten:
+            o.setWhiten(True)
         o.initialize(tr.cfg, tr.imu0)
         for k in range(n_run):
             _oracle_window(o, tr, k, N)
-        res[b] = o.getImuState()[13:16]
-    th = [threading.Thread(target=run, args=(b,)) for b in sample]
+        out[b] = o.getImuState()[13:16]
+    th = [threading.Thread(target=run, args=(b, False, res)) for b in sample]
+    if anisotropic:
+        th += [threading.Thread(target=run, args=(b, True, resw)) for b in sample]
     t0 = time.time()
     for t in th:
         t.start()
@@ -390,10 +397,13 @@ def ate_vs_reference(trajs, sample, p_dev, n_run, N):
         t.join()
     gt = {b: trajs[b].gt_frames["p"][n_run - 1] for b in sample}
     rms = lambda d: float(np.sqrt(np.mean([float(np.sum(np.square(x))) for x in d])))
-    return {"ate_ref_m": rms([res[b] - gt[b] for b in sample]), "ate_hip_sample_m": rms([p_dev[b] - gt[b] for b in sample]),
-            "ate_vs_ref_m": rms([p_dev[b] - res[b] for b in sample]),
-            "ate_vs_ref_note": "%d sampled trajectories, free-running from frame 0 to the end of the timed window (%d frames), float CPU oracle "
-                               "vs HIP path, %.1f s wall" % (len(sample), n_run, time.time() - t0)}
+    out = {"ate_ref_m": rms([res[b] - gt[b] for b in sample]), "ate_hip_sample_m": rms([p_dev[b] - gt[b] for b in sample]),
+           "ate_vs_ref_m": rms([p_dev[b] - res[b] for b in sample]),
+           "ate_vs_ref_note": "%d sampled trajectories, free-running from frame 0 to the end of the timed window (%d frames), float CPU oracle "
+                              "vs HIP path, %.1f s wall" % (len(sample), n_run, time.time() - t0)}
+    if anisotropic:
+        out["ate_vs_ref_whitened_m"] = rms([p_dev[b] - resw[b] for b in sample])
+    return out
 
 
 def cpu_baseline(tr, frame, budget_s, N):

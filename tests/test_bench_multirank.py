@@ -39,5 +39,7 @@ def test_cfg4_monte_carlo_mode_reports_per_sequence_ate():
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["config"]["name"] == "cfg4" and d["config"]["sequences"] == 5 and d["config"]["trajectories_per_gpu"] == 128
     assert len(d["ate_per_sequence_m"]) == 5 and max(d["ate_per_sequence_m"]) < 0.1
-    assert d["ate_vs_ref_m"] < 1e-2 and abs(d["ate_ref_m"] - d["ate_hip_sample_m"]) < 1e-2
+    # anisotropic noise: the device runs the row-pre-whitened update; reported against the oracle's whitened mode (the same
+    # construction) and against the literal R_n restatement -- both ~1e-5 m on these short runs
+    assert d["ate_vs_ref_whitened_m"] < 1e-3 and d["ate_vs_ref_m"] < 1e-2 and abs(d["ate_ref_m"] - d["ate_hip_sample_m"]) < 1e-2
     assert d["cpu_baseline"]["kind"] in ("reference", "port")
