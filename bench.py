@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=-1, help="timed K-step windows in all (default: until >= 0.5 s of timed region, 3..12)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams for the timed region (slices of the batch run concurrently)")
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams for the timed region (slices of the batch run concurrently)")
     ap.add_argument("--no-early-accept-pass", action="store_true", help="skip the extra measurement with the gate early accept (profiling runs)")
     ap.add_argument("--no-upload-pass", action="store_true", help="skip the window with per-frame input upload (profiling runs)")
     ap.add_argument("--compression", type=int, default=-1, help="msckf_hip_set_compression route (A/B runs; -1 = library default)")
