@@ -1,4 +1,4 @@
-// kernels_chol.hip -- blocked right-looking Cholesky on the matrix cores, one workgroup (8 wavefronts) per matrix.
+// kernels_chol.hip -- blocked right-looking Cholesky on the matrix cores, one workgroup (16 wavefronts) per matrix.
 //
 // Two uses, one kernel template:
 //   GRAM (T = double): [T_H | r_n] = chol(Lam^), Lam^ = [H_o | r_o]^T [H_o | r_o] accumulated by k_gram -- the
@@ -9,7 +9,7 @@
 //        the factorization turns into W = P T_H^T L^-T and z^T = (L^-1 r_n)^T; dx = K r_n = W z (msckf.h:1370-1373 without
 //        the explicit inverse).  NPART workgroups per trajectory share the appended rows (each redoes the factorization).
 //
-// The trailing matrix lives in MFMA accumulators: 16 x 16 blocks, 2 x 4 block-cyclic over the eight wavefronts.  Per panel
+// The trailing matrix lives in MFMA accumulators: 16 x 16 blocks, 4 x 4 block-cyclic over the sixteen wavefronts.  Per panel
 // of 16 columns:
 //   (1) the owners drop the panel's blocks into LDS;
 //   (2) ONE wavefront factors the 16 x 16 diagonal block with lane = row, pivots and multipliers broadcast by v_readlane,
@@ -67,13 +67,15 @@ __device__ unsigned long long g_chol_cycles[2][8];
 
 // NB: 16-column blocks of the factored matrix; NA: appended 16-row blocks held by ONE workgroup (GAIN), 0 for GRAM
 template <class T, class SO, int NB, int NA, int MODE, int NPART>
-__global__ __launch_bounds__(512) void k_chol_mfma(Dev<SO> d, int b0) {
+__global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0) {
   typedef typename Mf<T>::V V;
-  constexpr int NR = NB + NA, HR = (NR + 1) / 2, HC = (NB + 3) / 4, LP = 17;   // eight wavefronts: block (i, j) belongs to wavefront 4 (i & 1) + (j & 3)
+  constexpr int NR = NB + NA, HR = (NR + 3) / 4, HC = (NB + 3) / 4, LP = 17;   // sixteen wavefronts: block (i, j) belongs to wavefront 4 (i & 3) + (j & 3)
   const int b = b0 + (MODE == CH_GAIN ? blockIdx.y : blockIdx.x), part = MODE == CH_GAIN ? (int)blockIdx.x : 0;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int pi = w >> 2, pj = w & 3;
-  __builtin_amdgcn_s_setprio(3);   // latency-bound chain: win instruction arbitration against co-resident throughput waves of the other slice
+  // wavefront 0 carries the 16-pivot chains of the diagonal blocks: it wins instruction arbitration against the three
+  // wavefronts that share its SIMD (and everybody against co-resident throughput waves of another slice)
+  if (w == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
   int* st = d.stats + (long)b * STAT_STRIDE;
   const int mrows_ = st[STAT_MROWS], ncam_ = d.ncam[b];   // independent scalar loads, one wait
   if (mrows_ == 0) return;
@@ -135,8 +137,8 @@ __global__ __launch_bounds__(512) void k_chol_mfma(Dev<SO> d, int b0) {
 #pragma unroll
     for (int jj = 0; jj < HC; ++jj) {
       acc[ii][jj] = V{0, 0, 0, 0};
-      if (2 * ii + 1 < 4 * jj && 2 * ii + 1 < NB) continue;   // compile-time: main block row above the column block
-      const int i = 2 * ii + pi, j = 4 * jj + pj;
+      if (4 * ii + 3 < 4 * jj && 4 * ii + 3 < NB) continue;   // compile-time: main block row above the column block
+      const int i = 4 * ii + pi, j = 4 * jj + pj;
       if (i >= NR || j >= NB || (i < NB && j > i) || 16 * j >= n) continue;
       if (i < NB && 16 * i >= main_rows) continue;
 #pragma unroll
@@ -146,15 +148,15 @@ __global__ __launch_bounds__(512) void k_chol_mfma(Dev<SO> d, int b0) {
   for (int ii = 0; ii < HR; ++ii)
 #pragma unroll
     for (int jj = 0; jj < HC; ++jj) {
-      if (2 * ii + 1 < 4 * jj && 2 * ii + 1 < NB) continue;
-      const int i = 2 * ii + pi, j = 4 * jj + pj;
+      if (4 * ii + 3 < 4 * jj && 4 * ii + 3 < NB) continue;
+      const int i = 4 * ii + pi, j = 4 * jj + pj;
       if (i >= NR || j >= NB || (i < NB && j > i) || 16 * j >= n) continue;
       if (i < NB && 16 * i >= main_rows) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) if (!el_ok(16 * i + Mf<T>::row(lane, r), 16 * j + (lane & 15))) acc[ii][jj][r] = T(0);
     }
   if (GRAMLIKE)
-    for (int t = tid; t < 16 * NB; t += 512) { const double dv = lam_hat(Lam, Dg, d.ldR, nfull, d.n_cap, OFF + t, OFF + t); sD0[t] = t < n ? (T)dv : T(0); }
+    for (int t = tid; t < 16 * NB; t += 1024) { const double dv = lam_hat(Lam, Dg, d.ldR, nfull, d.n_cap, OFF + t, OFF + t); sD0[t] = t < n ? (T)dv : T(0); }
   const T tol = T(64.0 * 2.220446049250313e-16);
   int nskip = 0;
   T dxacc = 0;   // GAIN: thread t < app rows accumulates dx[app_lo + t] = sum_k W(., k) z_k
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(512) void k_chol_mfma(Dev<SO> d, int b0) {
     T (*sP)[LP] = sPP[0];
     for (int q = 0; q < CH_SPLIT / 16; ++q) {
       __syncthreads();
-      for (int e = tid; e < 16 * NB * 16; e += 512) {
+      for (int e = tid; e < 16 * NB * 16; e += 1024) {
         const int r = e >> 4, c = e & 15;
         if (SLIKE) sP[r][c] = OFF + r < nfull ? (T)Sm[(long)(OFF + r) * d.n6cap + 16 * q + c] : T(0);
         else {
@@ -184,8 +186,8 @@ __global__ __launch_bounds__(512) void k_chol_mfma(Dev<SO> d, int b0) {
         for (int s4 = 0; s4 < 4; ++s4) bq[s4] = sP[16 * j + (lane & 15)][4 * s4 + (lane >> 4)];
 #pragma unroll
         for (int ii = 0; ii < HR; ++ii) {
-          if (2 * ii + 1 < 4 * jj && 2 * ii + 1 < NB) continue;
-          const int i = 2 * ii + pi;
+          if (4 * ii + 3 < 4 * jj && 4 * ii + 3 < NB) continue;
+          const int i = 4 * ii + pi;
           if (i >= NR || i < j || 16 * i >= main_rows) continue;
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4) {
@@ -209,8 +211,8 @@ __global__ __launch_bounds__(512) void k_chol_mfma(Dev<SO> d, int b0) {
     if (pj == (p & 3)) {
 #pragma unroll
       for (int ii = 0; ii < HR; ++ii) {
-        if (2 * ii + 1 < p && 2 * ii + 1 < NB) continue;   // compile-time: block row above the panel
-        const int i = 2 * ii + pi;
+        if (4 * ii + 3 < p && 4 * ii + 3 < NB) continue;   // compile-time: block row above the panel
+        const int i = 4 * ii + pi;
         if (i < p || i >= NR) continue;
         if (WHICH == 1 && i != p) continue;
         if (WHICH == 2 && i == p) continue;
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(512) void k_chol_mfma(Dev<SO> d, int b0) {
     T bq[4];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) bq[s4] = sM[(lane >> 4) + 4 * s4][lane & 15];
-    for (int i = p + 1 + w; i < NR; i += 8) {
+    for (int i = p + 1 + w; i < NR; i += 16) {
       if (i < NB && 16 * i >= main_rows) continue;
       T a[4];
 #pragma unroll
@@ -285,16 +287,16 @@ __global__ __launch_bounds__(512) void k_chol_mfma(Dev<SO> d, int b0) {
       for (int r = 0; r < 4; ++r) sP[16 * i + Mf<T>::row(lane, r)][lane & 15] = y[r];
     }
   };
-  // (4) results of panel p, written by wavefronts 1..7 (448 threads) while wavefront 0 factors the next diagonal block
+  // (4) results of panel p, written by wavefronts 1..15 (960 threads) while wavefront 0 factors the next diagonal block
   auto outputs = [&](auto pc) __attribute__((always_inline)) {
     constexpr int p = decltype(pc)::value;
     T (*sP)[LP] = sPP[p & 1];
     T (*sM)[LP] = sMM[p & 1];
     if (w == 0) return;
-    const int t = tid - 64;                             // 0 .. 447
+    const int t = tid - 64;                             // 0 .. 959
     if (GRAMLIKE) {
       // rows 16p .. 16p+15 of T = L^T: T[k][c] = L(c, k), zero left of the diagonal and beyond column n
-      for (int c = t; c < 16 * NB; c += 448) {
+      for (int c = t; c < 16 * NB; c += 960) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           const int k = 16 * p + j;
@@ -304,23 +306,23 @@ __global__ __launch_bounds__(512) void k_chol_mfma(Dev<SO> d, int b0) {
         }
       }
       if (MODE == CH_GRAM_B) {                          // columns left of this launch's block: zero
-        for (int c = t; c < OFF; c += 448) {
+        for (int c = t; c < OFF; c += 960) {
 #pragma unroll
           for (int j = 0; j < 16; ++j) { const int k = 16 * p + j; if (k < n) Rt[(long)(OFF + k) * d.ldR + c] = SO(0); }
         }
       }
       if (MODE == CH_GRAM_A && two_level)
-        for (int e = t; e < 256; e += 448) d.Mp[((long)b * (CH_SPLIT / 16) + p) * 256 + e] = (double)sM[e >> 4][e & 15];
+        for (int e = t; e < 256; e += 960) d.Mp[((long)b * (CH_SPLIT / 16) + p) * 256 + e] = (double)sM[e >> 4][e & 15];
     } else if (SLIKE) {
       // L in place (row-major lower triangle of Smat) and this panel's M, for k_trsm_rows
-      for (int c = t; c < 16 * NB; c += 448) {
+      for (int c = t; c < 16 * NB; c += 960) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           const int k = 16 * p + j;
           if (c >= k && c < n && k < n) Sm[(long)(OFF + c) * d.n6cap + OFF + k] = (SO)sP[c][j];
         }
       }
-      for (int e = t; e < 256; e += 448) d.Mp2[((long)b * 24 + OFF / 16 + p) * 256 + e] = (SO)sM[e >> 4][e & 15];
+      for (int e = t; e < 256; e += 960) d.Mp2[((long)b * 24 + OFF / 16 + p) * 256 + e] = (SO)sM[e >> 4][e & 15];
     } else {
       // columns 16p .. 16p+15 of W for this part's rows; dx += W(:, k) z_k (thread 64 + a owns appended row a)
       if (t < app_per) {
@@ -352,8 +354,8 @@ __global__ __launch_bounds__(512) void k_chol_mfma(Dev<SO> d, int b0) {
       for (int s4 = 0; s4 < 4; ++s4) bq[s4] = sP[16 * j + (lane & 15)][4 * s4 + (lane >> 4)];
 #pragma unroll
       for (int ii = 0; ii < HR; ++ii) {
-        if (2 * ii + 1 < 4 * jj && 2 * ii + 1 < NB) continue;   // compile-time: main block row above the column block
-        const int i = 2 * ii + pi;
+        if (4 * ii + 3 < 4 * jj && 4 * ii + 3 < NB) continue;   // compile-time: main block row above the column block
+        const int i = 4 * ii + pi;
         if (i >= NR || (i < NB && (i < j || 16 * i >= main_rows))) continue;
         if (NEXT ? i != p + 1 : (i == p + 1 && j == p + 1)) continue;
 #pragma unroll
@@ -532,11 +534,11 @@ bool launch_chol_gain_large(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0) return true;
   const int nblk = (d.n6cap + 15) / 16;
   if (!d.Mp2 || nblk <= 12 || nblk > 24) return false;
-  hipLaunchKernelGGL((k_chol_mfma<S, S, 12, 0, CH_S_A, 1>), dim3(nb), dim3(512), 0, st, d, b0);
+  hipLaunchKernelGGL((k_chol_mfma<S, S, 12, 0, CH_S_A, 1>), dim3(nb), dim3(1024), 0, st, d, b0);
   hipLaunchKernelGGL((k_trsm_rows<S, S, 12, TR_S21>), dim3((nblk - 12 + 3) / 4, nb), dim3(256), 0, st, d, b0);
-  if (nblk <= 16) hipLaunchKernelGGL((k_chol_mfma<S, S, 4, 0, CH_S_B, 1>), dim3(nb), dim3(512), 0, st, d, b0);
-  else if (nblk <= 20) hipLaunchKernelGGL((k_chol_mfma<S, S, 8, 0, CH_S_B, 1>), dim3(nb), dim3(512), 0, st, d, b0);
-  else hipLaunchKernelGGL((k_chol_mfma<S, S, 12, 0, CH_S_B, 1>), dim3(nb), dim3(512), 0, st, d, b0);
+  if (nblk <= 16) hipLaunchKernelGGL((k_chol_mfma<S, S, 4, 0, CH_S_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0);
+  else if (nblk <= 20) hipLaunchKernelGGL((k_chol_mfma<S, S, 8, 0, CH_S_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0);
+  else hipLaunchKernelGGL((k_chol_mfma<S, S, 12, 0, CH_S_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0);
   const int rblk = (15 + d.n6cap + 1 + 15) / 16;          // 16-row blocks of [P T_H^T ; r_n^T]
   if (nblk <= 16) hipLaunchKernelGGL((k_trsm_rows<S, S, 16, TR_W>), dim3((rblk + 3) / 4, nb), dim3(256), 0, st, d, b0);
   else if (nblk <= 20) hipLaunchKernelGGL((k_trsm_rows<S, S, 20, TR_W>), dim3((rblk + 3) / 4, nb), dim3(256), 0, st, d, b0);
@@ -550,25 +552,25 @@ bool launch_chol_gram(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0) return true;
   const int nblk = d.ldR / 16;
   switch (nblk) {
-    case 4: hipLaunchKernelGGL((k_chol_mfma<double, S, 4, 0, CH_GRAM, 1>), dim3(nb), dim3(512), 0, st, d, b0); return true;
-    case 8: hipLaunchKernelGGL((k_chol_mfma<double, S, 8, 0, CH_GRAM, 1>), dim3(nb), dim3(512), 0, st, d, b0); return true;
-    case 12: hipLaunchKernelGGL((k_chol_mfma<double, S, 12, 0, CH_GRAM, 1>), dim3(nb), dim3(512), 0, st, d, b0); return true;
+    case 4: hipLaunchKernelGGL((k_chol_mfma<double, S, 4, 0, CH_GRAM, 1>), dim3(nb), dim3(1024), 0, st, d, b0); return true;
+    case 8: hipLaunchKernelGGL((k_chol_mfma<double, S, 8, 0, CH_GRAM, 1>), dim3(nb), dim3(1024), 0, st, d, b0); return true;
+    case 12: hipLaunchKernelGGL((k_chol_mfma<double, S, 12, 0, CH_GRAM, 1>), dim3(nb), dim3(1024), 0, st, d, b0); return true;
     default: break;
   }
   if (!d.Mp || (nblk != 16 && nblk != 20 && nblk != 24)) return false;
   // two levels: columns [0, 192), L21, Schur complement
-  hipLaunchKernelGGL((k_chol_mfma<double, S, 12, 0, CH_GRAM_A, 1>), dim3(nb), dim3(512), 0, st, d, b0);
+  hipLaunchKernelGGL((k_chol_mfma<double, S, 12, 0, CH_GRAM_A, 1>), dim3(nb), dim3(1024), 0, st, d, b0);
   hipLaunchKernelGGL((k_trsm_rows<double, S, 12, TR_GRAM>), dim3((nblk - 12 + 3) / 4, nb), dim3(256), 0, st, d, b0);
-  if (nblk == 16) hipLaunchKernelGGL((k_chol_mfma<double, S, 4, 0, CH_GRAM_B, 1>), dim3(nb), dim3(512), 0, st, d, b0);
-  else if (nblk == 20) hipLaunchKernelGGL((k_chol_mfma<double, S, 8, 0, CH_GRAM_B, 1>), dim3(nb), dim3(512), 0, st, d, b0);
-  else hipLaunchKernelGGL((k_chol_mfma<double, S, 12, 0, CH_GRAM_B, 1>), dim3(nb), dim3(512), 0, st, d, b0);
+  if (nblk == 16) hipLaunchKernelGGL((k_chol_mfma<double, S, 4, 0, CH_GRAM_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0);
+  else if (nblk == 20) hipLaunchKernelGGL((k_chol_mfma<double, S, 8, 0, CH_GRAM_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0);
+  else hipLaunchKernelGGL((k_chol_mfma<double, S, 12, 0, CH_GRAM_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0);
   return true;
 }
 
 // GAIN: parts x NA blocks of 16 rows must cover the D + 1 appended rows (each part also carries r_n^T)
 template <int NB, int NA, int NPART>
 static void gain_launch(const Dev<float>& d, int b0, int nb, hipStream_t st) {
-  hipLaunchKernelGGL((k_chol_mfma<float, float, NB, NA, CH_GAIN, NPART>), dim3(NPART, nb), dim3(512), 0, st, d, b0);
+  hipLaunchKernelGGL((k_chol_mfma<float, float, NB, NA, CH_GAIN, NPART>), dim3(NPART, nb), dim3(1024), 0, st, d, b0);
 }
 bool launch_chol_gain(const Dev<float>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0) return true;
