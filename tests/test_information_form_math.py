@@ -108,3 +108,44 @@ def test_gram_of_the_projected_stack_and_its_factor():
     dx2, P2 = update(R, Qtr)
     assert np.linalg.norm(dx1 - dx2) < 1e-9 * np.linalg.norm(dx2)
     assert np.linalg.norm(P1 - P2) < 1e-10 * np.linalg.norm(P2)
+
+
+def test_gate_pair_enumeration_covers_the_upper_triangle_once():
+    """k_feature's G = H_x P_cc H_x^T loop (kernels_feature.hip) enumerates the camera pairs (a, b), a <= b, of a track as a
+    rectangle of ceil(M / 2) rows of width M | 1 -- row k holds row k of the triangle followed by row M - 1 - k (M even) or
+    M - k (M odd) -- with the row index taken from a float product: every pair exactly once, for every track length the
+    kernel accepts, in the float arithmetic the kernel uses."""
+    f32 = np.float32
+    for M in range(2, 65):
+        Wd = M | 1
+        invW = f32(1.0) / f32(Wd)
+        seen = set()
+        for p in range(M * (M + 1) // 2):
+            k = int((f32(p) + f32(0.5)) * invW)
+            c = p - k * Wd
+            first = c < M - k
+            a = k if first else (M - k if (M & 1) else M - 1 - k)
+            b = a + (c if first else c - (M - k))
+            assert 0 <= a <= b < M, (M, p, a, b)
+            assert (a, b) not in seen, (M, p, a, b)
+            seen.add((a, b))
+        assert len(seen) == M * (M + 1) // 2
+
+
+def test_syrk_workgroup_enumeration_covers_the_upper_block_triangle_once():
+    """k_gram's SYRK launch (kernels_gram.hip): workgroup index -> (block row ti, first tile tj0) with GT_MAX tiles per
+    workgroup; with the shipped GT_MAX = 1 every 64 x 64 tile of the upper block triangle is one workgroup."""
+    for GT_MAX in (1, 3):
+        for np_cap in range(1, 7):
+            npairs = sum((np_cap - ti + GT_MAX - 1) // GT_MAX for ti in range(np_cap))
+            tiles = []
+            for bx in range(npairs):
+                rem, ti, tj0 = bx, 0, 0
+                for ti in range(np_cap):
+                    ng = (np_cap - ti + GT_MAX - 1) // GT_MAX
+                    if rem < ng:
+                        tj0 = ti + GT_MAX * rem
+                        break
+                    rem -= ng
+                tiles += [(ti, tj) for tj in range(tj0, min(tj0 + GT_MAX, np_cap))]
+            assert sorted(tiles) == [(i, j) for i in range(np_cap) for j in range(i, np_cap)], (GT_MAX, np_cap)
