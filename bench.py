@@ -4,9 +4,9 @@
 Workload (config.workload), default `--config cfg3`: BASELINE.json configs[2] -- synthetic 30-camera window, 200 ending
 feature tracks per update, float, 64 batched trajectories per GPU (SURVEY.md section 8d "cfg3").  One *step* = one filter
 update for every trajectory of the batch: 10 x propagate + augmentState + marginalize(200 tracks) + prune of the oldest
-camera state.  `value` is measured with all inputs (IMU samples and per-frame track work-lists) resident in HBM before
-the timed region; `value_with_worklist_upload` times the same kind of window with every frame's inputs uploaded from page-
-locked host memory inside the timed region (SURVEY.md 8d's definition of the metric; never `value`).
+camera state.  `value` is SURVEY.md 8d's metric: every frame's inputs (IMU samples + the frame's track work-lists) are
+copied from page-locked host memory to the device INSIDE the timed region, pipelined with the kernels
+(msckf_hip_run_frames_streamed); `resident_inputs` holds the same windows with all inputs already in HBM (upper bound).
 
 `--config cfg4`: BASELINE.json configs[3] stand-in (EuRoC MH_01..05 are not on disk): 5 synthetic sequences x noise seeds,
 EuRoC cam0 intrinsics (f_u != f_v), float, 128 trajectories per GPU, per-sequence ATE all-reduced over the ranks.
@@ -15,9 +15,11 @@ EuRoC cam0 intrinsics (f_u != f_v), float, 128 trajectories per GPU, per-sequenc
 (dtype MSCKF_HIP_F16H_F32P), 512 trajectories per GPU (32 distinct scenarios, each run by 16 filters; `--trajectories`
 overrides); no CPU leg at this size (one update of the reference's algorithm builds a 28 000 x 28 000 Q).
 
-Launch: `python bench.py --gpus 1 --steps K --warmup W`, or one rank per GPU under torch.distributed.run (trajectories are
+Launch: `python bench.py --gpus N --steps K --warmup W`.  N > 1 without a torch.distributed.run environment re-executes
+itself as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` (one rank per GPU, RCCL over xGMI; it fails
+if the node has fewer than N devices); under torch.distributed.run it uses the ranks it is given.  Trajectories are
 independent: rank r runs its own block of trajectories, weak scaling, no data-path collective; RCCL is used only for the
-timing reduction and the end-of-run ATE all-reduce).
+timing reduction and the end-of-run ATE all-reduce.
 
 Prints ONE JSON line on rank 0.  `value` is the first timed K-step window (the driver's contract); `repeats` holds the
 further windows (median / min / max).  `roofline` is for the dominant kernel (the longest single kernel of a step by HIP
@@ -70,6 +72,26 @@ def alg_flops_update(Ms, N, K_imu=K_IMU):
     return dict(feature=float(per_track.sum()), compress=float(compress), kalman=float(kalman), propagate=float(propagate), augment=float(augment), gram=gram)
 
 
+def executed_flops_update(Ms, N, K_imu=K_IMU):
+    """FLOP of one filter update AS BUILT (the algorithm the kernels execute, 2 per FMA, useful work counted once) -> dict
+    per stage.  k_feature: triangulation + Jacobian (750 M), reflectors in S and f64 + Z / B^ (450 M), block-sparse gate
+    G = H_x P_cc H_x^T from 6 x 6 blocks (192 per pair, M (M + 1) / 2 pairs), G V (24 M^2), register Cholesky of the
+    (rho + 1) x rho trapezoid.  Compression in information form: SYRK 3 (n + 1)^2 per track + block diagonal 54 M, Cholesky
+    (n + 1)^3 / 3.  Kalman in square-root gain form: P[:,15:] T^T (triangular T: D n^2), S = T PHt (n^3), S = L L^T with
+    [PHt ; r_n^T] riding along (n^3 / 3 + D n^2), symmetric rank-n downdate (D^2 n)."""
+    Ms = np.asarray(Ms, dtype=np.float64)
+    rho = 2 * Ms - 3
+    n, D = 6.0 * N, 15.0 + 6 * N
+    feature = float(np.sum(1200 * Ms + 96 * Ms * (Ms + 1) + 24 * Ms ** 2 + rho ** 3 / 3 + rho ** 2))
+    gram = float(np.sum(3.0 * (n + 1) ** 2 + 54.0 * Ms))
+    chol_gram = (n + 1) ** 3 / 3
+    kalman = D * n * n + n ** 3 + (n ** 3 / 3 + D * n * n) + D * D * n
+    propagate = K_imu * (4 * 15 ** 3 + 2 * 15 ** 2 * n + 600)
+    augment = 72 * D + 432
+    return dict(feature=feature, compress_stage1=gram, compress_merge=float(chol_gram), kalman=float(kalman),
+                propagate=float(propagate), augment=float(augment))
+
+
 def alg_bytes_update(Ms, N, s=4, K_imu=K_IMU):
     D = 15 + 6 * N
     return 2 * D * D * s + float(np.sum(2 * np.asarray(Ms)) * s) + 7 * N * s + D * s + 7 * K_imu * s
@@ -99,6 +121,30 @@ def make_trajectories(c, rank, n_frames):
     return [out[b % nu] for b in range(c["B"])]
 
 
+def self_launch_if_needed(args):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: re-execute as N ranks, one per GPU, on this node."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if args.gpus > 1 and int(env_world) != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s" % (args.gpus, env_world))
+        return
+    if args.gpus <= 1:
+        return
+    if os.environ.get("BENCH_DIST_BACKEND", "nccl") == "nccl":     # (the gloo test hook runs several ranks on one device)
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("bench.py: --gpus %d requested, %d HIP device(s) visible on this node" % (args.gpus, have))
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execvpe(sys.executable, cmd, dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,18 +157,22 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--streams", type=int, default=3, help="HIP streams for the timed region (slices of the batch run concurrently)")
     ap.add_argument("--no-early-accept-pass", action="store_true", help="skip the extra measurement with the gate early accept (profiling runs)")
-    ap.add_argument("--no-upload-pass", action="store_true", help="skip the window with per-frame input upload (profiling runs)")
-    ap.add_argument("--compression", type=int, default=-1, help="msckf_hip_set_compression route (A/B runs; -1 = library default)")
-    ap.add_argument("--cov-form", type=int, default=0, help="msckf_hip_set_covariance_update form (A/B runs; 0 = library default)")
+    ap.add_argument("--no-upload-pass", action="store_true",
+                    help="time the windows with resident inputs only (profiling runs: `value` is then the resident-input rate and says so)")
+    ap.add_argument("--ring", type=int, default=6, help="device staging sets of the streamed-input run (2..8)")
+    ap.add_argument("--upload-mode", type=int, default=0, help="0 host hand-over of uploaded frames (default), 1 device-side event waits")
+    ap.add_argument("--cu-reserve", type=int, default=0, help="compute units reserved per slice (msckf_hip_set_cu_reserve; 0 = off)")
+    ap.add_argument("--compression", type=int, default=-1, help="msckf_hip_set_compression route (A/B runs; -1 = library default, 0 TSQR, information form with 1 k_chol_T / 2 k_chol_blk / 3 k_chol_mfma)")
+    ap.add_argument("--cov-form", type=int, default=0, help="msckf_hip_set_covariance_update form (A/B runs; 0 = square-root gain, blocked solve (default), 1 Joseph, 2 square-root gain, register-resident solve)")
     ap.add_argument("--gate-early-accept", action="store_true",
                     help="exact early accept of the chi-square gate (msckf_hip_set_gate_early_accept); OFF for the headline number")
     args = ap.parse_args()
+    self_launch_if_needed(args)
     c = dict(CONFIGS[args.config])
     if args.trajectories > 0:
         c["B"] = args.trajectories
     if args.config == "cfg5":          # big windows: one repeat window by default, no CPU legs that take minutes
         args.no_early_accept_pass = True
-        args.no_upload_pass = True
         if args.repeats <= 0:
             args.repeats = 2
     N_WIN, F_TRK, B_TRAJ = c["N"], c["F"], c["B"]
@@ -134,20 +184,26 @@ def main():
     fill = N_WIN                     # frames needed to reach the steady-state window
     est_ms = 0.7 * B_TRAJ / 64.0 * (N_WIN / 30.0) ** 2 * (F_TRK / 200.0)    # rough step time, only used to size the number of repeat windows
     R = args.repeats if args.repeats > 0 else int(min(12, max(3, np.ceil(500.0 / (K * est_ms)))))
-    extra = (0 if args.no_upload_pass else 1) + 1 + (0 if (args.gate_early_accept or args.no_early_accept_pass) else 1)
-    n_frames = fill + W + K * (R + extra)   # [fill | warmup | R timed windows | upload window | profiled | early-accept window]
+    streamed = not args.no_upload_pass
+    R2 = min(R, 3) if streamed else 0                       # resident-input windows beside the streamed ones
+    extra = R2 + 1 + (0 if (args.gate_early_accept or args.no_early_accept_pass) else 1)
+    n_frames = fill + W + K * (R + extra)   # [fill | warmup | R timed windows | R2 resident windows | profiled | early-accept window]
+    rendezvous_only = bool(os.environ.get("BENCH_RENDEZVOUS_ONLY"))   # test hook, see below
     t_gen = time.time()
-    trajs = make_trajectories(c, rank, n_frames)
+    trajs = [] if rendezvous_only else make_trajectories(c, rank, n_frames)
     t_gen = time.time() - t_gen
 
+    # more hardware queues than the runtime's default 4: the slices' streams + the copy stream must not share one
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
-    if not torch.cuda.is_available():
+    if not torch.cuda.is_available() and not (rendezvous_only and os.environ.get("BENCH_DIST_BACKEND") == "gloo"):
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # test hooks (tests/test_bench_multirank.py): run the N>1 code path on a 1-GPU box with gloo
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     if os.environ.get("BENCH_DEVICE_OVERRIDE") is not None:
         local_rank = int(os.environ["BENCH_DEVICE_OVERRIDE"])
-    torch.cuda.set_device(local_rank)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
     red_dev = "cuda" if backend == "nccl" else "cpu"
     dist = None
     if world > 1:
@@ -156,6 +212,16 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
         else:
             dist.init_process_group(backend)
+    if rendezvous_only:                               # test hook: prove the N-rank launch + collective, then stop (no filter run)
+        ranks = torch.zeros(world, dtype=torch.float64, device=red_dev)
+        ranks[rank] = rank + 1
+        if dist is not None:
+            dist.all_reduce(ranks, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "ranks_seen": [int(x) - 1 for x in ranks.tolist()], "backend": backend if dist is not None else None}))
+        if dist is not None:
+            dist.barrier(); dist.destroy_process_group()
+        return
     from msckf_mono_amd import capi, shard
 
     t_up = time.time()
@@ -191,13 +257,18 @@ def main():
         return el
 
     bt.set_streams(args.streams)
+    bt.set_upload_ring(args.ring, args.upload_mode)
+    bt.set_cu_reserve(args.cu_reserve)
     if args.compression >= 0:
         bt.set_compression(args.compression)
     bt.set_covariance_update(args.cov_form)
     bt.set_gate_early_accept(args.gate_early_accept)
-    bt.run_frames(0, fill + W)       # window fill + warm-up (untimed)
     f = fill + W
-    elapsed = timed(f, f + K)        # ---- THE timed region: exactly K steps -> `value`
+    if streamed:                     # page-lock the frames that will be streamed (set-up, like every other allocation)
+        bt.scenario_pin(fill, f + K * R)
+    bt.run_frames(0, fill)           # window fill (untimed)
+    (bt.run_frames_streamed if streamed else bt.run_frames)(fill, f)   # W warm-up steps (untimed), on the path that is timed
+    elapsed = timed(f, f + K, streamed=streamed)   # ---- THE timed region: exactly K steps -> `value`
     f_end_timed = f + K
     sample = sorted(set(int(x) for x in np.linspace(0, B_TRAJ - 1, 8)))
     p_dev_sample = {b: bt.imu_state(b)[13:16].copy() for b in sample}   # positions at the end of the timed window
@@ -205,10 +276,12 @@ def main():
     f += K
     rep = [elapsed]
     for _ in range(R - 1):           # further windows of the same size: spread of the measurement
-        rep.append(timed(f, f + K)); f += K
-    upload_el, h2d_gbs = None, None
-    if not args.no_upload_pass:      # the same K-step window with every frame's inputs uploaded inside the timed region
-        upload_el = timed(f, f + K, streamed=True); f += K
+        rep.append(timed(f, f + K, streamed=streamed)); f += K
+    res_rep = []
+    for _ in range(R2):              # the same kind of window with every input already resident in HBM (upper bound)
+        res_rep.append(timed(f, f + K)); f += K
+    h2d_gbs = None
+    if streamed:
         try:                         # what the box's host-to-device path delivers from page-locked memory (64 MB copies)
             hbuf = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
             dbuf = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
@@ -242,13 +315,20 @@ def main():
     # ---- gate pass-rate / algorithmic work on the frames that were timed
     pass_rate = float(np.mean([s["n_passed"] / max(s["n_tracks"], 1) for s in stats]))
     fl = dict(feature=0.0, compress=0.0, kalman=0.0, propagate=0.0, augment=0.0, gram=0.0)
+    ex = dict(feature=0.0, compress_stage1=0.0, compress_merge=0.0, kalman=0.0, propagate=0.0, augment=0.0)
     by = 0.0
+    up_bytes = 0.0
     for tr in trajs:
         for ff in range(fill + W, fill + W + K):
             one = alg_flops_update(tr.frames[ff]["M"], N_WIN)
             for k2 in fl:
                 fl[k2] += one[k2] / (K * B_TRAJ)
+            one = executed_flops_update(tr.frames[ff]["M"], N_WIN)
+            for k2 in ex:
+                ex[k2] += one[k2] / (K * B_TRAJ)
             by += alg_bytes_update(tr.frames[ff]["M"], N_WIN) / (K * B_TRAJ)
+            # one frame's streamed block: IMU samples, track count + drop count, lengths + offsets, (slot, u, v) per observation
+            up_bytes += (K_IMU * 7 * 4 + 8 + 2 * 4 * F_TRK + 12.0 * float(np.sum(tr.frames[ff]["M"]))) / K
     f_update = sum(v for k2, v in fl.items() if k2 != "gram")   # the reference's algorithm (gram = the same stage as built, not additive)
 
     # ---- end-of-run ATE of the position against ground truth, per sequence: one all-reduce(sum) of {sum |e|^2, n}
@@ -270,7 +350,18 @@ def main():
         value = updates / elapsed
         ms_per_step = 1e3 * elapsed / K
         rep_vals = [updates / e for e in rep]
+        res_vals = [updates / e for e in res_rep]
         stage_ms = {k2: v[0] / max(v[1], 1) for k2, v in prof.items()}
+        # utilisation on EXECUTED work: the FLOP of the algorithm as built per stage / the stage's HIP-event time / the peak
+        # of the arithmetic the stage runs in (f64 matrix cores for the information-form compression, f32 elsewhere)
+        ex_peak = dict(feature=PEAK_F32_TFLOPS, compress_stage1=PEAK_F64_TFLOPS, compress_merge=PEAK_F64_TFLOPS, kalman=PEAK_F32_TFLOPS,
+                       propagate=PEAK_F32_TFLOPS, augment=PEAK_F32_TFLOPS)
+        executed_model = {}
+        for k2, flop in ex.items():
+            t_ms = stage_ms.get(k2, 0.0)
+            tf = flop * B_TRAJ / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
+            executed_model[k2] = {"flop_per_step": flop * B_TRAJ, "ms_per_step": t_ms, "tflops": tf, "peak": ex_peak[k2], "frac": tf / ex_peak[k2]}
+        ex_update = sum(ex.values())
         # single kernels with their own HIP-event pair; "kalman" is a launch SET (2 GEMMs + blocked gain solve + inject +
         # downdate) and is listed in stage_ms_per_step only.  Algorithmic FLOP = SURVEY.md section 8d per-unit figures of
         # the REFERENCE's algorithm (dense gate products, Householder compression), not the instructions executed.
@@ -289,7 +380,10 @@ def main():
         kd = kernels[dom]
         dom_flops = kd["flops"] * B_TRAJ
         achieved = dom_flops / (kd["ms"] * 1e-3) / 1e12 if kd["ms"] > 0 else 0.0
-        pmc = pmc_block(dom)
+        pmc, pmc_meta = pmc_block(dom)
+        dom_stage = {"k_feature": "feature", "k_gram": "compress_stage1", "k_chol_mfma": "compress_merge", "k_propagate": "propagate"}[dom]
+        frac = achieved / kd["peak"]
+        whole_frac = f_update * value / 1e12 / world / PEAK_F32_TFLOPS
         out = {
             "metric": "filter updates/sec (%d-cam window, %d feats)" % (N_WIN, F_TRK), "value": value, "unit": "updates/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -299,27 +393,38 @@ def main():
                        "parallelism": "replicated trajectories, %d per rank" % B_TRAJ,
                        "noise": "isotropic (f_u = f_v)" if c["iso"] else "anisotropic (EuRoC f_u != f_v, rows pre-whitened)",
                        "sequences": nseq, "gate_early_accept": bool(args.gate_early_accept), "streams": args.streams},
+            "inputs": ("uploaded per frame inside the timed region (SURVEY.md 8d): page-locked host memory -> staging ring on a copy stream, "
+                       "compact work-lists, %d sets" % args.ring) if streamed else "resident in HBM before the timed region (--no-upload-pass)",
+            "upload": None if not streamed else {"bytes_per_step_per_gpu": int(up_bytes), "ring": args.ring,
+                                                 "hand_over": "host" if args.upload_mode == 0 else "device events", "h2d_GBps_pinned_64MB": h2d_gbs},
             "repeats": {"windows": len(rep_vals), "steps_each": K, "values": rep_vals, "median": float(np.median(rep_vals)),
                         "min": float(np.min(rep_vals)), "max": float(np.max(rep_vals)),
                         "note": "value = windows[0] (the contract's K timed steps); the others are the same measurement on the following frames"},
-            "value_with_worklist_upload": None if upload_el is None else {
-                "value": updates / upload_el, "ms_per_step": 1e3 * upload_el / K,
-                "bytes_per_step": int(B_TRAJ * (K_IMU * 7 * 4 + 8 + F_TRK * 4 + F_TRK * N_WIN * 12)),
-                "h2d_GBps_pinned_64MB": h2d_gbs,
-                "note": "same K steps with each frame's IMU samples + work-list copied from page-locked host memory on a copy stream inside "
-                        "the timed region (msckf_hip_run_frames_streamed); SURVEY.md 8d's definition of the metric"},
+            "resident_inputs": None if not res_vals else {
+                "values": res_vals, "median": float(np.median(res_vals)), "ms_per_step": 1e3 * float(np.median(res_rep)) / K,
+                "streamed_over_resident": float(np.median(rep_vals) / np.median(res_vals)),
+                "note": "the same K-step windows with every frame's inputs already in HBM (msckf_hip_run_frames): an upper bound, never `value`"},
             "roofline": {"bound": kd["bound"], "kernel": dom, "achieved": achieved, "peak": kd["peak"], "unit": "TFLOP/s",
-                         "frac": achieved / kd["peak"], "traffic": None if pmc is None else pmc.get("bytes_per_launch"),
+                         "frac": frac if frac <= 1.0 else None,
+                         "executed_frac": executed_model[dom_stage]["frac"], "executed_tflops": executed_model[dom_stage]["tflops"],
+                         "traffic": None if pmc is None else pmc.get("bytes_per_launch"),
                          "why": kd["why"], "kernel_ms_per_step": kd["ms"], "alg_flops_per_launch": dom_flops,
-                         "note": "achieved = the REFERENCE algorithm's FLOP for this stage (SURVEY.md 8d: dense gate products) / measured kernel time; "
-                                 "the kernel executes a block-sparse form with far fewer FLOP -- see `executed`",
+                         "note": "achieved / frac = the REFERENCE algorithm's FLOP for this stage (SURVEY.md 8d: dense gate products) / measured kernel "
+                                 "time -- an algorithm-equivalent rate, not a utilisation (frac is null when it exceeds 1: alg_equivalent_ratio); "
+                                 "executed_frac = FLOP of the block-sparse algorithm the kernel runs (executed_model) / time / peak",
+                         "alg_equivalent_ratio": frac,
                          "executed": None if pmc is None else pmc.get("executed"),
+                         "traffic_source": pmc_meta,
+                         "executed_model": executed_model,
+                         "executed_flop_per_update": ex_update,
+                         "whole_update_executed_tflops": ex_update * value / 1e12 / world,
+                         "whole_update_executed_frac": ex_update * value / 1e12 / world / PEAK_F32_TFLOPS,
                          "kalman_set": {"ms_per_step": stage_ms["kalman"], "alg_flops_per_step": fl["kalman"] * B_TRAJ,
                                         "tflops_alg": fl["kalman"] * B_TRAJ / (stage_ms["kalman"] * 1e-3) / 1e12 if stage_ms["kalman"] > 0 else 0.0,
                                         "note": "square-root gain form: ~4.4 D^3 FLOP executed instead of the Joseph sequence's 16.3 D^3"},
                          "alg_flops_per_update": f_update, "alg_bytes_per_update": by,
-                         "whole_update_tflops": f_update * value / 1e12 / world,
-                         "whole_update_frac": f_update * value / 1e12 / world / PEAK_F32_TFLOPS,
+                         "whole_update_alg_equivalent_tflops": f_update * value / 1e12 / world,
+                         "whole_update_alg_equivalent_ratio": whole_frac,
                          "hbm_frac_alg": by * value / 1e9 / world / PEAK_HBM_GBS,
                          "stage_ms_per_step": stage_ms},
             "gate_pass_rate": pass_rate, "ate_m": ate, "ate_per_sequence_m": [float(x) for x in ate_seq],
@@ -344,18 +449,20 @@ def main():
 def pmc_block(kernel):
     """HBM bytes per launch and executed-instruction figures of a kernel from the committed rocprofv3 PMC passes
     (separate --pmc runs of this same command, profiles/pmc_traffic.json written by scripts/rocpd_pmc.py; FETCH_SIZE is
-    doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if absent."""
+    doubled as MI355X_MICROARCH.md prescribes for gfx950) and where they came from (profile tag + commit of the passes:
+    they are NOT collected in the run that prints them).  (None, None) if absent."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
-        return None
+        return None, None
     try:
         t = json.load(open(path))
+        meta = dict(t.get("_meta", {}), file="profiles/pmc_traffic.json", collected="separate rocprofv3 --pmc passes, not this run")
         for k2, v in t.items():
             if k2 == kernel or k2.startswith(kernel):
-                return v
+                return v, meta
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def _oracle_window(o, tr, k, N):

@@ -129,10 +129,19 @@ int msckf_hip_scenario_commit(msckf_hip_handle h);   /* H2D of everything staged
  * frames [f0, f1), asynchronously on the handle's stream */
 int msckf_hip_run_frames(msckf_hip_handle h, int f0, int f1);
 /* The same frames with the inputs handed over per frame, as the reference's callers do (IMU samples and the image's
- * tracks arrive with the image, asl_msckf.cpp:227-284): frame f's IMU samples and work-list are copied from the
- * page-locked host scenario to the device on a copy stream, double-buffered, while frame f-1 computes.  Results are
+ * tracks arrive with the image, asl_msckf.cpp:227-284): frame f's IMU samples and its COMPACT work-list (sum M_j slot /
+ * observation entries + per-track offsets, not padded [f_cap][m_cap] rows) are copied from page-locked host memory into one
+ * of `depth` device staging sets on a copy stream, up to depth - 1 frames ahead of the kernels that read them.  Results are
  * bit-identical to msckf_hip_run_frames; the difference is the PCIe leg inside the timed region. */
 int msckf_hip_run_frames_streamed(msckf_hip_handle h, int f0, int f1);
+/* Build the page-locked per-frame blocks of frames [f0, f1) (and size the device staging ring) ahead of time;
+ * msckf_hip_run_frames_streamed does it on first use otherwise.  Only frames that are streamed are ever page-locked;
+ * -ENOMEM leaves msckf_hip_run_frames on the resident scenario unaffected. */
+int msckf_hip_scenario_pin(msckf_hip_handle h, int f0, int f1);
+/* Staging ring of msckf_hip_run_frames_streamed: depth 2..8 (default 6); mode 0 (default) hands frames over between the
+ * uploading thread and the slices' enqueue threads on the HOST (no stream waits for another stream's event on the device),
+ * mode 1 uses hipStreamWaitEvent hand-overs.  Same results. */
+int msckf_hip_set_upload_ring(msckf_hip_handle h, int depth, int mode);
 int msckf_hip_sync(msckf_hip_handle h);
 /* HIP-event stage timing: enable, run, sync, then read accumulated milliseconds and launch counts for
  * stages 0 propagate, 1 augment, 2 k_feature, 3 compression A (k_gram_diag + k_gram | TSQR stage 1), 4 compression B
@@ -143,6 +152,11 @@ int msckf_hip_profile_read(msckf_hip_handle h, double* ms8, int* count8);
 /* run_frames on n = 1..8 HIP streams: the batch is cut into n slices of independent trajectories that run the
  * same kernel sequence concurrently (latency-bound stages of one slice overlap chip-filling stages of another). */
 int msckf_hip_set_streams(msckf_hip_handle h, int n);
+/* Reserve n (0 = off, rounded up to a multiple of 8, <= 64) compute units per slice for that slice alone: the slices'
+ * streams are created with CU masks (hipExtStreamCreateWithCUMask) that exclude the other slices' reserved units, so a
+ * slice's one-workgroup-per-trajectory kernels (blocked Choleskys, propagate, select, prune) find free units while another
+ * slice's per-track kernel fills the rest of the chip.  Scheduling only: results are bit-identical. */
+int msckf_hip_set_cu_reserve(msckf_hip_handle h, int n);
 /* Exact early accept of the chi-square gate (gatingTest, msckf.h:1103-1124), OFF by default: S = H_o P H_o^T + sigma^2 I
  * >= sigma^2 I, so gamma <= |r_o|^2 / sigma^2; when that bound is below half the threshold the track passes without
  * forming S.  Same decisions as the reference; the reported gamma of such a track is the bound (status bit 32). */

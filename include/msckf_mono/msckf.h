@@ -146,10 +146,11 @@ class MSCKF {
   }
   inline Camera<_S> getCamera() { return camera_; }
   inline std::vector<camState<_S>> getCamStates() const {
-    const int cap = 64;
-    std::vector<double> c(7 * cap), tm(cap); std::vector<int> ids(cap), lc(cap), nt(cap);
+    const int cap = std::max(msckf_hip_get_num_cam_states(h_, 0), 1);     // the count first: any configured n_cap fits
+    std::vector<double> c(7 * (size_t)cap), tm((size_t)cap); std::vector<int> ids((size_t)cap), lc((size_t)cap), nt((size_t)cap);
     const int n = msckf_hip_get_cam_states(h_, 0, c.data(), ids.data(), cap);
     const int nm = msckf_hip_get_cam_meta(h_, 0, tm.data(), nt.data(), lc.data(), cap);
+    if (n < 0 || nm < 0) std::fprintf(stderr, "msckf_mono shim: getCamStates failed: %s\n", msckf_hip_last_error());
     std::vector<camState<_S>> out;
     std::vector<uint64_t> fid;
     for (int i = 0; i < n; ++i) {

@@ -31,6 +31,7 @@ SYMBOLS = [
     "msckf_hip_augment_range", "msckf_hip_marginalize_range", "msckf_hip_drop_oldest_range", "msckf_hip_scenario_alloc",
     "msckf_hip_scenario_set", "msckf_hip_scenario_commit", "msckf_hip_run_frames", "msckf_hip_run_frames_streamed", "msckf_hip_sync",
     "msckf_hip_profile_enable", "msckf_hip_profile_read", "msckf_hip_set_streams", "msckf_hip_set_gate_early_accept",
+    "msckf_hip_scenario_pin", "msckf_hip_set_upload_ring", "msckf_hip_set_cu_reserve",
     "msckf_hip_set_compression", "msckf_hip_set_covariance_update", "msckf_hip_set_feature_overlap", "msckf_hip_get_pruned_states", "msckf_hip_get_cam_meta", "msckf_hip_get_tracked_feature_ids",
 ]
 
@@ -237,8 +238,20 @@ class Batch:
         _chk(self.L.msckf_hip_run_frames(self.h, f0, f1))
 
     def run_frames_streamed(self, f0, f1):
-        """run_frames with per-frame asynchronous H2D of the inputs (copy stream, double-buffered)"""
+        """run_frames with per-frame asynchronous H2D of the inputs (copy stream, ring of staging sets, compact work-lists)"""
         _chk(self.L.msckf_hip_run_frames_streamed(self.h, f0, f1))
+
+    def scenario_pin(self, f0, f1):
+        """page-lock the per-frame blocks of frames [f0, f1) ahead of a streamed run (outside any timed region)"""
+        _chk(self.L.msckf_hip_scenario_pin(self.h, int(f0), int(f1)))
+
+    def set_upload_ring(self, depth=6, mode=0):
+        """staging sets of run_frames_streamed (2..8); mode 0 host hand-over (default), 1 device-side event waits"""
+        _chk(self.L.msckf_hip_set_upload_ring(self.h, int(depth), int(mode)))
+
+    def set_cu_reserve(self, n):
+        """compute units reserved per slice for its one-workgroup-per-trajectory kernels (0 = off; CU-masked streams)"""
+        _chk(self.L.msckf_hip_set_cu_reserve(self.h, int(n)))
 
     def sync(self):
         _chk(self.L.msckf_hip_sync(self.h))
@@ -247,11 +260,13 @@ class Batch:
         _chk(self.L.msckf_hip_set_streams(self.h, int(n)))
 
     def set_compression(self, route):
-        """-1 default, 0 Householder TSQR, 1 information form, 2 information form + blocked Cholesky"""
+        """-1 default for the window size; 0 Householder TSQR; information form chol(H_o^T H_o) with 1 the register-resident
+        Cholesky k_chol_T, 2 k_chol_blk, 3 the blocked matrix-core Cholesky k_chol_mfma (the default where it fits)"""
         _chk(self.L.msckf_hip_set_compression(self.h, int(route)))
 
     def set_covariance_update(self, form):
-        """0 square-root gain form P - W W^T (default), 1 the reference's Joseph sequence"""
+        """0 square-root gain form P - W W^T with the blocked matrix-core solve (default), 1 the reference's Joseph sequence,
+        2 square-root gain form with the register-resident solve"""
         _chk(self.L.msckf_hip_set_covariance_update(self.h, int(form)))
 
     def set_feature_overlap(self, on):

@@ -39,6 +39,10 @@ enum {  // per-track status bits written by k_feature / k_select
   ST_MOTION_OK = 1, ST_TRI_VALID = 2, ST_GATE_PASS = 4, ST_INCLUDED = 8, ST_MOTION_SKIPPED = 16, ST_GATE_BOUND = 32
 };
 enum { STAT_NTRACKS = 0, STAT_MOTION_REJ, STAT_TRI_REJ, STAT_GATE_REJ, STAT_PASSED, STAT_MROWS, STAT_RROWS, STAT_ERR, STAT_STRIDE = 8 };
+// STAT_ERR is sticky (never cleared by an update) and a bit field: capacity overflow in augmentState; a non-positive pivot
+// in the factorization of S = T_H P T_H^T + R_n (the covariance lost positive definiteness: the square-root gain form
+// P <- P - W W^T has no PSD guarantee under rounding; the pivot is clamped so that the run continues, but it is reported)
+enum { STAT_ERR_NCAP = 1, STAT_ERR_PIVOT = 2 };
 
 template <class S>
 struct Dev {
@@ -51,9 +55,12 @@ struct Dev {
   S* imu; S* cam; S* prm; S* P; S* Ptmp; int* ncam; long long* n_resid;
   // current work-list (may point into a resident scenario)
   const int* trk_n; const int* trk_M; const int* trk_slots; const S* trk_obs;
+  // trk_off == null: padded single-call lists, track t of the launch's i-th trajectory starts at i * wl_stride_o + t * m_cap;
+  // else the COMPACT per-frame lists of a scenario: sum M_j entries, track t starts at trk_off[i * wl_stride_f + t] (wl_first)
+  const int* trk_off;
   long wl_stride_n;   // stride between trajectories in trk_n   (ints)
-  long wl_stride_f;   // stride between trajectories in trk_M   (ints)
-  long wl_stride_o;   // stride between trajectories in trk_slots (ints) / trk_obs (2 scalars each)
+  long wl_stride_f;   // stride between trajectories in trk_M / trk_off (ints)
+  long wl_stride_o;   // stride between trajectories in trk_slots (ints) / trk_obs (2 scalars each), padded lists only
   // mode 1 (second update of pruneRedundantStates, msckf.h:545-614): every track comes with its stored feature
   // position trk_pfin[b*f_cap+t][4] -- no checkMotion / triangulation, no Q4 bookkeeping
   int mode; const S* trk_pfin;
@@ -91,6 +98,24 @@ struct Dev {
   // prune
   int* keep; int* nkeep;
 };
+
+// first observation of track t of the launch's i-th trajectory in trk_slots / trk_obs
+template <class S> __device__ __forceinline__ long wl_first(const Dev<S>& d, int i, int t) {
+  return d.trk_off ? (long)d.trk_off[(long)i * d.wl_stride_f + t] : (long)i * d.wl_stride_o + (long)t * d.m_cap;
+}
+
+// XCD-aware decomposition of a 1-D grid of 8 * ceil(nb / 8) * items workgroups into (trajectory i < nb, item): MI355X places
+// workgroup w on XCD w % 8 (MI355X_MICROARCH.md, workgroup dispatch), each XCD has a private 4 MiB L2, and every item of a
+// trajectory reads the same covariance / per-track blocks.  Trajectories i, i + 8, ... share XCD i % 8, all their items
+// with them: one XCD's L2 holds 1/8 of the batch instead of all of it.  A pure speed choice (placement is not a contract);
+// returns false for the padding workgroups of an XCD that has fewer trajectories than the fullest one.
+__device__ __forceinline__ bool xcd_item(int nb, int items, int& i, int& item) {
+  const int w = (int)blockIdx.x, x = w & 7, j = w >> 3;
+  const int q = j / items;
+  i = x + 8 * q; item = j - q * items;
+  return i < nb;
+}
+inline int xcd_grid(int nb, int items) { return 8 * ((nb + 7) / 8) * items; }
 
 // measurement Jacobian element idx of the per-track blocks [track][m_cap][12]
 template <class S> __device__ __forceinline__ S ld_hx(const Dev<S>& d, long idx) {

@@ -159,6 +159,7 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0) {
     for (int t = tid; t < 16 * NB; t += 1024) { const double dv = lam_hat(Lam, Dg, d.ldR, nfull, d.n_cap, OFF + t, OFF + t); sD0[t] = t < n ? (T)dv : T(0); }
   const T tol = T(64.0 * 2.220446049250313e-16);
   int nskip = 0;
+  bool badpiv = false;   // factorization of S: a pivot that is not positive (P or S lost positive definiteness) -> STAT_ERR bit 2
   T dxacc = 0;   // GAIN: thread t < app rows accumulates dx[app_lo + t] = sum_k W(., k) z_k
   SO* Rt = d.Rbuf + ((long)b * d.nchunk) * (long)d.n6cap * d.ldR;
   SO* Wg = d.W + (long)b * d.ld * d.n6cap;
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0) {
         bool skip_l;
         T piv = x[qk];
         if (GRAMLIKE) skip_l = (k >= kcount) || !(piv > tol * d0);
-        else { skip_l = k >= kcount; piv = piv > T(0) ? piv : Lim<T>::tiny(); }
+        else { skip_l = k >= kcount; badpiv = badpiv || (lane == src && k < kcount && !(piv > T(0))); piv = piv > T(0) ? piv : Lim<T>::tiny(); }
         const T dinv_l = skip_l ? T(0) : fast_rsqrt(piv);
         const T dinv = wave_bcast(dinv_l, src);
         const T pv = wave_bcast(piv, src);
@@ -404,6 +405,7 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0) {
     atomicAdd(&g_chol_cycles[MODE == CH_GAIN ? 1 : 0][6], 1ull);
   }
 #endif
+  if (!GRAMLIKE && w == 0 && __any(badpiv ? 1 : 0) && lane == 0) atomicOr(&st[STAT_ERR], STAT_ERR_PIVOT);
   if (MODE == CH_GRAM || MODE == CH_GRAM_A) { if (tid == 0) st[STAT_RROWS] = nfull - nskip; }
   else if (MODE == CH_GRAM_B) { if (tid == 0) st[STAT_RROWS] -= nskip; }
   else if (SLIKE) {}

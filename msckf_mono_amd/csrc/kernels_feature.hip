@@ -217,9 +217,14 @@ __device__ __forceinline__ bool gate_chol(const S* sG, const S* sV, const S* sE,
 // LONG: tracks of more than 33 observations (2M - 2 > 64: windows beyond 33 cameras) keep the gate's Cholesky in registers
 // too (up to 16 x 16 blocks per lane); a separate instantiation, so that the short-track kernel keeps its register budget.
 template <class S, bool LONG>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (sizeof(S) == 4 ? 4 : 2), sizeof(S) == 4 && !LONG ? 4 : 2))) void k_feature(Dev<S> d, int b0) {
-  const int b = b0 + blockIdx.y, t = blockIdx.x, lane = threadIdx.x;
-  const int F = d.trk_n[(long)(b - b0) * d.wl_stride_n];
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (sizeof(S) == 4 ? 4 : 2), sizeof(S) == 4 && !LONG ? 4 : 2))) void k_feature(Dev<S> d, int b0, int nb) {
+  // all tracks of a trajectory on one XCD (xcd_item): the gate's 6 x 6 blocks of P then come out of an L2 that holds 1/8 of
+  // the batch's covariances (the (track, trajectory) grid spread every trajectory over all eight: 73 MB fetched per launch for
+  // 9.7 MB of covariance)
+  int bi, t;
+  if (!xcd_item(nb, d.f_cap, bi, t)) return;
+  const int b = b0 + bi, lane = threadIdx.x;
+  const int F = d.trk_n[(long)bi * d.wl_stride_n];
   if (t >= F) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int m_cap = d.m_cap;
@@ -235,8 +240,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
   int* sSlot = reinterpret_cast<int*>(sHx + xlen);
 
   const long tb = (long)b * d.f_cap + t;               // per-track output index
-  const int M = d.trk_M[(long)(b - b0) * d.wl_stride_f + t];
-  const long wo = (long)(b - b0) * d.wl_stride_o + (long)t * m_cap;
+  const int M = d.trk_M[(long)bi * d.wl_stride_f + t];
+  const long wo = wl_first(d, bi, t);
   const S* prm = d.prm + (long)b * PRM_STRIDE;
   const S* imu = d.imu + (long)b * IMU_STRIDE;
   const int ld = d.ld;
@@ -260,6 +265,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
   const M3<S> C = q2rot(qc);
   const V3<S> g = ld3(imu + IG);
   if (lane < m_cap) sSlot[lane] = act ? slot : -1;
+  const int slot_lo = wave_min_i(act ? slot : 0x7fffffff), slot_hi = -wave_min_i(act ? -slot : 0x7fffffff);
   // first camera of the track (lane 0) broadcast
   M3<S> C0; V3<S> p0;
 #pragma unroll
@@ -487,9 +493,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
     if (d.compress) {
       // B scattered to state columns ([3][ldR] f64, zero where unobserved, column n = Q_f^T r), the whitened
       // residual and the slot -> observation map for the block-diagonal part of the Gram matrix
+      // Only the columns of the track's slot range [first, last] are written (zeros where a slot inside the range is not
+      // observed); k_gram masks everything outside the range (trk_first carries both ends).  Zero-filling all 3 x ldR doubles
+      // of every track was 59 MB of the launch's 107 MB of writes.
       double* oB = d.trk_B + tb * 3 * (long)d.ldR;
       signed char* oI = d.trk_inv + tb * d.n_cap;
-      for (int e = lane; e < 3 * d.ldR; e += 64) oB[e] = 0.0;
+      const int c_lo = 6 * slot_lo, c_n = 6 * (slot_hi - slot_lo + 1);
+      for (int e = lane; e < 3 * c_n; e += 64) { const int q = e / c_n; oB[(long)q * d.ldR + c_lo + (e - q * c_n)] = 0.0; }
       for (int e = lane; e < d.n_cap; e += 64) oI[e] = -1;
       __syncthreads();
       if (act) {
@@ -562,12 +572,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
       const int a = first ? k : ((M & 1) ? M - k : M - 1 - k);
       const int bq = a + (first ? c : c - (M - k));
       const int sa2 = sSlot[a], sb2 = sSlot[bq];
-      const S* Pab = P + (long)(15 + 6 * sb2) * ld + 15 + 6 * sa2;   // element (i,j) at Pab[j*ld + i]
+      // The block P(6 s_a + i, 6 s_b + j) is read through its mirror image P(6 s_b + j, 6 s_a + i) (P is kept bit-symmetric):
+      // consecutive lanes are consecutive bq for one a, so with the b block along the ROWS of column-major P a wavefront's
+      // addresses are consecutive 24-byte runs of a few columns (~12 cache lines per load instead of 64).  Row 15 + 6 s is
+      // odd, so rows j = 1..4 of a run are two aligned pairs: 4 loads per column instead of 6.
+      const S* Pt = P + (long)(15 + 6 * sa2) * ld + 15 + 6 * sb2;   // element (i, j) at Pt[i * ld + j]
       S pv[6][6];
+      typedef S s2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-      for (int j = 0; j < 6; ++j)
-#pragma unroll
-        for (int i = 0; i < 6; ++i) pv[j][i] = (fdbg & 2) ? S(i == j ? 1e-4 : 0) : Pab[(long)j * ld + i];
+      for (int i = 0; i < 6; ++i) {
+        if (fdbg & 2) { for (int j = 0; j < 6; ++j) pv[j][i] = S(i == j ? 1e-4 : 0); continue; }
+        const S* col = Pt + (long)i * ld;
+        const s2 m12 = *reinterpret_cast<const s2*>(col + 1), m34 = *reinterpret_cast<const s2*>(col + 3);
+        pv[0][i] = col[0]; pv[1][i] = m12.x; pv[2][i] = m12.y; pv[3][i] = m34.x; pv[4][i] = m34.y; pv[5][i] = col[5];
+      }
       if constexpr (sizeof(S) == 4) {
         // both rows of the 2 x 6 block at once on the packed-f32 pipe: (T0j, T1j) += (h0i, h1i) * P(i, j)
         typedef float f2 __attribute__((ext_vector_type(2)));
@@ -712,12 +730,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
       if (act)
         for (int q = 0; q < 3; ++q) for (int k = 0; k < 6; ++k) oZ[(long)q * d.ldR + 6 * slot + k] = Zc[q][k];
     }
-    int fs = act ? slot : 0x7fffffff;
-    fs = wave_min_i(fs);
     if (lane == 0) {
       d.trk_status[tb] = status;
       d.trk_gamma[tb] = gamma;
-      d.trk_first[tb] = fs;
+      d.trk_first[tb] = slot_lo | (slot_hi << 8);   // first and last camera slot of the track (TRK_FIRST / TRK_LAST)
       S* opf = d.trk_pf + tb * 4;
       opf[0] = pf.x; opf[1] = pf.y; opf[2] = pf.z; opf[3] = 0;
     }
@@ -929,8 +945,8 @@ template <class S>
 void launch_feature(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0) return;
   const size_t lds = feature_lds_bytes(d.m_cap, sizeof(S));
-  if (2 * d.m_cap - 2 > 64) hipLaunchKernelGGL((k_feature<S, true>), dim3(d.f_cap, nb), dim3(64), lds, st, d, b0);
-  else hipLaunchKernelGGL((k_feature<S, false>), dim3(d.f_cap, nb), dim3(64), lds, st, d, b0);
+  if (2 * d.m_cap - 2 > 64) hipLaunchKernelGGL((k_feature<S, true>), dim3(xcd_grid(nb, d.f_cap)), dim3(64), lds, st, d, b0, nb);
+  else hipLaunchKernelGGL((k_feature<S, false>), dim3(xcd_grid(nb, d.f_cap)), dim3(64), lds, st, d, b0, nb);
 }
 #ifdef MSCKF_ABLATE
 void feat_debug_set(int val) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_feat_dbg), &val, sizeof(int)); }

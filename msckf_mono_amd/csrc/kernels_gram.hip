@@ -31,7 +31,7 @@ int g_gram_dbg = 0;
 // phase timers of the SYRK launch (shader-clock cycles of thread 0 of trajectory 0's workgroups): [strip][0 start-up + track
 // count, 1 K loop, 2 group sum, 3 epilogue, 4 launches]
 __device__ unsigned long long g_gram_cycles[8][5];
-#define GR_TICK(slot) do { if (threadIdx.x == 0 && blockIdx.y == 0) { const long long t_ = clock64(); atomicAdd(&g_gram_cycles[bx & 7][slot], (unsigned long long)(t_ - gr_t)); gr_t = t_; } } while (0)
+#define GR_TICK(slot) do { if (threadIdx.x == 0 && bi == 0) { const long long t_ = clock64(); atomicAdd(&g_gram_cycles[bx & 7][slot], (unsigned long long)(t_ - gr_t)); gr_t = t_; } } while (0)
 #else
 #define GR_TICK(slot) do {} while (0)
 #endif
@@ -89,15 +89,18 @@ __global__ __launch_bounds__(256) void k_gram_diag(Dev<S> d, int b0) {
 // twice the loads in flight and two wavefronts per SIMD on a loop that is bound by load latency, with a fixed summation
 // order.
 template <class S>
-__global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int npairs, int dbg, int xoff) {
-  const int b = b0 + blockIdx.y, grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, w = tid >> 6;
+__global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int nb, int npairs, int dbg, int xoff) {
+  // the tiles of one trajectory read the same rows of B^: all of them on the trajectory's XCD (xcd_item)
+  int bi, bxi;
+  if (!xcd_item(nb, npairs, bi, bxi)) return;
+  const int b = b0 + bi, grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, w = tid >> 6;
   const int* st = d.stats + (long)b * STAT_STRIDE;
   const int mrows_ = st[STAT_MROWS], P = st[STAT_PASSED], N = d.ncam[b];   // independent scalar loads, one wait
   if (mrows_ == 0) return;
   const int n = 6 * N, ldL = d.ldR, f_cap = d.f_cap, m_cap = d.m_cap;
   const int* order = d.trk_order + (long)b * f_cap;
 
-  const int bx = (int)blockIdx.x + xoff;
+  const int bx = bxi + xoff;
 #ifdef MSCKF_ABLATE
   long long gr_t = clock64();
 #endif
@@ -136,8 +139,9 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int npairs, int 
     int c = 0;
     for (int e = threadIdx.x; e < P && e < GORD; e += 512) {
       const int t = order[e];
-      sOrd[e] = t;
-      c += (d.trk_first[(long)b * f_cap + t] <= hi_slot) ? 1 : 0;
+      const int fl = d.trk_first[(long)b * f_cap + t];      // first | last << 8 camera slot of the track
+      sOrd[e] = t | ((fl & 63) << 10) | (((fl >> 8) & 63) << 16);
+      c += ((fl & 255) <= hi_slot) ? 1 : 0;
     }
     c = (int)wave_sum((float)c);
     if (lane == 0 && c) atomicAdd(&sCnt, c);
@@ -150,17 +154,26 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int npairs, int 
   // two register stages: the loads of chunk c+2 are issued as soon as chunk c has been staged to LDS, so two
   // chunks of global latency are in flight behind the MFMAs.  Branch-free: rows past the end are clamped to the
   // last row and masked when staged (a conditional per row makes the compiler drain vmcnt between the loads).
-  struct Stage { double a[GK / 4]; double b[GT_MAX][GK / 4]; };
+  // k_feature writes a track's rows of B^ only inside the track's slot range [first, last] and at column n (Q_f^T r): a row's
+  // loads stay unconditional (whatever an older frame left outside the range), `ok` masks them when they are staged
+  struct Stage { double a[GK / 4]; double b[GT_MAX][GK / 4]; unsigned ok; };
   Stage r0, r1;
   auto fetch = [&](Stage& r, int kc) {
     const double* rows[GK / 4];
+    unsigned okm = 0;
 #pragma unroll
     for (int it = 0; it < GK / 4; ++it) {
       const int kk = min(kc + lr + 4 * it, KT - 1);
       const int p = kk / 3, q = kk - 3 * p;
-      const int t = sOrd[min(p, GORD - 1)];
+      const int e = sOrd[min(p, GORD - 1)];
+      const int t = e & 1023, c_lo = 6 * ((e >> 10) & 63), c_hi = 6 * ((e >> 16) & 63) + 6;
       rows[it] = d.trk_B + (((long)b * f_cap + t) * 3 + q) * (long)ldL;
+      const int ca = 64 * ti + lc;
+      okm |= ((ca >= c_lo && ca < c_hi) || ca == n) ? (1u << it) : 0u;
+#pragma unroll
+      for (int u = 0; u < GT_MAX; ++u) { const int cb = 64 * (tj0 + u) + lc; okm |= ((cb >= c_lo && cb < c_hi) || cb == n) ? (1u << (8 * (u + 1) + it)) : 0u; }
     }
+    r.ok = okm;
 #pragma unroll
     for (int it = 0; it < GK / 4; ++it) {
       r.a[it] = rows[it][64 * ti + lc];
@@ -173,10 +186,10 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int npairs, int 
 #pragma unroll
     for (int it = 0; it < GK / 4; ++it) {
       const bool ok = kc + lr + 4 * it < KT;
-      sA[lr + 4 * it][lc] = ok ? r.a[it] : 0.0;
+      sA[lr + 4 * it][lc] = (ok && ((r.ok >> it) & 1u)) ? r.a[it] : 0.0;
 #pragma unroll
       for (int u = 0; u < GT_MAX; ++u)
-        if (tj0 + u > ti && tj0 + u < nt) sB[u][lr + 4 * it][lc] = ok ? r.b[u][it] : 0.0;
+        if (tj0 + u > ti && tj0 + u < nt) sB[u][lr + 4 * it][lc] = (ok && ((r.ok >> (8 * (u + 1) + it)) & 1u)) ? r.b[u][it] : 0.0;
     }
   };
   v4d acc[GT_MAX][2][2];
@@ -276,7 +289,7 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int npairs, int 
 #ifdef MSCKF_ABLATE
   __builtin_amdgcn_s_waitcnt(0);
   GR_TICK(3);
-  if (threadIdx.x == 0 && blockIdx.y == 0) atomicAdd(&g_gram_cycles[bx & 7][4], 1ull);
+  if (threadIdx.x == 0 && bi == 0) atomicAdd(&g_gram_cycles[bx & 7][4], 1ull);
 #endif
 }
 
@@ -526,7 +539,7 @@ void launch_gram(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase) {
     // (MFMA-bound, <= 192 workgroups).  In ONE launch the dispatcher packs strips two to a CU behind the reduction
     // workgroups and they share the matrix cores (measured: MFMA phase 2x longer).
     if (!(g_dbg & 1)) hipLaunchKernelGGL(k_gram_diag<S>, dim3(ndiag, nb), dim3(256), 0, st, d, b0);
-    hipLaunchKernelGGL(k_gram<S>, dim3(npairs, nb), dim3(512), gram_lds_bytes(), st, d, b0, npairs, g_dbg, 0);
+    hipLaunchKernelGGL(k_gram<S>, dim3(xcd_grid(nb, npairs)), dim3(512), gram_lds_bytes(), st, d, b0, nb, npairs, g_dbg, 0);
   }
   if (phase == 1) return;
   // k_chol_blk (blocked, trailing update on the f64 matrix cores) is 10 % faster than k_chol_T in isolation (104 vs

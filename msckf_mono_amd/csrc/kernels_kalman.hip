@@ -415,6 +415,7 @@ __global__ __launch_bounds__(256) void k_chol_inv(Dev<S> d, int b0) {
   for (int k = 0; k < n; ++k) {
     const S dkk = L[(long)k * ldl + k];
     const S dd = dsqrt(dkk > S(0) ? dkk : Lim<S>::tiny());
+    if (!(dkk > S(0)) && tid == 0) atomicOr(&d.stats[(long)b * STAT_STRIDE + STAT_ERR], STAT_ERR_PIVOT);
     __syncthreads();
     const S dinv = S(1) / dd;
     for (int i = k + tid; i < n; i += 256) L[(long)k * ldl + i] = (i == k) ? dd : L[(long)k * ldl + i] * dinv;
@@ -501,6 +502,7 @@ __global__ __launch_bounds__(256) void k_gain(Dev<S> d, int b0) {
       __syncthreads();
       const S dkk = sCol[buf][k];
       const S dpos = dkk > S(0) ? dkk : Lim<S>::tiny();
+      if (!(dkk > S(0)) && tid == 0) atomicOr(&d.stats[(long)b * STAT_STRIDE + STAT_ERR], STAT_ERR_PIVOT);   // S not positive definite: reported, run continues
       const S dinv = fast_rsqrt(dpos);
       const S dd = dpos * dinv;
       S li[NBN], lj[NBN], wi[NBD];
@@ -643,6 +645,7 @@ __global__ __launch_bounds__(256) void k_gain_split(Dev<S> d, int b0) {
       __syncthreads();
       const S dkk = sCol[buf][k];
       const S dpos = dkk > S(0) ? dkk : Lim<S>::tiny();
+      if (!(dkk > S(0)) && tid == 0) atomicOr(&d.stats[(long)b * STAT_STRIDE + STAT_ERR], STAT_ERR_PIVOT);   // S not positive definite: reported, run continues
       const S dinv = fast_rsqrt(dpos);
       const S dd = dpos * dinv;
       S li[NBN], lj[NBN], wi[NBQ];
@@ -735,6 +738,7 @@ __global__ __launch_bounds__(256) void k_gain_w(Dev<S> d, int b0) {
       __syncthreads();
       const S dkk = sCol[buf][k];
       const S dpos = dkk > S(0) ? dkk : Lim<S>::tiny();
+      if (!(dkk > S(0)) && tid == 0) atomicOr(&d.stats[(long)b * STAT_STRIDE + STAT_ERR], STAT_ERR_PIVOT);   // S not positive definite: reported, run continues
       const S dinv = fast_rsqrt(dpos);
       const S dd = dpos * dinv;
       S li[NBN], lj[NBN], wi[NBW];

@@ -150,11 +150,11 @@ __global__ __launch_bounds__(64 * QR_NW) void k_qr_update(Dev<S> d, int b0, int 
         my_t = order[lo];
         my_row = 3 + (grl - rs[lo]);              // row of Q^T [H_x | r]
         const long tb = (long)b * f_cap + my_t;
-        kmin = 6 * d.trk_first[tb];
+        kmin = 6 * (d.trk_first[tb] & 255);
         const S* Vr = d.trk_V + (tb * 2 * m_cap + my_row) * 4;
         my_v0 = Vr[0]; my_v1 = Vr[1]; my_v2 = Vr[2];
         my_ro = d.trk_ro[tb * 2 * m_cap + my_row];
-        my_c0 = 6 * d.trk_slots[(long)(b - b0) * d.wl_stride_o + (long)my_t * m_cap + (my_row >> 1)];
+        my_c0 = 6 * d.trk_slots[wl_first(d, b - b0, my_t) + (my_row >> 1)];
       }
       kmin = wave_min_i(kmin);
       S zf[3][NC];                                   // Z of the current track at this lane's columns

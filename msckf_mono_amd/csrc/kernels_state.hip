@@ -107,7 +107,7 @@ void prop_cycles_read(unsigned long long* out8, int reset) {
 template <class S>
 __device__ __forceinline__ void augment_body(const Dev<S>& d, int b, int tid, S* sJP) {
   const int n = d.ncam[b];
-  if (n >= d.n_cap) { if (tid == 0) d.stats[(long)b * STAT_STRIDE + STAT_ERR] = 1; return; }
+  if (n >= d.n_cap) { if (tid == 0) atomicOr(&d.stats[(long)b * STAT_STRIDE + STAT_ERR], STAT_ERR_NCAP); return; }
   const int D = 15 + 6 * n, ld = d.ld;
   const S* imu = d.imu + (long)b * IMU_STRIDE;
   const S* prm = d.prm + (long)b * PRM_STRIDE;

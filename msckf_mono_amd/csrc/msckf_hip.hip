@@ -18,6 +18,9 @@
 
 #include "../../include/msckf_hip.h"
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include "dev_common.h"
 
@@ -83,6 +86,9 @@ struct BatchBase {
   virtual int scen_commit() = 0;
   virtual int run_frames(int f0, int f1) = 0;
   virtual int run_frames_streamed(int f0, int f1) = 0;
+  virtual int scen_pin(int f0, int f1) = 0;
+  virtual int set_upload_ring(int depth, int mode) = 0;
+  virtual int set_cu_reserve(int n) = 0;
   virtual int sync() = 0;
   virtual int prof_enable(int on) = 0;
   virtual int prof_read(double* ms, int* cnt) = 0;
@@ -95,6 +101,46 @@ struct BatchBase {
 };
 
 constexpr int NSTAGE = 8;
+
+// Persistent enqueue threads of a batch (one per slice of run_frames / run_frames_streamed): a K-frame window is a few
+// milliseconds, creating and joining three std::threads per call was 1-2 % of it.
+struct Workers {
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable cv, cv_done;
+  std::function<void(int)> job;
+  unsigned long gen = 0;
+  int active = 0, pending = 0;
+  bool stop = false;
+  void loop(int idx) {
+    unsigned long seen = 0;
+    for (;;) {
+      std::function<void(int)> f;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return stop || gen != seen; });
+        if (stop) return;
+        seen = gen;
+        if (idx >= active) continue;
+        f = job;
+      }
+      f(idx);
+      { std::lock_guard<std::mutex> lk(m); if (--pending == 0) cv_done.notify_all(); }
+    }
+  }
+  // run f(0) .. f(n - 1) on the worker threads (not on the caller); wait() returns when all have finished
+  void start(int n, std::function<void(int)> f) {
+    while ((int)th.size() < n) { const int idx = (int)th.size(); th.emplace_back([this, idx] { loop(idx); }); }
+    { std::lock_guard<std::mutex> lk(m); job = std::move(f); active = n; pending = n; ++gen; }
+    cv.notify_all();
+  }
+  void wait() { std::unique_lock<std::mutex> lk(m); cv_done.wait(lk, [&] { return pending == 0; }); }
+  ~Workers() {
+    { std::lock_guard<std::mutex> lk(m); stop = true; }
+    cv.notify_all();
+    for (auto& t : th) t.join();
+  }
+};
 
 template <class S>
 struct Batch : BatchBase {
@@ -119,16 +165,32 @@ struct Batch : BatchBase {
   S* d_rd = nullptr; int rd_cap = 0;               // [B][rd_cap][7]
   S* d_pfin = nullptr;                              // [B][f_cap][4] stored feature positions (mode 1)
   int* wl_n = nullptr; int* wl_M = nullptr; int* wl_slots = nullptr; S* wl_obs = nullptr;  // [B]...[B][f_cap][m_cap]
-  // scenario
+  // scenario.  Work-lists are COMPACT: a cell (frame, trajectory) holds sum M_j (slot, observation) entries, track t of the
+  // cell starts at off[cell][t] counted from the frame's first entry (Dev::trk_off) -- not [f_cap][m_cap] padded rows (1.9x
+  // the payload at cfg3's track lengths, on the host, in HBM and in every per-frame upload).
   int sc_frames = 0, sc_K = 0;
-  S* sc_rd = nullptr; int* sc_n = nullptr; int* sc_M = nullptr; int* sc_slots = nullptr; S* sc_obs = nullptr; int* sc_drop = nullptr;
-  std::vector<S> h_rd, h_obs; std::vector<int> h_n, h_M, h_slots, h_drop;
+  bool committed = false;
+  S* sc_rd = nullptr; int* sc_n = nullptr; int* sc_M = nullptr; int* sc_off = nullptr; int* sc_drop = nullptr;
+  int* sc_slots = nullptr; S* sc_obs = nullptr; size_t sc_total = 0;      // sum over all cells
+  std::vector<S> h_rd; std::vector<int> h_n, h_M, h_off, h_drop;
+  std::vector<std::vector<int>> c_slots; std::vector<std::vector<S>> c_obs;   // per cell
+  std::vector<size_t> fr_base;                                             // [frames + 1] first entry of a frame in sc_slots / sc_obs
   std::vector<void*> sc_allocs;
-  // streamed inputs: per-frame H2D from the (page-locked) host copy into two device staging sets on a copy stream
-  bool host_pinned = false;
-  hipStream_t stc = nullptr; hipEvent_t ev_up[2] = {nullptr, nullptr}; hipEvent_t ev_use[2][MAXS] = {{nullptr}};
-  unsigned char* h_pack = nullptr; unsigned char* sg_blk[2] = {nullptr, nullptr};   // one packed block per frame: [rd | n | M | slots | obs | drop]
-  size_t pk_rd = 0, pk_n = 0, pk_M = 0, pk_slots = 0, pk_obs = 0, pk_drop = 0, pk_bytes = 0;
+  // streamed inputs (run_frames_streamed): frame f's block [rd | n | drop | M | off | slots | obs] is copied from page-locked
+  // host memory into one of `ring` device staging sets on a copy stream, `ring` - 1 frames ahead of the kernels that read it.
+  // Page-locked blocks are built on demand (scen_pin, or the first streamed run over a frame), only for frames that are
+  // streamed: a run_frames-only user never pays for them.
+  static constexpr int RING_MAX = 8;
+  int ring = 6, up_mode = 0;   // up_mode 0: the host threads hand frames over (no device-side cross-stream wait); 1: hipStreamWaitEvent
+  hipStream_t stc = nullptr; hipEvent_t ev_up[RING_MAX] = {nullptr}; hipEvent_t ev_use[RING_MAX][MAXS] = {{nullptr}};
+  unsigned char* sg_blk[RING_MAX] = {nullptr}; size_t sg_bytes = 0;
+  struct PinFrame { unsigned char* p = nullptr; size_t bytes = 0, off_obs = 0; };
+  std::vector<PinFrame> pinf; std::vector<void*> pin_chunks;
+  size_t pk_rd = 0, pk_n = 0, pk_drop = 0, pk_M = 0, pk_off = 0, pk_slots = 0;   // section offsets (256-byte aligned); obs follows the frame's slots
+  // slices of the batch: enqueue threads, optional CU-reserved streams
+  Workers workers;
+  int cu_reserve = 0, mst_nh = 0, mst_reserve = 0; hipStream_t mst[MAXS] = {nullptr};
+  hipEvent_t ev_join0 = nullptr;
   // profiling
   bool prof = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool[NSTAGE];
@@ -153,6 +215,7 @@ struct Batch : BatchBase {
     for (int i = 1; i < MAXS; ++i) HIPCHK(hipStreamCreateWithFlags(&stx[i], hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     for (int i = 1; i < MAXS; ++i) HIPCHK(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ev_join0, hipEventDisableTiming));
     for (int i = 0; i < MAXS; ++i) {
       HIPCHK(hipStreamCreateWithFlags(&sty[i], hipStreamNonBlocking));
       HIPCHK(hipEventCreateWithFlags(&ev_fa[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_fb[i], hipEventDisableTiming));
@@ -162,7 +225,9 @@ struct Batch : BatchBase {
     d.n6cap = 6 * n_cap;
     d.ld = ((15 + 6 * n_cap + 15) / 16) * 16;
     d.ldR = ((6 * n_cap + 1 + 63) / 64) * 64;
-    if (d.ldR / 64 > 6) return fail(-EINVAL, "n_cap too large for the QR kernel (6*n_cap+1 must be <= 384)");
+    // 6 n_cap + 1 <= 384 (n_cap <= 63): the compression kernels' column capacity; it also bounds everything indexed by a state
+    // column or a camera slot further down (k_prune_gather's 1024-entry LDS row table: D <= 393; 6-bit slot fields of trk_first)
+    if (d.ldR / 64 > 6) return fail(-ENOTSUP, "n_cap too large: 6*n_cap+1 must be <= 384 (at most 63 camera states)");
     int nch = 1;
     while (nch < 8 && (long)B * nch * 2 <= 256) nch *= 2;    // TSQR route: chunks x trajectories ~ one workgroup per CU
     d.nchunk = nch;
@@ -211,8 +276,10 @@ struct Batch : BatchBase {
     if (ev_fork) hipEventDestroy(ev_fork);
     if (ev_stage) hipEventDestroy(ev_stage);
     unpin_host();
-    for (int k = 0; k < 2; ++k) { if (ev_up[k]) hipEventDestroy(ev_up[k]); for (int i = 0; i < MAXS; ++i) if (ev_use[k][i]) hipEventDestroy(ev_use[k][i]); }
+    for (int k = 0; k < RING_MAX; ++k) { if (ev_up[k]) hipEventDestroy(ev_up[k]); for (int i = 0; i < MAXS; ++i) if (ev_use[k][i]) hipEventDestroy(ev_use[k][i]); if (sg_blk[k]) hipFree(sg_blk[k]); }
     if (stc) hipStreamDestroy(stc);
+    for (int i = 0; i < MAXS; ++i) if (mst[i]) hipStreamDestroy(mst[i]);
+    if (ev_join0) hipEventDestroy(ev_join0);
     if (h_stage) hipHostFree(h_stage);
     if (st) hipStreamDestroy(st);
   }
@@ -231,7 +298,7 @@ struct Batch : BatchBase {
   }
   int stage_release() { HIPCHK(hipEventRecord(ev_stage, st)); stage_busy = true; return 0; }
   void use_single_worklists() {
-    d.trk_n = wl_n; d.trk_M = wl_M; d.trk_slots = wl_slots; d.trk_obs = wl_obs;
+    d.trk_n = wl_n; d.trk_M = wl_M; d.trk_slots = wl_slots; d.trk_obs = wl_obs; d.trk_off = nullptr;
     d.wl_stride_n = 1; d.wl_stride_f = f_cap; d.wl_stride_o = (long)f_cap * m_cap;
   }
   // Dev view whose work-list pointers start at trajectory b0 (kernels index work-lists by b - b0)
@@ -526,7 +593,11 @@ struct Batch : BatchBase {
     HIPCHK(hipMemcpyAsync(tmp, d.stats + (size_t)b * STAT_STRIDE, sizeof(tmp), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     for (int i = 0; i < 7; ++i) out[i] = tmp[i];
-    return tmp[STAT_ERR] ? fail(-EOVERFLOW, "camera-state capacity n_cap exceeded in augmentState") : 0;
+    if (tmp[STAT_ERR] & STAT_ERR_NCAP) return fail(-EOVERFLOW, "camera-state capacity n_cap exceeded in augmentState");
+    if (tmp[STAT_ERR] & STAT_ERR_PIVOT)
+      return fail(-EDOM, "non-positive pivot in the factorization of S = T_H P T_H^T + R_n: the covariance lost positive definiteness "
+                         "(msckf_hip_set_covariance_update(h, 1) selects the reference's Joseph form)");
+    return 0;
   }
   int track_info(int b, double* out, int cap) override {
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
@@ -565,33 +636,42 @@ struct Batch : BatchBase {
     return D;
   }
   // ---- scenario
-  int scen_alloc(int n_frames, int K) override {
-    if (n_frames <= 0 || K <= 0) return fail(-EINVAL, "bad scenario size");
-    HIPCHK(hipSetDevice(device));
-    HIPCHK(hipStreamSynchronize(st));
+  void free_scenario_device() {
     for (void* q : sc_allocs) {                                  // a previous scenario is replaced, not leaked
       hipFree(q);
       allocs.erase(std::remove(allocs.begin(), allocs.end(), q), allocs.end());
     }
     sc_allocs.clear();
-    sc_frames = 0;
+    sc_rd = nullptr; sc_n = sc_M = sc_off = sc_drop = sc_slots = nullptr; sc_obs = nullptr; sc_total = 0;
+  }
+  template <class T> int sc_dalloc(T** p, size_t count) {
+    const size_t mark = allocs.size();
+    const int rc = dalloc(p, count);
+    sc_allocs.insert(sc_allocs.end(), allocs.begin() + mark, allocs.end());
+    return rc;
+  }
+  int scen_alloc(int n_frames, int K) override {
+    if (n_frames <= 0 || K <= 0) return fail(-EINVAL, "bad scenario size");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamSynchronize(st));
+    free_scenario_device();
+    sc_frames = 0; committed = false;
     unpin_host();
     const size_t Bz = B, FB = (size_t)n_frames * Bz;
-    h_rd.assign(FB * K * RD_STRIDE, S(0)); h_n.assign(FB, 0); h_M.assign(FB * f_cap, 0);
-    h_slots.assign(FB * f_cap * m_cap, 0); h_obs.assign(FB * f_cap * m_cap * 2, S(0)); h_drop.assign(FB, 0); h_maxslot.assign(FB, -1);
-    const size_t mark = allocs.size();
+    h_rd.assign(FB * K * RD_STRIDE, S(0)); h_n.assign(FB, 0); h_M.assign(FB * f_cap, 0); h_off.assign(FB * f_cap, 0);
+    h_drop.assign(FB, 0); h_maxslot.assign(FB, -1);
+    c_slots.assign(FB, std::vector<int>()); c_obs.assign(FB, std::vector<S>());
+    fr_base.assign((size_t)n_frames + 1, 0);
+    pinf.assign((size_t)n_frames, PinFrame());
     int rc = 0;
-    rc |= dalloc(&sc_rd, h_rd.size()); rc |= dalloc(&sc_n, h_n.size()); rc |= dalloc(&sc_M, h_M.size());
-    rc |= dalloc(&sc_slots, h_slots.size()); rc |= dalloc(&sc_obs, h_obs.size()); rc |= dalloc(&sc_drop, h_drop.size());
-    {   // packed per-frame block of run_frames_streamed (sections 256-byte aligned) and its two device staging copies
-      auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-      pk_rd = 0; pk_n = al(pk_rd + Bz * K * RD_STRIDE * sizeof(S)); pk_M = al(pk_n + Bz * sizeof(int));
-      pk_slots = al(pk_M + Bz * f_cap * sizeof(int)); pk_obs = al(pk_slots + Bz * f_cap * m_cap * sizeof(int));
-      pk_drop = al(pk_obs + Bz * f_cap * m_cap * 2 * sizeof(S)); pk_bytes = al(pk_drop + Bz * sizeof(int));
-      for (int k = 0; k < 2; ++k) rc |= dalloc(&sg_blk[k], pk_bytes);
-    }
-    sc_allocs.assign(allocs.begin() + mark, allocs.end());
+    rc |= sc_dalloc(&sc_rd, h_rd.size()); rc |= sc_dalloc(&sc_n, h_n.size()); rc |= sc_dalloc(&sc_M, h_M.size());
+    rc |= sc_dalloc(&sc_off, h_off.size()); rc |= sc_dalloc(&sc_drop, h_drop.size());
     if (rc) return rc;
+    {   // fixed sections of a streamed frame block; the frame's slots start at pk_slots, its observations follow them
+      auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+      pk_rd = 0; pk_n = al(pk_rd + Bz * K * RD_STRIDE * sizeof(S)); pk_drop = al(pk_n + Bz * sizeof(int));
+      pk_M = al(pk_drop + Bz * sizeof(int)); pk_off = al(pk_M + Bz * f_cap * sizeof(int)); pk_slots = al(pk_off + Bz * f_cap * sizeof(int));
+    }
     sc_frames = n_frames; sc_K = K;
     return 0;
   }
@@ -600,66 +680,203 @@ struct Batch : BatchBase {
     if (F < 0 || F > f_cap) return fail(-E2BIG, "more tracks than f_cap");
     if (n_drop < 0) return fail(-EINVAL, "negative n_drop");
     const size_t cell = (size_t)f * B + b;
+    size_t tot = 0;
     {   // validate before touching the staged cell (same rules as set_tracks)
-      size_t o = 0;
       for (int t = 0; t < F; ++t) {
         if (M[t] > m_cap || M[t] < 0) return fail(-E2BIG, "track longer than m_cap");
-        for (int k = 0; k < M[t]; ++k) if (slots[o + k] < 0 || slots[o + k] >= n_cap) return fail(-EINVAL, "camera slot out of range");
-        o += M[t];
+        for (int k = 0; k < M[t]; ++k) if (slots[tot + k] < 0 || slots[tot + k] >= n_cap) return fail(-EINVAL, "camera slot out of range");
+        tot += M[t];
       }
     }
     for (int k = 0; k < sc_K; ++k) for (int c = 0; c < RD_STRIDE; ++c) h_rd[(cell * sc_K + k) * RD_STRIDE + c] = (S)rd[k * RD_STRIDE + c];
     h_n[cell] = F; h_drop[cell] = n_drop;
-    { int mx = -1; size_t oo = 0; for (int t = 0; t < F; ++t) { for (int k = 0; k < M[t]; ++k) mx = std::max(mx, slots[oo + k]); oo += M[t]; } h_maxslot[cell] = mx; }
-    size_t o = 0;
-    for (int t = 0; t < f_cap; ++t) {
-      const int Mt = t < F ? M[t] : 0;
-      h_M[cell * f_cap + t] = Mt;
-      for (int k = 0; k < m_cap; ++k) {
-        const bool in = k < Mt;
-        h_slots[(cell * f_cap + t) * m_cap + k] = in ? slots[o + k] : 0;
-        h_obs[((cell * f_cap + t) * m_cap + k) * 2] = in ? (S)obs[2 * (o + k)] : S(0);
-        h_obs[((cell * f_cap + t) * m_cap + k) * 2 + 1] = in ? (S)obs[2 * (o + k) + 1] : S(0);
-      }
-      o += Mt;
-    }
+    for (int t = 0; t < f_cap; ++t) h_M[cell * f_cap + t] = t < F ? M[t] : 0;
+    c_slots[cell].assign(slots, slots + tot);
+    c_obs[cell].resize(2 * tot);
+    int mx = -1;
+    for (size_t e = 0; e < tot; ++e) { mx = std::max(mx, slots[e]); c_obs[cell][2 * e] = (S)obs[2 * e]; c_obs[cell][2 * e + 1] = (S)obs[2 * e + 1]; }
+    h_maxslot[cell] = mx;
+    committed = false;               // offsets move: the resident copy and the frame's page-locked block are stale until the next commit
+    pinf[f] = PinFrame();
     return 0;
   }
   // H2D of everything staged.  The host copy is kept, so cells may be patched with scenario_set and committed again.
   int scen_commit() override {
     if (sc_frames <= 0) return fail(-EINVAL, "no scenario allocated");
     HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamSynchronize(st));
+    const size_t Bz = B;
+    size_t total = 0;
+    for (int f = 0; f < sc_frames; ++f) {
+      fr_base[f] = total;
+      size_t in_frame = 0;
+      for (size_t b = 0; b < Bz; ++b) {
+        const size_t cell = (size_t)f * Bz + b;
+        size_t o = in_frame;
+        for (int t = 0; t < f_cap; ++t) { h_off[cell * f_cap + t] = (int)o; o += h_M[cell * f_cap + t]; }
+        in_frame += c_slots[cell].size();
+      }
+      if (in_frame > 0x7fffffffu) return fail(-E2BIG, "a frame's work-lists exceed 2^31 observations");
+      total += in_frame;
+    }
+    fr_base[sc_frames] = total;
+    if (total != sc_total || !sc_slots) {          // patched cells may have changed the compact size
+      for (void* q : {(void*)sc_slots, (void*)sc_obs})
+        if (q) { hipFree(q); allocs.erase(std::remove(allocs.begin(), allocs.end(), q), allocs.end()); sc_allocs.erase(std::remove(sc_allocs.begin(), sc_allocs.end(), q), sc_allocs.end()); }
+      sc_slots = nullptr; sc_obs = nullptr;
+      int rc = sc_dalloc(&sc_slots, total); rc |= sc_dalloc(&sc_obs, 2 * total);
+      if (rc) return rc;
+      sc_total = total;
+    }
     HIPCHK(hipMemcpyAsync(sc_rd, h_rd.data(), h_rd.size() * sizeof(S), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(sc_n, h_n.data(), h_n.size() * sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(sc_M, h_M.data(), h_M.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(sc_slots, h_slots.data(), h_slots.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(sc_obs, h_obs.data(), h_obs.size() * sizeof(S), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(sc_off, h_off.data(), h_off.size() * sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(sc_drop, h_drop.data(), h_drop.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    {   // size the pinned staging area once, for the largest frame
+      size_t mx = 0;
+      for (int f = 0; f < sc_frames; ++f) mx = std::max(mx, fr_base[f + 1] - fr_base[f]);
+      unsigned char* raw = nullptr;
+      int rc = stage_acquire(mx * (sizeof(int) + 2 * sizeof(S)), &raw);
+      if (rc) return rc;
+    }
+    for (int f = 0; f < sc_frames; ++f) {            // one frame at a time through the pinned staging area (bounded host memory)
+      const size_t nf = fr_base[f + 1] - fr_base[f];
+      if (!nf) continue;
+      unsigned char* raw = nullptr;
+      int rc = stage_acquire(nf * (sizeof(int) + 2 * sizeof(S)), &raw);
+      if (rc) return rc;
+      int* hs = reinterpret_cast<int*>(raw); S* ho = reinterpret_cast<S*>(raw + nf * sizeof(int));
+      size_t o = 0;
+      for (size_t b = 0; b < Bz; ++b) {
+        const size_t cell = (size_t)f * Bz + b, n = c_slots[cell].size();
+        if (n) { std::memcpy(hs + o, c_slots[cell].data(), n * sizeof(int)); std::memcpy(ho + 2 * o, c_obs[cell].data(), 2 * n * sizeof(S)); }
+        o += n;
+      }
+      HIPCHK(hipMemcpyAsync(sc_slots + fr_base[f], hs, nf * sizeof(int), hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(sc_obs + 2 * fr_base[f], ho, 2 * nf * sizeof(S), hipMemcpyHostToDevice, st));
+      rc = stage_release();
+      if (rc) return rc;
+    }
     HIPCHK(hipStreamSynchronize(st));
-    // page-locked, per-frame packed copy of the scenario for run_frames_streamed: ONE asynchronous H2D per frame
-    unpin_host();
-    HIPCHK(hipHostMalloc((void**)&h_pack, pk_bytes * (size_t)sc_frames, hipHostMallocDefault));
-    {
-      const size_t Bz = B;
-      for (int f = 0; f < sc_frames; ++f) {
-        unsigned char* blk = h_pack + (size_t)f * pk_bytes;
+    committed = true;
+    return 0;
+  }
+  // page-locked per-frame blocks for run_frames_streamed, frames [f0, f1) that do not have one yet; also sizes the device
+  // staging ring.  Called by run_frames_streamed itself; call it beforehand to keep the pinning out of a timed region.
+  int scen_pin(int f0, int f1) override {
+    if (f0 < 0 || f1 > sc_frames || f0 > f1) return fail(-EINVAL, "frame range out of bounds");
+    if (!committed) return fail(-EINVAL, "scenario not committed");
+    HIPCHK(hipSetDevice(device));
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t Bz = B;
+    size_t need = 0, maxb = sg_bytes;
+    std::vector<int> todo;
+    for (int f = f0; f < f1; ++f) {
+      const size_t nf = fr_base[f + 1] - fr_base[f];
+      const size_t off_obs = al(pk_slots + nf * sizeof(int)), bytes = al(off_obs + 2 * nf * sizeof(S));
+      maxb = std::max(maxb, bytes);
+      if (pinf[f].p) continue;
+      pinf[f].bytes = bytes; pinf[f].off_obs = off_obs;
+      need += bytes; todo.push_back(f);
+    }
+    if (!todo.empty()) {
+      unsigned char* chunk = nullptr;
+      if (hipHostMalloc((void**)&chunk, need, hipHostMallocDefault) != hipSuccess) {
+        for (int f : todo) pinf[f] = PinFrame();
+        return fail(-ENOMEM, "could not page-lock the frames to stream (run_frames on the resident scenario is unaffected)");
+      }
+      pin_chunks.push_back(chunk);
+      size_t o = 0;
+      for (int f : todo) {
+        unsigned char* blk = chunk + o;
         const size_t c0 = (size_t)f * Bz;
         std::memcpy(blk + pk_rd, h_rd.data() + c0 * sc_K * RD_STRIDE, Bz * sc_K * RD_STRIDE * sizeof(S));
         std::memcpy(blk + pk_n, h_n.data() + c0, Bz * sizeof(int));
-        std::memcpy(blk + pk_M, h_M.data() + c0 * f_cap, Bz * f_cap * sizeof(int));
-        std::memcpy(blk + pk_slots, h_slots.data() + c0 * f_cap * m_cap, Bz * f_cap * m_cap * sizeof(int));
-        std::memcpy(blk + pk_obs, h_obs.data() + c0 * f_cap * m_cap * 2, Bz * f_cap * m_cap * 2 * sizeof(S));
         std::memcpy(blk + pk_drop, h_drop.data() + c0, Bz * sizeof(int));
+        std::memcpy(blk + pk_M, h_M.data() + c0 * f_cap, Bz * f_cap * sizeof(int));
+        std::memcpy(blk + pk_off, h_off.data() + c0 * f_cap, Bz * f_cap * sizeof(int));
+        int* hs = reinterpret_cast<int*>(blk + pk_slots); S* ho = reinterpret_cast<S*>(blk + pinf[f].off_obs);
+        size_t e = 0;
+        for (size_t b = 0; b < Bz; ++b) {
+          const size_t cell = c0 + b, n = c_slots[cell].size();
+          if (n) { std::memcpy(hs + e, c_slots[cell].data(), n * sizeof(int)); std::memcpy(ho + 2 * e, c_obs[cell].data(), 2 * n * sizeof(S)); }
+          e += n;
+        }
+        pinf[f].p = blk;
+        o += pinf[f].bytes;
       }
     }
-    host_pinned = true;
+    if (maxb > sg_bytes || !sg_blk[0]) {
+      HIPCHK(hipStreamSynchronize(st));
+      if (stc) HIPCHK(hipStreamSynchronize(stc));
+      for (int k = 0; k < RING_MAX; ++k) { if (sg_blk[k]) hipFree(sg_blk[k]); sg_blk[k] = nullptr; }
+      for (int k = 0; k < RING_MAX; ++k) HIPCHK(hipMalloc((void**)&sg_blk[k], maxb));
+      sg_bytes = maxb;
+    }
     return 0;
   }
   int run_frames(int f0, int f1) override;
   int run_frames_streamed(int f0, int f1) override;
   void unpin_host() {
-    if (h_pack) hipHostFree(h_pack);
-    h_pack = nullptr; host_pinned = false;
+    for (void* q : pin_chunks) hipHostFree(q);
+    pin_chunks.clear();
+    for (auto& pf : pinf) pf = PinFrame();
+  }
+  int set_upload_ring(int depth, int mode) override {
+    if (depth < 2 || depth > RING_MAX || mode < 0 || mode > 1) return fail(-EINVAL, "ring depth 2..8; mode 0 host hand-over, 1 device-side event waits");
+    ring = depth; up_mode = mode;
+    return 0;
+  }
+  // Reserve n compute units per slice for that slice alone (0 = off).  The slices' streams are then created with CU masks
+  // (hipExtStreamCreateWithCUMask): slice i may run anywhere EXCEPT on the reserved units of the other slices.  The
+  // one-workgroup-per-trajectory kernels of a slice (blocked Choleskys, propagate, select, prune: 1024-thread workgroups that
+  // need a whole CU's registers) then always find free units, however many k_feature wavefronts of another slice are resident.
+  int set_cu_reserve(int n) override {
+    if (n < 0 || n > 64) return fail(-EINVAL, "0 .. 64 compute units per slice");
+    cu_reserve = (n + 7) / 8 * 8;          // mask bits interleave over the 8 XCDs: whole multiples keep every XCD equally wide
+    return 0;
+  }
+  int ensure_masked_streams(int nh) {
+    if (mst_nh == nh && mst_reserve == cu_reserve && mst[0]) return 0;
+    for (int i = 0; i < MAXS; ++i) if (mst[i]) { HIPCHK(hipStreamSynchronize(mst[i])); HIPCHK(hipStreamDestroy(mst[i])); mst[i] = nullptr; }
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    const int ncu = prop.multiProcessorCount, nw = (ncu + 31) / 32;
+    if ((long)cu_reserve * nh > ncu / 2) return fail(-EINVAL, "reserved compute units exceed half the device");
+    for (int i = 0; i < nh; ++i) {
+      std::vector<uint32_t> mask(nw, 0u);
+      for (int c = 0; c < ncu; ++c) {
+        const int owner = c / cu_reserve;                                      // slice that owns reserved unit c (>= nh: nobody)
+        if (owner >= nh || owner == i) mask[c >> 5] |= 1u << (c & 31);
+      }
+      HIPCHK(hipExtStreamCreateWithCUMask(&mst[i], (uint32_t)nw, mask.data()));
+    }
+    mst_nh = nh; mst_reserve = cu_reserve;
+    return 0;
+  }
+  // streams of the nh slices of a run: the handle's own streams, or the CU-masked ones
+  int slice_streams(int nh, hipStream_t* qs) {
+    if (cu_reserve > 0 && nh > 1) {
+      int rc = ensure_masked_streams(nh);
+      if (rc) return rc;
+      for (int i = 0; i < nh; ++i) qs[i] = mst[i];
+    } else for (int i = 0; i < nh; ++i) qs[i] = stx[i];
+    return 0;
+  }
+  int fork_slices(int nh, hipStream_t* qs, hipStream_t extra = nullptr) {
+    bool any = extra != nullptr;
+    for (int i = 0; i < nh; ++i) any = any || qs[i] != st;
+    if (!any) return 0;
+    HIPCHK(hipEventRecord(ev_fork, st));
+    for (int i = 0; i < nh; ++i) if (qs[i] != st) HIPCHK(hipStreamWaitEvent(qs[i], ev_fork, 0));
+    if (extra) HIPCHK(hipStreamWaitEvent(extra, ev_fork, 0));
+    return 0;
+  }
+  int join_slices(int nh, hipStream_t* qs) {
+    for (int i = 0; i < nh; ++i)
+      if (qs[i] != st) { hipEvent_t e = i == 0 ? ev_join0 : ev_join[i]; HIPCHK(hipEventRecord(e, qs[i])); HIPCHK(hipStreamWaitEvent(st, e, 0)); }
+    return 0;
   }
   int sync() override {
     HIPCHK(hipSetDevice(device));
@@ -718,27 +935,32 @@ int Batch<S>::drop_oldest(int b0, int nb, int n) {
 template <class S>
 int Batch<S>::run_frames(int f0, int f1) {
   if (f0 < 0 || f1 > sc_frames || f0 > f1) return fail(-EINVAL, "frame range out of bounds");
+  if (!committed) return fail(-EINVAL, "scenario not committed");
   HIPCHK(hipSetDevice(device));
   // Trajectories are independent, so the batch may be cut into slices that run the same kernel sequence on
   // separate streams: the latency-bound stages of one slice (gain solve, Cholesky, propagate: one workgroup per
   // trajectory) overlap with the chip-filling stages of the others.  Stage profiling forces a single stream.
   const int nh = prof ? 1 : std::max(1, std::min(nstreams, B));
-  if (nh > 1) { HIPCHK(hipEventRecord(ev_fork, st)); for (int i = 1; i < nh; ++i) HIPCHK(hipStreamWaitEvent(stx[i], ev_fork, 0)); }
-  // one host thread per slice enqueues that slice's kernels for all frames: ~25 launches per frame and slice would
+  hipStream_t qs[MAXS];
+  int rc = slice_streams(nh, qs);
+  if (rc) return rc;
+  rc = fork_slices(nh, qs);
+  if (rc) return rc;
+  // one host thread per slice enqueues that slice's kernels for all frames: ~13 launches per frame and slice would
   // otherwise serialise on one thread and make more than two slices launch-bound
   int slice_rc[MAXS] = {0};
   auto enqueue = [&](int hh) {
     (void)hipSetDevice(device);
     (void)hipGetLastError();
-    hipStream_t q = stx[hh];
+    hipStream_t q = qs[hh];
     const int b0 = (int)((long)B * hh / nh);
     const int nb = (int)((long)B * (hh + 1) / nh) - b0;
     for (int f = f0; f < f1; ++f) {
       const size_t cell0 = (size_t)f * B;
       Dev<S> v = d;
-      v.trk_n = sc_n + cell0 + b0; v.trk_M = sc_M + (cell0 + b0) * f_cap; v.trk_slots = sc_slots + (cell0 + b0) * f_cap * m_cap;
-      v.trk_obs = sc_obs + (cell0 + b0) * f_cap * m_cap * 2;
-      v.wl_stride_n = 1; v.wl_stride_f = f_cap; v.wl_stride_o = (long)f_cap * m_cap;
+      v.trk_n = sc_n + cell0 + b0; v.trk_M = sc_M + (cell0 + b0) * f_cap; v.trk_off = sc_off + (cell0 + b0) * f_cap;
+      v.trk_slots = sc_slots + fr_base[f]; v.trk_obs = sc_obs + 2 * fr_base[f];
+      v.wl_stride_n = 1; v.wl_stride_f = f_cap; v.wl_stride_o = 0;
       // k_feature reads only what the previous frame's prune left behind -- camera states and P blocks of slots below the
       // newest one, the constant gravity vector -- unless a track observes the camera this frame's augmentState adds.
       // When none does (host mirror of the window sizes, slots known since scenario_set) it runs on a side stream
@@ -775,41 +997,52 @@ int Batch<S>::run_frames(int f0, int f1) {
   };
   if (nh == 1) enqueue(0);
   else {
-    std::vector<std::thread> th;
-    for (int hh = 1; hh < nh; ++hh) th.emplace_back(enqueue, hh);
+    workers.start(nh - 1, [&](int idx) { enqueue(idx + 1); });
     enqueue(0);
-    for (auto& t : th) t.join();
+    workers.wait();
   }
-  for (int i = 1; i < nh; ++i) { HIPCHK(hipEventRecord(ev_join[i], stx[i])); HIPCHK(hipStreamWaitEvent(st, ev_join[i], 0)); }
+  rc = join_slices(nh, qs);
+  if (rc) return rc;
   for (int i = 0; i < nh; ++i)
     if (slice_rc[i]) return fail(-EIO, std::string("kernel launch failed on slice ") + std::to_string(i) + ": " + hipGetErrorString((hipError_t)slice_rc[i]));
   return 0;
 }
 
 // run_frames with the inputs handed over per frame, as the reference's callers do (asl_msckf.cpp:227-284: IMU samples and
-// the image's tracks arrive with the image): the IMU samples and the work-list of frame f are copied from the page-locked
-// host scenario into one of two device staging sets on a copy stream while frame f-1 computes; the slices' kernels wait for
-// the upload event of their frame, the upload of frame f+2 waits until every slice has consumed the set.
+// the image's tracks arrive with the image): frame f's block -- IMU samples + compact work-list, what the frame really
+// holds, not a padded maximum -- goes from page-locked host memory into staging set f % ring on a copy stream, up to
+// ring - 1 frames ahead of the kernels that consume it.  Hand-over (up_mode 0): the uploading thread waits for its copy on
+// the HOST and publishes the frame number; a slice's enqueue thread launches frame f only after that, and the uploader
+// reuses a set only after every slice's "consumed" event of frame f - ring has completed -- no stream ever waits for
+// another stream's event on the device (those waits cost 0.15-0.25 ms per frame with two staging sets).  up_mode 1 keeps
+// the device-side hipStreamWaitEvent protocol, for comparison.
 template <class S>
 int Batch<S>::run_frames_streamed(int f0, int f1) {
   if (f0 < 0 || f1 > sc_frames || f0 > f1) return fail(-EINVAL, "frame range out of bounds");
-  if (!host_pinned) return fail(-EINVAL, "scenario not committed");
+  if (!committed) return fail(-EINVAL, "scenario not committed");
   HIPCHK(hipSetDevice(device));
+  {
+    bool all = sg_blk[0] != nullptr;
+    for (int f = f0; f < f1 && all; ++f) all = pinf[f].p != nullptr;
+    if (!all) { int rc = scen_pin(f0, f1); if (rc) return rc; }
+  }
   if (!stc) {
     HIPCHK(hipStreamCreateWithFlags(&stc, hipStreamNonBlocking));
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < RING_MAX; ++k) {
       HIPCHK(hipEventCreateWithFlags(&ev_up[k], hipEventDisableTiming));
       for (int i = 0; i < MAXS; ++i) HIPCHK(hipEventCreateWithFlags(&ev_use[k][i], hipEventDisableTiming));
     }
   }
   const int nh = prof ? 1 : std::max(1, std::min(nstreams, B));
-  HIPCHK(hipEventRecord(ev_fork, st));
-  HIPCHK(hipStreamWaitEvent(stc, ev_fork, 0));
-  for (int i = 1; i < nh; ++i) HIPCHK(hipStreamWaitEvent(stx[i], ev_fork, 0));
-  // One host thread per slice enqueues that slice's kernels (as run_frames does); this thread enqueues the uploads.  An
-  // event must be RECORDED (enqueued) before a wait on it is enqueued, so the threads hand frame numbers over through
-  // atomics: up_enq = frames whose upload + record are enqueued, use_enq[s] = frames whose consumption record is enqueued.
-  std::atomic<int> up_enq{f0};
+  const int R = ring, mode = up_mode;
+  hipStream_t qs[MAXS];
+  int rc = slice_streams(nh, qs);
+  if (rc) return rc;
+  rc = fork_slices(nh, qs, stc);
+  if (rc) return rc;
+  // up_rdy = frames whose block may be read (mode 0: the copy has completed; mode 1: copy + event record are enqueued --
+  // an event must be recorded before a wait on it is enqueued); use_enq[s] = frames whose "consumed" record is enqueued.
+  std::atomic<int> up_rdy{f0};
   std::atomic<int> use_enq[MAXS];
   for (int i = 0; i < MAXS; ++i) use_enq[i].store(f0);
   std::atomic<int> failed{0};
@@ -817,20 +1050,20 @@ int Batch<S>::run_frames_streamed(int f0, int f1) {
   auto slice = [&](int hh) {
     (void)hipSetDevice(device);
     (void)hipGetLastError();
-    hipStream_t q = stx[hh];
+    hipStream_t q = qs[hh];
     const int b0 = (int)((long)B * hh / nh);
     const int nb = (int)((long)B * (hh + 1) / nh) - b0;
     for (int f = f0; f < f1; ++f) {
-      while (up_enq.load(std::memory_order_acquire) <= f && !failed.load()) std::this_thread::yield();
+      while (up_rdy.load(std::memory_order_acquire) <= f && !failed.load()) std::this_thread::yield();
       if (failed.load()) break;
-      const int k = (f - f0) & 1;
+      const int k = (f - f0) % R;
       unsigned char* blk = sg_blk[k];
-      (void)hipStreamWaitEvent(q, ev_up[k], 0);
+      if (mode == 1) (void)hipStreamWaitEvent(q, ev_up[k], 0);
       Dev<S> v = d;
       v.trk_n = reinterpret_cast<int*>(blk + pk_n) + b0; v.trk_M = reinterpret_cast<int*>(blk + pk_M) + (size_t)b0 * f_cap;
-      v.trk_slots = reinterpret_cast<int*>(blk + pk_slots) + (size_t)b0 * f_cap * m_cap;
-      v.trk_obs = reinterpret_cast<S*>(blk + pk_obs) + (size_t)b0 * f_cap * m_cap * 2;
-      v.wl_stride_n = 1; v.wl_stride_f = f_cap; v.wl_stride_o = (long)f_cap * m_cap;
+      v.trk_off = reinterpret_cast<int*>(blk + pk_off) + (size_t)b0 * f_cap;
+      v.trk_slots = reinterpret_cast<int*>(blk + pk_slots); v.trk_obs = reinterpret_cast<S*>(blk + pinf[f].off_obs);
+      v.wl_stride_n = 1; v.wl_stride_f = f_cap; v.wl_stride_o = 0;
       stage_begin(0, q); launch_propagate<S>(v, b0, nb, reinterpret_cast<S*>(blk + pk_rd) + (size_t)b0 * sc_K * RD_STRIDE, (long)sc_K * RD_STRIDE, sc_K, q, !prof); stage_end(0, q);
       if (prof) { stage_begin(1, q); launch_augment<S>(v, b0, nb, q); stage_end(1, q); }
       launch_update(v, b0, nb, q);
@@ -846,25 +1079,26 @@ int Batch<S>::run_frames_streamed(int f0, int f1) {
     }
     slice_rc[hh] = (int)hipGetLastError();
   };
-  std::vector<std::thread> th;
-  for (int hh = 0; hh < nh; ++hh) th.emplace_back(slice, hh);
+  workers.start(nh, slice);
   int rc_up = 0;
   for (int f = f0; f < f1 && !rc_up; ++f) {
-    const int k = (f - f0) & 1;
-    if (f - f0 >= 2)
-      for (int i = 0; i < nh; ++i) {   // the set is free again once every slice has consumed frame f-2
-        while (use_enq[i].load(std::memory_order_acquire) <= f - 2) std::this_thread::yield();
-        if (hipStreamWaitEvent(stc, ev_use[k][i], 0) != hipSuccess) rc_up = -EIO;
+    const int k = (f - f0) % R;
+    if (f - f0 >= R)
+      for (int i = 0; i < nh && !rc_up; ++i) {   // the set is free again once every slice has consumed frame f - R
+        while (use_enq[i].load(std::memory_order_acquire) <= f - R) std::this_thread::yield();
+        const hipError_t e = mode == 0 ? hipEventSynchronize(ev_use[k][i]) : hipStreamWaitEvent(stc, ev_use[k][i], 0);
+        if (e != hipSuccess) rc_up = -EIO;
       }
-    if (hipMemcpyAsync(sg_blk[k], h_pack + (size_t)f * pk_bytes, pk_bytes, hipMemcpyHostToDevice, stc) != hipSuccess) rc_up = -EIO;
-    if (hipEventRecord(ev_up[k], stc) != hipSuccess) rc_up = -EIO;
+    if (!rc_up && hipMemcpyAsync(sg_blk[k], pinf[f].p, pinf[f].bytes, hipMemcpyHostToDevice, stc) != hipSuccess) rc_up = -EIO;
+    if (!rc_up && (mode == 0 ? hipStreamSynchronize(stc) : hipEventRecord(ev_up[k], stc)) != hipSuccess) rc_up = -EIO;
     if (rc_up) failed.store(1);
-    up_enq.store(f + 1, std::memory_order_release);
+    up_rdy.store(f + 1, std::memory_order_release);
   }
   if (rc_up) failed.store(1);
-  for (auto& t : th) t.join();
+  workers.wait();
   if (rc_up) return fail(rc_up, "input upload failed");
-  for (int i = 1; i < nh; ++i) { HIPCHK(hipEventRecord(ev_join[i], stx[i])); HIPCHK(hipStreamWaitEvent(st, ev_join[i], 0)); }
+  rc = join_slices(nh, qs);
+  if (rc) return rc;
   HIPCHK(hipEventRecord(ev_join[1], stc)); HIPCHK(hipStreamWaitEvent(st, ev_join[1], 0));
   for (int i = 0; i < nh; ++i)
     if (slice_rc[i]) return fail(-EIO, std::string("kernel launch failed on slice ") + std::to_string(i) + ": " + hipGetErrorString((hipError_t)slice_rc[i]));
@@ -1328,6 +1562,9 @@ int msckf_hip_sync(msckf_hip_handle h) { return H(h)->sync(); }
 int msckf_hip_profile_enable(msckf_hip_handle h, int on) { return H(h)->prof_enable(on); }
 int msckf_hip_profile_read(msckf_hip_handle h, double* ms7, int* count7) { return H(h)->prof_read(ms7, count7); }
 int msckf_hip_set_streams(msckf_hip_handle h, int n) { return H(h)->set_streams(n); }
+int msckf_hip_scenario_pin(msckf_hip_handle h, int f0, int f1) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->scen_pin(f0, f1); }
+int msckf_hip_set_upload_ring(msckf_hip_handle h, int depth, int mode) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_upload_ring(depth, mode); }
+int msckf_hip_set_cu_reserve(msckf_hip_handle h, int n) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_cu_reserve(n); }
 int msckf_hip_set_feature_overlap(msckf_hip_handle h, int on) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_feature_overlap(on); }
 int msckf_hip_set_covariance_update(msckf_hip_handle h, int form) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_cov_update(form); }
 int msckf_hip_set_compression(msckf_hip_handle h, int route) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_compression(route); }

@@ -1,12 +1,11 @@
 # Collect the round's evidence on the GPU box (run through gpurun from the repo root):
-#   GPU test-suite, bench.py JSON, rocprofv3 kernel trace of bench.py (single stream), three PMC passes.
-# Outputs land in gpurun_out/$TAG; the summaries to be judged are then copied into profiles/ by hand.
-TAG=${TAG:-r02}
+#   bench.py JSON, rocprofv3 kernel trace of bench.py (single stream, resident inputs), PMC passes (traffic, instruction mix,
+#   issue / wait breakdown).  Outputs land in gpurun_out/$TAG; the summaries to be judged are then copied into profiles/ by hand.
+TAG=${TAG:-r03}
 OUT=/root/repo/gpurun_out/$TAG
 set -x
 mkdir -p $OUT
-python -m pytest tests -m gpu -q 2>&1 | tail -3 > $OUT/pytest_tail.txt
-python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; tail -c 600 $OUT/bench.json
+export PMC_TAG=$TAG PMC_COMMIT=${PMC_COMMIT:-unknown}
 cd /tmp && export TMPDIR=/tmp
 COMMON="--steps 10 --warmup 3 --no-cpu-baseline --no-early-accept-pass --no-upload-pass --repeats 1 --streams 1"
 rocprofv3 --kernel-trace --stats -d /tmp/p1 -o r -- python /root/repo/bench.py $COMMON > /tmp/b1.log 2>&1
@@ -15,7 +14,9 @@ ROCPD_TAIL=20 python /root/repo/scripts/rocpd_summary.py $DB $OUT/kernel_stats_t
 python /root/repo/scripts/rocpd_summary.py $DB $OUT/kernel_stats_all.md > /dev/null
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p2 -o r -- python /root/repo/bench.py $COMMON > /tmp/b2.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p3 -o r -- python /root/repo/bench.py $COMMON > /tmp/b3.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace -d /tmp/p4 -o r -- python /root/repo/bench.py $COMMON > /tmp/b4.log 2>&1
-tail -2 /tmp/b4.log | cut -c1-300
-python /root/repo/scripts/rocpd_pmc.py $OUT/pmc.md $(find /tmp/p2 /tmp/p3 /tmp/p4 -name "*.db") > /dev/null
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD --kernel-trace -d /tmp/p4 -o r -- python /root/repo/bench.py $COMMON > /tmp/b4.log 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_ACTIVE_INST_LDS --kernel-trace -d /tmp/p5 -o r -- python /root/repo/bench.py $COMMON > /tmp/b5.log 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE --kernel-trace -d /tmp/p6 -o r -- python /root/repo/bench.py $COMMON > /tmp/b6.log 2>&1
+tail -2 /tmp/b5.log | cut -c1-300
+python /root/repo/scripts/rocpd_pmc.py $OUT/pmc.md $(find /tmp/p2 /tmp/p3 /tmp/p4 /tmp/p5 /tmp/p6 -name "*.db") > /dev/null
 ls -la $OUT

@@ -46,10 +46,15 @@ def main():
             tr[key] = dict(kernel=k, fetch_kib=f, write_kib=w, bytes_per_launch=(2 * f + w) * 1024,
                            note="FETCH_SIZE doubled (gfx950 under-reports wide coalesced reads by 2x); WRITE_SIZE uncalibrated")
             ex = {c: res[(k, c)] for c in ("SQ_INSTS_VALU", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_VALU_MFMA_MOPS_F64",
-                                           "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES") if (k, c) in res}
+                                           "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY",
+                                           "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAVES", "SQ_ACTIVE_INST_LDS",
+                                           "SQ_ACTIVE_INST_VMEM", "SQ_WAIT_INST_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SALU") if (k, c) in res}
             if ex:   # executed work per launch (wave-level instruction counts summed over the chip), for roofline.executed
                 tr[key]["executed"] = ex
     if tr:
+        # provenance: which profile round and which commit the passes ran on (bench.py prints it beside the numbers)
+        tr["_meta"] = dict(tag=os.environ.get("PMC_TAG", ""), commit=os.environ.get("PMC_COMMIT", ""),
+                           command="bench.py --steps 10 --warmup 3 --no-upload-pass --streams 1 under rocprofv3 --pmc (one pass per counter set)")
         json.dump(tr, open(os.path.join(os.path.dirname(out) or ".", "pmc_traffic.json"), "w"), indent=1)
 
 

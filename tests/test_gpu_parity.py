@@ -559,6 +559,80 @@ def test_float_long_run_stays_with_the_double_oracle(capi, po):
     assert np.linalg.norm(xd[13:16] - tr.gt_frames["p"][nf - 1]) < 0.1
 
 
+def test_float_long_horizon_square_root_gain_form_keeps_p_positive(capi):
+    """4 000 free-running frames in float (200 s of flight) on the default covariance update P <- P - W W^T, which -- unlike
+    the reference's Joseph form (msckf.h:1394-1403) -- has no PSD guarantee under rounding: P must stay bit-symmetric and
+    positive (smallest eigenvalue above -1e-6 of the largest) at checkpoints along the run, no factorization of S may ever
+    have met a non-positive pivot (last_stats raises on the sticky STAT_ERR_PIVOT flag), and the filter must stay with the
+    same run on the Joseph form (set_covariance_update(1)) and with ground truth."""
+    N, F, nf = 10, 40, 4000
+    tr = sc.Trajectory(2, 91, N, F, nf)
+    res = {}
+    for form in (0, 1):
+        bt = capi.Batch(1, N, F, N, capi.F32)
+        bt.set_covariance_update(form)
+        bt.scenario_alloc(nf, sc.IMU_PER_FRAME)
+        bt.initialize(0, tr.cfg, tr.imu0)
+        for k in range(nf):
+            fr = tr.frames[k]
+            bt.scenario_set(k, 0, tr.imu_for_frame(k), fr["M"], fr["slots"], fr["obs"], 1 if fr["Nw"] == N else 0)
+        bt.scenario_commit()
+        for k0 in range(0, nf, 500):
+            bt.run_frames(k0, k0 + 500); bt.sync()
+            st = bt.last_stats(0)                         # raises if a pivot of S was ever <= 0
+            P = bt.covariance(0)
+            assert np.all(np.isfinite(P)) and np.array_equal(P, P.T), (form, k0)
+            w = np.linalg.eigvalsh(P)
+            assert w.min() > -1e-6 * w.max(), (form, k0, w.min(), w.max())
+            assert st["n_passed"] > 0
+        res[form] = (bt.imu_state(0), bt.covariance(0))
+        bt.close()
+    (x0, P0), (x1, P1) = res[0], res[1]
+    gt = tr.gt_frames["p"][nf - 1]
+    assert np.linalg.norm(x0[13:16] - gt) < 0.3 and np.linalg.norm(x1[13:16] - gt) < 0.3
+    assert np.linalg.norm(x0[13:16] - x1[13:16]) < 0.05           # two free-running float filters, 4 000 updates
+    assert np.linalg.norm(P0 - P1) / np.linalg.norm(P1) < 0.1
+
+
+def test_scenario_cells_can_be_restaged_and_committed_again(capi):
+    """Work-lists are stored compactly, so re-staging a cell with a different number of observations moves every later
+    offset: run_frames refuses a scenario with uncommitted changes; after the second commit the run equals a batch that
+    was staged that way from the start (resident and streamed)."""
+    N, F, nf, B = 8, 16, 13, 3
+    trs = [sc.Trajectory(2, 60 + b, N, F, nf) for b in range(B)]
+
+    def stage(bt, patched):
+        for b, tr in enumerate(trs):
+            bt.initialize(b, tr.cfg, tr.imu0)
+            for k in range(nf):
+                fr = tr.frames[k]
+                M, slots, obs = fr["M"], fr["slots"], fr["obs"]
+                if patched and k == 10 and b == 1:           # drop the first three tracks of one cell
+                    n0 = int(np.sum(M[:3]))
+                    M, slots, obs = M[3:], slots[n0:], obs[n0:]
+                bt.scenario_set(k, b, tr.imu_for_frame(k), M, slots, obs, 1 if fr["Nw"] == N else 0)
+    a, c, e = capi.Batch(B, N, F, N, capi.F32), capi.Batch(B, N, F, N, capi.F32), capi.Batch(B, N, F, N, capi.F32)
+    for bt in (a, c, e):
+        bt.scenario_alloc(nf, sc.IMU_PER_FRAME)
+    stage(a, True); a.scenario_commit()
+    stage(c, False); c.scenario_commit()
+    fr = trs[1].frames[10]
+    n0 = int(np.sum(fr["M"][:3]))
+    c.scenario_set(10, 1, trs[1].imu_for_frame(10), fr["M"][3:], fr["slots"][n0:], fr["obs"][n0:], 1 if fr["Nw"] == N else 0)
+    with pytest.raises(Exception):
+        c.run_frames(0, nf)
+    c.scenario_commit()
+    stage(e, True); e.scenario_commit()
+    a.run_frames(0, nf); a.sync()
+    c.run_frames(0, nf); c.sync()
+    e.run_frames_streamed(0, nf); e.sync()
+    for b in range(B):
+        for other in (c, e):
+            assert np.array_equal(a.covariance(b), other.covariance(b))
+            assert np.array_equal(a.imu_state(b), other.imu_state(b))
+            assert np.array_equal(a.cam_states(b)[0], other.cam_states(b)[0])
+
+
 def test_cfg5_geometry_runs_and_stays_consistent(capi):
     """60-camera window (BASELINE.json configs[4] geometry, fewer tracks): exercises NC = 6 QR tiles and the
     global-memory Cholesky path; float."""
