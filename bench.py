@@ -155,13 +155,12 @@ def main():
     ap.add_argument("--repeats", type=int, default=-1, help="timed K-step windows in all (default: until >= 0.5 s of timed region, 3..12)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    ap.add_argument("--streams", type=int, default=3, help="HIP streams for the timed region (slices of the batch run concurrently)")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams for the timed region (slices of the batch run concurrently)")
     ap.add_argument("--no-early-accept-pass", action="store_true", help="skip the extra measurement with the gate early accept (profiling runs)")
     ap.add_argument("--no-upload-pass", action="store_true",
                     help="time the windows with resident inputs only (profiling runs: `value` is then the resident-input rate and says so)")
     ap.add_argument("--ring", type=int, default=6, help="device staging sets of the streamed-input run (2..8)")
     ap.add_argument("--upload-mode", type=int, default=0, help="0 host hand-over of uploaded frames (default), 1 device-side event waits")
-    ap.add_argument("--cu-reserve", type=int, default=0, help="compute units reserved per slice (msckf_hip_set_cu_reserve; 0 = off)")
     ap.add_argument("--compression", type=int, default=-1, help="msckf_hip_set_compression route (A/B runs; -1 = library default, 0 TSQR, information form with 1 k_chol_T / 2 k_chol_blk / 3 k_chol_mfma)")
     ap.add_argument("--cov-form", type=int, default=0, help="msckf_hip_set_covariance_update form (A/B runs; 0 = square-root gain, blocked solve (default), 1 Joseph, 2 square-root gain, register-resident solve)")
     ap.add_argument("--gate-early-accept", action="store_true",
@@ -258,16 +257,17 @@ def main():
 
     bt.set_streams(args.streams)
     bt.set_upload_ring(args.ring, args.upload_mode)
-    bt.set_cu_reserve(args.cu_reserve)
     if args.compression >= 0:
         bt.set_compression(args.compression)
     bt.set_covariance_update(args.cov_form)
     bt.set_gate_early_accept(args.gate_early_accept)
     f = fill + W
+    run_timed_path = bt.run_frames_streamed if streamed else bt.run_frames
     if streamed:                     # page-lock the frames that will be streamed (set-up, like every other allocation)
-        bt.scenario_pin(fill, f + K * R)
-    bt.run_frames(0, fill)           # window fill (untimed)
-    (bt.run_frames_streamed if streamed else bt.run_frames)(fill, f)   # W warm-up steps (untimed), on the path that is timed
+        bt.scenario_pin(0, f + K * R)
+    run_timed_path(0, fill)          # window fill (untimed), on the path that is timed: the staging ring wraps several times
+    run_timed_path(fill, f)          # W warm-up steps (untimed)
+    bt.sync()
     elapsed = timed(f, f + K, streamed=streamed)   # ---- THE timed region: exactly K steps -> `value`
     f_end_timed = f + K
     sample = sorted(set(int(x) for x in np.linspace(0, B_TRAJ - 1, 8)))

@@ -103,8 +103,13 @@ int msckf_hip_set_cam_pose(msckf_hip_handle h, int b, int slot, const double* ca
 int msckf_hip_get_num_residualized(msckf_hip_handle h, int b, long long* n);
 int msckf_hip_set_num_residualized(msckf_hip_handle h, int b, long long n);
 /* last marginalize: out[0..6] = n_tracks, motion-rejected, triangulation-rejected, gate-rejected, passed,
- * stacked rows m, kept rows r */
+ * stacked rows m, kept rows r.  Also the place where the trajectory's sticky device-side error flags surface (out7 is
+ * filled regardless): -EOVERFLOW camera-state capacity exceeded in augmentState; -EDOM a factorization of
+ * S = T_H P T_H^T + R_n (msckf.h:1369) met a non-positive pivot since the flags were last cleared -- the covariance lost
+ * positive definiteness (the pivot is clamped and the run continues; the reference's explicit S.inverse() would return
+ * garbage silently). */
 int msckf_hip_last_stats(msckf_hip_handle h, int b, int* out7);
+int msckf_hip_clear_error_flags(msckf_hip_handle h, int b);
 /* per track of the last marginalize: out[t*8 + ..] = motion_ok tri_valid gate_pass included gamma p_f_G(3) */
 int msckf_hip_last_tracks(msckf_hip_handle h, int b, double* out8, int cap);
 int msckf_hip_last_deltax(msckf_hip_handle h, int b, double* dx, int cap);
@@ -152,11 +157,6 @@ int msckf_hip_profile_read(msckf_hip_handle h, double* ms8, int* count8);
 /* run_frames on n = 1..8 HIP streams: the batch is cut into n slices of independent trajectories that run the
  * same kernel sequence concurrently (latency-bound stages of one slice overlap chip-filling stages of another). */
 int msckf_hip_set_streams(msckf_hip_handle h, int n);
-/* Reserve n (0 = off, rounded up to a multiple of 8, <= 64) compute units per slice for that slice alone: the slices'
- * streams are created with CU masks (hipExtStreamCreateWithCUMask) that exclude the other slices' reserved units, so a
- * slice's one-workgroup-per-trajectory kernels (blocked Choleskys, propagate, select, prune) find free units while another
- * slice's per-track kernel fills the rest of the chip.  Scheduling only: results are bit-identical. */
-int msckf_hip_set_cu_reserve(msckf_hip_handle h, int n);
 /* Exact early accept of the chi-square gate (gatingTest, msckf.h:1103-1124), OFF by default: S = H_o P H_o^T + sigma^2 I
  * >= sigma^2 I, so gamma <= |r_o|^2 / sigma^2; when that bound is below half the threshold the track passes without
  * forming S.  Same decisions as the reference; the reported gamma of such a track is the bound (status bit 32). */

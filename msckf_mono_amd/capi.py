@@ -31,7 +31,7 @@ SYMBOLS = [
     "msckf_hip_augment_range", "msckf_hip_marginalize_range", "msckf_hip_drop_oldest_range", "msckf_hip_scenario_alloc",
     "msckf_hip_scenario_set", "msckf_hip_scenario_commit", "msckf_hip_run_frames", "msckf_hip_run_frames_streamed", "msckf_hip_sync",
     "msckf_hip_profile_enable", "msckf_hip_profile_read", "msckf_hip_set_streams", "msckf_hip_set_gate_early_accept",
-    "msckf_hip_scenario_pin", "msckf_hip_set_upload_ring", "msckf_hip_set_cu_reserve",
+    "msckf_hip_scenario_pin", "msckf_hip_set_upload_ring", "msckf_hip_clear_error_flags",
     "msckf_hip_set_compression", "msckf_hip_set_covariance_update", "msckf_hip_set_feature_overlap", "msckf_hip_get_pruned_states", "msckf_hip_get_cam_meta", "msckf_hip_get_tracked_feature_ids",
 ]
 
@@ -249,9 +249,8 @@ class Batch:
         """staging sets of run_frames_streamed (2..8); mode 0 host hand-over (default), 1 device-side event waits"""
         _chk(self.L.msckf_hip_set_upload_ring(self.h, int(depth), int(mode)))
 
-    def set_cu_reserve(self, n):
-        """compute units reserved per slice for its one-workgroup-per-trajectory kernels (0 = off; CU-masked streams)"""
-        _chk(self.L.msckf_hip_set_cu_reserve(self.h, int(n)))
+    def clear_error_flags(self, b):
+        _chk(self.L.msckf_hip_clear_error_flags(self.h, int(b)))
 
     def sync(self):
         _chk(self.L.msckf_hip_sync(self.h))

@@ -225,6 +225,9 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0) {
   // (2) diagonal block on ONE wavefront, all 64 lanes busy: lane (r = lane & 15, g = lane >> 4) holds row r, columns
   // 4q + g of the block and of the identity image v.  Per pivot: rsqrt on the owner, dinv by v_readlane, the scaled pivot
   // column and the multipliers L(j, k) reach the other lanes through the LDS crossbar (ds_bpermute), 4 + 4 FMAs/lane.
+  // Measured and rejected (round 3): lane = row with the whole row in registers, L(j, k) broadcast by v_readlane as an SGPR
+  // operand of the FMA, L^-1 built by the same instruction stream in lanes 16..31 -- no LDS inside the chain, 120 FMAs + 240
+  // v_readlane per block instead of 12 ds_bpermute per pivot: 60 -> 73 us (f64), 51 -> 60 us (f32).
   auto diag = [&](auto pc) __attribute__((always_inline)) {
     constexpr int p = decltype(pc)::value;
     T (*sP)[LP] = sPP[p & 1];

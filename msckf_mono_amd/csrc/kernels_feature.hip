@@ -219,8 +219,12 @@ __device__ __forceinline__ bool gate_chol(const S* sG, const S* sV, const S* sE,
 template <class S, bool LONG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (sizeof(S) == 4 ? 4 : 2), sizeof(S) == 4 && !LONG ? 4 : 2))) void k_feature(Dev<S> d, int b0, int nb) {
   // all tracks of a trajectory on one XCD (xcd_item): the gate's 6 x 6 blocks of P then come out of an L2 that holds 1/8 of
-  // the batch's covariances (the (track, trajectory) grid spread every trajectory over all eight: 73 MB fetched per launch for
-  // 9.7 MB of covariance)
+  // the batch's covariances (the (track, trajectory) grid spread every trajectory over all eight: 68 MB fetched per launch for
+  // 9.7 MB of covariance; now 17 MB).  Measured and rejected: a PERSISTENT form of this kernel -- one residency
+  // of wavefronts pulling tracks from per-XCD ticket queues, so that a set of compute units could be kept free for the
+  // one-workgroup-per-trajectory kernels of the other slices: 134 -> 174 us even with one 128-byte line per ticket counter
+  // and prefetched tickets (all wavefronts start in phase and hit the same pipes together), and the units kept free were
+  // taken by the next slice's per-track wavefronts.
   int bi, t;
   if (!xcd_item(nb, d.f_cap, bi, t)) return;
   const int b = b0 + bi, lane = threadIdx.x;
@@ -498,8 +502,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
       // of every track was 59 MB of the launch's 107 MB of writes.
       double* oB = d.trk_B + tb * 3 * (long)d.ldR;
       signed char* oI = d.trk_inv + tb * d.n_cap;
+      // (a track that saw every camera of its range -- the usual case -- has no gap to zero: its 3 x 6 M values are the
+      // only thing written; slots of a track are distinct, msckf_hip_set_tracks / scenario_set reject repeats)
       const int c_lo = 6 * slot_lo, c_n = 6 * (slot_hi - slot_lo + 1);
-      for (int e = lane; e < 3 * c_n; e += 64) { const int q = e / c_n; oB[(long)q * d.ldR + c_lo + (e - q * c_n)] = 0.0; }
+      if (slot_hi - slot_lo + 1 != M)
+        for (int e = lane; e < 3 * c_n; e += 64) { const int q = e / c_n; oB[(long)q * d.ldR + c_lo + (e - q * c_n)] = 0.0; }
       for (int e = lane; e < d.n_cap; e += 64) oI[e] = -1;
       __syncthreads();
       if (act) {

@@ -90,9 +90,10 @@ __global__ __launch_bounds__(256) void k_gram_diag(Dev<S> d, int b0) {
 // order.
 template <class S>
 __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int nb, int npairs, int dbg, int xoff) {
-  // the tiles of one trajectory read the same rows of B^: all of them on the trajectory's XCD (xcd_item)
-  int bi, bxi;
-  if (!xcd_item(nb, npairs, bi, bxi)) return;
+  // (tiles of one trajectory on the trajectory's XCD, xcd_item: fetch 54 -> 22 MB per launch, time unchanged -- the loop is
+  // bound by load latency and the matrix cores, not by L2 misses; the plain mapping stays)
+  const int bi = (int)blockIdx.x / npairs, bxi = (int)blockIdx.x - bi * npairs;
+  if (bi >= nb) return;
   const int b = b0 + bi, grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, w = tid >> 6;
   const int* st = d.stats + (long)b * STAT_STRIDE;
   const int mrows_ = st[STAT_MROWS], P = st[STAT_PASSED], N = d.ncam[b];   // independent scalar loads, one wait
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int nb, int npai
     for (int e = threadIdx.x; e < P && e < GORD; e += 512) {
       const int t = order[e];
       const int fl = d.trk_first[(long)b * f_cap + t];      // first | last << 8 camera slot of the track
-      sOrd[e] = t | ((fl & 63) << 10) | (((fl >> 8) & 63) << 16);
+      sOrd[e] = t | ((fl & 63) << 10) | ((((fl >> 8) & 63) - (fl & 63) + 1) << 16);   // track, first slot, slots in the range
       c += ((fl & 255) <= hi_slot) ? 1 : 0;
     }
     c = (int)wave_sum((float)c);
@@ -157,6 +158,11 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int nb, int npai
   // k_feature writes a track's rows of B^ only inside the track's slot range [first, last] and at column n (Q_f^T r): a row's
   // loads stay unconditional (whatever an older frame left outside the range), `ok` masks them when they are staged
   struct Stage { double a[GK / 4]; double b[GT_MAX][GK / 4]; unsigned ok; };
+  const int ca_col = 64 * ti + lc;
+  const bool ca_isn = ca_col == n;
+  int cb_col[GT_MAX]; bool cb_isn[GT_MAX];
+#pragma unroll
+  for (int u = 0; u < GT_MAX; ++u) { cb_col[u] = 64 * (tj0 + u) + lc; cb_isn[u] = cb_col[u] == n; }
   Stage r0, r1;
   auto fetch = [&](Stage& r, int kc) {
     const double* rows[GK / 4];
@@ -166,12 +172,12 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int nb, int npai
       const int kk = min(kc + lr + 4 * it, KT - 1);
       const int p = kk / 3, q = kk - 3 * p;
       const int e = sOrd[min(p, GORD - 1)];
-      const int t = e & 1023, c_lo = 6 * ((e >> 10) & 63), c_hi = 6 * ((e >> 16) & 63) + 6;
+      const int t = e & 1023, c_lo = 6 * ((e >> 10) & 63);
+      const unsigned c_w = 6u * (unsigned)(e >> 16);
       rows[it] = d.trk_B + (((long)b * f_cap + t) * 3 + q) * (long)ldL;
-      const int ca = 64 * ti + lc;
-      okm |= ((ca >= c_lo && ca < c_hi) || ca == n) ? (1u << it) : 0u;
+      okm |= (((unsigned)(ca_col - c_lo) < c_w) || ca_isn) ? (1u << it) : 0u;
 #pragma unroll
-      for (int u = 0; u < GT_MAX; ++u) { const int cb = 64 * (tj0 + u) + lc; okm |= ((cb >= c_lo && cb < c_hi) || cb == n) ? (1u << (8 * (u + 1) + it)) : 0u; }
+      for (int u = 0; u < GT_MAX; ++u) okm |= (((unsigned)(cb_col[u] - c_lo) < c_w) || cb_isn[u]) ? (1u << (8 * (u + 1) + it)) : 0u;
     }
     r.ok = okm;
 #pragma unroll
@@ -539,7 +545,7 @@ void launch_gram(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase) {
     // (MFMA-bound, <= 192 workgroups).  In ONE launch the dispatcher packs strips two to a CU behind the reduction
     // workgroups and they share the matrix cores (measured: MFMA phase 2x longer).
     if (!(g_dbg & 1)) hipLaunchKernelGGL(k_gram_diag<S>, dim3(ndiag, nb), dim3(256), 0, st, d, b0);
-    hipLaunchKernelGGL(k_gram<S>, dim3(xcd_grid(nb, npairs)), dim3(512), gram_lds_bytes(), st, d, b0, nb, npairs, g_dbg, 0);
+    hipLaunchKernelGGL(k_gram<S>, dim3(nb * npairs), dim3(512), gram_lds_bytes(), st, d, b0, nb, npairs, g_dbg, 0);
   }
   if (phase == 1) return;
   // k_chol_blk (blocked, trailing update on the f64 matrix cores) is 10 % faster than k_chol_T in isolation (104 vs

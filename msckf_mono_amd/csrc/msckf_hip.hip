@@ -12,6 +12,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <dlfcn.h>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -30,6 +32,30 @@ using namespace msckf;
 
 thread_local std::string g_err;
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+// rocTX ranges under the reference's stage names (asl_msckf.cpp:229-296: imu_prop, msckf_augment_state, msckf_update,
+// msckf_add_features, msckf_marginalize, msckf_prune_redundant, msckf_prune_empty_states) around the host side of every stage,
+// so that a `rocprofv3 --marker-trace` timeline of a caller reads like the reference's StageTiming message.  Off unless
+// MSCKF_HIP_ROCTX=1; the marker library is opened at run time (no link dependency).
+struct Roctx {
+  int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
+  Roctx() {
+    const char* e = getenv("MSCKF_HIP_ROCTX");
+    if (!e || !atoi(e)) return;
+    void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
+    push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+    pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (!push || !pop) { push = nullptr; pop = nullptr; }
+  }
+};
+const Roctx& roctx() { static Roctx r; return r; }
+struct StageRange {
+  bool on;
+  explicit StageRange(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+  ~StageRange() { if (on) roctx().pop(); }
+};
 
 #define HIPCHK(expr)                                                                         \
   do {                                                                                       \
@@ -88,7 +114,6 @@ struct BatchBase {
   virtual int run_frames_streamed(int f0, int f1) = 0;
   virtual int scen_pin(int f0, int f1) = 0;
   virtual int set_upload_ring(int depth, int mode) = 0;
-  virtual int set_cu_reserve(int n) = 0;
   virtual int sync() = 0;
   virtual int prof_enable(int on) = 0;
   virtual int prof_read(double* ms, int* cnt) = 0;
@@ -98,6 +123,7 @@ struct BatchBase {
   virtual int set_cov_update(int form) = 0;
   virtual int set_feature_overlap(int on) = 0;
   virtual int clear_stats(int b) = 0;
+  virtual int clear_errors(int b) = 0;
 };
 
 constexpr int NSTAGE = 8;
@@ -187,10 +213,7 @@ struct Batch : BatchBase {
   struct PinFrame { unsigned char* p = nullptr; size_t bytes = 0, off_obs = 0; };
   std::vector<PinFrame> pinf; std::vector<void*> pin_chunks;
   size_t pk_rd = 0, pk_n = 0, pk_drop = 0, pk_M = 0, pk_off = 0, pk_slots = 0;   // section offsets (256-byte aligned); obs follows the frame's slots
-  // slices of the batch: enqueue threads, optional CU-reserved streams
-  Workers workers;
-  int cu_reserve = 0, mst_nh = 0, mst_reserve = 0; hipStream_t mst[MAXS] = {nullptr};
-  hipEvent_t ev_join0 = nullptr;
+  Workers workers;   // enqueue threads of the slices
   // profiling
   bool prof = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool[NSTAGE];
@@ -215,7 +238,6 @@ struct Batch : BatchBase {
     for (int i = 1; i < MAXS; ++i) HIPCHK(hipStreamCreateWithFlags(&stx[i], hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     for (int i = 1; i < MAXS; ++i) HIPCHK(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&ev_join0, hipEventDisableTiming));
     for (int i = 0; i < MAXS; ++i) {
       HIPCHK(hipStreamCreateWithFlags(&sty[i], hipStreamNonBlocking));
       HIPCHK(hipEventCreateWithFlags(&ev_fa[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_fb[i], hipEventDisableTiming));
@@ -278,8 +300,7 @@ struct Batch : BatchBase {
     unpin_host();
     for (int k = 0; k < RING_MAX; ++k) { if (ev_up[k]) hipEventDestroy(ev_up[k]); for (int i = 0; i < MAXS; ++i) if (ev_use[k][i]) hipEventDestroy(ev_use[k][i]); if (sg_blk[k]) hipFree(sg_blk[k]); }
     if (stc) hipStreamDestroy(stc);
-    for (int i = 0; i < MAXS; ++i) if (mst[i]) hipStreamDestroy(mst[i]);
-    if (ev_join0) hipEventDestroy(ev_join0);
+
     if (h_stage) hipHostFree(h_stage);
     if (st) hipStreamDestroy(st);
   }
@@ -323,6 +344,12 @@ struct Batch : BatchBase {
     ev_used[s]++;
   }
 
+  // a track observes a camera at most once (the kernels rely on it: slot -> observation map, contiguous-range test)
+  static bool repeated_slot(const int* s, int M) {
+    unsigned long long seen = 0;
+    for (int k = 0; k < M; ++k) { const unsigned long long bit = 1ull << (s[k] & 63); if (s[k] >= 0 && s[k] < 64 && (seen & bit)) return true; seen |= bit; }
+    return false;
+  }
   int chk(int b) const { return (b < 0 || b >= B) ? -EINVAL : 0; }
   int chk_range(int b0, int nb) const { return (b0 < 0 || nb < 0 || b0 + nb > B) ? -EINVAL : 0; }
 
@@ -393,6 +420,7 @@ struct Batch : BatchBase {
     if (F < 0 || F > f_cap) return fail(-E2BIG, "more tracks than f_cap");
     HIPCHK(hipSetDevice(device));
     for (int t = 0; t < F; ++t) if (M[t] > m_cap || M[t] < 0) return fail(-E2BIG, "track longer than m_cap");
+    { size_t o = 0; for (int t = 0; t < F; ++t) { if (repeated_slot(slots + o, M[t])) return fail(-EINVAL, "camera slot repeated within a track"); o += M[t]; } }
     // only the F rows in use travel: [F] lengths, [F][m_cap] slots, [F][m_cap][2] coordinates, one pinned block
     const size_t nM = (size_t)F, nS = (size_t)F * m_cap, nO = (size_t)F * m_cap * 2;
     const size_t offS = ((nM * sizeof(int) + 15) / 16) * 16, offO = offS + ((nS * sizeof(int) + 15) / 16) * 16;
@@ -430,6 +458,12 @@ struct Batch : BatchBase {
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipMemsetAsync(d.stats + (size_t)b * STAT_STRIDE, 0, sizeof(int) * STAT_ERR, st));
+    return 0;
+  }
+  int clear_errors(int b) override {
+    if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemsetAsync(d.stats + (size_t)b * STAT_STRIDE + STAT_ERR, 0, sizeof(int), st));
     return 0;
   }
   void launch_update(const Dev<S>& vin, int b0, int nb, hipStream_t q, bool feature_done = false) {
@@ -685,6 +719,7 @@ struct Batch : BatchBase {
       for (int t = 0; t < F; ++t) {
         if (M[t] > m_cap || M[t] < 0) return fail(-E2BIG, "track longer than m_cap");
         for (int k = 0; k < M[t]; ++k) if (slots[tot + k] < 0 || slots[tot + k] >= n_cap) return fail(-EINVAL, "camera slot out of range");
+        if (repeated_slot(slots + tot, M[t])) return fail(-EINVAL, "camera slot repeated within a track");
         tot += M[t];
       }
     }
@@ -828,46 +863,13 @@ struct Batch : BatchBase {
     ring = depth; up_mode = mode;
     return 0;
   }
-  // Reserve n compute units per slice for that slice alone (0 = off).  The slices' streams are then created with CU masks
-  // (hipExtStreamCreateWithCUMask): slice i may run anywhere EXCEPT on the reserved units of the other slices.  The
-  // one-workgroup-per-trajectory kernels of a slice (blocked Choleskys, propagate, select, prune: 1024-thread workgroups that
-  // need a whole CU's registers) then always find free units, however many k_feature wavefronts of another slice are resident.
-  int set_cu_reserve(int n) override {
-    if (n < 0 || n > 64) return fail(-EINVAL, "0 .. 64 compute units per slice");
-    cu_reserve = (n + 7) / 8 * 8;          // mask bits interleave over the 8 XCDs: whole multiples keep every XCD equally wide
-    return 0;
-  }
-  int ensure_masked_streams(int nh) {
-    if (mst_nh == nh && mst_reserve == cu_reserve && mst[0]) return 0;
-    for (int i = 0; i < MAXS; ++i) if (mst[i]) { HIPCHK(hipStreamSynchronize(mst[i])); HIPCHK(hipStreamDestroy(mst[i])); mst[i] = nullptr; }
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, device));
-    const int ncu = prop.multiProcessorCount, nw = (ncu + 31) / 32;
-    if ((long)cu_reserve * nh > ncu / 2) return fail(-EINVAL, "reserved compute units exceed half the device");
-    for (int i = 0; i < nh; ++i) {
-      std::vector<uint32_t> mask(nw, 0u);
-      for (int c = 0; c < ncu; ++c) {
-        const int owner = c / cu_reserve;                                      // slice that owns reserved unit c (>= nh: nobody)
-        if (owner >= nh || owner == i) mask[c >> 5] |= 1u << (c & 31);
-      }
-      HIPCHK(hipExtStreamCreateWithCUMask(&mst[i], (uint32_t)nw, mask.data()));
-    }
-    mst_nh = nh; mst_reserve = cu_reserve;
-    return 0;
-  }
-  // streams of the nh slices of a run: the handle's own streams, or the CU-masked ones
+  // streams of the nh slices of a run
   int slice_streams(int nh, hipStream_t* qs) {
-    if (cu_reserve > 0 && nh > 1) {
-      int rc = ensure_masked_streams(nh);
-      if (rc) return rc;
-      for (int i = 0; i < nh; ++i) qs[i] = mst[i];
-    } else for (int i = 0; i < nh; ++i) qs[i] = stx[i];
+    for (int i = 0; i < nh; ++i) qs[i] = stx[i];
     return 0;
   }
   int fork_slices(int nh, hipStream_t* qs, hipStream_t extra = nullptr) {
-    bool any = extra != nullptr;
-    for (int i = 0; i < nh; ++i) any = any || qs[i] != st;
-    if (!any) return 0;
+    if (nh <= 1 && !extra) return 0;
     HIPCHK(hipEventRecord(ev_fork, st));
     for (int i = 0; i < nh; ++i) if (qs[i] != st) HIPCHK(hipStreamWaitEvent(qs[i], ev_fork, 0));
     if (extra) HIPCHK(hipStreamWaitEvent(extra, ev_fork, 0));
@@ -875,7 +877,7 @@ struct Batch : BatchBase {
   }
   int join_slices(int nh, hipStream_t* qs) {
     for (int i = 0; i < nh; ++i)
-      if (qs[i] != st) { hipEvent_t e = i == 0 ? ev_join0 : ev_join[i]; HIPCHK(hipEventRecord(e, qs[i])); HIPCHK(hipStreamWaitEvent(st, e, 0)); }
+      if (qs[i] != st) { HIPCHK(hipEventRecord(ev_join[i], qs[i])); HIPCHK(hipStreamWaitEvent(st, ev_join[i], 0)); }
     return 0;
   }
   int sync() override {
@@ -979,13 +981,19 @@ int Batch<S>::run_frames(int f0, int f1) {
         (void)hipEventRecord(ev_fb[hh], sty[hh]);
       }
       // propagate and augmentState are always back to back here: one launch (the per-stage profile keeps them apart)
-      stage_begin(0, q); launch_propagate<S>(v, b0, nb, sc_rd + (cell0 + b0) * sc_K * RD_STRIDE, (long)sc_K * RD_STRIDE, sc_K, q, !prof); stage_end(0, q);
-      if (prof) { stage_begin(1, q); launch_augment<S>(v, b0, nb, q); stage_end(1, q); }
+      {
+        StageRange r("imu_prop+msckf_augment_state");
+        stage_begin(0, q); launch_propagate<S>(v, b0, nb, sc_rd + (cell0 + b0) * sc_K * RD_STRIDE, (long)sc_K * RD_STRIDE, sc_K, q, !prof); stage_end(0, q);
+        if (prof) { stage_begin(1, q); launch_augment<S>(v, b0, nb, q); stage_end(1, q); }
+      }
       if (early) (void)hipStreamWaitEvent(q, ev_fb[hh], 0);
-      launch_update(v, b0, nb, q, early);
-      stage_begin(6, q);
-      launch_prune<S>(v, b0, nb, q, (const int*)(sc_drop + cell0 + b0), 0);
-      stage_end(6, q);
+      { StageRange r("msckf_marginalize"); launch_update(v, b0, nb, q, early); }
+      {
+        StageRange r("msckf_prune_empty_states");
+        stage_begin(6, q);
+        launch_prune<S>(v, b0, nb, q, (const int*)(sc_drop + cell0 + b0), 0);
+        stage_end(6, q);
+      }
       for (int b = b0; b < b0 + nb; ++b) {   // host mirror of the window size: augment, then drop n_drop (clamped as k_make_keep does)
         if (h_ncam[b] < n_cap) h_ncam[b]++;
         h_ncam[b] -= std::max(0, std::min(h_drop[cell0 + b], h_ncam[b]));
@@ -1436,11 +1444,12 @@ int msckf_hip_destroy(msckf_hip_handle h) { delete H(h); return 0; }
 int msckf_hip_initialize(msckf_hip_handle h, int b, const double* cam12, const double* noise29, const double* params8, const double* imu29) {
   return H(h)->init(b, cam12, noise29, params8, imu29);
 }
-int msckf_hip_propagate(msckf_hip_handle h, int b, const double* readings7, int K) { return H(h)->propagate(b, 1, readings7, K); }
+int msckf_hip_propagate(msckf_hip_handle h, int b, const double* readings7, int K) { StageRange r("imu_prop"); return H(h)->propagate(b, 1, readings7, K); }
 int msckf_hip_augment_state(msckf_hip_handle h, int b, int state_id, double time) {
   BatchBase* B = H(h);
   if (b < 0 || b >= B->B) return fail(-EINVAL, "trajectory index out of range");
   if ((int)B->traj[b].cams.size() >= B->n_cap) return fail(-EOVERFLOW, "camera-state capacity n_cap exceeded");
+  StageRange r("msckf_augment_state");
   int rc = B->augment(b, 1);
   if (rc) return rc;
   B->traj[b].cams.push_back(CamMeta{state_id, time, -1, {}});
@@ -1449,22 +1458,27 @@ int msckf_hip_augment_state(msckf_hip_handle h, int b, int state_id, double time
 }
 int msckf_hip_update(msckf_hip_handle h, int b, const double* meas2, const uint64_t* ids, int n) {
   if (b < 0 || b >= H(h)->B) return fail(-EINVAL, "trajectory index out of range");
+  StageRange r("msckf_update");
   return host_update(H(h), b, meas2, ids, n);
 }
 int msckf_hip_add_features(msckf_hip_handle h, int b, const double* meas2, const uint64_t* ids, int n) {
   if (b < 0 || b >= H(h)->B) return fail(-EINVAL, "trajectory index out of range");
+  StageRange r("msckf_add_features");
   return host_add_features(H(h), b, meas2, ids, n);
 }
 int msckf_hip_marginalize(msckf_hip_handle h, int b) {
   if (b < 0 || b >= H(h)->B) return fail(-EINVAL, "trajectory index out of range");
+  StageRange r("msckf_marginalize");
   return host_marginalize(H(h), b);
 }
 int msckf_hip_prune_empty_states(msckf_hip_handle h, int b) {
   if (b < 0 || b >= H(h)->B) return fail(-EINVAL, "trajectory index out of range");
+  StageRange r("msckf_prune_empty_states");
   return host_prune_empty(H(h), b);
 }
 int msckf_hip_prune_redundant_states(msckf_hip_handle h, int b) {
   if (b < 0 || b >= H(h)->B) return fail(-EINVAL, "trajectory index out of range");
+  StageRange r("msckf_prune_redundant");
   return host_prune_redundant(H(h), b);
 }
 int msckf_hip_finish(msckf_hip_handle h, int b) {
@@ -1542,6 +1556,7 @@ int msckf_hip_set_cam_pose(msckf_hip_handle h, int b, int slot, const double* ca
 int msckf_hip_get_num_residualized(msckf_hip_handle h, int b, long long* n) { return H(h)->get_nres(b, n); }
 int msckf_hip_set_num_residualized(msckf_hip_handle h, int b, long long n) { return H(h)->set_nres(b, n); }
 int msckf_hip_last_stats(msckf_hip_handle h, int b, int* out7) { return H(h)->stats(b, out7); }
+int msckf_hip_clear_error_flags(msckf_hip_handle h, int b) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->clear_errors(b); }
 int msckf_hip_last_tracks(msckf_hip_handle h, int b, double* out8, int cap) { return H(h)->track_info(b, out8, cap); }
 int msckf_hip_last_deltax(msckf_hip_handle h, int b, double* dx, int cap) { return H(h)->deltax(b, dx, cap); }
 
@@ -1564,7 +1579,6 @@ int msckf_hip_profile_read(msckf_hip_handle h, double* ms7, int* count7) { retur
 int msckf_hip_set_streams(msckf_hip_handle h, int n) { return H(h)->set_streams(n); }
 int msckf_hip_scenario_pin(msckf_hip_handle h, int f0, int f1) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->scen_pin(f0, f1); }
 int msckf_hip_set_upload_ring(msckf_hip_handle h, int depth, int mode) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_upload_ring(depth, mode); }
-int msckf_hip_set_cu_reserve(msckf_hip_handle h, int n) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_cu_reserve(n); }
 int msckf_hip_set_feature_overlap(msckf_hip_handle h, int on) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_feature_overlap(on); }
 int msckf_hip_set_covariance_update(msckf_hip_handle h, int form) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_cov_update(form); }
 int msckf_hip_set_compression(msckf_hip_handle h, int route) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_compression(route); }

@@ -37,6 +37,8 @@ def lib(impl="oracle"):
     if impl not in _LIBS:
         path = {"oracle": os.path.join(_HERE, "liboracle.so"), "ref": os.path.join(_HERE, "_ref", "lib_ref.so"),
                 "ref_alt": os.path.join(_HERE, "_ref", "lib_ref_alt.so")}[impl]
+        if impl == "oracle" and os.environ.get("ORACLE_SANITIZED"):     # make -C oracle asan: AddressSanitizer + UBSan build of the restatement
+            path = os.path.join(_HERE, "liboracle_asan.so")
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""One process, one resident scenario (cfg3), many launch variants: streams x CU reserve x upload ring / hand-over, each
+"""One process, one resident scenario (cfg3), many launch variants: streams x upload ring / hand-over, each
 re-initialised and measured on the SAME frames (window fill, warm-up, then R windows of K steps; median updates/s).
 Experiment helper for DESIGN.md's tables; the driver's number comes from bench.py.
-Usage: sweep_variants.py [--steps 20] [--windows 5] [--hwq 8] "streams=3,reserve=0,streamed=1,ring=6,mode=0" ..."""
+Usage: sweep_variants.py [--steps 20] [--windows 5] [--hwq 8] "streams=3,streamed=1,ring=6,mode=0" ..."""
 import argparse, json, os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
@@ -37,11 +37,11 @@ def main():
     bt.scenario_pin(N, nfr)
     ref = None
     for v in a.variants:
-        kv = dict(streams=3, reserve=0, streamed=1, ring=6, mode=0, early=0)
+        kv = dict(streams=3, streamed=1, ring=6, mode=0, early=0)
         kv.update({k: int(x) for k, x in (p.split("=") for p in v.split(",") if p)})
         for b, tr in enumerate(trajs):
             bt.initialize(b, tr.cfg, tr.imu0)
-        bt.set_streams(kv["streams"]); bt.set_cu_reserve(kv["reserve"]); bt.set_upload_ring(kv["ring"], kv["mode"])
+        bt.set_streams(kv["streams"]); bt.set_upload_ring(kv["ring"], kv["mode"])
         bt.set_gate_early_accept(bool(kv["early"]))
         run = bt.run_frames_streamed if kv["streamed"] else bt.run_frames
         bt.run_frames(0, N); run(N, N + W); bt.sync()

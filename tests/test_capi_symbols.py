@@ -74,3 +74,21 @@ def test_product_never_imports_the_oracle():
                 assert not re.search(r'#include\s+"[^"]*oracle', txt), f
     inc = open(os.path.join(ROOT, "include", "msckf_hip.h")).read()
     assert "torch" not in inc
+
+
+def test_every_batch_method_used_by_bench_and_tests_exists():
+    """bench.py, scripts/sweep_variants.py and the GPU tests drive capi.Batch by method name; a binding removed by mistake
+    must fail here, on the CPU, not on the GPU box."""
+    import glob, os, re
+    from msckf_mono_amd import capi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, "bench.py"), os.path.join(root, "scripts", "sweep_variants.py"), os.path.join(root, "tests", "helpers.py"),
+             os.path.join(root, "__graft_entry__.py")] + glob.glob(os.path.join(root, "tests", "test_gpu_*.py"))
+    used = set()
+    for f in files:
+        used |= set(re.findall(r"\b(?:bt|batch|a|c|e)\.([a-z_]+)\(", open(f).read()))
+    have = set(dir(capi.Batch))
+    missing = sorted(m for m in used if m not in have and m not in dir(dict) and m not in dir(list) and m not in ("scenario_alloc_",))
+    # names that belong to other objects reached through the same variable names in the tests
+    missing = [m for m in missing if m not in ("run", "sum", "startswith", "update", "lib")]
+    assert not missing, missing

@@ -54,14 +54,13 @@ def _snapshot(bt, B):
 
 
 def test_cfg3_streams_give_bit_identical_results(capi, cfg3_trajs):
-    """bench.py runs on 3 streams (threaded enqueue, one slice of the batch per stream: 21 / 21 / 22 trajectories).
-    Trajectories are independent, so 1, 2, 3 (uneven slices), 4 and 8 streams must give BIT-identical states and covariances
-    for all 64 trajectories -- also with compute units reserved per slice (CU-masked streams: scheduling only)."""
+    """bench.py runs on several streams (threaded enqueue, one slice of the batch per stream: 3 streams = 21 / 21 / 22
+    trajectories).  Trajectories are independent, so 1, 2, 3 (uneven slices), 4 and 8 streams must give BIT-identical states
+    and covariances for all 64 trajectories."""
     c = CFG3
     ref = None
-    for ns, reserve in ((1, 0), (2, 0), (3, 0), (4, 0), (8, 0), (3, 24)):
+    for ns in (1, 2, 3, 4, 8):
         bt = _resident_batch(capi, cfg3_trajs, c["N"], c["F"], c["nf"], 32, capi.F32, streams=ns)
-        bt.set_cu_reserve(reserve)
         bt.run_frames(0, c["nf"]); bt.sync()
         snap = _snapshot(bt, c["B"])
         stats = [bt.last_stats(b) for b in range(c["B"])]
@@ -72,19 +71,19 @@ def test_cfg3_streams_give_bit_identical_results(capi, cfg3_trajs):
             continue
         for b in range(c["B"]):
             for x, y in zip(snap[b], ref[b]):
-                assert np.array_equal(x, y), (ns, reserve, b)
+                assert np.array_equal(x, y), (ns, b)
     # inputs uploaded per frame inside the run (msckf_hip_run_frames_streamed: compact per-frame blocks from page-locked
     # memory, copy stream, ring of staging sets; host or device-event hand-over): same bits.  A ring of 2 wraps 16 times.
-    for ns, ring, mode, reserve in ((1, 6, 0, 0), (3, 6, 0, 0), (3, 2, 0, 0), (2, 3, 1, 0), (3, 4, 0, 16)):
+    for ns, ring, mode in ((1, 6, 0), (3, 6, 0), (3, 2, 0), (2, 3, 1), (4, 4, 0)):
         bt = _resident_batch(capi, cfg3_trajs, c["N"], c["F"], c["nf"], 32, capi.F32, streams=ns)
-        bt.set_upload_ring(ring, mode); bt.set_cu_reserve(reserve)
+        bt.set_upload_ring(ring, mode)
         bt.scenario_pin(0, 11)                       # explicit for the first call, on demand for the second
         bt.run_frames_streamed(0, 11); bt.run_frames_streamed(11, c["nf"]); bt.sync()
         snap = _snapshot(bt, c["B"])
         bt.close()
         for b in range(c["B"]):
             for x, y in zip(snap[b], ref[b]):
-                assert np.array_equal(x, y), ("streamed", ns, ring, mode, reserve, b)
+                assert np.array_equal(x, y), ("streamed", ns, ring, mode, b)
 
 
 def test_cfg3_batch_of_64_vs_oracle(capi, po, cfg3_trajs):

@@ -119,3 +119,42 @@ def test_gram_mode_follows_the_qr_modes_over_a_long_float_run(oracle_lib):
     for a, g in ((fs["d"], fs["gd"]), (fs["a"], fs["g"])):
         assert 0 < g.lastStats()["r_rows"] < a.lastStats()["r_rows"]
         assert g.lastStats()["m_rows"] == a.lastStats()["m_rows"]
+
+
+def test_restatement_is_clean_under_asan_and_ubsan(tmp_path):
+    """The restatement (oracle/msckf_oracle.hpp) built with -fsanitize=address,undefined (make -C oracle asan) runs a filter
+    scenario -- work-list path with pruning, the public id-stream path with pruneRedundantStates, float and double -- in a
+    child process with the sanitizer runtimes preloaded; any out-of-bounds access, use-after-free or undefined operation
+    aborts the child (-fno-sanitize-recover)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "asan"])
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    ubsan = subprocess.check_output(["gcc", "-print-file-name=libubsan.so"], text=True).strip()
+    code = r'''
+import sys, os
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "oracle")); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, helpers as H, pyoracle as po
+from msckf_mono_amd import scenario as sc
+assert po.lib()._name.endswith("liboracle_asan.so")
+for dt in (po.F64, po.F32):
+    N, F, nf = 8, 24, 16
+    tr = sc.Trajectory(2, 7, N, F, nf)
+    for mode in (po.LEAN, po.FAITHFUL):
+        o = po.Oracle(dt, mode); o.initialize(tr.cfg, tr.imu0)
+        for k in range(nf):
+            H.oracle_frame(o, tr, k, N)
+        assert np.all(np.isfinite(o.getCovariance()))
+N, F, nf = 26, 12, 30
+cfg = sc.filter_config(N); cfg["max_cam_states"] = 20; cfg["redundancy_distance_thresh"] = 0.25; cfg["redundancy_angle_thresh"] = 0.25; cfg["translation_threshold"] = 0.01
+tr = sc.Trajectory(2, 77, N, F, nf, cfg=cfg); st = tr.stream()
+o = po.Oracle(po.F64, po.LEAN); o.initialize(tr.cfg, tr.imu0)
+for k in range(nf):
+    o.propagate(tr.imu_for_frame(k)); o.augmentState(k, tr.frame_times[k]); o.update(*st[k]["cur"]); o.addFeatures(*st[k]["new"])
+    o.marginalize(); o.pruneRedundantStates(); o.pruneEmptyStates()
+o.finish()
+print("SANITIZED_OK")
+''' % (root, root, root)
+    env = dict(os.environ, ORACLE_SANITIZED="1", LD_PRELOAD=asan + ":" + ubsan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0 and "SANITIZED_OK" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
