@@ -88,6 +88,9 @@ struct Dev {
   //   Lam    [B][ldR][ldR]      f64   sum B^T B, upper 64x64 tiles
   int compress;   // 0 Householder TSQR; information form with 1 k_chol_T, 2 k_chol_blk, 3 k_chol_mfma (kernels_chol.hip)
   double* trk_B; S* trk_rw; signed char* trk_inv; double* Dg; double* Lam;
+  // split-K SYRK (kernels_gram.hip): gram_parts == 3: tiles of block row ti are summed by min(ti + 1, 3) workgroups into copies
+  // of Lam^ that lie lam_part doubles apart; the blocked Cholesky adds the copies while loading.  lam_part == 0: one copy only
+  int gram_parts; long lam_part;
   S* Mp2;       // [B][24][16][16] per-panel M of the two-level factorization of S (6 n_cap > 192), else null
   double* Mp;   // [B][12][16][16] per-panel M of level A of the two-level Gram factorization (windows with 6 n_cap + 1 > 192), else null
   // covariance update: 0 = square-root gain form P <- P - W W^T, S factored by the blocked matrix-core Cholesky (float) /

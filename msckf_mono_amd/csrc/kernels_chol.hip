@@ -143,6 +143,16 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0) {
       if (i < NB && 16 * i >= main_rows) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[ii][jj][r] = *el_ptr(16 * i + Mf<T>::row(lane, r), 16 * j + (lane & 15));
+      // split-K SYRK (kernels_gram.hip): the tiles of block column j / 4 came in min(j / 4 + 1, 3) partial sums, lam_part apart;
+      // added here in a fixed order (the loads are as unconditional as the ones above: one more round trip, no waits between)
+      if (MODE == CH_GRAM && d.gram_parts == 3 && jj >= 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ii][jj][r] += *(el_ptr(16 * i + Mf<T>::row(lane, r), 16 * j + (lane & 15)) + d.lam_part);
+        if (jj >= 2) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[ii][jj][r] += *(el_ptr(16 * i + Mf<T>::row(lane, r), 16 * j + (lane & 15)) + 2 * d.lam_part);
+        }
+      }
     }
 #pragma unroll
   for (int ii = 0; ii < HR; ++ii)
@@ -156,7 +166,14 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0) {
       for (int r = 0; r < 4; ++r) if (!el_ok(16 * i + Mf<T>::row(lane, r), 16 * j + (lane & 15))) acc[ii][jj][r] = T(0);
     }
   if (GRAMLIKE)
-    for (int t = tid; t < 16 * NB; t += 1024) { const double dv = lam_hat(Lam, Dg, d.ldR, nfull, d.n_cap, OFF + t, OFF + t); sD0[t] = t < n ? (T)dv : T(0); }
+    for (int t = tid; t < 16 * NB; t += 1024) {
+      double dv = lam_hat(Lam, Dg, d.ldR, nfull, d.n_cap, OFF + t, OFF + t);
+      if (MODE == CH_GRAM && d.gram_parts == 3) {
+        if (t >= 64) dv += lam_hat(Lam + d.lam_part, Dg, d.ldR, nfull, d.n_cap, t, t);
+        if (t >= 128) dv += lam_hat(Lam + 2 * d.lam_part, Dg, d.ldR, nfull, d.n_cap, t, t);
+      }
+      sD0[t] = t < n ? (T)dv : T(0);
+    }
   const T tol = T(64.0 * 2.220446049250313e-16);
   int nskip = 0;
   bool badpiv = false;   // factorization of S: a pivot that is not positive (P or S lost positive definiteness) -> STAT_ERR bit 2

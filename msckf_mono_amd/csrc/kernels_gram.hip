@@ -111,13 +111,20 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int nb, int npai
   // sorted by first slot (k_select), every column of the panel is zero for the others, so the K loop runs over a
   // prefix of the sorted order (tracks end at the newest camera, so the stack is a staircase: ~35 % of the tracks
   // reach the first panel, ~75 % the second at a 30-camera window).
+  // SPLIT K: the stack is a staircase, so a tile of block row ti sums over a prefix of the sorted tracks that grows with ti
+  // (~35 % / 75 % / 100 % of them at a 30-camera window) and the launch used to wait for the one workgroup of the last
+  // diagonal tile.  With d.gram_parts == 3 a tile of block row ti is cut into min(ti + 1, 3) workgroups over contiguous
+  // chunk ranges of its K loop (1 + 1 + 1, 2 + 2, 3: ten workgroups of about equal length per trajectory instead of six);
+  // each writes its partial sum to its own copy of Lam^ (d.lam_part apart) and the blocked Cholesky adds the copies, in a
+  // fixed order, while it loads (kernels_chol.hip) -- no atomics, no extra pass, bit-reproducible.
   const int np_cap = ldL / 64;                       // panels the buffers hold
-  int ti = 0, tj0 = 0;
+  int ti = 0, tj0 = 0, part = 0, nparts = 1;
   {
     int rem = bx;
     for (ti = 0; ti < np_cap; ++ti) {
-      const int ng = (np_cap - ti + GT_MAX - 1) / GT_MAX;
-      if (rem < ng) { tj0 = ti + GT_MAX * rem; break; }
+      nparts = d.gram_parts > 1 ? min(ti + 1, d.gram_parts) : 1;
+      const int ng = (np_cap - ti + GT_MAX - 1) / GT_MAX * nparts;
+      if (rem < ng) { tj0 = ti + GT_MAX * (rem / nparts); part = rem % nparts; break; }
       rem -= ng;
     }
   }
@@ -149,6 +156,9 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int nb, int npai
   }
   __syncthreads();
   const int KT = 3 * sCnt;
+  // this workgroup's share of the K loop: whole chunks [k_lo, KE)
+  const int nchunk_k = (KT + GK - 1) / GK;
+  const int k_lo = GK * (nchunk_k * part / nparts), KE = min(KT, GK * (nchunk_k * (part + 1) / nparts));
   GR_TICK(0);
   const int lr = tid >> 6, lc = tid & 63;
   const int wi = w & 1, wj = w >> 1;
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int nb, int npai
   auto stage = [&](const Stage& r, int kc) {
 #pragma unroll
     for (int it = 0; it < GK / 4; ++it) {
-      const bool ok = kc + lr + 4 * it < KT;
+      const bool ok = kc + lr + 4 * it < KE;
       sA[lr + 4 * it][lc] = (ok && ((r.ok >> it) & 1u)) ? r.a[it] : 0.0;
 #pragma unroll
       for (int u = 0; u < GT_MAX; ++u)
@@ -228,21 +238,21 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int nb, int npai
   };
   // group g takes the chunks g, g + 2, g + 4, ... (chunk = GK rows); the loop control runs on group 0's chunk (uniform for
   // the workgroup: both groups pass the same barriers), a group whose chunk lies past the end stages zeros and skips the MFMAs
-  const int goff = grp * GK;
-  if (goff < KT) fetch(r0, goff);
-  if (2 * GK + goff < KT) fetch(r1, 2 * GK + goff);
-  for (int kc = 0; kc < KT; kc += 4 * GK) {
+  const int goff = k_lo + grp * GK;
+  if (goff < KE) fetch(r0, goff);
+  if (2 * GK + goff < KE) fetch(r1, 2 * GK + goff);
+  for (int kc = 0; k_lo + kc < KE; kc += 4 * GK) {
     __syncthreads();
     stage(r0, kc + goff);
     __syncthreads();
-    if (kc + 4 * GK + goff < KT && !(dbg & 2)) fetch(r0, kc + 4 * GK + goff);
-    if (!(dbg & 4) && kc + goff < KT) compute();
-    if (kc + 2 * GK >= KT) break;
+    if (kc + 4 * GK + goff < KE && !(dbg & 2)) fetch(r0, kc + 4 * GK + goff);
+    if (!(dbg & 4) && kc + goff < KE) compute();
+    if (k_lo + kc + 2 * GK >= KE) break;
     __syncthreads();
     stage(r1, kc + 2 * GK + goff);
     __syncthreads();
-    if (kc + 6 * GK + goff < KT && !(dbg & 2)) fetch(r1, kc + 6 * GK + goff);
-    if (!(dbg & 4) && kc + 2 * GK + goff < KT) compute();
+    if (kc + 6 * GK + goff < KE && !(dbg & 2)) fetch(r1, kc + 6 * GK + goff);
+    if (!(dbg & 4) && kc + 2 * GK + goff < KE) compute();
   }
   // sum of the two groups through the (now free) stage area: group 1 stores, group 0 adds in a fixed order
   __syncthreads();
@@ -274,7 +284,7 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int nb, int npai
   // epilogue: Lam^ = (block-diagonal part, reduced by the launch that precedes this one on the stream) - sum B^T B.  Only the
   // lower triangle is read downstream (lam_hat): acc[u][ib][jb] holds rows 64 tj + 32 wj + 16 jb .., columns 64 ti + 32 wi +
   // 16 ib .. (transposed accumulation), one coalesced store per element; a diagonal tile is stored whole
-  double* Lam = d.Lam + (long)b * ldL * ldL;
+  double* Lam = d.Lam + (long)part * d.lam_part + (long)b * ldL * ldL;   // part 0 carries the block-diagonal term
   const double* Dgb = d.Dg + (long)b * d.n_cap * DG_STRIDE;
 #pragma unroll
   for (int u = 0; u < GT_MAX; ++u) {
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int nb, int npai
         for (int r = 0; r < 4; ++r) {
           const int j = 64 * tj + wj * 32 + jb * 16 + (lane >> 4) + 4 * r;     // row of Lam^ (>= the column, except inside a diagonal tile)
           const int i = 64 * ti + wi * 32 + ib * 16 + (lane & 15);            // column
-          const double val = lam_diag_term(Dgb, n, d.n_cap, i, j) - acc[u][ib][jb][r];
+          const double val = (part == 0 ? lam_diag_term(Dgb, n, d.n_cap, i, j) : 0.0) - acc[u][ib][jb][r];
           Lam[(long)j * ldL + i] = val;
         }
   }
@@ -530,15 +540,18 @@ void gram_cycles_read(unsigned long long* out40, int reset) {
 #endif
 
 template <class S>
-void launch_gram(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase) {
+void launch_gram(const Dev<S>& din, int b0, int nb, hipStream_t st, int phase) {
   if (nb <= 0) return;
+  Dev<S> d = din;
+  // split-K partial sums only where the consumer adds them up: the single-level blocked Cholesky (k_chol_mfma, CH_GRAM)
+  d.gram_parts = (d.compress == 3 && d.ldR <= 192 && d.lam_part > 0) ? 3 : 1;
 #ifdef MSCKF_ABLATE
   const int g_dbg = g_gram_dbg;
 #else
   const int g_dbg = 0;
 #endif
   int npairs = 0;                                             // SYRK workgroups: <= GT_MAX tiles of one block row each
-  for (int ti = 0; ti < d.ldR / 64; ++ti) npairs += (d.ldR / 64 - ti + GT_MAX - 1) / GT_MAX;
+  for (int ti = 0; ti < d.ldR / 64; ++ti) npairs += (d.ldR / 64 - ti + GT_MAX - 1) / GT_MAX * (d.gram_parts > 1 ? std::min(ti + 1, d.gram_parts) : 1);
   const int ndiag = (d.n_cap + 3) / 4;
   if (phase != 2) {
     // two launches of the same kernel: the block-diagonal reduction (short, many small workgroups) and the SYRK strips

@@ -1,19 +1,11 @@
 cd /root/repo
-O=gpurun_out/r03d; mkdir -p $O
-timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -30 > $O/pytest.txt
-timeout 700 python scripts/sweep_variants.py --steps 20 --windows 5 "streams=3,streamed=0" "streams=3" "streams=4,streamed=0" "streams=4" "streams=5" "streams=6" "streams=5,streamed=0" "streams=1,streamed=0" > $O/sweep.txt 2>&1
-MSCKF_HIP_GRAM_XCD=1 timeout 300 python scripts/sweep_variants.py --steps 20 --windows 5 "streams=4,streamed=0" "streams=1,streamed=0" > $O/sweep_gramxcd.txt 2>&1
+O=gpurun_out/r03e; mkdir -p $O
+timeout 1200 python -m pytest tests -m gpu -q -x 2>&1 | tail -30 > $O/pytest.txt
+timeout 700 python scripts/sweep_variants.py --steps 20 --windows 5 "streams=4,streamed=0" "streams=4" "streams=3,streamed=0" "streams=1,streamed=0" > $O/sweep.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 COMMON="--steps 10 --warmup 3 --no-cpu-baseline --no-early-accept-pass --no-upload-pass --repeats 1 --streams 1"
 rocprofv3 --kernel-trace --stats -d /tmp/p1 -o r -- python /root/repo/bench.py $COMMON > /tmp/b1.log 2>&1
 DB=$(find /tmp/p1 -name "*.db" | head -1)
 ROCPD_TAIL=20 python /root/repo/scripts/rocpd_summary.py $DB /root/repo/$O/kernel_stats_tail20.md > /dev/null
 cd /root/repo
-timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --streams 4 > $O/bench_s4.json 2> $O/bench.err
-timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_s3.json 2>> $O/bench.err
-tail -4 $O/pytest.txt; cat $O/sweep.txt $O/sweep_gramxcd.txt | cut -c1-200; head -14 $O/kernel_stats_tail20.md
-python - <<'P'
-import json
-for f in ("bench_s4","bench_s3"):
-    d=json.load(open("gpurun_out/r03d/%s.json"%f)); print(f, round(d["value"]), [round(x) for x in d["repeats"]["values"]], d["resident_inputs"]["median"])
-P
+tail -4 $O/pytest.txt; cat $O/sweep.txt | cut -c1-200; head -14 $O/kernel_stats_tail20.md
