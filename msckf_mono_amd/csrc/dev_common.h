@@ -69,6 +69,7 @@ struct Dev {
   // frame's prune: ncam after prune + 1) instead of ncam, which augmentState is incrementing meanwhile
   int ncam_bias; int* ncam_upd;
   int* nprev;   // [B] window size before the prune in flight (k_prune_gather -> k_prune_commit)
+  int* nres_upd;   // [B] n_resid at the start of the update in flight (k_feature -> k_select_diag)
   int gate_early;   // exact early accept of the chi-square gate by the bound |r_o|^2 / sigma^2 (k_feature), off by default
   // per-track products of k_feature
   int* trk_status; S* trk_pf; S* trk_gamma; S* trk_Hx; S* trk_V; S* trk_Zf; S* trk_ro; int* trk_first;
@@ -337,9 +338,10 @@ template <class S> void launch_augment(const Dev<S>& d, int b0, int nb, hipStrea
 template <class S> void launch_prune(const Dev<S>& d, int b0, int nb, hipStream_t st, const int* drop = nullptr, int drop_const = -1);
 template <class S> void launch_feature(const Dev<S>& d, int b0, int nb, hipStream_t st);
 template <class S> void launch_select(const Dev<S>& d, int b0, int nb, hipStream_t st);
+template <class S> void launch_select_diag(const Dev<S>& d, int b0, int nb, hipStream_t st);   // k_select + block-diagonal part of Lam^ in one launch
 // phase: 0 = stage 1 + merges, 1 = stage 1 only (chunk-local QR updates), 2 = merge tree only
 template <class S> void launch_compress(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase);
-// phase: 0 = both, 1 = Gram accumulation only, 2 = Cholesky only
+// phase: 0 = both, 1 = Gram accumulation only, 2 = Cholesky only, 3 = SYRK only (the block-diagonal part came with launch_select_diag)
 template <class S> void launch_gram(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase);
 template <class S> void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st);
 // blocked matrix-core Cholesky (kernels_chol.hip): [T | r_n] = chol(Lam^) for the information form; S = L L^T with

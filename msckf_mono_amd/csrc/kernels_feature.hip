@@ -230,6 +230,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
   const int b = b0 + bi, lane = threadIdx.x;
   const int F = d.trk_n[(long)bi * d.wl_stride_n];
   if (t >= F) return;
+  // tracks residualized before this update, for the block-diagonal reduction that runs in k_select's launch (it must not read
+  // n_resid while k_select updates it)
+  if (t == 0 && lane == 0) d.nres_upd[b] = (int)(d.n_resid[b] > 1000 ? 1000 : d.n_resid[b]);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int m_cap = d.m_cap;
   // G (symmetric, 2M x 2M) plus the appended r_o row 2M as a packed lower triangle: element (i, j), j <= i, at TRI(i, j)
@@ -755,8 +758,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
 // Once more than 3 tracks have been residualized the decisions are independent per track and run
 // lane-parallel; the first few frames of a run take the serial path.
 template <class S>
-__global__ __launch_bounds__(64) void k_select(Dev<S> d, int b0, int nb) {
-  const int i = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void select_body(const Dev<S>& d, const int b0, const int nb, const int i, const int lane) {
   if (i >= nb) return;
   const int b = b0 + i;
   const int F = d.trk_n[(long)i * d.wl_stride_n];
@@ -933,6 +935,79 @@ __global__ __launch_bounds__(64) void k_select(Dev<S> d, int b0, int nb) {
   }
 }
 
+template <class S>
+__global__ __launch_bounds__(64) void k_select(Dev<S> d, int b0, int nb) { select_body<S>(d, b0, nb, (int)blockIdx.x, (int)threadIdx.x); }
+
+// k_select and the block-diagonal part of Lam^ (sum h^T h per camera slot, sum h^T r; information-form route) in ONE launch:
+// both only read what k_feature left behind, both are latency-bound (one wavefront per trajectory: 11 us; one per camera
+// slot: 16 us), and as two launches they ran one after the other.  Workgroup ndiag of a trajectory is k_select (its first
+// wavefront); workgroups 0 .. ndiag - 1 reduce four camera slots each, one wavefront per slot, lanes over ALL tracks of the
+// update with the inclusion decision re-derived from the raw status bits (k_select's rule, msckf.h:352-399):
+//   steady state: M >= 2, motion ok, triangulation valid, gate passed;
+//   while fewer than 4 tracks have ever been residualized (Q4, msckf.h:354) the motion check is skipped up to and including
+//   the track that brings the count to 4 -- found by scanning the tracks in order from the count k_feature recorded at the
+//   start of the update (nres_upd: n_resid itself is being updated by the k_select workgroup of this very launch).
+// Two dependent load levels (status | slot map -> Jacobian block) instead of three (sorted order -> slot map -> block).
+template <class S>
+__global__ __launch_bounds__(256) void k_select_diag(Dev<S> d, int b0, int nb, int ndiag) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = blockIdx.y;
+  if ((int)blockIdx.x == ndiag) { if (tid < 64) select_body<S>(d, b0, nb, i, tid); return; }
+  const int b = b0 + i;
+  const int N = d.ncam[b], F = d.trk_n[(long)i * d.wl_stride_n];
+  const int s = 4 * (int)blockIdx.x + w;
+  if (s >= N) return;
+  const int f_cap = d.f_cap, m_cap = d.m_cap;
+  const int* stt = d.trk_status + (long)b * f_cap;
+  const int* Mv = d.trk_M + (long)i * d.wl_stride_f;
+  constexpr int ALL = ST_MOTION_OK | ST_TRI_VALID | ST_GATE_PASS;
+  int tcut = 0;                                      // tracks below tcut skip the motion check (Q4)
+  if (d.mode == 0 && F > 0) {
+    int need = 4 - d.nres_upd[b];                    // valid tracks still to come before the motion check applies
+    if (need > 0) {
+      tcut = F;
+      for (int t0 = 0; t0 < F && need > 0; t0 += 64) {
+        const int t = t0 + lane;
+        const bool v = t < F && Mv[t] >= 2 && (stt[t] & ST_TRI_VALID);
+        unsigned long long m = __ballot(v);
+        const int c = __popcll(m);
+        if (c < need) { need -= c; continue; }
+        int pos = 0;
+        for (int k = 0; k < need; ++k) { pos = __builtin_ctzll(m); m &= m - 1; }
+        tcut = t0 + pos + 1; need = 0;
+      }
+    }
+  }
+  double acc[27];
+#pragma unroll
+  for (int e = 0; e < 27; ++e) acc[e] = 0.0;
+  for (int t = lane; t < F; t += 64) {
+    const long tb = (long)b * f_cap + t;
+    const int sx = stt[t], M = Mv[t];
+    const int oi = d.trk_inv[tb * d.n_cap + s];      // issued with the status loads; meaningful only for residualized tracks
+    const int need_bits = t < tcut ? (ST_TRI_VALID | ST_GATE_PASS) : ALL;
+    if (M < 2 || (sx & need_bits) != need_bits || oi < 0) continue;
+    const long h0i = (tb * m_cap + oi) * 12;
+    const S* rw = d.trk_rw + tb * 2 * m_cap + 2 * oi;
+    double h0[6], h1[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { h0[k] = (double)ld_hx(d, h0i + k); h1[k] = (double)ld_hx(d, h0i + 6 + k); }
+    const double r0 = (double)rw[0], r1 = (double)rw[1];
+    int e = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int c = a; c < 6; ++c) acc[e++] += h0[a] * h0[c] + h1[a] * h1[c];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) acc[21 + a] += h0[a] * r0 + h1[a] * r1;
+  }
+  double* out = d.Dg + ((long)b * d.n_cap + s) * DG_STRIDE;
+#pragma unroll
+  for (int e = 0; e < 27; ++e) {
+    const double v = wave_sum(acc[e]);
+    if (lane == 0) out[e] = v;
+  }
+}
+
 size_t feature_lds_bytes(int m_cap, size_t scalar) {
   const size_t r2 = 2 * (size_t)m_cap + 1;
   const size_t x = std::max<size_t>((size_t)m_cap * 12, 256 + 2 * (size_t)m_cap * 3);
@@ -964,10 +1039,18 @@ void launch_select(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0) return;
   hipLaunchKernelGGL(k_select<S>, dim3(nb), dim3(64), 0, st, d, b0, nb);
 }
+template <class S>
+void launch_select_diag(const Dev<S>& d, int b0, int nb, hipStream_t st) {
+  if (nb <= 0) return;
+  const int ndiag = (d.n_cap + 3) / 4;
+  hipLaunchKernelGGL(k_select_diag<S>, dim3(ndiag + 1, nb), dim3(256), 0, st, d, b0, nb, ndiag);
+}
 
 template void launch_feature<float>(const Dev<float>&, int, int, hipStream_t);
 template void launch_feature<double>(const Dev<double>&, int, int, hipStream_t);
 template void launch_select<float>(const Dev<float>&, int, int, hipStream_t);
 template void launch_select<double>(const Dev<double>&, int, int, hipStream_t);
+template void launch_select_diag<float>(const Dev<float>&, int, int, hipStream_t);
+template void launch_select_diag<double>(const Dev<double>&, int, int, hipStream_t);
 
 }  // namespace msckf

@@ -190,12 +190,15 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int nb, int npai
       for (int u = 0; u < GT_MAX; ++u) okm |= (((unsigned)(cb_col[u] - c_lo) < c_w) || cb_isn[u]) ? (1u << (8 * (u + 1) + it)) : 0u;
     }
     r.ok = okm;
+    // every lane loads (no branch, no wait between the loads), but a lane whose column lies outside the track's slot range
+    // reads one fixed, always-cached word instead of a row element nobody wrote: ~45 % of the row elements at cfg3
+    const double* dummy = d.Dg;
 #pragma unroll
     for (int it = 0; it < GK / 4; ++it) {
-      r.a[it] = rows[it][64 * ti + lc];
+      r.a[it] = *(((okm >> it) & 1u) ? rows[it] + 64 * ti + lc : dummy);
 #pragma unroll
       for (int u = 0; u < GT_MAX; ++u)
-        if (tj0 + u > ti && tj0 + u < nt) r.b[u][it] = rows[it][64 * (tj0 + u) + lc];
+        if (tj0 + u > ti && tj0 + u < nt) r.b[u][it] = *(((okm >> (8 * (u + 1) + it)) & 1u) ? rows[it] + 64 * (tj0 + u) + lc : dummy);
     }
   };
   auto stage = [&](const Stage& r, int kc) {
@@ -554,13 +557,14 @@ void launch_gram(const Dev<S>& din, int b0, int nb, hipStream_t st, int phase) {
   for (int ti = 0; ti < d.ldR / 64; ++ti) npairs += (d.ldR / 64 - ti + GT_MAX - 1) / GT_MAX * (d.gram_parts > 1 ? std::min(ti + 1, d.gram_parts) : 1);
   const int ndiag = (d.n_cap + 3) / 4;
   if (phase != 2) {
+    // (phase 3: the block-diagonal reduction already ran in k_select's launch, launch_select_diag)
     // two launches of the same kernel: the block-diagonal reduction (short, many small workgroups) and the SYRK strips
     // (MFMA-bound, <= 192 workgroups).  In ONE launch the dispatcher packs strips two to a CU behind the reduction
     // workgroups and they share the matrix cores (measured: MFMA phase 2x longer).
-    if (!(g_dbg & 1)) hipLaunchKernelGGL(k_gram_diag<S>, dim3(ndiag, nb), dim3(256), 0, st, d, b0);
+    if (!(g_dbg & 1) && phase != 3) hipLaunchKernelGGL(k_gram_diag<S>, dim3(ndiag, nb), dim3(256), 0, st, d, b0);
     hipLaunchKernelGGL(k_gram<S>, dim3(nb * npairs), dim3(512), gram_lds_bytes(), st, d, b0, nb, npairs, g_dbg, 0);
   }
-  if (phase == 1) return;
+  if (phase == 1 || phase == 3) return;
   // k_chol_blk (blocked, trailing update on the f64 matrix cores) is 10 % faster than k_chol_T in isolation (104 vs
   // 114 us) but holds the whole register file of its CU (256 VGPR + 188 AGPR), so nothing of the other slice's stream
   // co-schedules with it: 3 % slower end to end with two streams.  Kept selectable (msckf_hip_set_compression(h, 2)).

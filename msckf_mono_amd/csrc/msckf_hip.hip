@@ -278,7 +278,7 @@ struct Batch : BatchBase {
     }
     rc |= dalloc(&d.PHt, Bz * dn); rc |= dalloc(&d.Smat, Bz * nl); rc |= dalloc(&d.Linv, Bz * nl); rc |= dalloc(&d.W, Bz * dn);
     rc |= dalloc(&d.K, Bz * dn); rc |= dalloc(&d.A, Bz * pl); rc |= dalloc(&d.AP, Bz * pl); rc |= dalloc(&d.X, Bz * pl); rc |= dalloc(&d.dx, Bz * d.ld);
-    rc |= dalloc(&d.keep, Bz * n_cap); rc |= dalloc(&d.nkeep, Bz); rc |= dalloc(&d.ncam_upd, Bz); rc |= dalloc(&d.nprev, Bz);
+    rc |= dalloc(&d.keep, Bz * n_cap); rc |= dalloc(&d.nkeep, Bz); rc |= dalloc(&d.ncam_upd, Bz); rc |= dalloc(&d.nprev, Bz); rc |= dalloc(&d.nres_upd, Bz);
     rc |= dalloc(&d_pfin, TF * 4); d.trk_pfin = d_pfin; d.mode = 0; d.joseph = 0; d.ncam_bias = 0;
     rd_cap = 64;
     rc |= dalloc(&d_rd, Bz * rd_cap * RD_STRIDE);
@@ -472,9 +472,10 @@ struct Batch : BatchBase {
     Dev<S> v = vin;
     if (compress_route >= 0) v.compress = (compress_route && d.trk_B) ? compress_route : 0;
     if (!feature_done) { stage_begin(2, q); launch_feature<S>(v, b0, nb, q); stage_end(2, q); }
-    stage_begin(7, q); launch_select<S>(v, b0, nb, q); stage_end(7, q);
+    // information form: k_select and the block-diagonal reduction share a launch (both only read k_feature's outputs)
+    stage_begin(7, q); if (v.compress) launch_select_diag<S>(v, b0, nb, q); else launch_select<S>(v, b0, nb, q); stage_end(7, q);
     if (v.compress) {
-      stage_begin(3, q); launch_gram<S>(v, b0, nb, q, 1); stage_end(3, q);
+      stage_begin(3, q); launch_gram<S>(v, b0, nb, q, 3); stage_end(3, q);
       stage_begin(4, q); launch_gram<S>(v, b0, nb, q, 2); stage_end(4, q);
     } else {
       stage_begin(3, q); launch_compress<S>(v, b0, nb, q, 1); stage_end(3, q);
