@@ -149,8 +149,9 @@ int msckf_hip_scenario_pin(msckf_hip_handle h, int f0, int f1);
 int msckf_hip_set_upload_ring(msckf_hip_handle h, int depth, int mode);
 int msckf_hip_sync(msckf_hip_handle h);
 /* HIP-event stage timing: enable, run, sync, then read accumulated milliseconds and launch counts for
- * stages 0 propagate, 1 augment, 2 k_feature, 3 compression A (k_gram_diag + k_gram | TSQR stage 1), 4 compression B
- * (k_chol_mfma | TSQR merge), 5 kalman, 6 prune, 7 k_select.  (While profiling, run_frames launches propagate and
+ * stages 0 propagate, 1 augment, 2 k_feature, 3 compression A (k_gram | TSQR stage 1), 4 compression B
+ * (k_chol_mfma | TSQR merge), 5 kalman, 6 prune, 7 k_select (information form: k_select_diag, which also reduces the
+ * block-diagonal part of the Gram matrix).  (While profiling, run_frames launches propagate and
  * augmentState separately; otherwise they share one launch.) */
 int msckf_hip_profile_enable(msckf_hip_handle h, int on);
 int msckf_hip_profile_read(msckf_hip_handle h, double* ms8, int* count8);

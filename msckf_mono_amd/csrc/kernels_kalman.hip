@@ -244,6 +244,9 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   // register-staged software pipeline: the global loads of tile t+1 are in flight while tile t runs on the MFMAs
+  // (measured and rejected, round 3: a second register stage -- tile t+2 in flight behind two tiles of MFMAs: 80 registers,
+  // PHt / S / downdate 21.8 / 23.6 / 31.7 -> 23.2 / 24.9 / 32.4 us; with ~0.5 us of MFMA per tile and six tiles per workgroup
+  // these launches are bound by their fixed start-up and drain, not by exposed load latency)
   constexpr int NQ = GT / 4;
   S ra[NQ], rb[NQ];
   const int a_i = i0 + (tid & 63), a_ic = min(a_i, M - 1);
