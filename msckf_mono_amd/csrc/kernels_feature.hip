@@ -545,6 +545,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
     for (int s2 = 0; s2 < 2; ++s2) qr[s2] = r[s2] - (v[s2][0] * y[0] + v[s2][1] * y[1] + v[s2][2] * y[2]);
   }
 
+  // ---- TSQR route only: publish the compact representation of the projected block (V, Z scattered to state columns, Q^T r)
+  // HERE, before the gate: nothing below changes it, and V / Z / Q^T r would otherwise stay live across the gate's Cholesky
+  // (the kernel sits at its register budget: they were what got spilled, on every track of either route)
+  if (!(fdbg & 64) && !d.compress) {
+    S* oV = d.trk_V + (tb * 2 * m_cap) * 4;
+    S* oZ = d.trk_Zf + tb * 3 * (long)d.ldR;   // Z scattered to state columns: [3][ldR], zero where unobserved
+    S* oR = d.trk_ro + tb * 2 * m_cap;
+    if (act) {
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int row = row0 + s2;
+        oV[row * 4 + 0] = v[s2][0]; oV[row * 4 + 1] = v[s2][1]; oV[row * 4 + 2] = v[s2][2]; oV[row * 4 + 3] = 0;
+        oR[row] = qr[s2];   // (Q^T r)[row]; rows >= 3 are r_o
+      }
+    }
+    for (int e = lane; e < 3 * d.ldR; e += 64) oZ[e] = 0;
+    __syncthreads();
+    if (act)
+      for (int q = 0; q < 3; ++q) for (int k = 0; k < 6; ++k) oZ[(long)q * d.ldR + 6 * slot + k] = Zc[q][k];
+  }
+
   // ---- optional exact early accept of the gate (msckf_hip_set_gate_early_accept, off by default): S >= sigma^2 I, so
   // gamma = r_o^T S^-1 r_o <= |r_o|^2 / sigma^2.  If that bound is already below the chi-square threshold (with a
   // factor 2 in hand for the rounding of P's smallest eigenvalues) the track passes whatever G is: no G, no E, no
@@ -724,22 +744,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
 
   // ---- publish the compact representation of the projected block
   if (!(fdbg & 64)) {
-    if (!d.compress) {
-      S* oV = d.trk_V + (tb * 2 * m_cap) * 4;
-      S* oZ = d.trk_Zf + tb * 3 * (long)d.ldR;   // Z scattered to state columns: [3][ldR], zero where unobserved
-      S* oR = d.trk_ro + tb * 2 * m_cap;
-      if (act) {
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const int row = row0 + s2;
-          oV[row * 4 + 0] = v[s2][0]; oV[row * 4 + 1] = v[s2][1]; oV[row * 4 + 2] = v[s2][2]; oV[row * 4 + 3] = 0;
-          oR[row] = qr[s2];   // (Q^T r)[row]; rows >= 3 are r_o
-        }
-      }
-      for (int e = lane; e < 3 * d.ldR; e += 64) oZ[e] = 0;
-      __syncthreads();
-      if (act)
-        for (int q = 0; q < 3; ++q) for (int k = 0; k < 6; ++k) oZ[(long)q * d.ldR + 6 * slot + k] = Zc[q][k];
-    }
     if (lane == 0) {
       d.trk_status[tb] = status;
       d.trk_gamma[tb] = gamma;

@@ -1,5 +1,5 @@
 cd /root/repo
-O=gpurun_out/r03h; mkdir -p $O
+O=gpurun_out/r03i; mkdir -p $O
 timeout 1200 python -m pytest tests -m gpu -q -x 2>&1 | tail -30 > $O/pytest.txt
 timeout 700 python scripts/sweep_variants.py --steps 20 --windows 5 "streams=4,streamed=0" "streams=4" "streams=1,streamed=0" > $O/sweep.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
@@ -8,4 +8,4 @@ rocprofv3 --kernel-trace --stats -d /tmp/p1 -o r -- python /root/repo/bench.py $
 DB=$(find /tmp/p1 -name "*.db" | head -1)
 ROCPD_TAIL=20 python /root/repo/scripts/rocpd_summary.py $DB /root/repo/$O/kernel_stats_tail20.md > /dev/null
 cd /root/repo
-tail -4 $O/pytest.txt; cat $O/sweep.txt | cut -c1-200; head -16 $O/kernel_stats_tail20.md
+tail -4 $O/pytest.txt; cat $O/sweep.txt | cut -c1-200; head -8 $O/kernel_stats_tail20.md
