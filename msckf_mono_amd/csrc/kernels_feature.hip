@@ -15,9 +15,9 @@
 // (2M-3)*(15+6N); for the information-form route (default, kernels_gram.hip) it publishes B = Q_f^T [H_x | r] in f64
 // (reflectors redone in f64 so that H_o^T H_o = H_x^T H_x - B^T B holds to f64 rounding), the whitened residual and
 // the slot -> observation map.  The gate uses G = H_x P_cc H_x^T assembled from 6x6 blocks of P (192 M^2 flop instead
-// of the dense 2 rho D^2) and S = (Q^T G Q)[3:,3:] + sigma^2 I as a rank-6 correction of G, factored by a
-// register-resident Cholesky (8 x 8 lane grid, specialised on the track length; LDS fallback for 2M-2 > 64) with r_o
-// riding along as an extra row (gamma = |L^-1 r_o|^2).
+// of the dense 2 rho D^2) and never projects it: gamma = r_o^T S^-1 r_o is the generalized-least-squares residual
+// min_x (r - H_f x)^T N^-1 (r - H_f x), N = G + sigma^2 I, so ONE register-resident Cholesky of N (8 x 8 lane grid,
+// specialised on the track length) with [r^T ; H_f^T] riding along yields it from a 4 x 4 Schur corner (gate_chol).
 #include "chi2_table.h"
 #include "dev_common.h"
 
@@ -130,92 +130,128 @@ __device__ __forceinline__ void house3(T hf[2][3], int lane, T v[2][3], T Tm[3][
 #define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
 #define SYM(i, j) ((i) >= (j) ? TRI(i, j) : TRI(j, i))
 
-// Register-resident Cholesky of S = (Q^T G Q)[3:,3:] + sigma^2 I with the r_o row appended: the wavefront is an
-// 8 x 8 lane grid, lane (tx,ty) owns elements (8a+tx, 8b+ty) of the (rho+1) x rho lower trapezoid, NB = number of
-// 8 x 8 blocks in use (compile-time: a short track runs a proportionally shorter instruction stream).  One LDS
-// exchange of the pivot column per step.  Returns false when a pivot is not positive; gamma = |L^-1 r_o|^2.
+// Gate statistic without the projected block.  With N = G + sigma^2 I (2M x 2M, G = H_x P_cc H_x^T) and A any basis of the
+// left null space of H_f,
+//     gamma = r_o^T (A^T N A)^-1 r_o = min_x (r - H_f x)^T N^-1 (r - H_f x) = y^T y - b^T C^-1 b,
+//     y = L^-1 r,  Y = L^-1 H_f,  b = Y^T y,  C = Y^T Y,   N = L L^T
+// (the generalized-least-squares identity; gatingTest, msckf.h:1103-1124, computes the left-hand side).  So the gate is ONE
+// Cholesky of N with the four rows [r^T ; H_f^T] riding along and a zero 4 x 4 corner: after the 2M pivots the corner holds
+// -[y^T y, b^T ; b, C] (the Schur complement).  No null-space reflectors in working precision, no G V product, no rank-6
+// correction E of G, no gamma accumulation per pivot -- a third of the kernel's instructions in the form this replaces
+// (S = (Q^T G Q)[3:,3:] assembled from G, V and E = (G V) T - 1/2 V (T^T V^T G V T)).
+//
+// Register-resident: the wavefront is an 8 x 8 lane grid, lane (tx,ty) owns elements (8a+tx, 8b+ty) of the lower triangle of
+// the (2M + 4)-square matrix, NB = number of 8 x 8 blocks in use (compile-time: a short track runs a proportionally
+// shorter instruction stream).  One LDS exchange of the pivot column per step.  sG: packed lower triangle, rows 0 .. 2M-1
+// = G, rows 2M .. 2M+3 = [r ; H_f columns] (their corner entries are ignored).  Returns false when a pivot is not
+// positive; the corner is left in sC[qi * 4 + qj], qj <= qi.
 template <class S, int NB>
-__device__ __forceinline__ bool gate_chol(const S* sG, const S* sV, const S* sE, S* sC, int lane, int rho, int R2, S sig2, S& gamma) {
+__device__ __forceinline__ bool gate_chol(const S* sG, S* sC, int lane, int R2, S sig2) {
   bool spd = true;
-  {
-    // register-resident: the wavefront is an 8 x 8 grid, lane (tx,ty) owns elements (8a+tx, 8b+ty) of the
-    // (rho+1) x rho lower trapezoid; one LDS exchange of the pivot column per step, no workgroup barrier
-    const int tx = lane & 7, ty = lane >> 3;
-    constexpr int NBS = NB <= 8 ? 8 : 16, CB = 8 * NBS;   // exchange buffer: [2][8 tx][NBS block rows]
-    S A[NB][NB];
-    S vr[NB][3], er[NB][3];
+  const int tx = lane & 7, ty = lane >> 3, nr = R2 + 4;
+  constexpr int NBS = NB <= 8 ? 8 : 16, CB = 8 * NBS;   // exchange buffer: [2][8 tx][NBS block rows]
+  S A[NB][NB];
+  int rbase[NB];   // packed-triangle offset of row 8 a2 + tx (a block below the diagonal block never needs SYM's swap)
 #pragma unroll
-    for (int a2 = 0; a2 < NB; ++a2) {
+  for (int a2 = 0; a2 < NB; ++a2) rbase[a2] = TRI(8 * a2 + tx, 0);
+#pragma unroll
+  for (int b2 = 0; b2 < NB; ++b2) {
+    const int j = 8 * b2 + ty;
+#pragma unroll
+    for (int a2 = b2; a2 < NB; ++a2) {
       const int i = 8 * a2 + tx;
-      const bool ok = i < rho;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) { vr[a2][q] = ok ? sV[(3 + i) * 3 + q] : S(0); er[a2][q] = ok ? sE[(3 + i) * 3 + q] : S(0); }
-    }
-    int rbase[NB];   // packed-triangle offset of row 3 + 8 a2 + tx (a block below the diagonal block never needs SYM's swap)
-#pragma unroll
-    for (int a2 = 0; a2 < NB; ++a2) rbase[a2] = TRI(3 + 8 * a2 + tx, 3);
-#pragma unroll
-    for (int b2 = 0; b2 < NB; ++b2) {
-      const int j = 8 * b2 + ty;
-      const bool okj = j < rho;
-      S vc[3], ec[3];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) { vc[q] = okj ? sV[(3 + j) * 3 + q] : S(0); ec[q] = okj ? sE[(3 + j) * 3 + q] : S(0); }
-#pragma unroll
-      for (int a2 = b2; a2 < NB; ++a2) {
-        const int i = 8 * a2 + tx;
-        S val = 0;
-        if (okj && i < rho) {
-          val = sG[a2 > b2 ? rbase[a2] + j : SYM(3 + i, 3 + j)] - (vr[a2][0] * ec[0] + vr[a2][1] * ec[1] + vr[a2][2] * ec[2])
-                - (er[a2][0] * vc[0] + er[a2][1] * vc[1] + er[a2][2] * vc[2]);
-          if (i == j) val += sig2;
-        } else if (okj && i == rho) {
-          val = sG[TRI(R2, 3 + j)];            // appended row: r_o
-        }
-        A[a2][b2] = val;
+      S val = 0;
+      if (i < nr && j < nr && !(i >= R2 && j >= R2)) {
+        val = sG[a2 > b2 ? rbase[a2] + j : SYM(i, j)];
+        if (i == j) val += sig2;
       }
-    }
-    __syncthreads();
-    // pivot column exchange through sC, 2 x 64 entries laid out [buf][tx*8 + a]
-    int bufc = 0;
-#pragma unroll
-    for (int kb = 0; kb < NB; ++kb) {
-      const int kk_hi = min(8, rho - 8 * kb);
-      for (int kk = 0; kk < kk_hi; ++kk) {
-        const int k = 8 * kb + kk;
-        if (ty == kk) {
-#pragma unroll
-          for (int a2 = kb; a2 < NB; ++a2) sC[bufc * CB + tx * NBS + a2] = A[a2][kb];
-        }
-        __syncthreads();
-        const S dkk = sC[bufc * CB + kk * NBS + kb];
-        if (!(dkk > S(0))) { spd = false; break; }
-        // L is never needed itself: the update is A(i, j) -= A(i, k) A(j, k) / d and gamma += r_k^2 / d -- one reciprocal
-        // (hardware seed; double: + Newton) and one scaled operand instead of rsqrt + Newton and two scaled operands
-        const S dinv2 = sizeof(S) == 4 ? (S)__builtin_amdgcn_rcpf((float)dkk) : fast_rcp(dkk);
-        S li[NB], lj[NB];
-#pragma unroll
-        for (int a2 = kb; a2 < NB; ++a2) li[a2] = (a2 > kb || tx > kk) ? sC[bufc * CB + tx * NBS + a2] * dinv2 : S(0);
-#pragma unroll
-        for (int b2 = kb; b2 < NB; ++b2) lj[b2] = (b2 > kb || ty > kk) ? sC[bufc * CB + ty * NBS + b2] : S(0);
-        {   // y_k^2 = (r_o row)[k]^2 / d  ->  gamma
-          const S y = sC[bufc * CB + (rho & 7) * NBS + (rho >> 3)];
-          gamma += y * y * dinv2;
-        }
-#pragma unroll
-        for (int a2 = kb; a2 < NB; ++a2)
-#pragma unroll
-          for (int b2 = kb; b2 <= a2; ++b2) A[a2][b2] -= li[a2] * lj[b2];
-        bufc ^= 1;
-      }
-      if (!spd) break;
+      A[a2][b2] = val;
     }
   }
+  __syncthreads();
+  // pivot column exchange through sC, 2 x 64 entries laid out [buf][tx*8 + a]
+  int bufc = 0;
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    const int kk_hi = min(8, R2 - 8 * kb);
+    for (int kk = 0; kk < kk_hi; ++kk) {
+      if (ty == kk) {
+#pragma unroll
+        for (int a2 = kb; a2 < NB; ++a2) sC[bufc * CB + tx * NBS + a2] = A[a2][kb];
+      }
+      __syncthreads();
+      const S dkk = sC[bufc * CB + kk * NBS + kb];
+      if (!(dkk > S(0))) { spd = false; break; }
+      // L is never needed itself: the update is A(i, j) -= A(i, k) A(j, k) / d -- one reciprocal (hardware seed; double:
+      // + Newton) and one scaled operand instead of rsqrt + Newton and two scaled operands
+      const S dinv2 = sizeof(S) == 4 ? (S)__builtin_amdgcn_rcpf((float)dkk) : fast_rcp(dkk);
+      S li[NB], lj[NB];
+#pragma unroll
+      for (int a2 = kb; a2 < NB; ++a2) li[a2] = (a2 > kb || tx > kk) ? sC[bufc * CB + tx * NBS + a2] * dinv2 : S(0);
+#pragma unroll
+      for (int b2 = kb; b2 < NB; ++b2) lj[b2] = (b2 > kb || ty > kk) ? sC[bufc * CB + ty * NBS + b2] : S(0);
+#pragma unroll
+      for (int a2 = kb; a2 < NB; ++a2)
+#pragma unroll
+        for (int b2 = kb; b2 <= a2; ++b2) A[a2][b2] -= li[a2] * lj[b2];
+      bufc ^= 1;
+    }
+    if (!spd) break;
+  }
+  __syncthreads();
+  // the 4 x 4 corner (rows / columns 2M .. 2M+3) sits in the last two block rows / columns in use; NB may exceed the blocks
+  // in use by one (the long-track instantiations come in steps of two), so the last three are searched
+#pragma unroll
+  for (int a2 = (NB >= 3 ? NB - 3 : 0); a2 < NB; ++a2)
+#pragma unroll
+    for (int b2 = (NB >= 3 ? NB - 3 : 0); b2 <= a2; ++b2) {
+      const int qi = 8 * a2 + tx - R2, qj = 8 * b2 + ty - R2;
+      if (qi >= 0 && qi < 4 && qj >= 0 && qj <= qi) sC[qi * 4 + qj] = A[a2][b2];
+    }
+  __syncthreads();
   return spd;
 }
 
-// LONG: tracks of more than 33 observations (2M - 2 > 64: windows beyond 33 cameras) keep the gate's Cholesky in registers
-// too (up to 16 x 16 blocks per lane); a separate instantiation, so that the short-track kernel keeps its register budget.
+// gamma = y^T y - b^T C^-1 b from the corner -[y^T y, . ; b, C] left by the factorization (c[qi * 4 + qj], qj <= qi).  C is
+// 3 x 3 symmetric positive definite (H_f has full column rank for a triangulable feature); a direction H_f says nothing
+// about (pivot below rounding of C's diagonal) contributes nothing.
+template <class S>
+__device__ __forceinline__ S gate_gamma_from_corner(const S* c) {
+  const S yy = -c[0];
+  const S b0 = -c[4], b1 = -c[8], b2 = -c[12];
+  const S c00 = -c[5], c10 = -c[9], c11 = -c[10], c20 = -c[13], c21 = -c[14], c22 = -c[15];
+  const S tol = (sizeof(S) == 4 ? S(1e-6) : S(1e-13)) * (c00 + c11 + c22);
+  S g = yy;
+  // LDL^T forward elimination of [C | b]
+  if (c00 > tol) {
+    const S i0 = S(1) / c00;
+    const S l10 = c10 * i0, l20 = c20 * i0;
+    const S d1 = c11 - l10 * c10, e21 = c21 - l20 * c10, f1 = b1 - l10 * b0, f2 = b2 - l20 * b0;
+    g -= b0 * b0 * i0;
+    if (d1 > tol) {
+      const S i1 = S(1) / d1;
+      const S l21 = e21 * i1;
+      const S d2 = c22 - l20 * c20 - l21 * e21, h2 = f2 - l21 * f1;
+      g -= f1 * f1 * i1;
+      if (d2 > tol) g -= h2 * h2 / d2;
+    } else {
+      const S d2 = c22 - l20 * c20;
+      if (d2 > tol) g -= f2 * f2 / d2;
+    }
+  } else {
+    if (c11 > tol) {
+      const S i1 = S(1) / c11;
+      const S l21 = c21 * i1;
+      const S d2 = c22 - l21 * c21, h2 = b2 - l21 * b1;
+      g -= b1 * b1 * i1;
+      if (d2 > tol) g -= h2 * h2 / d2;
+    } else if (c22 > tol) g -= b2 * b2 / c22;
+  }
+  return g > S(0) ? g : S(0);
+}
+
+// LONG: tracks of more than 30 observations (2M + 4 > 64) keep the gate's Cholesky in registers too (up to 16 x 16 blocks
+// per lane); a separate instantiation, so that the short-track kernel keeps its register budget.
 template <class S, bool LONG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (sizeof(S) == 4 ? 4 : 2), sizeof(S) == 4 && !LONG ? 4 : 2))) void k_feature(Dev<S> d, int b0, int nb) {
   // all tracks of a trajectory on one XCD (xcd_item): the gate's 6 x 6 blocks of P then come out of an L2 that holds 1/8 of
@@ -235,15 +271,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
   if (t == 0 && lane == 0) d.nres_upd[b] = (int)(d.n_resid[b] > 1000 ? 1000 : d.n_resid[b]);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int m_cap = d.m_cap;
-  // G (symmetric, 2M x 2M) plus the appended r_o row 2M as a packed lower triangle: element (i, j), j <= i, at TRI(i, j)
-  // sHx (G stage only) shares its space with sC + sE (written after the G stage's closing barrier): 10 KB per wavefront at
-  // m_cap = 30, sixteen wavefronts per CU
-  S* sG = reinterpret_cast<S*>(smem_raw);              // [(2 m_cap + 1)(2 m_cap + 2) / 2]
-  S* sV = sG + (2 * m_cap + 1) * (2 * m_cap + 2) / 2;  // [2 m_cap][3]
-  S* sHx = sV + 2 * m_cap * 3;                         // [m_cap][12]
-  S* sC = sHx;                                         // [2][64] ([2][128] LONG) pivot-column exchange of the register Cholesky
-  S* sE = sC + 256;                                    // [2 m_cap][3]
-  const int xlen = (m_cap * 12 > 256 + 2 * m_cap * 3) ? m_cap * 12 : 256 + 2 * m_cap * 3;
+  // N's source G (symmetric, 2M x 2M) plus the four rows that ride along (r, the columns of H_f) as a packed lower triangle:
+  // element (i, j), j <= i, at TRI(i, j).  sHx (G stage only) shares its space with sC, the pivot-column exchange of the
+  // register Cholesky (written after the G stage's closing barrier): 9.9 KB per wavefront at m_cap = 30, sixteen per CU
+  S* sG = reinterpret_cast<S*>(smem_raw);              // [(2 m_cap + 4)(2 m_cap + 5) / 2]
+  S* sHx = sG + (2 * m_cap + 4) * (2 * m_cap + 5) / 2; // [m_cap][12]
+  S* sC = sHx;                                         // [2][64] ([2][128] LONG); afterwards the 4 x 4 corner
+  const int xlen = m_cap * 12 > 256 ? m_cap * 12 : 256;
   int* sSlot = reinterpret_cast<int*>(sHx + xlen);
 
   const long tb = (long)b * d.f_cap + t;               // per-track output index
@@ -521,73 +555,78 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
     }
   }
 
-  // ---- Householder QR of H_f_j (2M x 3) in working precision: compact WY for the gate (and the QR compression)
-  S v[2][3], Tm[3][3];
+  // ---- TSQR route only: Householder QR of H_f_j (2M x 3) in working precision as compact WY, Z_c = T^T (V_rows^T Hx_c)
+  // (3 x 6, local to the lane), Q^T r = r - V (T^T (V^T r)); published right away (nothing below changes them).  The
+  // information-form route needs none of this: its reflectors were the f64 ones above, and the gate below works on H_f itself.
   const int row0 = 2 * lane;
-  house3<S>(hf, lane, v, Tm);
-  // Z_c = T^T (V_rows^T Hx_c)  (3 x 6), local to the lane
-  S Zc[3][6];
-  {
-    S Wc[3][6];
-    for (int q = 0; q < 3; ++q) for (int k = 0; k < 6; ++k) Wc[q][k] = v[0][q] * hx[0][k] + v[1][q] * hx[1][k];
-    for (int q = 0; q < 3; ++q) for (int k = 0; k < 6; ++k) {
-      S s = 0;
-      for (int p = 0; p <= q; ++p) s += Tm[p][q] * Wc[p][k];
-      Zc[q][k] = s;
-    }
-  }
-  // Q^T r = r - V (T^T (V^T r))
-  S qr[2];
-  {
-    S wr[3], y[3];
-    for (int q = 0; q < 3; ++q) wr[q] = wave_sum(v[0][q] * r[0] + v[1][q] * r[1]);
-    for (int q = 0; q < 3; ++q) { S s = 0; for (int p = 0; p <= q; ++p) s += Tm[p][q] * wr[p]; y[q] = s; }
-    for (int s2 = 0; s2 < 2; ++s2) qr[s2] = r[s2] - (v[s2][0] * y[0] + v[s2][1] * y[1] + v[s2][2] * y[2]);
-  }
-
-  // ---- TSQR route only: publish the compact representation of the projected block (V, Z scattered to state columns, Q^T r)
-  // HERE, before the gate: nothing below changes it, and V / Z / Q^T r would otherwise stay live across the gate's Cholesky
-  // (the kernel sits at its register budget: they were what got spilled, on every track of either route)
-  if (!(fdbg & 64) && !d.compress) {
-    S* oV = d.trk_V + (tb * 2 * m_cap) * 4;
-    S* oZ = d.trk_Zf + tb * 3 * (long)d.ldR;   // Z scattered to state columns: [3][ldR], zero where unobserved
-    S* oR = d.trk_ro + tb * 2 * m_cap;
-    if (act) {
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int row = row0 + s2;
-        oV[row * 4 + 0] = v[s2][0]; oV[row * 4 + 1] = v[s2][1]; oV[row * 4 + 2] = v[s2][2]; oV[row * 4 + 3] = 0;
-        oR[row] = qr[s2];   // (Q^T r)[row]; rows >= 3 are r_o
+  S rr_ro = 0;                                         // |r_o|^2, for the optional early accept of the gate only
+  if (!d.compress) {
+    S hfw[2][3], v[2][3], Tm[3][3];
+    for (int i = 0; i < 2; ++i) for (int k = 0; k < 3; ++k) hfw[i][k] = hf[i][k];
+    house3<S>(hfw, lane, v, Tm);
+    S Zc[3][6];
+    {
+      S Wc[3][6];
+      for (int q = 0; q < 3; ++q) for (int k = 0; k < 6; ++k) Wc[q][k] = v[0][q] * hx[0][k] + v[1][q] * hx[1][k];
+      for (int q = 0; q < 3; ++q) for (int k = 0; k < 6; ++k) {
+        S s = 0;
+        for (int p = 0; p <= q; ++p) s += Tm[p][q] * Wc[p][k];
+        Zc[q][k] = s;
       }
     }
-    for (int e = lane; e < 3 * d.ldR; e += 64) oZ[e] = 0;
-    __syncthreads();
-    if (act)
-      for (int q = 0; q < 3; ++q) for (int k = 0; k < 6; ++k) oZ[(long)q * d.ldR + 6 * slot + k] = Zc[q][k];
+    S qr[2];
+    {
+      S wr[3], y[3];
+      for (int q = 0; q < 3; ++q) wr[q] = wave_sum(v[0][q] * r[0] + v[1][q] * r[1]);
+      for (int q = 0; q < 3; ++q) { S s = 0; for (int p = 0; p <= q; ++p) s += Tm[p][q] * wr[p]; y[q] = s; }
+      for (int s2 = 0; s2 < 2; ++s2) qr[s2] = r[s2] - (v[s2][0] * y[0] + v[s2][1] * y[1] + v[s2][2] * y[2]);
+    }
+    if (d.gate_early) {
+      S rr = 0;
+      for (int s2 = 0; s2 < 2; ++s2) { const int row = row0 + s2; if (row >= 3 && row < 2 * M) rr += qr[s2] * qr[s2]; }
+      rr_ro = wave_sum(rr);
+    }
+    if (!(fdbg & 64)) {
+      S* oV = d.trk_V + (tb * 2 * m_cap) * 4;
+      S* oZ = d.trk_Zf + tb * 3 * (long)d.ldR;   // Z scattered to state columns: [3][ldR], zero where unobserved
+      S* oR = d.trk_ro + tb * 2 * m_cap;
+      if (act) {
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int row = row0 + s2;
+          oV[row * 4 + 0] = v[s2][0]; oV[row * 4 + 1] = v[s2][1]; oV[row * 4 + 2] = v[s2][2]; oV[row * 4 + 3] = 0;
+          oR[row] = qr[s2];   // (Q^T r)[row]; rows >= 3 are r_o
+        }
+      }
+      for (int e = lane; e < 3 * d.ldR; e += 64) oZ[e] = 0;
+      __syncthreads();
+      if (act)
+        for (int q = 0; q < 3; ++q) for (int k = 0; k < 6; ++k) oZ[(long)q * d.ldR + 6 * slot + k] = Zc[q][k];
+    }
+  } else if (d.gate_early) {
+    // |r_o|^2 = |r|^2 - |first three entries of Q_f^T r|^2 (the f64 reflectors above)
+    const S rn = wave_sum(r[0] * r[0] + r[1] * r[1]);
+    rr_ro = rn - (S)(cq[0] * cq[0] + cq[1] * cq[1] + cq[2] * cq[2]);
   }
 
   // ---- optional exact early accept of the gate (msckf_hip_set_gate_early_accept, off by default): S >= sigma^2 I, so
   // gamma = r_o^T S^-1 r_o <= |r_o|^2 / sigma^2.  If that bound is already below the chi-square threshold (with a
-  // factor 2 in hand for the rounding of P's smallest eigenvalues) the track passes whatever G is: no G, no E, no
-  // Cholesky.  The decision is the reference's; trk_gamma then holds the bound and the status carries ST_GATE_BOUND.
+  // factor 2 in hand for the rounding of P's smallest eigenvalues) the track passes whatever G is: no G, no Cholesky.
+  // The decision is the reference's; trk_gamma then holds the bound and the status carries ST_GATE_BOUND.
   const S thresh = S(c_chi2[M < 98 ? M : 98]);   // table[dof+1], dof = M-1   (:433, :1117)
   bool spd = true;
   S gamma = 0;
   bool early = false;
   if (d.gate_early) {
-    S rr = 0;
-    for (int s2 = 0; s2 < 2; ++s2) { const int row = row0 + s2; if (row >= 3 && row < 2 * M) rr += qr[s2] * qr[s2]; }
-    rr = wave_sum(rr);
-    const S ub = rr / prm[PRM_SIG2];
+    const S ub = rr_ro / prm[PRM_SIG2];
     if (ub < S(0.5) * thresh) { early = true; gamma = ub; status |= ST_GATE_BOUND; }
   }
   if (!early) {
-  // ---- stage H_x, V in LDS; G = H_x P_cc H_x^T from 6x6 blocks of P (upper block-triangle + mirror)
+  // ---- stage H_x in LDS; G = H_x P_cc H_x^T from 6x6 blocks of P (upper block-triangle + mirror)
   if (lane < m_cap) {
     for (int i = 0; i < 2; ++i) for (int k = 0; k < 6; ++k) sHx[lane * 12 + i * 6 + k] = hx[i][k];
-    for (int s2 = 0; s2 < 2; ++s2) for (int q = 0; q < 3; ++q) sV[(row0 + s2) * 3 + q] = v[s2][q];
   }
   __syncthreads();
-  const int R2 = 2 * M, rho = R2 - 3;
+  const int R2 = 2 * M;
   const S* P = d.P + (long)b * ld * ld;
   {
     // pairs (a, bq), a <= bq, enumerated as a rectangle of M/2 (rounded up) rows of width M | 1: row k of the rectangle
@@ -653,92 +692,59 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
       }
     }
   }
-  __syncthreads();
-  // ---- E = (G V) T - 1/2 V (T^T V^T G V T)
-  if (!(fdbg & 128)) {
-    // rows row0, row0 + 1 of G V with G in its packed triangle: the address of G(row0, c) advances by 1 up to the diagonal
-    // and by c + 1 beyond it (running index instead of a triangular-number computation per element), row0 + 1 sits
-    // row0 + 1 entries further below the diagonal and 1 entry further beyond it
-    S gv[2][3] = {{0, 0, 0}, {0, 0, 0}};
-    if (row0 < R2 && !(fdbg & 16)) {
-      int idx = TRI(row0, 0);
-      for (int c = 0; c < R2; ++c) {
-        const S g0 = sG[idx], g1 = sG[idx + (c <= row0 ? row0 + 1 : 1)];
-        const S v0 = sV[c * 3], v1 = sV[c * 3 + 1], v2 = sV[c * 3 + 2];
-        gv[0][0] += g0 * v0; gv[0][1] += g0 * v1; gv[0][2] += g0 * v2;
-        gv[1][0] += g1 * v0; gv[1][1] += g1 * v1; gv[1][2] += g1 * v2;
-        idx += c < row0 ? 1 : c + 1;
-      }
-    }
-    S vgv[3][3];
-    for (int p = 0; p < 3; ++p) for (int q = 0; q < 3; ++q) vgv[p][q] = wave_sum(v[0][p] * gv[0][q] + v[1][p] * gv[1][q]);
-    S tmp[3][3], C3[3][3];
-    for (int p = 0; p < 3; ++p) for (int q = 0; q < 3; ++q) { S s = 0; for (int k = 0; k < 3; ++k) s += vgv[p][k] * Tm[k][q]; tmp[p][q] = s; }
-    for (int p = 0; p < 3; ++p) for (int q = 0; q < 3; ++q) { S s = 0; for (int k = 0; k < 3; ++k) s += Tm[k][p] * tmp[k][q]; C3[p][q] = s; }
+  // ---- the four rows that ride along: r^T and the three columns of H_f (rows 2M .. 2M+3 of the packed triangle)
+  if (act) {
     for (int s2 = 0; s2 < 2; ++s2) {
       const int row = row0 + s2;
-      if (row < R2)
-        for (int q = 0; q < 3; ++q) {
-          S y1 = 0, vc = 0;
-          for (int k = 0; k < 3; ++k) { y1 += gv[s2][k] * Tm[k][q]; vc += v[s2][k] * C3[k][q]; }
-          sE[row * 3 + q] = y1 - S(0.5) * vc;
-        }
+      sG[TRI(R2, row)] = r[s2];
+      for (int q = 0; q < 3; ++q) sG[TRI(R2 + 1 + q, row)] = hf[s2][q];
     }
-    // r_o rides along as the extra row 2M of the factorisation
-    for (int s2 = 0; s2 < 2; ++s2) { const int row = row0 + s2; if (row >= 3 && row < R2) sG[TRI(R2, row)] = qr[s2]; }
   }
   __syncthreads();
-  // ---- S = (Q^T G Q)[3:,3:] + sigma^2 I, Cholesky with the r_o row appended, gamma = |L^-1 r_o|^2
+  // ---- gamma = r_o^T S^-1 r_o through N = G + sigma^2 I = L L^T (gate_chol): y = L^-1 r, Y = L^-1 H_f, gamma = y^T y - b^T C^-1 b
   const S sig2 = prm[PRM_SIG2];
-  (void)0;
+  const int nr = R2 + 4;
   if (fdbg & 4) { gamma = 0; }
-  else if (LONG && rho + 1 > 64 && rho + 1 <= (sizeof(S) == 4 ? 128 : 96)) {   // double: 12 blocks fit the register file, longer tracks take the LDS path
-    const int nbr = (rho >> 3) + 1;
-    if (nbr <= 10) spd = gate_chol<S, LONG ? 10 : 1>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma);
-    else if (nbr <= 12) spd = gate_chol<S, LONG ? 12 : 1>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma);
-    else if (nbr <= 14) spd = gate_chol<S, (LONG && sizeof(S) == 4) ? 14 : 1>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma);
-    else spd = gate_chol<S, (LONG && sizeof(S) == 4) ? 16 : 1>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma);
+  else if (LONG && nr > 64 && nr <= (sizeof(S) == 4 ? 128 : 96)) {   // double: 12 blocks fit the register file, longer tracks take the LDS path
+    const int nbr = (nr + 7) >> 3;
+    if (nbr <= 10) spd = gate_chol<S, LONG ? 10 : 1>(sG, sC, lane, R2, sig2);
+    else if (nbr <= 12) spd = gate_chol<S, LONG ? 12 : 1>(sG, sC, lane, R2, sig2);
+    else if (nbr <= 14) spd = gate_chol<S, (LONG && sizeof(S) == 4) ? 14 : 1>(sG, sC, lane, R2, sig2);
+    else spd = gate_chol<S, (LONG && sizeof(S) == 4) ? 16 : 1>(sG, sC, lane, R2, sig2);
   }
-  else if (rho + 1 <= 64) {
-    const int nbr = (rho >> 3) + 1;   // 8 x 8 blocks in use (wave-uniform)
+  else if (nr <= 64) {
+    const int nbr = (nr + 7) >> 3;   // 8 x 8 blocks in use (wave-uniform)
     switch (nbr) {
-      case 1: spd = gate_chol<S, 1>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma); break;
-      case 2: spd = gate_chol<S, 2>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma); break;
-      case 3: spd = gate_chol<S, 3>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma); break;
-      case 4: spd = gate_chol<S, 4>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma); break;
-      case 5: spd = gate_chol<S, 5>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma); break;
-      case 6: spd = gate_chol<S, 6>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma); break;
-      case 7: spd = gate_chol<S, 7>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma); break;
-      default: spd = gate_chol<S, 8>(sG, sV, sE, sC, lane, rho, R2, sig2, gamma); break;
+      case 1: spd = gate_chol<S, 1>(sG, sC, lane, R2, sig2); break;
+      case 2: spd = gate_chol<S, 2>(sG, sC, lane, R2, sig2); break;
+      case 3: spd = gate_chol<S, 3>(sG, sC, lane, R2, sig2); break;
+      case 4: spd = gate_chol<S, 4>(sG, sC, lane, R2, sig2); break;
+      case 5: spd = gate_chol<S, 5>(sG, sC, lane, R2, sig2); break;
+      case 6: spd = gate_chol<S, 6>(sG, sC, lane, R2, sig2); break;
+      case 7: spd = gate_chol<S, 7>(sG, sC, lane, R2, sig2); break;
+      default: spd = gate_chol<S, 8>(sG, sC, lane, R2, sig2); break;
     }
   } else {
-    for (int i = 3 + lane; i < R2; i += 64) {
-      const S vi0 = sV[i * 3], vi1 = sV[i * 3 + 1], vi2 = sV[i * 3 + 2];
-      const S ei0 = sE[i * 3], ei1 = sE[i * 3 + 1], ei2 = sE[i * 3 + 2];
-      for (int j = 3; j <= i; ++j) {
-        S sv = sG[TRI(i, j)] - (vi0 * sE[j * 3] + vi1 * sE[j * 3 + 1] + vi2 * sE[j * 3 + 2])
-               - (ei0 * sV[j * 3] + ei1 * sV[j * 3 + 1] + ei2 * sV[j * 3 + 2]);
-        if (i == j) sv += sig2;
-        sG[TRI(i, j)] = sv;
-      }
-    }
+    // in place in the packed triangle (tracks too long for the register file): sigma^2 on the diagonal, zero corner, 2M pivots
+    for (int i = lane; i < R2; i += 64) sG[TRI(i, i)] += sig2;
+    if (lane < 16) { const int qi = lane >> 2, qj = lane & 3; if (qj <= qi) sG[TRI(R2 + qi, R2 + qj)] = 0; }
     __syncthreads();
-    for (int k = 3; k < R2; ++k) {
+    for (int k = 0; k < R2; ++k) {
       const S dkk = sG[TRI(k, k)];
       if (!(dkk > S(0))) { spd = false; break; }
       const S dinv = S(1) / dsqrt(dkk);
-      for (int i = k + 1 + lane; i <= R2; i += 64) sG[TRI(i, k)] *= dinv;
+      for (int i = k + 1 + lane; i < nr; i += 64) sG[TRI(i, k)] *= dinv;
       __syncthreads();
-      for (int i = k + 1 + lane; i <= R2; i += 64) {
+      for (int i = k + 1 + lane; i < nr; i += 64) {
         const S lik = sG[TRI(i, k)];
-        const int jmax = i < R2 ? i : R2 - 1;
-        for (int j = k + 1; j <= jmax; ++j) sG[TRI(i, j)] -= lik * sG[TRI(j, k)];
+        for (int j = k + 1; j <= i; ++j) sG[TRI(i, j)] -= lik * sG[TRI(j, k)];
       }
       __syncthreads();
     }
-    for (int k = 3 + lane; k < R2; k += 64) { const S y = sG[TRI(R2, k)]; gamma += y * y; }
-    gamma = wave_sum(gamma);
+    if (lane < 16) { const int qi = lane >> 2, qj = lane & 3; if (qj <= qi) sC[qi * 4 + qj] = sG[TRI(R2 + qi, R2 + qj)]; }
+    __syncthreads();
   }
+  if (spd && !(fdbg & 4)) gamma = gate_gamma_from_corner<S>(sC);
   }   // !early
   if (spd && gamma < thresh) status |= ST_GATE_PASS;
 
@@ -1013,9 +1019,9 @@ __global__ __launch_bounds__(256) void k_select_diag(Dev<S> d, int b0, int nb, i
 }
 
 size_t feature_lds_bytes(int m_cap, size_t scalar) {
-  const size_t r2 = 2 * (size_t)m_cap + 1;
-  const size_t x = std::max<size_t>((size_t)m_cap * 12, 256 + 2 * (size_t)m_cap * 3);
-  return (r2 * (r2 + 1) / 2 + 2 * (size_t)m_cap * 3 + x) * scalar + (size_t)m_cap * sizeof(int) + 16;
+  const size_t r2 = 2 * (size_t)m_cap + 4;
+  const size_t x = std::max<size_t>((size_t)m_cap * 12, 256);
+  return (r2 * (r2 + 1) / 2 + x) * scalar + (size_t)m_cap * sizeof(int) + 16;
 }
 
 // one-time, per-device setup (called from msckf_hip_create after hipSetDevice): chi-square table, LDS limits
@@ -1031,7 +1037,7 @@ template <class S>
 void launch_feature(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0) return;
   const size_t lds = feature_lds_bytes(d.m_cap, sizeof(S));
-  if (2 * d.m_cap - 2 > 64) hipLaunchKernelGGL((k_feature<S, true>), dim3(xcd_grid(nb, d.f_cap)), dim3(64), lds, st, d, b0, nb);
+  if (2 * d.m_cap + 4 > 64) hipLaunchKernelGGL((k_feature<S, true>), dim3(xcd_grid(nb, d.f_cap)), dim3(64), lds, st, d, b0, nb);
   else hipLaunchKernelGGL((k_feature<S, false>), dim3(xcd_grid(nb, d.f_cap)), dim3(64), lds, st, d, b0, nb);
 }
 #ifdef MSCKF_ABLATE
