@@ -130,6 +130,14 @@ __device__ __forceinline__ void house3(T hf[2][3], int lane, T v[2][3], T Tm[3][
 #define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
 #define SYM(i, j) ((i) >= (j) ? TRI(i, j) : TRI(j, i))
 
+// value of `v` in the lane whose byte index (lane << 2) is `src4`: ds_bpermute, the LDS crossbar without LDS memory
+__device__ __forceinline__ float lane_gather(float v, int src4) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(v))); }
+__device__ __forceinline__ double lane_gather(double v, int src4) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_ds_bpermute(src4, (int)(b & 0xffffffffLL)), hi = __builtin_amdgcn_ds_bpermute(src4, (int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // Gate statistic without the projected block.  With N = G + sigma^2 I (2M x 2M, G = H_x P_cc H_x^T) and A any basis of the
 // left null space of H_f,
 //     gamma = r_o^T (A^T N A)^-1 r_o = min_x (r - H_f x)^T N^-1 (r - H_f x) = y^T y - b^T C^-1 b,
@@ -142,14 +150,13 @@ __device__ __forceinline__ void house3(T hf[2][3], int lane, T v[2][3], T Tm[3][
 //
 // Register-resident: the wavefront is an 8 x 8 lane grid, lane (tx,ty) owns elements (8a+tx, 8b+ty) of the lower triangle of
 // the (2M + 4)-square matrix, NB = number of 8 x 8 blocks in use (compile-time: a short track runs a proportionally
-// shorter instruction stream).  One LDS exchange of the pivot column per step.  sG: packed lower triangle, rows 0 .. 2M-1
+// shorter instruction stream).  sG: packed lower triangle, rows 0 .. 2M-1
 // = G, rows 2M .. 2M+3 = [r ; H_f columns] (their corner entries are ignored).  Returns false when a pivot is not
 // positive; the corner is left in sC[qi * 4 + qj], qj <= qi.
 template <class S, int NB>
 __device__ __forceinline__ bool gate_chol(const S* sG, S* sC, int lane, int R2, S sig2) {
   bool spd = true;
   const int tx = lane & 7, ty = lane >> 3, nr = R2 + 4;
-  constexpr int NBS = NB <= 8 ? 8 : 16, CB = 8 * NBS;   // exchange buffer: [2][8 tx][NBS block rows]
   S A[NB][NB];
   int rbase[NB];   // packed-triangle offset of row 8 a2 + tx (a block below the diagonal block never needs SYM's swap)
 #pragma unroll
@@ -168,33 +175,34 @@ __device__ __forceinline__ bool gate_chol(const S* sG, S* sC, int lane, int R2, 
       A[a2][b2] = val;
     }
   }
-  __syncthreads();
-  // pivot column exchange through sC, 2 x 64 entries laid out [buf][tx*8 + a]
-  int bufc = 0;
+  // Pivot k = 8 kb + kk: the pivot itself is read from its owner lane (kk, kk) by v_readlane (an SGPR: the reciprocal starts at
+  // once), and the pivot column reaches the lanes through the LDS crossbar WITHOUT touching LDS memory (ds_bpermute): row
+  // 8 a + tx of the column lives in lane (tx, kk), row 8 b + ty in lane (ty, kk).  One crossbar round trip per pivot, no
+  // barrier, no exec-masked branches (the write column / barrier / read pivot / read column exchange this replaces was
+  // three to four serialized LDS round trips per pivot).
 #pragma unroll
   for (int kb = 0; kb < NB; ++kb) {
     const int kk_hi = min(8, R2 - 8 * kb);
     for (int kk = 0; kk < kk_hi; ++kk) {
-      if (ty == kk) {
-#pragma unroll
-        for (int a2 = kb; a2 < NB; ++a2) sC[bufc * CB + tx * NBS + a2] = A[a2][kb];
-      }
-      __syncthreads();
-      const S dkk = sC[bufc * CB + kk * NBS + kb];
+      const S dkk = wave_bcast(A[kb][kb], kk * 9);
       if (!(dkk > S(0))) { spd = false; break; }
       // L is never needed itself: the update is A(i, j) -= A(i, k) A(j, k) / d -- one reciprocal (hardware seed; double:
       // + Newton) and one scaled operand instead of rsqrt + Newton and two scaled operands
       const S dinv2 = sizeof(S) == 4 ? (S)__builtin_amdgcn_rcpf((float)dkk) : fast_rcp(dkk);
+      const int src_i = (kk * 8 + tx) << 2, src_j = (kk * 8 + ty) << 2;
       S li[NB], lj[NB];
 #pragma unroll
-      for (int a2 = kb; a2 < NB; ++a2) li[a2] = (a2 > kb || tx > kk) ? sC[bufc * CB + tx * NBS + a2] * dinv2 : S(0);
+      for (int a2 = kb; a2 < NB; ++a2) li[a2] = lane_gather(A[a2][kb], src_i);
 #pragma unroll
-      for (int b2 = kb; b2 < NB; ++b2) lj[b2] = (b2 > kb || ty > kk) ? sC[bufc * CB + ty * NBS + b2] : S(0);
+      for (int b2 = kb; b2 < NB; ++b2) lj[b2] = lane_gather(A[b2][kb], src_j);
+      li[kb] = tx > kk ? li[kb] : S(0);
+      lj[kb] = ty > kk ? lj[kb] : S(0);
+#pragma unroll
+      for (int a2 = kb; a2 < NB; ++a2) li[a2] *= dinv2;
 #pragma unroll
       for (int a2 = kb; a2 < NB; ++a2)
 #pragma unroll
         for (int b2 = kb; b2 <= a2; ++b2) A[a2][b2] -= li[a2] * lj[b2];
-      bufc ^= 1;
     }
     if (!spd) break;
   }
@@ -272,12 +280,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int m_cap = d.m_cap;
   // N's source G (symmetric, 2M x 2M) plus the four rows that ride along (r, the columns of H_f) as a packed lower triangle:
-  // element (i, j), j <= i, at TRI(i, j).  sHx (G stage only) shares its space with sC, the pivot-column exchange of the
-  // register Cholesky (written after the G stage's closing barrier): 9.9 KB per wavefront at m_cap = 30, sixteen per CU
+  // element (i, j), j <= i, at TRI(i, j).  sHx (G stage only) shares its space with sC, where the factorization leaves the
+  // 4 x 4 corner: 9.9 KB per wavefront at m_cap = 30, sixteen per CU
   S* sG = reinterpret_cast<S*>(smem_raw);              // [(2 m_cap + 4)(2 m_cap + 5) / 2]
   S* sHx = sG + (2 * m_cap + 4) * (2 * m_cap + 5) / 2; // [m_cap][12]
-  S* sC = sHx;                                         // [2][64] ([2][128] LONG); afterwards the 4 x 4 corner
-  const int xlen = m_cap * 12 > 256 ? m_cap * 12 : 256;
+  S* sC = sHx;                                         // [16]: the corner
+  const int xlen = m_cap * 12 > 16 ? m_cap * 12 : 16;
   int* sSlot = reinterpret_cast<int*>(sHx + xlen);
 
   const long tb = (long)b * d.f_cap + t;               // per-track output index
@@ -1020,7 +1028,7 @@ __global__ __launch_bounds__(256) void k_select_diag(Dev<S> d, int b0, int nb, i
 
 size_t feature_lds_bytes(int m_cap, size_t scalar) {
   const size_t r2 = 2 * (size_t)m_cap + 4;
-  const size_t x = std::max<size_t>((size_t)m_cap * 12, 256);
+  const size_t x = std::max<size_t>((size_t)m_cap * 12, 16);
   return (r2 * (r2 + 1) / 2 + x) * scalar + (size_t)m_cap * sizeof(int) + 16;
 }
 
