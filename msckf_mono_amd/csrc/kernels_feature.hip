@@ -415,7 +415,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
       const S dl[3] = {wave_bcast(dlc[0], cand), wave_bcast(dlc[1], cand), wave_bcast(dlc[2], cand)};
       const S na = sa - dl[0], nb = sb - dl[1], nr = srho - dl[2];
       delta_norm = lm_sqrt(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
-      const S new_cost = wave_sum(act ? tri_cost(T, na, nb, nr, zx, zy) : S(0));
+      // A step that no longer changes any of the three parameters (it is below half an ulp of each: the usual fate of the
+      // upper rungs of the ladder in the last outer iteration) gives bit for bit the cost already held in total_cost -- the
+      // same function of the same arguments -- so the candidate fails without being evaluated (same control flow, same result)
+      S new_cost = total_cost;
+      if (!(na == sa && nb == sb && nr == srho)) new_cost = wave_sum(act ? tri_cost(T, na, nb, nr, zx, zy) : S(0));
       if (new_cost < total_cost) {
         reduced = true; sa = na; sb = nb; srho = nr; total_cost = new_cost;
         const S lam_now = wave_bcast(lam_c, cand);

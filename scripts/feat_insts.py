@@ -7,8 +7,8 @@ every knob gets a freshly warmed-up filter and ONE knobbed frame (the last k_fea
 import os
 import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-KNOBS = [("full", 0), ("noLM", 1), ("noPload", 2), ("noG", 32), ("noChol", 4), ("noF64", 8), ("noGV", 16), ("noE", 128),
-         ("noPublish", 64), ("noMotion", 256), ("gate_off(G,E,chol)", 32 | 128 | 4), ("all", 1 | 32 | 128 | 4 | 8 | 64 | 256), ("full", 0)]
+KNOBS = [("full", 0), ("noLM", 1), ("noPload", 2), ("noG", 32), ("noChol", 4), ("noF64", 8),
+         ("noPublish", 64), ("noMotion", 256), ("gate_off(G,chol)", 32 | 4), ("all", 1 | 32 | 4 | 8 | 64 | 256), ("full", 0)]
 N, F, B = 30, 200, 64
 NF = N + 3
 

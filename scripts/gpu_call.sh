@@ -1,5 +1,5 @@
 cd /root/repo
-O=gpurun_out/r03i; mkdir -p $O
+O=gpurun_out/r03k; mkdir -p $O
 timeout 1200 python -m pytest tests -m gpu -q -x 2>&1 | tail -30 > $O/pytest.txt
 timeout 700 python scripts/sweep_variants.py --steps 20 --windows 5 "streams=4,streamed=0" "streams=4" "streams=1,streamed=0" > $O/sweep.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
