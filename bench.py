@@ -74,15 +74,15 @@ def alg_flops_update(Ms, N, K_imu=K_IMU):
 
 def executed_flops_update(Ms, N, K_imu=K_IMU):
     """FLOP of one filter update AS BUILT (the algorithm the kernels execute, 2 per FMA, useful work counted once) -> dict
-    per stage.  k_feature: triangulation + Jacobian (750 M), reflectors in S and f64 + Z / B^ (450 M), block-sparse gate
-    G = H_x P_cc H_x^T from 6 x 6 blocks (192 per pair, M (M + 1) / 2 pairs), G V (24 M^2), register Cholesky of the
-    (rho + 1) x rho trapezoid.  Compression in information form: SYRK 3 (n + 1)^2 per track + block diagonal 54 M, Cholesky
+    per stage.  k_feature: triangulation + Jacobian (750 M), f64 reflectors + B^ (300 M), block-sparse gate
+    G = H_x P_cc H_x^T from 6 x 6 blocks (192 per pair, M (M + 1) / 2 pairs), register Cholesky of N = G + sigma^2 I with
+    the four rows [r ; H_f] riding along ((2M)^3 / 3 + 4 (2M)^2).  Compression in information form: SYRK 3 (n + 1)^2 per track + block diagonal 54 M, Cholesky
     (n + 1)^3 / 3.  Kalman in square-root gain form: P[:,15:] T^T (triangular T: D n^2), S = T PHt (n^3), S = L L^T with
     [PHt ; r_n^T] riding along (n^3 / 3 + D n^2), symmetric rank-n downdate (D^2 n)."""
     Ms = np.asarray(Ms, dtype=np.float64)
     rho = 2 * Ms - 3
     n, D = 6.0 * N, 15.0 + 6 * N
-    feature = float(np.sum(1200 * Ms + 96 * Ms * (Ms + 1) + 24 * Ms ** 2 + rho ** 3 / 3 + rho ** 2))
+    feature = float(np.sum(1050 * Ms + 96 * Ms * (Ms + 1) + (2 * Ms) ** 3 / 3 + 4 * (2 * Ms) ** 2))
     gram = float(np.sum(3.0 * (n + 1) ** 2 + 54.0 * Ms))
     chol_gram = (n + 1) ** 3 / 3
     kalman = D * n * n + n ** 3 + (n ** 3 / 3 + D * n * n) + D * D * n
