@@ -143,15 +143,17 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0) {
       if (i < NB && 16 * i >= main_rows) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[ii][jj][r] = *el_ptr(16 * i + Mf<T>::row(lane, r), 16 * j + (lane & 15));
-      // split-K SYRK (kernels_gram.hip): the tiles of block column j / 4 came in min(j / 4 + 1, 3) partial sums, lam_part apart;
-      // added here in a fixed order (the loads are as unconditional as the ones above: one more round trip, no waits between)
-      if (MODE == CH_GRAM && d.gram_parts == 3 && jj >= 1) {
+      // split-K SYRK (kernels_gram.hip): the tiles of block column j / 4 came in min(j / 4 + P - 2, P) partial sums (P =
+      // d.gram_parts), lam_part apart; added here in a fixed order (the loads are as unconditional as the ones above: more
+      // round trips, no waits between)
+      if (MODE == CH_GRAM && d.gram_parts >= 3) {
+        const int ncopy = min(jj + d.gram_parts - 2, d.gram_parts);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[ii][jj][r] += *(el_ptr(16 * i + Mf<T>::row(lane, r), 16 * j + (lane & 15)) + d.lam_part);
-        if (jj >= 2) {
+        for (int c = 1; c < 4; ++c)
+          if (c < ncopy) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[ii][jj][r] += *(el_ptr(16 * i + Mf<T>::row(lane, r), 16 * j + (lane & 15)) + 2 * d.lam_part);
-        }
+            for (int r = 0; r < 4; ++r) acc[ii][jj][r] += *(el_ptr(16 * i + Mf<T>::row(lane, r), 16 * j + (lane & 15)) + c * d.lam_part);
+          }
       }
     }
 #pragma unroll
@@ -168,9 +170,9 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0) {
   if (GRAMLIKE)
     for (int t = tid; t < 16 * NB; t += 1024) {
       double dv = lam_hat(Lam, Dg, d.ldR, nfull, d.n_cap, OFF + t, OFF + t);
-      if (MODE == CH_GRAM && d.gram_parts == 3) {
-        if (t >= 64) dv += lam_hat(Lam + d.lam_part, Dg, d.ldR, nfull, d.n_cap, t, t);
-        if (t >= 128) dv += lam_hat(Lam + 2 * d.lam_part, Dg, d.ldR, nfull, d.n_cap, t, t);
+      if (MODE == CH_GRAM && d.gram_parts >= 3) {
+        const int ncopy = min(t / 64 + d.gram_parts - 2, d.gram_parts);
+        for (int c = 1; c < ncopy; ++c) dv += lam_hat(Lam + c * d.lam_part, Dg, d.ldR, nfull, d.n_cap, t, t);
       }
       sD0[t] = t < n ? (T)dv : T(0);
     }

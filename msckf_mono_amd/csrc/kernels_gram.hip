@@ -113,8 +113,9 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int nb, int npai
   // reach the first panel, ~75 % the second at a 30-camera window).
   // SPLIT K: the stack is a staircase, so a tile of block row ti sums over a prefix of the sorted tracks that grows with ti
   // (~35 % / 75 % / 100 % of them at a 30-camera window) and the launch used to wait for the one workgroup of the last
-  // diagonal tile.  With d.gram_parts == 3 a tile of block row ti is cut into min(ti + 1, 3) workgroups over contiguous
-  // chunk ranges of its K loop (1 + 1 + 1, 2 + 2, 3: ten workgroups of about equal length per trajectory instead of six);
+  // diagonal tile.  With d.gram_parts == P (3 or 4) a tile of block row ti is cut into min(ti + P - 2, P) workgroups over
+  // contiguous chunk ranges of its K loop (P = 3: 1 + 1 + 1, 2 + 2, 3 -- ten workgroups of about equal length per trajectory
+  // instead of six; P = 4: 2 + 2 + 2, 3 + 3, 4 -- sixteen);
   // each writes its partial sum to its own copy of Lam^ (d.lam_part apart) and the blocked Cholesky adds the copies, in a
   // fixed order, while it loads (kernels_chol.hip) -- no atomics, no extra pass, bit-reproducible.
   const int np_cap = ldL / 64;                       // panels the buffers hold
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int nb, int npai
   {
     int rem = bx;
     for (ti = 0; ti < np_cap; ++ti) {
-      nparts = d.gram_parts > 1 ? min(ti + 1, d.gram_parts) : 1;
+      nparts = d.gram_parts > 1 ? min(ti + d.gram_parts - 2, d.gram_parts) : 1;
       const int ng = (np_cap - ti + GT_MAX - 1) / GT_MAX * nparts;
       if (rem < ng) { tj0 = ti + GT_MAX * (rem / nparts); part = rem % nparts; break; }
       rem -= ng;
@@ -547,14 +548,14 @@ void launch_gram(const Dev<S>& din, int b0, int nb, hipStream_t st, int phase) {
   if (nb <= 0) return;
   Dev<S> d = din;
   // split-K partial sums only where the consumer adds them up: the single-level blocked Cholesky (k_chol_mfma, CH_GRAM)
-  d.gram_parts = (d.compress == 3 && d.ldR <= 192 && d.lam_part > 0) ? 3 : 1;
+  d.gram_parts = (d.compress == 3 && d.ldR <= 192 && d.lam_part > 0) ? (din.gram_parts >= 3 ? din.gram_parts : 3) : 1;
 #ifdef MSCKF_ABLATE
   const int g_dbg = g_gram_dbg;
 #else
   const int g_dbg = 0;
 #endif
   int npairs = 0;                                             // SYRK workgroups: <= GT_MAX tiles of one block row each
-  for (int ti = 0; ti < d.ldR / 64; ++ti) npairs += (d.ldR / 64 - ti + GT_MAX - 1) / GT_MAX * (d.gram_parts > 1 ? std::min(ti + 1, d.gram_parts) : 1);
+  for (int ti = 0; ti < d.ldR / 64; ++ti) npairs += (d.ldR / 64 - ti + GT_MAX - 1) / GT_MAX * (d.gram_parts > 1 ? std::min(ti + d.gram_parts - 2, d.gram_parts) : 1);
   const int ndiag = (d.n_cap + 3) / 4;
   if (phase != 2) {
     // (phase 3: the block-diagonal reduction already ran in k_select's launch, launch_select_diag)

@@ -273,8 +273,9 @@ struct Batch : BatchBase {
       if (d.ldR > 192) rc |= dalloc(&d.Mp, Bz * 12 * 256);
       rc |= dalloc(&d.trk_B, TF * 3 * (size_t)d.ldR); rc |= dalloc(&d.trk_rw, TF * 2 * m_cap); rc |= dalloc(&d.trk_inv, TF * n_cap);
       rc |= dalloc(&d.Dg, Bz * n_cap * DG_STRIDE);
-      d.gram_parts = 1; d.lam_part = d.ldR <= 192 ? (long)(Bz * (size_t)d.ldR * d.ldR) : 0;     // three copies of Lam^ for the split-K SYRK (windows up to 31 cameras)
-      rc |= dalloc(&d.Lam, Bz * (size_t)d.ldR * d.ldR * (d.lam_part ? 3 : 1));
+      d.lam_part = d.ldR <= 192 ? (long)(Bz * (size_t)d.ldR * d.ldR) : 0;     // up to four copies of Lam^ for the split-K SYRK (windows up to 31 cameras)
+      d.gram_parts = 3;   // P = 4 (sixteen workgroups per trajectory) measured: k_gram 56 -> 54 us, the Cholesky's extra load round 64 -> 66 us
+      rc |= dalloc(&d.Lam, Bz * (size_t)d.ldR * d.ldR * (d.lam_part ? 4 : 1));
     }
     rc |= dalloc(&d.PHt, Bz * dn); rc |= dalloc(&d.Smat, Bz * nl); rc |= dalloc(&d.Linv, Bz * nl); rc |= dalloc(&d.W, Bz * dn);
     rc |= dalloc(&d.K, Bz * dn); rc |= dalloc(&d.A, Bz * pl); rc |= dalloc(&d.AP, Bz * pl); rc |= dalloc(&d.X, Bz * pl); rc |= dalloc(&d.dx, Bz * d.ld);
