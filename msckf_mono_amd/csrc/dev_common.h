@@ -234,6 +234,14 @@ __device__ __forceinline__ double wave_bcast(double v, int lane) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 __device__ __forceinline__ int wave_bcast(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+// value of `v` in the lane whose byte index (lane << 2) is `src4`: ds_bpermute, the LDS crossbar without LDS memory
+__device__ __forceinline__ float lane_gather(float v, int src4) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(v))); }
+__device__ __forceinline__ double lane_gather(double v, int src4) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_ds_bpermute(src4, (int)(b & 0xffffffffLL)), hi = __builtin_amdgcn_ds_bpermute(src4, (int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // Wave-wide reductions on the DPP network instead of ds_bpermute shuffles: a reduction is four DPP steps inside the
 // rows of 16 lanes (quad swaps, half-row mirror, row mirror: every lane of a row ends up with the row's result)
 // plus one v_readlane per row.  A dependent chain of 6 LDS-crossbar round trips becomes ~10 short VALU ops; the

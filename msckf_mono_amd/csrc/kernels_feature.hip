@@ -130,14 +130,6 @@ __device__ __forceinline__ void house3(T hf[2][3], int lane, T v[2][3], T Tm[3][
 #define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
 #define SYM(i, j) ((i) >= (j) ? TRI(i, j) : TRI(j, i))
 
-// value of `v` in the lane whose byte index (lane << 2) is `src4`: ds_bpermute, the LDS crossbar without LDS memory
-__device__ __forceinline__ float lane_gather(float v, int src4) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(v))); }
-__device__ __forceinline__ double lane_gather(double v, int src4) {
-  const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_ds_bpermute(src4, (int)(b & 0xffffffffLL)), hi = __builtin_amdgcn_ds_bpermute(src4, (int)(b >> 32));
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
 // Gate statistic without the projected block.  With N = G + sigma^2 I (2M x 2M, G = H_x P_cc H_x^T) and A any basis of the
 // left null space of H_f,
 //     gamma = r_o^T (A^T N A)^-1 r_o = min_x (r - H_f x)^T N^-1 (r - H_f x) = y^T y - b^T C^-1 b,
