@@ -247,6 +247,10 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0) {
   // Measured and rejected (round 3): lane = row with the whole row in registers, L(j, k) broadcast by v_readlane as an SGPR
   // operand of the FMA, L^-1 built by the same instruction stream in lanes 16..31 -- no LDS inside the chain, 120 FMAs + 240
   // v_readlane per block instead of 12 ds_bpermute per pivot: 60 -> 73 us (f64), 51 -> 60 us (f32).
+  // Also rejected (round 3): four ADJACENT columns per lane, a 4-column panel factored with v_readlane multipliers (uniform
+  // source lanes), only the finished panel crossing to the other groups by ds_bpermute + a rank-4 update (3 crossbar round
+  // trips per block instead of 16): diagonal-block phase 102 k -> 131 k cycles (f64), 66 k -> 75 k (f32).  On this chip a
+  // VALU -> v_readlane -> VALU hop on the critical chain costs more than the ds_bpermute it replaces.
   auto diag = [&](auto pc) __attribute__((always_inline)) {
     constexpr int p = decltype(pc)::value;
     T (*sP)[LP] = sPP[p & 1];
