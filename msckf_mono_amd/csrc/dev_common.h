@@ -97,6 +97,7 @@ struct Dev {
   // covariance update: 0 = square-root gain form P <- P - W W^T, S factored by the blocked matrix-core Cholesky (float) /
   // the register-resident one (double); 1 = the reference's Joseph sequence; 2 = square-root gain form, register-resident solve
   int joseph;
+  int gain_fused_s;   // float blocked gain solve: S = T_H (P T_H^T)[15:, :] + sigma^2 I is formed inside k_chol_mfma (no S GEMM launch)
   // Kalman work matrices
   S* PHt; S* Smat; S* Linv; S* W; S* K; S* A; S* AP; S* X; S* dx;
   // prune

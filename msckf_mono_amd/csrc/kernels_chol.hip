@@ -141,6 +141,47 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0) {
       const int i = 4 * ii + pi, j = 4 * jj + pj;
       if (i >= NR || j >= NB || (i < NB && j > i) || 16 * j >= n) continue;
       if (i < NB && 16 * i >= main_rows) continue;
+      if (MODE == CH_GAIN && d.gain_fused_s && i < NB) {
+        // S = T_H (P T_H^T)[15:, :] + sigma^2 I (msckf.h:1369) formed HERE, straight into the accumulators, instead of being
+        // loaded: block (i, j) = sum over the k-blocks kb >= i (T_H is upper triangular) of T(16 i .., k) PHt(15 + k, 16 j ..),
+        // four MFMAs per k-block, operands from global memory (T rows as one 16-byte load per lane, PHt through its
+        // row-major copy).  The S GEMM was a launch of its own (24 us, bound by its start-up and drain); every part of a
+        // trajectory redoes the product, as it redoes the factorization.
+        if constexpr (MODE == CH_GAIN) {
+          const int rr = lane & 15, gq = lane >> 4;
+          const T* Trow = reinterpret_cast<const T*>(R0) + (long)min(16 * i + rr, d.n6cap - 1) * d.ldR;
+          const T* Bcol = reinterpret_cast<const T*>(PHtT) + min(16 * j + rr, d.n6cap - 1);
+          V sacc = V{0, 0, 0, 0};
+          typedef T t4 __attribute__((ext_vector_type(4)));
+          const int kbmax = min(NB, (n + 15) >> 4);
+          // six k-blocks per pass: their thirty loads are issued together (clamped addresses, masks afterwards), then the MFMAs
+          constexpr int KU = 6;
+          for (int kb0 = i; kb0 < kbmax; kb0 += KU) {
+            t4 a4[KU]; T bv[KU][4];
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+              const int k0 = 16 * min(kb0 + u, NB - 1) + 4 * gq;
+              a4[u] = *reinterpret_cast<const t4*>(Trow + k0);
+#pragma unroll
+              for (int s4 = 0; s4 < 4; ++s4) bv[u][s4] = Bcol[(long)min(15 + k0 + s4, d.ld - 1) * d.n6cap];
+            }
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+              if (kb0 + u >= kbmax) break;
+              const int k0 = 16 * (kb0 + u) + 4 * gq;
+#pragma unroll
+              for (int s4 = 0; s4 < 4; ++s4) {
+                const bool ok = k0 + s4 < n;
+                sacc = Mf<T>::mma(ok ? a4[u][s4] : T(0), ok ? bv[u][s4] : T(0), sacc);
+              }
+            }
+          }
+          const T sg2 = (T)d.prm[(long)b * PRM_STRIDE + PRM_SIG2];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[ii][jj][r] = sacc[r] + ((i == j && Mf<T>::row(lane, r) == (lane & 15)) ? sg2 : T(0));
+        }
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[ii][jj][r] = *el_ptr(16 * i + Mf<T>::row(lane, r), 16 * j + (lane & 15));
       // split-K SYRK (kernels_gram.hip): the tiles of block column j / 4 came in min(j / 4 + P - 2, P) partial sums (P =

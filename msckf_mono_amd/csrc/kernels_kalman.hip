@@ -936,7 +936,9 @@ void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0) return;
   const int n = d.n6cap, D = 15 + n;
   gemm<S, OP_PHT>(d, b0, nb, D, n, st);
-  gemm<S, OP_S>(d, b0, nb, n, n, st);
+  // S: formed inside the blocked gain solve where that runs (float, square-root gain form, windows up to 32 cameras)
+  const bool s_fused = sizeof(S) == 4 && d.joseph == 0 && d.gain_fused_s && (n + 15) / 16 <= 12;
+  if (!s_fused) gemm<S, OP_S>(d, b0, nb, n, n, st);
   const int nbn = (n + 15) / 16;
   const int nbn_max = sizeof(S) == 4 ? 12 : 8;
   const size_t lds_chol = (size_t)n * (n + 1) * sizeof(S);
