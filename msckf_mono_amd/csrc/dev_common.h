@@ -52,7 +52,7 @@ struct Dev {
   int ldR;     // row stride of the QR work matrices: 64*NC >= 6*n_cap + 1
   int nchunk;  // TSQR chunks per trajectory
   // filter state
-  S* imu; S* cam; S* prm; S* P; S* Ptmp; int* ncam; long long* n_resid;
+  S* imu; S* cam; S* prm; S* P; int* ncam; long long* n_resid;
   // current work-list (may point into a resident scenario)
   const int* trk_n; const int* trk_M; const int* trk_slots; const S* trk_obs;
   // trk_off == null: padded single-call lists, track t of the launch's i-th trajectory starts at i * wl_stride_o + t * m_cap;
@@ -68,7 +68,7 @@ struct Dev {
   // when no track of the frame observes the newest camera): it then takes the window size from ncam_upd (left by the previous
   // frame's prune: ncam after prune + 1) instead of ncam, which augmentState is incrementing meanwhile
   int ncam_bias; int* ncam_upd;
-  int* nprev;   // [B] window size before the prune in flight (k_prune_gather -> k_prune_commit)
+  unsigned* prune_bar;   // [B * 32] (one 128-byte line each) arrival counter of k_prune_inplace's per-trajectory barrier (only ever grows)
   int* nres_upd;   // [B] n_resid at the start of the update in flight (k_feature -> k_select_diag)
   int gate_early;   // exact early accept of the chi-square gate by the bound |r_o|^2 / sigma^2 (k_feature), off by default
   // per-track products of k_feature

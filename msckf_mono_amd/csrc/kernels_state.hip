@@ -151,6 +151,21 @@ __global__ __launch_bounds__(256) void k_augment(Dev<S> d, int b0) {
   augment_body<S>(d, b, tid, reinterpret_cast<S*>(smem_raw));
 }
 
+// 16x16x4 MFMA of the scalar type, with the row a lane group's accumulator register r belongs to
+typedef double pd4 __attribute__((ext_vector_type(4)));
+typedef float pf4 __attribute__((ext_vector_type(4)));
+template <class T> struct Mfs;
+template <> struct Mfs<double> {   // v_mfma_f64_16x16x4_f64: C/D row = g + 4 r
+  typedef pd4 V;
+  static __device__ __forceinline__ V mma(double a, double b, V c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int crow(int g, int r) { return g + 4 * r; }
+};
+template <> struct Mfs<float> {    // v_mfma_f32_16x16x4_f32: C/D row = 4 g + r
+  typedef pf4 V;
+  static __device__ __forceinline__ V mma(float a, float b, V c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int crow(int g, int r) { return 4 * g + r; }
+};
+
 template <class S, bool AUGMENT>
 __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* readings, long rd_stride, int K) {
   const int b = b0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -160,8 +175,8 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
 #endif
   __shared__ S sState[(PG + 1) * SST];
   __shared__ S sPhi[PG * 225];
-  __shared__ S sScr[4][3 * 225];
-  __shared__ S sTot[2][225];
+  __shared__ S sQt[PG * 32];        // G Q G^T dT of the group's samples, compact: [0,15) diagonal, [15,24) the C^T Qa C block, 31 = 0
+  __shared__ S sTot[225];
   __shared__ S sPii[225];
   __shared__ S sNull[12];          // q_null v_null p_null used by the next sample
   __shared__ S sG[4];
@@ -176,6 +191,19 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
   const int ld = d.ld;
   const int n = 6 * d.ncam[b];
   const S* rd = readings + (long)(b - b0) * rd_stride;
+  // the IMU-camera block of P is only multiplied by Phi_total at the very end: fetch this wave's tiles of it (16 camera
+  // columns each, B-operand layout of the 16x16x4 MFMA) now, so that the loads fly under the whole chain
+  constexpr int PIC_T = 6;   // 4 waves x 6 tiles x 16 columns >= 6 * 63
+  S pic[PIC_T][4];
+  {
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int t = 0; t < PIC_T; ++t) {
+      const int col = (w + 4 * t) * 16 + c;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) { const int k = Mfs<S>::crow(g, kk); pic[t][kk] = (col < n && k < 15) ? P[(long)(15 + col) * ld + k] : S(0); }
+    }
+  }
   if (tid < 16) sState[tid] = imu[tid];                 // q b_g v b_a p
   if (tid < 3) sG[tid] = imu[IG + tid];
   if (tid >= 64 && tid < 64 + 12) sQ[tid - 64] = prm[PRM_Q + tid - 64];
@@ -183,10 +211,18 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
   for (int e = tid; e < 225; e += 256) {
     const int i = e / 15, j = e % 15;
     sPii[e] = P[(long)j * ld + i];
-    sTot[0][e] = (i == j) ? S(1) : S(0);
   }
   __syncthreads();
-  int cur = 0;   // which sTot buffer is current
+  // chain matrices in MFMA accumulator layout (phase C): wave 0 P_II, wave 1 Phi_total
+  typename Mfs<S>::V Mreg = {0, 0, 0, 0};
+  {
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = Mfs<S>::crow(g, r);
+      if (i < 15 && c < 15) Mreg[r] = w == 0 ? sPii[i * 15 + c] : (i == c ? S(1) : S(0));
+    }
+  }
   for (int k0 = 0; k0 < K; k0 += PG) {
     const int G = min(PG, K - k0);
     for (int e = tid; e < G * RD_STRIDE; e += 256) sRd[e] = rd[(long)k0 * RD_STRIDE + e];
@@ -335,77 +371,113 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
           Phi[(12 + i) * 15 + j] = A2.m[i][j] - e2v[i] * s3[j];
         }
       }
+    } else if (tid >= 64) {
+      // waves 1-3 meanwhile: G Q G^T dT = diag(Qw, Qbg, C^T Qa C, Qba, 0) dT of every sample of the group   (calcG :899-902, Q diagonal)
+      for (int e = tid - 64; e < G * 32; e += 192) {
+        const int s = e >> 5, q = e & 31;
+        const S dT = sRd[s * RD_STRIDE + 6];
+        S val = 0;
+        if (q < 12 && q / 3 != 2) val = sQ[q] * dT;
+        else if (q >= 15 && q < 24) {
+          const M3<S> C = q2rot(ldq(sState + s * SST));
+          const int i = (q - 15) / 3, j = (q - 15) % 3;
+          S sm = 0;
+          for (int kk = 0; kk < 3; ++kk) sm += C.m[kk][i] * sQ[6 + kk] * C.m[kk][j];
+          val = sm * dT;
+        }
+        sQt[e] = val;
+      }
     }
     __syncthreads();
     PR_TICK(2);
-    // ---- C: sequential chains over the group with the whole workgroup: thread e < 225 owns element (ei, ej) of the 15 x 15
-    // results; P_II <- sym(Phi (P_II + G Q G^T dT) Phi^T) (:134,143) and Phi_total <- Phi Phi_total advance together, two
-    // barriers per sample: the thread forms both (Phi M Phi^T)(ei, ej) and (ej, ei), so the symmetrisation of :143 needs no
-    // exchange (and both halves get the same bits), and adds the next sample's process noise to its own element
+    // ---- C: sequential chains over the group on the matrix cores, in registers.  Wave 0 carries P_II <- sym(Phi (P_II +
+    // G Q G^T dT) Phi^T) (:134,143), wave 1 carries Phi_total <- Phi Phi_total; both hold their 16 x 16 (zero-padded) matrix
+    // in the accumulator layout of the 16x16x4 MFMA, lane (g, c) register r = M[crow(g, r)][c].  Taking the k-slot of MFMA kk,
+    // lane group g, to mean k = crow(g, kk), that same register file IS the B operand of M (B[k][c]) and the A operand of M^T
+    // (A[c][k]), and one set of four values per lane, aPhi[kk] = Phi[c][crow(g, kk)], is both the A operand of Phi and the B
+    // operand of Phi^T.  So with P symmetric:  Y = P Phi^T = mma(A = P regs, B = aPhi),  Phi Y = mma(A = aPhi, B = Y regs),
+    // (Phi Y)^T = Y^T Phi^T = mma(A = Y regs, B = aPhi) -- the transpose comes out of the matrix core with the same products
+    // summed in the same order, so the symmetrisation of :143 is a register add and both halves get the same bits.  No
+    // barrier and no LDS traffic inside the chain besides the four reads of Phi and the process-noise term (table sQt,
+    // filled by waves 1-3 during phase B).
     {
-      S* T1 = sScr[0];
-      const int ei = tid / 15, ej = tid % 15;
-      // this thread's element of G Q G^T dT = diag(Qw, Qbg, C^T Qa C, Qba, 0) dT of sample s   (calcG :899-902, Q diagonal)
-      auto qterm = [&](int s) -> S {
-        if (tid >= 225) return S(0);
-        const S dT = sRd[s * RD_STRIDE + 6];
-        const int bi = ei / 3, bj = ej / 3;
-        if (bi != bj || bi == 4) return S(0);
-        if (bi == 2) {
-          const M3<S> C = q2rot(ldq(sState + s * SST));
-          const int i = ei - 6, j = ej - 6;
-          S sm = 0;
-          for (int kk = 0; kk < 3; ++kk) sm += C.m[kk][i] * sQ[6 + kk] * C.m[kk][j];
-          return sm * dT;
-        }
-        return ei == ej ? sQ[ei] * dT : S(0);
-      };
-      if (tid < 225) sPii[tid] += qterm(0);
-      int c2 = cur;
-      for (int s = 0; s < G; ++s) {
-        const S* Ph = sPhi + s * 225;
-        __syncthreads();
-        if (tid < 225) {
-          S a1 = 0, a2 = 0;
+      typedef Mfs<S> MF;
+      const int g = lane >> 4, c = lane & 15;
+      if (w < 2) {
+        const S* qt = sQt;
+        int qidx[4];   // where this lane's four elements find their process-noise term in a sample's compact table
 #pragma unroll
-          for (int k = 0; k < 15; ++k) { const S ph = Ph[ei * 15 + k]; a1 += ph * sPii[k * 15 + ej]; a2 += ph * sTot[c2][k * 15 + ej]; }
-          T1[tid] = a1; sTot[c2 ^ 1][tid] = a2;
+        for (int r = 0; r < 4; ++r) {
+          const int i = MF::crow(g, r), bi = i / 3;
+          qidx[r] = (bi != c / 3 || bi >= 4) ? 31 : (bi == 2 ? 15 + (i - 6) * 3 + (c - 6) : (i == c ? i : 31));
         }
-        __syncthreads();
-        if (tid < 225) {
-          S tij = 0, tji = 0;
+        if (w == 0) {
 #pragma unroll
-          for (int k = 0; k < 15; ++k) { tij += T1[ei * 15 + k] * Ph[ej * 15 + k]; tji += T1[ej * 15 + k] * Ph[ei * 15 + k]; }
-          const S sym = ei <= ej ? (tij + tji) / S(2) : (tji + tij) / S(2);
-          sPii[tid] = sym + (s + 1 < G ? qterm(s + 1) : S(0));
+          for (int r = 0; r < 4; ++r) Mreg[r] += qt[qidx[r]];
         }
-        c2 ^= 1;
+        for (int s = 0; s < G; ++s) {
+          const S* Ph = sPhi + s * 225;
+          S aPhi[4];
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) { const int k = MF::crow(g, kk); aPhi[kk] = (k < 15 && c < 15) ? Ph[c * 15 + k] : S(0); }
+          typename MF::V zero = {0, 0, 0, 0};
+          if (w == 0) {
+            typename MF::V Y = zero, Pn = zero, Pt = zero;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) Y = MF::mma(Mreg[kk], aPhi[kk], Y);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) { Pn = MF::mma(aPhi[kk], Y[kk], Pn); Pt = MF::mma(Y[kk], aPhi[kk], Pt); }
+            qt += 32;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Mreg[r] = (Pn[r] + Pt[r]) / S(2) + (s + 1 < G ? qt[qidx[r]] : S(0));
+          } else {
+            typename MF::V Tn = zero;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) Tn = MF::mma(aPhi[kk], Mreg[kk], Tn);
+            Mreg = Tn;
+          }
+        }
       }
     }
-    if (G & 1) cur ^= 1;      // the Phi_total buffer flipped G times
     __syncthreads();
     if (tid < 16) sState[tid] = sState[G * SST + tid];   // carry the last state of the group to slot 0
     __syncthreads();
     PR_TICK(3);
   }
+  // chain results back to LDS for the write-back
+  if (w < 2) {
+    const int g = lane >> 4, c = lane & 15;
+    S* dst = w == 0 ? sPii : sTot;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int i = Mfs<S>::crow(g, r); if (i < 15 && c < 15) dst[i * 15 + c] = Mreg[r]; }
+  }
+  __syncthreads();
   // ---- write back: state, nulls (re-anchored to the final state), P_II, P_IC
   if (tid < 16) imu[tid] = sState[tid];
   if (tid < 4) imu[IQN + tid] = sState[tid];
   if (tid >= 4 && tid < 7) imu[IVN + tid - 4] = sState[7 + tid - 4];
   if (tid >= 8 && tid < 11) imu[IPN + tid - 8] = sState[13 + tid - 8];
   for (int e = tid; e < 225; e += 256) { const int i = e / 15, j = e % 15; P[(long)j * ld + i] = sPii[e]; }
-  const S* Tot = sTot[cur];
-  for (int c = tid; c < n; c += 256) {
-    S col[15];
-    S* pc = P + (long)(15 + c) * ld;
+  // P_IC <- Phi_total P_IC (and its mirror), 16 camera columns per MFMA tile; the operand columns were fetched at kernel entry
+  {
+    const int g = lane >> 4, c = lane & 15;
+    S aT[4];
 #pragma unroll
-    for (int i = 0; i < 15; ++i) col[i] = pc[i];
+    for (int kk = 0; kk < 4; ++kk) { const int k = Mfs<S>::crow(g, kk); aT[kk] = (k < 15 && c < 15) ? sTot[c * 15 + k] : S(0); }
 #pragma unroll
-    for (int i = 0; i < 15; ++i) {
-      S sm = 0;
+    for (int t = 0; t < PIC_T; ++t) {
+      const int col = (w + 4 * t) * 16 + c;
+      if ((w + 4 * t) * 16 >= n) break;
+      typename Mfs<S>::V o = {0, 0, 0, 0};
 #pragma unroll
-      for (int kk = 0; kk < 15; ++kk) sm += Tot[i * 15 + kk] * col[kk];
-      pc[i] = sm; P[(long)i * ld + 15 + c] = sm;
+      for (int kk = 0; kk < 4; ++kk) o = Mfs<S>::mma(aT[kk], pic[t][kk], o);
+      if (col < n) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = Mfs<S>::crow(g, r);
+          if (i < 15) { P[(long)(15 + col) * ld + i] = o[r]; P[(long)i * ld + 15 + col] = o[r]; }
+        }
+      }
     }
   }
 #ifdef MSCKF_ABLATE
@@ -422,15 +494,21 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
   }
 }
 
-// Drop camera states: gather the kept camera slots (keep[] ascending) of P into Ptmp, then copy back
-// (square_slice / column_slice of the covariance, matrix_utils.h:58-87, as two passes through Ptmp).  Workgroup = a set of
-// columns; the source row of every kept row is looked up once per workgroup (LDS table), threads run down a column
-// (coalesced) -- no integer division per element.  The keep list is either the host's (d.keep / d.nkeep: pruneEmptyStates,
-// pruneRedundantStates) or "drop the n_drop oldest" (drop array of the resident scenario, or a constant), which every
-// workgroup derives itself; workgroup 0 of a trajectory also publishes it, compacts cam[] and leaves the old window size
-// for the commit pass, whose workgroup 0 finally sets ncam (no launch of the pass reads ncam any more at that point).
-template <class S>
-__global__ __launch_bounds__(256) void k_prune_gather(Dev<S> d, int b0, const int* drop, int drop_const, int use_keep) {
+// Drop camera states in place: P <- P[keep, keep] (square_slice / column_slice of the covariance, matrix_utils.h:58-87;
+// keep[] ascending).  PRUNE_G workgroups per trajectory each own every PRUNE_G-th destination column: a workgroup loads all
+// its source elements into registers, the PRUNE_G workgroups of the trajectory meet at a counter barrier (every source has
+// been read), then each stores its destinations.  One pass over the kept part of P (read once, written once) and one launch,
+// where the earlier gather-into-a-copy + copy-back pair moved it twice through two launches.  The barrier needs the PRUNE_G
+// workgroups of a trajectory co-resident: they are consecutive in dispatch order and small (256 threads, < 2 KB of LDS), so
+// they are unless the chip is full, in which case the ones that are wait for earlier work to retire, not for each other's
+// slots.  The counter only grows (target = next multiple of PRUNE_G above the value a workgroup drew; wrap-safe compare), so
+// it needs no reset between launches; a trajectory that drops nothing skips the barrier with all its workgroups.
+// The keep list is either the host's (d.keep / d.nkeep: pruneEmptyStates, pruneRedundantStates) or "drop the n_drop oldest"
+// (drop array of the resident scenario, or a constant), which every workgroup derives itself; workgroup 0 of a trajectory
+// also publishes it, compacts cam[] and, after the barrier (every workgroup has read the old window size), sets ncam.
+constexpr int PRUNE_G = 16;
+template <class S, int RMAX, int CMAX>
+__global__ __launch_bounds__(256) void k_prune_inplace(Dev<S> d, int b0, const int* drop, int drop_const, int use_keep) {
   const int b = b0 + blockIdx.y, tid = threadIdx.x;
   const int n = d.ncam[b];
   int nk, nd = 0;
@@ -438,7 +516,7 @@ __global__ __launch_bounds__(256) void k_prune_gather(Dev<S> d, int b0, const in
   else { nd = drop ? drop[blockIdx.y] : drop_const; nd = nd < 0 ? 0 : (nd > n ? n : nd); nk = n - nd; }
   int* keep = d.keep + (long)b * d.n_cap;
   if (blockIdx.x == 0) {
-    if (tid == 0) { d.nprev[b] = n; d.ncam_upd[b] = min(nk, n) + 1; if (!use_keep) d.nkeep[b] = nk; }
+    if (tid == 0) { d.ncam_upd[b] = min(nk, n) + 1; if (!use_keep) d.nkeep[b] = nk; }
     if (!use_keep) for (int k = tid; k < nk; k += 256) keep[k] = nd + k;
     if (nk < n && tid < 64) {
       // compact cam[]: keep[] ascending => source slot >= destination slot
@@ -457,28 +535,40 @@ __global__ __launch_bounds__(256) void k_prune_gather(Dev<S> d, int b0, const in
   }
   if (nk >= n) return;
   const int Dn = 15 + 6 * nk, ld = d.ld;
-  const S* P = d.P + (long)b * ld * ld;
-  S* T = d.Ptmp + (long)b * ld * ld;
-  __shared__ int sSrc[1024];
-  for (int i = tid; i < Dn && i < 1024; i += 256) sSrc[i] = i < 15 ? i : 15 + 6 * (use_keep ? keep[(i - 15) / 6] : nd + (i - 15) / 6) + (i - 15) % 6;
-  __syncthreads();
-  for (int j = blockIdx.x; j < Dn; j += gridDim.x) {
-    const S* src = P + (long)sSrc[j] * ld;
-    S* dst = T + (long)j * ld;
-    for (int i = tid; i < Dn; i += 256) dst[i] = src[sSrc[i]];
-  }
-}
-template <class S>
-__global__ __launch_bounds__(256) void k_prune_commit(Dev<S> d, int b0) {
-  const int b = b0 + blockIdx.y;
-  const int nk = d.nkeep[b], n = d.nprev[b];
-  if (nk >= n) return;
-  const int Dn = 15 + 6 * nk, ld = d.ld;
   S* P = d.P + (long)b * ld * ld;
-  const S* T = d.Ptmp + (long)b * ld * ld;
-  for (int j = blockIdx.x; j < Dn; j += gridDim.x)
-    for (int i = threadIdx.x; i < Dn; i += 256) P[(long)j * ld + i] = T[(long)j * ld + i];
-  if (blockIdx.x == 0 && threadIdx.x == 0) d.ncam[b] = nk;
+  __shared__ int sSrc[256 * RMAX];   // Dn <= ld <= 256 * RMAX (launch_prune picks RMAX from ld)
+  for (int i = tid; i < Dn; i += 256) sSrc[i] = i < 15 ? i : 15 + 6 * (use_keep ? keep[(i - 15) / 6] : nd + (i - 15) / 6) + (i - 15) % 6;
+  __syncthreads();
+  S v[CMAX][RMAX];
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    const int j = blockIdx.x + c * PRUNE_G;
+    if (j < Dn) {
+      const S* src = P + (long)sSrc[j] * ld;
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) { const int i = tid + r * 256; v[c][r] = i < Dn ? src[sSrc[i]] : S(0); }
+    }
+  }
+  // every load has returned before this workgroup reports in: a later store of another workgroup must not overtake a read
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    unsigned* bar = d.prune_bar + (long)b * 32;   // a 128-byte line per trajectory: same-line atomics serialise (~25 ns each)
+    const unsigned old = atomicAdd(bar, 1u);
+    const unsigned target = (old / PRUNE_G + 1u) * PRUNE_G;
+    while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    const int j = blockIdx.x + c * PRUNE_G;
+    if (j < Dn) {
+      S* dst = P + (long)j * ld;
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) { const int i = tid + r * 256; if (i < Dn) dst[i] = v[c][r]; }
+    }
+  }
+  if (blockIdx.x == 0 && tid == 0) d.ncam[b] = nk;
 }
 
 template <class S>
@@ -499,8 +589,10 @@ template <class S>
 void launch_prune(const Dev<S>& d, int b0, int nb, hipStream_t st, const int* drop, int drop_const) {
   if (nb <= 0) return;
   const int use_keep = (!drop && drop_const < 0) ? 1 : 0;
-  hipLaunchKernelGGL(k_prune_gather<S>, dim3(32, nb), dim3(256), 0, st, d, b0, drop, drop_const, use_keep);
-  hipLaunchKernelGGL(k_prune_commit<S>, dim3(32, nb), dim3(256), 0, st, d, b0);
+  const dim3 grid(PRUNE_G, nb);
+  // registers hold ceil(ld / PRUNE_G) columns x ceil(ld / 256) rows per thread (ld <= 400: n_cap <= 63)
+  if (d.ld <= 256) hipLaunchKernelGGL((k_prune_inplace<S, 1, 16>), grid, dim3(256), 0, st, d, b0, drop, drop_const, use_keep);
+  else hipLaunchKernelGGL((k_prune_inplace<S, 2, 25>), grid, dim3(256), 0, st, d, b0, drop, drop_const, use_keep);
 }
 
 template void launch_propagate<float>(const Dev<float>&, int, int, const float*, long, int, hipStream_t, bool);

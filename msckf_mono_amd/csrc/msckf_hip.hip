@@ -248,7 +248,7 @@ struct Batch : BatchBase {
     d.ld = ((15 + 6 * n_cap + 15) / 16) * 16;
     d.ldR = ((6 * n_cap + 1 + 63) / 64) * 64;
     // 6 n_cap + 1 <= 384 (n_cap <= 63): the compression kernels' column capacity; it also bounds everything indexed by a state
-    // column or a camera slot further down (k_prune_gather's 1024-entry LDS row table: D <= 393; 6-bit slot fields of trk_first)
+    // column or a camera slot further down (k_prune_inplace keeps ceil(ld / 16) x ceil(ld / 256) <= 25 x 2 elements per thread: ld <= 400; 6-bit slot fields of trk_first)
     if (d.ldR / 64 > 6) return fail(-ENOTSUP, "n_cap too large: 6*n_cap+1 must be <= 384 (at most 63 camera states)");
     int nch = 1;
     while (nch < 8 && (long)B * nch * 2 <= 256) nch *= 2;    // TSQR route: chunks x trajectories ~ one workgroup per CU
@@ -257,7 +257,7 @@ struct Batch : BatchBase {
     const size_t TF = Bz * f_cap;
     int rc = 0;
     rc |= dalloc(&d.imu, Bz * IMU_STRIDE); rc |= dalloc(&d.cam, Bz * n_cap * CAM_STRIDE); rc |= dalloc(&d.prm, Bz * PRM_STRIDE);
-    rc |= dalloc(&d.P, Bz * pl); rc |= dalloc(&d.Ptmp, Bz * pl); rc |= dalloc(&d.ncam, Bz); rc |= dalloc(&d.n_resid, Bz);
+    rc |= dalloc(&d.P, Bz * pl); rc |= dalloc(&d.ncam, Bz); rc |= dalloc(&d.n_resid, Bz);
     rc |= dalloc(&d.trk_status, TF); rc |= dalloc(&d.trk_pf, TF * 4); rc |= dalloc(&d.trk_gamma, TF);
     d.h16 = h16 ? 1 : 0; d.trk_Hx = nullptr; d.trk_Hx16 = nullptr;
     if (h16) rc |= dalloc(&d.trk_Hx16, TF * m_cap * 12); else rc |= dalloc(&d.trk_Hx, TF * m_cap * 12);
@@ -279,7 +279,7 @@ struct Batch : BatchBase {
     }
     rc |= dalloc(&d.PHt, Bz * dn); rc |= dalloc(&d.Smat, Bz * nl); rc |= dalloc(&d.Linv, Bz * nl); rc |= dalloc(&d.W, Bz * dn);
     rc |= dalloc(&d.K, Bz * dn); rc |= dalloc(&d.A, Bz * pl); rc |= dalloc(&d.AP, Bz * pl); rc |= dalloc(&d.X, Bz * pl); rc |= dalloc(&d.dx, Bz * d.ld);
-    rc |= dalloc(&d.keep, Bz * n_cap); rc |= dalloc(&d.nkeep, Bz); rc |= dalloc(&d.ncam_upd, Bz); rc |= dalloc(&d.nprev, Bz); rc |= dalloc(&d.nres_upd, Bz);
+    rc |= dalloc(&d.keep, Bz * n_cap); rc |= dalloc(&d.nkeep, Bz); rc |= dalloc(&d.ncam_upd, Bz); rc |= dalloc(&d.prune_bar, Bz * 32); rc |= dalloc(&d.nres_upd, Bz);
     rc |= dalloc(&d_pfin, TF * 4); d.trk_pfin = d_pfin; d.mode = 0; d.joseph = 0; d.ncam_bias = 0;
     { const char* e = getenv("MSCKF_HIP_FUSED_S"); d.gain_fused_s = e ? atoi(e) : 1; }   // 0: the S GEMM as a launch of its own (A/B runs)
     rd_cap = 64;

@@ -615,7 +615,9 @@ def test_float_long_horizon_square_root_gain_form_keeps_p_positive(capi):
     last_common = max(k for k in snaps1 if k in snaps0 and k <= 1500)
     assert last_common >= 1000, (sorted(snaps1)[-3:], trips1)
     (x0, P0), (x1, P1) = snaps0[last_common], snaps1[last_common]
-    assert np.linalg.norm(x0[13:16] - x1[13:16]) < 0.05           # two free-running float filters
+    # two free-running float filters, 75 s in: the global position is unobservable (its std is metres by now) and the two
+    # covariance updates round differently at every frame
+    assert np.linalg.norm(x0[13:16] - x1[13:16]) < 0.15
     assert np.linalg.norm(P0 - P1) / np.linalg.norm(P1) < 0.05
     print("Joseph form in float: pivot flag first found raised at frame", trips1[:1], "(sqrt-gain form: never in", nf, "frames)")
 
