@@ -53,6 +53,12 @@ struct Dev {
   int nchunk;  // TSQR chunks per trajectory
   // filter state
   S* imu; S* cam; S* prm; S* P; int* ncam; long long* n_resid;
+  // run_frames, square-root gain form: the frame's prune ("drop the fuse_drop[i] oldest camera states") rides on the covariance
+  // downdate -- P - W W^T is written straight to its pruned position in the OTHER covariance buffer, Pout (no in-place hazard,
+  // no prune launch); the host swaps P and the spare buffer after such a frame.  Pout == null: plain downdate in place.
+  // ncam cannot change while the downdate's other workgroups may still read it: it stays at the old window size, the new
+  // one waits in ncam_upd (as "size after the next augment") for the next frame's k_propagate (ncam_defer = 1) to commit.
+  S* Pout; const int* fuse_drop; int ncam_defer;
   // current work-list (may point into a resident scenario)
   const int* trk_n; const int* trk_M; const int* trk_slots; const S* trk_obs;
   // trk_off == null: padded single-call lists, track t of the launch's i-th trajectory starts at i * wl_stride_o + t * m_cap;
@@ -121,6 +127,29 @@ __device__ __forceinline__ bool xcd_item(int nb, int items, int& i, int& item) {
   return i < nb;
 }
 inline int xcd_grid(int nb, int items) { return 8 * ((nb + 7) / 8) * items; }
+
+// Bookkeeping of a prune, by one workgroup of the trajectory (first 64 threads; nthreads >= 64): publishes the keep list when
+// it is "drop the nd oldest", the window size after the next augment (ncam_upd), and compacts cam[] (keep[] ascending =>
+// source slot >= destination slot).  n = window size before, nk = after.  Does not touch ncam.
+template <class S>
+__device__ __forceinline__ void prune_bookkeeping(const Dev<S>& d, int b, int tid, int n, int nk, int nd, int use_keep) {
+  int* keep = d.keep + (long)b * d.n_cap;
+  if (tid == 0) { d.ncam_upd[b] = min(nk, n) + 1; if (!use_keep) d.nkeep[b] = nk; }
+  if (!use_keep && tid < 64) for (int k = tid; k < nk; k += 64) keep[k] = nd + k;
+  if (nk < n && tid < 64) {
+    S* cam = d.cam + (long)b * d.n_cap * CAM_STRIDE;
+    for (int base = 0; base < nk; base += 64) {
+      const int i = base + tid;
+      S v[CAM_STRIDE];
+      if (i < nk) { const int src = use_keep ? keep[i] : nd + i; for (int k = 0; k < CAM_STRIDE; ++k) v[k] = cam[(long)src * CAM_STRIDE + k]; }
+      __builtin_amdgcn_wave_barrier();
+      __threadfence_block();
+      if (i < nk) for (int k = 0; k < CAM_STRIDE; ++k) cam[(long)i * CAM_STRIDE + k] = v[k];
+      __builtin_amdgcn_wave_barrier();
+      __threadfence_block();
+    }
+  }
+}
 
 // measurement Jacobian element idx of the per-track blocks [track][m_cap][12]
 template <class S> __device__ __forceinline__ S ld_hx(const Dev<S>& d, long idx) {

@@ -290,6 +290,24 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int nb, int npai
   // 16 ib .. (transposed accumulation), one coalesced store per element; a diagonal tile is stored whole
   double* Lam = d.Lam + (long)part * d.lam_part + (long)b * ldL * ldL;   // part 0 carries the block-diagonal term
   const double* Dgb = d.Dg + (long)b * d.n_cap * DG_STRIDE;
+  // two passes: first every block-diagonal term is fetched and folded into the accumulator (all loads in flight together),
+  // then the stores.  In one pass (load, subtract, store per element) each load has to wait for the previous element's store
+  // to be acknowledged -- stores count in vmcnt and the compiler cannot rule out that Lam aliases Dg.
+#pragma unroll
+  for (int u = 0; u < GT_MAX; ++u) {
+    const int tj = tj0 + u;
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 64 * tj + wj * 32 + jb * 16 + (lane >> 4) + 4 * r;     // row of Lam^ (>= the column, except inside a diagonal tile)
+          const int i = 64 * ti + wi * 32 + ib * 16 + (lane & 15);            // column
+          const double term = (part == 0 && tj < nt) ? lam_diag_term(Dgb, n, d.n_cap, i, j) : 0.0;
+          acc[u][ib][jb][r] = term - acc[u][ib][jb][r];
+        }
+  }
 #pragma unroll
   for (int u = 0; u < GT_MAX; ++u) {
     const int tj = tj0 + u;
@@ -300,10 +318,9 @@ __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int nb, int npai
       for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int j = 64 * tj + wj * 32 + jb * 16 + (lane >> 4) + 4 * r;     // row of Lam^ (>= the column, except inside a diagonal tile)
-          const int i = 64 * ti + wi * 32 + ib * 16 + (lane & 15);            // column
-          const double val = (part == 0 ? lam_diag_term(Dgb, n, d.n_cap, i, j) : 0.0) - acc[u][ib][jb][r];
-          Lam[(long)j * ldL + i] = val;
+          const int j = 64 * tj + wj * 32 + jb * 16 + (lane >> 4) + 4 * r;
+          const int i = 64 * ti + wi * 32 + ib * 16 + (lane & 15);
+          Lam[(long)j * ldL + i] = acc[u][ib][jb][r];
         }
   }
 #ifdef MSCKF_ABLATE

@@ -204,35 +204,79 @@ template <class S>
 __device__ __forceinline__ void inject_from_dx(const Dev<S>& d, int b, int tid, int nthreads) {
   const S* dx = d.dx + (long)b * d.ld;
   S* imu = d.imu + (long)b * IMU_STRIDE;
+  // every load of a thread is issued before its first store (a store to imu / cam may alias dx as far as the compiler knows:
+  // interleaved, each += became its own load -> wait -> store round trip, ~12 in a row on the thread that also owns a GEMM tile)
   if (tid == 0) {
-    const Q4<S> q = qmul(update_quat(mk3(dx[0], dx[1], dx[2])), ldq(imu + IQ));   // not re-normalised (:1376-1378)
-    stq(imu + IQ, q);
-    for (int k = 0; k < 3; ++k) { imu[IBG + k] += dx[3 + k]; imu[IV + k] += dx[6 + k]; imu[IBA + k] += dx[9 + k]; imu[IP + k] += dx[12 + k]; }
+    const V3<S> th = mk3(dx[0], dx[1], dx[2]);
+    const Q4<S> q0 = ldq(imu + IQ);
+    stq(imu + IQ, qmul(update_quat(th), q0));   // not re-normalised (:1376-1378)
   }
+  if (tid >= 3 && tid < 15) imu[tid + 1] += dx[tid];   // b_g v b_a p follow q in the state block in dx's order
+  static_assert(IBG == 4 && IV == 7 && IBA == 10 && IP == 13, "IMU state block order");
   const int N = d.ncam[b];
   for (int c = tid; c < N; c += nthreads) {
     S* cs = d.cam + ((long)b * d.n_cap + c) * CAM_STRIDE;
-    const Q4<S> q = qnormalized(qmul(update_quat(mk3(dx[15 + 6 * c], dx[16 + 6 * c], dx[17 + 6 * c])), ldq(cs)));
-    stq(cs, q);
-    for (int k = 0; k < 3; ++k) cs[4 + k] += dx[18 + 6 * c + k];
+    const V3<S> th = mk3(dx[15 + 6 * c], dx[16 + 6 * c], dx[17 + 6 * c]);
+    const V3<S> dp = mk3(dx[18 + 6 * c], dx[19 + 6 * c], dx[20 + 6 * c]);
+    const Q4<S> q0 = ldq(cs);
+    const V3<S> p0 = ld3(cs + 4);
+    stq(cs, qnormalized(qmul(update_quat(th), q0)));
+    st3(cs + 4, p0 + dp);
   }
 }
 
-constexpr int GT = 32;   // k-tile of the MFMA GEMM
+#ifdef MSCKF_ABLATE
+// phase timers of the -DMSCKF_ABLATE build (scripts/chol_phases.py): shader-clock cycles of thread 0 of tile (1, 1) of the PHt
+// (row 0) and downdate (row 1) products: set-up, first k-tile landed, k loop, epilogue (stores acknowledged), launches
+__device__ unsigned long long g_gemm_cycles[2][8];
+void gemm_cycles_read(unsigned long long* out16, int reset) {
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_gemm_cycles), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_cycles), z, sizeof(z)); }
+}
+// wall-clock (100 MHz) start / end of every workgroup of the last PHt (row 0) / downdate (row 1) launch
+__device__ unsigned long long g_gemm_trace[2][4096][2];
+void gemm_trace_read(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_trace), sizeof(unsigned long long) * 2 * 4096 * 2); }
+#define GM_TRACE(which) do { if ((OP == OP_PHT || OP == OP_DOWN) && threadIdx.x == 0) { const int wg_ = (int)blockIdx.x; if (wg_ < 4096) g_gemm_trace[OP == OP_DOWN][wg_][which] = wall_clock64(); } } while (0)
+#define GM_TICK(slot) do { if ((OP == OP_PHT || OP == OP_DOWN) && threadIdx.x == 0 && bx == 0 && by == 1) { const long long t_ = clock64(); atomicAdd(&g_gemm_cycles[OP == OP_DOWN][slot], (unsigned long long)(t_ - gm_t)); gm_t = t_; } } while (0)
+#else
+#define GM_TICK(slot) do { } while (0)
+#define GM_TRACE(which) do { } while (0)
+#endif
+constexpr int GT = 64;   // k-tile of the MFMA GEMM (the staging maps below assume 64)
 
 template <int OP>
-__global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0) {
+__global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0, int nb, int tiles_x, int tiles_y) {
   using S = float;
-  const int b = b0 + blockIdx.z;
-  if ((OP == OP_X || OP == OP_DOWN) && blockIdx.x > blockIdx.y) return;   // symmetric: the epilogue mirrors the upper tiles into P
-  if (OP == OP_S && blockIdx.x < blockIdx.y) return;   // S is symmetric: the gain solve reads its lower triangle
+  // workgroup -> (trajectory, tile) with all tiles of a trajectory on one XCD (xcd_item): the tiles of a product share their
+  // operand panels, and an XCD's L2 is private -- with the tiles of a trajectory dealt round-robin over the eight XCDs every
+  // XCD pulled every trajectory's operands over the fabric
+  int bi_, tile_;
+  if (!xcd_item(nb, tiles_x * tiles_y, bi_, tile_)) return;
+  const int b = b0 + bi_, bx = tile_ % tiles_x, by = tile_ / tiles_x;
+#ifdef MSCKF_ABLATE
+  long long gm_t = clock64();
+  GM_TRACE(0); GM_TRACE(1);
+#endif
+  if ((OP == OP_X || OP == OP_DOWN) && bx > by) return;   // symmetric: the epilogue mirrors the upper tiles into P
+  if (OP == OP_S && bx < by) return;   // S is symmetric: the gain solve reads its lower triangle
   const int mrows_ = d.stats[(long)b * STAT_STRIDE + STAT_MROWS];   // loaded together with the window size (independent scalar loads, one wait)
   const KView<S> v = make_view(d, b);
-  if (mrows_ == 0) return;
-  if (OP == OP_DOWN && blockIdx.x == 0 && blockIdx.y == 0) inject_from_dx<S>(d, b, threadIdx.x, 256);
+  // downdate with the frame's prune riding on it (Dev::Pout): a trajectory without an update still has its covariance moved
+  const bool fused_prune = OP == OP_DOWN && d.Pout != nullptr;
+  if (mrows_ == 0 && !fused_prune) return;
+  int nd_ = 0;
+  if (fused_prune) { nd_ = d.fuse_drop[bi_]; nd_ = nd_ < 0 ? 0 : (nd_ > v.n / 6 ? v.n / 6 : nd_); }
+  if (OP == OP_DOWN && bx == 0 && by == 0) {
+    if (mrows_ != 0) inject_from_dx<S>(d, b, threadIdx.x, 256);
+    if (fused_prune) {
+      __syncthreads();   // the camera states just corrected are compacted by other threads
+      prune_bookkeeping<S>(d, b, threadIdx.x, v.n / 6, v.n / 6 - nd_, nd_, 0);
+    }
+  }
   int M, N, K;
   op_dims<S, OP>(v, M, N, K);
-  const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+  if (mrows_ == 0) K = 0;   // (fused prune only) nothing to subtract
+  const int i0 = bx * 64, j0 = by * 64;
   if (i0 >= M || j0 >= N) return;
   __shared__ S sbuf[2 * GT * 65];
   S (*sA)[65] = reinterpret_cast<S (*)[65]>(sbuf);
@@ -247,6 +291,8 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0) {
   // (measured and rejected, round 3: a second register stage -- tile t+2 in flight behind two tiles of MFMAs: 80 registers,
   // PHt / S / downdate 21.8 / 23.6 / 31.7 -> 23.2 / 24.9 / 32.4 us; with ~0.5 us of MFMA per tile and six tiles per workgroup
   // these launches are bound by their fixed start-up and drain, not by exposed load latency)
+  // (also rejected: all six k-tiles of a short product requested at once, 96 staging registers: downdate 31.7 -> 39.9 us, PHt
+  // 22.0 -> 24.7 us -- what bound the downdate was its epilogue, see below)
   constexpr int NQ = GT / 4;
   S ra[NQ], rb[NQ];
   const int a_i = i0 + (tid & 63), a_ic = min(a_i, M - 1);
@@ -257,7 +303,7 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0) {
       ra[q] = *opa_ptr<OP>(v, a_ic, gk);
       int kb, jj;
       if (BContigJ<OP>::value) { jj = tid & 63; kb = (tid >> 6) + 4 * q; }
-      else { kb = (tid & 15) + 16 * (q & 1); jj = (tid >> 4) + 16 * (q >> 1); }
+      else { kb = tid & 63; jj = (tid >> 6) + 4 * q; }   // GT = 64: a wavefront reads 64 consecutive k of one column
       rb[q] = *opb_ptr<OP>(v, min(k0 + kb, K - 1), min(j0 + jj, N - 1));
     }
   };
@@ -268,7 +314,7 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0) {
       sA[kk][tid & 63] = (a_i < M && gk < K) ? opa_fix<OP>(v, a_i, gk, ra[q]) : 0.f;
       int kb, jj;
       if (BContigJ<OP>::value) { jj = tid & 63; kb = kk; }
-      else { kb = (tid & 15) + 16 * (q & 1); jj = (tid >> 4) + 16 * (q >> 1); }
+      else { kb = tid & 63; jj = (tid >> 6) + 4 * q; }   // GT = 64: a wavefront reads 64 consecutive k of one column
       const int gj = j0 + jj, gk2 = k0 + kb;
       sB[kb][jj] = (gj < N && gk2 < K) ? opb_fix<OP>(v, gk2, gj, rb[q]) : 0.f;
     }
@@ -278,30 +324,32 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0) {
   if (OP == OP_PHT || OP == OP_KE) kbeg = (j0 / GT) * GT;            // B(k, j) = T[j][k] / E(j, k): zero for k < j
   if (OP == OP_S) kbeg = (i0 / GT) * GT;                             // A(i, k) = T[i][k]: zero for k < i
   if (OP == OP_A) K = min(K, max(j0 + 64 - 15, 0));                  // B(k, j) = T_H[k][j]: zero for k > j - 15
+  GM_TICK(0);
   if (kbeg < K) fetch(kbeg);
   for (int k0 = kbeg; k0 < K; k0 += GT) {
     stage(k0);
     __syncthreads();
+    if (k0 == kbeg) GM_TICK(1);
     if (k0 + GT < K) fetch(k0 + GT);
     if (wave_live) {
-      const int kend = min(GT, K - k0);
+      // rows of the tile beyond K were staged as zeros: no bound inside the tile, so that the operand reads of all its MFMAs
+      // can be issued ahead of the chain (a branch per MFMA kept each read -> wait -> MFMA step apart)
 #pragma unroll
       for (int kk = 0; kk < GT; kk += 2) {
-        if (kk < kend) {
-          const S bj = sB[kk + (lane >> 5)][32 * wn + (lane & 31)];   // MFMA A operand: rows of the result = j
-          const S ai = sA[kk + (lane >> 5)][32 * wm + (lane & 31)];   // MFMA B operand: cols of the result = i
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bj, ai, acc, 0, 0, 0);
-        }
+        const S bj = sB[kk + (lane >> 5)][32 * wn + (lane & 31)];   // MFMA A operand: rows of the result = j
+        const S ai = sA[kk + (lane >> 5)][32 * wm + (lane & 31)];   // MFMA B operand: cols of the result = i
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bj, ai, acc, 0, 0, 0);
       }
     }
     __syncthreads();
   }
+  GM_TICK(2);
   const int gi = i0 + 32 * wm + (lane & 31);
   if (OP == OP_X) {
     // P <- (X + X^T)/2 (msckf.h:1418) fused into the product: X is not materialised.  Tiles above the block diagonal
     // write their values to both halves of P; a diagonal tile averages with its own transpose through LDS.
     S* Pw = const_cast<S*>(v.P);
-    if (blockIdx.x != blockIdx.y) {
+    if (bx != by) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int gj = j0 + 32 * wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -321,12 +369,56 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0) {
     }
     return;
   }
+  if (OP == OP_DOWN) {
+    // P <- P - W W^T on the upper triangle (diagonal tiles), both halves written from the same value.  All sixteen old values
+    // are requested before the first store: interleaved (load, subtract, two stores per element) the compiler must assume
+    // that a store changes the next element's load and waits for the stores' acknowledgement every time -- sixteen serial
+    // round trips, which were ~24 of this launch's 32 us
+    S* Pw = const_cast<S*>(v.P);
+    S old[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int gj = j0 + 32 * wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      old[r] = (gi <= gj && gj < N) ? Pw[(long)gj * v.ld + gi] : 0.f;
+    }
+    if (fused_prune) {
+      // rows / columns of the nd_ oldest camera states vanish, later ones move up by 6 nd_: written to the other buffer
+      S* Po = d.Pout + (long)b * v.ld * v.ld;
+      const int cut = 15 + 6 * nd_;
+      const int di = gi < 15 ? gi : gi - 6 * nd_;
+      const bool keep_i = gi < 15 || gi >= cut;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gj = j0 + 32 * wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int dj = gj < 15 ? gj : gj - 6 * nd_;
+        if (gi <= gj && gj < N && keep_i && (gj < 15 || gj >= cut)) { const S val = old[r] - acc[r]; Po[(long)dj * v.ld + di] = val; Po[(long)di * v.ld + dj] = val; }
+      }
+    } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int gj = j0 + 32 * wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (gi <= gj && gj < N) { const S val = old[r] - acc[r]; Pw[(long)gj * v.ld + gi] = val; Pw[(long)gi * v.ld + gj] = val; }
+    }
+    }
+#ifdef MSCKF_ABLATE
+    __builtin_amdgcn_s_waitcnt(0);
+    GM_TICK(3);
+    GM_TRACE(1);
+    if (threadIdx.x == 0 && bx == 0 && by == 1) atomicAdd(&g_gemm_cycles[1][4], 1ull);
+#endif
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int gj = j0 + 32 * wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (OP == OP_DOWN) { if (gi <= gj && gj < N) op_store<S, OP>(v, gi, gj, acc[r]); }   // upper triangle of diagonal tiles, mirrored
-    else if (gi < M && gj < N) op_store<S, OP>(v, gi, gj, acc[r]);
+    if (gi < M && gj < N) op_store<S, OP>(v, gi, gj, acc[r]);
   }
+#ifdef MSCKF_ABLATE
+  __builtin_amdgcn_s_waitcnt(0);
+  GM_TICK(3);
+  GM_TRACE(1);
+  if (OP == OP_PHT && threadIdx.x == 0 && bx == 0 && by == 1) atomicAdd(&g_gemm_cycles[0][4], 1ull);
+#endif
 }
 
 // f64 tile GEMM on the matrix cores: v_mfma_f64_16x16x4_f64, 64 x 64 output tile per workgroup, each wavefront a
@@ -341,10 +433,20 @@ __global__ __launch_bounds__(256) void k_gemm_mfma64(Dev<double> d, int b0) {
   if (OP == OP_S && blockIdx.x < blockIdx.y) return;       // (X is needed in full: k_symmetrize averages X and X^T)
   const int mrows_ = d.stats[(long)b * STAT_STRIDE + STAT_MROWS];   // loaded together with the window size (independent scalar loads, one wait)
   const KView<S> v = make_view(d, b);
-  if (mrows_ == 0) return;
-  if (OP == OP_DOWN && blockIdx.x == 0 && blockIdx.y == 0) inject_from_dx<S>(d, b, threadIdx.x, 256);
+  const bool fused_prune = OP == OP_DOWN && d.Pout != nullptr;   // see the float kernel
+  if (mrows_ == 0 && !fused_prune) return;
+  int nd_ = 0;
+  if (fused_prune) { nd_ = d.fuse_drop[blockIdx.z]; nd_ = nd_ < 0 ? 0 : (nd_ > v.n / 6 ? v.n / 6 : nd_); }
+  if (OP == OP_DOWN && blockIdx.x == 0 && blockIdx.y == 0) {
+    if (mrows_ != 0) inject_from_dx<S>(d, b, threadIdx.x, 256);
+    if (fused_prune) {
+      __syncthreads();
+      prune_bookkeeping<S>(d, b, threadIdx.x, v.n / 6, v.n / 6 - nd_, nd_, 0);
+    }
+  }
   int M, N, K;
   op_dims<S, OP>(v, M, N, K);
+  if (mrows_ == 0) K = 0;
   const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
   if (i0 >= M || j0 >= N) return;
   constexpr int KT = 16;
@@ -386,6 +488,32 @@ __global__ __launch_bounds__(256) void k_gemm_mfma64(Dev<double> d, int b0) {
     __syncthreads();
   }
   // acc[jb][ib][r] = C(i = i0 + 32 wm + 16 ib + (lane & 15), j = j0 + 32 wn + 16 jb + (lane >> 4) + 4 r)
+  if (OP == OP_DOWN) {   // old values of P first, all loads in flight together, then the stores (see the float kernel)
+    S* Pw = const_cast<S*>(v.P);
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gi = i0 + 32 * wm + 16 * ib + (lane & 15), gj = j0 + 32 * wn + 16 * jb + (lane >> 4) + 4 * r;
+          const S old = (gi <= gj && gj < N) ? Pw[(long)gj * v.ld + gi] : S(0);
+          acc[jb][ib][r] = old - acc[jb][ib][r];
+        }
+    S* Po = fused_prune ? d.Pout + (long)b * v.ld * v.ld : Pw;
+    const int cut = 15 + 6 * nd_;
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gi = i0 + 32 * wm + 16 * ib + (lane & 15), gj = j0 + 32 * wn + 16 * jb + (lane >> 4) + 4 * r;
+          const int di = gi < 15 ? gi : gi - 6 * nd_, dj = gj < 15 ? gj : gj - 6 * nd_;
+          if (gi <= gj && gj < N && (gi < 15 || gi >= cut) && (gj < 15 || gj >= cut)) { Po[(long)dj * v.ld + di] = acc[jb][ib][r]; Po[(long)di * v.ld + dj] = acc[jb][ib][r]; }
+        }
+    return;
+  }
 #pragma unroll
   for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
@@ -393,8 +521,7 @@ __global__ __launch_bounds__(256) void k_gemm_mfma64(Dev<double> d, int b0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int gi = i0 + 32 * wm + 16 * ib + (lane & 15), gj = j0 + 32 * wn + 16 * jb + (lane >> 4) + 4 * r;
-        if (OP == OP_DOWN) { if (gi <= gj && gj < N) op_store<S, OP>(v, gi, gj, acc[jb][ib][r]); }
-        else if (gi < M && gj < N) op_store<S, OP>(v, gi, gj, acc[jb][ib][r]);
+        if (gi < M && gj < N) op_store<S, OP>(v, gi, gj, acc[jb][ib][r]);
       }
 }
 
@@ -909,7 +1036,8 @@ __global__ __launch_bounds__(256) void k_symmetrize(Dev<S> d, int b0) {
 
 template <int OP>
 static void gemm_launch(const Dev<float>& d, int b0, int nb, int Mmax, int Nmax, hipStream_t st) {
-  hipLaunchKernelGGL((k_gemm_mfma<OP>), dim3((Mmax + 63) / 64, (Nmax + 63) / 64, nb), dim3(256), 0, st, d, b0);
+  const int tx = (Mmax + 63) / 64, ty = (Nmax + 63) / 64;
+  hipLaunchKernelGGL((k_gemm_mfma<OP>), dim3(xcd_grid(nb, tx * ty)), dim3(256), 0, st, d, b0, nb, tx, ty);
 }
 template <int OP>
 static void gemm_launch(const Dev<double>& d, int b0, int nb, int Mmax, int Nmax, hipStream_t st) {

@@ -189,7 +189,11 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
   const S* prm = d.prm + (long)b * PRM_STRIDE;
   S* P = d.P + (long)b * d.ld * d.ld;
   const int ld = d.ld;
-  const int n = 6 * d.ncam[b];
+  // a prune that rode on the previous frame's covariance downdate left the new window size in ncam_upd (+1): commit it here,
+  // where no other workgroup of the trajectory can be reading ncam (augment_body re-reads it behind barriers of this workgroup)
+  const int ncams = d.ncam_defer ? d.ncam_upd[b] - 1 : d.ncam[b];
+  if (d.ncam_defer && tid == 0) d.ncam[b] = ncams;
+  const int n = 6 * ncams;
   const S* rd = readings + (long)(b - b0) * rd_stride;
   // the IMU-camera block of P is only multiplied by Phi_total at the very end: fetch this wave's tiles of it (16 camera
   // columns each, B-operand layout of the 16x16x4 MFMA) now, so that the loads fly under the whole chain
@@ -514,25 +518,8 @@ __global__ __launch_bounds__(256) void k_prune_inplace(Dev<S> d, int b0, const i
   int nk, nd = 0;
   if (use_keep) nk = d.nkeep[b];
   else { nd = drop ? drop[blockIdx.y] : drop_const; nd = nd < 0 ? 0 : (nd > n ? n : nd); nk = n - nd; }
-  int* keep = d.keep + (long)b * d.n_cap;
-  if (blockIdx.x == 0) {
-    if (tid == 0) { d.ncam_upd[b] = min(nk, n) + 1; if (!use_keep) d.nkeep[b] = nk; }
-    if (!use_keep) for (int k = tid; k < nk; k += 256) keep[k] = nd + k;
-    if (nk < n && tid < 64) {
-      // compact cam[]: keep[] ascending => source slot >= destination slot
-      S* cam = d.cam + (long)b * d.n_cap * CAM_STRIDE;
-      for (int base = 0; base < nk; base += 64) {
-        const int i = base + tid;
-        S v[CAM_STRIDE];
-        if (i < nk) { const int src = use_keep ? keep[i] : nd + i; for (int k = 0; k < CAM_STRIDE; ++k) v[k] = cam[(long)src * CAM_STRIDE + k]; }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        if (i < nk) for (int k = 0; k < CAM_STRIDE; ++k) cam[(long)i * CAM_STRIDE + k] = v[k];
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-      }
-    }
-  }
+  const int* keep = d.keep + (long)b * d.n_cap;
+  if (blockIdx.x == 0) prune_bookkeeping<S>(d, b, tid, n, nk, nd, use_keep);
   if (nk >= n) return;
   const int Dn = 15 + 6 * nk, ld = d.ld;
   S* P = d.P + (long)b * ld * ld;

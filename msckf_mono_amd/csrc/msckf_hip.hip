@@ -184,6 +184,8 @@ struct Batch : BatchBase {
   // slot its work-list touches: run_frames overlaps k_feature with propagate + augment when no track sees the newest camera
   std::vector<int> h_ncam, h_maxslot;
   hipStream_t sty[MAXS] = {nullptr}; hipEvent_t ev_fa[MAXS] = {nullptr}, ev_fb[MAXS] = {nullptr};
+  S* P_spare = nullptr;   // second covariance buffer: target of a downdate that carries the frame's prune (Dev::Pout)
+  int fuse_prune = 1;     // run_frames: prune rides on the downdate (MSCKF_HIP_FUSE_PRUNE=0: separate k_prune_inplace launch)
   int overlap_feature = 0;   // measured on MI355X at cfg3: 100 k -> 82 k updates/s with the overlap on (k_feature floods the CUs the
                              // latency-bound propagate/augment workgroups need); kept selectable, off by default
   int compress_route = -1;   // -1 default, 0 Householder TSQR, 1 information form, 2 information form + blocked Cholesky
@@ -257,7 +259,9 @@ struct Batch : BatchBase {
     const size_t TF = Bz * f_cap;
     int rc = 0;
     rc |= dalloc(&d.imu, Bz * IMU_STRIDE); rc |= dalloc(&d.cam, Bz * n_cap * CAM_STRIDE); rc |= dalloc(&d.prm, Bz * PRM_STRIDE);
-    rc |= dalloc(&d.P, Bz * pl); rc |= dalloc(&d.ncam, Bz); rc |= dalloc(&d.n_resid, Bz);
+    rc |= dalloc(&d.P, Bz * pl); rc |= dalloc(&P_spare, Bz * pl); d.Pout = nullptr; d.fuse_drop = nullptr; d.ncam_defer = 0;
+    if (const char* e = getenv("MSCKF_HIP_FUSE_PRUNE")) fuse_prune = atoi(e) != 0;
+    rc |= dalloc(&d.ncam, Bz); rc |= dalloc(&d.n_resid, Bz);
     rc |= dalloc(&d.trk_status, TF); rc |= dalloc(&d.trk_pf, TF * 4); rc |= dalloc(&d.trk_gamma, TF);
     d.h16 = h16 ? 1 : 0; d.trk_Hx = nullptr; d.trk_Hx16 = nullptr;
     if (h16) rc |= dalloc(&d.trk_Hx16, TF * m_cap * 12); else rc |= dalloc(&d.trk_Hx, TF * m_cap * 12);
@@ -469,6 +473,11 @@ struct Batch : BatchBase {
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipMemsetAsync(d.stats + (size_t)b * STAT_STRIDE + STAT_ERR, 0, sizeof(int), st));
     return 0;
+  }
+  // every slice ran the same frames: all but the last of a call carry their prune on the downdate and flip the buffers
+  void commit_buffer_parity(int f0, int f1) {
+    const bool fuse = fuse_prune && !prof && !overlap_feature && d.joseph == 0;
+    if (fuse && f1 - f0 >= 2 && ((f1 - f0 - 1) & 1)) std::swap(d.P, P_spare);
   }
   void launch_update(const Dev<S>& vin, int b0, int nb, hipStream_t q, bool feature_done = false) {
     Dev<S> v = vin;
@@ -962,9 +971,14 @@ int Batch<S>::run_frames(int f0, int f1) {
     hipStream_t q = qs[hh];
     const int b0 = (int)((long)B * hh / nh);
     const int nb = (int)((long)B * (hh + 1) / nh) - b0;
+    S* curP = d.P; S* spare = P_spare;   // a frame whose prune rides on the downdate leaves the covariance in the other buffer
+    bool pending = false;                // ... and the new window size for the next k_propagate to commit
     for (int f = f0; f < f1; ++f) {
       const size_t cell0 = (size_t)f * B;
       Dev<S> v = d;
+      v.P = curP; v.ncam_defer = pending ? 1 : 0;
+      // the call's last frame prunes with its own launch: ncam must be final when run_frames returns
+      const bool fuse = fuse_prune && !prof && !overlap_feature && d.joseph == 0 && f + 1 < f1;
       v.trk_n = sc_n + cell0 + b0; v.trk_M = sc_M + (cell0 + b0) * f_cap; v.trk_off = sc_off + (cell0 + b0) * f_cap;
       v.trk_slots = sc_slots + fr_base[f]; v.trk_obs = sc_obs + 2 * fr_base[f];
       v.wl_stride_n = 1; v.wl_stride_f = f_cap; v.wl_stride_o = 0;
@@ -992,12 +1006,16 @@ int Batch<S>::run_frames(int f0, int f1) {
         if (prof) { stage_begin(1, q); launch_augment<S>(v, b0, nb, q); stage_end(1, q); }
       }
       if (early) (void)hipStreamWaitEvent(q, ev_fb[hh], 0);
-      { StageRange r("msckf_marginalize"); launch_update(v, b0, nb, q, early); }
-      {
+      v.ncam_defer = 0;
+      if (fuse) { v.Pout = spare; v.fuse_drop = (const int*)(sc_drop + cell0 + b0); }
+      { StageRange r(fuse ? "msckf_marginalize+msckf_prune_empty_states" : "msckf_marginalize"); launch_update(v, b0, nb, q, early); }
+      if (fuse) { std::swap(curP, spare); pending = true; }
+      else {
         StageRange r("msckf_prune_empty_states");
         stage_begin(6, q);
         launch_prune<S>(v, b0, nb, q, (const int*)(sc_drop + cell0 + b0), 0);
         stage_end(6, q);
+        pending = false;
       }
       for (int b = b0; b < b0 + nb; ++b) {   // host mirror of the window size: augment, then drop n_drop (clamped as k_make_keep does)
         if (h_ncam[b] < n_cap) h_ncam[b]++;
@@ -1018,6 +1036,7 @@ int Batch<S>::run_frames(int f0, int f1) {
   if (rc) return rc;
   for (int i = 0; i < nh; ++i)
     if (slice_rc[i]) return fail(-EIO, std::string("kernel launch failed on slice ") + std::to_string(i) + ": " + hipGetErrorString((hipError_t)slice_rc[i]));
+  commit_buffer_parity(f0, f1);
   return 0;
 }
 
@@ -1066,6 +1085,8 @@ int Batch<S>::run_frames_streamed(int f0, int f1) {
     hipStream_t q = qs[hh];
     const int b0 = (int)((long)B * hh / nh);
     const int nb = (int)((long)B * (hh + 1) / nh) - b0;
+    S* curP = d.P; S* spare = P_spare;
+    bool pending = false;
     for (int f = f0; f < f1; ++f) {
       while (up_rdy.load(std::memory_order_acquire) <= f && !failed.load()) std::this_thread::yield();
       if (failed.load()) break;
@@ -1077,12 +1098,20 @@ int Batch<S>::run_frames_streamed(int f0, int f1) {
       v.trk_off = reinterpret_cast<int*>(blk + pk_off) + (size_t)b0 * f_cap;
       v.trk_slots = reinterpret_cast<int*>(blk + pk_slots); v.trk_obs = reinterpret_cast<S*>(blk + pinf[f].off_obs);
       v.wl_stride_n = 1; v.wl_stride_f = f_cap; v.wl_stride_o = 0;
+      v.P = curP; v.ncam_defer = pending ? 1 : 0;
+      const bool fuse = fuse_prune && !prof && !overlap_feature && d.joseph == 0 && f + 1 < f1;   // as in run_frames
       stage_begin(0, q); launch_propagate<S>(v, b0, nb, reinterpret_cast<S*>(blk + pk_rd) + (size_t)b0 * sc_K * RD_STRIDE, (long)sc_K * RD_STRIDE, sc_K, q, !prof); stage_end(0, q);
       if (prof) { stage_begin(1, q); launch_augment<S>(v, b0, nb, q); stage_end(1, q); }
+      v.ncam_defer = 0;
+      if (fuse) { v.Pout = spare; v.fuse_drop = (const int*)(reinterpret_cast<int*>(blk + pk_drop) + b0); }
       launch_update(v, b0, nb, q);
-      stage_begin(6, q);
-      launch_prune<S>(v, b0, nb, q, (const int*)(reinterpret_cast<int*>(blk + pk_drop) + b0), 0);
-      stage_end(6, q);
+      if (fuse) { std::swap(curP, spare); pending = true; }
+      else {
+        stage_begin(6, q);
+        launch_prune<S>(v, b0, nb, q, (const int*)(reinterpret_cast<int*>(blk + pk_drop) + b0), 0);
+        stage_end(6, q);
+        pending = false;
+      }
       (void)hipEventRecord(ev_use[k][hh], q);
       for (int b = b0; b < b0 + nb; ++b) {   // host mirror of the window size
         if (h_ncam[b] < n_cap) h_ncam[b]++;
@@ -1115,6 +1144,7 @@ int Batch<S>::run_frames_streamed(int f0, int f1) {
   HIPCHK(hipEventRecord(ev_join[1], stc)); HIPCHK(hipStreamWaitEvent(st, ev_join[1], 0));
   for (int i = 0; i < nh; ++i)
     if (slice_rc[i]) return fail(-EIO, std::string("kernel launch failed on slice ") + std::to_string(i) + ": " + hipGetErrorString((hipError_t)slice_rc[i]));
+  commit_buffer_parity(f0, f1);
   return 0;
 }
 
@@ -1407,7 +1437,7 @@ BatchBase* H(msckf_hip_handle h) { return reinterpret_cast<BatchBase*>(h); }
 }  // namespace
 
 #ifdef MSCKF_ABLATE
-namespace msckf { void qr_debug_set(int idx, int val); void feat_debug_set(int val); extern int g_gram_dbg; void chol_cycles_read(unsigned long long* out16, int reset); void prop_cycles_read(unsigned long long* out8, int reset); void gram_cycles_read(unsigned long long* out40, int reset); }
+namespace msckf { void qr_debug_set(int idx, int val); void feat_debug_set(int val); extern int g_gram_dbg; void chol_cycles_read(unsigned long long* out16, int reset); void prop_cycles_read(unsigned long long* out8, int reset); void gram_cycles_read(unsigned long long* out40, int reset); void gemm_cycles_read(unsigned long long* out16, int reset); void gemm_trace_read(unsigned long long* out); }
 #endif
 
 extern "C" {
@@ -1422,6 +1452,8 @@ void msckf_hip_debug_set(int idx, int val) {
 void msckf_hip_debug_chol_cycles(unsigned long long* out16, int reset) { msckf::chol_cycles_read(out16, reset); }
 void msckf_hip_debug_prop_cycles(unsigned long long* out8, int reset) { msckf::prop_cycles_read(out8, reset); }
 void msckf_hip_debug_gram_cycles(unsigned long long* out40, int reset) { msckf::gram_cycles_read(out40, reset); }
+void msckf_hip_debug_gemm_cycles(unsigned long long* out16, int reset) { msckf::gemm_cycles_read(out16, reset); }
+void msckf_hip_debug_gemm_trace(unsigned long long* out) { msckf::gemm_trace_read(out); }
 #endif
 
 const char* msckf_hip_last_error(void) { return g_err.c_str(); }

@@ -10,7 +10,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from msckf_mono_amd import capi, scenario as sc  # noqa: E402
 
-N, F, B, nf = 30, 200, 8, 40
+N, F, B, nf = 30, 200, int(os.environ.get("PHASES_B", "8")), 40
 trajs = [sc.Trajectory(3, b, N, F, nf) for b in range(B)]
 bt = capi.Batch(B, N, F, N, capi.F32)
 bt.set_compression(3); bt.set_covariance_update(0)
@@ -29,6 +29,8 @@ po8 = (C.c_ulonglong * 8)()
 bt.L.msckf_hip_debug_prop_cycles(po8, 1)
 g40 = (C.c_ulonglong * 40)()
 bt.L.msckf_hip_debug_gram_cycles(g40, 1)
+m16 = (C.c_ulonglong * 16)()
+bt.L.msckf_hip_debug_gemm_cycles(m16, 1)
 bt.run_frames(32, nf); bt.sync()
 bt.L.msckf_hip_debug_chol_cycles(out, 1)
 names = ["load", "panel->LDS", "diag block", "L21", "outputs", "trailing"]
@@ -44,3 +46,8 @@ g = np.array(g40, dtype=np.float64).reshape(8, 5)
 for strip in range(8):
     if g[strip, 4] > 0:
         print("k_gram SYRK strip", strip, "launches", int(g[strip, 4]), {a: int(c / g[strip, 4]) for a, c in zip(["start-up + count", "K loop", "group sum", "epilogue"], g[strip, :4])}, "total", int(g[strip, :4].sum() / g[strip, 4]))
+bt.L.msckf_hip_debug_gemm_cycles(m16, 1)
+m = np.array(m16, dtype=np.float64).reshape(2, 8)
+for row, nm in enumerate(("PHt", "downdate")):
+    if m[row, 4] > 0:
+        print("k_gemm_mfma", nm, "tile (1,1) launches", int(m[row, 4]), {a: int(c / m[row, 4]) for a, c in zip(["set-up", "first k-tile", "k loop", "epilogue"], m[row, :4])}, "total", int(m[row, :4].sum() / m[row, 4]))

@@ -37,12 +37,13 @@ def main():
     bt.scenario_pin(N, nfr)
     ref = None
     for v in a.variants:
-        kv = dict(streams=3, streamed=1, ring=6, mode=0, early=0)
+        kv = dict(streams=3, streamed=1, ring=6, mode=0, early=0, overlap=0)
         kv.update({k: int(x) for k, x in (p.split("=") for p in v.split(",") if p)})
         for b, tr in enumerate(trajs):
             bt.initialize(b, tr.cfg, tr.imu0)
         bt.set_streams(kv["streams"]); bt.set_upload_ring(kv["ring"], kv["mode"])
         bt.set_gate_early_accept(bool(kv["early"]))
+        bt.set_feature_overlap(bool(kv["overlap"]))
         run = bt.run_frames_streamed if kv["streamed"] else bt.run_frames
         bt.run_frames(0, N); run(N, N + W); bt.sync()
         vals = []
