@@ -253,7 +253,7 @@ __device__ __forceinline__ S gate_gamma_from_corner(const S* c) {
 // LONG: tracks of more than 30 observations (2M + 4 > 64) keep the gate's Cholesky in registers too (up to 16 x 16 blocks
 // per lane); a separate instantiation, so that the short-track kernel keeps its register budget.
 template <class S, bool LONG>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (sizeof(S) == 4 ? 4 : 2), sizeof(S) == 4 && !LONG ? 4 : 2))) void k_feature(Dev<S> d, int b0, int nb) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (sizeof(S) == 4 ? 4 : 2), sizeof(S) == 4 && !LONG ? 4 : 2))) void k_feature(Dev<S> d, int b0, int nb, int lm, int m_lo, int m_hi) {
   // all tracks of a trajectory on one XCD (xcd_item): the gate's 6 x 6 blocks of P then come out of an L2 that holds 1/8 of
   // the batch's covariances (the (track, trajectory) grid spread every trajectory over all eight: 68 MB fetched per launch for
   // 9.7 MB of covariance; now 17 MB).  Measured and rejected: a PERSISTENT form of this kernel -- one residency
@@ -273,11 +273,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
   const int m_cap = d.m_cap;
   // N's source G (symmetric, 2M x 2M) plus the four rows that ride along (r, the columns of H_f) as a packed lower triangle:
   // element (i, j), j <= i, at TRI(i, j).  sHx (G stage only) shares its space with sC, where the factorization leaves the
-  // 4 x 4 corner: 9.9 KB per wavefront at m_cap = 30, sixteen per CU
-  S* sG = reinterpret_cast<S*>(smem_raw);              // [(2 m_cap + 4)(2 m_cap + 5) / 2]
-  S* sHx = sG + (2 * m_cap + 4) * (2 * m_cap + 5) / 2; // [m_cap][12]
+  // 4 x 4 corner: 9.9 KB per wavefront at 30 observations, sixteen per CU.  The LDS layout is sized for lm <= m_cap
+  // observations: with long windows launch_feature bins the tracks by length (this launch takes m_lo < M <= m_hi), so that
+  // a short track does not hold the 31 KB a 60-observation track needs (5 wavefronts per CU)
+  S* sG = reinterpret_cast<S*>(smem_raw);              // [(2 lm + 4)(2 lm + 5) / 2]
+  S* sHx = sG + (2 * lm + 4) * (2 * lm + 5) / 2;       // [lm][12]
   S* sC = sHx;                                         // [16]: the corner
-  const int xlen = m_cap * 12 > 16 ? m_cap * 12 : 16;
+  const int xlen = lm * 12 > 16 ? lm * 12 : 16;
   int* sSlot = reinterpret_cast<int*>(sHx + xlen);
 
   const long tb = (long)b * d.f_cap + t;               // per-track output index
@@ -293,6 +295,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
 #else
   constexpr int fdbg = 0;
 #endif
+  if (M <= m_lo || M > m_hi) return;                   // another launch's bin
   if (M < 2 || M > m_cap || M > 64) {                  // cannot be residualized (checkMotion :982 returns false)
     if (lane == 0) { d.trk_status[tb] = 0; d.trk_gamma[tb] = 0; d.trk_first[tb] = 0; }
     return;
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
   const S zx = act ? d.trk_obs[2 * (wo + lane)] : S(0), zy = act ? d.trk_obs[2 * (wo + lane) + 1] : S(0);
   const M3<S> C = q2rot(qc);
   const V3<S> g = ld3(imu + IG);
-  if (lane < m_cap) sSlot[lane] = act ? slot : -1;
+  if (lane < lm) sSlot[lane] = act ? slot : -1;
   const int slot_lo = wave_min_i(act ? slot : 0x7fffffff), slot_hi = -wave_min_i(act ? -slot : 0x7fffffff);
   // first camera of the track (lane 0) broadcast
   M3<S> C0; V3<S> p0;
@@ -626,7 +629,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
   }
   if (!early) {
   // ---- stage H_x in LDS; G = H_x P_cc H_x^T from 6x6 blocks of P (upper block-triangle + mirror)
-  if (lane < m_cap) {
+  if (lane < lm) {
     for (int i = 0; i < 2; ++i) for (int k = 0; k < 6; ++k) sHx[lane * 12 + i * 6 + k] = hx[i][k];
   }
   __syncthreads();
@@ -1040,9 +1043,20 @@ void feature_device_setup() {
 template <class S>
 void launch_feature(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0) return;
-  const size_t lds = feature_lds_bytes(d.m_cap, sizeof(S));
-  if (2 * d.m_cap + 4 > 64) hipLaunchKernelGGL((k_feature<S, true>), dim3(xcd_grid(nb, d.f_cap)), dim3(64), lds, st, d, b0, nb);
-  else hipLaunchKernelGGL((k_feature<S, false>), dim3(xcd_grid(nb, d.f_cap)), dim3(64), lds, st, d, b0, nb);
+  const dim3 grid(xcd_grid(nb, d.f_cap));
+  constexpr int ALL_LO = -0x7fffffff, ALL_HI = 0x7fffffff, M_REG = 30;   // 2 * 30 + 4 = 64: the register-resident gate factorization
+  if (d.m_cap <= M_REG) {
+    hipLaunchKernelGGL((k_feature<S, false>), grid, dim3(64), feature_lds_bytes(d.m_cap, sizeof(S)), st, d, b0, nb, d.m_cap, ALL_LO, ALL_HI);
+    return;
+  }
+  // long windows: tracks binned by length, one launch per bin over the same grid (a workgroup whose track belongs to another
+  // bin returns at once).  Occupancy is set by the LDS of the bin's longest track, not of the window's
+  hipLaunchKernelGGL((k_feature<S, false>), grid, dim3(64), feature_lds_bytes(M_REG, sizeof(S)), st, d, b0, nb, M_REG, ALL_LO, M_REG);
+  const int mid = (M_REG + d.m_cap + 1) / 2;
+  if (d.m_cap - M_REG >= 16) {
+    hipLaunchKernelGGL((k_feature<S, true>), grid, dim3(64), feature_lds_bytes(mid, sizeof(S)), st, d, b0, nb, mid, M_REG, mid);
+    hipLaunchKernelGGL((k_feature<S, true>), grid, dim3(64), feature_lds_bytes(d.m_cap, sizeof(S)), st, d, b0, nb, d.m_cap, mid, ALL_HI);
+  } else hipLaunchKernelGGL((k_feature<S, true>), grid, dim3(64), feature_lds_bytes(d.m_cap, sizeof(S)), st, d, b0, nb, d.m_cap, M_REG, ALL_HI);
 }
 #ifdef MSCKF_ABLATE
 void feat_debug_set(int val) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_feat_dbg), &val, sizeof(int)); }
