@@ -292,6 +292,16 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0) {
   // source lanes), only the finished panel crossing to the other groups by ds_bpermute + a rank-4 update (3 crossbar round
   // trips per block instead of 16): diagonal-block phase 102 k -> 131 k cycles (f64), 66 k -> 75 k (f32).  On this chip a
   // VALU -> v_readlane -> VALU hop on the critical chain costs more than the ds_bpermute it replaces.
+  // Also rejected (round 3): the rank-1 update formed from the UNSCALED column, x(r, j) -= x(r, k) x(j, k) / piv, so that the
+  // crossbar reads of column k do not wait for the pivot's rsqrt: 100 k -> 106 k cycles (f64), 66 k -> 71 k (f32), and the
+  // float result drifts past the square-root-gain vs Joseph tolerance (1 / piv = rsqrt^2 loses a bit per pivot): the step is
+  // bound by the number of crossbar operations a wavefront can have in flight, not by the rsqrt in front of them.
+  // bound by the number of crossbar operations a wavefront can have in flight, not by the rsqrt in front of them.
+  // Also rejected (round 3): a leaner pivot step -- columns left unscaled until the end of the block, no per-element masks
+  // (zero multipliers instead), crossbar addresses formed once: ~30 instead of ~50 instructions per pivot in f32, yet 64 k -> 68 k
+  // cycles (f32), and the sixteen saved scale factors pushed the f64 instance into spills (load 15 k -> 39 k cycles).  Neither
+  // the instruction count nor the number of waits sets the ~335 (f32) / ~490 (f64) cycles per pivot; what remains is the chain
+  // rsq -> Newton -> v_readlane -> scale -> ds_bpermute -> FMA itself.
   auto diag = [&](auto pc) __attribute__((always_inline)) {
     constexpr int p = decltype(pc)::value;
     T (*sP)[LP] = sPP[p & 1];
@@ -318,16 +328,25 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0) {
         const T c_own = (r == k) ? pv * dinv : (r > k ? x[qk] * dinv : T(0));
         const T vk_own = v[qk] * dinv;
         if (g == gk) { x[qk] = c_own; v[qk] = vk_own; }
+        // all crossbar reads of the step are issued back to back, then one wait (left to itself the scheduler pairs them with
+        // the FMAs: three ds_bpermute latencies per pivot instead of one; diagonal blocks 100 k -> 94 k cycles in f64, 66 k ->
+        // 64 k in f32)
         const T c = __shfl(c_own, 16 * gk + r, 64);     // L(r, k) for every group
         const T vk = __shfl(vk_own, 16 * gk + r, 64);   // v(r, k)
+        T ljk[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           if (4 * q + 3 <= k) continue;                 // compile-time: all of this register's columns are <= k
+          ljk[q] = __shfl(c_own, 16 * gk + ((4 * q + g) & 15), 64);   // L(j, k)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (4 * q + 3 <= k) continue;
           const int j = 4 * q + g;
-          const T ljk = __shfl(c_own, 16 * gk + (j & 15), 64);   // L(j, k)
           if (j > k) {
-            if (r >= j) x[q] -= c * ljk;
-            v[q] -= vk * ljk;
+            if (r >= j) x[q] -= c * ljk[q];
+            v[q] -= vk * ljk[q];
           }
         }
       }

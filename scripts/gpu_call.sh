@@ -1,12 +1,8 @@
 cd /root/repo
-O=gpurun_out/r03ac; mkdir -p $O
+O=gpurun_out/r03af; mkdir -p $O
+PHASES_B=8 MSCKF_HIP_LIB=/root/repo/msckf_mono_amd/lib_ab/libmsckf_hip_ablate.so python scripts/chol_phases.py > $O/phases.txt 2>&1
+grep -E "GRAM|GAIN" $O/phases.txt | cut -c1-300
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $O/pytest.txt
 tail -5 $O/pytest.txt
-python bench.py --config cfg5 --steps 10 --warmup 3 --no-cpu-baseline --no-early-accept-pass > $O/bench_cfg5.json 2>$O/cfg5.err
-python -c "
-import json;j=json.loads(open('$O/bench_cfg5.json').read().strip().splitlines()[-1]);print('cfg5', j['value'], j.get('resident_inputs',{}).get('median'))"
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d /tmp/p1 -o r -- python /root/repo/bench.py --config cfg5 --steps 6 --warmup 2 --no-cpu-baseline --no-early-accept-pass --no-upload-pass --repeats 1 --streams 1 > /tmp/b1.log 2>&1
-DB=$(find /tmp/p1 -name "*.db" | head -1)
-ROCPD_TAIL=12 python /root/repo/scripts/rocpd_summary.py $DB /root/repo/$O/kernel_stats_cfg5.md > /dev/null
-head -12 /root/repo/$O/kernel_stats_cfg5.md
+python scripts/sweep_variants.py --steps 20 --windows 5 "streams=4,streamed=0" "streams=4,streamed=1" "streams=1,streamed=0" > $O/sweep.txt 2>&1
+cat $O/sweep.txt | cut -c1-250
