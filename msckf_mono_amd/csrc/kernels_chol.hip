@@ -67,10 +67,13 @@ __device__ unsigned long long g_chol_cycles[2][8];
 
 // NB: 16-column blocks of the factored matrix; NA: appended 16-row blocks held by ONE workgroup (GAIN), 0 for GRAM
 template <class T, class SO, int NB, int NA, int MODE, int NPART>
-__global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0) {
+__global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0, int nb) {
   typedef typename Mf<T>::V V;
   constexpr int NR = NB + NA, HR = (NR + 3) / 4, HC = (NB + 3) / 4, LP = 17;   // sixteen wavefronts: block (i, j) belongs to wavefront 4 (i & 3) + (j & 3)
-  const int b = b0 + (MODE == CH_GAIN ? blockIdx.y : blockIdx.x), part = MODE == CH_GAIN ? (int)blockIdx.x : 0;
+  // GAIN: the NPART workgroups of a trajectory read the same T and P T_H^T: on one XCD (xcd_item), whose L2 then serves three of the four
+  int bi_ = (int)blockIdx.x, part = 0;
+  if (MODE == CH_GAIN && !xcd_item(nb, NPART, bi_, part)) return;
+  const int b = b0 + bi_;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int pi = w >> 2, pj = w & 3;
   // wavefront 0 carries the 16-pivot chains of the diagonal blocks: it wins instruction arbitration against the three
@@ -622,11 +625,11 @@ bool launch_chol_gain_large(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0) return true;
   const int nblk = (d.n6cap + 15) / 16;
   if (!d.Mp2 || nblk <= 12 || nblk > 24) return false;
-  hipLaunchKernelGGL((k_chol_mfma<S, S, 12, 0, CH_S_A, 1>), dim3(nb), dim3(1024), 0, st, d, b0);
+  hipLaunchKernelGGL((k_chol_mfma<S, S, 12, 0, CH_S_A, 1>), dim3(nb), dim3(1024), 0, st, d, b0, nb);
   hipLaunchKernelGGL((k_trsm_rows<S, S, 12, TR_S21>), dim3((nblk - 12 + 3) / 4, nb), dim3(256), 0, st, d, b0);
-  if (nblk <= 16) hipLaunchKernelGGL((k_chol_mfma<S, S, 4, 0, CH_S_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0);
-  else if (nblk <= 20) hipLaunchKernelGGL((k_chol_mfma<S, S, 8, 0, CH_S_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0);
-  else hipLaunchKernelGGL((k_chol_mfma<S, S, 12, 0, CH_S_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0);
+  if (nblk <= 16) hipLaunchKernelGGL((k_chol_mfma<S, S, 4, 0, CH_S_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0, nb);
+  else if (nblk <= 20) hipLaunchKernelGGL((k_chol_mfma<S, S, 8, 0, CH_S_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0, nb);
+  else hipLaunchKernelGGL((k_chol_mfma<S, S, 12, 0, CH_S_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0, nb);
   const int rblk = (15 + d.n6cap + 1 + 15) / 16;          // 16-row blocks of [P T_H^T ; r_n^T]
   if (nblk <= 16) hipLaunchKernelGGL((k_trsm_rows<S, S, 16, TR_W>), dim3((rblk + 3) / 4, nb), dim3(256), 0, st, d, b0);
   else if (nblk <= 20) hipLaunchKernelGGL((k_trsm_rows<S, S, 20, TR_W>), dim3((rblk + 3) / 4, nb), dim3(256), 0, st, d, b0);
@@ -640,25 +643,25 @@ bool launch_chol_gram(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0) return true;
   const int nblk = d.ldR / 16;
   switch (nblk) {
-    case 4: hipLaunchKernelGGL((k_chol_mfma<double, S, 4, 0, CH_GRAM, 1>), dim3(nb), dim3(1024), 0, st, d, b0); return true;
-    case 8: hipLaunchKernelGGL((k_chol_mfma<double, S, 8, 0, CH_GRAM, 1>), dim3(nb), dim3(1024), 0, st, d, b0); return true;
-    case 12: hipLaunchKernelGGL((k_chol_mfma<double, S, 12, 0, CH_GRAM, 1>), dim3(nb), dim3(1024), 0, st, d, b0); return true;
+    case 4: hipLaunchKernelGGL((k_chol_mfma<double, S, 4, 0, CH_GRAM, 1>), dim3(nb), dim3(1024), 0, st, d, b0, nb); return true;
+    case 8: hipLaunchKernelGGL((k_chol_mfma<double, S, 8, 0, CH_GRAM, 1>), dim3(nb), dim3(1024), 0, st, d, b0, nb); return true;
+    case 12: hipLaunchKernelGGL((k_chol_mfma<double, S, 12, 0, CH_GRAM, 1>), dim3(nb), dim3(1024), 0, st, d, b0, nb); return true;
     default: break;
   }
   if (!d.Mp || (nblk != 16 && nblk != 20 && nblk != 24)) return false;
   // two levels: columns [0, 192), L21, Schur complement
-  hipLaunchKernelGGL((k_chol_mfma<double, S, 12, 0, CH_GRAM_A, 1>), dim3(nb), dim3(1024), 0, st, d, b0);
+  hipLaunchKernelGGL((k_chol_mfma<double, S, 12, 0, CH_GRAM_A, 1>), dim3(nb), dim3(1024), 0, st, d, b0, nb);
   hipLaunchKernelGGL((k_trsm_rows<double, S, 12, TR_GRAM>), dim3((nblk - 12 + 3) / 4, nb), dim3(256), 0, st, d, b0);
-  if (nblk == 16) hipLaunchKernelGGL((k_chol_mfma<double, S, 4, 0, CH_GRAM_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0);
-  else if (nblk == 20) hipLaunchKernelGGL((k_chol_mfma<double, S, 8, 0, CH_GRAM_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0);
-  else hipLaunchKernelGGL((k_chol_mfma<double, S, 12, 0, CH_GRAM_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0);
+  if (nblk == 16) hipLaunchKernelGGL((k_chol_mfma<double, S, 4, 0, CH_GRAM_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0, nb);
+  else if (nblk == 20) hipLaunchKernelGGL((k_chol_mfma<double, S, 8, 0, CH_GRAM_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0, nb);
+  else hipLaunchKernelGGL((k_chol_mfma<double, S, 12, 0, CH_GRAM_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0, nb);
   return true;
 }
 
 // GAIN: parts x NA blocks of 16 rows must cover the D + 1 appended rows (each part also carries r_n^T)
 template <int NB, int NA, int NPART>
 static void gain_launch(const Dev<float>& d, int b0, int nb, hipStream_t st) {
-  hipLaunchKernelGGL((k_chol_mfma<float, float, NB, NA, CH_GAIN, NPART>), dim3(NPART, nb), dim3(1024), 0, st, d, b0);
+  hipLaunchKernelGGL((k_chol_mfma<float, float, NB, NA, CH_GAIN, NPART>), dim3(xcd_grid(nb, NPART)), dim3(1024), 0, st, d, b0, nb);
 }
 bool launch_chol_gain(const Dev<float>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0) return true;

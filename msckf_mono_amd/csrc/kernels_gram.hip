@@ -90,10 +90,11 @@ __global__ __launch_bounds__(256) void k_gram_diag(Dev<S> d, int b0) {
 // order.
 template <class S>
 __global__ __launch_bounds__(512) void k_gram(Dev<S> d, int b0, int nb, int npairs, int dbg, int xoff) {
-  // (tiles of one trajectory on the trajectory's XCD, xcd_item: fetch 54 -> 22 MB per launch, time unchanged -- the loop is
-  // bound by load latency and the matrix cores, not by L2 misses; the plain mapping stays)
-  const int bi = (int)blockIdx.x / npairs, bxi = (int)blockIdx.x - bi * npairs;
-  if (bi >= nb) return;
+  // tiles of one trajectory on the trajectory's XCD (xcd_item): every strip reads the trajectory's B^ rows, and an XCD's L2 is
+  // private -- fetch 54 -> 22 MB per launch.  The time does not change (the loop is bound by load latency and the matrix
+  // cores, not by L2 misses); the fabric traffic is what the other slices' kernels get back
+  int bi, bxi;
+  if (!xcd_item(nb, npairs, bi, bxi)) return;
   const int b = b0 + bi, grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, w = tid >> 6;
   const int* st = d.stats + (long)b * STAT_STRIDE;
   const int mrows_ = st[STAT_MROWS], P = st[STAT_PASSED], N = d.ncam[b];   // independent scalar loads, one wait
@@ -580,7 +581,7 @@ void launch_gram(const Dev<S>& din, int b0, int nb, hipStream_t st, int phase) {
     // (MFMA-bound, <= 192 workgroups).  In ONE launch the dispatcher packs strips two to a CU behind the reduction
     // workgroups and they share the matrix cores (measured: MFMA phase 2x longer).
     if (!(g_dbg & 1) && phase != 3) hipLaunchKernelGGL(k_gram_diag<S>, dim3(ndiag, nb), dim3(256), 0, st, d, b0);
-    hipLaunchKernelGGL(k_gram<S>, dim3(nb * npairs), dim3(512), gram_lds_bytes(), st, d, b0, nb, npairs, g_dbg, 0);
+    hipLaunchKernelGGL(k_gram<S>, dim3(xcd_grid(nb, npairs)), dim3(512), gram_lds_bytes(), st, d, b0, nb, npairs, g_dbg, 0);
   }
   if (phase == 1 || phase == 3) return;
   // k_chol_blk (blocked, trailing update on the f64 matrix cores) is 10 % faster than k_chol_T in isolation (104 vs
