@@ -131,7 +131,10 @@ int msckf_hip_scenario_set(msckf_hip_handle h, int frame, int b, const double* r
                            const int* M, const int* slots, const double* obs2, int n_drop);
 int msckf_hip_scenario_commit(msckf_hip_handle h);   /* H2D of everything staged */
 /* one filter update per trajectory per frame: K x propagate + augmentState + marginalize + prune, for
- * frames [f0, f1), asynchronously on the handle's stream */
+ * frames [f0, f1), asynchronously on the handle's stream.  Results do not depend on how a range is cut into calls.
+ * (In the square-root gain form the prune of every frame but a call's last rides on the covariance downdate, which
+ * writes the pruned covariance into the handle's second buffer -- one launch less per frame; environment
+ * MSCKF_HIP_FUSE_PRUNE=0 at create time keeps the separate prune launch, for A/B runs.) */
 int msckf_hip_run_frames(msckf_hip_handle h, int f0, int f1);
 /* The same frames with the inputs handed over per frame, as the reference's callers do (IMU samples and the image's
  * tracks arrive with the image, asl_msckf.cpp:227-284): frame f's IMU samples and its COMPACT work-list (sum M_j slot /
