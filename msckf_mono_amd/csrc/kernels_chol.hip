@@ -514,13 +514,16 @@ enum { TR_GRAM = 0, TR_S21 = 1, TR_W = 2 };
 // compiler must not move the reads above the writes -- per-thread addresses differ, so only the fences order them
 #define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 template <class T, class SO, int NP, int TMODE>
-__global__ __launch_bounds__(256) void k_trsm_rows(Dev<SO> d, int b0) {
+__global__ __launch_bounds__(256) void k_trsm_rows(Dev<SO> d, int b0, int nb, int nwg) {
   typedef typename Mf<T>::V V;
   constexpr int LP = 17;
-  const int b = b0 + blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // the row blocks of a trajectory all read its factor L: on one XCD (xcd_item), whose private L2 then fetches it once
+  int bi_, wg_;
+  if (!xcd_item(nb, nwg, bi_, wg_)) return;
+  const int b = b0 + bi_, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int* st = d.stats + (long)b * STAT_STRIDE;
   if (st[STAT_MROWS] == 0) return;
-  const int i = 4 * (int)blockIdx.x + w;                 // 16-row block
+  const int i = 4 * wg_ + w;                             // 16-row block
   const int nfull = 6 * d.ncam[b], D = 15 + nfull;
   const int ncols = TMODE == TR_W ? nfull : min(nfull, CH_SPLIT);      // columns of L that exist
   const int R0 = TMODE == TR_W ? 16 * i : CH_SPLIT + 16 * i;           // first row of the block (TR_W: row of [PHt ; r_n^T])
@@ -626,14 +629,14 @@ bool launch_chol_gain_large(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   const int nblk = (d.n6cap + 15) / 16;
   if (!d.Mp2 || nblk <= 12 || nblk > 24) return false;
   hipLaunchKernelGGL((k_chol_mfma<S, S, 12, 0, CH_S_A, 1>), dim3(nb), dim3(1024), 0, st, d, b0, nb);
-  hipLaunchKernelGGL((k_trsm_rows<S, S, 12, TR_S21>), dim3((nblk - 12 + 3) / 4, nb), dim3(256), 0, st, d, b0);
+  hipLaunchKernelGGL((k_trsm_rows<S, S, 12, TR_S21>), dim3(xcd_grid(nb, (nblk - 12 + 3) / 4)), dim3(256), 0, st, d, b0, nb, (nblk - 12 + 3) / 4);
   if (nblk <= 16) hipLaunchKernelGGL((k_chol_mfma<S, S, 4, 0, CH_S_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0, nb);
   else if (nblk <= 20) hipLaunchKernelGGL((k_chol_mfma<S, S, 8, 0, CH_S_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0, nb);
   else hipLaunchKernelGGL((k_chol_mfma<S, S, 12, 0, CH_S_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0, nb);
   const int rblk = (15 + d.n6cap + 1 + 15) / 16;          // 16-row blocks of [P T_H^T ; r_n^T]
-  if (nblk <= 16) hipLaunchKernelGGL((k_trsm_rows<S, S, 16, TR_W>), dim3((rblk + 3) / 4, nb), dim3(256), 0, st, d, b0);
-  else if (nblk <= 20) hipLaunchKernelGGL((k_trsm_rows<S, S, 20, TR_W>), dim3((rblk + 3) / 4, nb), dim3(256), 0, st, d, b0);
-  else hipLaunchKernelGGL((k_trsm_rows<S, S, 24, TR_W>), dim3((rblk + 3) / 4, nb), dim3(256), 0, st, d, b0);
+  if (nblk <= 16) hipLaunchKernelGGL((k_trsm_rows<S, S, 16, TR_W>), dim3(xcd_grid(nb, (rblk + 3) / 4)), dim3(256), 0, st, d, b0, nb, (rblk + 3) / 4);
+  else if (nblk <= 20) hipLaunchKernelGGL((k_trsm_rows<S, S, 20, TR_W>), dim3(xcd_grid(nb, (rblk + 3) / 4)), dim3(256), 0, st, d, b0, nb, (rblk + 3) / 4);
+  else hipLaunchKernelGGL((k_trsm_rows<S, S, 24, TR_W>), dim3(xcd_grid(nb, (rblk + 3) / 4)), dim3(256), 0, st, d, b0, nb, (rblk + 3) / 4);
   hipLaunchKernelGGL((k_dx_wz<S>), dim3(nb), dim3(256), 0, st, d, b0);
   return true;
 }
@@ -651,7 +654,7 @@ bool launch_chol_gram(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if (!d.Mp || (nblk != 16 && nblk != 20 && nblk != 24)) return false;
   // two levels: columns [0, 192), L21, Schur complement
   hipLaunchKernelGGL((k_chol_mfma<double, S, 12, 0, CH_GRAM_A, 1>), dim3(nb), dim3(1024), 0, st, d, b0, nb);
-  hipLaunchKernelGGL((k_trsm_rows<double, S, 12, TR_GRAM>), dim3((nblk - 12 + 3) / 4, nb), dim3(256), 0, st, d, b0);
+  hipLaunchKernelGGL((k_trsm_rows<double, S, 12, TR_GRAM>), dim3(xcd_grid(nb, (nblk - 12 + 3) / 4)), dim3(256), 0, st, d, b0, nb, (nblk - 12 + 3) / 4);
   if (nblk == 16) hipLaunchKernelGGL((k_chol_mfma<double, S, 4, 0, CH_GRAM_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0, nb);
   else if (nblk == 20) hipLaunchKernelGGL((k_chol_mfma<double, S, 8, 0, CH_GRAM_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0, nb);
   else hipLaunchKernelGGL((k_chol_mfma<double, S, 12, 0, CH_GRAM_B, 1>), dim3(nb), dim3(1024), 0, st, d, b0, nb);
