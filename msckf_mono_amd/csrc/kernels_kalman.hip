@@ -23,7 +23,8 @@
 
 namespace msckf {
 
-enum { OP_PHT = 0, OP_S, OP_W, OP_K, OP_A, OP_AP, OP_X, OP_KE, OP_DOWN };
+enum { OP_PHT = 0, OP_S, OP_W, OP_K, OP_A, OP_AP, OP_X, OP_KE, OP_DOWN,
+       OP_PHTT };   // PHt = P[:,15:] T^T written ONLY as its row-major copy (float MFMA kernel): all the blocked gain solve reads
 
 template <class S>
 struct KView {
@@ -244,9 +245,14 @@ void gemm_trace_read(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, H
 #endif
 constexpr int GT = 64;   // k-tile of the MFMA GEMM (the staging maps below assume 64)
 
-template <int OP>
+template <int OPX>
 __global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0, int nb, int tiles_x, int tiles_y) {
   using S = float;
+  // OP_PHTT: the PHt product with the accumulator holding the block itself instead of its transpose, so that the lanes run along
+  // the row-major copy's contiguous index j and that copy is the only output (the column-major PHt has no reader when S is
+  // formed inside the blocked gain solve): half the bytes, and the one store that was strided is gone
+  constexpr bool ROWMAJ = OPX == OP_PHTT;
+  constexpr int OP = ROWMAJ ? (int)OP_PHT : OPX;
   // workgroup -> (trajectory, tile) with all tiles of a trajectory on one XCD (xcd_item): the tiles of a product share their
   // operand panels, and an XCD's L2 is private -- with the tiles of a trajectory dealt round-robin over the eight XCDs every
   // XCD pulled every trajectory's operands over the fabric
@@ -338,12 +344,27 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0, int nb,
       for (int kk = 0; kk < GT; kk += 2) {
         const S bj = sB[kk + (lane >> 5)][32 * wn + (lane & 31)];   // MFMA A operand: rows of the result = j
         const S ai = sA[kk + (lane >> 5)][32 * wm + (lane & 31)];   // MFMA B operand: cols of the result = i
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bj, ai, acc, 0, 0, 0);
+        acc = ROWMAJ ? __builtin_amdgcn_mfma_f32_32x32x2f32(ai, bj, acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(bj, ai, acc, 0, 0, 0);
       }
     }
     __syncthreads();
   }
   GM_TICK(2);
+  if (ROWMAJ) {
+    const int gj = j0 + 32 * wn + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int gi2 = i0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (gi2 < M && gj < N) v.PHtT[(long)gi2 * v.ldn + gj] = acc[r];
+    }
+#ifdef MSCKF_ABLATE
+    __builtin_amdgcn_s_waitcnt(0);
+    GM_TICK(3);
+    GM_TRACE(1);
+    if (threadIdx.x == 0 && bx == 0 && by == 1) atomicAdd(&g_gemm_cycles[0][4], 1ull);
+#endif
+    return;
+  }
   const int gi = i0 + 32 * wm + (lane & 31);
   if (OP == OP_X) {
     // P <- (X + X^T)/2 (msckf.h:1418) fused into the product: X is not materialised.  Tiles above the block diagonal
@@ -373,7 +394,7 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0, int nb,
     // P <- P - W W^T on the upper triangle (diagonal tiles), both halves written from the same value.  All sixteen old values
     // are requested before the first store: interleaved (load, subtract, two stores per element) the compiler must assume
     // that a store changes the next element's load and waits for the stores' acknowledgement every time -- sixteen serial
-    // round trips, which were ~24 of this launch's 32 us
+    // round trips (31.7 -> 29.4 us)
     S* Pw = const_cast<S*>(v.P);
     S old[16];
 #pragma unroll
@@ -381,24 +402,35 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0, int nb,
       const int gj = j0 + 32 * wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       old[r] = (gi <= gj && gj < N) ? Pw[(long)gj * v.ld + gi] : 0.f;
     }
-    if (fused_prune) {
-      // rows / columns of the nd_ oldest camera states vanish, later ones move up by 6 nd_: written to the other buffer
-      S* Po = d.Pout + (long)b * v.ld * v.ld;
-      const int cut = 15 + 6 * nd_;
-      const int di = gi < 15 ? gi : gi - 6 * nd_;
-      const bool keep_i = gi < 15 || gi >= cut;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int gj = j0 + 32 * wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int dj = gj < 15 ? gj : gj - 6 * nd_;
-        if (gi <= gj && gj < N && keep_i && (gj < 15 || gj >= cut)) { const S val = old[r] - acc[r]; Po[(long)dj * v.ld + di] = val; Po[(long)di * v.ld + dj] = val; }
-      }
-    } else {
+    // Rows / columns of the nd_ oldest camera states vanish, later ones move up by 6 nd_ (fused prune: into the other buffer;
+    // nd_ = 0 otherwise).  The value goes to (row, column) = (i, j) with the lanes along i, and to its mirror image (j, i)
+    // through an LDS transpose so that the lanes run along j there too: the mirror store straight from the accumulator
+    // layout was a 4-byte store per lane with a stride of a whole column (PHt's row-major copy had the same: 20.7 -> 15.1 us)
+    S* Po = fused_prune ? d.Pout + (long)b * v.ld * v.ld : Pw;
+    const int cut = 15 + 6 * nd_;
+    const int di = gi < 15 ? gi : gi - 6 * nd_;
+    const bool keep_i = gi < 15 || gi >= cut;
+    S (*sT)[65] = reinterpret_cast<S (*)[65]>(sbuf);   // [64][65]: the k loop ended with a barrier
+    const int li = 32 * wm + (lane & 31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int gj = j0 + 32 * wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (gi <= gj && gj < N) { const S val = old[r] - acc[r]; Pw[(long)gj * v.ld + gi] = val; Pw[(long)gi * v.ld + gj] = val; }
+      const int lj = 32 * wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), gj = j0 + lj;
+      const int dj = gj < 15 ? gj : gj - 6 * nd_;
+      const S val = old[r] - acc[r];
+      sT[li][lj] = val;
+      if (gi <= gj && gj < N && keep_i && (gj < 15 || gj >= cut)) Po[(long)dj * v.ld + di] = val;
     }
+    __syncthreads();
+    {
+      const int lj = tid & 63, gj = j0 + lj;
+      const int dj = gj < 15 ? gj : gj - 6 * nd_;
+      const bool keep_j = gj < N && (gj < 15 || gj >= cut);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int li2 = (tid >> 6) + 4 * q, gi2 = i0 + li2;
+        const int di2 = gi2 < 15 ? gi2 : gi2 - 6 * nd_;
+        if (keep_j && gi2 <= gj && (gi2 < 15 || gi2 >= cut)) Po[(long)di2 * v.ld + dj] = sT[li2][lj];
+      }
     }
 #ifdef MSCKF_ABLATE
     __builtin_amdgcn_s_waitcnt(0);
@@ -1048,6 +1080,9 @@ static void gemm(const Dev<S>& d, int b0, int nb, int Mmax, int Nmax, hipStream_
   gemm_launch<OP>(d, b0, nb, Mmax, Nmax, st);
 }
 
+static void gemm_pht_rowmajor(const Dev<float>& d, int b0, int nb, int Mmax, int Nmax, hipStream_t st) { gemm_launch<OP_PHTT>(d, b0, nb, Mmax, Nmax, st); }
+static void gemm_pht_rowmajor(const Dev<double>& d, int b0, int nb, int Mmax, int Nmax, hipStream_t st) { gemm_launch<OP_PHT>(d, b0, nb, Mmax, Nmax, st); }   // (never taken: s_fused is float only)
+
 template <class S, int NBN>
 static void launch_gain_w(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   // more workgroups per trajectory while the batch leaves CUs idle (the Cholesky of S is redone by each of them)
@@ -1063,9 +1098,10 @@ template <class S>
 void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0) return;
   const int n = d.n6cap, D = 15 + n;
-  gemm<S, OP_PHT>(d, b0, nb, D, n, st);
-  // S: formed inside the blocked gain solve where that runs (float, square-root gain form, windows up to 32 cameras)
+  // S: formed inside the blocked gain solve where that runs (float, square-root gain form, windows up to 32 cameras); nothing
+  // then reads the column-major PHt, so only its row-major copy is written
   const bool s_fused = sizeof(S) == 4 && d.joseph == 0 && d.gain_fused_s && (n + 15) / 16 <= 12;
+  if (s_fused) gemm_pht_rowmajor(d, b0, nb, D, n, st); else gemm<S, OP_PHT>(d, b0, nb, D, n, st);
   if (!s_fused) gemm<S, OP_S>(d, b0, nb, n, n, st);
   const int nbn = (n + 15) / 16;
   const int nbn_max = sizeof(S) == 4 ? 12 : 8;

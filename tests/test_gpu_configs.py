@@ -86,6 +86,43 @@ def test_cfg3_streams_give_bit_identical_results(capi, cfg3_trajs):
                 assert np.array_equal(x, y), ("streamed", ns, ring, mode, b)
 
 
+@pytest.mark.parametrize("dtype_name", ["f32", "f64"])
+def test_prune_on_the_downdate_equals_the_separate_prune(capi, dtype_name):
+    """Inside run_frames the prune of every frame but a call's last rides on the covariance downdate (written to its pruned
+    position in the handle's second covariance buffer, window size committed by the next frame's propagate), the last frame
+    of a call prunes with its own launch.  However a frame range is cut into calls -- all at once, frame by frame (no
+    fused frame at all), in pieces of 2 and 3 (odd and even numbers of buffer swaps per call), streamed or resident --
+    states, camera states, covariance, window size and statistics must be the SAME BITS, and the getters must read the
+    buffer that is current after an odd number of swaps."""
+    N, F, B = 8, 40, 6
+    nf = N + 9
+    dtype = capi.F32 if dtype_name == "f32" else capi.F64
+    trajs = [sc.Trajectory(2, 300 + b, N, F, nf) for b in range(B)]
+
+    def run(cuts, streamed=False, streams=1):
+        bt = _resident_batch(capi, trajs, N, F, nf, 12, dtype, streams=streams)
+        a = 0
+        for c in cuts:
+            (bt.run_frames_streamed if streamed else bt.run_frames)(a, a + c)
+            a += c
+        assert a == nf
+        bt.sync()
+        out = _snapshot(bt, B), [bt.num_cam_states(b) for b in range(B)], [bt.last_stats(b) for b in range(B)]
+        bt.close()
+        return out
+
+    ref = run([1] * nf)                              # every frame its own call: the separate prune launch throughout
+    assert all(n == N - 1 for n in ref[1])           # the window is full and one state is dropped per frame
+    for cuts, kw in (([nf], {}), ([2] * (nf // 2) + [nf % 2] * (nf % 2), {}), ([3, 4, 3, nf - 10], {}),
+                     ([nf], dict(streams=3)), ([4, nf - 4], dict(streamed=True, streams=2))):
+        snap, ncam, stats = run([c for c in cuts if c], **kw)
+        assert ncam == ref[1], (cuts, kw)
+        for b in range(B):
+            for x, y in zip(snap[b], ref[0][b]):
+                assert np.array_equal(x, y), (dtype_name, cuts, kw, b)
+            assert stats[b] == ref[2][b], (cuts, kw, b)
+
+
 def test_cfg3_batch_of_64_vs_oracle(capi, po, cfg3_trajs):
     """The benched configuration against the oracle: after the window is full, 8 sampled trajectories of the 64 hand their
     state + covariance to a float oracle (teacher forcing, device -> oracle), both run the next filter update on the same
