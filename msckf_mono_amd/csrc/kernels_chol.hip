@@ -60,6 +60,7 @@ constexpr int CH_SPLIT = 192;   // columns of level A
 // phase timers of the -DMSCKF_ABLATE build: shader-clock cycles of workgroup 0's thread 0 per phase, summed over launches
 // [mode][0 load, 1 panel->LDS, 2 diagonal block, 3 L21, 4 outputs, 5 trailing update, 6 launches]
 __device__ unsigned long long g_chol_cycles[2][8];
+__device__ int g_chol_dbg = 0;   // ablation: 1 the other wavefronts skip outputs / trailing update while wavefront 0 factors the next diagonal block (wrong results, timing only)
 #define CH_TICK(slot) do { if (tid == 0) { const long long t_ = clock64(); cyc[slot] += t_ - tlast; tlast = t_; } } while (0)
 #else
 #define CH_TICK(slot) do {} while (0)
@@ -305,6 +306,10 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0, int nb) {
   // cycles (f32), and the sixteen saved scale factors pushed the f64 instance into spills (load 15 k -> 39 k cycles).  Neither
   // the instruction count nor the number of waits sets the ~335 (f32) / ~490 (f64) cycles per pivot; what remains is the chain
   // rsq -> Newton -> v_readlane -> scale -> ds_bpermute -> FMA itself.
+  // Also rejected (round 3): TWO pivots per crossbar round trip in float (raw columns k and k + 1 read together, column k + 1
+  // brought up to date locally, d2 = x(k+1, k+1) - L(k+1, k)^2 from three broadcast scalars -- the same products and bits as
+  // the one-pivot form): eight dependent crossbar latencies per block instead of sixteen, diagonal blocks 64.4 k -> 65.2 k
+  // cycles (profiles/r03_aj_*).  So the crossbar latency is not what a pivot step waits for either.
   auto diag = [&](auto pc) __attribute__((always_inline)) {
     constexpr int p = decltype(pc)::value;
     T (*sP)[LP] = sPP[p & 1];
@@ -479,9 +484,15 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0, int nb) {
       CH_TICK(4);
       if (more) diag(std::integral_constant<int, pn>{});
       CH_TICK(2);
+#ifdef MSCKF_ABLATE
+      if (!(g_chol_dbg & 1)) {
+#endif
       outputs(pc);
       trail(pc, std::false_type{});
       if (more) drop(std::integral_constant<int, pn>{}, std::integral_constant<int, 2>{});   // the rest of the next panel (rows disjoint from the diagonal block's)
+#ifdef MSCKF_ABLATE
+      }
+#endif
       __syncthreads();
       CH_TICK(5);
     }
@@ -677,6 +688,7 @@ bool launch_chol_gain(const Dev<float>& d, int b0, int nb, hipStream_t st) {
 }
 
 #ifdef MSCKF_ABLATE
+void chol_debug_set(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chol_dbg), &v, sizeof(int)); }
 void chol_cycles_read(unsigned long long* out16, int reset) {
   (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_chol_cycles), sizeof(unsigned long long) * 16);
   if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chol_cycles), z, sizeof(z)); }

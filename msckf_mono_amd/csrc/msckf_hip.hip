@@ -1437,7 +1437,7 @@ BatchBase* H(msckf_hip_handle h) { return reinterpret_cast<BatchBase*>(h); }
 }  // namespace
 
 #ifdef MSCKF_ABLATE
-namespace msckf { void qr_debug_set(int idx, int val); void feat_debug_set(int val); extern int g_gram_dbg; void chol_cycles_read(unsigned long long* out16, int reset); void prop_cycles_read(unsigned long long* out8, int reset); void gram_cycles_read(unsigned long long* out40, int reset); void gemm_cycles_read(unsigned long long* out16, int reset); void gemm_trace_read(unsigned long long* out); }
+namespace msckf { void qr_debug_set(int idx, int val); void feat_debug_set(int val); extern int g_gram_dbg; void chol_cycles_read(unsigned long long* out16, int reset); void chol_debug_set(int v); void prop_cycles_read(unsigned long long* out8, int reset); void gram_cycles_read(unsigned long long* out40, int reset); void gemm_cycles_read(unsigned long long* out16, int reset); void gemm_trace_read(unsigned long long* out); }
 #endif
 
 extern "C" {
@@ -1447,6 +1447,7 @@ extern "C" {
 void msckf_hip_debug_set(int idx, int val) {
   if (idx == 200) { msckf::feat_debug_set(val); return; }
   if (idx == 300) { msckf::g_gram_dbg = val; return; }
+  if (idx == 400) { msckf::chol_debug_set(val); return; }
   msckf::qr_debug_set(idx, val);
 }
 void msckf_hip_debug_chol_cycles(unsigned long long* out16, int reset) { msckf::chol_cycles_read(out16, reset); }

@@ -23,6 +23,8 @@ for k in range(nf):
         bt.scenario_set(k, b, tr.imu_for_frame(k), fr["M"], fr["slots"], fr["obs"], 1 if fr["Nw"] == N else 0)
 bt.scenario_commit()
 bt.run_frames(0, 32); bt.sync()
+if os.environ.get("CHOL_DBG"):
+    bt.L.msckf_hip_debug_set(400, int(os.environ["CHOL_DBG"]))   # ablation knob of kernels_chol.hip (timing only: results are wrong)
 out = (C.c_ulonglong * 16)()
 bt.L.msckf_hip_debug_chol_cycles(out, 1)
 po8 = (C.c_ulonglong * 8)()
