@@ -310,6 +310,8 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0, int nb) {
   // brought up to date locally, d2 = x(k+1, k+1) - L(k+1, k)^2 from three broadcast scalars -- the same products and bits as
   // the one-pivot form): eight dependent crossbar latencies per block instead of sixteen, diagonal blocks 64.4 k -> 65.2 k
   // cycles (profiles/r03_aj_*).  So the crossbar latency is not what a pivot step waits for either.
+  // And the hardware v_rsq_f32 without its Newton step (three dependent operations less per pivot): 60.5 k -> 57.9 k cycles, but
+  // the float square-root-gain vs Joseph comparison fails its 1e-3 -- the seed is not accurate enough for 180 pivots in a row.
   auto diag = [&](auto pc) __attribute__((always_inline)) {
     constexpr int p = decltype(pc)::value;
     T (*sP)[LP] = sPP[p & 1];
