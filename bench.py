@@ -371,8 +371,9 @@ def main():
             "k_gram": dict(ms=stage_ms["compress_stage1"], flops=fl["gram"], bound="mfma", peak=PEAK_F64_TFLOPS,
                            why="SYRK of the projected blocks on v_mfma_f64_16x16x4 (information form: its own FLOP, ~20x fewer than the "
                                "reference's Householder QR of the stack): bound by load latency, not by the matrix cores"),
-            "k_chol_mfma": dict(ms=stage_ms["compress_merge"], flops=0.0, bound="mfma", peak=PEAK_F64_TFLOPS,
-                                why="blocked f64 Cholesky of the Gram matrix, one workgroup per trajectory: latency bound"),
+            "k_chol_mfma": dict(ms=stage_ms["compress_merge"], flops=ex.get("compress_merge", 0.0), bound="mfma", peak=PEAK_F64_TFLOPS,
+                                why="blocked f64 Cholesky of the Gram matrix ((n+1)^3/3 FLOP: the information form's own, the reference has no "
+                                    "such stage), one workgroup per trajectory: bound by its 16-pivot diagonal-block chains"),
             "k_propagate": dict(ms=stage_ms["propagate"], flops=fl["propagate"], bound="valu", peak=PEAK_F32_TFLOPS,
                                 why="sequential 15x15 chain per trajectory: latency bound"),
         }

@@ -104,6 +104,10 @@ struct Dev {
   // the register-resident one (double); 1 = the reference's Joseph sequence; 2 = square-root gain form, register-resident solve
   int joseph;
   int gain_fused_s;   // float blocked gain solve: S = T_H (P T_H^T)[15:, :] + sigma^2 I is formed inside k_chol_mfma (no S GEMM launch)
+  // gain_fused_s == 2 (default; 3 = the same with a zero wait, so that tests reach the fall-back): the parts of a trajectory share the product -- each forms a quarter of S's blocks, writes them to Smat
+  // with agent-scope stores, the parts meet at a counter barrier (gain_bar, one 128-byte line per trajectory, only grows) and
+  // read the rest back -- a part that does not see its siblings within ~1 ms forms the missing blocks itself; 1: every part forms all of S
+  unsigned* gain_bar;
   // Kalman work matrices
   S* PHt; S* Smat; S* Linv; S* W; S* K; S* A; S* AP; S* X; S* dx;
   // prune

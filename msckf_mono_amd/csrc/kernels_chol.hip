@@ -77,6 +77,10 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0, int nb) {
   const int b = b0 + bi_;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int pi = w >> 2, pj = w & 3;
+  // which part of a trajectory forms the S blocks of register set (ii, jj) when the parts share the product (gain_fused_s == 2):
+  // block row set 0 (up to twelve k-blocks per block) alone on part 0, the two sets of row set 1 on parts 1 and 2, row set 2's
+  // three (few k-blocks each) on parts 1, 2, 3
+  auto s_owner = [](int ii, int jj) -> int { return (ii == 0 ? 0 : (ii == 1 ? 1 + jj : (jj == 2 ? 3 : 1 + jj))) % NPART; };
   // wavefront 0 carries the 16-pivot chains of the diagonal blocks: it wins instruction arbitration against the three
   // wavefronts that share its SIMD (and everybody against co-resident throughput waves of another slice)
   if (w == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);
@@ -135,6 +139,47 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0, int nb) {
 #ifdef MSCKF_ABLATE
   long long cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
 #endif
+  // S = T_H (P T_H^T)[15:, :] + sigma^2 I (msckf.h:1369) is formed HERE, straight into the accumulators, instead of being
+  // loaded: block (i, j) = sum over the k-blocks kb >= i (T_H is upper triangular) of T(16 i .., k) PHt(15 + k, 16 j ..),
+  // four MFMAs per k-block, operands from global memory (T rows as one 16-byte load per lane, PHt through its
+  // row-major copy).  The S GEMM was a launch of its own (24 us, bound by its start-up and drain).
+  auto s_block = [&](int i, int j) -> V {
+    V out = V{0, 0, 0, 0};
+    if constexpr (MODE == CH_GAIN) {
+      const int rr = lane & 15, gq = lane >> 4;
+      const T* Trow = reinterpret_cast<const T*>(R0) + (long)min(16 * i + rr, d.n6cap - 1) * d.ldR;
+      const T* Bcol = reinterpret_cast<const T*>(PHtT) + min(16 * j + rr, d.n6cap - 1);
+      V sacc = V{0, 0, 0, 0};
+      typedef T t4 __attribute__((ext_vector_type(4)));
+      const int kbmax = min(NB, (n + 15) >> 4);
+      // six k-blocks per pass: their thirty loads are issued together (clamped addresses, masks afterwards), then the MFMAs
+      constexpr int KU = 6;
+      for (int kb0 = i; kb0 < kbmax; kb0 += KU) {
+        t4 a4[KU]; T bv[KU][4];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+          const int k0 = 16 * min(kb0 + u, NB - 1) + 4 * gq;
+          a4[u] = *reinterpret_cast<const t4*>(Trow + k0);
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) bv[u][s4] = Bcol[(long)min(15 + k0 + s4, d.ld - 1) * d.n6cap];
+        }
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+          if (kb0 + u >= kbmax) break;
+          const int k0 = 16 * (kb0 + u) + 4 * gq;
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const bool ok = k0 + s4 < n;
+            sacc = Mf<T>::mma(ok ? a4[u][s4] : T(0), ok ? bv[u][s4] : T(0), sacc);
+          }
+        }
+      }
+      const T sg2 = (T)d.prm[(long)b * PRM_STRIDE + PRM_SIG2];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[r] = sacc[r] + ((i == j && Mf<T>::row(lane, r) == (lane & 15)) ? sg2 : T(0));
+    }
+    return out;
+  };
   V acc[HR][HC];
 #pragma unroll
   for (int ii = 0; ii < HR; ++ii)
@@ -145,47 +190,8 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0, int nb) {
       const int i = 4 * ii + pi, j = 4 * jj + pj;
       if (i >= NR || j >= NB || (i < NB && j > i) || 16 * j >= n) continue;
       if (i < NB && 16 * i >= main_rows) continue;
-      if (MODE == CH_GAIN && d.gain_fused_s && i < NB) {
-        // S = T_H (P T_H^T)[15:, :] + sigma^2 I (msckf.h:1369) formed HERE, straight into the accumulators, instead of being
-        // loaded: block (i, j) = sum over the k-blocks kb >= i (T_H is upper triangular) of T(16 i .., k) PHt(15 + k, 16 j ..),
-        // four MFMAs per k-block, operands from global memory (T rows as one 16-byte load per lane, PHt through its
-        // row-major copy).  The S GEMM was a launch of its own (24 us, bound by its start-up and drain); every part of a
-        // trajectory redoes the product, as it redoes the factorization.
-        if constexpr (MODE == CH_GAIN) {
-          const int rr = lane & 15, gq = lane >> 4;
-          const T* Trow = reinterpret_cast<const T*>(R0) + (long)min(16 * i + rr, d.n6cap - 1) * d.ldR;
-          const T* Bcol = reinterpret_cast<const T*>(PHtT) + min(16 * j + rr, d.n6cap - 1);
-          V sacc = V{0, 0, 0, 0};
-          typedef T t4 __attribute__((ext_vector_type(4)));
-          const int kbmax = min(NB, (n + 15) >> 4);
-          // six k-blocks per pass: their thirty loads are issued together (clamped addresses, masks afterwards), then the MFMAs
-          constexpr int KU = 6;
-          for (int kb0 = i; kb0 < kbmax; kb0 += KU) {
-            t4 a4[KU]; T bv[KU][4];
-#pragma unroll
-            for (int u = 0; u < KU; ++u) {
-              const int k0 = 16 * min(kb0 + u, NB - 1) + 4 * gq;
-              a4[u] = *reinterpret_cast<const t4*>(Trow + k0);
-#pragma unroll
-              for (int s4 = 0; s4 < 4; ++s4) bv[u][s4] = Bcol[(long)min(15 + k0 + s4, d.ld - 1) * d.n6cap];
-            }
-#pragma unroll
-            for (int u = 0; u < KU; ++u) {
-              if (kb0 + u >= kbmax) break;
-              const int k0 = 16 * (kb0 + u) + 4 * gq;
-#pragma unroll
-              for (int s4 = 0; s4 < 4; ++s4) {
-                const bool ok = k0 + s4 < n;
-                sacc = Mf<T>::mma(ok ? a4[u][s4] : T(0), ok ? bv[u][s4] : T(0), sacc);
-              }
-            }
-          }
-          const T sg2 = (T)d.prm[(long)b * PRM_STRIDE + PRM_SIG2];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[ii][jj][r] = sacc[r] + ((i == j && Mf<T>::row(lane, r) == (lane & 15)) ? sg2 : T(0));
-        }
-        continue;
-      }
+      if (MODE == CH_GAIN && d.gain_fused_s >= 2 && i < NB && s_owner(ii, jj) != part) continue;   // a sibling part forms this block
+      if (MODE == CH_GAIN && d.gain_fused_s && i < NB) { acc[ii][jj] = s_block(i, j); continue; }
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[ii][jj][r] = *el_ptr(16 * i + Mf<T>::row(lane, r), 16 * j + (lane & 15));
       // split-K SYRK (kernels_gram.hip): the tiles of block column j / 4 came in min(j / 4 + P - 2, P) partial sums (P =
@@ -201,6 +207,62 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0, int nb) {
           }
       }
     }
+  // The product S is MFMA-bound on the one CU a part runs on (11.6 MFLOP against 256 FLOP/cycle: ~46 k cycles when every part
+  // forms all of it).  Split: a part forms the blocks s_owner() gives it (the costly block rows -- many k-blocks -- spread over
+  // the parts), publishes them in Smat with agent-scope stores (write-through: the siblings may sit on another XCD), the parts
+  // of the trajectory meet at a counter barrier, and each reads the blocks it did not form.
+  if constexpr (MODE == CH_GAIN) {
+    if (d.gain_fused_s >= 2) {
+      T* Sg = reinterpret_cast<T*>(Sm);
+#pragma unroll
+      for (int ii = 0; ii < HR; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < HC; ++jj) {
+          if (4 * ii + 3 < 4 * jj && 4 * ii + 3 < NB) continue;
+          const int i = 4 * ii + pi, j = 4 * jj + pj;
+          if (i >= NB || j > i || 16 * j >= n || 16 * i >= main_rows || s_owner(ii, jj) != part) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * i + Mf<T>::row(lane, r), col = 16 * j + (lane & 15);
+            if (row < d.n6cap && col < d.n6cap) __hip_atomic_store(Sg + (long)row * d.n6cap + col, acc[ii][jj][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's stores have been acknowledged
+      __syncthreads();
+      // The wait is BOUNDED: nothing guarantees that the siblings are resident (another process or slice may hold the CUs they
+      // need while this part holds its own), so after ~1 ms without them this part forms the missing blocks itself -- the same
+      // instruction sequence its sibling would have run, the same bits; the split is a speed-up, never a dependency.
+      __shared__ int s_all_here;
+      if (tid == 0) {
+        unsigned* bar = d.gain_bar + (long)b * 32;
+        const unsigned old = atomicAdd(bar, 1u);
+        const unsigned target = (old / NPART + 1u) * NPART;
+        int here = 0;
+        const int max_spin = d.gain_fused_s == 3 ? 0 : 20000;   // 3: test hook -- never wait, so that the fall-back runs
+        for (int spin = 0; spin <= max_spin; ++spin) {
+          if ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { here = 1; break; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        s_all_here = here;
+      }
+      __syncthreads();
+      const bool all_here = s_all_here != 0;
+#pragma unroll
+      for (int ii = 0; ii < HR; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < HC; ++jj) {
+          if (4 * ii + 3 < 4 * jj && 4 * ii + 3 < NB) continue;
+          const int i = 4 * ii + pi, j = 4 * jj + pj;
+          if (i >= NB || j > i || 16 * j >= n || 16 * i >= main_rows || s_owner(ii, jj) == part) continue;
+          if (!all_here) { acc[ii][jj] = s_block(i, j); continue; }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = min(16 * i + Mf<T>::row(lane, r), d.n6cap - 1), col = min(16 * j + (lane & 15), d.n6cap - 1);
+            acc[ii][jj][r] = __hip_atomic_load(Sg + (long)row * d.n6cap + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+    }
+  }
 #pragma unroll
   for (int ii = 0; ii < HR; ++ii)
 #pragma unroll

@@ -285,7 +285,8 @@ struct Batch : BatchBase {
     rc |= dalloc(&d.K, Bz * dn); rc |= dalloc(&d.A, Bz * pl); rc |= dalloc(&d.AP, Bz * pl); rc |= dalloc(&d.X, Bz * pl); rc |= dalloc(&d.dx, Bz * d.ld);
     rc |= dalloc(&d.keep, Bz * n_cap); rc |= dalloc(&d.nkeep, Bz); rc |= dalloc(&d.ncam_upd, Bz); rc |= dalloc(&d.prune_bar, Bz * 32); rc |= dalloc(&d.nres_upd, Bz);
     rc |= dalloc(&d_pfin, TF * 4); d.trk_pfin = d_pfin; d.mode = 0; d.joseph = 0; d.ncam_bias = 0;
-    { const char* e = getenv("MSCKF_HIP_FUSED_S"); d.gain_fused_s = e ? atoi(e) : 1; }   // 0: the S GEMM as a launch of its own (A/B runs)
+    { const char* e = getenv("MSCKF_HIP_FUSED_S"); d.gain_fused_s = e ? atoi(e) : 2; }
+    rc |= dalloc(&d.gain_bar, Bz * 32);   // 0: the S GEMM as a launch of its own (A/B runs)
     rd_cap = 64;
     rc |= dalloc(&d_rd, Bz * rd_cap * RD_STRIDE);
     rc |= dalloc(&wl_n, Bz); rc |= dalloc(&wl_M, TF); rc |= dalloc(&wl_slots, TF * m_cap); rc |= dalloc(&wl_obs, TF * m_cap * 2);
