@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
     for (int t = 0; t < PIC_T; ++t) {
       const int col = (w + 4 * t) * 16 + c;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) { const int k = Mfs<S>::crow(g, kk); pic[t][kk] = (col < n && k < 15) ? P[(long)(15 + col) * ld + k] : S(0); }
+      for (int kk = 0; kk < 4; ++kk) { const int k = Mfs<S>::crow(g, kk); pic[t][kk] = P[(long)(15 + min(col, d.n6cap - 1)) * ld + min(k, 14)]; }   // unconditional (masked where used): no wait for the window size in front of the kernel's first loads
     }
   }
   if (tid < 16) sState[tid] = imu[tid];                 // q b_g v b_a p
@@ -216,6 +216,7 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
     const int i = e / 15, j = e % 15;
     sPii[e] = P[(long)j * ld + i];
   }
+  for (int e = tid; e < min(PG, K) * RD_STRIDE; e += 256) sRd[e] = rd[e];   // the first group's IMU samples ride on the same round trip
   __syncthreads();
   // chain matrices in MFMA accumulator layout (phase C): wave 0 P_II, wave 1 Phi_total
   typename Mfs<S>::V Mreg = {0, 0, 0, 0};
@@ -229,8 +230,7 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
   }
   for (int k0 = 0; k0 < K; k0 += PG) {
     const int G = min(PG, K - k0);
-    for (int e = tid; e < G * RD_STRIDE; e += 256) sRd[e] = rd[(long)k0 * RD_STRIDE + e];
-    __syncthreads();
+    if (k0 > 0) { for (int e = tid; e < G * RD_STRIDE; e += 256) sRd[e] = rd[(long)k0 * RD_STRIDE + e]; __syncthreads(); }
     PR_TICK(0);
     const V3<S> g = mk3(sG[0], sG[1], sG[2]);
     // ---- A: state chain.  The gyro bias does not change during propagation, so the RK step of sample s is a LINEAR map
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
       if ((w + 4 * t) * 16 >= n) break;
       typename Mfs<S>::V o = {0, 0, 0, 0};
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) o = Mfs<S>::mma(aT[kk], pic[t][kk], o);
+      for (int kk = 0; kk < 4; ++kk) o = Mfs<S>::mma(aT[kk], (col < n && Mfs<S>::crow(g, kk) < 15) ? pic[t][kk] : S(0), o);
       if (col < n) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
