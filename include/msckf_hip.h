@@ -158,6 +158,10 @@ int msckf_hip_sync(msckf_hip_handle h);
  * augmentState separately; otherwise they share one launch.) */
 int msckf_hip_profile_enable(msckf_hip_handle h, int on);
 int msckf_hip_profile_read(msckf_hip_handle h, double* ms8, int* count8);
+/* Milliseconds an event pair with nothing between its two records reads on the handle's stream (mean of 64 pairs): every
+ * stage timer above brackets its launches with such a pair, so a single-kernel stage reads the kernel's duration plus
+ * this.  (The reference's StageTiming message, asl_msckf.cpp:229-296, is host wall-clock and has no such term.) */
+int msckf_hip_profile_event_overhead(msckf_hip_handle h, double* ms);
 /* run_frames on n = 1..8 HIP streams: the batch is cut into n slices of independent trajectories that run the
  * same kernel sequence concurrently (latency-bound stages of one slice overlap chip-filling stages of another). */
 int msckf_hip_set_streams(msckf_hip_handle h, int n);

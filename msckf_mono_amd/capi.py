@@ -30,7 +30,7 @@ SYMBOLS = [
     "msckf_hip_last_tracks", "msckf_hip_last_deltax", "msckf_hip_set_tracks", "msckf_hip_propagate_range",
     "msckf_hip_augment_range", "msckf_hip_marginalize_range", "msckf_hip_drop_oldest_range", "msckf_hip_scenario_alloc",
     "msckf_hip_scenario_set", "msckf_hip_scenario_commit", "msckf_hip_run_frames", "msckf_hip_run_frames_streamed", "msckf_hip_sync",
-    "msckf_hip_profile_enable", "msckf_hip_profile_read", "msckf_hip_set_streams", "msckf_hip_set_gate_early_accept",
+    "msckf_hip_profile_enable", "msckf_hip_profile_read", "msckf_hip_profile_event_overhead", "msckf_hip_set_streams", "msckf_hip_set_gate_early_accept",
     "msckf_hip_scenario_pin", "msckf_hip_set_upload_ring", "msckf_hip_clear_error_flags",
     "msckf_hip_set_compression", "msckf_hip_set_covariance_update", "msckf_hip_set_feature_overlap", "msckf_hip_get_pruned_states", "msckf_hip_get_cam_meta", "msckf_hip_get_tracked_feature_ids",
 ]
@@ -276,6 +276,11 @@ class Batch:
 
     def profile_enable(self, on=True):
         _chk(self.L.msckf_hip_profile_enable(self.h, 1 if on else 0))
+
+    def profile_event_overhead(self):
+        ms = C.c_double(0.0)
+        _chk(self.L.msckf_hip_profile_event_overhead(self.h, C.byref(ms)))
+        return float(ms.value)
 
     def profile_read(self):
         ms = np.zeros(8); cnt = np.zeros(8, dtype=np.int32)

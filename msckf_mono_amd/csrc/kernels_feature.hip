@@ -968,6 +968,10 @@ __global__ __launch_bounds__(64) void k_select(Dev<S> d, int b0, int nb) { selec
 // Measured and rejected (round 3): the two load levels batched over four rounds of 64 tracks (clamped addresses, masked
 // afterwards, no `continue`): 16.5 -> 22.0 us -- 190 registers, and the Jacobian blocks of the ~45 % of (track, slot) pairs
 // that do not exist are fetched too.
+// Also rejected: one workgroup per slot with its four wavefronts splitting the rounds (16.5 -> 23.0 us: the 27 f64 butterfly
+// reductions, ~1 600 instructions per wavefront, are then done four times over), and the 27 sums through an LDS transpose
+// instead of butterflies (~160 instructions, but 58 KB of LDS per workgroup: 18.6 us, and the changed summation order moves
+// the float TSQR-vs-information-form comparison at the 60-camera geometry past its tolerance).
 template <class S>
 __global__ __launch_bounds__(256) void k_select_diag(Dev<S> d, int b0, int nb, int ndiag) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, i = blockIdx.y;

@@ -117,6 +117,7 @@ struct BatchBase {
   virtual int sync() = 0;
   virtual int prof_enable(int on) = 0;
   virtual int prof_read(double* ms, int* cnt) = 0;
+  virtual int prof_event_overhead(double* ms) = 0;
   virtual int set_streams(int n) = 0;
   virtual int set_gate_early(int on) = 0;
   virtual int set_compression(int route) = 0;
@@ -923,6 +924,24 @@ struct Batch : BatchBase {
     nstreams = n;
     return 0;
   }
+  // what an event pair with NOTHING between its records measures on this stream (the marker packets themselves): the stage
+  // timers of prof_read hold one such pair per launch, so a single-kernel stage reads kernel time + this
+  int prof_event_overhead(double* ms) override {
+    HIPCHK(hipSetDevice(device));
+    hipEvent_t a, b2;
+    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b2));
+    HIPCHK(hipStreamSynchronize(st));
+    double tot = 0; const int reps = 64;
+    for (int i = 0; i < reps; ++i) {
+      HIPCHK(hipEventRecord(a, st)); HIPCHK(hipEventRecord(b2, st));
+      HIPCHK(hipEventSynchronize(b2));
+      float t = 0; HIPCHK(hipEventElapsedTime(&t, a, b2));
+      tot += t;
+    }
+    hipEventDestroy(a); hipEventDestroy(b2);
+    *ms = tot / reps;
+    return 0;
+  }
   int prof_read(double* ms, int* cnt) override {
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamSynchronize(st));
@@ -1615,6 +1634,7 @@ int msckf_hip_run_frames_streamed(msckf_hip_handle h, int f0, int f1) { return H
 int msckf_hip_sync(msckf_hip_handle h) { return H(h)->sync(); }
 int msckf_hip_profile_enable(msckf_hip_handle h, int on) { return H(h)->prof_enable(on); }
 int msckf_hip_profile_read(msckf_hip_handle h, double* ms7, int* count7) { return H(h)->prof_read(ms7, count7); }
+int msckf_hip_profile_event_overhead(msckf_hip_handle h, double* ms) { if (!h || !ms) return fail(-EINVAL, "null argument"); return H(h)->prof_event_overhead(ms); }
 int msckf_hip_set_streams(msckf_hip_handle h, int n) { return H(h)->set_streams(n); }
 int msckf_hip_scenario_pin(msckf_hip_handle h, int f0, int f1) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->scen_pin(f0, f1); }
 int msckf_hip_set_upload_ring(msckf_hip_handle h, int depth, int mode) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_upload_ring(depth, mode); }
