@@ -146,6 +146,27 @@ def test_gain_solve_forms_s_the_same_alone_shared_or_after_a_missed_rendezvous(c
                 assert np.array_equal(x, y), (mode, b)
 
 
+def test_stage_timers_and_the_reading_of_an_empty_event_pair(capi, cfg3_trajs):
+    """msckf_hip_profile_*: HIP-event pairs around every stage's launches on the library's stream (bench.py's roofline takes its
+    kernel time from them), and msckf_hip_profile_event_overhead: what such a pair reads with nothing between its records,
+    which bench.py takes off.  Two profiled frames give two pairs per stage; every single-kernel stage reads more than the
+    empty pair and less than a millisecond at this size."""
+    c = CFG3
+    bt = _resident_batch(capi, cfg3_trajs[:8], c["N"], c["F"], 33, 32, capi.F32)
+    bt.run_frames(0, 31); bt.sync()
+    bt.profile_enable(True)
+    bt.run_frames(31, 33); bt.sync()
+    prof = bt.profile_read()
+    bt.profile_enable(False)
+    oh = bt.profile_event_overhead()
+    bt.close()
+    assert 0.0 < oh < 0.1, oh
+    for stage in ("propagate", "augment", "feature", "compress_stage1", "compress_merge", "kalman", "prune", "select"):
+        ms, cnt = prof[stage]
+        assert cnt == 2, (stage, prof)
+        assert oh < ms / cnt < 1.0, (stage, ms / cnt, oh)
+
+
 def test_cfg3_batch_of_64_vs_oracle(capi, po, cfg3_trajs):
     """The benched configuration against the oracle: after the window is full, 8 sampled trajectories of the 64 hand their
     state + covariance to a float oracle (teacher forcing, device -> oracle), both run the next filter update on the same
