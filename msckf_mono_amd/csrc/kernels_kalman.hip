@@ -394,7 +394,8 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0, int nb,
     // P <- P - W W^T on the upper triangle (diagonal tiles), both halves written from the same value.  All sixteen old values
     // are requested before the first store: interleaved (load, subtract, two stores per element) the compiler must assume
     // that a store changes the next element's load and waits for the stores' acknowledgement every time -- sixteen serial
-    // round trips (31.7 -> 29.4 us)
+    // round trips (31.7 -> 29.4 us).  (Requesting them in front of the k loop instead, so that they arrive under it: no change,
+    // 26.4 vs 26.5 us.)
     S* Pw = const_cast<S*>(v.P);
     S old[16];
 #pragma unroll
