@@ -235,8 +235,12 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0, int nb) {
       __shared__ int s_all_here;
       if (tid == 0) {
         unsigned* bar = d.gain_bar + (long)b * 32;
-        const unsigned old = atomicAdd(bar, 1u);
-        const unsigned target = (old / NPART + 1u) * NPART;
+        // the counter advances by a power of two per launch (three parts: part 0 counts twice), so that launches stay aligned
+        // with the multiples of GP across the 2^32 wrap
+        constexpr unsigned GP = NPART == 3 ? 4u : (unsigned)NPART;
+        static_assert((GP & (GP - 1)) == 0, "rendezvous group size must divide 2^32");
+        const unsigned old = atomicAdd(bar, (NPART == 3 && part == 0) ? 2u : 1u);
+        const unsigned target = (old / GP + 1u) * GP;
         int here = 0;
         const int max_spin = d.gain_fused_s == 3 ? 0 : 20000;   // 3: test hook -- never wait, so that the fall-back runs
         for (int spin = 0; spin <= max_spin; ++spin) {

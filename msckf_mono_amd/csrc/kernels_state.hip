@@ -505,7 +505,10 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
 // where the earlier gather-into-a-copy + copy-back pair moved it twice through two launches.  The barrier needs the PRUNE_G
 // workgroups of a trajectory co-resident: they are consecutive in dispatch order and small (256 threads, < 2 KB of LDS), so
 // they are unless the chip is full, in which case the ones that are wait for earlier work to retire, not for each other's
-// slots.  The counter only grows (target = next multiple of PRUNE_G above the value a workgroup drew; wrap-safe compare), so
+// slots.  (Progress: a launch's workgroups are dispatched in index order, so at any time at most ONE trajectory of a launch is
+// partly resident -- fewer than 16 spinning workgroups per concurrent launch against thousands of workgroup slots; every other
+// resident workgroup belongs to a complete group, finishes and frees its slot.  Unlike the gain solve's rendezvous this wait
+// has no fall-back: the data move in place.)  The counter only grows (target = next multiple of PRUNE_G above the value a workgroup drew; wrap-safe compare), so
 // it needs no reset between launches; a trajectory that drops nothing skips the barrier with all its workgroups.
 // The keep list is either the host's (d.keep / d.nkeep: pruneEmptyStates, pruneRedundantStates) or "drop the n_drop oldest"
 // (drop array of the resident scenario, or a constant), which every workgroup derives itself; workgroup 0 of a trajectory

@@ -149,3 +149,88 @@ def test_syrk_workgroup_enumeration_covers_the_upper_block_triangle_once():
                     rem -= ng
                 tiles += [(ti, tj) for tj in range(tj0, min(tj0 + GT_MAX, np_cap))]
             assert sorted(tiles) == [(i, j) for i in range(np_cap) for j in range(i, np_cap)], (GT_MAX, np_cap)
+
+
+def test_xcd_item_mapping_keeps_a_trajectory_on_one_xcd_and_covers_every_item_once():
+    """dev_common.h xcd_item / xcd_grid (k_feature, k_gram, the GEMM tiles, the gain Cholesky's parts, k_trsm_rows): MI355X
+    places workgroup w on XCD w % 8; workgroup w = x + 8 j serves trajectory x + 8 (j // items), item j % items.  Every
+    (trajectory, item) pair exactly once, all items of trajectory i on XCD i % 8, padding workgroups only where an XCD has
+    fewer trajectories than the fullest one."""
+    for nb in (1, 3, 8, 16, 21, 64, 65):
+        for items in (1, 4, 10, 16, 200):
+            grid = 8 * ((nb + 7) // 8) * items
+            seen = {}
+            for w in range(grid):
+                x, j = w & 7, w >> 3
+                q = j // items
+                i, item = x + 8 * q, j - q * items
+                if i >= nb:
+                    continue                                  # padding workgroup: returns at once
+                assert (i, item) not in seen
+                seen[(i, item)] = w % 8
+            assert len(seen) == nb * items
+            assert all(xcd == i % 8 for (i, _), xcd in seen.items())
+
+
+def test_shared_s_product_ownership_partitions_the_blocks():
+    """kernels_chol.hip s_owner: which of a trajectory's NPART gain-solve workgroups forms the S blocks of register set
+    (ii, jj) (block rows 4 ii .. 4 ii + 3, block columns 4 jj .. 4 jj + 3, jj <= ii).  Every set has exactly one owner below
+    NPART, and with the cost of a block row (its number of k-blocks, NB - i: T_H is upper triangular) the most loaded part
+    carries about a third of the product, not all of it."""
+    def owner(ii, jj, NPART):
+        return (0 if ii == 0 else (1 + jj if ii == 1 else (3 if jj == 2 else 1 + jj))) % NPART
+    for NB, NPART in ((4, 3), (8, 3), (12, 4)):
+        sets = [(ii, jj) for ii in range(NB // 4) for jj in range(ii + 1)]
+        load = [0.0] * NPART
+        for ii, jj in sets:
+            o = owner(ii, jj, NPART)
+            assert 0 <= o < NPART
+            blocks = [(i, j) for i in range(4 * ii, 4 * ii + 4) for j in range(4 * jj, 4 * jj + 4) if j <= i]
+            load[o] += sum(NB - i for i, j in blocks)
+        total = sum(load)
+        assert abs(total - sum(NB - i for i in range(NB) for j in range(i + 1))) < 1e-9
+        if NB == 12:
+            assert max(load) / total < 0.40, load       # 364 k-block products: 136 | 98 | 98 | 32
+
+
+def test_counter_barrier_target_is_wrap_safe():
+    """k_prune_inplace (16 workgroups per trajectory) / the gain solve's rendezvous (4 parts, or 3 with part 0 counting twice): a
+    workgroup draws `old` from a counter that only grows and waits until the counter has reached the next multiple of the
+    group size GP above it, compared as (int)(counter - target) >= 0.  GP is a power of two, so launch after launch the
+    workgroups of a trajectory release together -- also across the 2^32 wrap."""
+    M32 = 1 << 32
+    for adds in ([1] * 16, [1] * 4, [2, 1, 1]):           # what each arriving workgroup adds; GP = sum
+        GP = sum(adds)
+        assert GP & (GP - 1) == 0
+        counter = (M32 - 3 * GP) % M32                    # wraps in the fourth launch
+        for launch in range(8):
+            targets = []
+            for k, inc in enumerate(adds):
+                old = counter
+                counter = (counter + inc) % M32
+                targets.append(((old // GP + 1) * GP) % M32)
+                done = (counter - targets[-1]) % M32
+                done = done - M32 if done >= (1 << 31) else done   # the (int) cast
+                assert (done >= 0) == (k == len(adds) - 1), (adds, launch, k)
+            assert len(set(targets)) == 1
+
+
+def test_prune_on_the_downdate_index_map():
+    """k_gemm_mfma<OP_DOWN> with Dev::Pout: dropping the nd oldest camera states sends row / column g of the covariance to
+    g (IMU block), nowhere (15 <= g < 15 + 6 nd) or g - 6 nd -- the same as P[keep][:, keep] with keep = the IMU block and
+    the camera states nd .. N - 1 (matrix_utils.h:58-87 square_slice)."""
+    rng = np.random.default_rng(5)
+    for N, nd in ((5, 0), (5, 1), (8, 3), (4, 4)):
+        D = 15 + 6 * N
+        P = rng.standard_normal((D, D)); P = P + P.T
+        cut = 15 + 6 * nd
+        out = np.full((D, D), np.nan)
+        for gi in range(D):
+            for gj in range(gi, D):                         # upper triangle, mirrored (as the tiles do)
+                if (gi < 15 or gi >= cut) and (gj < 15 or gj >= cut):
+                    di, dj = (gi if gi < 15 else gi - 6 * nd), (gj if gj < 15 else gj - 6 * nd)
+                    out[dj, di] = out[di, dj] = P[gi, gj]
+        keep = list(range(15)) + list(range(cut, D))
+        ref = P[np.ix_(keep, keep)]
+        Dn = len(keep)
+        assert np.array_equal(out[:Dn, :Dn], ref)
