@@ -107,7 +107,8 @@ int msckf_hip_set_num_residualized(msckf_hip_handle h, int b, long long n);
  * filled regardless): -EOVERFLOW camera-state capacity exceeded in augmentState; -EDOM a factorization of
  * S = T_H P T_H^T + R_n (msckf.h:1369) met a non-positive pivot since the flags were last cleared -- the covariance lost
  * positive definiteness (the pivot is clamped and the run continues; the reference's explicit S.inverse() would return
- * garbage silently). */
+ * garbage silently); -ETIMEDOUT the workgroups of an in-place prune never met at their rendezvous (bounded wait, ~0.3 s: the
+ * trajectory's covariance is invalid from then on, the device is not hung). */
 int msckf_hip_last_stats(msckf_hip_handle h, int b, int* out7);
 int msckf_hip_clear_error_flags(msckf_hip_handle h, int b);
 /* per track of the last marginalize: out[t*8 + ..] = motion_ok tri_valid gate_pass included gamma p_f_G(3) */

@@ -42,7 +42,7 @@ enum { STAT_NTRACKS = 0, STAT_MOTION_REJ, STAT_TRI_REJ, STAT_GATE_REJ, STAT_PASS
 // STAT_ERR is sticky (never cleared by an update) and a bit field: capacity overflow in augmentState; a non-positive pivot
 // in the factorization of S = T_H P T_H^T + R_n (the covariance lost positive definiteness: the square-root gain form
 // P <- P - W W^T has no PSD guarantee under rounding; the pivot is clamped so that the run continues, but it is reported)
-enum { STAT_ERR_NCAP = 1, STAT_ERR_PIVOT = 2 };
+enum { STAT_ERR_NCAP = 1, STAT_ERR_PIVOT = 2, STAT_ERR_SYNC = 4 };   // SYNC: k_prune_inplace's rendezvous gave up (see there)
 
 template <class S>
 struct Dev {

@@ -546,7 +546,15 @@ __global__ __launch_bounds__(256) void k_prune_inplace(Dev<S> d, int b0, const i
     unsigned* bar = d.prune_bar + (long)b * 32;   // a 128-byte line per trajectory: same-line atomics serialise (~25 ns each)
     const unsigned old = atomicAdd(bar, 1u);
     const unsigned target = (old / PRUNE_G + 1u) * PRUNE_G;
-    while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(2);
+    // bounded (~0.3 s; a rendezvous takes microseconds): a workgroup that never sees its siblings raises the sticky
+    // STAT_ERR_SYNC flag (msckf_hip_last_stats: -ETIMEDOUT) and goes on -- the trajectory's covariance is then invalid, but the
+    // device is not hung
+    bool met = false;
+    for (int spin = 0; spin < (1 << 18); ++spin) {
+      if ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { met = true; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (!met) atomicOr(&d.stats[(long)b * STAT_STRIDE + STAT_ERR], STAT_ERR_SYNC);
   }
   __syncthreads();
 #pragma unroll

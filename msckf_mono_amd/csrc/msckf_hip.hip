@@ -644,6 +644,7 @@ struct Batch : BatchBase {
     HIPCHK(hipStreamSynchronize(st));
     for (int i = 0; i < 7; ++i) out[i] = tmp[i];
     if (tmp[STAT_ERR] & STAT_ERR_NCAP) return fail(-EOVERFLOW, "camera-state capacity n_cap exceeded in augmentState");
+    if (tmp[STAT_ERR] & STAT_ERR_SYNC) return fail(-ETIMEDOUT, "the workgroups of an in-place prune never met (k_prune_inplace): this trajectory's covariance is invalid");
     if (tmp[STAT_ERR] & STAT_ERR_PIVOT)
       return fail(-EDOM, "non-positive pivot in the factorization of S = T_H P T_H^T + R_n: the covariance lost positive definiteness "
                          "(msckf_hip_set_covariance_update(h, 1) selects the reference's Joseph form)");

@@ -1,5 +1,4 @@
 cd /root/repo
-O=gpurun_out/r03_y; mkdir -p $O
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $O/pytest.txt
-tail -3 $O/pytest.txt
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+O=gpurun_out/r03_z2; mkdir -p $O
+timeout 200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py::test_prune_on_the_downdate_equals_the_separate_prune -m gpu -x -q 2>&1 | tail -4 > $O/pytest.txt
+cat $O/pytest.txt
