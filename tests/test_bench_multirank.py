@@ -24,8 +24,13 @@ def test_two_ranks_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 4
     assert abs(d["value"] - 2 * 64 * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 1e-6
-    assert d["roofline"]["bound"] in ("valu", "mfma", "hbm") and 0 < d["roofline"]["frac"] < 1
-    assert 0 < d["roofline"]["executed_frac"] < d["roofline"]["frac"]
+    # which kernel is the longest with two ranks sharing one GPU varies (k_feature, or the one-workgroup-per-trajectory Cholesky
+    # when the other rank's per-track kernel holds the CUs): frac is the algorithm-equivalent rate, null when it exceeds 1 (the
+    # raw ratio stays in alg_equivalent_ratio), and never below the utilisation on executed work
+    rf = d["roofline"]
+    assert rf["bound"] in ("valu", "mfma", "hbm") and rf["alg_equivalent_ratio"] > 0
+    assert rf["frac"] is None or 0 < rf["frac"] <= 1
+    assert 0 < rf["executed_frac"] <= rf["alg_equivalent_ratio"] * (1 + 1e-9)
     assert d["ate_m"] < 0.05 and len(d["ate_per_sequence_m"]) == 1
     assert d["repeats"]["windows"] >= 3 and d["repeats"]["values"][0] == d["value"]
     # the headline is SURVEY.md 8d's metric: inputs uploaded inside the timed region; the resident-input rate sits beside it
