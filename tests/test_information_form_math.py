@@ -234,3 +234,34 @@ def test_prune_on_the_downdate_index_map():
         ref = P[np.ix_(keep, keep)]
         Dn = len(keep)
         assert np.array_equal(out[:Dn, :Dn], ref)
+
+
+def test_epilogues_of_the_update_kernels_hold_no_serialized_store_load_chains(tmp_path):
+    """Stores count in vmcnt on gfx950, so `P[i] = P[i] - acc[i]` element by element compiles to load -> wait (also for the
+    previous stores' acknowledgement) -> store, once per element: the covariance downdate and k_gram's epilogue were written
+    that way (sixteen serial round trips each) until round 3.  hipcc cross-compiles here: the ISA of those kernels is
+    checked for store -> load -> s_waitcnt vmcnt(0) sequences (scripts/experiments/store_load_chains.py)."""
+    import os, shutil, subprocess, sys
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts", "experiments"))
+    from store_load_chains import count_chains
+
+    def isa(name):
+        out = str(tmp_path / (name + ".s"))
+        subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast", "-fno-slp-vectorize", "-S", "--cuda-device-only",
+                        "-I" + os.path.join(root, "include"), "-o", out, os.path.join(root, "msckf_mono_amd", "csrc", name + ".hip")],
+                       check=True, capture_output=True, timeout=600)
+        return count_chains(out)
+    with ThreadPoolExecutor(2) as ex:
+        kal, gram = ex.map(isa, ["kernels_kalman", "kernels_gram"])
+    checked = 0
+    for name, n in list(kal.items()) + list(gram.items()):
+        if ("k_gemm_mfma" in name and ("ILi8E" in name or "ILi9E" in name or "ILi0E" in name)) or name.startswith("_ZN5msckf6k_gramI"):
+            assert n <= 1, (name, n)
+            checked += 1
+    assert checked >= 6, (checked, sorted(kal)[:5])
