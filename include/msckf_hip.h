@@ -25,15 +25,20 @@
  *   reading7 omega(3) a(3) dT                                                           types.h:78-84
  *   cam7     q_CG(4) p_C_G(3)                                                           types.h:57-67
  *
- * Pixel noise: with u_var_prime == v_var_prime (the configuration the throughput metric is quoted on) the update
- * is independent of the null-space basis and of the compression order and matches the reference to rounding.
- * With u_var_prime != v_var_prime (EuRoC intrinsics, asl_msckf.cpp:77-78) the reference's own result is not
- * reproducible beyond ~1e-4 in the biases / ~1e-7 in attitude per update: msckf.h:1347 keeps the rounding-level rows of
- * R that belong to the window's gauge directions, and their (rounding-noise) Q columns enter R_n = Q_1^T R_o Q_1 with
- * O(1) weights (measured with the reference's own source under two roundings, tests/test_ref_vs_oracle.py).  This
- * library pre-whitens every observation row by 1/sigma_u resp. 1/sigma_v and runs the filter with unit noise -- the
- * basis-independent generalized-least-squares update -- which stays within a small multiple of that envelope
- * (same test; < 2e-6 on attitude, position, velocity and covariance, < 2e-3 relative on the gyro bias).
+ * Pixel noise: with u_var_prime == v_var_prime (the configuration the throughput metric is quoted on) the update is
+ * independent of the null-space basis and of the compression order and matches the reference to rounding.  With
+ * u_var_prime != v_var_prime (EuRoC intrinsics, asl_msckf.cpp:77-78) the library builds the reference's own construction on
+ * the device (msckf_hip_set_anisotropic_noise, mode 0, default): R_o_j = A_j^T R_j A_j with A_j the trailing columns of the
+ * column-pivoted Householder Q of H_f_j (= JacobiSVD's trailing U columns, msckf.h:954-955), HouseholderQR of the stack in
+ * the reference's column and row order with the zero-tail rule (rows 0..14 of H_o pass verbatim), R_n = Q_1^T R_o Q_1
+ * (msckf.h:423-431, 1343-1366).  The reference's own result there is not reproducible beyond ~1e-4 in the biases per
+ * update: a column that depends on the previous ones (the window's gauge directions) has a rounding-level tail, the
+ * reflector built from it is rounding noise, and its row enters R_n with O(1) weight (measured with the reference's own
+ * source under two roundings, tests/test_ref_vs_oracle.py).  tail_tol > 0 treats such a tail (below tail_tol * |column|) as
+ * the zero it is in exact arithmetic -- the reference's algorithm in its exact-arithmetic limit, reproducible to rounding
+ * and as close to either rounding of the reference as they are to each other; tail_tol = 0 is msckf.h's rule to the
+ * letter.  Mode 1 pre-whitens every observation row by 1/sigma_u resp. 1/sigma_v and runs the filter with unit noise (the
+ * full generalized-least-squares update: statistically the better estimator, but not the reference's).
  */
 #ifndef MSCKF_HIP_H
 #define MSCKF_HIP_H
@@ -188,6 +193,17 @@ int msckf_hip_set_covariance_update(msckf_hip_handle h, int form);
  * frame left behind).  Bit-identical results; OFF by default -- on MI355X at the benchmark configuration the per-track
  * kernel starves the latency-bound propagate/augment workgroups of CUs (100 k -> 82 k updates/s). */
 int msckf_hip_set_feature_overlap(msckf_hip_handle h, int on);
+/* Anisotropic pixel noise, u_var_prime != v_var_prime (see the header comment): mode 0 (default) the reference's
+ * R_o_j = A_j^T R_j A_j / HouseholderQR in column order / R_n = Q_1^T R_o Q_1 on the device (msckf.h:423-431, 1343-1366;
+ * f64, one workgroup per trajectory over the dense stack: the parity route, not a throughput route), its result handed to
+ * the update as the information matrix [T_H | r_n]^T R_n^-1 [T_H | r_n]; mode 1 rows pre-whitened by 1/sigma (generalized
+ * least squares).  tail_tol: zero-tail tolerance of mode 0, < 0 = default (1e-10 double, 2e-4 float), 0 = the reference's
+ * rule to the letter.  Applies to every trajectory of the handle, initialized or not.  -ENOMEM when the stack does not fit
+ * (f_cap (2 m_cap - 3) x (6 n_cap + 1) doubles per trajectory). */
+int msckf_hip_set_anisotropic_noise(msckf_hip_handle h, int mode, double tail_tol);
+/* last marginalize of trajectory b on the literal route: out[0..3] = stacked rows m, kept rows r of R (msckf.h:1347),
+ * Householder steps that reflected, steps whose tail fell under tail_tol. */
+int msckf_hip_literal_info(msckf_hip_handle h, int b, int* out4);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,7 @@ SYMBOLS = [
     "msckf_hip_profile_enable", "msckf_hip_profile_read", "msckf_hip_profile_event_overhead", "msckf_hip_set_streams", "msckf_hip_set_gate_early_accept",
     "msckf_hip_scenario_pin", "msckf_hip_set_upload_ring", "msckf_hip_clear_error_flags",
     "msckf_hip_set_compression", "msckf_hip_set_covariance_update", "msckf_hip_set_feature_overlap", "msckf_hip_get_pruned_states", "msckf_hip_get_cam_meta", "msckf_hip_get_tracked_feature_ids",
+    "msckf_hip_set_anisotropic_noise", "msckf_hip_literal_info",
 ]
 
 
@@ -273,6 +274,17 @@ class Batch:
 
     def set_gate_early_accept(self, on):
         _chk(self.L.msckf_hip_set_gate_early_accept(self.h, 1 if on else 0))
+
+    def set_anisotropic_noise(self, mode, tail_tol=-1.0):
+        """u_var' != v_var': 0 (default) the reference's R_o_j = A_j^T R_j A_j / HouseholderQR / R_n = Q_1^T R_o Q_1 on the
+        device (msckf.h:423-431, 1343-1366), 1 rows pre-whitened by 1/sigma.  tail_tol < 0: default, 0: the reference's
+        zero-tail rule to the letter"""
+        _chk(self.L.msckf_hip_set_anisotropic_noise(self.h, int(mode), C.c_double(float(tail_tol))))
+
+    def literal_info(self, b):
+        o = np.zeros(4, dtype=np.int32)
+        _chk(self.L.msckf_hip_literal_info(self.h, int(b), o.ctypes.data_as(_ip)))
+        return dict(zip(["m_rows", "kept_rows", "reflected", "skipped_by_tolerance"], o.tolist()))
 
     def profile_enable(self, on=True):
         _chk(self.L.msckf_hip_profile_enable(self.h, 1 if on else 0))

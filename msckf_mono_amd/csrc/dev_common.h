@@ -33,7 +33,10 @@ enum {  // offsets into prm[]
   PRM_MINTL = 31, PRM_MAXTL = 32, PRM_MAXCS = 33,
   // derived at initialize: row weights and the noise variance the kernels run with.  Isotropic noise: (1, 1, u_var');
   // anisotropic noise: rows are pre-whitened by (1/sigma_u, 1/sigma_v) and the filter runs with unit variance.
-  PRM_WU = 34, PRM_WV = 35, PRM_SIG2 = 36
+  // PRM_SIG2: noise variance of the UPDATE (S = T_H P T_H^T + sigma^2 I); PRM_SIG2G: of the chi-square gate (msckf.h:1117 uses
+  // u_var' whatever v_var' is).  They differ only on the literal anisotropic route (PRM_LIT = 1: rows unweighted, the gate
+  // with u_var' as in the reference, the update with unit noise on the information matrix of kernels_literal.hip).
+  PRM_WU = 34, PRM_WV = 35, PRM_SIG2 = 36, PRM_SIG2G = 37, PRM_LIT = 38
 };
 enum {  // per-track status bits written by k_feature / k_select
   ST_MOTION_OK = 1, ST_TRI_VALID = 2, ST_GATE_PASS = 4, ST_INCLUDED = 8, ST_MOTION_SKIPPED = 16, ST_GATE_BOUND = 32
@@ -43,6 +46,15 @@ enum { STAT_NTRACKS = 0, STAT_MOTION_REJ, STAT_TRI_REJ, STAT_GATE_REJ, STAT_PASS
 // in the factorization of S = T_H P T_H^T + R_n (the covariance lost positive definiteness: the square-root gain form
 // P <- P - W W^T has no PSD guarantee under rounding; the pivot is clamped so that the run continues, but it is reported)
 enum { STAT_ERR_NCAP = 1, STAT_ERR_PIVOT = 2, STAT_ERR_SYNC = 4 };   // SYNC: k_prune_inplace's rendezvous gave up (see there)
+
+// work space of the literal anisotropic compression (kernels_literal.hip / literal_core.h), per trajectory; null when no
+// trajectory of the batch uses it
+struct LitBufs {
+  double* X = nullptr; double* tau = nullptr; double* Vf = nullptr; double* Tf = nullptr; double* TH = nullptr; double* G = nullptr; double* Z = nullptr;
+  int* row0 = nullptr; int* obs0 = nullptr; int* kept = nullptr; int* info = nullptr;
+  int ldx = 0, r_cap = 0, ldg = 0, ldz = 0, kept_stride = 0;
+  double tol = 0;
+};
 
 template <class S>
 struct Dev {
@@ -112,6 +124,7 @@ struct Dev {
   S* PHt; S* Smat; S* Linv; S* W; S* K; S* A; S* AP; S* X; S* dx;
   // prune
   int* keep; int* nkeep;
+  LitBufs lit;
 };
 
 // first observation of track t of the launch's i-th trajectory in trk_slots / trk_obs
@@ -386,6 +399,7 @@ template <class S> void launch_compress(const Dev<S>& d, int b0, int nb, hipStre
 // phase: 0 = both, 1 = Gram accumulation only, 2 = Cholesky only, 3 = SYRK only (the block-diagonal part came with launch_select_diag)
 template <class S> void launch_gram(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase);
 template <class S> void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st);
+template <class S> void launch_literal(const Dev<S>& d, int b0, int nb, hipStream_t st);   // kernels_literal.hip: Lam^ of the literal anisotropic compression
 // blocked matrix-core Cholesky (kernels_chol.hip): [T | r_n] = chol(Lam^) for the information form; S = L L^T with
 // [PHt ; r_n^T] appended (W, dx) for the float Kalman stage.  Return false when the window does not fit the kernel.
 template <class S> bool launch_chol_gram(const Dev<S>& d, int b0, int nb, hipStream_t st);

@@ -474,7 +474,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
       }
     }
     if (!act) { r[0] = 0; r[1] = 0; }
-    // row weights: (1,1) for isotropic noise, (1/sigma_u, 1/sigma_v) pre-whitening for anisotropic noise
+    // row weights: (1,1) for isotropic noise and on the literal anisotropic route (kernels_literal.hip), (1/sigma_u, 1/sigma_v)
+    // when anisotropic noise is handled by pre-whitening
     const S wu = prm[PRM_WU], wv = prm[PRM_WV];
     r[0] *= wu; r[1] *= wv;
     for (int k = 0; k < 6; ++k) { hx[0][k] *= wu; hx[1][k] *= wv; }
@@ -624,7 +625,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
   S gamma = 0;
   bool early = false;
   if (d.gate_early) {
-    const S ub = rr_ro / prm[PRM_SIG2];
+    const S ub = rr_ro / prm[PRM_SIG2G];
     if (ub < S(0.5) * thresh) { early = true; gamma = ub; status |= ST_GATE_BOUND; }
   }
   if (!early) {
@@ -709,7 +710,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
   }
   __syncthreads();
   // ---- gamma = r_o^T S^-1 r_o through N = G + sigma^2 I = L L^T (gate_chol): y = L^-1 r, Y = L^-1 H_f, gamma = y^T y - b^T C^-1 b
-  const S sig2 = prm[PRM_SIG2];
+  const S sig2 = prm[PRM_SIG2G];
   const int nr = R2 + 4;
   if (fdbg & 4) { gamma = 0; }
   else if (LONG && nr > 64 && nr <= (sizeof(S) == 4 ? 128 : 96)) {   // double: 12 blocks fit the register file, longer tracks take the LDS path

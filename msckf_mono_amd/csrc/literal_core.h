@@ -1,0 +1,409 @@
+// literal_core.h -- the reference's measurement compression under ANISOTROPIC pixel noise (u_var' != v_var', the shipped
+// EuRoC configuration asl_msckf.cpp:77-78), built the reference's way for one trajectory:
+//
+//   msckf.h:423        R_j     = diag(u', v', u', v', ...)
+//   msckf.h:954-957    A_j     = trailing 2M-3 columns of JacobiSVD's full U of H_f_j   (= of the Q of a column-pivoted
+//                                Householder QR: Eigen's QR preconditioner for a tall matrix), H_o_j = A_j^T H_x_j
+//   msckf.h:430-431    r_o_j   = A_j^T r_j,   R_o_j = A_j^T R_j A_j
+//   msckf.h:436-441    H_o, r_o, R_o stacked in the order of feature_tracks_to_residualize_
+//   msckf.h:1343-1348  HouseholderQR(H_o) in column order; a step whose tail is zero is the identity (Eigen's
+//                      makeHouseholder), so the 15 zero IMU columns hand rows 0..14 of H_o through VERBATIM and a
+//                      dependent / zero camera column hands its row through (Q2); rows of R that are non-zero are kept
+//   msckf.h:1365-1366  r_n = Q_1^T r_o,  R_n = Q_1^T R_o Q_1
+//
+// and then handed to the filter's update as the information matrix it stands for,
+//       Lam^ = [T_H | r_n]^T R_n^-1 [T_H | r_n]            ((6N + 1) x (6N + 1), f64),
+// whose Cholesky factor [T^ | r^] with unit noise gives the same K r_n and the same covariance as (T_H, r_n, R_n) in
+// msckf.h:1368-1418 (posterior information P^-1 + T_H^T R_n^-1 T_H, information vector T_H^T R_n^-1 r_n): everything after
+// the compression is the library's existing update with sigma^2 = 1.
+//
+// Zero tails: in floating point the tail of a column that depends on the previous ones (the window's gauge directions; a
+// stack with fewer rows than columns) is rounding noise, not zero, and the reference then reflects along a direction that
+// is rounding noise -- its own result moves by ~1e-4 (gyro bias) between two roundings (tests/test_ref_vs_oracle.py).
+// `tol` > 0 treats a tail below tol * |column| as the zero it stands for and drops rows of R whose entries are all below
+// tol * max|R| (exactly zero in exact arithmetic): the reference's algorithm in its exact-arithmetic limit, reproducible to
+// rounding.  tol = 0 is the reference's rule to the letter (tail^2 <= numeric_limits::min).
+//
+// Written once for two compilers: hipcc (kernels_literal.hip: one workgroup per trajectory, phases separated by barriers)
+// and g++ -DLIT_HOST (tests/cpp/literal_host.cpp: the same phases run serially, checked against the oracle on the CPU).
+// All arithmetic in f64 whatever the filter's scalar type.
+#ifndef MSCKF_LITERAL_CORE_H
+#define MSCKF_LITERAL_CORE_H
+
+#include <math.h>
+
+namespace msckf {
+namespace lit {
+
+#ifdef LIT_HOST
+#define LIT_FN inline
+struct Ctx { int tid = 0, nt = 1, lane = 0, wave = 0, nw = 1; double* red = nullptr; };
+LIT_FN void barrier(const Ctx&) {}
+template <class F> LIT_FN void par_for(const Ctx&, long n, F f) { for (long i = 0; i < n; ++i) f(i); }
+template <class F> LIT_FN double wg_sum(const Ctx&, long lo, long hi, F f) { double s = 0; for (long i = lo; i < hi; ++i) s += f(i); return s; }
+template <class F> LIT_FN double wg_max(const Ctx&, long lo, long hi, F f) { double s = 0; for (long i = lo; i < hi; ++i) { const double v = f(i); s = v > s ? v : s; } return s; }
+// wave_for: item j is handled by one whole wavefront; inside, lane_for / wave_sum spread a row range over its lanes
+template <class F> LIT_FN void wave_for(const Ctx&, long lo, long hi, F f) { for (long j = lo; j < hi; ++j) f(j); }
+template <class F> LIT_FN void lane_for(const Ctx&, long lo, long hi, F f) { for (long i = lo; i < hi; ++i) f(i); }
+template <class F> LIT_FN double wave_sum_range(const Ctx&, long lo, long hi, F f) { double s = 0; for (long i = lo; i < hi; ++i) s += f(i); return s; }
+LIT_FN bool first_lane(const Ctx&) { return true; }
+LIT_FN bool first_thread(const Ctx&) { return true; }
+#else
+#define LIT_FN __device__ __forceinline__
+struct Ctx { int tid, nt, lane, wave, nw; double* red; };   // red: LDS scratch, nw + 2 doubles
+LIT_FN void barrier(const Ctx&) { __syncthreads(); }
+template <class F> LIT_FN void par_for(const Ctx& c, long n, F f) { for (long i = c.tid; i < n; i += c.nt) f(i); }
+template <class F> LIT_FN double wg_sum(const Ctx& c, long lo, long hi, F f) {
+  double s = 0;
+  for (long i = lo + c.tid; i < hi; i += c.nt) s += f(i);
+  s = wave_sum(s);
+  __syncthreads();                       // red may still be read from the previous reduction
+  if (c.lane == 0) c.red[c.wave] = s;
+  __syncthreads();
+  double t = 0;
+  for (int w = 0; w < c.nw; ++w) t += c.red[w];   // same order in every thread: a uniform value
+  return t;
+}
+template <class F> LIT_FN double wg_max(const Ctx& c, long lo, long hi, F f) {
+  double s = 0;
+  for (long i = lo + c.tid; i < hi; i += c.nt) { const double v = f(i); s = v > s ? v : s; }
+  s = wave_max(s);
+  __syncthreads();
+  if (c.lane == 0) c.red[c.wave] = s;
+  __syncthreads();
+  double t = 0;
+  for (int w = 0; w < c.nw; ++w) t = c.red[w] > t ? c.red[w] : t;
+  return t;
+}
+template <class F> LIT_FN void wave_for(const Ctx& c, long lo, long hi, F f) { for (long j = lo + c.wave; j < hi; j += c.nw) f(j); }
+template <class F> LIT_FN void lane_for(const Ctx& c, long lo, long hi, F f) { for (long i = lo + c.lane; i < hi; i += 64) f(i); }
+template <class F> LIT_FN double wave_sum_range(const Ctx& c, long lo, long hi, F f) {
+  double s = 0;
+  for (long i = lo + c.lane; i < hi; i += 64) s += f(i);
+  return wave_sum(s);
+}
+LIT_FN bool first_lane(const Ctx& c) { return c.lane == 0; }
+LIT_FN bool first_thread(const Ctx& c) { return c.tid == 0; }
+#endif
+
+// One trajectory's inputs (what k_feature / k_select left behind) and work space.  HT: scalar type of the Jacobian blocks.
+template <class HT>
+struct Args {
+  // ---- inputs
+  int F;                    // tracks in the work-list
+  int m_cap;                // observations per track the per-track arrays are laid out for
+  int N;                    // camera states in the window; n = 6 N state columns
+  const int* status;        // [F] bit `inc_bit` set: the track's rows enter the stack (msckf.h:352-441)
+  int inc_bit;
+  const int* M;             // [F]
+  const int* slots;         // slot of observation o of track t at slots[first(t) + o]
+  const int* off;           // first(t) = off ? off[t] : t * m_cap
+  const HT* Hx;             // [F][m_cap][12]: rows 2o, 2o+1 of H_x_j as 2 x 6 (camera columns of slot o)   msckf.h:915-950
+  const HT* rw;             // [F][2 m_cap]: r_j                                                             msckf.h:960-978
+  double u_var, v_var, tol;
+  // ---- work space (f64), all per trajectory
+  int ldx;                  // row capacity of X (>= stacked rows m)
+  double* X;                // [ldx x (n + 1)] column-major: [H_o(:, 15:) | r_o], then R / reflectors, then Q'
+  double* tau;              // [n]
+  double* Vf;               // [F][2 m_cap][3] reflectors of H_f_j (unit lower trapezoidal, implicit ones) -> A_j
+  double* Tf;               // [F][9] compact-WY T of those
+  int* row0;                // [F + 1] first stacked row of track t (list order), row0[F] = m
+  int* obs0;                // [F + 1] first observation index of track t among the stacked tracks
+  int* kept;                // [n + 16] kept rows of R (msckf.h:1347)
+  int r_cap;                // >= n + 15 (row capacity of TH / G / Z)
+  double* TH;               // [r_cap x (n + 1)] column-major: kept rows of [R | Q^T r_o]
+  int ldg;                  // row capacity of G (>= stacked observations)
+  double* G;                // [ldg x r_cap] column-major: u-rows of A Q_1   (R_n = v' I + (u' - v') G^T G)
+  int ldz;                  // r_cap + n + 1
+  double* Z;                // [ldz x ldz] column-major lower triangle: [[R_n, .], [TH^T, 0]] -> Schur complement -Lam^
+  // ---- outputs
+  double* Lam; int ldL;     // Lam^(hi, lo), lo <= hi <= n, at Lam[hi * ldL + lo]  (what k_chol_mfma / lam_hat read)
+  int* info;                // [4]: stacked rows m, kept rows r, reflected steps, steps skipped by the tolerance
+};
+
+template <class HT> LIT_FN int first_obs(const Args<HT>& a, int t) { return a.off ? a.off[t] : t * a.m_cap; }
+// V of a track's H_f factorization with its implicit structure
+LIT_FN double vf_at(const double* V, int i, int q) { return i < q ? 0.0 : (i == q ? 1.0 : V[i * 3 + q]); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// per track: column-pivoted Householder QR of H_f_j = -H_x_j(:, 3:6) (2M x 3), in place in V (essential parts below the
+// diagonal), compact-WY T with Q = H_0 H_1 H_2 = I - V T V^T.  The pivot rule is the oracle's (and Eigen's, away from
+// ties): the remaining column of largest squared norm over rows k.., first one wins.  Serial: one thread per track.
+template <class HT>
+LIT_FN void track_null_space(const Args<HT>& a, int t) {
+  const int M = a.M[t], R2 = 2 * M;
+  double* V = a.Vf + (long)t * 2 * a.m_cap * 3;
+  double* T = a.Tf + (long)t * 9;
+  const HT* hx = a.Hx + (long)t * a.m_cap * 12;
+  for (int i = 0; i < R2; ++i)
+    for (int c = 0; c < 3; ++c) V[i * 3 + c] = -(double)hx[(i >> 1) * 12 + (i & 1) * 6 + 3 + c];
+  double tau[3] = {0, 0, 0};
+  const int steps = R2 < 3 ? R2 : 3;
+  for (int k = 0; k < steps; ++k) {
+    int big = k; double best = -1.0;
+    for (int j = k; j < 3; ++j) {
+      double s = 0;
+      for (int i = k; i < R2; ++i) s += V[i * 3 + j] * V[i * 3 + j];
+      if (s > best) { best = s; big = j; }
+    }
+    if (big != k) for (int i = 0; i < R2; ++i) { const double x = V[i * 3 + k]; V[i * 3 + k] = V[i * 3 + big]; V[i * 3 + big] = x; }
+    double tail2 = 0;
+    for (int i = k + 1; i < R2; ++i) tail2 += V[i * 3 + k] * V[i * 3 + k];
+    const double c0 = V[k * 3 + k];
+    if (tail2 <= 2.2250738585072014e-308) { tau[k] = 0; for (int i = k + 1; i < R2; ++i) V[i * 3 + k] = 0; continue; }
+    double beta = sqrt(c0 * c0 + tail2);
+    if (c0 >= 0.0) beta = -beta;
+    const double inv = 1.0 / (c0 - beta);
+    for (int i = k + 1; i < R2; ++i) V[i * 3 + k] *= inv;
+    tau[k] = (beta - c0) / beta;
+    V[k * 3 + k] = beta;
+    for (int j = k + 1; j < 3; ++j) {
+      double s = V[k * 3 + j];
+      for (int i = k + 1; i < R2; ++i) s += V[i * 3 + k] * V[i * 3 + j];
+      s *= tau[k];
+      V[k * 3 + j] -= s;
+      for (int i = k + 1; i < R2; ++i) V[i * 3 + j] -= s * V[i * 3 + k];
+    }
+  }
+  double d01 = 0, d02 = 0, d12 = 0;
+  for (int i = 0; i < R2; ++i) {
+    const double v0 = vf_at(V, i, 0), v1 = vf_at(V, i, 1), v2 = vf_at(V, i, 2);
+    d01 += v0 * v1; d02 += v0 * v2; d12 += v1 * v2;
+  }
+  for (int i = 0; i < 9; ++i) T[i] = 0;
+  T[0] = tau[0]; T[4] = tau[1]; T[8] = tau[2];
+  T[1] = -tau[1] * T[0] * d01;                       // T(0,1)
+  T[2] = -tau[2] * (T[0] * d02 + T[1] * d12);        // T(0,2)
+  T[5] = -tau[2] * T[4] * d12;                       // T(1,2)
+}
+
+// the whole compression for one trajectory; every thread of the workgroup calls it with the same arguments
+template <class HT>
+LIT_FN void literal_compress(const Ctx& c, const Args<HT>& a) {
+  const int n = 6 * a.N, D = 15 + n, F = a.F;
+  // ---- stacked row / observation offsets in list order (msckf.h:404-441)
+  if (first_thread(c)) {
+    int r = 0, o = 0;
+    for (int t = 0; t < F; ++t) {
+      a.row0[t] = r; a.obs0[t] = o;
+      if (a.status[t] & a.inc_bit) { r += 2 * a.M[t] - 3; o += a.M[t]; }
+    }
+    a.row0[F] = r; a.obs0[F] = o;
+    a.info[0] = r;
+  }
+  barrier(c);
+  const int m = a.row0[F], mobs = a.obs0[F];
+  const long ldx = a.ldx;
+  double* X = a.X;
+  if (m <= 0) { if (first_thread(c)) { a.info[1] = 0; a.info[2] = 0; a.info[3] = 0; } return; }
+
+  // ---- A_j: null space of H_f_j^T per track (msckf.h:954-955)
+  par_for(c, F, [&](long t) { if (a.status[t] & a.inc_bit) track_null_space(a, (int)t); });
+  par_for(c, (long)m * (n + 1), [&](long e) { const long j = e / m, i = e - j * m; X[i + ldx * j] = 0.0; });
+  barrier(c);
+
+  // ---- H_o_j = A_j^T H_x_j and r_o_j = A_j^T r_j written to their place in the stack (msckf.h:957, :430, :436-437):
+  // (Q_f^T h)_i = h_i - V(i, :) T^T V^T h, rows 3.. ; a column of H_x_j has two non-zero entries (rows 2o, 2o+1)
+  {
+    const int cper = 6 * a.m_cap + 1;    // columns of [H_x_j | r_j] (padded)
+    par_for(c, (long)F * cper, [&](long e) {
+      const int t = (int)(e / cper), cc = (int)(e - (long)t * cper);
+      if (!(a.status[t] & a.inc_bit)) return;
+      const int M = a.M[t], R2 = 2 * M;
+      if (cc > 6 * M) return;
+      const double* V = a.Vf + (long)t * 2 * a.m_cap * 3;
+      const double* T = a.Tf + (long)t * 9;
+      const HT* hx = a.Hx + (long)t * a.m_cap * 12;
+      double s[3] = {0, 0, 0};
+      int o = -1, col; double h0 = 0, h1 = 0;
+      if (cc < 6 * M) {
+        o = cc / 6; const int kk = cc - 6 * o;
+        h0 = (double)hx[o * 12 + kk]; h1 = (double)hx[o * 12 + 6 + kk];
+        for (int q = 0; q < 3; ++q) s[q] = vf_at(V, 2 * o, q) * h0 + vf_at(V, 2 * o + 1, q) * h1;
+        col = 6 * a.slots[first_obs(a, t) + o] + kk;
+      } else {
+        const HT* r = a.rw + (long)t * 2 * a.m_cap;
+        for (int i = 0; i < R2; ++i) for (int q = 0; q < 3; ++q) s[q] += vf_at(V, i, q) * (double)r[i];
+        col = n;
+      }
+      double w[3];
+      for (int q = 0; q < 3; ++q) { double x = 0; for (int p = 0; p <= q; ++p) x += T[p * 3 + q] * s[p]; w[q] = x; }   // T^T s
+      double* xc = X + ldx * col + a.row0[t];
+      for (int i = 3; i < R2; ++i) {
+        double h;
+        if (cc < 6 * M) h = (i == 2 * o) ? h0 : ((i == 2 * o + 1) ? h1 : 0.0);
+        else h = (double)(a.rw + (long)t * 2 * a.m_cap)[i];
+        xc[i - 3] = h - (vf_at(V, i, 0) * w[0] + vf_at(V, i, 1) * w[1] + vf_at(V, i, 2) * w[2]);
+      }
+    });
+  }
+  barrier(c);
+
+  // ---- HouseholderQR(H_o) in column order (msckf.h:1343).  Steps 0..14 meet the zero IMU columns: identity.  Step 15 + k
+  // works on camera column k, rows 15 + k.. ; r_o (column n) rides along, so that column n ends as Q^T r_o.
+  const int steps_total = m < D ? m : D;
+  const int msteps = steps_total - 15 > 0 ? steps_total - 15 : 0;
+  const double tol2 = a.tol * a.tol;
+  int n_reflect = 0, n_skip_tol = 0;
+  for (int k = 0; k < msteps; ++k) {
+    const int p = 15 + k;
+    double* xk = X + ldx * k;
+    const double tail2 = wg_sum(c, p + 1, m, [&](long i) { return xk[i] * xk[i]; });
+    double zero2 = 2.2250738585072014e-308;
+    if (a.tol > 0) {
+      const double head2 = wg_sum(c, 0, p + 1, [&](long i) { return xk[i] * xk[i]; });
+      const double z = tol2 * (head2 + tail2);
+      zero2 = z > zero2 ? z : zero2;
+    }
+    const double c0 = xk[p];
+    barrier(c);
+    if (tail2 <= zero2) {
+      if (tail2 > 2.2250738585072014e-308) ++n_skip_tol;
+      if (first_thread(c)) a.tau[k] = 0.0;
+      par_for(c, m - (p + 1), [&](long i) { xk[p + 1 + i] = 0.0; });
+      barrier(c);
+      continue;
+    }
+    ++n_reflect;
+    double beta = sqrt(c0 * c0 + tail2);
+    if (c0 >= 0.0) beta = -beta;
+    const double inv = 1.0 / (c0 - beta), tk = (beta - c0) / beta;
+    par_for(c, m - (p + 1), [&](long i) { xk[p + 1 + i] *= inv; });
+    if (first_thread(c)) { xk[p] = beta; a.tau[k] = tk; }
+    barrier(c);
+    wave_for(c, k + 1, n + 1, [&](long j) {
+      double* xj = X + ldx * j;
+      double s = wave_sum_range(c, p + 1, m, [&](long i) { return xk[i] * xj[i]; });
+      s = (s + xj[p]) * tk;
+      lane_for(c, p + 1, m, [&](long i) { xj[i] -= s * xk[i]; });
+      if (first_lane(c)) xj[p] -= s;
+    });
+    barrier(c);
+  }
+
+  // ---- rows of R that are kept (msckf.h:1345-1348: the upper-triangular view, a row with any non-zero entry)
+  double rmax = 0;
+  if (a.tol > 0) {
+    rmax = wg_max(c, 0, (long)steps_total * n, [&](long e) {
+      const long j = e / steps_total, i = e - j * steps_total;
+      return (j + 15 >= i) ? fabs(X[i + ldx * j]) : 0.0;
+    });
+  }
+  barrier(c);
+  int* flag = a.kept + (n + 16);   // scratch behind the kept list: [steps_total] flags
+  par_for(c, steps_total, [&](long i) {
+    int any = 0;
+    const int c_lo = i >= 15 ? (int)i - 15 : 0;
+    for (int j = c_lo; j < n && !any; ++j) { const double v = fabs(X[i + ldx * j]); any = a.tol > 0 ? (v > a.tol * rmax) : (v != 0.0); }
+    flag[i] = any;
+  });
+  barrier(c);
+  if (first_thread(c)) {
+    int nr = 0;
+    for (int i = 0; i < steps_total; ++i) if (flag[i]) a.kept[nr++] = i;
+    a.info[1] = nr; a.info[2] = n_reflect; a.info[3] = n_skip_tol;
+  }
+  barrier(c);
+  const int nr = a.info[1];
+  const int rc = a.r_cap;
+  // [T_H | r_n]: kept rows of the upper-triangular view and of Q^T r_o (msckf.h:1351-1365)
+  par_for(c, (long)nr * (n + 1), [&](long e) {
+    const int j = (int)(e / nr), k = (int)(e - (long)j * nr), row = a.kept[k];
+    double v = X[row + ldx * j];
+    if (j < n && j + 15 < row) v = 0.0;
+    a.TH[k + (long)rc * j] = v;
+  });
+  barrier(c);
+
+  // ---- Q' = H_15 H_16 ... (first msteps columns), generated in place of the reflectors (backward accumulation); its
+  // columns are zero in rows 0..14, and column k is zero above row 15 + k before H_k .. H_15 reach it.
+  par_for(c, (long)msteps * 15, [&](long e) { const long j = e / 15, i = e - j * 15; if (i < m) X[i + ldx * j] = 0.0; });
+  barrier(c);
+  for (int k = msteps - 1; k >= 0; --k) {
+    const int p = 15 + k;
+    double* xk = X + ldx * k;
+    const double tk = a.tau[k];
+    if (tk != 0.0) {
+      wave_for(c, k + 1, msteps, [&](long j) {
+        double* xj = X + ldx * j;
+        double s = wave_sum_range(c, p + 1, m, [&](long i) { return xk[i] * xj[i]; });
+        s = (s + xj[p]) * tk;
+        lane_for(c, p + 1, m, [&](long i) { xj[i] -= s * xk[i]; });
+        if (first_lane(c)) xj[p] -= s;
+      });
+    }
+    barrier(c);
+    par_for(c, m - 15, [&](long ii) {
+      const long i = 15 + ii;
+      if (i < p) xk[i] = 0.0; else if (i == p) xk[i] = 1.0 - tk; else xk[i] = -tk * xk[i];
+    });
+    barrier(c);
+  }
+
+  // ---- G = u-rows of A Q_1 (stacked observations x kept rows): R_n = Q_1^T R_o Q_1 = v' I + (u' - v') G^T G
+  // (msckf.h:423, 431, 1366).  Column k of Q_1 is e_row for a kept row < 15, else column row - 15 of Q'.
+  // A_j q = Q_f [0; q] = q~ - V T (V^T q~), q~ = [0, 0, 0, q]
+  par_for(c, (long)F * nr, [&](long e) {
+    const int t = (int)(e / nr), k = (int)(e - (long)t * nr);
+    if (!(a.status[t] & a.inc_bit)) return;
+    const int M = a.M[t], rho = 2 * M - 3, r0 = a.row0[t], row = a.kept[k];
+    const double* V = a.Vf + (long)t * 2 * a.m_cap * 3;
+    const double* T = a.Tf + (long)t * 9;
+    const double* q = row >= 15 ? X + ldx * (row - 15) + r0 : nullptr;
+    auto qv = [&](int i) -> double { return q ? q[i] : ((r0 + i == row) ? 1.0 : 0.0); };   // i in [0, rho)
+    double s[3] = {0, 0, 0};
+    for (int i = 0; i < rho; ++i) { const double x = qv(i); if (x != 0.0) for (int qq = 0; qq < 3; ++qq) s[qq] += vf_at(V, i + 3, qq) * x; }
+    double w[3];
+    for (int pp = 0; pp < 3; ++pp) { double x = 0; for (int qq = pp; qq < 3; ++qq) x += T[pp * 3 + qq] * s[qq]; w[pp] = x; }   // T s
+    double* g = a.G + (long)a.ldg * k + a.obs0[t];
+    for (int o = 0; o < M; ++o) {
+      const int i = 2 * o;
+      const double qt = i >= 3 ? qv(i - 3) : 0.0;
+      g[o] = qt - (vf_at(V, i, 0) * w[0] + vf_at(V, i, 1) * w[1] + vf_at(V, i, 2) * w[2]);
+    }
+  });
+  barrier(c);
+
+  // ---- Z = [[R_n, .], [[T_H | r_n]^T, 0]] (lower triangle); eliminating the nr pivots of R_n leaves
+  // -[T_H | r_n]^T R_n^-1 [T_H | r_n] in the trailing block
+  const int nz = nr + n + 1;
+  const long ldz = a.ldz;
+  double* Z = a.Z;
+  const double dlt = a.u_var - a.v_var;
+  par_for(c, (long)nr * nr, [&](long e) {
+    const int j = (int)(e / nr), i = (int)(e - (long)j * nr);
+    if (i < j) return;
+    const double* gi = a.G + (long)a.ldg * i; const double* gj = a.G + (long)a.ldg * j;
+    double s = 0;
+    for (int o = 0; o < mobs; ++o) s += gi[o] * gj[o];
+    Z[i + ldz * j] = dlt * s + (i == j ? a.v_var : 0.0);
+  });
+  par_for(c, (long)(n + 1) * nz, [&](long e) {
+    const int j = (int)(e / (n + 1)), cc = (int)(e - (long)j * (n + 1));
+    Z[(nr + cc) + ldz * j] = j < nr ? a.TH[j + (long)rc * cc] : 0.0;
+  });
+  barrier(c);
+  for (int k = 0; k < nr; ++k) {
+    const double dk = Z[k + ldz * k];
+    const double dinv = 1.0 / dk;
+    // row-parallel: thread i updates Z(i, k+1 .. i) with Z(i, k) Z(j, k) / d
+    par_for(c, nz - (k + 1), [&](long ii) {
+      const long i = k + 1 + ii;
+      const double lik = Z[i + ldz * k] * dinv;
+      if (lik == 0.0) return;
+      for (long j = k + 1; j <= i; ++j) Z[i + ldz * j] -= lik * Z[j + ldz * k];
+    });
+    barrier(c);
+  }
+  // ---- Lam^ (lower triangle incl. row n) where the blocked Cholesky reads it
+  par_for(c, (long)(n + 1) * (n + 1), [&](long e) {
+    const int hi = (int)(e / (n + 1)), lo = (int)(e - (long)hi * (n + 1));
+    if (lo > hi) return;
+    a.Lam[(long)hi * a.ldL + lo] = -Z[(nr + hi) + ldz * (nr + lo)];
+  });
+  barrier(c);
+}
+
+}  // namespace lit
+}  // namespace msckf
+#endif

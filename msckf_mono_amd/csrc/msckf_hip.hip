@@ -125,6 +125,8 @@ struct BatchBase {
   virtual int set_feature_overlap(int on) = 0;
   virtual int clear_stats(int b) = 0;
   virtual int clear_errors(int b) = 0;
+  virtual int set_aniso(int mode, double tol) = 0;
+  virtual int lit_info(int b, int* out4) = 0;
 };
 
 constexpr int NSTAGE = 8;
@@ -190,6 +192,13 @@ struct Batch : BatchBase {
   int overlap_feature = 0;   // measured on MI355X at cfg3: 100 k -> 82 k updates/s with the overlap on (k_feature floods the CUs the
                              // latency-bound propagate/augment workgroups need); kept selectable, off by default
   int compress_route = -1;   // -1 default, 0 Householder TSQR, 1 information form, 2 information form + blocked Cholesky
+  // anisotropic pixel noise (u_var' != v_var'): 0 = the reference's construction R_o_j = A_j^T R_j A_j, R_n = Q_1^T R_o Q_1 on
+  // the device (kernels_literal.hip; default), 1 = rows pre-whitened by 1/sigma (generalized least squares, unit noise)
+  int aniso_mode = 0;
+  double lit_tol = -1;       // zero-tail tolerance of the literal route; < 0: 1e-10 (double) / 2e-4 (float: H_x is float-rounded)
+  std::vector<double> h_uv;  // [B][2] u_var', v_var' as initialize() got them
+  std::vector<char> h_lit;   // [B] trajectory runs the literal route
+  int n_lit = 0;
   // single-call staging on device
   S* d_rd = nullptr; int rd_cap = 0;               // [B][rd_cap][7]
   S* d_pfin = nullptr;                              // [B][f_cap][4] stored feature positions (mode 1)
@@ -245,7 +254,7 @@ struct Batch : BatchBase {
       HIPCHK(hipStreamCreateWithFlags(&sty[i], hipStreamNonBlocking));
       HIPCHK(hipEventCreateWithFlags(&ev_fa[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_fb[i], hipEventDisableTiming));
     }
-    h_ncam.assign(B, 0);
+    h_ncam.assign(B, 0); h_uv.assign((size_t)2 * B, 0.0); h_lit.assign(B, 0);
     d.B = B; d.n_cap = n_cap; d.f_cap = f_cap; d.m_cap = m_cap;
     d.n6cap = 6 * n_cap;
     d.ld = ((15 + 6 * n_cap + 15) / 16) * 16;
@@ -363,6 +372,59 @@ struct Batch : BatchBase {
   int chk(int b) const { return (b < 0 || b >= B) ? -EINVAL : 0; }
   int chk_range(int b0, int nb) const { return (b0 < 0 || nb < 0 || b0 + nb > B) ? -EINVAL : 0; }
 
+  // The five derived noise parameters PRM_WU .. PRM_LIT of trajectory b for the batch's anisotropic-noise mode
+  // (dev_common.h); allocates the literal route's work space when the first trajectory needs it.
+  int derive_noise(int b, S* out5) {
+    const double u = h_uv[2 * (size_t)b], v = h_uv[2 * (size_t)b + 1];
+    const bool was = h_lit[b] != 0;
+    bool lit = false;
+    if (u == v) { out5[0] = 1; out5[1] = 1; out5[2] = (S)u; out5[3] = (S)u; out5[4] = 0; }
+    else if (aniso_mode == 0 && !h16 && d.trk_B) { out5[0] = 1; out5[1] = 1; out5[2] = 1; out5[3] = (S)u; out5[4] = 1; lit = true; }
+    else { out5[0] = (S)(1.0 / std::sqrt(u)); out5[1] = (S)(1.0 / std::sqrt(v)); out5[2] = 1; out5[3] = 1; out5[4] = 0; }
+    if (lit && !d.lit.X) { const int rc = lit_alloc(); if (rc) return rc; }
+    if (lit != was) { n_lit += lit ? 1 : -1; h_lit[b] = lit ? 1 : 0; }
+    return 0;
+  }
+  // work space of kernels_literal.hip: the dense stack [H_o | r_o] (f_cap (2 m_cap - 3) rows x (6 n_cap + 1) columns, f64) per
+  // trajectory and the small matrices of its tail; only allocated when a trajectory has u_var' != v_var' on the literal route
+  int lit_alloc() {
+    LitBufs& L = d.lit;
+    const size_t Bz = B, n1 = (size_t)d.n6cap + 1;
+    L.ldx = ((f_cap * std::max(2 * m_cap - 3, 1) + 7) / 8) * 8;
+    L.r_cap = d.n6cap + 15; L.ldg = f_cap * m_cap; L.ldz = L.r_cap + (int)n1; L.kept_stride = 2 * (d.n6cap + 16) + 16;
+    L.tol = lit_tol >= 0 ? lit_tol : (sizeof(S) == 4 ? 2e-4 : 1e-10);
+    int rc = 0;
+    rc |= dalloc(&L.X, Bz * L.ldx * n1); rc |= dalloc(&L.tau, Bz * n1);
+    rc |= dalloc(&L.Vf, Bz * f_cap * 2 * m_cap * 3); rc |= dalloc(&L.Tf, Bz * f_cap * 9);
+    rc |= dalloc(&L.row0, Bz * (f_cap + 1)); rc |= dalloc(&L.obs0, Bz * (f_cap + 1)); rc |= dalloc(&L.kept, Bz * L.kept_stride);
+    rc |= dalloc(&L.TH, Bz * L.r_cap * n1); rc |= dalloc(&L.G, Bz * (size_t)L.ldg * L.r_cap); rc |= dalloc(&L.Z, Bz * (size_t)L.ldz * L.ldz);
+    rc |= dalloc(&L.info, Bz * 4);
+    if (rc) { L.X = nullptr; return fail(-ENOMEM, "work space of the literal anisotropic route (msckf_hip_set_anisotropic_noise(h, 1, 0) selects pre-whitening)"); }
+    return 0;
+  }
+  int set_aniso(int mode, double tol) override {
+    if (mode < 0 || mode > 1) return fail(-EINVAL, "mode: 0 the reference's R_n = Q_1^T R_o Q_1 on the device, 1 pre-whitened rows");
+    HIPCHK(hipSetDevice(device));
+    aniso_mode = mode; lit_tol = tol;
+    d.lit.tol = tol >= 0 ? tol : (sizeof(S) == 4 ? 2e-4 : 1e-10);
+    for (int b = 0; b < B; ++b) {
+      if (!traj[b].initialized) continue;
+      S out5[5];
+      const int rc = derive_noise(b, out5);
+      if (rc) return rc;
+      HIPCHK(hipMemcpyAsync(d.prm + (size_t)b * PRM_STRIDE + PRM_WU, out5, sizeof(out5), hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));
+    }
+    return 0;
+  }
+  int lit_info(int b, int* out4) override {
+    if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
+    if (!d.lit.info) { for (int i = 0; i < 4; ++i) out4[i] = 0; return 0; }
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemcpyAsync(out4, d.lit.info + (size_t)b * 4, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+  }
   int init(int b, const double* cam, const double* noise, const double* params, const double* imu) override {
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
     if (!(noise[0] > 0) || !(noise[1] > 0)) return fail(-EINVAL, "u_var_prime / v_var_prime must be positive");
@@ -372,8 +434,8 @@ struct Batch : BatchBase {
     prm[PRM_UVAR] = (S)noise[0]; prm[PRM_VVAR] = (S)noise[1];
     for (int i = 0; i < 12; ++i) prm[PRM_Q + i] = (S)noise[2 + i];
     for (int i = 0; i < 8; ++i) prm[PRM_GN + i] = (S)params[i];
-    if (noise[0] == noise[1]) { prm[PRM_WU] = 1; prm[PRM_WV] = 1; prm[PRM_SIG2] = (S)noise[0]; }
-    else { prm[PRM_WU] = (S)(1.0 / std::sqrt(noise[0])); prm[PRM_WV] = (S)(1.0 / std::sqrt(noise[1])); prm[PRM_SIG2] = 1; }
+    h_uv[2 * (size_t)b] = noise[0]; h_uv[2 * (size_t)b + 1] = noise[1];
+    { const int rc0 = derive_noise(b, prm + PRM_WU); if (rc0) return rc0; }
     for (int i = 0; i < 29; ++i) st_imu[i] = (S)imu[i];
     for (int i = 0; i < 4; ++i) st_imu[IQN + i] = st_imu[IQ + i];        // msckf.h:83-85
     for (int i = 0; i < 3; ++i) { st_imu[IVN + i] = st_imu[IV + i]; st_imu[IPN + i] = st_imu[IP + i]; }
@@ -484,11 +546,17 @@ struct Batch : BatchBase {
   void launch_update(const Dev<S>& vin, int b0, int nb, hipStream_t q, bool feature_done = false) {
     Dev<S> v = vin;
     if (compress_route >= 0) v.compress = (compress_route && d.trk_B) ? compress_route : 0;
+    if (n_lit > 0 && !v.compress) v.compress = d.compress;   // the literal route hands over an information matrix: Cholesky tail
     if (!feature_done) { stage_begin(2, q); launch_feature<S>(v, b0, nb, q); stage_end(2, q); }
     // information form: k_select and the block-diagonal reduction share a launch (both only read k_feature's outputs)
     stage_begin(7, q); if (v.compress) launch_select_diag<S>(v, b0, nb, q); else launch_select<S>(v, b0, nb, q); stage_end(7, q);
     if (v.compress) {
-      stage_begin(3, q); launch_gram<S>(v, b0, nb, q, 3); stage_end(3, q);
+      // anisotropic pixel noise, literal route: the information matrix of the reference's (T_H, r_n, R_n) replaces H_o^T H_o
+      // for those trajectories (kernels_literal.hip); the SYRK is skipped when every trajectory of the batch is one
+      stage_begin(3, q);
+      if (n_lit < B) launch_gram<S>(v, b0, nb, q, 3);
+      if (n_lit > 0) launch_literal<S>(v, b0, nb, q);
+      stage_end(3, q);
       stage_begin(4, q); launch_gram<S>(v, b0, nb, q, 2); stage_end(4, q);
     } else {
       stage_begin(3, q); launch_compress<S>(v, b0, nb, q, 1); stage_end(3, q);
@@ -1643,5 +1711,7 @@ int msckf_hip_set_feature_overlap(msckf_hip_handle h, int on) { if (!h) return f
 int msckf_hip_set_covariance_update(msckf_hip_handle h, int form) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_cov_update(form); }
 int msckf_hip_set_compression(msckf_hip_handle h, int route) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_compression(route); }
 int msckf_hip_set_gate_early_accept(msckf_hip_handle h, int on) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_gate_early(on); }
+int msckf_hip_set_anisotropic_noise(msckf_hip_handle h, int mode, double tail_tol) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_aniso(mode, tail_tol); }
+int msckf_hip_literal_info(msckf_hip_handle h, int b, int* out4) { if (!h || !out4) return fail(-EINVAL, "null argument"); return H(h)->lit_info(b, out4); }
 
 }  // extern "C"

@@ -194,8 +194,10 @@ template <class S> struct Quat {
 //   tail^2 <= numeric_limits::min  -> tau = 0, beta = c0 (step is the identity)
 //   else beta = -sign(c0)*sqrt(c0^2+tail^2), essential = tail/(c0-beta), tau = (beta-c0)/beta.
 // On return A holds R in its upper triangle and the essential parts below; tau[k] per step.
+// tail_tol > 0: the zero-tail rule with a rounding threshold -- a tail below tail_tol * |column| (a column that depends
+// on the previous ones: exactly zero in exact arithmetic) is treated as the zero it stands for.
 template <class S>
-void householder_qr_inplace(Mat<S>& A, std::vector<S>& tau) {
+void householder_qr_inplace(Mat<S>& A, std::vector<S>& tau, double tail_tol = 0) {
   const int m = A.r, n = A.c, steps = std::min(m, n);
   tau.assign(steps, S(0));
   std::vector<S> w(n);
@@ -204,7 +206,9 @@ void householder_qr_inplace(Mat<S>& A, std::vector<S>& tau) {
     S tail2 = 0;
     for (int i = k + 1; i < m; ++i) tail2 += ck[i] * ck[i];
     const S c0 = ck[k];
-    if (tail2 <= std::numeric_limits<S>::min()) {
+    S zero2 = std::numeric_limits<S>::min();
+    if (tail_tol > 0) { S head2 = 0; for (int i = 0; i <= k; ++i) head2 += ck[i] * ck[i]; zero2 = std::max(zero2, S(tail_tol * tail_tol) * (head2 + tail2)); }
+    if (tail2 <= zero2) {
       tau[k] = 0;
       for (int i = k + 1; i < m; ++i) ck[i] = 0;
       continue;

@@ -109,6 +109,12 @@ class MSCKF {
   UpdateStats last_stats;
   std::vector<TrackDebug> last_tracks;
   Mat<S> last_deltaX;
+  // debug capture of the last measurementUpdate (tests only): stacked [H_o, r_o], compressed T_H, r_n, R_n and S
+  bool capture = false;
+  Mat<S> last_Ho, last_ro, last_TH, last_rn, last_Rn, last_S;
+  // per track whose Jacobian was formed in the last marginalize(), in list order: camera slots, H_x_j as [M][2][6], r_j [2M],
+  // gated in (stacked) or not
+  mutable std::vector<std::vector<int>> cap_slots; mutable std::vector<std::vector<double>> cap_hx, cap_r; mutable std::vector<int> cap_pass;
 
   // ---------------------------------------------------------------- msckf.h:72-97
   void initialize(const Camera<S>& camera, const NoiseParams<S>& noise_params,
@@ -273,6 +279,7 @@ class MSCKF {
   // ---------------------------------------------------------------- msckf.h:336-449
   void marginalize() {
     last_stats = UpdateStats(); last_tracks.clear(); last_deltaX.resize(0, 0);
+    cap_slots.clear(); cap_hx.clear(); cap_r.clear(); cap_pass.clear();
     if (feature_tracks_to_residualize_.empty()) return;
     last_stats.n_tracks = (int)feature_tracks_to_residualize_.size();
     last_tracks.resize(feature_tracks_to_residualize_.size());
@@ -319,6 +326,7 @@ class MSCKF {
       double gamma = 0;
       const bool pass = gatingTest(H_o_j, r_o_j, (int)track.cam_states.size() - 1, &gamma);
       last_tracks[iter].gamma = gamma; last_tracks[iter].gate_pass = pass; last_tracks[iter].rows = H_o_j.r;
+      if (capture) { std::vector<double> rr(r_j.r); for (int i = 0; i < r_j.r; ++i) rr[i] = (double)r_j(i, 0); cap_r.push_back(rr); cap_pass.push_back(pass ? 1 : 0); }
       if (pass) {
         for (int i = 0; i < H_o_j.r; ++i) r_o(stack + i, 0) = r_o_j(i, 0);
         H_o.set_block(stack, 0, H_o_j);
@@ -766,6 +774,14 @@ class MSCKF {
       }
     }
     whitenRows(H_f); whitenRows(H_x);
+    if (capture) {
+      std::vector<int> sl(M); std::vector<double> hx((size_t)M * 12);
+      for (int c = 0; c < M; ++c) {
+        sl[c] = (int)idx[c];
+        for (int i = 0; i < 2; ++i) for (int k = 0; k < 6; ++k) hx[(size_t)c * 12 + i * 6 + k] = (double)H_x(2 * c + i, 15 + 6 * (int)idx[c] + k);
+      }
+      cap_slots.push_back(sl); cap_hx.push_back(hx);
+    }
     const int rows = 2 * M;
     Mat<S> QR = H_f; std::vector<S> tau;
     // JacobiSVD(ComputeFullU) of the tall H_f_j = column-pivoted Householder QR preconditioner; its trailing
@@ -834,6 +850,7 @@ class MSCKF {
     const int D = T_H.c;
     Mat<S> PHt = mul_abt(P, T_H);                 // D x nr
     Mat<S> Smat = add(mul(T_H, PHt), R_n);        // :1369
+    if (capture) { last_TH = T_H; last_rn = r_n; last_Rn = R_n; last_S = Smat; }
     Mat<S> K = mul(PHt, inverse(Smat));           // :1370
     Mat<S> dX = mul(K, r_n);                      // :1373
     last_deltaX = dX;
@@ -894,10 +911,11 @@ class MSCKF {
     last_stats.m_rows = m;
     if (m == 0) return;
     const int D = H_o.c;
+    if (capture) { last_Ho = H_o; last_ro = r_o; }
     if (mode == GRAM && (uvar() == vvar())) { measurementUpdateGram(H_o, r_o); return; }
     Mat<S> P = fullP();
     Mat<S> QR = H_o; std::vector<S> tau;
-    householder_qr_inplace(QR, tau);              // :1343
+    householder_qr_inplace(QR, tau, tiny_row_tol);              // :1343 (tiny_row_tol > 0: thresholded zero-tail rule)
     const int steps = std::min(m, D);
     std::vector<int> kept;                        // nonZeroRows of the upper-triangular view :1345-1348
     S rmax = 0;

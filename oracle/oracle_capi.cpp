@@ -48,6 +48,9 @@ struct Base {
   virtual void set_whiten(int w) = 0;
   virtual void set_colpiv(int w) = 0;
   virtual void set_tiny(double t) = 0;
+  virtual void set_capture(int on) = 0;
+  virtual int last_matrix(int which, double* out, long cap, int* cols) = 0;
+  virtual int last_track_inputs(int* M, int* pass, int* slots, double* hx, double* r, int cap_f, int cap_m) = 0;
 };
 
 template <class S>
@@ -155,6 +158,31 @@ struct Impl : Base {
   void set_whiten(int w) override { f.whiten = w != 0; }
   void set_colpiv(int w) override { f.colpiv_null = w != 0; }
   void set_tiny(double t) override { f.tiny_row_tol = t; }
+  void set_capture(int on) override { f.capture = on != 0; }
+  // per track of the last marginalize() whose Jacobian was formed (set_capture): M, gated in?, slots [cap_m], H_x [cap_m][12], r [2 cap_m]
+  int last_track_inputs(int* M, int* pass, int* slots, double* hx, double* r, int cap_f, int cap_m) override {
+    const int F = (int)f.cap_slots.size();
+    if (F > cap_f) return -F;
+    for (int t = 0; t < F; ++t) {
+      const int m = (int)f.cap_slots[t].size();
+      if (m > cap_m) return -F;
+      M[t] = m; pass[t] = f.cap_pass[t];
+      for (int k = 0; k < m; ++k) slots[(size_t)t * cap_m + k] = f.cap_slots[t][k];
+      for (int k = 0; k < 12 * m; ++k) hx[(size_t)t * cap_m * 12 + k] = f.cap_hx[t][k];
+      for (int k = 0; k < 2 * m; ++k) r[(size_t)t * 2 * cap_m + k] = f.cap_r[t][k];
+    }
+    return F;
+  }
+  // which: 0 H_o, 1 r_o, 2 T_H, 3 r_n, 4 R_n, 5 S of the last measurementUpdate (column-major); returns rows
+  int last_matrix(int which, double* out, long cap, int* cols) override {
+    const Mat<S>* m[6] = {&f.last_Ho, &f.last_ro, &f.last_TH, &f.last_rn, &f.last_Rn, &f.last_S};
+    if (which < 0 || which > 5) return -1;
+    const Mat<S>& a = *m[which];
+    *cols = a.c;
+    if ((long)a.r * a.c > cap) return -a.r;
+    for (int j = 0; j < a.c; ++j) for (int i = 0; i < a.r; ++i) out[(long)j * a.r + i] = (double)a(i, j);
+    return a.r;
+  }
 };
 }  // namespace
 
@@ -195,6 +223,9 @@ void* oracle_clone(void* h) { return ((Base*)h)->clone(); }
 void oracle_set_whiten(void* h, int w) { ((Base*)h)->set_whiten(w); }
 void oracle_set_colpiv_null(void* h, int w) { ((Base*)h)->set_colpiv(w); }
 void oracle_set_tiny_row_tol(void* h, double t) { ((Base*)h)->set_tiny(t); }
+void oracle_set_capture(void* h, int on) { ((Base*)h)->set_capture(on); }
+int oracle_last_track_inputs(void* h, int* M, int* pass, int* slots, double* hx, double* r, int cap_f, int cap_m) { return ((Base*)h)->last_track_inputs(M, pass, slots, hx, r, cap_f, cap_m); }
+int oracle_last_matrix(void* h, int which, double* out, long cap, int* cols) { return ((Base*)h)->last_matrix(which, out, cap, cols); }
 
 // Timed CPU baseline: run `n_filters` independent filters over the same pre-built per-frame call
 // sequence on `n_threads` std::threads (one filter per thread at a time, as the reference is

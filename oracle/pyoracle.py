@@ -212,6 +212,15 @@ class Oracle:
         default) or unpivoted reflectors"""
         self.L.oracle_set_colpiv_null(self.h, 1 if on else 0)
 
+    def setTinyRowTol(self, tol):
+        """restatement only: zero-tail rule of HouseholderQR(H_o) with a rounding threshold (a tail below tol * |column| is the
+        zero it stands for; rows of R with all entries below tol * max|R| are dropped) -- the reference's algorithm in its
+        exact-arithmetic limit; 0 (default) = msckf.h:1343-1348 to the letter"""
+        self.L.oracle_set_tiny_row_tol(self.h, C.c_double(float(tol)))
+
+    def setCapture(self, on=True):
+        self.L.oracle_set_capture(self.h, 1 if on else 0)
+
     def setMode(self, mode):
         self.L.oracle_set_mode(self.h, int(mode))
 

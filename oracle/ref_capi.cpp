@@ -222,6 +222,8 @@ void oracle_set_mode(void*, int) {}
 void* oracle_clone(void* h) { return ((Base*)h)->clone(); }
 void oracle_set_whiten(void*, int) {}
 void oracle_set_colpiv_null(void*, int) {}
+void oracle_set_tiny_row_tol(void*, double) {}
+void oracle_set_capture(void*, int) {}
 // chi_squared_test_table as the reference built it (msckf.h:91-95), for the table test
 int oracle_chi2_table(void* h, double* out, int cap) {
   Impl<double>* d = dynamic_cast<Impl<double>*>((Base*)h);

@@ -1,0 +1,36 @@
+// literal_host.cpp -- TEST HARNESS: msckf_mono_amd/csrc/literal_core.h (the device's literal anisotropic compression, written
+// for two compilers) compiled for the host with -DLIT_HOST, so that its algorithm can be held against the oracle on the
+// CPU (tests/test_literal_core.py).  The product runs the same header inside kernels_literal.hip.
+#include <cstdlib>
+#include <vector>
+
+#define LIT_HOST
+#include "../../msckf_mono_amd/csrc/literal_core.h"
+
+extern "C" int lit_host_compress(int F, int m_cap, int N, const int* included, const int* M, const int* slots /*[F][m_cap]*/,
+                                 const double* Hx /*[F][m_cap][12]*/, const double* rw /*[F][2 m_cap]*/, double u_var, double v_var,
+                                 double tol, double* Lam /*[(6N+1)^2], (hi, lo) at hi * (6N+1) + lo*/, int* info4,
+                                 double* TH_out /*[(6N+15) x (6N+1)] column-major or null*/) {
+  using namespace msckf::lit;
+  const int n = 6 * N;
+  int m = 0, mobs = 0;
+  for (int t = 0; t < F; ++t) if (included[t]) { m += 2 * M[t] - 3; mobs += M[t]; }
+  Args<double> a;
+  a.F = F; a.m_cap = m_cap; a.N = N; a.status = included; a.inc_bit = 1; a.M = M; a.slots = slots; a.off = nullptr;
+  a.Hx = Hx; a.rw = rw; a.u_var = u_var; a.v_var = v_var; a.tol = tol;
+  a.ldx = m + 8;
+  std::vector<double> X((size_t)a.ldx * (n + 1)), tau(n + 1), Vf((size_t)F * 2 * m_cap * 3), Tf((size_t)F * 9);
+  std::vector<int> row0(F + 1), obs0(F + 1), kept(2 * (n + 16) + 16);
+  a.X = X.data(); a.tau = tau.data(); a.Vf = Vf.data(); a.Tf = Tf.data(); a.row0 = row0.data(); a.obs0 = obs0.data(); a.kept = kept.data();
+  a.r_cap = n + 15;
+  std::vector<double> TH((size_t)a.r_cap * (n + 1)), G((size_t)(mobs + 8) * a.r_cap);
+  a.TH = TH.data(); a.ldg = mobs + 8; a.G = G.data();
+  a.ldz = a.r_cap + n + 1;
+  std::vector<double> Z((size_t)a.ldz * a.ldz);
+  a.Z = Z.data();
+  a.Lam = Lam; a.ldL = n + 1; a.info = info4;
+  Ctx c;
+  literal_compress(c, a);
+  if (TH_out) for (size_t i = 0; i < TH.size(); ++i) TH_out[i] = TH[i];
+  return 0;
+}

@@ -456,8 +456,9 @@ def test_error_behaviour(capi):
 
 
 def test_anisotropic_pixel_noise_euroc_intrinsics(capi, po):
-    """f_u != f_v (the reference's shipped EuRoC configuration, asl_msckf.cpp:77-78).  The device pre-whitens the
-    observation rows; the oracle's `whiten` mode is the same construction (1e-6 in double), and its literal
+    """f_u != f_v (the reference's shipped EuRoC configuration, asl_msckf.cpp:77-78), the device's pre-whitened route
+    (msckf_hip_set_anisotropic_noise(h, 1); the default literal route is held in tests/test_gpu_literal.py).  The device
+    pre-whitens the observation rows; the oracle's `whiten` mode is the same construction (1e-6 in double), and its literal
     restatement of the reference's A_j^T R_j A_j / Q_1^T R_o Q_1 path agrees at the level two valid
     implementations can (~1e-3 per update in dx)."""
     N, F, nf = 8, 30, 16
@@ -466,7 +467,7 @@ def test_anisotropic_pixel_noise_euroc_intrinsics(capi, po):
     tr = sc.Trajectory(2, 12, N, F, nf, cfg=cfg)
     ow = po.Oracle(po.F64, po.LEAN); ow.initialize(tr.cfg, tr.imu0); ow.setWhiten(True)
     ol = po.Oracle(po.F64, po.LEAN); ol.initialize(tr.cfg, tr.imu0)
-    bt = capi.Batch(1, N, F, N, capi.F64); bt.initialize(0, tr.cfg, tr.imu0)
+    bt = capi.Batch(1, N, F, N, capi.F64); bt.set_anisotropic_noise(1); bt.initialize(0, tr.cfg, tr.imu0)
     for k in range(nf):
         H.oracle_frame(ow, tr, k, N); H.oracle_frame(ol, tr, k, N); H.device_frame(bt, 0, tr, k, N)
         assert H.worst(_errs(bt, 0, ow)) < 1e-6, (k, _errs(bt, 0, ow))

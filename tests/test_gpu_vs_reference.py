@@ -64,6 +64,8 @@ def _teacher_forced_vs_reference(capi, po, prec, tr, N, F, nf, first, m_cap=None
         teacher.setWhiten(True)
     teacher.initialize(tr.cfg, tr.imu0)
     bt = capi.Batch(1, N, max(F, 1), m_cap or max(N, 4), cd)
+    if whiten:
+        bt.set_anisotropic_noise(1)
     bt.initialize(0, tr.cfg, tr.imu0)
     env = {i: {} for i in impls}
     compared = 0
