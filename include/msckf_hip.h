@@ -60,6 +60,10 @@ enum { MSCKF_HIP_F32 = 0, MSCKF_HIP_F64 = 1, MSCKF_HIP_F16H_F32P = 2 };
  * f_cap tracks per update, m_cap observations per track (<= 64).  replaces: MSCKF() ctor, msckf.h:69. */
 int msckf_hip_create(int B, int n_cap, int f_cap, int m_cap, int dtype, int device, msckf_hip_handle* out);
 int msckf_hip_destroy(msckf_hip_handle h);
+/* Value semantics of the reference object (MSCKF<_S> is copyable, msckf.h:31-67): dst <- the filter state of every trajectory
+ * of src (states, parameters, covariance, counters, flags, host-side track bookkeeping, mode switches).  Both handles must
+ * have been created with the same B, capacities and dtype; work buffers and a resident scenario are not copied. */
+int msckf_hip_copy_state(msckf_hip_handle dst, msckf_hip_handle src);
 const char* msckf_hip_last_error(void);
 
 /* ---- the reference's public member functions, per trajectory b ---------------------------------------- */
@@ -112,10 +116,13 @@ int msckf_hip_set_num_residualized(msckf_hip_handle h, int b, long long n);
  * filled regardless): -EOVERFLOW camera-state capacity exceeded in augmentState; -EDOM a factorization of
  * S = T_H P T_H^T + R_n (msckf.h:1369) met a non-positive pivot since the flags were last cleared -- the covariance lost
  * positive definiteness (the pivot is clamped and the run continues; the reference's explicit S.inverse() would return
- * garbage silently); -ETIMEDOUT the workgroups of an in-place prune never met at their rendezvous (bounded wait, ~0.3 s: the
- * trajectory's covariance is invalid from then on, the device is not hung). */
+ * garbage silently).  (No kernel waits for another workgroup without a fall-back: the in-place prune is one workgroup per
+ * trajectory, the gain solve's shared product is re-formed locally when a sibling does not show up.) */
 int msckf_hip_last_stats(msckf_hip_handle h, int b, int* out7);
 int msckf_hip_clear_error_flags(msckf_hip_handle h, int b);
+/* the sticky flags themselves, without turning them into a return code: bit 0 capacity overflow (-EOVERFLOW above), bit 1
+ * non-positive pivot (-EDOM above).  For callers that poll many trajectories and want the statistics either way. */
+int msckf_hip_get_error_flags(msckf_hip_handle h, int b, int* flags);
 /* per track of the last marginalize: out[t*8 + ..] = motion_ok tri_valid gate_pass included gamma p_f_G(3) */
 int msckf_hip_last_tracks(msckf_hip_handle h, int b, double* out8, int cap);
 int msckf_hip_last_deltax(msckf_hip_handle h, int b, double* dx, int cap);

@@ -12,7 +12,10 @@
 //   * one filter = one batch handle with B = 1; capacities come from MSCKFParams (override with
 //     MSCKF_SHIM_N_CAP / MSCKF_SHIM_F_CAP / MSCKF_SHIM_M_CAP);
 //   * Q_imu / initial_imu_covar are read through their diagonals (every caller passes .asDiagonal());
-//   * u_var_prime != v_var_prime (EuRoC intrinsics) is handled by row pre-whitening, see include/msckf_hip.h;
+//   * u_var_prime != v_var_prime (EuRoC intrinsics): the reference's R_o_j = A_j^T R_j A_j / R_n = Q_1^T R_o Q_1 construction
+//     runs on the device, see include/msckf_hip.h (msckf_hip_set_anisotropic_noise);
+//   * capacities: a window or a track list beyond the handle's capacity does not abort the caller (the reference has no
+//     error channel): the call is refused, lastError() returns -EOVERFLOW / -E2BIG from then on until initialize();
 //   * getCamStates()[i].tracked_feature_ids / getPrunedStates() carry the reference's payloads (time, poses, ids,
 //     last_correlated_id) -- asl_msckf.cpp:379-424 reads them;
 //   * additive: getCovariance(), lastError().
@@ -68,8 +71,9 @@ class MSCKF {
 
   MSCKF() {}
   ~MSCKF() { if (h_) msckf_hip_destroy(h_); }
-  MSCKF(const MSCKF&) = delete;
-  MSCKF& operator=(const MSCKF&) = delete;
+  // value semantics, as the reference object (msckf.h:31-67): a copy owns its own device-side filter
+  MSCKF(const MSCKF& o) { copy_from(o); }
+  MSCKF& operator=(const MSCKF& o) { if (this != &o) copy_from(o); return *this; }
 
   // msckf.h:72
   void initialize(const Camera<_S>& camera, const noiseParams<_S>& noise_params,
@@ -80,6 +84,7 @@ class MSCKF {
     // the window may grow past max_cam_states up to ~max_track_length; 63 is the build's limit
     if (n_cap <= 0) n_cap = std::min(63, std::max(msckf_params.max_cam_states, std::min(msckf_params.max_track_length, 60)) + 3);
     if (m_cap <= 0) m_cap = std::min(64, std::max(4, std::min(msckf_params.max_track_length, n_cap)));
+    n_cap_ = n_cap; m_cap_ = m_cap; sticky_ = 0;
     rc_ = msckf_hip_create(1, n_cap, MSCKF_SHIM_F_CAP, m_cap, sizeof(_S) == 4 ? MSCKF_HIP_F32 : MSCKF_HIP_F64, 0, &h_);
     if (report("create")) return;
     double cam[12] = {(double)camera.c_u, (double)camera.c_v, (double)camera.f_u, (double)camera.f_v, (double)camera.b,
@@ -190,18 +195,40 @@ class MSCKF {
     rc_ = msckf_hip_get_covariance(h_, 0, P.data(), D);
     return P;
   }
-  int lastError() const { return rc_; }
+  // 0, or the -errno code of the last failed call; a refused call (capacity: -EOVERFLOW, -E2BIG) and the device-side sticky
+  // flags (window beyond n_cap, covariance no longer positive definite: msckf_hip_last_stats) stay reported until initialize()
+  int lastError() {
+    if (sticky_) return sticky_;
+    if (h_) {
+      int flags = 0;
+      if (msckf_hip_get_error_flags(h_, 0, &flags) == 0 && flags) { int st[7]; sticky_ = msckf_hip_last_stats(h_, 0, st); }
+    }
+    return sticky_ ? sticky_ : rc_;
+  }
 
  private:
   msckf_hip_handle h_ = nullptr;
   Camera<_S> camera_;
-  int rc_ = 0;
+  int rc_ = 0, sticky_ = 0, n_cap_ = 0, m_cap_ = 0;
   std::vector<double> buf_;
   std::vector<uint64_t> ids_;
 
   bool report(const char* what) {
-    if (rc_ < 0) { std::fprintf(stderr, "[msckf_hip] %s failed (%d): %s\n", what, rc_, msckf_hip_last_error()); return true; }
+    if (rc_ < 0) {
+      std::fprintf(stderr, "[msckf_hip] %s failed (%d): %s\n", what, rc_, msckf_hip_last_error());
+      if (!sticky_) sticky_ = rc_;     // the filter is no longer what the caller thinks it is: keep saying so
+      return true;
+    }
     return false;
+  }
+  void copy_from(const MSCKF& o) {
+    if (h_) { msckf_hip_destroy(h_); h_ = nullptr; }
+    camera_ = o.camera_; rc_ = o.rc_; sticky_ = o.sticky_; n_cap_ = o.n_cap_; m_cap_ = o.m_cap_;
+    if (!o.h_) return;
+    rc_ = msckf_hip_create(1, n_cap_, MSCKF_SHIM_F_CAP, m_cap_, sizeof(_S) == 4 ? MSCKF_HIP_F32 : MSCKF_HIP_F64, 0, &h_);
+    if (report("create (copy)")) return;
+    rc_ = msckf_hip_copy_state(h_, o.h_);
+    report("copy_state");
   }
   void flatten(const Vec2List& m, const std::vector<size_t>& ids) {
     buf_.resize(2 * m.size()); ids_.resize(ids.size());

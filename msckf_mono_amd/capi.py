@@ -33,7 +33,7 @@ SYMBOLS = [
     "msckf_hip_profile_enable", "msckf_hip_profile_read", "msckf_hip_profile_event_overhead", "msckf_hip_set_streams", "msckf_hip_set_gate_early_accept",
     "msckf_hip_scenario_pin", "msckf_hip_set_upload_ring", "msckf_hip_clear_error_flags",
     "msckf_hip_set_compression", "msckf_hip_set_covariance_update", "msckf_hip_set_feature_overlap", "msckf_hip_get_pruned_states", "msckf_hip_get_cam_meta", "msckf_hip_get_tracked_feature_ids",
-    "msckf_hip_set_anisotropic_noise", "msckf_hip_literal_info",
+    "msckf_hip_set_anisotropic_noise", "msckf_hip_literal_info", "msckf_hip_get_error_flags", "msckf_hip_copy_state",
 ]
 
 
@@ -196,9 +196,28 @@ class Batch:
     def set_num_residualized(self, b, n):
         _chk(self.L.msckf_hip_set_num_residualized(self.h, b, C.c_longlong(int(n))))
 
-    def last_stats(self, b):
-        o = np.zeros(7, dtype=np.int32); _chk(self.L.msckf_hip_last_stats(self.h, b, o.ctypes.data_as(_ip)))
-        return dict(zip(["n_tracks", "n_motion_rejected", "n_tri_rejected", "n_gate_rejected", "n_passed", "m_rows", "r_rows"], o.tolist()))
+    def last_stats(self, b, strict=True):
+        """strict: a sticky device-side error flag of the trajectory raises (msckf_hip_last_stats returns its code); otherwise the
+        statistics come back either way with the flag bits under "error_flags" (a poll over many trajectories must not lose
+        the numbers because one of them once clamped a pivot)"""
+        o = np.zeros(7, dtype=np.int32)
+        rc = self.L.msckf_hip_last_stats(self.h, b, o.ctypes.data_as(_ip))
+        d = dict(zip(["n_tracks", "n_motion_rejected", "n_tri_rejected", "n_gate_rejected", "n_passed", "m_rows", "r_rows"], o.tolist()))
+        if strict:
+            _chk(rc)
+            return d
+        d["error_flags"] = self.error_flags(b)
+        if rc < 0 and not d["error_flags"]:
+            _chk(rc)
+        return d
+
+    def copy_state_from(self, other):
+        _chk(self.L.msckf_hip_copy_state(self.h, other.h))
+
+    def error_flags(self, b):
+        f = C.c_int(0)
+        _chk(self.L.msckf_hip_get_error_flags(self.h, int(b), C.byref(f)))
+        return int(f.value)
 
     def last_tracks(self, b):
         o = np.zeros((self.f_cap, 8)); n = _chk(self.L.msckf_hip_last_tracks(self.h, b, o.ctypes.data_as(_dp), self.f_cap)); return o[:n]

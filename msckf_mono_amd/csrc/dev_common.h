@@ -45,7 +45,7 @@ enum { STAT_NTRACKS = 0, STAT_MOTION_REJ, STAT_TRI_REJ, STAT_GATE_REJ, STAT_PASS
 // STAT_ERR is sticky (never cleared by an update) and a bit field: capacity overflow in augmentState; a non-positive pivot
 // in the factorization of S = T_H P T_H^T + R_n (the covariance lost positive definiteness: the square-root gain form
 // P <- P - W W^T has no PSD guarantee under rounding; the pivot is clamped so that the run continues, but it is reported)
-enum { STAT_ERR_NCAP = 1, STAT_ERR_PIVOT = 2, STAT_ERR_SYNC = 4 };   // SYNC: k_prune_inplace's rendezvous gave up (see there)
+enum { STAT_ERR_NCAP = 1, STAT_ERR_PIVOT = 2 };
 
 // work space of the literal anisotropic compression (kernels_literal.hip / literal_core.h), per trajectory; null when no
 // trajectory of the batch uses it
@@ -86,7 +86,6 @@ struct Dev {
   // when no track of the frame observes the newest camera): it then takes the window size from ncam_upd (left by the previous
   // frame's prune: ncam after prune + 1) instead of ncam, which augmentState is incrementing meanwhile
   int ncam_bias; int* ncam_upd;
-  unsigned* prune_bar;   // [B * 32] (one 128-byte line each) arrival counter of k_prune_inplace's per-trajectory barrier (only ever grows)
   int* nres_upd;   // [B] n_resid at the start of the update in flight (k_feature -> k_select_diag)
   int gate_early;   // exact early accept of the chi-square gate by the bound |r_o|^2 / sigma^2 (k_feature), off by default
   // per-track products of k_feature

@@ -499,74 +499,55 @@ __global__ __launch_bounds__(256) void k_propagate(Dev<S> d, int b0, const S* re
 }
 
 // Drop camera states in place: P <- P[keep, keep] (square_slice / column_slice of the covariance, matrix_utils.h:58-87;
-// keep[] ascending).  PRUNE_G workgroups per trajectory each own every PRUNE_G-th destination column: a workgroup loads all
-// its source elements into registers, the PRUNE_G workgroups of the trajectory meet at a counter barrier (every source has
-// been read), then each stores its destinations.  One pass over the kept part of P (read once, written once) and one launch,
-// where the earlier gather-into-a-copy + copy-back pair moved it twice through two launches.  The barrier needs the PRUNE_G
-// workgroups of a trajectory co-resident: they are consecutive in dispatch order and small (256 threads, < 2 KB of LDS), so
-// they are unless the chip is full, in which case the ones that are wait for earlier work to retire, not for each other's
-// slots.  (Progress: a launch's workgroups are dispatched in index order, so at any time at most ONE trajectory of a launch is
-// partly resident -- fewer than 16 spinning workgroups per concurrent launch against thousands of workgroup slots; every other
-// resident workgroup belongs to a complete group, finishes and frees its slot.  Unlike the gain solve's rendezvous this wait
-// has no fall-back: the data move in place.)  The counter only grows (target = next multiple of PRUNE_G above the value a workgroup drew; wrap-safe compare), so
-// it needs no reset between launches; a trajectory that drops nothing skips the barrier with all its workgroups.
+// keep[] ascending).  ONE workgroup of 1024 threads per trajectory sweeps the destination columns in ascending chunks of
+// 4 CMAX: all sources of a chunk are loaded into registers (and have returned: s_waitcnt + workgroup barrier), then stored.
+// keep[] ascending means source index >= destination index in both directions, so the columns a chunk overwrites are
+// sources only of destinations at or before that chunk -- already moved, or held in registers.  No workgroup ever waits for
+// another one: the earlier form (16 workgroups per trajectory meeting at a counter barrier before their stores) depended on
+// the co-residency of its workgroups, which HIP does not promise, and stored anyway when the bounded wait ran out.
 // The keep list is either the host's (d.keep / d.nkeep: pruneEmptyStates, pruneRedundantStates) or "drop the n_drop oldest"
-// (drop array of the resident scenario, or a constant), which every workgroup derives itself; workgroup 0 of a trajectory
-// also publishes it, compacts cam[] and, after the barrier (every workgroup has read the old window size), sets ncam.
-constexpr int PRUNE_G = 16;
+// (drop array of the resident scenario, or a constant); the workgroup also publishes it, compacts cam[] and sets ncam.
 template <class S, int RMAX, int CMAX>
-__global__ __launch_bounds__(256) void k_prune_inplace(Dev<S> d, int b0, const int* drop, int drop_const, int use_keep) {
+__global__ __launch_bounds__(1024) void k_prune_inplace(Dev<S> d, int b0, const int* drop, int drop_const, int use_keep) {
   const int b = b0 + blockIdx.y, tid = threadIdx.x;
   const int n = d.ncam[b];
   int nk, nd = 0;
   if (use_keep) nk = d.nkeep[b];
   else { nd = drop ? drop[blockIdx.y] : drop_const; nd = nd < 0 ? 0 : (nd > n ? n : nd); nk = n - nd; }
   const int* keep = d.keep + (long)b * d.n_cap;
-  if (blockIdx.x == 0) prune_bookkeeping<S>(d, b, tid, n, nk, nd, use_keep);
+  prune_bookkeeping<S>(d, b, tid, n, nk, nd, use_keep);
   if (nk >= n) return;
   const int Dn = 15 + 6 * nk, ld = d.ld;
   S* P = d.P + (long)b * ld * ld;
   __shared__ int sSrc[256 * RMAX];   // Dn <= ld <= 256 * RMAX (launch_prune picks RMAX from ld)
-  for (int i = tid; i < Dn; i += 256) sSrc[i] = i < 15 ? i : 15 + 6 * (use_keep ? keep[(i - 15) / 6] : nd + (i - 15) / 6) + (i - 15) % 6;
+  for (int i = tid; i < Dn; i += 1024) sSrc[i] = i < 15 ? i : 15 + 6 * (use_keep ? keep[(i - 15) / 6] : nd + (i - 15) / 6) + (i - 15) % 6;
   __syncthreads();
-  S v[CMAX][RMAX];
+  const int ri = tid & 255, cg = tid >> 8;   // thread = row ri (+ 256 r) of the columns j0 + cg + 4 c
+  for (int j0 = 0; j0 < Dn; j0 += 4 * CMAX) {
+    S v[CMAX][RMAX];
 #pragma unroll
-  for (int c = 0; c < CMAX; ++c) {
-    const int j = blockIdx.x + c * PRUNE_G;
-    if (j < Dn) {
-      const S* src = P + (long)sSrc[j] * ld;
+    for (int c = 0; c < CMAX; ++c) {
+      const int j = j0 + cg + 4 * c;
+      if (j < Dn) {
+        const S* src = P + (long)sSrc[j] * ld;
 #pragma unroll
-      for (int r = 0; r < RMAX; ++r) { const int i = tid + r * 256; v[c][r] = i < Dn ? src[sSrc[i]] : S(0); }
+        for (int r = 0; r < RMAX; ++r) { const int i = ri + r * 256; v[c][r] = i < Dn ? src[sSrc[i]] : S(0); }
+      }
     }
-  }
-  // every load has returned before this workgroup reports in: a later store of another workgroup must not overtake a read
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    unsigned* bar = d.prune_bar + (long)b * 32;   // a 128-byte line per trajectory: same-line atomics serialise (~25 ns each)
-    const unsigned old = atomicAdd(bar, 1u);
-    const unsigned target = (old / PRUNE_G + 1u) * PRUNE_G;
-    // bounded (~0.3 s; a rendezvous takes microseconds): a workgroup that never sees its siblings raises the sticky
-    // STAT_ERR_SYNC flag (msckf_hip_last_stats: -ETIMEDOUT) and goes on -- the trajectory's covariance is then invalid, but the
-    // device is not hung
-    bool met = false;
-    for (int spin = 0; spin < (1 << 18); ++spin) {
-      if ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { met = true; break; }
-      __builtin_amdgcn_s_sleep(2);
-    }
-    if (!met) atomicOr(&d.stats[(long)b * STAT_STRIDE + STAT_ERR], STAT_ERR_SYNC);
-  }
-  __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every load of the chunk has returned ...
+    __syncthreads();                                     // ... in every wavefront, before any of its destinations is written
 #pragma unroll
-  for (int c = 0; c < CMAX; ++c) {
-    const int j = blockIdx.x + c * PRUNE_G;
-    if (j < Dn) {
-      S* dst = P + (long)j * ld;
+    for (int c = 0; c < CMAX; ++c) {
+      const int j = j0 + cg + 4 * c;
+      if (j < Dn) {
+        S* dst = P + (long)j * ld;
 #pragma unroll
-      for (int r = 0; r < RMAX; ++r) { const int i = tid + r * 256; if (i < Dn) dst[i] = v[c][r]; }
+        for (int r = 0; r < RMAX; ++r) { const int i = ri + r * 256; if (i < Dn) dst[i] = v[c][r]; }
+      }
     }
+    // the next chunk's sources are columns beyond this chunk's destinations (source >= destination): no barrier needed here
   }
-  if (blockIdx.x == 0 && tid == 0) d.ncam[b] = nk;
+  if (tid == 0) d.ncam[b] = nk;
 }
 
 template <class S>
@@ -587,10 +568,10 @@ template <class S>
 void launch_prune(const Dev<S>& d, int b0, int nb, hipStream_t st, const int* drop, int drop_const) {
   if (nb <= 0) return;
   const int use_keep = (!drop && drop_const < 0) ? 1 : 0;
-  const dim3 grid(PRUNE_G, nb);
-  // registers hold ceil(ld / PRUNE_G) columns x ceil(ld / 256) rows per thread (ld <= 400: n_cap <= 63)
-  if (d.ld <= 256) hipLaunchKernelGGL((k_prune_inplace<S, 1, 16>), grid, dim3(256), 0, st, d, b0, drop, drop_const, use_keep);
-  else hipLaunchKernelGGL((k_prune_inplace<S, 2, 25>), grid, dim3(256), 0, st, d, b0, drop, drop_const, use_keep);
+  const dim3 grid(1, nb);
+  // a chunk holds 4 CMAX columns x ceil(ld / 256) rows per thread in registers (ld <= 400: n_cap <= 63)
+  if (d.ld <= 256) hipLaunchKernelGGL((k_prune_inplace<S, 1, 16>), grid, dim3(1024), 0, st, d, b0, drop, drop_const, use_keep);
+  else hipLaunchKernelGGL((k_prune_inplace<S, 2, 12>), grid, dim3(1024), 0, st, d, b0, drop, drop_const, use_keep);
 }
 
 template void launch_propagate<float>(const Dev<float>&, int, int, const float*, long, int, hipStream_t, bool);

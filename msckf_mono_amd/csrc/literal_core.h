@@ -370,13 +370,13 @@ LIT_FN void literal_compress(const Ctx& c, const Args<HT>& a) {
   const long ldz = a.ldz;
   double* Z = a.Z;
   const double dlt = a.u_var - a.v_var;
-  par_for(c, (long)nr * nr, [&](long e) {
+  // one wavefront per element of the lower triangle, lanes along the stacked observations (G is column-major: coalesced)
+  wave_for(c, 0, (long)nr * nr, [&](long e) {
     const int j = (int)(e / nr), i = (int)(e - (long)j * nr);
     if (i < j) return;
     const double* gi = a.G + (long)a.ldg * i; const double* gj = a.G + (long)a.ldg * j;
-    double s = 0;
-    for (int o = 0; o < mobs; ++o) s += gi[o] * gj[o];
-    Z[i + ldz * j] = dlt * s + (i == j ? a.v_var : 0.0);
+    const double s = wave_sum_range(c, 0, mobs, [&](long o) { return gi[o] * gj[o]; });
+    if (first_lane(c)) Z[i + ldz * j] = dlt * s + (i == j ? a.v_var : 0.0);
   });
   par_for(c, (long)(n + 1) * nz, [&](long e) {
     const int j = (int)(e / (n + 1)), cc = (int)(e - (long)j * (n + 1));
@@ -386,12 +386,13 @@ LIT_FN void literal_compress(const Ctx& c, const Args<HT>& a) {
   for (int k = 0; k < nr; ++k) {
     const double dk = Z[k + ldz * k];
     const double dinv = 1.0 / dk;
-    // row-parallel: thread i updates Z(i, k+1 .. i) with Z(i, k) Z(j, k) / d
-    par_for(c, nz - (k + 1), [&](long ii) {
-      const long i = k + 1 + ii;
-      const double lik = Z[i + ldz * k] * dinv;
-      if (lik == 0.0) return;
-      for (long j = k + 1; j <= i; ++j) Z[i + ldz * j] -= lik * Z[j + ldz * k];
+    // one wavefront per trailing column j, lanes along its rows i >= j: Z(i, j) -= Z(i, k) Z(j, k) / d
+    const double* zk = Z + ldz * k;
+    wave_for(c, k + 1, nz, [&](long j) {
+      const double ljk = zk[j] * dinv;
+      if (ljk == 0.0) return;
+      double* zj = Z + ldz * j;
+      lane_for(c, j, nz, [&](long i) { zj[i] -= zk[i] * ljk; });
     });
     barrier(c);
   }

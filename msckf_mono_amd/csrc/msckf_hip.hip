@@ -126,6 +126,8 @@ struct BatchBase {
   virtual int clear_stats(int b) = 0;
   virtual int clear_errors(int b) = 0;
   virtual int set_aniso(int mode, double tol) = 0;
+  virtual int error_flags(int b, int* flags) = 0;
+  virtual int copy_from(BatchBase* src) = 0;
   virtual int lit_info(int b, int* out4) = 0;
 };
 
@@ -293,7 +295,7 @@ struct Batch : BatchBase {
     }
     rc |= dalloc(&d.PHt, Bz * dn); rc |= dalloc(&d.Smat, Bz * nl); rc |= dalloc(&d.Linv, Bz * nl); rc |= dalloc(&d.W, Bz * dn);
     rc |= dalloc(&d.K, Bz * dn); rc |= dalloc(&d.A, Bz * pl); rc |= dalloc(&d.AP, Bz * pl); rc |= dalloc(&d.X, Bz * pl); rc |= dalloc(&d.dx, Bz * d.ld);
-    rc |= dalloc(&d.keep, Bz * n_cap); rc |= dalloc(&d.nkeep, Bz); rc |= dalloc(&d.ncam_upd, Bz); rc |= dalloc(&d.prune_bar, Bz * 32); rc |= dalloc(&d.nres_upd, Bz);
+    rc |= dalloc(&d.keep, Bz * n_cap); rc |= dalloc(&d.nkeep, Bz); rc |= dalloc(&d.ncam_upd, Bz); rc |= dalloc(&d.nres_upd, Bz);
     rc |= dalloc(&d_pfin, TF * 4); d.trk_pfin = d_pfin; d.mode = 0; d.joseph = 0; d.ncam_bias = 0;
     { const char* e = getenv("MSCKF_HIP_FUSED_S"); d.gain_fused_s = e ? atoi(e) : 2; }
     rc |= dalloc(&d.gain_bar, Bz * 32);   // 0: the S GEMM as a launch of its own (A/B runs)
@@ -712,10 +714,37 @@ struct Batch : BatchBase {
     HIPCHK(hipStreamSynchronize(st));
     for (int i = 0; i < 7; ++i) out[i] = tmp[i];
     if (tmp[STAT_ERR] & STAT_ERR_NCAP) return fail(-EOVERFLOW, "camera-state capacity n_cap exceeded in augmentState");
-    if (tmp[STAT_ERR] & STAT_ERR_SYNC) return fail(-ETIMEDOUT, "the workgroups of an in-place prune never met (k_prune_inplace): this trajectory's covariance is invalid");
     if (tmp[STAT_ERR] & STAT_ERR_PIVOT)
       return fail(-EDOM, "non-positive pivot in the factorization of S = T_H P T_H^T + R_n: the covariance lost positive definiteness "
                          "(msckf_hip_set_covariance_update(h, 1) selects the reference's Joseph form)");
+    return 0;
+  }
+  // value semantics of the reference object (MSCKF<_S> is copyable, msckf.h:31-67): the filter state of every trajectory
+  // -- IMU / camera states, parameters, covariance, window size, counters, flags -- and the host-side track bookkeeping;
+  // work buffers and a resident scenario are not state and are not copied
+  int copy_from(BatchBase* src) override {
+    Batch<S>* o = dynamic_cast<Batch<S>*>(src);
+    if (!o || o->B != B || o->n_cap != n_cap || o->f_cap != f_cap || o->m_cap != m_cap || o->h16 != h16)
+      return fail(-EINVAL, "copy_state: handles differ in shape or dtype");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamSynchronize(o->st));
+    const size_t Bz = B, pl = (size_t)d.ld * d.ld;
+    auto cp = [&](void* dst, const void* sp, size_t bytes) { return hipMemcpyAsync(dst, sp, bytes, hipMemcpyDeviceToDevice, st); };
+    HIPCHK(cp(d.imu, o->d.imu, Bz * IMU_STRIDE * sizeof(S))); HIPCHK(cp(d.cam, o->d.cam, Bz * n_cap * CAM_STRIDE * sizeof(S)));
+    HIPCHK(cp(d.prm, o->d.prm, Bz * PRM_STRIDE * sizeof(S))); HIPCHK(cp(d.P, o->d.P, Bz * pl * sizeof(S)));
+    HIPCHK(cp(d.ncam, o->d.ncam, Bz * sizeof(int))); HIPCHK(cp(d.n_resid, o->d.n_resid, Bz * sizeof(long long)));
+    HIPCHK(cp(d.stats, o->d.stats, Bz * STAT_STRIDE * sizeof(int))); HIPCHK(cp(d.ncam_upd, o->d.ncam_upd, Bz * sizeof(int)));
+    traj = o->traj; h_ncam = o->h_ncam; h_uv = o->h_uv;
+    compress_route = o->compress_route; d.joseph = o->d.joseph; d.gate_early = o->d.gate_early; nstreams = o->nstreams;
+    overlap_feature = o->overlap_feature; d.gain_fused_s = o->d.gain_fused_s; fuse_prune = o->fuse_prune;
+    HIPCHK(hipStreamSynchronize(st));
+    return set_aniso(o->aniso_mode, o->lit_tol);   // re-derives the per-trajectory noise parameters, allocates the literal route's work space if needed
+  }
+  int error_flags(int b, int* flags) override {
+    if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemcpyAsync(flags, d.stats + (size_t)b * STAT_STRIDE + STAT_ERR, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     return 0;
   }
   int track_info(int b, double* out, int cap) override {
@@ -1712,6 +1741,8 @@ int msckf_hip_set_covariance_update(msckf_hip_handle h, int form) { if (!h) retu
 int msckf_hip_set_compression(msckf_hip_handle h, int route) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_compression(route); }
 int msckf_hip_set_gate_early_accept(msckf_hip_handle h, int on) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_gate_early(on); }
 int msckf_hip_set_anisotropic_noise(msckf_hip_handle h, int mode, double tail_tol) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_aniso(mode, tail_tol); }
+int msckf_hip_copy_state(msckf_hip_handle dst, msckf_hip_handle src) { if (!dst || !src) return fail(-EINVAL, "null handle"); return H(dst)->copy_from(H(src)); }
+int msckf_hip_get_error_flags(msckf_hip_handle h, int b, int* flags) { if (!h || !flags) return fail(-EINVAL, "null argument"); return H(h)->error_flags(b, flags); }
 int msckf_hip_literal_info(msckf_hip_handle h, int b, int* out4) { if (!h || !out4) return fail(-EINVAL, "null argument"); return H(h)->lit_info(b, out4); }
 
 }  // extern "C"

@@ -1,6 +1,9 @@
-// tests/cpp/shim_demo.cpp -- compiles the drop-in shim (include/msckf_mono/msckf.h) WITHOUT Eigen and drives it
-// with the call sequence of datasets/asl_msckf.cpp:227-294 on a tiny hand-made scene; prints the state so the
-// pytest wrapper can compare it with the oracle fed the same numbers (read from stdin).
+// tests/cpp/shim_demo.cpp -- compiles the drop-in shim (include/msckf_mono/msckf.h) and drives it with the call
+// sequence of datasets/asl_msckf.cpp:227-294 on a small scene; prints the state so the pytest wrapper can compare it
+// with the oracle fed the same numbers (read from stdin).  Two builds: WITHOUT Eigen (pod_types.h stand-ins, compiled by
+// the test itself) and the branch a maintainer builds -- <Eigen/Dense> + the reference's own <msckf_mono/types.h>, against
+// oracle/ref_shim's Eigen surface (tests/cpp/Makefile, built where /root/reference exists, the binary travels).  A copy of
+// the filter taken mid-run (MSCKF is copyable, msckf.h:31-67) finishes the run as well and must print the same state.
 //   input : cam12 noise29 params8 imu29, then frames: "F K" K*7 readings, n_cur (x y id)*, n_new (x y id)*
 #include <cstdio>
 #include <iostream>
@@ -23,8 +26,14 @@ int main() {
   for (int i = 0; i < 3; ++i) camera.p_C_I(i) = cam[9 + i];
   noiseParams<S> np;
   np.u_var_prime = noise[0]; np.v_var_prime = noise[1];
+#ifdef MSCKF_SHIM_EIGEN   // the reference's own noiseParams (types.h:86-92): dense matrices, diagonal in every caller
+  np.Q_imu.setZero(); np.initial_imu_covar.setZero();
+  for (int i = 0; i < 12; ++i) np.Q_imu(i, i) = noise[2 + i];
+  for (int i = 0; i < 15; ++i) np.initial_imu_covar(i, i) = noise[14 + i];
+#else
   for (int i = 0; i < 12; ++i) np.Q_imu_diag[i] = noise[2 + i];
   for (int i = 0; i < 15; ++i) np.initial_imu_covar_diag[i] = noise[14 + i];
+#endif
   MSCKFParams<S> mp;
   mp.max_gn_cost_norm = prm[0]; mp.min_rcond = prm[1]; mp.translation_threshold = prm[2];
   mp.redundancy_angle_thresh = prm[3]; mp.redundancy_distance_thresh = prm[4];
@@ -39,7 +48,10 @@ int main() {
   int nframes;
   std::cin >> nframes;
   int state_k = 0;
+  MSCKF<S> twin;                                   // assigned from msckf half-way, then fed the same calls
+  bool have_twin = false;
   for (int f = 0; f < nframes; ++f) {
+    if (f == nframes / 2) { twin = msckf; have_twin = true; if (twin.lastError()) return 4; }
     int K; std::cin >> K;
     for (int k = 0; k < K; ++k) {
       imuReading<S> rd;
@@ -48,6 +60,7 @@ int main() {
       std::cin >> rd.dT;
       state_k++;                                   // asl_msckf.cpp:227
       msckf.propagate(rd);                         // :233
+      if (have_twin) twin.propagate(rd);
     }
     MSCKF<S>::Vec2List cur, fresh; std::vector<size_t> cur_ids, new_ids;
     int n; std::cin >> n;
@@ -60,6 +73,18 @@ int main() {
     msckf.marginalize();                           // :284
     msckf.pruneEmptyStates();                      // :294
     if (msckf.lastError()) return 3;
+    if (have_twin) {
+      twin.augmentState(state_k, (S)f); twin.update(cur, cur_ids); twin.addFeatures(fresh, new_ids); twin.marginalize(); twin.pruneEmptyStates();
+      if (twin.lastError()) return 5;
+    }
+  }
+  {   // the copy ran the second half on its own device-side filter: same state, bit for bit
+    imuState<S> a = msckf.getImuState(), b = twin.getImuState();
+    bool same = a.q_IG.w() == b.q_IG.w() && a.q_IG.x() == b.q_IG.x() && msckf.getNumCamStates() == twin.getNumCamStates();
+    for (int i = 0; i < 3; ++i) same = same && a.p_I_G(i) == b.p_I_G(i) && a.v_I_G(i) == b.v_I_G(i) && a.b_g(i) == b.b_g(i);
+    std::vector<double> Pa = msckf.getCovariance(), Pb = twin.getCovariance();
+    same = same && Pa == Pb;
+    if (!same) { std::fprintf(stderr, "copy of the filter diverged from the original\n"); return 6; }
   }
   imuState<S> out = msckf.getImuState();
   std::printf("%.17g %.17g %.17g %.17g ", out.q_IG.w(), out.q_IG.x(), out.q_IG.y(), out.q_IG.z());

@@ -32,22 +32,17 @@ def test_shim_eigen_branch_compiles_against_the_reference_types():
     assert out.returncode == 0, out.stderr
 
 
-@pytest.mark.gpu
-def test_shim_runs_like_the_asl_runner(tmp_path, oracle_lib):
-    po = oracle_lib
+def _run_shim_demo(exe, po, N=6, F=8, nf=12, traj=21, isotropic=True):
+    """feed the executable the call sequence of asl_msckf.cpp:227-294 and hold what it prints against the oracle"""
     from msckf_mono_amd import capi
-    exe = str(tmp_path / "shim_demo")
-    libdir = os.path.dirname(capi.LIB_PATH)
-    cmd = ["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), SRC, "-o", exe, "-L" + libdir, "-lmsckf_hip",
-           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
-    out = subprocess.run(cmd, capture_output=True, text=True)
-    assert out.returncode == 0, out.stderr
-    N, F, nf = 6, 8, 12
-    tr = sc.Trajectory(2, 21, N, F, nf)
+    cfg = sc.filter_config(N, isotropic=isotropic)
+    tr = sc.Trajectory(2, traj, N, F, nf, cfg=cfg)
     st = tr.stream()
     cam, noise, prm = capi.pack_config(tr.cfg)
     lines = [" ".join(repr(float(x)) for x in np.concatenate([cam, noise, prm, tr.imu0])), str(nf)]
     o = po.Oracle(po.F64, po.LEAN)
+    if not isotropic:
+        o.setTinyRowTol(1e-10)
     o.initialize(tr.cfg, tr.imu0)
     sid = 0
     for k in range(nf):
@@ -61,7 +56,7 @@ def test_shim_runs_like_the_asl_runner(tmp_path, oracle_lib):
         o.update(st[k]["cur"][0], st[k]["cur"][1]); o.addFeatures(st[k]["new"][0], st[k]["new"][1])
         o.marginalize(); o.pruneEmptyStates()
     run = subprocess.run([exe], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=600)
-    assert run.returncode == 0, run.stderr
+    assert run.returncode == 0, (run.returncode, run.stderr)
     rows = run.stdout.strip().splitlines()
     imu = np.array([float(x) for x in rows[0].split()])
     ncam, nmap = [int(x) for x in rows[1].split()]
@@ -83,3 +78,31 @@ def test_shim_runs_like_the_asl_runner(tmp_path, oracle_lib):
     got = np.array([float(x) for x in ps[1:]]).reshape(-1, 9)
     assert np.array_equal(got[:, 0], ref[:, 8]) and np.array_equal(got[:, 1], ref[:, 7])
     assert np.allclose(got[:, 2:9], ref[:, 0:7], atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_shim_runs_like_the_asl_runner(tmp_path, oracle_lib):
+    """Eigen-free build of the shim, compiled here, linked against libmsckf_hip.so: the reference's call order, by-value
+    getters, and a copy of the filter taken mid-run (value semantics, msckf.h:31-67) that must end bit-identical."""
+    from msckf_mono_amd import capi
+    exe = str(tmp_path / "shim_demo")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    cmd = ["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), SRC, "-o", exe, "-L" + libdir, "-lmsckf_hip",
+           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    _run_shim_demo(exe, oracle_lib)
+    _run_shim_demo(exe, oracle_lib, N=8, F=16, nf=14, traj=22, isotropic=False)      # EuRoC intrinsics: the literal anisotropic route behind the shim
+
+
+@pytest.mark.gpu
+def test_shim_eigen_branch_runs(oracle_lib):
+    """The branch a maintainer builds -- <Eigen/Dense> and the reference's own <msckf_mono/types.h> (here over
+    oracle/ref_shim's Eigen surface: Eigen is not installed) -- as an executable: built by tests/cpp/Makefile where
+    /root/reference exists (__graft_entry__.build()), it travels to the GPU box like oracle/_ref/; same run, same
+    assertions as the Eigen-free build."""
+    exe = os.path.join(ROOT, "tests", "cpp", "_built", "shim_demo_eigen")
+    if not os.path.exists(exe):
+        pytest.skip("tests/cpp/_built/shim_demo_eigen not built (needs /root/reference at build time)")
+    _run_shim_demo(exe, oracle_lib)
+    _run_shim_demo(exe, oracle_lib, N=8, F=16, nf=14, traj=22, isotropic=False)

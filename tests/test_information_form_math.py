@@ -194,7 +194,7 @@ def test_shared_s_product_ownership_partitions_the_blocks():
 
 
 def test_counter_barrier_target_is_wrap_safe():
-    """k_prune_inplace (16 workgroups per trajectory) / the gain solve's rendezvous (4 parts, or 3 with part 0 counting twice): a
+    """the gain solve's rendezvous (4 parts, or 3 with part 0 counting twice; the group of 16 is kept as a generic case): a
     workgroup draws `old` from a counter that only grows and waits until the counter has reached the next multiple of the
     group size GP above it, compared as (int)(counter - target) >= 0.  GP is a power of two, so launch after launch the
     workgroups of a trajectory release together -- also across the 2^32 wrap."""
