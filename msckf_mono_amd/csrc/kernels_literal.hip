@@ -3,11 +3,13 @@
 // (rows 0..14 of H_o verbatim), R_n = Q_1^T R_o Q_1 (msckf.h:423-431, 1343-1366) -- see literal_core.h, which holds the
 // algorithm (shared with the host build that tests/test_literal_core.py checks against the oracle on the CPU).
 //
-// One workgroup of 1024 threads per trajectory, f64, the stack [H_o | r_o] dense in global memory: this is the parity route
-// of the shipped EuRoC configuration, not the throughput route (isotropic noise takes the information form of
-// kernels_gram.hip, which never builds the stack).  Its output is the information matrix Lam^ = [T_H | r_n]^T R_n^-1
-// [T_H | r_n] in the place where k_gram leaves H_o^T H_o, so that the blocked Cholesky and the Kalman stage run unchanged
-// with sigma^2 = 1.
+// One workgroup of 1024 threads per trajectory, f64.  Two routes (literal_core.h): where the stack has the usual shape --
+// every later Householder step reflects until the gauge columns -- the compression follows from the Cholesky factor of
+// H_o^T H_o (k_gram's f64 Gram matrix) minus the rows handed through, plus row solves for the u-rows of A Q_1: no m x n
+// stack is built; otherwise (few rows, a dependent column in the middle of the sweep: the shape is checked on the
+// factorization) the reference's sequence runs to the letter on the dense stack in global memory.  The output is the
+// information matrix Lam^ = [T_H | r_n]^T R_n^-1 [T_H | r_n] in the place where k_gram leaves H_o^T H_o, so that the blocked
+// Cholesky and the Kalman stage run unchanged with sigma^2 = 1.
 #include "dev_common.h"
 #include "literal_core.h"
 
@@ -40,14 +42,17 @@ __global__ __launch_bounds__(1024) void k_literal(Dev<S> d, int b0, int nb) {
   a.ldx = L.ldx; a.X = L.X + (long)b * L.ldx * n1;
   a.tau = L.tau + (long)b * n1;
   a.Vf = L.Vf + (long)b * d.f_cap * 2 * d.m_cap * 3; a.Tf = L.Tf + (long)b * d.f_cap * 9;
-  a.row0 = L.row0 + (long)b * (d.f_cap + 1); a.obs0 = L.obs0 + (long)b * (d.f_cap + 1);
+  a.row0 = L.row0 + (long)b * (d.f_cap + 1); a.obs0 = L.obs0 + (long)b * (d.f_cap + 1); a.otrk = L.otrk + (long)b * L.ldg;
   a.kept = L.kept + (long)b * L.kept_stride;
   a.r_cap = L.r_cap; a.TH = L.TH + (long)b * L.r_cap * n1;
   a.ldg = L.ldg; a.G = L.G + (long)b * L.ldg * L.r_cap;
   a.ldz = L.ldz; a.Z = L.Z + (long)b * L.ldz * L.ldz;
   a.Lam = d.Lam + (long)b * d.ldR * d.ldR; a.ldL = d.ldR;
-  a.info = L.info + (long)b * 4;
-  lit::literal_compress(c, a);
+  a.info = L.info + (long)b * 6;
+  a.LamIn = a.Lam; a.lam_part = d.lam_part; a.gram_parts = (d.compress == 3 && d.ldR <= 192 && d.lam_part > 0) ? (d.gram_parts >= 3 ? d.gram_parts : 3) : 1;
+  a.inv = d.trk_inv + (long)b * d.f_cap * d.n_cap; a.inv_stride = d.n_cap;
+  a.W = L.W + (long)b * L.w_stride;
+  lit::literal_compress(c, a, L.route);
   // the blocked Cholesky adds the split-K copies of Lam^ that k_gram leaves (Dev::lam_part apart): none here
   if (d.lam_part) {
     const int n = 6 * a.N;

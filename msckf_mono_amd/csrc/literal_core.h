@@ -109,16 +109,22 @@ struct Args {
   double* Tf;               // [F][9] compact-WY T of those
   int* row0;                // [F + 1] first stacked row of track t (list order), row0[F] = m
   int* obs0;                // [F + 1] first observation index of track t among the stacked tracks
-  int* kept;                // [n + 16] kept rows of R (msckf.h:1347)
+  int* otrk;                // [ldg] track of stacked observation g
+  int* kept;                // [6 (n + 16) + 64] kept rows of R (msckf.h:1347) + flag / index scratch behind them
   int r_cap;                // >= n + 15 (row capacity of TH / G / Z)
   double* TH;               // [r_cap x (n + 1)] column-major: kept rows of [R | Q^T r_o]
   int ldg;                  // row capacity of G (>= stacked observations)
   double* G;                // [ldg x r_cap] column-major: u-rows of A Q_1   (R_n = v' I + (u' - v') G^T G)
   int ldz;                  // r_cap + n + 1
   double* Z;                // [ldz x ldz] column-major lower triangle: [[R_n, .], [TH^T, 0]] -> Schur complement -Lam^
+  // ---- fast path only (literal_compress_fast): H_o^T H_o as k_gram left it, the slot -> observation map, scratch
+  const double* LamIn;      // [H_o | r_o]^T [H_o | r_o], element (hi, lo), lo <= hi <= n, at LamIn[hi * ldL + lo] (+ split-K copies)
+  long lam_part; int gram_parts;   // copies of LamIn lam_part doubles apart: block column lo / 64 came in min(lo / 64 + parts - 2, parts) partial sums
+  const signed char* inv; int inv_stride;   // observation index of camera slot s in track t at inv[t * inv_stride + s], -1 = not observed
+  double* W;                // scratch: (n + 1)^2 + ZCAP (n + 1) + ZCAP 2 m_cap doubles
   // ---- outputs
   double* Lam; int ldL;     // Lam^(hi, lo), lo <= hi <= n, at Lam[hi * ldL + lo]  (what k_chol_mfma / lam_hat read)
-  int* info;                // [4]: stacked rows m, kept rows r, reflected steps, steps skipped by the tolerance
+  int* info;                // [6]: stacked rows m, kept rows r, reflected steps, steps skipped by the tolerance, route (1 fast, 2 general), rows handed through verbatim
 };
 
 template <class HT> LIT_FN int first_obs(const Args<HT>& a, int t) { return a.off ? a.off[t] : t * a.m_cap; }
@@ -177,11 +183,54 @@ LIT_FN void track_null_space(const Args<HT>& a, int t) {
   T[5] = -tau[2] * T[4] * d12;                       // T(1,2)
 }
 
-// the whole compression for one trajectory; every thread of the workgroup calls it with the same arguments
+// Tail of both routes: R_n = v' I + (u' - v') G^T G (msckf.h:1366), then Z = [[R_n, .], [[T_H | r_n]^T, 0]] (lower triangle);
+// eliminating the nr pivots of R_n leaves -[T_H | r_n]^T R_n^-1 [T_H | r_n] in the trailing block = -Lam^.
 template <class HT>
-LIT_FN void literal_compress(const Ctx& c, const Args<HT>& a) {
-  const int n = 6 * a.N, D = 15 + n, F = a.F;
-  // ---- stacked row / observation offsets in list order (msckf.h:404-441)
+LIT_FN void information_from_compressed(const Ctx& c, const Args<HT>& a, int n, int nr, int mobs) {
+  const int rc = a.r_cap;
+  const int nz = nr + n + 1;
+  const long ldz = a.ldz;
+  double* Z = a.Z;
+  const double dlt = a.u_var - a.v_var;
+  // one wavefront per element of the lower triangle, lanes along the stacked observations (G is column-major: coalesced)
+  wave_for(c, 0, (long)nr * nr, [&](long e) {
+    const int j = (int)(e / nr), i = (int)(e - (long)j * nr);
+    if (i < j) return;
+    const double* gi = a.G + (long)a.ldg * i; const double* gj = a.G + (long)a.ldg * j;
+    const double s = wave_sum_range(c, 0, mobs, [&](long o) { return gi[o] * gj[o]; });
+    if (first_lane(c)) Z[i + ldz * j] = dlt * s + (i == j ? a.v_var : 0.0);
+  });
+  par_for(c, (long)(n + 1) * nz, [&](long e) {
+    const int j = (int)(e / (n + 1)), cc = (int)(e - (long)j * (n + 1));
+    Z[(nr + cc) + ldz * j] = j < nr ? a.TH[j + (long)rc * cc] : 0.0;
+  });
+  barrier(c);
+  for (int k = 0; k < nr; ++k) {
+    const double dk = Z[k + ldz * k];
+    const double dinv = 1.0 / dk;
+    // one wavefront per trailing column j, lanes along its rows i >= j: Z(i, j) -= Z(i, k) Z(j, k) / d
+    const double* zk = Z + ldz * k;
+    wave_for(c, k + 1, nz, [&](long j) {
+      const double ljk = zk[j] * dinv;
+      if (ljk == 0.0) return;
+      double* zj = Z + ldz * j;
+      lane_for(c, j, nz, [&](long i) { zj[i] -= zk[i] * ljk; });
+    });
+    barrier(c);
+  }
+  // ---- Lam^ (lower triangle incl. row n) where the blocked Cholesky reads it
+  par_for(c, (long)(n + 1) * (n + 1), [&](long e) {
+    const int hi = (int)(e / (n + 1)), lo = (int)(e - (long)hi * (n + 1));
+    if (lo > hi) return;
+    a.Lam[(long)hi * a.ldL + lo] = -Z[(nr + hi) + ldz * (nr + lo)];
+  });
+  barrier(c);
+}
+
+// Stacked row / observation offsets in list order (msckf.h:404-441) and A_j per track.  Returns the stacked rows m.
+template <class HT>
+LIT_FN int prepare(const Ctx& c, const Args<HT>& a) {
+  const int F = a.F;
   if (first_thread(c)) {
     int r = 0, o = 0;
     for (int t = 0; t < F; ++t) {
@@ -189,16 +238,26 @@ LIT_FN void literal_compress(const Ctx& c, const Args<HT>& a) {
       if (a.status[t] & a.inc_bit) { r += 2 * a.M[t] - 3; o += a.M[t]; }
     }
     a.row0[F] = r; a.obs0[F] = o;
-    a.info[0] = r;
+    a.info[0] = r; a.info[1] = 0; a.info[2] = 0; a.info[3] = 0; a.info[4] = 0; a.info[5] = 0;
   }
   barrier(c);
-  const int m = a.row0[F], mobs = a.obs0[F];
+  if (a.row0[F] <= 0) return 0;
+  // A_j: null space of H_f_j^T per track (msckf.h:954-955); observation -> track map
+  par_for(c, F, [&](long t) {
+    if (!(a.status[t] & a.inc_bit)) return;
+    track_null_space(a, (int)t);
+    for (int o = 0; o < a.M[t]; ++o) a.otrk[a.obs0[t] + o] = (int)t;
+  });
+  barrier(c);
+  return a.row0[F];
+}
+
+// The general route: the reference's sequence to the letter on the dense stack (any shape of stack).
+template <class HT>
+LIT_FN void literal_general(const Ctx& c, const Args<HT>& a, const int m, const int mobs) {
+  const int n = 6 * a.N, D = 15 + n, F = a.F;
   const long ldx = a.ldx;
   double* X = a.X;
-  if (m <= 0) { if (first_thread(c)) { a.info[1] = 0; a.info[2] = 0; a.info[3] = 0; } return; }
-
-  // ---- A_j: null space of H_f_j^T per track (msckf.h:954-955)
-  par_for(c, F, [&](long t) { if (a.status[t] & a.inc_bit) track_null_space(a, (int)t); });
   par_for(c, (long)m * (n + 1), [&](long e) { const long j = e / m, i = e - j * m; X[i + ldx * j] = 0.0; });
   barrier(c);
 
@@ -301,7 +360,7 @@ LIT_FN void literal_compress(const Ctx& c, const Args<HT>& a) {
   if (first_thread(c)) {
     int nr = 0;
     for (int i = 0; i < steps_total; ++i) if (flag[i]) a.kept[nr++] = i;
-    a.info[1] = nr; a.info[2] = n_reflect; a.info[3] = n_skip_tol;
+    a.info[1] = nr; a.info[2] = n_reflect; a.info[3] = n_skip_tol; a.info[4] = 2; a.info[5] = steps_total - msteps;
   }
   barrier(c);
   const int nr = a.info[1];
@@ -363,46 +422,258 @@ LIT_FN void literal_compress(const Ctx& c, const Args<HT>& a) {
     }
   });
   barrier(c);
+  information_from_compressed(c, a, n, nr, mobs);
+}
 
-  // ---- Z = [[R_n, .], [[T_H | r_n]^T, 0]] (lower triangle); eliminating the nr pivots of R_n leaves
-  // -[T_H | r_n]^T R_n^-1 [T_H | r_n] in the trailing block
-  const int nz = nr + n + 1;
-  const long ldz = a.ldz;
-  double* Z = a.Z;
-  const double dlt = a.u_var - a.v_var;
-  // one wavefront per element of the lower triangle, lanes along the stacked observations (G is column-major: coalesced)
-  wave_for(c, 0, (long)nr * nr, [&](long e) {
-    const int j = (int)(e / nr), i = (int)(e - (long)j * nr);
-    if (i < j) return;
-    const double* gi = a.G + (long)a.ldg * i; const double* gj = a.G + (long)a.ldg * j;
-    const double s = wave_sum_range(c, 0, mobs, [&](long o) { return gi[o] * gj[o]; });
-    if (first_lane(c)) Z[i + ldz * j] = dlt * s + (i == j ? a.v_var : 0.0);
-  });
-  par_for(c, (long)(n + 1) * nz, [&](long e) {
-    const int j = (int)(e / (n + 1)), cc = (int)(e - (long)j * (n + 1));
-    Z[(nr + cc) + ldz * j] = j < nr ? a.TH[j + (long)rc * cc] : 0.0;
+// ---------------------------------------------------------------------------------------------------------------------
+// The fast route, for the usual shape of a stack: many more rows than columns, every camera of the window (but for leading
+// ones nobody saw) observed, rank deficiency only in the window's gauge directions.  Then HouseholderQR(H_o) does nothing
+// special after handing through the first z = 15 + 6 c0 rows (c0 = leading cameras without an observation): every later
+// step reflects until the columns that depend on the previous ones are reached, and those are the last ones, whose steps
+// find nothing but zeros below (rows dropped).  So Q_1 = [e_0 .. e_(z-1) | Q'] with Q' ANY orthonormal basis of the column
+// space of H' = H_o(z:, :), and the update depends on Q_1 only through its span (T_H, r_n, R_n transform together under a
+// rotation of the kept rows).  With H' = Q' R':
+//     R'      = chol(H'^T H'),  H'^T H' = H_o^T H_o - H_o(:z)^T H_o(:z);  H_o^T H_o is what k_gram accumulates in f64
+//               (sum_j [H_x | r]^T (I - Q_f Q_f^T) [H_x | r]: independent of the null-space basis)
+//     Q'^T r' = R'^-T H'^T r'                         (the augmented column of the same factorization)
+//     u-rows of A Q_1 = [ u-rows of A(:, :z) | (u-rows of A_b A_b^T H_x) R'^-1 ],  A_b = the columns of A below row z:
+//               A_b A_b^T = I - Q_f(:, :d) Q_f(:, :d)^T per track, d = 3 + (rows of the track among the first z)
+// -- no m x n stack, no reflector sweep: O(n^3 + (sum M) n^2) instead of O(m n^2) passes over 8 MB per trajectory.
+// Whether the stack has that shape is checked on the factorization itself (a column found dependent -- pivot below
+// tol^2 |column|^2, the Householder tail rule in Gram form -- followed by an independent one, or a pivot too close to the
+// threshold to call, or m <= z, or z > LIT_ZCAP): if not, the caller runs literal_general.  Returns whether it applied.
+constexpr int LIT_ZCAP = 63;
+
+template <class HT>
+LIT_FN double lam_in(const Args<HT>& a, int hi, int lo) {   // hi >= lo
+  const double* p = a.LamIn + (long)hi * a.ldL + lo;
+  double v = p[0];
+  if (a.lam_part && a.gram_parts >= 3) {
+    const int nc0 = lo / 64 + a.gram_parts - 2, nc = nc0 < a.gram_parts ? nc0 : a.gram_parts;
+    for (int cpy = 1; cpy < nc; ++cpy) v += p[cpy * a.lam_part];
+  }
+  return v;
+}
+
+template <class HT>
+LIT_FN bool literal_fast(const Ctx& c, const Args<HT>& a, const int m, const int mobs) {
+  const int n = 6 * a.N, F = a.F, n1 = n + 1;
+  double* C = a.W;                              // (n + 1)^2 column-major, lower triangle: Lam' -> L = R'^T (row n: Q'^T r')
+  double* Xt = C + (long)n1 * n1;               // [LIT_ZCAP][n + 1] row-major: rows 0..z-1 of [H_o | r_o]
+  double* At = Xt + (long)LIT_ZCAP * n1;        // [LIT_ZCAP][2 m_cap]: column i - row0 of A_j, for the z top rows
+  double* dcol = a.tau;                         // [n] |column|^2 of H_o (incl. the top rows)
+  const int ks = n + 16;
+  int* flag = a.kept + ks;                      // [ks] kept flags of top rows
+  int* skip = a.kept + 2 * ks;                  // [ks] column found dependent
+  int* kidx = a.kept + 3 * ks;                  // [ks] ordinal of a column among the independent ones, -1
+  int* topt = a.kept + 4 * ks;                  // [LIT_ZCAP + 1] track of top row i
+  int* shared = a.kept + 5 * ks;                // z, ok, r', skipped-active count
+  // ---- z and the tracks of the top rows
+  if (first_thread(c)) {
+    unsigned long long seen = 0;
+    for (int t = 0; t < F; ++t)
+      if (a.status[t] & a.inc_bit) for (int o = 0; o < a.M[t]; ++o) seen |= 1ull << (a.slots[first_obs(a, t) + o] & 63);
+    int c0 = 0;
+    while (c0 < a.N && !((seen >> c0) & 1ull)) ++c0;
+    const int z = 15 + 6 * c0;
+    int ok = (z <= LIT_ZCAP && m > z && a.LamIn != nullptr) ? 1 : 0;
+    if (ok) {
+      int t = 0;
+      for (int i = 0; i < z; ++i) {
+        while (!(a.status[t] & a.inc_bit) || a.row0[t] + 2 * a.M[t] - 3 <= i) ++t;
+        topt[i] = t;
+      }
+    }
+    shared[0] = z; shared[1] = ok;
+  }
+  barrier(c);
+  const int z = shared[0];
+  if (!shared[1]) return false;
+  // ---- a_i = A_j e_(i - row0) = Q_f e_(3 + i - row0), the top rows of [H_o | r_o] (msckf.h:957, :430)
+  par_for(c, (long)z * n1, [&](long e) { Xt[e] = 0.0; });
+  barrier(c);
+  par_for(c, z, [&](long i) {
+    const int t = topt[i], M = a.M[t], R2 = 2 * M, q = 3 + (int)i - a.row0[t];
+    const double* V = a.Vf + (long)t * 2 * a.m_cap * 3;
+    const double* T = a.Tf + (long)t * 9;
+    double* ai = At + i * 2 * a.m_cap;
+    double sv[3], w[3];
+    for (int p = 0; p < 3; ++p) sv[p] = vf_at(V, q, p);
+    for (int p = 0; p < 3; ++p) { double x = 0; for (int qq = p; qq < 3; ++qq) x += T[p * 3 + qq] * sv[qq]; w[p] = x; }   // T V(q, :)^T
+    for (int r = 0; r < R2; ++r) ai[r] = (r == q ? 1.0 : 0.0) - (vf_at(V, r, 0) * w[0] + vf_at(V, r, 1) * w[1] + vf_at(V, r, 2) * w[2]);
+    const HT* hx = a.Hx + (long)t * a.m_cap * 12;
+    const HT* rr = a.rw + (long)t * 2 * a.m_cap;
+    double* xr = Xt + i * n1;
+    double sr = 0;
+    for (int o = 0; o < M; ++o) {
+      const int col = 6 * a.slots[first_obs(a, t) + o];
+      for (int kk = 0; kk < 6; ++kk) xr[col + kk] = ai[2 * o] * (double)hx[o * 12 + kk] + ai[2 * o + 1] * (double)hx[o * 12 + 6 + kk];
+      sr += ai[2 * o] * (double)rr[2 * o] + ai[2 * o + 1] * (double)rr[2 * o + 1];
+    }
+    xr[n] = sr;
   });
   barrier(c);
-  for (int k = 0; k < nr; ++k) {
-    const double dk = Z[k + ldz * k];
-    const double dinv = 1.0 / dk;
-    // one wavefront per trailing column j, lanes along its rows i >= j: Z(i, j) -= Z(i, k) Z(j, k) / d
-    const double* zk = Z + ldz * k;
-    wave_for(c, k + 1, nz, [&](long j) {
-      const double ljk = zk[j] * dinv;
+  // ---- Lam' = H_o^T H_o - (top rows)^T (top rows), lower triangle incl. row n
+  par_for(c, (long)n1 * n1, [&](long e) {
+    const int lo = (int)(e / n1), hi = (int)(e - (long)lo * n1);
+    if (hi < lo) return;
+    const double full = (hi == n && lo == n) ? 0.0 : lam_in(a, hi, lo);
+    double s = 0;
+    for (int i = 0; i < z; ++i) s += Xt[i * n1 + hi] * Xt[i * n1 + lo];
+    C[hi + (long)n1 * lo] = full - s;
+    if (hi == lo && hi < n) dcol[hi] = full;
+  });
+  barrier(c);
+  // ---- Cholesky with the zero-tail rule in Gram form: the pivot of column k IS |tail|^2 of Householder step 15 + k
+  // The Gram matrix cannot see a tail below ~1e-5 |column| (measured: the pivots of the gauge columns come out at up to
+  // 3e-11 |column|^2 at a 30-camera window, the smallest independent pivot at 1e-3): threshold 1e-7, and anything within a
+  // factor 16 of it is left to the general route's tail test
+  const double t2a = a.tol * a.tol, t2 = t2a > 1e-7 ? t2a : 1e-7;
+  int ok = 1;
+  for (int k = 0; k < n; ++k) {
+    double* ck = C + (long)n1 * k;
+    const double piv = ck[k], dk = dcol[k];
+    const bool indep = dk > 0.0 && piv > t2 * dk;
+    if (dk > 0.0 && piv > t2 * dk * (1.0 / 16) && piv < t2 * dk * 16) ok = 0;     // too close to the threshold to call
+    barrier(c);
+    if (!indep) {
+      if (first_thread(c)) skip[k] = 1;
+      par_for(c, n1 - k, [&](long i) { ck[k + i] = 0.0; });
+      barrier(c);
+      continue;
+    }
+    const double dinv = 1.0 / sqrt(piv);
+    if (first_thread(c)) skip[k] = 0;
+    par_for(c, n1 - k, [&](long i) { ck[k + i] *= dinv; });       // column k of L (the diagonal becomes sqrt(piv))
+    barrier(c);
+    wave_for(c, k + 1, n, [&](long j) {
+      const double ljk = ck[j];
       if (ljk == 0.0) return;
-      double* zj = Z + ldz * j;
-      lane_for(c, j, nz, [&](long i) { zj[i] -= zk[i] * ljk; });
+      double* cj = C + (long)n1 * j;
+      lane_for(c, j, n1, [&](long i) { cj[i] -= ck[i] * ljk; });
     });
     barrier(c);
   }
-  // ---- Lam^ (lower triangle incl. row n) where the blocked Cholesky reads it
-  par_for(c, (long)(n + 1) * (n + 1), [&](long e) {
-    const int hi = (int)(e / (n + 1)), lo = (int)(e - (long)hi * (n + 1));
-    if (lo > hi) return;
-    a.Lam[(long)hi * a.ldL + lo] = -Z[(nr + hi) + ldz * (nr + lo)];
+  // ---- shape of the stack: the dependent columns must be the last of the observed ones
+  if (first_thread(c)) {
+    int rp = 0, nsk = 0, seen_skip = 0;
+    for (int k = 0; k < n; ++k) {
+      if (dcol[k] > 0.0) {
+        if (skip[k]) { seen_skip = 1; ++nsk; }
+        else if (seen_skip) ok = 0;
+      }
+      kidx[k] = skip[k] ? -1 : rp;
+      if (!skip[k]) ++rp;
+    }
+    shared[1] = ok; shared[2] = rp; shared[3] = nsk;
+  }
+  barrier(c);
+  if (!shared[1]) return false;
+  const int rp = shared[2];
+  // ---- rows that are kept (msckf.h:1345-1348) and [T_H | r_n]
+  double rmax = 0;
+  if (a.tol > 0) {
+    const double r1 = wg_max(c, 0, (long)z * n, [&](long e) { const long i = e / n, j = e - i * n; return (j + 15 >= i) ? fabs(Xt[i * n1 + j]) : 0.0; });
+    const double r2 = wg_max(c, 0, (long)n * n, [&](long e) { const long k = e / n, j = e - k * n; return (j >= k && !skip[k]) ? fabs(C[j + (long)n1 * k]) : 0.0; });
+    rmax = r1 > r2 ? r1 : r2;
+  }
+  barrier(c);
+  par_for(c, z, [&](long i) {
+    int any = 0;
+    const int c_lo = i >= 15 ? (int)i - 15 : 0;
+    for (int j = c_lo; j < n && !any; ++j) { const double v = fabs(Xt[i * n1 + j]); any = a.tol > 0 ? (v > a.tol * rmax) : (v != 0.0); }
+    flag[i] = any;
   });
   barrier(c);
+  if (first_thread(c)) {
+    int nr = 0;
+    for (int i = 0; i < z; ++i) if (flag[i]) a.kept[nr++] = i;
+    shared[4] = nr;                                   // kept top rows
+    for (int k = 0; k < n; ++k) if (!skip[k]) a.kept[nr++] = z + k;   // (row labels only: z + column)
+    a.info[1] = nr; a.info[2] = rp; a.info[3] = shared[3]; a.info[4] = 1; a.info[5] = z;
+  }
+  barrier(c);
+  const int nr = a.info[1], ztk = shared[4];
+  const int rc = a.r_cap;
+  par_for(c, (long)nr * n1, [&](long e) {
+    const int j = (int)(e / nr), k = (int)(e - (long)j * nr);
+    double v;
+    if (k < ztk) { const int row = a.kept[k]; v = (j < n && j + 15 < row) ? 0.0 : Xt[row * n1 + j]; }
+    else { const int col = a.kept[k] - z; v = j >= col ? C[j + (long)n1 * col] : 0.0; }
+    a.TH[k + (long)rc * j] = v;
+  });
+  // ---- G, top columns: u-rows of A e_i (non-zero inside the row's own track)
+  par_for(c, (long)ztk * mobs, [&](long e) {
+    const int k = (int)(e / mobs), g = (int)(e - (long)k * mobs), i = a.kept[k], t = topt[i];
+    const int o = g - a.obs0[t];
+    a.G[(long)a.ldg * k + g] = (a.otrk[g] == t) ? At[i * 2 * a.m_cap + 2 * o] : 0.0;
+  });
+  // ---- G, the other columns: x = (u-row of A_b A_b^T H_x) R'^-1 per stacked observation, 16 columns at a time
+  par_for(c, mobs, [&](long g) {
+    const int t = a.otrk[g], o = (int)g - a.obs0[t], M = a.M[t], R2 = 2 * M, rho = R2 - 3;
+    int kt = z - a.row0[t]; kt = kt < 0 ? 0 : (kt > rho ? rho : kt);
+    const int d = 3 + kt;
+    const double* V = a.Vf + (long)t * 2 * a.m_cap * 3;
+    const double* T = a.Tf + (long)t * 9;
+    const HT* hx = a.Hx + (long)t * a.m_cap * 12;
+    const signed char* inv = a.inv + (long)t * a.inv_stride;
+    double* gout = a.G + (long)a.ldg * ztk + g;
+    if (d >= R2) { for (int k = 0; k < rp; ++k) gout[(long)a.ldg * k] = 0.0; return; }
+    double tv[3], Sd[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, ev[3];
+    for (int p = 0; p < 3; ++p) tv[p] = vf_at(V, 2 * o, 0) * T[0 * 3 + p] + vf_at(V, 2 * o, 1) * T[1 * 3 + p] + vf_at(V, 2 * o, 2) * T[2 * 3 + p];
+    for (int q = 0; q < d; ++q) for (int p1 = 0; p1 < 3; ++p1) for (int p = 0; p < 3; ++p) Sd[p1][p] += vf_at(V, q, p1) * vf_at(V, q, p);
+    for (int p = 0; p < 3; ++p) ev[p] = (2 * o < d ? vf_at(V, 2 * o, p) : 0.0) - (tv[0] * Sd[0][p] + tv[1] * Sd[1][p] + tv[2] * Sd[2][p]);
+    auto qf = [&](int q) -> double { return (q == 2 * o ? 1.0 : 0.0) - (tv[0] * vf_at(V, q, 0) + tv[1] * vf_at(V, q, 1) + tv[2] * vf_at(V, q, 2)); };   // Q_f(2o, q)
+    auto hhat = [&](int col) -> double {
+      const int slot = col / 6, kk = col - 6 * slot, op = inv[slot];
+      if (op < 0) return 0.0;
+      const double h0 = (double)hx[op * 12 + kk], h1 = (double)hx[op * 12 + 6 + kk];
+      double sv[3], val = op == o ? h0 : 0.0;
+      for (int p = 0; p < 3; ++p) sv[p] = vf_at(V, 2 * op, p) * h0 + vf_at(V, 2 * op + 1, p) * h1;
+      for (int q = 0; q < 3; ++q) { double w = 0; for (int p = 0; p <= q; ++p) w += T[p * 3 + q] * sv[p]; val += ev[q] * w; }
+      if (2 * op < d) val -= qf(2 * op) * h0;
+      if (2 * op + 1 < d) val -= qf(2 * op + 1) * h1;
+      return val;
+    };
+    int smin = 1 << 30;
+    for (int o2 = 0; o2 < M; ++o2) { const int sl = a.slots[first_obs(a, t) + o2]; smin = sl < smin ? sl : smin; }
+    const int cb0 = (6 * smin / 16) * 16;
+    for (int k = 0; k < n; ++k) if (k < cb0 && kidx[k] >= 0) gout[(long)a.ldg * kidx[k]] = 0.0;
+    for (int cb = cb0; cb < n; cb += 16) {
+      double acc[16];
+      for (int j = 0; j < 16; ++j) acc[j] = cb + j < n ? hhat(cb + j) : 0.0;
+      for (int cp = cb0; cp < cb; ++cp) {
+        if (kidx[cp] < 0) continue;
+        const double xc = gout[(long)a.ldg * kidx[cp]];
+        if (xc == 0.0) continue;
+        const double* rrow = C + (long)n1 * cp + cb;          // R'(cp, cb + j)
+        for (int j = 0; j < 16; ++j) if (cb + j < n) acc[j] -= xc * rrow[j];
+      }
+      for (int j = 0; j < 16; ++j) {
+        const int col = cb + j;
+        if (col >= n || kidx[col] < 0) continue;
+        const double* rrow = C + (long)n1 * col + cb;
+        const double x = acc[j] / rrow[j];
+        gout[(long)a.ldg * kidx[col]] = x;
+        for (int j2 = j + 1; j2 < 16; ++j2) if (cb + j2 < n) acc[j2] -= x * rrow[j2];
+      }
+    }
+  });
+  barrier(c);
+  information_from_compressed(c, a, n, nr, mobs);
+  return true;
+}
+
+// route: 0 = fast when the stack has the shape for it, else general; 1 = general; 2 = fast only (tests: Lam^ is left
+// untouched and info[4] = 0 when the shape check fails)
+template <class HT>
+LIT_FN void literal_compress(const Ctx& c, const Args<HT>& a, const int route = 0) {
+  const int m = prepare(c, a);
+  if (m <= 0) return;
+  const int mobs = a.obs0[a.F];
+  if (route != 1 && literal_fast(c, a, m, mobs)) return;
+  if (route == 2) return;
+  literal_general(c, a, m, mobs);
 }
 
 }  // namespace lit

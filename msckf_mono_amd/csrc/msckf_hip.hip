@@ -197,6 +197,7 @@ struct Batch : BatchBase {
   // anisotropic pixel noise (u_var' != v_var'): 0 = the reference's construction R_o_j = A_j^T R_j A_j, R_n = Q_1^T R_o Q_1 on
   // the device (kernels_literal.hip; default), 1 = rows pre-whitened by 1/sigma (generalized least squares, unit noise)
   int aniso_mode = 0;
+  int lit_route = 0;         // 0 fast where the stack has the shape for it, else general; 1 general only; 2 fast only (tests)
   double lit_tol = -1;       // zero-tail tolerance of the literal route; < 0: 1e-10 (double) / 2e-4 (float: H_x is float-rounded)
   std::vector<double> h_uv;  // [B][2] u_var', v_var' as initialize() got them
   std::vector<char> h_lit;   // [B] trajectory runs the literal route
@@ -273,6 +274,7 @@ struct Batch : BatchBase {
     rc |= dalloc(&d.imu, Bz * IMU_STRIDE); rc |= dalloc(&d.cam, Bz * n_cap * CAM_STRIDE); rc |= dalloc(&d.prm, Bz * PRM_STRIDE);
     rc |= dalloc(&d.P, Bz * pl); rc |= dalloc(&P_spare, Bz * pl); d.Pout = nullptr; d.fuse_drop = nullptr; d.ncam_defer = 0;
     if (const char* e = getenv("MSCKF_HIP_FUSE_PRUNE")) fuse_prune = atoi(e) != 0;
+    if (const char* e = getenv("MSCKF_HIP_LITERAL_ROUTE")) lit_route = atoi(e);   // A/B runs and tests: 1 general route only, 2 fast route only
     rc |= dalloc(&d.ncam, Bz); rc |= dalloc(&d.n_resid, Bz);
     rc |= dalloc(&d.trk_status, TF); rc |= dalloc(&d.trk_pf, TF * 4); rc |= dalloc(&d.trk_gamma, TF);
     d.h16 = h16 ? 1 : 0; d.trk_Hx = nullptr; d.trk_Hx16 = nullptr;
@@ -393,14 +395,17 @@ struct Batch : BatchBase {
     LitBufs& L = d.lit;
     const size_t Bz = B, n1 = (size_t)d.n6cap + 1;
     L.ldx = ((f_cap * std::max(2 * m_cap - 3, 1) + 7) / 8) * 8;
-    L.r_cap = d.n6cap + 15; L.ldg = f_cap * m_cap; L.ldz = L.r_cap + (int)n1; L.kept_stride = 2 * (d.n6cap + 16) + 16;
+    L.r_cap = d.n6cap + 63; L.ldg = f_cap * m_cap + 8; L.ldz = L.r_cap + (int)n1; L.kept_stride = 6 * (d.n6cap + 16) + 64;   // 63 = LIT_ZCAP (literal_core.h)
+    L.w_stride = (long)(n1 * n1 + 63 * n1 + 63 * 2 * (size_t)m_cap);
     L.tol = lit_tol >= 0 ? lit_tol : (sizeof(S) == 4 ? 2e-4 : 1e-10);
+    L.route = lit_route;
     int rc = 0;
     rc |= dalloc(&L.X, Bz * L.ldx * n1); rc |= dalloc(&L.tau, Bz * n1);
     rc |= dalloc(&L.Vf, Bz * f_cap * 2 * m_cap * 3); rc |= dalloc(&L.Tf, Bz * f_cap * 9);
-    rc |= dalloc(&L.row0, Bz * (f_cap + 1)); rc |= dalloc(&L.obs0, Bz * (f_cap + 1)); rc |= dalloc(&L.kept, Bz * L.kept_stride);
+    rc |= dalloc(&L.row0, Bz * (f_cap + 1)); rc |= dalloc(&L.obs0, Bz * (f_cap + 1)); rc |= dalloc(&L.otrk, Bz * L.ldg); rc |= dalloc(&L.kept, Bz * L.kept_stride);
     rc |= dalloc(&L.TH, Bz * L.r_cap * n1); rc |= dalloc(&L.G, Bz * (size_t)L.ldg * L.r_cap); rc |= dalloc(&L.Z, Bz * (size_t)L.ldz * L.ldz);
-    rc |= dalloc(&L.info, Bz * 4);
+    rc |= dalloc(&L.W, Bz * (size_t)L.w_stride);
+    rc |= dalloc(&L.info, Bz * 6);
     if (rc) { L.X = nullptr; return fail(-ENOMEM, "work space of the literal anisotropic route (msckf_hip_set_anisotropic_noise(h, 1, 0) selects pre-whitening)"); }
     return 0;
   }
@@ -409,6 +414,7 @@ struct Batch : BatchBase {
     HIPCHK(hipSetDevice(device));
     aniso_mode = mode; lit_tol = tol;
     d.lit.tol = tol >= 0 ? tol : (sizeof(S) == 4 ? 2e-4 : 1e-10);
+    d.lit.route = lit_route;
     for (int b = 0; b < B; ++b) {
       if (!traj[b].initialized) continue;
       S out5[5];
@@ -421,9 +427,9 @@ struct Batch : BatchBase {
   }
   int lit_info(int b, int* out4) override {
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
-    if (!d.lit.info) { for (int i = 0; i < 4; ++i) out4[i] = 0; return 0; }
+    if (!d.lit.info) { for (int i = 0; i < 6; ++i) out4[i] = 0; return 0; }
     HIPCHK(hipSetDevice(device));
-    HIPCHK(hipMemcpyAsync(out4, d.lit.info + (size_t)b * 4, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out4, d.lit.info + (size_t)b * 6, 6 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return 0;
   }
@@ -554,9 +560,9 @@ struct Batch : BatchBase {
     stage_begin(7, q); if (v.compress) launch_select_diag<S>(v, b0, nb, q); else launch_select<S>(v, b0, nb, q); stage_end(7, q);
     if (v.compress) {
       // anisotropic pixel noise, literal route: the information matrix of the reference's (T_H, r_n, R_n) replaces H_o^T H_o
-      // for those trajectories (kernels_literal.hip); the SYRK is skipped when every trajectory of the batch is one
+      // for those trajectories (kernels_literal.hip)
       stage_begin(3, q);
-      if (n_lit < B) launch_gram<S>(v, b0, nb, q, 3);
+      launch_gram<S>(v, b0, nb, q, 3);                    // (the literal route's fast path starts from the same f64 Gram matrix)
       if (n_lit > 0) launch_literal<S>(v, b0, nb, q);
       stage_end(3, q);
       stage_begin(4, q); launch_gram<S>(v, b0, nb, q, 2); stage_end(4, q);

@@ -7,10 +7,12 @@
 #define LIT_HOST
 #include "../../msckf_mono_amd/csrc/literal_core.h"
 
+// route: 0 fast when the stack has the shape for it, else general; 1 general; 2 fast only.  LamIn: [H_o | r_o]^T [H_o | r_o]
+// ((6N+1)^2, element (hi, lo) at hi * (6N+1) + lo; what k_gram accumulates on the device), may be null for route 1.
 extern "C" int lit_host_compress(int F, int m_cap, int N, const int* included, const int* M, const int* slots /*[F][m_cap]*/,
                                  const double* Hx /*[F][m_cap][12]*/, const double* rw /*[F][2 m_cap]*/, double u_var, double v_var,
-                                 double tol, double* Lam /*[(6N+1)^2], (hi, lo) at hi * (6N+1) + lo*/, int* info4,
-                                 double* TH_out /*[(6N+15) x (6N+1)] column-major or null*/) {
+                                 double tol, int route, const double* LamIn, double* Lam /*[(6N+1)^2], (hi, lo) at hi * (6N+1) + lo*/,
+                                 int* info6, double* TH_out /*[(6N+15) x (6N+1)] column-major or null*/) {
   using namespace msckf::lit;
   const int n = 6 * N;
   int m = 0, mobs = 0;
@@ -20,17 +22,24 @@ extern "C" int lit_host_compress(int F, int m_cap, int N, const int* included, c
   a.Hx = Hx; a.rw = rw; a.u_var = u_var; a.v_var = v_var; a.tol = tol;
   a.ldx = m + 8;
   std::vector<double> X((size_t)a.ldx * (n + 1)), tau(n + 1), Vf((size_t)F * 2 * m_cap * 3), Tf((size_t)F * 9);
-  std::vector<int> row0(F + 1), obs0(F + 1), kept(2 * (n + 16) + 16);
+  std::vector<int> row0(F + 1), obs0(F + 1), kept(6 * (n + 16) + 64), otrk(mobs + 8);
   a.X = X.data(); a.tau = tau.data(); a.Vf = Vf.data(); a.Tf = Tf.data(); a.row0 = row0.data(); a.obs0 = obs0.data(); a.kept = kept.data();
-  a.r_cap = n + 15;
+  a.otrk = otrk.data();
+  a.r_cap = n + LIT_ZCAP;
   std::vector<double> TH((size_t)a.r_cap * (n + 1)), G((size_t)(mobs + 8) * a.r_cap);
   a.TH = TH.data(); a.ldg = mobs + 8; a.G = G.data();
   a.ldz = a.r_cap + n + 1;
   std::vector<double> Z((size_t)a.ldz * a.ldz);
   a.Z = Z.data();
-  a.Lam = Lam; a.ldL = n + 1; a.info = info4;
+  std::vector<signed char> inv((size_t)F * 64, (signed char)-1);
+  for (int t = 0; t < F; ++t) for (int o = 0; o < M[t]; ++o) inv[(size_t)t * 64 + slots[(size_t)t * m_cap + o]] = (signed char)o;
+  a.inv = inv.data(); a.inv_stride = 64;
+  std::vector<double> W((size_t)(n + 1) * (n + 1) + (size_t)LIT_ZCAP * (n + 1) + (size_t)LIT_ZCAP * 2 * m_cap);
+  a.W = W.data();
+  a.LamIn = LamIn; a.lam_part = 0; a.gram_parts = 1;
+  a.Lam = Lam; a.ldL = n + 1; a.info = info6;
   Ctx c;
-  literal_compress(c, a);
-  if (TH_out) for (size_t i = 0; i < TH.size(); ++i) TH_out[i] = TH[i];
+  literal_compress(c, a, route);
+  if (TH_out) for (size_t i = 0; i < (size_t)(n + 15) * (n + 1); ++i) { const size_t col = i / (n + 15), row = i % (n + 15); TH_out[i] = TH[row + (size_t)a.r_cap * col]; }
   return 0;
 }
