@@ -121,6 +121,44 @@ def make_trajectories(c, rank, n_frames):
     return [out[b % nu] for b in range(c["B"])]
 
 
+def _parse_cpulist(txt):
+    out = []
+    for part in txt.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def host_cpus_for_rank(local_rank, n):
+    """n host cores for this rank's uploading + enqueue threads: on the GPU's NUMA node when sysfs tells, one disjoint block
+    per local rank, never the node's first two cores (interrupt and runtime helper threads land there).  [] = do not pin."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        cpus = allowed
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(local_rank)
+            bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+            if node >= 0:
+                on_node = [c for c in _parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % node).read()) if c in set(allowed)]
+                if len(on_node) >= n + 2:
+                    cpus = on_node
+        except Exception:
+            pass
+        lws = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+        pool = cpus[2:] if len(cpus) >= lws * n + 2 else cpus
+        if len(pool) < lws * n:
+            return []
+        per = len(pool) // lws
+        blk = pool[(local_rank % lws) * per:(local_rank % lws) * per + n]
+        return blk if len(blk) == n else []
+    except Exception:
+        return []
+
+
 def self_launch_if_needed(args):
     """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: re-execute as N ranks, one per GPU, on this node."""
     env_world = os.environ.get("WORLD_SIZE")
@@ -163,6 +201,7 @@ def main():
     ap.add_argument("--upload-mode", type=int, default=0, help="0 host hand-over of uploaded frames (default), 1 device-side event waits")
     ap.add_argument("--compression", type=int, default=-1, help="msckf_hip_set_compression route (A/B runs; -1 = library default, 0 TSQR, information form with 1 k_chol_T / 2 k_chol_blk / 3 k_chol_mfma)")
     ap.add_argument("--cov-form", type=int, default=0, help="msckf_hip_set_covariance_update form (A/B runs; 0 = square-root gain, blocked solve (default), 1 Joseph, 2 square-root gain, register-resident solve)")
+    ap.add_argument("--no-pin", action="store_true", help="leave the uploading / enqueue threads where the scheduler puts them (default: one core each on the GPU's NUMA node)")
     ap.add_argument("--aniso-mode", type=int, default=0, help="u_var' != v_var' (cfg4): 0 the reference's literal R_n = Q_1^T R_o Q_1 on the device (default), 1 rows pre-whitened (GLS)")
     ap.add_argument("--gate-early-accept", action="store_true",
                     help="exact early accept of the chi-square gate (msckf_hip_set_gate_early_accept); OFF for the headline number")
@@ -183,7 +222,7 @@ def main():
     K, W = args.steps, args.warmup
     fill = N_WIN                     # frames needed to reach the steady-state window
     est_ms = 0.7 * B_TRAJ / 64.0 * (N_WIN / 30.0) ** 2 * (F_TRK / 200.0)    # rough step time, only used to size the number of repeat windows
-    R = args.repeats if args.repeats > 0 else int(min(12, max(3, np.ceil(500.0 / (K * est_ms)))))
+    R = args.repeats if args.repeats > 0 else int(min(48, max(3, np.ceil(250.0 / (K * est_ms)))))
     streamed = not args.no_upload_pass
     R2 = min(R, 3) if streamed else 0                       # resident-input windows beside the streamed ones
     extra = R2 + 1 + (0 if (args.gate_early_accept or args.no_early_accept_pass) else 1)
@@ -258,6 +297,9 @@ def main():
         return el
 
     bt.set_streams(args.streams)
+    pin_cpus = [] if args.no_pin else host_cpus_for_rank(local_rank, args.streams + 1)
+    if pin_cpus:
+        bt.set_host_affinity(pin_cpus)
     bt.set_upload_ring(args.ring, args.upload_mode)
     if args.compression >= 0:
         bt.set_compression(args.compression)
@@ -399,7 +441,8 @@ def main():
                        "cam_window": N_WIN, "tracks_per_update": F_TRK, "trajectories_per_gpu": B_TRAJ, "imu_per_update": K_IMU,
                        "parallelism": "replicated trajectories, %d per rank" % B_TRAJ,
                        "noise": "isotropic (f_u = f_v)" if c["iso"] else ("anisotropic (EuRoC f_u != f_v): " + ("the reference's R_o_j = A_j^T R_j A_j / HouseholderQR / R_n = Q_1^T R_o Q_1 on the device (kernels_literal.hip)" if args.aniso_mode == 0 else "rows pre-whitened by 1/sigma (GLS)")),
-                       "sequences": nseq, "gate_early_accept": bool(args.gate_early_accept), "streams": args.streams},
+                       "sequences": nseq, "gate_early_accept": bool(args.gate_early_accept), "streams": args.streams,
+                       "host_affinity": pin_cpus or None},
             "inputs": ("uploaded per frame inside the timed region (SURVEY.md 8d): page-locked host memory -> staging ring on a copy stream, "
                        "compact work-lists, %d sets" % args.ring) if streamed else "resident in HBM before the timed region (--no-upload-pass)",
             "upload": None if not streamed else {"bytes_per_step_per_gpu": int(up_bytes), "ring": args.ring,
@@ -498,7 +541,7 @@ def ate_vs_reference(trajs, sample, p_dev, n_run, N, anisotropic=False, literal=
         if whiten:
             o.setWhiten(True)
         elif anisotropic:
-            o.setTinyRowTol(2e-4)
+            o.setTinyRowTol(1e-3)
         o.initialize(tr.cfg, tr.imu0)
         for k in range(n_run):
             _oracle_window(o, tr, k, N)
@@ -521,7 +564,7 @@ def ate_vs_reference(trajs, sample, p_dev, n_run, N, anisotropic=False, literal=
     if anisotropic:
         out["ate_vs_ref_literal_m"] = rms([p_dev[b] - res[b] for b in sample])
         out["ate_vs_ref_whitened_m"] = rms([p_dev[b] - resw[b] for b in sample])
-        out["ate_vs_ref_is"] = "literal restatement (zero-tail tolerance 2e-4)" if literal else "pre-whitened restatement"
+        out["ate_vs_ref_is"] = "literal restatement (zero-tail tolerance 1e-3)" if literal else "pre-whitened restatement"
     return out
 
 

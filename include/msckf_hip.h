@@ -178,6 +178,11 @@ int msckf_hip_profile_event_overhead(msckf_hip_handle h, double* ms);
 /* run_frames on n = 1..8 HIP streams: the batch is cut into n slices of independent trajectories that run the
  * same kernel sequence concurrently (latency-bound stages of one slice overlap chip-filling stages of another). */
 int msckf_hip_set_streams(msckf_hip_handle h, int n);
+/* Host cores for the threads of msckf_hip_run_frames / _streamed: cpus[0] for the calling thread while it uploads frames
+ * (restored on return), cpus[1 + i] for the enqueue thread of slice i.  The hand-overs between them are spin waits; without
+ * this the threads run wherever the scheduler puts them (n = 0 clears the list).  One core each, ideally on the GPU's NUMA
+ * node. */
+int msckf_hip_set_host_affinity(msckf_hip_handle h, const int* cpus, int n);
 /* Exact early accept of the chi-square gate (gatingTest, msckf.h:1103-1124), OFF by default: S = H_o P H_o^T + sigma^2 I
  * >= sigma^2 I, so gamma <= |r_o|^2 / sigma^2; when that bound is below half the threshold the track passes without
  * forming S.  Same decisions as the reference; the reported gamma of such a track is the bound (status bit 32). */
@@ -203,7 +208,7 @@ int msckf_hip_set_feature_overlap(msckf_hip_handle h, int on);
 /* Anisotropic pixel noise, u_var_prime != v_var_prime (see the header comment): mode 0 (default) the reference's
  * R_o_j = A_j^T R_j A_j / HouseholderQR in column order / R_n = Q_1^T R_o Q_1 on the device (msckf.h:423-431, 1343-1366;
  * f64, one workgroup per trajectory), its result handed to the update as the information matrix
- * [T_H | r_n]^T R_n^-1 [T_H | r_n]; mode 1 rows pre-whitened by 1/sigma (generalized least squares).  tail_tol: zero-tail tolerance of mode 0, < 0 = default (1e-10 double, 2e-4 float), 0 = the reference's
+ * [T_H | r_n]^T R_n^-1 [T_H | r_n]; mode 1 rows pre-whitened by 1/sigma (generalized least squares).  tail_tol: zero-tail tolerance of mode 0, < 0 = default (1e-10 double, 1e-3 float), 0 = the reference's
  * rule to the letter.  Applies to every trajectory of the handle, initialized or not.  -ENOMEM when the stack does not fit
  * (f_cap (2 m_cap - 3) x (6 n_cap + 1) doubles per trajectory). */
 int msckf_hip_set_anisotropic_noise(msckf_hip_handle h, int mode, double tail_tol);

@@ -33,7 +33,7 @@ SYMBOLS = [
     "msckf_hip_profile_enable", "msckf_hip_profile_read", "msckf_hip_profile_event_overhead", "msckf_hip_set_streams", "msckf_hip_set_gate_early_accept",
     "msckf_hip_scenario_pin", "msckf_hip_set_upload_ring", "msckf_hip_clear_error_flags",
     "msckf_hip_set_compression", "msckf_hip_set_covariance_update", "msckf_hip_set_feature_overlap", "msckf_hip_get_pruned_states", "msckf_hip_get_cam_meta", "msckf_hip_get_tracked_feature_ids",
-    "msckf_hip_set_anisotropic_noise", "msckf_hip_literal_info", "msckf_hip_get_error_flags", "msckf_hip_copy_state",
+    "msckf_hip_set_anisotropic_noise", "msckf_hip_literal_info", "msckf_hip_get_error_flags", "msckf_hip_copy_state", "msckf_hip_set_host_affinity",
 ]
 
 
@@ -274,6 +274,11 @@ class Batch:
 
     def sync(self):
         _chk(self.L.msckf_hip_sync(self.h))
+
+    def set_host_affinity(self, cpus):
+        """cpus[0]: the calling thread while it uploads frames; cpus[1 + i]: enqueue thread of slice i"""
+        a = np.ascontiguousarray(list(cpus), dtype=np.int32)
+        _chk(self.L.msckf_hip_set_host_affinity(self.h, a.ctypes.data_as(_ip), int(a.size)))
 
     def set_streams(self, n):
         _chk(self.L.msckf_hip_set_streams(self.h, int(n)))

@@ -525,16 +525,17 @@ LIT_FN bool literal_fast(const Ctx& c, const Args<HT>& a, const int m, const int
   });
   barrier(c);
   // ---- Cholesky with the zero-tail rule in Gram form: the pivot of column k IS |tail|^2 of Householder step 15 + k
-  // The Gram matrix cannot see a tail below ~1e-5 |column| (measured: the pivots of the gauge columns come out at up to
-  // 3e-11 |column|^2 at a 30-camera window, the smallest independent pivot at 1e-3): threshold 1e-7, and anything within a
-  // factor 16 of it is left to the general route's tail test
-  const double t2a = a.tol * a.tol, t2 = t2a > 1e-7 ? t2a : 1e-7;
+  // A column is dependent when pivot <= lo |column|^2 and independent when pivot >= hi |column|^2; in between the Gram
+  // matrix cannot tell (measured at a 30-camera window: the pivots of the gauge columns come out at up to 3e-11 |column|^2
+  // from f64 Jacobians, ~1e-8 from float-rounded ones; the smallest independent pivot at 1e-3) and the general route's
+  // tail test decides.  lo = tol^2 is the Householder rule itself.
+  const double t2a = a.tol * a.tol, lo2 = t2a > 1e-9 ? t2a : 1e-9, hi2 = 30 * lo2 > 3e-5 ? 30 * lo2 : 3e-5;
   int ok = 1;
   for (int k = 0; k < n; ++k) {
     double* ck = C + (long)n1 * k;
     const double piv = ck[k], dk = dcol[k];
-    const bool indep = dk > 0.0 && piv > t2 * dk;
-    if (dk > 0.0 && piv > t2 * dk * (1.0 / 16) && piv < t2 * dk * 16) ok = 0;     // too close to the threshold to call
+    const bool indep = dk > 0.0 && piv >= hi2 * dk;
+    if (dk > 0.0 && piv > lo2 * dk && piv < hi2 * dk) ok = 0;                     // too close to call
     barrier(c);
     if (!indep) {
       if (first_thread(c)) skip[k] = 1;

@@ -24,6 +24,8 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <pthread.h>
+#include <sched.h>
 #include "dev_common.h"
 
 
@@ -119,6 +121,7 @@ struct BatchBase {
   virtual int prof_read(double* ms, int* cnt) = 0;
   virtual int prof_event_overhead(double* ms) = 0;
   virtual int set_streams(int n) = 0;
+  virtual int set_host_affinity(const int* cpus, int n) = 0;
   virtual int set_gate_early(int on) = 0;
   virtual int set_compression(int route) = 0;
   virtual int set_cov_update(int form) = 0;
@@ -143,8 +146,18 @@ struct Workers {
   unsigned long gen = 0;
   int active = 0, pending = 0;
   bool stop = false;
+  // worker idx runs on cpus[idx + 1] (cpus[0] is the calling thread's: the uploader of run_frames_streamed) when a list was
+  // given (msckf_hip_set_host_affinity): the hand-overs between the uploading thread and the slices' enqueue threads are
+  // spin waits, and a waiter that the scheduler moves or parks costs a frame's worth of time
+  std::vector<int> cpus;
+  static void pin_self(int cpu) {
+    if (cpu < 0) return;
+    cpu_set_t set; CPU_ZERO(&set); CPU_SET(cpu, &set);
+    (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+  }
   void loop(int idx) {
     unsigned long seen = 0;
+    int pinned = -2;
     for (;;) {
       std::function<void(int)> f;
       {
@@ -154,6 +167,8 @@ struct Workers {
         seen = gen;
         if (idx >= active) continue;
         f = job;
+        const int want = idx + 1 < (int)cpus.size() ? cpus[idx + 1] : -1;
+        if (want != pinned) { pin_self(want); pinned = want; }
       }
       f(idx);
       { std::lock_guard<std::mutex> lk(m); if (--pending == 0) cv_done.notify_all(); }
@@ -198,7 +213,7 @@ struct Batch : BatchBase {
   // the device (kernels_literal.hip; default), 1 = rows pre-whitened by 1/sigma (generalized least squares, unit noise)
   int aniso_mode = 0;
   int lit_route = 0;         // 0 fast where the stack has the shape for it, else general; 1 general only; 2 fast only (tests)
-  double lit_tol = -1;       // zero-tail tolerance of the literal route; < 0: 1e-10 (double) / 2e-4 (float: H_x is float-rounded)
+  double lit_tol = -1;       // zero-tail tolerance of the literal route; < 0: 1e-10 (double) / 1e-3 (float: H_x is float-rounded)
   std::vector<double> h_uv;  // [B][2] u_var', v_var' as initialize() got them
   std::vector<char> h_lit;   // [B] trajectory runs the literal route
   int n_lit = 0;
@@ -397,7 +412,7 @@ struct Batch : BatchBase {
     L.ldx = ((f_cap * std::max(2 * m_cap - 3, 1) + 7) / 8) * 8;
     L.r_cap = d.n6cap + 63; L.ldg = f_cap * m_cap + 8; L.ldz = L.r_cap + (int)n1; L.kept_stride = 6 * (d.n6cap + 16) + 64;   // 63 = LIT_ZCAP (literal_core.h)
     L.w_stride = (long)(n1 * n1 + 63 * n1 + 63 * 2 * (size_t)m_cap);
-    L.tol = lit_tol >= 0 ? lit_tol : (sizeof(S) == 4 ? 2e-4 : 1e-10);
+    L.tol = lit_tol >= 0 ? lit_tol : (sizeof(S) == 4 ? 1e-3 : 1e-10);
     L.route = lit_route;
     int rc = 0;
     rc |= dalloc(&L.X, Bz * L.ldx * n1); rc |= dalloc(&L.tau, Bz * n1);
@@ -413,7 +428,7 @@ struct Batch : BatchBase {
     if (mode < 0 || mode > 1) return fail(-EINVAL, "mode: 0 the reference's R_n = Q_1^T R_o Q_1 on the device, 1 pre-whitened rows");
     HIPCHK(hipSetDevice(device));
     aniso_mode = mode; lit_tol = tol;
-    d.lit.tol = tol >= 0 ? tol : (sizeof(S) == 4 ? 2e-4 : 1e-10);
+    d.lit.tol = tol >= 0 ? tol : (sizeof(S) == 4 ? 1e-3 : 1e-10);
     d.lit.route = lit_route;
     for (int b = 0; b < B; ++b) {
       if (!traj[b].initialized) continue;
@@ -1023,6 +1038,11 @@ struct Batch : BatchBase {
     compress_route = route;
     return 0;
   }
+  int set_host_affinity(const int* cpus, int n) override {
+    std::lock_guard<std::mutex> lk(workers.m);
+    workers.cpus.assign(cpus, cpus + std::max(n, 0));
+    return 0;
+  }
   int set_streams(int n) override {
     if (n < 1 || n > MAXS) return fail(-EINVAL, "1 to 8 streams");
     nstreams = n;
@@ -1245,6 +1265,11 @@ int Batch<S>::run_frames_streamed(int f0, int f1) {
     }
     slice_rc[hh] = (int)hipGetLastError();
   };
+  // the uploading (calling) thread on its own core for the duration of the call, when a list of cores was given
+  cpu_set_t old_mask; bool repin = false;
+  if (!workers.cpus.empty() && workers.cpus[0] >= 0 && pthread_getaffinity_np(pthread_self(), sizeof(old_mask), &old_mask) == 0) {
+    Workers::pin_self(workers.cpus[0]); repin = true;
+  }
   workers.start(nh, slice);
   int rc_up = 0;
   for (int f = f0; f < f1 && !rc_up; ++f) {
@@ -1262,6 +1287,7 @@ int Batch<S>::run_frames_streamed(int f0, int f1) {
   }
   if (rc_up) failed.store(1);
   workers.wait();
+  if (repin) (void)pthread_setaffinity_np(pthread_self(), sizeof(old_mask), &old_mask);
   if (rc_up) return fail(rc_up, "input upload failed");
   rc = join_slices(nh, qs);
   if (rc) return rc;
@@ -1739,6 +1765,7 @@ int msckf_hip_sync(msckf_hip_handle h) { return H(h)->sync(); }
 int msckf_hip_profile_enable(msckf_hip_handle h, int on) { return H(h)->prof_enable(on); }
 int msckf_hip_profile_read(msckf_hip_handle h, double* ms7, int* count7) { return H(h)->prof_read(ms7, count7); }
 int msckf_hip_profile_event_overhead(msckf_hip_handle h, double* ms) { if (!h || !ms) return fail(-EINVAL, "null argument"); return H(h)->prof_event_overhead(ms); }
+int msckf_hip_set_host_affinity(msckf_hip_handle h, const int* cpus, int n) { if (!h || (n > 0 && !cpus)) return fail(-EINVAL, "null argument"); return H(h)->set_host_affinity(cpus, n); }
 int msckf_hip_set_streams(msckf_hip_handle h, int n) { return H(h)->set_streams(n); }
 int msckf_hip_scenario_pin(msckf_hip_handle h, int f0, int f1) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->scen_pin(f0, f1); }
 int msckf_hip_set_upload_ring(msckf_hip_handle h, int depth, int mode) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_upload_ring(depth, mode); }
