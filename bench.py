@@ -45,6 +45,10 @@ PEAK_F32_TFLOPS = 157.3   # MI355X dense f32 (vector = f32-input MFMA) peak, MI3
 PEAK_F64_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
 CONFIGS = {
+    # cfg2 has its own driver (run_cfg2): one double-precision filter through the per-call API
+    "cfg2": dict(cid=2, N=10, F=50, B=1, iso=True, nseq=1, dtype="f64",
+                 workload="BASELINE.json configs[1]: synthetic IMU + features, 10-cam window / 50 feats, double, 1 GPU single trajectory, "
+                          "driven call by call through the drop-in shim as datasets/asl_msckf.cpp:227-296 drives the reference"),
     # name: config id (seed family), window, tracks, trajectories per GPU, isotropic noise, sequences
     "cfg3": dict(cid=3, N=30, F=200, B=64, iso=True, nseq=1, dtype="f32",
                  workload="BASELINE.json configs[2]: synthetic 30-cam window / 200 feats, float, 64 batched trajectories per GPU"),
@@ -119,6 +123,17 @@ def make_trajectories(c, rank, n_frames):
         with ProcessPoolExecutor(nproc) as ex:
             out = list(ex.map(_make_traj, jobs, chunksize=max(1, len(jobs) // (4 * nproc))))
     return [out[b % nu] for b in range(c["B"])]
+
+
+def csrc_hash():
+    """identity of the kernel sources a measurement belongs to: sha256 over msckf_mono_amd/csrc/*.hip, *.h (sorted by name)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "msckf_mono_amd", "csrc")
+    for fn in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(fn).encode()); h.update(open(fn, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _parse_cpulist(txt):
@@ -207,6 +222,8 @@ def main():
                     help="exact early accept of the chi-square gate (msckf_hip_set_gate_early_accept); OFF for the headline number")
     args = ap.parse_args()
     self_launch_if_needed(args)
+    if args.config == "cfg2":
+        return run_cfg2(args)
     c = dict(CONFIGS[args.config])
     if args.trajectories > 0:
         c["B"] = args.trajectories
@@ -454,14 +471,17 @@ def main():
                 "values": res_vals, "median": float(np.median(res_vals)), "ms_per_step": 1e3 * float(np.median(res_rep)) / K,
                 "streamed_over_resident": float(np.median(rep_vals) / np.median(res_vals)),
                 "note": "the same K-step windows with every frame's inputs already in HBM (msckf_hip_run_frames): an upper bound, never `value`"},
-            "roofline": {"bound": kd["bound"], "kernel": dom, "achieved": achieved, "peak": kd["peak"], "unit": "TFLOP/s",
-                         "frac": frac if frac <= 1.0 else None,
+            "roofline": {"bound": kd["bound"], "kernel": dom, "achieved": executed_model[dom_stage]["tflops"], "peak": kd["peak"], "unit": "TFLOP/s",
+                         "frac": executed_model[dom_stage]["frac"],
                          "executed_frac": executed_model[dom_stage]["frac"], "executed_tflops": executed_model[dom_stage]["tflops"],
+                         "executed_flops_per_launch": executed_model[dom_stage]["flop_per_step"],
+                         "alg_equivalent_tflops": achieved,
                          "traffic": None if pmc is None else pmc.get("bytes_per_launch"),
                          "why": kd["why"], "kernel_ms_per_step": kd["ms"], "kernel_ms_note": "HIP-event pair around the launch on the library's stream, minus the reading of an empty pair (event_pair_overhead_ms): comparable with rocprofv3's kernel-trace duration", "alg_flops_per_launch": dom_flops,
-                         "note": "achieved / frac = the REFERENCE algorithm's FLOP for this stage (SURVEY.md 8d: dense gate products) / measured kernel "
-                                 "time -- an algorithm-equivalent rate, not a utilisation (frac is null when it exceeds 1: alg_equivalent_ratio); "
-                                 "executed_frac = FLOP of the block-sparse algorithm the kernel runs (executed_model) / time / peak",
+                         "note": "achieved / frac = FLOP of the algorithm the kernel executes (executed_model: block-sparse gate, one Cholesky of "
+                                 "G + sigma^2 I) per launch / measured kernel time / peak -- a utilisation, <= 1 by construction; alg_equivalent_* = the "
+                                 "REFERENCE algorithm's FLOP for this stage (SURVEY.md 8d: dense gate products) / the same time: what the run time "
+                                 "would buy of the reference's arithmetic at peak, not a utilisation (it may exceed 1)",
                          "alg_equivalent_ratio": frac,
                          "executed": None if pmc is None else pmc.get("executed"),
                          "traffic_source": pmc_meta,
@@ -496,23 +516,176 @@ def main():
         dist.destroy_process_group()
 
 
+def run_cfg2(args):
+    """BASELINE.json configs[1]: ONE double-precision filter (10-camera window, 50 tracks per update), driven exactly as the
+    reference's callers drive theirs: bench_src/cfg2_driver.cpp is compiled against the drop-in shim (include/msckf_mono/msckf.h)
+    and libmsckf_hip.so and makes one propagate() call per IMU sample with the by-value getImuState() after it, then
+    augmentState / update / addFeatures / marginalize / pruneEmptyStates per image (asl_msckf.cpp:227-296), timing every stage
+    with the host wall clock as the reference's StageTiming does.  `value` = filter updates per second of that loop (latency
+    bound: one trajectory cannot fill the chip); beside it the reference's own source in double on one host core
+    (`cpu_baseline.kind` "reference"), the per-stage microseconds of both, the HIP-event stage timers of the same frames, and
+    the state against the CPU oracle at the end of the run."""
+    import subprocess
+    import tempfile
+    c = CONFIGS["cfg2"]
+    N, F = c["N"], c["F"]
+    K, W = args.steps, args.warmup
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.gpus > 1:
+        raise SystemExit("bench.py --config cfg2 is the single-trajectory latency configuration: 1 GPU")
+    from msckf_mono_amd import scenario as sc
+    nf = N + W + K
+    tr = sc.Trajectory(2, 0, N, F, nf, cfg=sc.filter_config(N, isotropic=True))
+    st = tr.stream()
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    from msckf_mono_amd import capi
+    # ---- the timed loop: C++ caller over the shim
+    build = tempfile.mkdtemp(prefix="cfg2_")
+    exe = os.path.join(build, "cfg2_driver")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    cc = subprocess.run(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "bench_src", "cfg2_driver.cpp"), "-o", exe,
+                         "-L" + libdir, "-lmsckf_hip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"],
+                        capture_output=True, text=True)
+    if cc.returncode:
+        raise SystemExit("cfg2 driver did not compile: " + cc.stderr[-2000:])
+    cam, noise, prm = capi.pack_config(tr.cfg)
+    lines = [" ".join(repr(float(x)) for x in np.concatenate([cam, noise, prm, tr.imu0])), "%d %d" % (nf, N + W)]
+    for k in range(nf):
+        rd = tr.imu_for_frame(k)
+        lines.append(str(len(rd)) + " " + " ".join(repr(float(x)) for x in rd.ravel()))
+        for kind in ("cur", "new"):
+            obs, ids = st[k][kind]
+            lines.append(str(len(ids)) + " " + " ".join("%r %r %d" % (float(z[0]), float(z[1]), i) for z, i in zip(obs, ids)))
+    text = "\n".join(lines) + "\n"
+    runs = []
+    for _ in range(max(1, args.repeats if args.repeats > 0 else 5)):       # every run replays the whole sequence: fill + warm-up untimed, K frames timed
+        r = subprocess.run([exe], input=text, capture_output=True, text=True, timeout=600)
+        if r.returncode:
+            raise SystemExit("cfg2 driver failed (%d): %s" % (r.returncode, r.stderr[-2000:]))
+        runs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    first = runs[0]
+    frame_us = np.array(first["frame_us"])
+    value = len(frame_us) / (frame_us.sum() * 1e-6)
+    rep_vals = [len(x["frame_us"]) / (sum(x["frame_us"]) * 1e-6) for x in runs]
+
+    # ---- the same frames through the C-ABI with the library's HIP-event stage timers (which kernel dominates, executed FLOP)
+    f = capi.MSCKF(capi.F64, n_cap=N + 3, f_cap=max(F, 64), m_cap=N + 3)
+    f.initialize(tr.cfg, tr.imu0)
+    sid = 0
+    Ms_timed = []
+    for k in range(nf):
+        if k == N + W:
+            f.batch.sync(); f.batch.profile_enable(True)
+        for r7 in tr.imu_for_frame(k):
+            sid += 1; f.propagate(r7)
+        f.augmentState(sid, float(k)); f.update(*st[k]["cur"]); f.addFeatures(*st[k]["new"]); f.marginalize(); f.pruneEmptyStates()
+        if k >= N + W:
+            Ms_timed.append(tr.frames[k]["M"])
+    prof = f.batch.profile_read(); f.batch.profile_enable(False)
+    ev_pair_ms = f.batch.profile_event_overhead()
+    imu_c = f.getImuState(); P_c = f.getCovariance()
+    stage_ms = {k2: max(v[0] / max(v[1], 1) - ev_pair_ms, 0.0) if v[1] else 0.0 for k2, v in prof.items()}
+    ex = dict(feature=0.0, compress_stage1=0.0, compress_merge=0.0, kalman=0.0)
+    for Ms in Ms_timed:
+        one = executed_flops_update(Ms, N)
+        for k2 in ex:
+            ex[k2] += one[k2] / len(Ms_timed)
+    ex_peak = dict(feature=PEAK_F64_TFLOPS, compress_stage1=PEAK_F64_TFLOPS, compress_merge=PEAK_F64_TFLOPS, kalman=PEAK_F64_TFLOPS)
+    model = {k2: {"flop_per_update": ex[k2], "ms": stage_ms.get(k2, 0.0), "tflops": (ex[k2] / (stage_ms[k2] * 1e-3) / 1e12 if stage_ms.get(k2, 0) > 0 else 0.0),
+                  "peak": ex_peak[k2]} for k2 in ex}
+    for m in model.values():
+        m["frac"] = m["tflops"] / m["peak"]
+    dom_stage = max(model, key=lambda k2: model[k2]["ms"])
+    dom_kernel = {"feature": "k_feature<double>", "compress_stage1": "k_gram", "compress_merge": "k_chol_mfma<double> (Gram)", "kalman": "kalman launch set (k_gemm_mfma<double>, k_gain_w)"}[dom_stage]
+
+    # ---- CPU: the reference's own source in double on ONE core (the reference is single-threaded), and the oracle for parity
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    def cpu_run(o, timed_from):
+        o.initialize(tr.cfg, tr.imu0)
+        sid2 = 0; t_acc = 0.0; stages = dict(imu_prop=0.0, msckf_augment_state=0.0, msckf_update=0.0, msckf_add_features=0.0, msckf_marginalize=0.0, msckf_prune_empty_states=0.0)
+        for k in range(nf):
+            t0 = time.perf_counter()
+            rd = tr.imu_for_frame(k)
+            o.propagate(rd); sid2 += len(rd); t1 = time.perf_counter()
+            o.augmentState(sid2, float(k)); t2 = time.perf_counter()
+            o.update(*st[k]["cur"]); t3 = time.perf_counter()
+            o.addFeatures(*st[k]["new"]); t4 = time.perf_counter()
+            o.marginalize(); t5 = time.perf_counter()
+            o.pruneEmptyStates(); t6 = time.perf_counter()
+            if k >= timed_from:
+                t_acc += t6 - t0
+                for nm, dt in zip(stages, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5)):
+                    stages[nm] += dt
+        n_t = nf - timed_from
+        return n_t / t_acc, {k2: 1e6 * v / n_t for k2, v in stages.items()}
+    lean = po.Oracle(po.F64, po.LEAN)
+    lean_rate, lean_stage = cpu_run(lean, N + W)
+    cpu = None
+    if not args.no_cpu_baseline:
+        if po.ref_available():
+            ref_rate, ref_stage = cpu_run(po.Oracle(po.F64, impl="ref"), N + W)
+            cpu = {"value": ref_rate, "unit": "updates/s", "cores": 1, "kind": "reference",
+                   "sample": "%d filter updates of one double-precision filter (10-cam window, 50 tracks), the reference's own msckf.h over oracle/ref_shim "
+                             "(not Eigen: neither Eigen nor Boost is installed), one thread" % K,
+                   "stage_us": ref_stage, "lean_value": lean_rate, "lean_stage_us": lean_stage}
+        else:
+            cpu = {"value": lean_rate, "unit": "updates/s", "cores": 1, "kind": "port", "sample": "%d filter updates, oracle LEAN mode (lib_ref.so not present)" % K, "stage_us": lean_stage}
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as Hh
+    err_state = Hh.rel(np.array(first["imu"]), lean.getImuState()[:16])
+    err_capi = Hh.state_errors(imu_c, lean.getImuState(), f.getCamStates()[0], lean.getCamStates()[0], P_c, lean.getCovariance())
+    trP = float(np.trace(lean.getCovariance()))
+    out = {
+        "metric": "filter updates/sec (%d-cam window, %d feats)" % (N, F), "value": value, "unit": "updates/s", "n_gpus": 1, "steps": K, "warmup": W,
+        "ms_per_step": 1e3 / value, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": c["workload"], "name": "cfg2", "cam_window": N, "tracks_per_update": F, "trajectories_per_gpu": 1, "imu_per_update": K_IMU,
+                   "parallelism": "one trajectory, one stream: every call of the reference's API is a call into libmsckf_hip.so",
+                   "noise": "isotropic (f_u = f_v)"},
+        "latency_us": {"per_update_mean": float(frame_us.mean()), "per_update_median": float(np.median(frame_us)), "per_update_max": float(frame_us.max()),
+                       "stage_mean": first["stage_us"],
+                       "note": "host wall clock around each call of the shim, as the reference's StageTiming (asl_msckf.cpp:229-296); imu_prop = 10 x "
+                               "(propagate + by-value getImuState: a device round trip each); read_state = getImuState + getNumCamStates after the image"},
+        "repeats": {"runs": len(rep_vals), "values": rep_vals, "median": float(np.median(rep_vals)), "min": float(np.min(rep_vals)), "max": float(np.max(rep_vals)),
+                    "note": "value = the first run; every run replays fill + warm-up untimed and times the same K frames"},
+        "roofline": {"bound": "mfma" if dom_stage != "feature" else "valu", "kernel": dom_kernel, "achieved": model[dom_stage]["tflops"], "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s",
+                     "frac": model[dom_stage]["frac"], "traffic": None,
+                     "traffic_note": "no PMC pass for this configuration: a single trajectory's kernels are one workgroup (or one wavefront per track) each, "
+                                     "bound by launch and dependency latency -- see latency_us",
+                     "kernel_ms_per_update": model[dom_stage]["ms"], "executed_model": model, "stage_ms_per_update": stage_ms, "event_pair_overhead_ms": ev_pair_ms,
+                     "note": "frac = FLOP of the algorithm as built for the stage (executed_flops_update) / HIP-event time of the stage / f64 peak"},
+        "cpu_baseline": cpu,
+        "parity": {"shim_run_vs_oracle_state_rel": err_state, "capi_run_vs_oracle": err_capi,
+                   "trace_P_rel": abs(first["trace_P"] - trP) / trP, "bar": 1e-6},
+    }
+    print(json.dumps(out))
+
+
 def pmc_block(kernel):
     """HBM bytes per launch and executed-instruction figures of a kernel from the committed rocprofv3 PMC passes
     (separate --pmc runs of this same command, profiles/pmc_traffic.json written by scripts/rocpd_pmc.py; FETCH_SIZE is
-    doubled as MI355X_MICROARCH.md prescribes for gfx950) and where they came from (profile tag + commit of the passes:
-    they are NOT collected in the run that prints them).  (None, None) if absent."""
+    doubled as MI355X_MICROARCH.md prescribes for gfx950) and where they came from (profile tag, commit and kernel-source
+    hash of the passes: they are NOT collected in the run that prints them).  The counters are only reported when the
+    passes ran on the kernel sources this run was built from (csrc_hash); otherwise (None, meta with the reason)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
-        return None, None
+        return None, {"stale": True, "reason": "profiles/pmc_traffic.json absent"}
     try:
         t = json.load(open(path))
         meta = dict(t.get("_meta", {}), file="profiles/pmc_traffic.json", collected="separate rocprofv3 --pmc passes, not this run")
+        now = csrc_hash()
+        if meta.get("csrc_hash") != now:
+            meta.update(stale=True, csrc_hash_now=now,
+                        reason="the PMC passes ran on other kernel sources (csrc_hash %s) than this run's (%s): traffic / executed withheld" % (meta.get("csrc_hash"), now))
+            return None, meta
+        meta["stale"] = False
         for k2, v in t.items():
             if k2 == kernel or k2.startswith(kernel):
                 return v, meta
-    except Exception:
-        pass
-    return None, None
+    except Exception as e:
+        return None, {"stale": True, "reason": "profiles/pmc_traffic.json unreadable: %r" % (e,)}
+    return None, meta
 
 
 def _oracle_window(o, tr, k, N):
@@ -541,7 +714,7 @@ def ate_vs_reference(trajs, sample, p_dev, n_run, N, anisotropic=False, literal=
         if whiten:
             o.setWhiten(True)
         elif anisotropic:
-            o.setTinyRowTol(1e-3)
+            o.setTinyRowTol(8e-4)
         o.initialize(tr.cfg, tr.imu0)
         for k in range(n_run):
             _oracle_window(o, tr, k, N)
@@ -564,7 +737,7 @@ def ate_vs_reference(trajs, sample, p_dev, n_run, N, anisotropic=False, literal=
     if anisotropic:
         out["ate_vs_ref_literal_m"] = rms([p_dev[b] - res[b] for b in sample])
         out["ate_vs_ref_whitened_m"] = rms([p_dev[b] - resw[b] for b in sample])
-        out["ate_vs_ref_is"] = "literal restatement (zero-tail tolerance 1e-3)" if literal else "pre-whitened restatement"
+        out["ate_vs_ref_is"] = "literal restatement (zero-tail tolerance 8e-4)" if literal else "pre-whitened restatement"
     return out
 
 
@@ -610,6 +783,8 @@ def cpu_baseline(tr, frame, budget_s, N):
             f.setMode(po.FAITHFUL)
     t_f = po.time_updates(filters, min(cores, n_f), 1, rd, frame, fr["M"], fr["slots"], fr["obs"], 1)
     return {"value": n_f / t_f, "unit": "updates/s", "cores": min(cores, n_f), "kind": kind,
+            "implementation": "the reference's own msckf.h / types.h / matrix_utils.h, unmodified, compiled against oracle/ref_shim (this repository's "
+                              "Eigen / Boost stand-in with naive GEMMs: Eigen is not installed), NOT Eigen" if kind == "reference" else "oracle restatement, FAITHFUL mode",
             "sample": "%d filters x 1 filter update (30-cam window, 200 tracks, f32), %s, %.1f s wall" % (n_f, what, t_f),
             "lean_value": lean_rate, "lean_cores": cores,
             "lean_sample": "%d filters x 1 update, oracle LEAN mode (thin QR, no dense R_o), %.2f s wall" % (len(lean), t_lean)}

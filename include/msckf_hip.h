@@ -208,15 +208,16 @@ int msckf_hip_set_feature_overlap(msckf_hip_handle h, int on);
 /* Anisotropic pixel noise, u_var_prime != v_var_prime (see the header comment): mode 0 (default) the reference's
  * R_o_j = A_j^T R_j A_j / HouseholderQR in column order / R_n = Q_1^T R_o Q_1 on the device (msckf.h:423-431, 1343-1366;
  * f64, one workgroup per trajectory), its result handed to the update as the information matrix
- * [T_H | r_n]^T R_n^-1 [T_H | r_n]; mode 1 rows pre-whitened by 1/sigma (generalized least squares).  tail_tol: zero-tail tolerance of mode 0, < 0 = default (1e-10 double, 1e-3 float), 0 = the reference's
+ * [T_H | r_n]^T R_n^-1 [T_H | r_n]; mode 1 rows pre-whitened by 1/sigma (generalized least squares).  tail_tol: zero-tail tolerance of mode 0, < 0 = default (1e-10 double, 8e-4 float), 0 = the reference's
  * rule to the letter.  Applies to every trajectory of the handle, initialized or not.  -ENOMEM when the stack does not fit
  * (f_cap (2 m_cap - 3) x (6 n_cap + 1) doubles per trajectory). */
 int msckf_hip_set_anisotropic_noise(msckf_hip_handle h, int mode, double tail_tol);
 /* last marginalize of trajectory b on the literal route: out[0..5] = stacked rows m, kept rows r of R (msckf.h:1347),
  * Householder steps that reflected, steps whose tail fell under tail_tol, route taken (1: from the Cholesky factor of
  * H_o^T H_o minus the rows handed through -- the usual shape of a stack; 2: the reflector sweep over the dense stack),
- * rows handed through verbatim (15 + 6 x leading cameras nobody saw). */
-int msckf_hip_literal_info(msckf_hip_handle h, int b, int* out6);
+ * rows handed through verbatim (15 + 6 x leading cameras nobody saw), and of the shape check of route 1: -100 log10 of the
+ * smallest pivot / |column|^2 taken as independent and of the largest taken as dependent. */
+int msckf_hip_literal_info(msckf_hip_handle h, int b, int* out8);
 
 #ifdef __cplusplus
 }

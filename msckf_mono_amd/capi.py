@@ -306,9 +306,9 @@ class Batch:
         _chk(self.L.msckf_hip_set_anisotropic_noise(self.h, int(mode), C.c_double(float(tail_tol))))
 
     def literal_info(self, b):
-        o = np.zeros(6, dtype=np.int32)
+        o = np.zeros(8, dtype=np.int32)
         _chk(self.L.msckf_hip_literal_info(self.h, int(b), o.ctypes.data_as(_ip)))
-        return dict(zip(["m_rows", "kept_rows", "reflected", "skipped_by_tolerance", "route", "rows_handed_through"], o.tolist()))
+        return dict(zip(["m_rows", "kept_rows", "reflected", "skipped_by_tolerance", "route", "rows_handed_through", "min_indep_mlog", "max_dep_mlog"], o.tolist()))
 
     def profile_enable(self, on=True):
         _chk(self.L.msckf_hip_profile_enable(self.h, 1 if on else 0))

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(1024) void k_literal(Dev<S> d, int b0, int nb) {
   a.ldg = L.ldg; a.G = L.G + (long)b * L.ldg * L.r_cap;
   a.ldz = L.ldz; a.Z = L.Z + (long)b * L.ldz * L.ldz;
   a.Lam = d.Lam + (long)b * d.ldR * d.ldR; a.ldL = d.ldR;
-  a.info = L.info + (long)b * 6;
+  a.info = L.info + (long)b * 8;
   a.LamIn = a.Lam; a.lam_part = d.lam_part; a.gram_parts = (d.compress == 3 && d.ldR <= 192 && d.lam_part > 0) ? (d.gram_parts >= 3 ? d.gram_parts : 3) : 1;
   a.inv = d.trk_inv + (long)b * d.f_cap * d.n_cap; a.inv_stride = d.n_cap;
   a.W = L.W + (long)b * L.w_stride;

@@ -213,7 +213,7 @@ struct Batch : BatchBase {
   // the device (kernels_literal.hip; default), 1 = rows pre-whitened by 1/sigma (generalized least squares, unit noise)
   int aniso_mode = 0;
   int lit_route = 0;         // 0 fast where the stack has the shape for it, else general; 1 general only; 2 fast only (tests)
-  double lit_tol = -1;       // zero-tail tolerance of the literal route; < 0: 1e-10 (double) / 1e-3 (float: H_x is float-rounded)
+  double lit_tol = -1;       // zero-tail tolerance of the literal route; < 0: 1e-10 (double) / 8e-4 (float: H_x is float-rounded)
   std::vector<double> h_uv;  // [B][2] u_var', v_var' as initialize() got them
   std::vector<char> h_lit;   // [B] trajectory runs the literal route
   int n_lit = 0;
@@ -412,7 +412,7 @@ struct Batch : BatchBase {
     L.ldx = ((f_cap * std::max(2 * m_cap - 3, 1) + 7) / 8) * 8;
     L.r_cap = d.n6cap + 63; L.ldg = f_cap * m_cap + 8; L.ldz = L.r_cap + (int)n1; L.kept_stride = 6 * (d.n6cap + 16) + 64;   // 63 = LIT_ZCAP (literal_core.h)
     L.w_stride = (long)(n1 * n1 + 63 * n1 + 63 * 2 * (size_t)m_cap);
-    L.tol = lit_tol >= 0 ? lit_tol : (sizeof(S) == 4 ? 1e-3 : 1e-10);
+    L.tol = lit_tol >= 0 ? lit_tol : (sizeof(S) == 4 ? 8e-4 : 1e-10);
     L.route = lit_route;
     int rc = 0;
     rc |= dalloc(&L.X, Bz * L.ldx * n1); rc |= dalloc(&L.tau, Bz * n1);
@@ -420,7 +420,7 @@ struct Batch : BatchBase {
     rc |= dalloc(&L.row0, Bz * (f_cap + 1)); rc |= dalloc(&L.obs0, Bz * (f_cap + 1)); rc |= dalloc(&L.otrk, Bz * L.ldg); rc |= dalloc(&L.kept, Bz * L.kept_stride);
     rc |= dalloc(&L.TH, Bz * L.r_cap * n1); rc |= dalloc(&L.G, Bz * (size_t)L.ldg * L.r_cap); rc |= dalloc(&L.Z, Bz * (size_t)L.ldz * L.ldz);
     rc |= dalloc(&L.W, Bz * (size_t)L.w_stride);
-    rc |= dalloc(&L.info, Bz * 6);
+    rc |= dalloc(&L.info, Bz * 8);
     if (rc) { L.X = nullptr; return fail(-ENOMEM, "work space of the literal anisotropic route (msckf_hip_set_anisotropic_noise(h, 1, 0) selects pre-whitening)"); }
     return 0;
   }
@@ -428,7 +428,7 @@ struct Batch : BatchBase {
     if (mode < 0 || mode > 1) return fail(-EINVAL, "mode: 0 the reference's R_n = Q_1^T R_o Q_1 on the device, 1 pre-whitened rows");
     HIPCHK(hipSetDevice(device));
     aniso_mode = mode; lit_tol = tol;
-    d.lit.tol = tol >= 0 ? tol : (sizeof(S) == 4 ? 1e-3 : 1e-10);
+    d.lit.tol = tol >= 0 ? tol : (sizeof(S) == 4 ? 8e-4 : 1e-10);
     d.lit.route = lit_route;
     for (int b = 0; b < B; ++b) {
       if (!traj[b].initialized) continue;
@@ -442,9 +442,9 @@ struct Batch : BatchBase {
   }
   int lit_info(int b, int* out4) override {
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
-    if (!d.lit.info) { for (int i = 0; i < 6; ++i) out4[i] = 0; return 0; }
+    if (!d.lit.info) { for (int i = 0; i < 8; ++i) out4[i] = 0; return 0; }
     HIPCHK(hipSetDevice(device));
-    HIPCHK(hipMemcpyAsync(out4, d.lit.info + (size_t)b * 6, 6 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out4, d.lit.info + (size_t)b * 8, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return 0;
   }

@@ -6,6 +6,7 @@ OUT=/root/repo/gpurun_out/$TAG
 set -x
 mkdir -p $OUT
 export PMC_TAG=$TAG PMC_COMMIT=${PMC_COMMIT:-unknown}
+export PMC_CSRC_HASH=$(python -c 'import bench; print(bench.csrc_hash())')
 cd /tmp && export TMPDIR=/tmp
 COMMON="--steps 10 --warmup 3 --no-cpu-baseline --no-early-accept-pass --no-upload-pass --repeats 1 --streams 1"
 rocprofv3 --kernel-trace --stats -d /tmp/p1 -o r -- python /root/repo/bench.py $COMMON > /tmp/b1.log 2>&1

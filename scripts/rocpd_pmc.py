@@ -55,7 +55,7 @@ def main():
                 tr[key]["executed"] = ex
     if tr:
         # provenance: which profile round and which commit the passes ran on (bench.py prints it beside the numbers)
-        tr["_meta"] = dict(tag=os.environ.get("PMC_TAG", ""), commit=os.environ.get("PMC_COMMIT", ""),
+        tr["_meta"] = dict(tag=os.environ.get("PMC_TAG", ""), commit=os.environ.get("PMC_COMMIT", ""), csrc_hash=os.environ.get("PMC_CSRC_HASH", ""),
                            command="bench.py --steps 10 --warmup 3 --no-upload-pass --streams 1 under rocprofv3 --pmc (one pass per counter set)")
         json.dump(tr, open(os.path.join(os.path.dirname(out) or ".", "pmc_traffic.json"), "w"), indent=1)
 

@@ -12,7 +12,7 @@
 extern "C" int lit_host_compress(int F, int m_cap, int N, const int* included, const int* M, const int* slots /*[F][m_cap]*/,
                                  const double* Hx /*[F][m_cap][12]*/, const double* rw /*[F][2 m_cap]*/, double u_var, double v_var,
                                  double tol, int route, const double* LamIn, double* Lam /*[(6N+1)^2], (hi, lo) at hi * (6N+1) + lo*/,
-                                 int* info6, double* TH_out /*[(6N+15) x (6N+1)] column-major or null*/) {
+                                 int* info8, double* TH_out /*[(6N+15) x (6N+1)] column-major or null*/) {
   using namespace msckf::lit;
   const int n = 6 * N;
   int m = 0, mobs = 0;
@@ -37,7 +37,7 @@ extern "C" int lit_host_compress(int F, int m_cap, int N, const int* included, c
   std::vector<double> W((size_t)(n + 1) * (n + 1) + (size_t)LIT_ZCAP * (n + 1) + (size_t)LIT_ZCAP * 2 * m_cap);
   a.W = W.data();
   a.LamIn = LamIn; a.lam_part = 0; a.gram_parts = 1;
-  a.Lam = Lam; a.ldL = n + 1; a.info = info6;
+  a.Lam = Lam; a.ldL = n + 1; a.info = info8;
   Ctx c;
   literal_compress(c, a, route);
   if (TH_out) for (size_t i = 0; i < (size_t)(n + 15) * (n + 1); ++i) { const size_t col = i / (n + 15), row = i % (n + 15); TH_out[i] = TH[row + (size_t)a.r_cap * col]; }

@@ -72,7 +72,7 @@ def gram_of_the_stack(N, M, inc, slots, hx, r):
 def host_compress(lit, N, M, inc, slots, hx, r, u, v, tol, route=1):
     F, m_cap = hx.shape[0], hx.shape[1]
     n = 6 * N
-    Lam = np.zeros((n + 1, n + 1)); info = np.zeros(6, dtype=np.int32)
+    Lam = np.zeros((n + 1, n + 1)); info = np.zeros(8, dtype=np.int32)
     TH = np.zeros((n + 1, n + 15))
     Lin = np.ascontiguousarray(gram_of_the_stack(N, M, inc, slots, hx, r)) if route != 1 else None
     rc = lit.lit_host_compress(F, m_cap, N, np.ascontiguousarray(inc, dtype=np.int32).ctypes.data_as(_ip),
