@@ -115,6 +115,8 @@ def make_trajectories(c, rank, n_frames):
     are initialised in this process (fork)."""
     from concurrent.futures import ProcessPoolExecutor
     nu = min(c.get("uniq", c["B"]), c["B"])            # distinct scenarios (cfg5: the batch repeats them)
+    if os.environ.get("BENCH_SAME_SEEDS"):              # test hook (tests/test_bench_multirank.py): every rank runs rank 0's trajectories
+        rank = 0
     jobs = [(c["cid"], rank * nu + b, c["N"], c["F"], n_frames, c["iso"], (rank * nu + b) % c["nseq"]) for b in range(nu)]
     nproc = max(1, min(32, (os.cpu_count() or 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))), len(jobs)))
     if nproc == 1:
@@ -406,6 +408,17 @@ def main():
         dist.all_reduce(t_all, op=dist.ReduceOp.SUM)
         acc_all = t_all.cpu().numpy()
     ate = float(np.sqrt(acc_all[0] / max(acc_all[1], 1.0)))
+    # which ranks took part, and (test hook BENCH_SAME_SEEDS: every rank ran the same trajectories) whether they all ended in
+    # the same bits -- one all-gather of the final positions, off the timed path
+    ranks_seen, ranks_equal = [rank], None
+    if dist is not None:
+        mine = torch.tensor(np.concatenate([[float(rank)], np.concatenate(p_est)]), device=red_dev, dtype=torch.float64)
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        got = [g.cpu().numpy() for g in got]
+        ranks_seen = sorted(int(g[0]) for g in got)
+        if os.environ.get("BENCH_SAME_SEEDS"):
+            ranks_equal = bool(all(np.array_equal(g[1:], got[0][1:]) for g in got))
 
     if rank == 0:
         updates = world * B_TRAJ * K
@@ -497,6 +510,7 @@ def main():
                          "whole_update_alg_equivalent_ratio": whole_frac,
                          "hbm_frac_alg": by * value / 1e9 / world / PEAK_HBM_GBS,
                          "stage_ms_per_step": stage_ms, "stage_ms_per_step_raw_event_pairs": stage_raw, "event_pair_overhead_ms": ev_pair_ms},
+            "ranks_seen": ranks_seen, "ranks_bit_identical_for_equal_seeds": ranks_equal,
             "gate_pass_rate": pass_rate, "ate_m": ate, "ate_per_sequence_m": [float(x) for x in ate_seq],
             "scenario_gen_s": t_gen, "scenario_upload_s": t_up,
             "with_gate_early_accept": None if early_ms is None else {

@@ -97,14 +97,26 @@ def _rot_to_quat(R):
     return sc.rot_to_quat(np.asarray(R, dtype=np.float64))
 
 
+def _load_sensor_yaml(path):
+    """sensor.yaml as the reference reads it: through cv::FileStorage (asl_readers.h:54-63), which insists on the OpenCV header
+    line `%YAML:1.0` (the reference's README has the user add it to every EuRoC sensor.yaml).  That line is not a YAML
+    directive (`%YAML 1.0` would be), so it is dropped before parsing; files without it parse as well."""
+    with open(path) as f:
+        text = f.read()
+    lines = text.splitlines()
+    if lines and lines[0].strip().startswith("%YAML"):
+        lines = lines[1:]
+    return yaml.safe_load("\n".join(lines))
+
+
 def read_dataset(mav):
     """Parse an ASL `mav0` directory -> dict(imu_t, readings[n,7], cam (q_CI, p_C_I, intrinsics), cam_t, gt, tracks)."""
-    imu_cfg = yaml.safe_load(open(os.path.join(mav, "imu0", "sensor.yaml")))
+    imu_cfg = _load_sensor_yaml(os.path.join(mav, "imu0", "sensor.yaml"))
     dT = 1.0 / float(imu_cfg["rate_hz"])                       # Q6: the reader sets dT = 1/rate_hz (asl_readers.cpp:170-171,202)
     rows = _read_csv(os.path.join(mav, "imu0", "data.csv"), 7)
     imu_t = np.array([int(r[0]) for r in rows], dtype=np.int64)
     readings = np.array([[float(x) for x in r[1:7]] + [dT] for r in rows])
-    cam_cfg = yaml.safe_load(open(os.path.join(mav, "cam0", "sensor.yaml")))
+    cam_cfg = _load_sensor_yaml(os.path.join(mav, "cam0", "sensor.yaml"))
     T = np.array(cam_cfg["T_BS"]["data"], dtype=np.float64).reshape(4, 4)
     q_bs = _rot_to_quat(T[:3, :3])
     q_CI = np.array([q_bs[0], -q_bs[1], -q_bs[2], -q_bs[3]])   # Quaternion(R_BS).inverse()   asl_readers.cpp:31

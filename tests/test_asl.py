@@ -33,6 +33,38 @@ def test_round_trip(dataset):
     assert np.allclose(s0[:19], tr.imu0[:19], atol=1e-12)
 
 
+def test_reader_parses_the_original_euroc_layout():
+    """tests/golden/euroc_layout/mav0: a few lines typed in the ORIGINAL EuRoC on-disk layout (not written by asl.write_dataset)
+    -- sensor.yaml with the `%YAML:1.0` line cv::FileStorage needs (asl_readers.h:54-63, README), comments, multi-line T_BS
+    flow sequences and trailing `#fu, fv, cu, cv`; CSVs with EuRoC's header lines and CRLF line ends -- read the way
+    datasets/asl_readers.cpp:12-75, 141-206, 244-342 reads them."""
+    import os
+    mav = os.path.join(H.ROOT, "tests", "golden", "euroc_layout", "mav0")
+    ds = asl.read_dataset(mav)
+    # imu0: t, w(3), a(3); dT = 1 / rate_hz whatever the stamps say (asl_readers.cpp:170-171, 202)
+    assert ds["imu_t"].tolist() == [1403636579758555392, 1403636579763555584, 1403636579768555520, 1403636579773555456, 1403636579778555392]
+    assert ds["readings"].shape == (5, 7) and np.all(ds["readings"][:, 6] == 1.0 / 200)
+    assert ds["readings"][0, 0] == -0.099134701513277898 and ds["readings"][4, 5] == -2.484351333333333
+    # cam0: q_CI = Quaternion(R_BS).inverse(), p_C_I = p_BS, intrinsics fu fv cu cv (asl_readers.cpp:27-50)
+    T = np.array([[0.0148655429818, -0.999880929698, 0.00414029679422, -0.0216401454975],
+                  [0.999557249008, 0.0149672133247, 0.025715529948, -0.064676986768],
+                  [-0.0257744366974, 0.00375618835797, 0.999660727178, 0.00981073058949]])
+    assert ds["cam"]["intrinsics"] == [458.654, 457.296, 367.215, 248.375] and ds["cam"]["rate_hz"] == 20
+    assert np.allclose(sc.quat_to_rot(ds["cam"]["q_CI"]), T[:, :3].T, atol=1e-9) and np.array_equal(ds["cam"]["p_C_I"], T[:, 3])
+    assert ds["cam_t"].tolist() == [1403636579763555584, 1403636579813555456]
+    # ground truth: t, p, q(w,x,y,z), v, b_w, b_a; q_IG = q^-1, v <- q * v (asl_readers.cpp:338-339)
+    g = ds["gt"]
+    assert g["t"][0] == 1403636580838555648 and np.array_equal(g["p"][0], [4.688319, -1.786938, 0.783338])
+    q = np.array([0.534108, -0.153029, -0.827383, -0.082152])
+    assert np.allclose(g["q_IG"][0], q * [1, -1, -1, -1] / (q @ q), atol=1e-15)
+    assert np.allclose(g["v"][0], sc.quat_to_rot(q) @ np.array([-0.027876, 0.033207, 0.800006]), atol=1e-15)
+    assert np.array_equal(g["b_g"][2], [-0.003172, 0.021267, 0.078502]) and np.array_equal(g["b_a"][2], [-0.025266, 0.136696, 0.075593])
+    assert ds["tracks"] == {}                      # no front-end track dump in an original dataset
+    # the runner's parameters come out of the same files (asl_msckf.cpp:73-117): EuRoC's f_u != f_v
+    cfg = asl.filter_config_from_dataset(ds)
+    assert cfg["u_var_prime"] == (7.0 / 458.654) ** 2 and cfg["v_var_prime"] == (7.0 / 457.296) ** 2
+
+
 def test_runner_equals_scenario_loop(dataset, oracle_lib):
     po = oracle_lib
     tr, ds = dataset

@@ -74,3 +74,23 @@ def test_cfg2_single_trajectory_latency_config_runs():
     assert d["roofline"]["peak"] == 78.6 and 0 < d["roofline"]["frac"] < 1
     assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["cores"] == 1
     assert d["parity"]["shim_run_vs_oracle_state_rel"] < 1e-6 and max(d["parity"]["capi_run_vs_oracle"].values()) < 1e-6
+
+
+@pytest.mark.gpu
+def test_eight_rank_rehearsal_on_one_device():
+    """The driver's 8-GPU launch cannot be tried from here (one GPU per box): eight ranks share device 0 instead (gloo, 8
+    trajectories each), which exercises what an 8-rank node does to the HOST -- 8 x (uploading thread + 4 enqueue threads) on
+    disjoint cores taken from LOCAL_RANK, eight scenario pools, the max-over-ranks timing and the per-sequence ATE all-reduce
+    -- and, with every rank given the same seeds, that all ranks end in the same bits.  Not a scaling measurement."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BENCH_DIST_BACKEND="gloo", BENCH_DEVICE_OVERRIDE="0", BENCH_SAME_SEEDS="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--trajectories", "8", "--steps", "3", "--warmup", "1", "--repeats", "2",
+           "--no-cpu-baseline", "--no-early-accept-pass"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == list(range(8)) and d["ranks_bit_identical_for_equal_seeds"] is True
+    assert abs(d["value"] - 8 * 8 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
+    assert d["config"]["host_affinity"] is None or len(d["config"]["host_affinity"]) == 5
