@@ -52,6 +52,7 @@ enum { STAT_ERR_NCAP = 1, STAT_ERR_PIVOT = 2 };
 struct LitBufs {
   double* X = nullptr; double* tau = nullptr; double* Vf = nullptr; double* Tf = nullptr; double* TH = nullptr; double* G = nullptr; double* Z = nullptr; double* W = nullptr;
   int* row0 = nullptr; int* obs0 = nullptr; int* otrk = nullptr; int* kept = nullptr; int* info = nullptr;
+  long long* tim = nullptr;   // [B][16] phase stamps of k_literal (100 MHz wall clock), only with MSCKF_HIP_LITERAL_TIMERS=1
   int ldx = 0, r_cap = 0, ldg = 0, ldz = 0, kept_stride = 0;
   long w_stride = 0;
   int route = 0;     // 0: fast where the stack has the shape for it, else general; 1: general only; 2: fast only (tests)

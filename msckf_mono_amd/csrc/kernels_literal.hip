@@ -25,7 +25,7 @@ __global__ __launch_bounds__(1024) void k_literal(Dev<S> d, int b0, int nb) {
   if (st[STAT_MROWS] == 0) return;
   __shared__ double red[20];
   lit::Ctx c;
-  c.tid = threadIdx.x; c.nt = blockDim.x; c.lane = threadIdx.x & 63; c.wave = threadIdx.x >> 6; c.nw = blockDim.x >> 6; c.red = red;
+  c.tid = threadIdx.x; c.nt = blockDim.x; c.lane = threadIdx.x & 63; c.wave = threadIdx.x >> 6; c.nw = blockDim.x >> 6; c.red = red; c.tim = d.lit.tim ? d.lit.tim + (long)b * 16 : nullptr;
   const LitBufs& L = d.lit;
   const int n1 = d.n6cap + 1;
   lit::Args<S> a;

@@ -46,11 +46,17 @@ template <class F> LIT_FN double wg_max(const Ctx&, long lo, long hi, F f) { dou
 template <class F> LIT_FN void wave_for(const Ctx&, long lo, long hi, F f) { for (long j = lo; j < hi; ++j) f(j); }
 template <class F> LIT_FN void lane_for(const Ctx&, long lo, long hi, F f) { for (long i = lo; i < hi; ++i) f(i); }
 template <class F> LIT_FN double wave_sum_range(const Ctx&, long lo, long hi, F f) { double s = 0; for (long i = lo; i < hi; ++i) s += f(i); return s; }
+// NV sums over a row range at once: f(i, v) adds row i's contribution to v[0..NV)
+template <int NV, class F> LIT_FN void wave_sum_vec(const Ctx&, long lo, long hi, double (&out)[NV], F f) {
+  for (int k = 0; k < NV; ++k) out[k] = 0;
+  for (long i = lo; i < hi; ++i) f(i, out);
+}
 LIT_FN bool first_lane(const Ctx&) { return true; }
 LIT_FN bool first_thread(const Ctx&) { return true; }
+LIT_FN void tick(const Ctx&, int) {}
 #else
 #define LIT_FN __device__ __forceinline__
-struct Ctx { int tid, nt, lane, wave, nw; double* red; };   // red: LDS scratch, nw + 2 doubles
+struct Ctx { int tid, nt, lane, wave, nw; double* red; long long* tim; };   // red: LDS scratch, nw + 2 doubles; tim: phase stamps (100 MHz) or null
 LIT_FN void barrier(const Ctx&) { __syncthreads(); }
 template <class F> LIT_FN void par_for(const Ctx& c, long n, F f) { for (long i = c.tid; i < n; i += c.nt) f(i); }
 template <class F> LIT_FN double wg_sum(const Ctx& c, long lo, long hi, F f) {
@@ -82,8 +88,17 @@ template <class F> LIT_FN double wave_sum_range(const Ctx& c, long lo, long hi, 
   for (long i = lo + c.lane; i < hi; i += 64) s += f(i);
   return wave_sum(s);
 }
+template <int NV, class F> LIT_FN void wave_sum_vec(const Ctx& c, long lo, long hi, double (&out)[NV], F f) {
+  double v[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = 0;
+  for (long i = lo + c.lane; i < hi; i += 64) f(i, v);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) out[k] = wave_sum(v[k]);
+}
 LIT_FN bool first_lane(const Ctx& c) { return c.lane == 0; }
 LIT_FN bool first_thread(const Ctx& c) { return c.tid == 0; }
+LIT_FN void tick(const Ctx& c, int slot) { if (c.tim && c.tid == 0) c.tim[slot] = (long long)wall_clock64(); }
 #endif
 
 // One trajectory's inputs (what k_feature / k_select left behind) and work space.  HT: scalar type of the Jacobian blocks.
@@ -121,7 +136,7 @@ struct Args {
   const double* LamIn;      // [H_o | r_o]^T [H_o | r_o], element (hi, lo), lo <= hi <= n, at LamIn[hi * ldL + lo] (+ split-K copies)
   long lam_part; int gram_parts;   // copies of LamIn lam_part doubles apart: block column lo / 64 came in min(lo / 64 + parts - 2, parts) partial sums
   const signed char* inv; int inv_stride;   // observation index of camera slot s in track t at inv[t * inv_stride + s], -1 = not observed
-  double* W;                // scratch: (n + 1)^2 + ZCAP (n + 1) + ZCAP 2 m_cap doubles
+  double* W;                // scratch: (n + 1)^2 + ZCAP (n + 1) + ZCAP 2 m_cap + F 18 m_cap + 3 ldg doubles
   // ---- outputs
   double* Lam; int ldL;     // Lam^(hi, lo), lo <= hi <= n, at Lam[hi * ldL + lo]  (what k_chol_mfma / lam_hat read)
   int* info;                // [8]: stacked rows m, kept rows r, reflected steps, steps skipped by the tolerance, route (1 fast, 2 general), rows handed
@@ -193,19 +208,39 @@ LIT_FN void information_from_compressed(const Ctx& c, const Args<HT>& a, int n, 
   const long ldz = a.ldz;
   double* Z = a.Z;
   const double dlt = a.u_var - a.v_var;
-  // one wavefront per element of the lower triangle, lanes along the stacked observations (G is column-major: coalesced)
-  wave_for(c, 0, (long)nr * nr, [&](long e) {
-    const int j = (int)(e / nr), i = (int)(e - (long)j * nr);
-    if (i < j) return;
-    const double* gi = a.G + (long)a.ldg * i; const double* gj = a.G + (long)a.ldg * j;
-    const double s = wave_sum_range(c, 0, mobs, [&](long o) { return gi[o] * gj[o]; });
-    if (first_lane(c)) Z[i + ldz * j] = dlt * s + (i == j ? a.v_var : 0.0);
+  // one wavefront per 4 x 4 tile of the lower triangle, lanes along the stacked observations (G is column-major: coalesced):
+  // eight column loads feed sixteen products (one load pair per product took 14 of the fast route's 27 ms)
+  const int ntile = (nr + 3) / 4;
+  wave_for(c, 0, (long)ntile * ntile, [&](long e) {
+    const int tj = (int)(e / ntile), ti = (int)(e - (long)tj * ntile);
+    if (ti < tj) return;
+    const double* gi[4]; const double* gj[4];
+    for (int q = 0; q < 4; ++q) {
+      const int ri = 4 * ti + q < nr ? 4 * ti + q : nr - 1, rj = 4 * tj + q < nr ? 4 * tj + q : nr - 1;
+      gi[q] = a.G + (long)a.ldg * ri; gj[q] = a.G + (long)a.ldg * rj;
+    }
+    double acc[16];
+    wave_sum_vec<16>(c, 0, mobs, acc, [&](long o, double (&v)[16]) {
+      const double x0 = gi[0][o], x1 = gi[1][o], x2 = gi[2][o], x3 = gi[3][o];
+      const double y0 = gj[0][o], y1 = gj[1][o], y2 = gj[2][o], y3 = gj[3][o];
+      v[0] += x0 * y0; v[1] += x0 * y1; v[2] += x0 * y2; v[3] += x0 * y3;
+      v[4] += x1 * y0; v[5] += x1 * y1; v[6] += x1 * y2; v[7] += x1 * y3;
+      v[8] += x2 * y0; v[9] += x2 * y1; v[10] += x2 * y2; v[11] += x2 * y3;
+      v[12] += x3 * y0; v[13] += x3 * y1; v[14] += x3 * y2; v[15] += x3 * y3;
+    });
+    if (first_lane(c))
+      for (int qi = 0; qi < 4; ++qi)
+        for (int qj = 0; qj < 4; ++qj) {
+          const int i = 4 * ti + qi, j = 4 * tj + qj;
+          if (i < nr && j <= i) Z[i + ldz * j] = dlt * acc[qi * 4 + qj] + (i == j ? a.v_var : 0.0);
+        }
   });
   par_for(c, (long)(n + 1) * nz, [&](long e) {
     const int j = (int)(e / (n + 1)), cc = (int)(e - (long)j * (n + 1));
     Z[(nr + cc) + ldz * j] = j < nr ? a.TH[j + (long)rc * cc] : 0.0;
   });
   barrier(c);
+  tick(c, 7);
   for (int k = 0; k < nr; ++k) {
     const double dk = Z[k + ldz * k];
     const double dinv = 1.0 / dk;
@@ -219,6 +254,7 @@ LIT_FN void information_from_compressed(const Ctx& c, const Args<HT>& a, int n, 
     });
     barrier(c);
   }
+  tick(c, 8);
   // ---- Lam^ (lower triangle incl. row n) where the blocked Cholesky reads it
   par_for(c, (long)(n + 1) * (n + 1), [&](long e) {
     const int hi = (int)(e / (n + 1)), lo = (int)(e - (long)hi * (n + 1));
@@ -462,6 +498,8 @@ LIT_FN bool literal_fast(const Ctx& c, const Args<HT>& a, const int m, const int
   double* C = a.W;                              // (n + 1)^2 column-major, lower triangle: Lam' -> L = R'^T (row n: Q'^T r')
   double* Xt = C + (long)n1 * n1;               // [LIT_ZCAP][n + 1] row-major: rows 0..z-1 of [H_o | r_o]
   double* At = Xt + (long)LIT_ZCAP * n1;        // [LIT_ZCAP][2 m_cap]: column i - row0 of A_j, for the z top rows
+  double* Bt = At + (long)LIT_ZCAP * 2 * a.m_cap;   // [F][3][6 m_cap]: rows 0..2 of Q_f^T H_x_j (compact: column 6 o + kk)
+  double* Qfu = Bt + (long)F * 18 * a.m_cap;    // [ldg][3]: Q_f(2o, 0..2) per stacked observation
   double* dcol = a.tau;                         // [n] |column|^2 of H_o (incl. the top rows)
   const int ks = n + 16;
   int* flag = a.kept + ks;                      // [ks] kept flags of top rows
@@ -469,6 +507,7 @@ LIT_FN bool literal_fast(const Ctx& c, const Args<HT>& a, const int m, const int
   int* kidx = a.kept + 3 * ks;                  // [ks] ordinal of a column among the independent ones, -1
   int* topt = a.kept + 4 * ks;                  // [LIT_ZCAP + 1] track of top row i
   int* shared = a.kept + 5 * ks;                // z, ok, r', skipped-active count
+  tick(c, 1);
   // ---- z and the tracks of the top rows
   if (first_thread(c)) {
     unsigned long long seen = 0;
@@ -514,6 +553,7 @@ LIT_FN bool literal_fast(const Ctx& c, const Args<HT>& a, const int m, const int
     xr[n] = sr;
   });
   barrier(c);
+  tick(c, 2);
   // ---- Lam' = H_o^T H_o - (top rows)^T (top rows), lower triangle incl. row n
   par_for(c, (long)n1 * n1, [&](long e) {
     const int lo = (int)(e / n1), hi = (int)(e - (long)lo * n1);
@@ -525,6 +565,7 @@ LIT_FN bool literal_fast(const Ctx& c, const Args<HT>& a, const int m, const int
     if (hi == lo && hi < n) dcol[hi] = full;
   });
   barrier(c);
+  tick(c, 3);
   // ---- Cholesky with the zero-tail rule in Gram form: the pivot of column k IS |tail|^2 of Householder step 15 + k
   // The pivot of column k is |tail|^2 of Householder step 15 + k, so the Householder rule itself decides: dependent iff
   // pivot <= tol^2 |column|^2.  What the f64 Gram matrix resolves (measured over the benchmark's sequences at a 30-camera
@@ -532,7 +573,9 @@ LIT_FN bool literal_fast(const Ctx& c, const Args<HT>& a, const int m, const int
   // earlier pivots amplify the rounding), columns that depend on the others only up to the float rounding of H_x at up to
   // 2e-7, independent ones from 2e-6.  Hence tol^2 no finer than 1e-7 here, and a pivot within 10 % of the threshold is left
   // to the general route's tail test.
-  const double t2a = a.tol * a.tol, lo2 = t2a > 1e-7 ? t2a : 1e-7, band = 0.1 * lo2;
+  // (Float Jacobians: the two populations overlap in weak geometry -- whichever way such a column is called is inside the
+  // float filter's own rounding, so the threshold decides and nothing is handed to the general route.)
+  const double t2a = a.tol * a.tol, lo2 = t2a > 1e-7 ? t2a : 1e-7, band = sizeof(HT) == 4 ? 0.0 : 0.1 * lo2;
   int ok = 1;
   double min_ind = 1.0, max_dep = 1e-300;
   for (int k = 0; k < n; ++k) {
@@ -560,6 +603,7 @@ LIT_FN bool literal_fast(const Ctx& c, const Args<HT>& a, const int m, const int
     });
     barrier(c);
   }
+  tick(c, 4);
   // ---- shape of the stack: the dependent columns must be the last of the observed ones
   if (first_thread(c)) {
     int rp = 0, nsk = 0, seen_skip = 0;
@@ -615,6 +659,34 @@ LIT_FN bool literal_fast(const Ctx& c, const Args<HT>& a, const int m, const int
     const int o = g - a.obs0[t];
     a.G[(long)a.ldg * k + g] = (a.otrk[g] == t) ? At[i * 2 * a.m_cap + 2 * o] : 0.0;
   });
+  tick(c, 5);
+  // ---- rows 0..2 of Q_f^T H_x_j per track and Q_f(2o, 0..2) per observation: with them a u-row of the projected Jacobian
+  // is three products per entry for every track that has no row among the first z (d = 3)
+  par_for(c, (long)F * 6 * a.m_cap, [&](long e) {
+    const int t = (int)(e / (6 * a.m_cap)), cc = (int)(e - (long)t * 6 * a.m_cap);
+    if (!(a.status[t] & a.inc_bit) || cc >= 6 * a.M[t]) return;
+    const double* V = a.Vf + (long)t * 2 * a.m_cap * 3;
+    const double* T = a.Tf + (long)t * 9;
+    const HT* hx = a.Hx + (long)t * a.m_cap * 12;
+    const int op = cc / 6, kk = cc - 6 * op;
+    const double h0 = (double)hx[op * 12 + kk], h1 = (double)hx[op * 12 + 6 + kk];
+    double sv[3], w[3];
+    for (int p2 = 0; p2 < 3; ++p2) sv[p2] = vf_at(V, 2 * op, p2) * h0 + vf_at(V, 2 * op + 1, p2) * h1;
+    for (int q = 0; q < 3; ++q) { double x = 0; for (int p2 = 0; p2 <= q; ++p2) x += T[p2 * 3 + q] * sv[p2]; w[q] = x; }
+    for (int q = 0; q < 3; ++q) {
+      const double hq = q == 2 * op ? h0 : (q == 2 * op + 1 ? h1 : 0.0);
+      Bt[((long)t * 3 + q) * 6 * a.m_cap + cc] = hq - (vf_at(V, q, 0) * w[0] + vf_at(V, q, 1) * w[1] + vf_at(V, q, 2) * w[2]);
+    }
+  });
+  par_for(c, mobs, [&](long g) {
+    const int t = a.otrk[g], o = (int)g - a.obs0[t];
+    const double* V = a.Vf + (long)t * 2 * a.m_cap * 3;
+    const double* T = a.Tf + (long)t * 9;
+    double tv[3];
+    for (int p2 = 0; p2 < 3; ++p2) tv[p2] = vf_at(V, 2 * o, 0) * T[0 * 3 + p2] + vf_at(V, 2 * o, 1) * T[1 * 3 + p2] + vf_at(V, 2 * o, 2) * T[2 * 3 + p2];
+    for (int q = 0; q < 3; ++q) Qfu[g * 3 + q] = (q == 2 * o ? 1.0 : 0.0) - (tv[0] * vf_at(V, q, 0) + tv[1] * vf_at(V, q, 1) + tv[2] * vf_at(V, q, 2));
+  });
+  barrier(c);
   // ---- G, the other columns: x = (u-row of A_b A_b^T H_x) R'^-1 per stacked observation, 16 columns at a time
   par_for(c, mobs, [&](long g) {
     const int t = a.otrk[g], o = (int)g - a.obs0[t], M = a.M[t], R2 = 2 * M, rho = R2 - 3;
@@ -648,7 +720,21 @@ LIT_FN bool literal_fast(const Ctx& c, const Args<HT>& a, const int m, const int
     for (int k = 0; k < n; ++k) if (k < cb0 && kidx[k] >= 0) gout[(long)a.ldg * kidx[k]] = 0.0;
     for (int cb = cb0; cb < n; cb += 16) {
       double acc[16];
-      for (int j = 0; j < 16; ++j) acc[j] = cb + j < n ? hhat(cb + j) : 0.0;
+      if (d == 3) {
+        const double q0 = Qfu[g * 3], q1 = Qfu[g * 3 + 1], q2 = Qfu[g * 3 + 2];
+        const double* b0 = Bt + (long)t * 3 * 6 * a.m_cap; const double* b1 = b0 + 6 * a.m_cap; const double* b2 = b1 + 6 * a.m_cap;
+        for (int j = 0; j < 16; ++j) {
+          const int col = cb + j;
+          double val = 0.0;
+          if (col < n) {
+            const int slot = col / 6, kk = col - 6 * slot, op = inv[slot];
+            if (op >= 0) { const int cc = 6 * op + kk; val = (op == o ? (double)hx[op * 12 + kk] : 0.0) - (q0 * b0[cc] + q1 * b1[cc] + q2 * b2[cc]); }
+          }
+          acc[j] = val;
+        }
+      } else {
+        for (int j = 0; j < 16; ++j) acc[j] = cb + j < n ? hhat(cb + j) : 0.0;
+      }
       for (int cp = cb0; cp < cb; ++cp) {
         if (kidx[cp] < 0) continue;
         const double xc = gout[(long)a.ldg * kidx[cp]];
@@ -667,7 +753,9 @@ LIT_FN bool literal_fast(const Ctx& c, const Args<HT>& a, const int m, const int
     }
   });
   barrier(c);
+  tick(c, 6);
   information_from_compressed(c, a, n, nr, mobs);
+  tick(c, 9);
   return true;
 }
 
@@ -675,6 +763,7 @@ LIT_FN bool literal_fast(const Ctx& c, const Args<HT>& a, const int m, const int
 // untouched and info[4] = 0 when the shape check fails)
 template <class HT>
 LIT_FN void literal_compress(const Ctx& c, const Args<HT>& a, const int route = 0) {
+  tick(c, 0);
   const int m = prepare(c, a);
   if (m <= 0) return;
   const int mobs = a.obs0[a.F];

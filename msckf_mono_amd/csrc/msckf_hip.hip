@@ -88,7 +88,7 @@ struct BatchBase {
   bool h16 = false;   // dtype MSCKF_HIP_F16H_F32P: fp16 measurement Jacobian, f32 state and covariance
   std::vector<HostTraj> traj;
   virtual int init(int b, const double* cam, const double* noise, const double* params, const double* imu) = 0;
-  virtual int propagate(int b0, int nb, const double* rd, int K) = 0;
+  virtual int propagate(int b0, int nb, const double* rd, int K, bool mirror = false) = 0;
   virtual int augment(int b0, int nb) = 0;
   virtual int set_tracks(int b, int F, const int* M, const int* slots, const double* obs) = 0;
   virtual int marginalize(int b0, int nb) = 0;
@@ -215,6 +215,13 @@ struct Batch : BatchBase {
   int lit_route = 0;         // 0 fast where the stack has the shape for it, else general; 1 general only; 2 fast only (tests)
   double lit_tol = -1;       // zero-tail tolerance of the literal route; < 0: 1e-10 (double) / 8e-4 (float: H_x is float-rounded)
   std::vector<double> h_uv;  // [B][2] u_var', v_var' as initialize() got them
+  // Host mirror of the IMU state for the single-filter API: getImuState() is called once per IMU sample by the reference's
+  // runner (asl_msckf.cpp:231) and must be synchronously available on the host; between two images only
+  // propagate() changes it, and propogateImuStateRK (msckf.h:1425-1467) is a few hundred FLOP -- so msckf_hip_propagate
+  // advances this copy with the reference's own RK sequence while the device advances the state the filter uses, and
+  // msckf_hip_get_imu_state answers from it without a device round trip.  Any other device-side change of the state
+  // (marginalize, the batched calls) invalidates it; the next getter reads the device and re-validates.
+  std::vector<S> h_imu; std::vector<char> h_imu_ok;
   std::vector<char> h_lit;   // [B] trajectory runs the literal route
   int n_lit = 0;
   // single-call staging on device
@@ -272,7 +279,7 @@ struct Batch : BatchBase {
       HIPCHK(hipStreamCreateWithFlags(&sty[i], hipStreamNonBlocking));
       HIPCHK(hipEventCreateWithFlags(&ev_fa[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_fb[i], hipEventDisableTiming));
     }
-    h_ncam.assign(B, 0); h_uv.assign((size_t)2 * B, 0.0); h_lit.assign(B, 0);
+    h_ncam.assign(B, 0); h_uv.assign((size_t)2 * B, 0.0); h_lit.assign(B, 0); h_imu.assign((size_t)B * IMU_STRIDE, S(0)); h_imu_ok.assign(B, 0);
     d.B = B; d.n_cap = n_cap; d.f_cap = f_cap; d.m_cap = m_cap;
     d.n6cap = 6 * n_cap;
     d.ld = ((15 + 6 * n_cap + 15) / 16) * 16;
@@ -411,7 +418,7 @@ struct Batch : BatchBase {
     const size_t Bz = B, n1 = (size_t)d.n6cap + 1;
     L.ldx = ((f_cap * std::max(2 * m_cap - 3, 1) + 7) / 8) * 8;
     L.r_cap = d.n6cap + 63; L.ldg = f_cap * m_cap + 8; L.ldz = L.r_cap + (int)n1; L.kept_stride = 6 * (d.n6cap + 16) + 64;   // 63 = LIT_ZCAP (literal_core.h)
-    L.w_stride = (long)(n1 * n1 + 63 * n1 + 63 * 2 * (size_t)m_cap);
+    L.w_stride = (long)(n1 * n1 + 63 * n1 + 63 * 2 * (size_t)m_cap + (size_t)f_cap * 18 * m_cap + 3 * (size_t)L.ldg);
     L.tol = lit_tol >= 0 ? lit_tol : (sizeof(S) == 4 ? 8e-4 : 1e-10);
     L.route = lit_route;
     int rc = 0;
@@ -421,6 +428,7 @@ struct Batch : BatchBase {
     rc |= dalloc(&L.TH, Bz * L.r_cap * n1); rc |= dalloc(&L.G, Bz * (size_t)L.ldg * L.r_cap); rc |= dalloc(&L.Z, Bz * (size_t)L.ldz * L.ldz);
     rc |= dalloc(&L.W, Bz * (size_t)L.w_stride);
     rc |= dalloc(&L.info, Bz * 8);
+    if (const char* e = getenv("MSCKF_HIP_LITERAL_TIMERS")) if (atoi(e)) rc |= dalloc(&L.tim, Bz * 16);
     if (rc) { L.X = nullptr; return fail(-ENOMEM, "work space of the literal anisotropic route (msckf_hip_set_anisotropic_noise(h, 1, 0) selects pre-whitening)"); }
     return 0;
   }
@@ -446,6 +454,14 @@ struct Batch : BatchBase {
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipMemcpyAsync(out4, d.lit.info + (size_t)b * 8, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (d.lit.tim) {     // MSCKF_HIP_LITERAL_TIMERS=1 (profiling runs): phase durations of the last launch in microseconds on stderr
+      long long t[16];
+      HIPCHK(hipMemcpyAsync(t, d.lit.tim + (size_t)b * 16, sizeof(t), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      std::fprintf(stderr, "[k_literal b=%d] us: prepare %.0f top %.0f lam' %.0f chol %.0f shape+TH %.0f row solves %.0f  G^T G %.0f eliminate %.0f store %.0f\n", b,
+                   (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01, (t[5] - t[4]) * 0.01, (t[6] - t[5]) * 0.01,
+                   (t[7] - t[6]) * 0.01, (t[8] - t[7]) * 0.01, (t[9] - t[8]) * 0.01);
+    }
     return 0;
   }
   int init(int b, const double* cam, const double* noise, const double* params, const double* imu) override {
@@ -464,6 +480,7 @@ struct Batch : BatchBase {
     for (int i = 0; i < 3; ++i) { st_imu[IVN + i] = st_imu[IV + i]; st_imu[IPN + i] = st_imu[IP + i]; }
     std::vector<S> P((size_t)d.ld * d.ld, S(0));
     for (int i = 0; i < 15; ++i) P[(size_t)i * d.ld + i] = (S)noise[14 + i];
+    std::copy(st_imu, st_imu + IMU_STRIDE, h_imu.begin() + (size_t)b * IMU_STRIDE); h_imu_ok[b] = 1;
     HIPCHK(hipMemcpyAsync(d.prm + (size_t)b * PRM_STRIDE, prm, sizeof(prm), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d.imu + (size_t)b * IMU_STRIDE, st_imu, sizeof(st_imu), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d.P + (size_t)b * d.ld * d.ld, P.data(), P.size() * sizeof(S), hipMemcpyHostToDevice, st));
@@ -480,9 +497,52 @@ struct Batch : BatchBase {
     t.redundancy_angle_thresh = params[3]; t.redundancy_distance_thresh = params[4];
     return 0;
   }
-  int propagate(int b0, int nb, const double* rd, int K) override {
+  // propogateImuStateRK (msckf.h:1425-1467) + the anchors of msckf.h:138-141 on the host copy of trajectory b, in S arithmetic
+  static void host_rk(S* x, const double* rd7) {
+    const S dT = (S)rd7[6];
+    const S w[3] = {(S)rd7[0] - x[IBG], (S)rd7[1] - x[IBG + 1], (S)rd7[2] - x[IBG + 2]};
+    // 0.5 * omegaMat(w) applied to y = (-x, -y, -z, w) of q_IG (matrix_utils.h:19-30)
+    auto op = [&](const S y[4], S o[4]) {
+      o[0] = S(0.5) * (w[2] * y[1] - w[1] * y[2] + w[0] * y[3]);
+      o[1] = S(0.5) * (-w[2] * y[0] + w[0] * y[2] + w[1] * y[3]);
+      o[2] = S(0.5) * (w[1] * y[0] - w[0] * y[1] + w[2] * y[3]);
+      o[3] = S(0.5) * (-w[0] * y[0] - w[1] * y[1] - w[2] * y[2]);
+    };
+    const S y0[4] = {-x[IQ + 1], -x[IQ + 2], -x[IQ + 3], x[IQ]};
+    S k0[4], k1[4], k2[4], k3[4], k4[4], k5[4], t[4];
+    op(y0, k0);
+    for (int i = 0; i < 4; ++i) t[i] = y0[i] + (k0[i] / S(4)) * dT;
+    op(t, k1);
+    for (int i = 0; i < 4; ++i) t[i] = y0[i] + (k0[i] / S(8) + k1[i] / S(8)) * dT;
+    op(t, k2);
+    for (int i = 0; i < 4; ++i) t[i] = y0[i] + (-k1[i] / S(2) + k2[i]) * dT;
+    op(t, k3);
+    for (int i = 0; i < 4; ++i) t[i] = y0[i] + (k0[i] * S(3) / S(16) + k3[i] * S(9) / S(16)) * dT;
+    op(t, k4);
+    for (int i = 0; i < 4; ++i) t[i] = y0[i] + (-k0[i] * S(3) / S(7) + k1[i] * S(2) / S(7) + k2[i] * S(12) / S(7) - k3[i] * S(12) / S(7) + k4[i] * S(8) / S(7)) * dT;
+    op(t, k5);
+    S yt[4];
+    for (int i = 0; i < 4; ++i) yt[i] = y0[i] + (S(7) * k0[i] + S(32) * k2[i] + S(12) * k3[i] + S(32) * k4[i] + S(7) * k5[i]) * dT / S(90);
+    S q[4] = {yt[3], -yt[0], -yt[1], -yt[2]};
+    const S nq = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    // v += (C_IG^T (a - b_a) + g) dT with the OLD attitude, p += v_old dT
+    const S qw = x[IQ], qx = x[IQ + 1], qy = x[IQ + 2], qz = x[IQ + 3];
+    const S R[3][3] = {{1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)},
+                       {2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)},
+                       {2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)}};
+    const S am[3] = {(S)rd7[3] - x[IBA], (S)rd7[4] - x[IBA + 1], (S)rd7[5] - x[IBA + 2]};
+    for (int i = 0; i < 3; ++i) x[IP + i] += x[IV + i] * dT;
+    for (int i = 0; i < 3; ++i) x[IV + i] += (R[0][i] * am[0] + R[1][i] * am[1] + R[2][i] * am[2] + x[IG + i]) * dT;
+    for (int i = 0; i < 4; ++i) x[IQ + i] = q[i] / nq;
+    for (int i = 0; i < 4; ++i) x[IQN + i] = x[IQ + i];
+    for (int i = 0; i < 3; ++i) { x[IVN + i] = x[IV + i]; x[IPN + i] = x[IP + i]; }
+  }
+  void invalidate_imu(int b0, int nb) { for (int b = b0; b < b0 + nb && b < B; ++b) h_imu_ok[b] = 0; }
+  int propagate(int b0, int nb, const double* rd, int K, bool mirror) override {
     if (chk_range(b0, nb)) return fail(-EINVAL, "trajectory range out of bounds");
     if (K < 0) return fail(-EINVAL, "negative sample count");
+    if (mirror && nb == 1) { if (h_imu_ok[b0]) for (int k = 0; k < K; ++k) host_rk(h_imu.data() + (size_t)b0 * IMU_STRIDE, rd + (size_t)k * RD_STRIDE); }
+    else invalidate_imu(b0, nb);
     HIPCHK(hipSetDevice(device));
     for (int k0 = 0; k0 < K; k0 += rd_cap) {
       const int kk = std::min(rd_cap, K - k0);
@@ -567,6 +627,7 @@ struct Batch : BatchBase {
     if (fuse && f1 - f0 >= 2 && ((f1 - f0 - 1) & 1)) std::swap(d.P, P_spare);
   }
   void launch_update(const Dev<S>& vin, int b0, int nb, hipStream_t q, bool feature_done = false) {
+    invalidate_imu(b0, nb);            // the update corrects the IMU state on the device (msckf.h:1376-1383)
     Dev<S> v = vin;
     if (compress_route >= 0) v.compress = (compress_route && d.trk_B) ? compress_route : 0;
     if (n_lit > 0 && !v.compress) v.compress = d.compress;   // the literal route hands over an information matrix: Cholesky tail
@@ -651,10 +712,13 @@ struct Batch : BatchBase {
   }
   int get_imu(int b, double* o) override {
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
-    HIPCHK(hipSetDevice(device));
-    S tmp[IMU_STRIDE];
-    HIPCHK(hipMemcpyAsync(tmp, d.imu + (size_t)b * IMU_STRIDE, sizeof(tmp), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    S* tmp = h_imu.data() + (size_t)b * IMU_STRIDE;
+    if (!h_imu_ok[b]) {
+      HIPCHK(hipSetDevice(device));
+      HIPCHK(hipMemcpyAsync(tmp, d.imu + (size_t)b * IMU_STRIDE, IMU_STRIDE * sizeof(S), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      h_imu_ok[b] = 1;
+    }
     for (int i = 0; i < 29; ++i) o[i] = (double)tmp[i];
     return 0;
   }
@@ -665,6 +729,7 @@ struct Batch : BatchBase {
     for (int i = 0; i < 29; ++i) tmp[i] = (S)in[i];
     HIPCHK(hipMemcpyAsync(d.imu + (size_t)b * IMU_STRIDE, tmp, sizeof(tmp), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
+    std::copy(tmp, tmp + IMU_STRIDE, h_imu.begin() + (size_t)b * IMU_STRIDE); h_imu_ok[b] = 1;
     return 0;
   }
   int get_cams(int b, double* o, int cap, int* nout) override {
@@ -755,7 +820,7 @@ struct Batch : BatchBase {
     HIPCHK(cp(d.prm, o->d.prm, Bz * PRM_STRIDE * sizeof(S))); HIPCHK(cp(d.P, o->d.P, Bz * pl * sizeof(S)));
     HIPCHK(cp(d.ncam, o->d.ncam, Bz * sizeof(int))); HIPCHK(cp(d.n_resid, o->d.n_resid, Bz * sizeof(long long)));
     HIPCHK(cp(d.stats, o->d.stats, Bz * STAT_STRIDE * sizeof(int))); HIPCHK(cp(d.ncam_upd, o->d.ncam_upd, Bz * sizeof(int)));
-    traj = o->traj; h_ncam = o->h_ncam; h_uv = o->h_uv;
+    traj = o->traj; h_ncam = o->h_ncam; h_uv = o->h_uv; h_imu = o->h_imu; h_imu_ok = o->h_imu_ok;
     compress_route = o->compress_route; d.joseph = o->d.joseph; d.gate_early = o->d.gate_early; nstreams = o->nstreams;
     overlap_feature = o->overlap_feature; d.gain_fused_s = o->d.gain_fused_s; fuse_prune = o->fuse_prune;
     HIPCHK(hipStreamSynchronize(st));
@@ -1632,7 +1697,7 @@ int msckf_hip_destroy(msckf_hip_handle h) { delete H(h); return 0; }
 int msckf_hip_initialize(msckf_hip_handle h, int b, const double* cam12, const double* noise29, const double* params8, const double* imu29) {
   return H(h)->init(b, cam12, noise29, params8, imu29);
 }
-int msckf_hip_propagate(msckf_hip_handle h, int b, const double* readings7, int K) { StageRange r("imu_prop"); return H(h)->propagate(b, 1, readings7, K); }
+int msckf_hip_propagate(msckf_hip_handle h, int b, const double* readings7, int K) { StageRange r("imu_prop"); return H(h)->propagate(b, 1, readings7, K, true); }
 int msckf_hip_augment_state(msckf_hip_handle h, int b, int state_id, double time) {
   BatchBase* B = H(h);
   if (b < 0 || b >= B->B) return fail(-EINVAL, "trajectory index out of range");

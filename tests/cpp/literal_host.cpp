@@ -34,7 +34,7 @@ extern "C" int lit_host_compress(int F, int m_cap, int N, const int* included, c
   std::vector<signed char> inv((size_t)F * 64, (signed char)-1);
   for (int t = 0; t < F; ++t) for (int o = 0; o < M[t]; ++o) inv[(size_t)t * 64 + slots[(size_t)t * m_cap + o]] = (signed char)o;
   a.inv = inv.data(); a.inv_stride = 64;
-  std::vector<double> W((size_t)(n + 1) * (n + 1) + (size_t)LIT_ZCAP * (n + 1) + (size_t)LIT_ZCAP * 2 * m_cap);
+  std::vector<double> W((size_t)(n + 1) * (n + 1) + (size_t)LIT_ZCAP * (n + 1) + (size_t)LIT_ZCAP * 2 * m_cap + (size_t)F * 18 * m_cap + 3 * (size_t)(mobs + 8));
   a.W = W.data();
   a.LamIn = LamIn; a.lam_part = 0; a.gram_parts = 1;
   a.Lam = Lam; a.ldL = n + 1; a.info = info8;

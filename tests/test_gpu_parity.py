@@ -455,6 +455,37 @@ def test_error_behaviour(capi):
         capi.MSCKF(capi.F32, n_cap=4, f_cap=4, m_cap=4).update([[0, 0]], [1])   # update before initialize
 
 
+def test_get_imu_state_after_propagate_is_answered_from_the_host_mirror(capi, po):
+    """msckf_hip_propagate advances a host copy of the IMU state with the reference's RK sequence (msckf.h:1425-1467) beside the
+    device, so that the by-value getImuState() the ASL runner makes per IMU sample (asl_msckf.cpp:231) needs no device round
+    trip; the copy is dropped whenever the device changes the state otherwise.  Per sample: the getter vs the oracle; then the
+    same state read from the device (a batched no-op propagate invalidates the copy) within rounding of it."""
+    for dt_dev, dt_or, tol in ((capi.F64, po.F64, 1e-12), (capi.F32, po.F32, 2e-6)):
+        N, F, nf = 6, 8, 8
+        tr = sc.Trajectory(2, 31, N, F, nf)
+        st = tr.stream()
+        f = capi.MSCKF(dt_dev, n_cap=N + 3, f_cap=64, m_cap=N + 3)
+        o = po.Oracle(dt_or, po.LEAN)
+        f.initialize(tr.cfg, tr.imu0); o.initialize(tr.cfg, tr.imu0)
+        sid = 0
+        for k in range(nf):
+            for r7 in tr.imu_for_frame(k):
+                sid += 1
+                f.propagate(r7); o.propagate(r7)
+                a, b = f.getImuState(), o.getImuState()
+                assert H.rel(a[:16], b[:16]) < tol and H.rel(a[19:29], b[19:29]) < tol, (k, sid)
+            mirror = f.getImuState()
+            assert f.batch.L.msckf_hip_propagate_range(f.batch.h, 0, 1, None, 0) == 0      # K = 0: launches nothing, drops the host copy
+            dev = f.getImuState()
+            assert H.rel(mirror[:16], dev[:16]) < (1e-13 if dt_dev == capi.F64 else 2e-6)
+            f.augmentState(sid, float(k)); o.augmentState(sid, float(k))
+            f.update(*st[k]["cur"]); o.update(*st[k]["cur"])
+            f.addFeatures(*st[k]["new"]); o.addFeatures(*st[k]["new"])
+            f.marginalize(); o.marginalize(); f.pruneEmptyStates(); o.pruneEmptyStates()
+            assert H.rel(f.getImuState()[:16], o.getImuState()[:16]) < (1e-6 if dt_dev == capi.F64 else 1e-3)
+        f.batch.close()
+
+
 def test_anisotropic_pixel_noise_euroc_intrinsics(capi, po):
     """f_u != f_v (the reference's shipped EuRoC configuration, asl_msckf.cpp:77-78), the device's pre-whitened route
     (msckf_hip_set_anisotropic_noise(h, 1); the default literal route is held in tests/test_gpu_literal.py).  The device
