@@ -491,6 +491,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
   // f64 on the (float-rounded) H_f; the gate below keeps the S-precision reflectors.
   double Bq[3][6], cq[3];
   if (d.compress && !(fdbg & 8)) {
+   if constexpr (sizeof(S) == 4) {
+    // Float filters: only B^T B = [H_x | r]^T H_f (H_f^T H_f)^-1 H_f^T [H_x | r] matters downstream (k_gram), so any B with that
+    // Gram matrix will do: B = L^-1 H_f^T [H_x | r] with H_f^T H_f = L L^T (3 x 3, f64).  H_f^T H_x is LOCAL to the lane (the
+    // camera's 6 columns meet only this observation's two rows): nine f64 wave sums (H_f^T H_f, H_f^T r) and no broadcast,
+    // where the three reflectors took twelve sums and a dozen broadcasts (17 % of the kernel's instructions).  The squared
+    // condition of H_f costs ~1e-10 in the projector -- below the float Jacobian's own rounding; double filters keep the
+    // reflectors (a low-parallax window needs the projector to 1e-13).
+    const double f0[3] = {(double)hf[0][0], (double)hf[0][1], (double)hf[0][2]}, f1[3] = {(double)hf[1][0], (double)hf[1][1], (double)hf[1][2]};
+    const double s00 = wave_sum(f0[0] * f0[0] + f1[0] * f1[0]), s01 = wave_sum(f0[0] * f0[1] + f1[0] * f1[1]), s02 = wave_sum(f0[0] * f0[2] + f1[0] * f1[2]);
+    const double s11 = wave_sum(f0[1] * f0[1] + f1[1] * f1[1]), s12 = wave_sum(f0[1] * f0[2] + f1[1] * f1[2]), s22 = wave_sum(f0[2] * f0[2] + f1[2] * f1[2]);
+    const double r0 = (double)r[0], r1 = (double)r[1];
+    const double t0 = wave_sum(f0[0] * r0 + f1[0] * r1), t1 = wave_sum(f0[1] * r0 + f1[1] * r1), t2 = wave_sum(f0[2] * r0 + f1[2] * r1);
+    const double tiny = 1e-300;
+    const double i00 = fast_rsqrt(s00 > tiny ? s00 : tiny), l10 = s01 * i00, l20 = s02 * i00;
+    const double p11 = s11 - l10 * l10, i11 = fast_rsqrt(p11 > tiny ? p11 : tiny), l21 = (s12 - l20 * l10) * i11;
+    const double p22 = s22 - l20 * l20 - l21 * l21, i22 = fast_rsqrt(p22 > tiny ? p22 : tiny);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const double h0 = (double)hx[0][k], h1 = (double)hx[1][k];
+      const double g0 = f0[0] * h0 + f1[0] * h1, g1 = f0[1] * h0 + f1[1] * h1, g2 = f0[2] * h0 + f1[2] * h1;
+      const double b0v = g0 * i00, b1v = (g1 - l10 * b0v) * i11;
+      Bq[0][k] = b0v; Bq[1][k] = b1v; Bq[2][k] = (g2 - l20 * b0v - l21 * b1v) * i22;
+    }
+    cq[0] = t0 * i00; cq[1] = (t1 - l10 * cq[0]) * i11; cq[2] = (t2 - l20 * cq[0] - l21 * cq[1]) * i22;
+   } else {
     double hfd[2][3], vd[2][3], Td[3][3];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -530,6 +555,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
       }
       cq[i] = ri - (vi[0] * yd[0] + vi[1] * yd[1] + vi[2] * yd[2]);
     }
+   }
   }
 
   // ---- publish H_x and, for the information form, B^ = Q_f^T [H_x | r] right away: nothing below changes them, and the 42

@@ -15,6 +15,8 @@
 
 namespace msckf {
 
+constexpr int LIT_LDS_DOUBLES = 8000;   // 62.5 KB: chunks of rows of G for the G^T G stage (two workgroups per CU still fit)
+
 template <class S>
 __global__ __launch_bounds__(1024) void k_literal(Dev<S> d, int b0, int nb) {
   const int bi = blockIdx.x, b = b0 + bi;
@@ -24,8 +26,9 @@ __global__ __launch_bounds__(1024) void k_literal(Dev<S> d, int b0, int nb) {
   int* st = d.stats + (long)b * STAT_STRIDE;
   if (st[STAT_MROWS] == 0) return;
   __shared__ double red[20];
+  extern __shared__ double lit_lds[];
   lit::Ctx c;
-  c.tid = threadIdx.x; c.nt = blockDim.x; c.lane = threadIdx.x & 63; c.wave = threadIdx.x >> 6; c.nw = blockDim.x >> 6; c.red = red; c.tim = d.lit.tim ? d.lit.tim + (long)b * 16 : nullptr;
+  c.tid = threadIdx.x; c.nt = blockDim.x; c.lane = threadIdx.x & 63; c.wave = threadIdx.x >> 6; c.nw = blockDim.x >> 6; c.red = red; c.tim = d.lit.tim ? d.lit.tim + (long)b * 16 : nullptr; c.lds = lit_lds; c.lds_doubles = LIT_LDS_DOUBLES;
   const LitBufs& L = d.lit;
   const int n1 = d.n6cap + 1;
   lit::Args<S> a;
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(1024) void k_literal(Dev<S> d, int b0, int nb) {
 template <class S>
 void launch_literal(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0 || !d.lit.X) return;
-  hipLaunchKernelGGL(k_literal<S>, dim3(nb), dim3(1024), 0, st, d, b0, nb);
+  hipLaunchKernelGGL(k_literal<S>, dim3(nb), dim3(1024), LIT_LDS_DOUBLES * sizeof(double), st, d, b0, nb);
 }
 template void launch_literal<float>(const Dev<float>&, int, int, hipStream_t);
 template void launch_literal<double>(const Dev<double>&, int, int, hipStream_t);

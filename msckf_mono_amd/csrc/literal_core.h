@@ -51,12 +51,21 @@ template <int NV, class F> LIT_FN void wave_sum_vec(const Ctx&, long lo, long hi
   for (int k = 0; k < NV; ++k) out[k] = 0;
   for (long i = lo; i < hi; ++i) f(i, out);
 }
+// lower triangle of G^T G (G: mobs x nr, column-major with leading dimension ldg): st(i, j, value) for every j <= i < nr
+template <class ST> LIT_FN void syrk_lower(const Ctx&, const double* G, long ldg, int nr, int mobs, ST st) {
+  for (int j = 0; j < nr; ++j)
+    for (int i = j; i < nr; ++i) {
+      double s = 0;
+      for (int o = 0; o < mobs; ++o) s += G[o + ldg * i] * G[o + ldg * j];
+      st(i, j, s);
+    }
+}
 LIT_FN bool first_lane(const Ctx&) { return true; }
 LIT_FN bool first_thread(const Ctx&) { return true; }
 LIT_FN void tick(const Ctx&, int) {}
 #else
 #define LIT_FN __device__ __forceinline__
-struct Ctx { int tid, nt, lane, wave, nw; double* red; long long* tim; };   // red: LDS scratch, nw + 2 doubles; tim: phase stamps (100 MHz) or null
+struct Ctx { int tid, nt, lane, wave, nw; double* red; long long* tim; double* lds; int lds_doubles; };   // red: LDS scratch, nw + 2 doubles; tim: phase stamps (100 MHz) or null; lds: staging area
 LIT_FN void barrier(const Ctx&) { __syncthreads(); }
 template <class F> LIT_FN void par_for(const Ctx& c, long n, F f) { for (long i = c.tid; i < n; i += c.nt) f(i); }
 template <class F> LIT_FN double wg_sum(const Ctx& c, long lo, long hi, F f) {
@@ -95,6 +104,45 @@ template <int NV, class F> LIT_FN void wave_sum_vec(const Ctx& c, long lo, long 
   for (long i = lo + c.lane; i < hi; i += 64) f(i, v);
 #pragma unroll
   for (int k = 0; k < NV; ++k) out[k] = wave_sum(v[k]);
+}
+// G is read from global memory ONCE: chunks of rows are staged in LDS ([row][column], row stride nr | 1), every thread owns
+// one 4 x 4 tile of the lower triangle (a second pass takes the tiles beyond the thread count) and keeps its sixteen sums in
+// registers across the chunks.  (One wavefront per tile with lanes along the rows re-read eight columns per tile: 220 MB per
+// trajectory at a 30-camera window, and at 128 trajectories per launch the step was bound by that traffic.)
+template <class ST> LIT_FN void syrk_lower(const Ctx& c, const double* G, long ldg, int nr, int mobs, ST st) {
+  const int ntile = (nr + 3) / 4, ntl = ntile * (ntile + 1) / 2, ldl = nr | 1;
+  const int rows = c.lds_doubles / ldl;          // rows of G per chunk
+  for (int e0 = 0; e0 < ntl; e0 += c.nt) {
+    const int e = e0 + c.tid;
+    int ti = 0, tj = 0;
+    if (e < ntl) { ti = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5); while (ti * (ti + 1) / 2 > e) --ti; while ((ti + 1) * (ti + 2) / 2 <= e) ++ti; tj = e - ti * (ti + 1) / 2; }
+    double acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0;
+    for (int o0 = 0; o0 < mobs; o0 += rows) {
+      const int nrow = mobs - o0 < rows ? mobs - o0 : rows;
+      __syncthreads();
+      for (long x = c.tid; x < (long)nrow * nr; x += c.nt) { const int k = (int)(x / nrow), o = (int)(x - (long)k * nrow); c.lds[o * ldl + k] = G[o0 + o + ldg * k]; }
+      __syncthreads();
+      if (e < ntl) {
+        const double* li = c.lds + 4 * ti; const double* lj = c.lds + 4 * tj;
+        const int i3 = 4 * ti + 3 < nr ? 3 : nr - 1 - 4 * ti, j3 = 4 * tj + 3 < nr ? 3 : nr - 1 - 4 * tj;   // clamp inside the matrix (edge tiles)
+        for (int o = 0; o < nrow; ++o) {
+          const double* ri = li + o * ldl; const double* rj = lj + o * ldl;
+          const double x0 = ri[0], x1 = ri[i3 < 1 ? i3 : 1], x2 = ri[i3 < 2 ? i3 : 2], x3 = ri[i3];
+          const double y0 = rj[0], y1 = rj[j3 < 1 ? j3 : 1], y2 = rj[j3 < 2 ? j3 : 2], y3 = rj[j3];
+          acc[0] += x0 * y0; acc[1] += x0 * y1; acc[2] += x0 * y2; acc[3] += x0 * y3;
+          acc[4] += x1 * y0; acc[5] += x1 * y1; acc[6] += x1 * y2; acc[7] += x1 * y3;
+          acc[8] += x2 * y0; acc[9] += x2 * y1; acc[10] += x2 * y2; acc[11] += x2 * y3;
+          acc[12] += x3 * y0; acc[13] += x3 * y1; acc[14] += x3 * y2; acc[15] += x3 * y3;
+        }
+      }
+    }
+    if (e < ntl)
+      for (int qi = 0; qi < 4; ++qi)
+        for (int qj = 0; qj < 4; ++qj) { const int i = 4 * ti + qi, j = 4 * tj + qj; if (i < nr && j <= i) st(i, j, acc[qi * 4 + qj]); }
+  }
+  __syncthreads();
 }
 LIT_FN bool first_lane(const Ctx& c) { return c.lane == 0; }
 LIT_FN bool first_thread(const Ctx& c) { return c.tid == 0; }
@@ -208,33 +256,7 @@ LIT_FN void information_from_compressed(const Ctx& c, const Args<HT>& a, int n, 
   const long ldz = a.ldz;
   double* Z = a.Z;
   const double dlt = a.u_var - a.v_var;
-  // one wavefront per 4 x 4 tile of the lower triangle, lanes along the stacked observations (G is column-major: coalesced):
-  // eight column loads feed sixteen products (one load pair per product took 14 of the fast route's 27 ms)
-  const int ntile = (nr + 3) / 4;
-  wave_for(c, 0, (long)ntile * ntile, [&](long e) {
-    const int tj = (int)(e / ntile), ti = (int)(e - (long)tj * ntile);
-    if (ti < tj) return;
-    const double* gi[4]; const double* gj[4];
-    for (int q = 0; q < 4; ++q) {
-      const int ri = 4 * ti + q < nr ? 4 * ti + q : nr - 1, rj = 4 * tj + q < nr ? 4 * tj + q : nr - 1;
-      gi[q] = a.G + (long)a.ldg * ri; gj[q] = a.G + (long)a.ldg * rj;
-    }
-    double acc[16];
-    wave_sum_vec<16>(c, 0, mobs, acc, [&](long o, double (&v)[16]) {
-      const double x0 = gi[0][o], x1 = gi[1][o], x2 = gi[2][o], x3 = gi[3][o];
-      const double y0 = gj[0][o], y1 = gj[1][o], y2 = gj[2][o], y3 = gj[3][o];
-      v[0] += x0 * y0; v[1] += x0 * y1; v[2] += x0 * y2; v[3] += x0 * y3;
-      v[4] += x1 * y0; v[5] += x1 * y1; v[6] += x1 * y2; v[7] += x1 * y3;
-      v[8] += x2 * y0; v[9] += x2 * y1; v[10] += x2 * y2; v[11] += x2 * y3;
-      v[12] += x3 * y0; v[13] += x3 * y1; v[14] += x3 * y2; v[15] += x3 * y3;
-    });
-    if (first_lane(c))
-      for (int qi = 0; qi < 4; ++qi)
-        for (int qj = 0; qj < 4; ++qj) {
-          const int i = 4 * ti + qi, j = 4 * tj + qj;
-          if (i < nr && j <= i) Z[i + ldz * j] = dlt * acc[qi * 4 + qj] + (i == j ? a.v_var : 0.0);
-        }
-  });
+  syrk_lower(c, a.G, a.ldg, nr, mobs, [&](int i, int j, double sgg) { Z[i + ldz * j] = dlt * sgg + (i == j ? a.v_var : 0.0); });
   par_for(c, (long)(n + 1) * nz, [&](long e) {
     const int j = (int)(e / (n + 1)), cc = (int)(e - (long)j * (n + 1));
     Z[(nr + cc) + ldz * j] = j < nr ? a.TH[j + (long)rc * cc] : 0.0;

@@ -151,12 +151,12 @@ def _steady_state_vs_reference(capi, po, trs, N, F, n_updates, m_cap, dtype_dev,
 
 def test_cfg3_window_float_hip_vs_reference_source(capi, po):
     """BASELINE configs[2] geometry (30-camera window, 200 tracks, float): the reference's own float arithmetic -- full m x m
-    Q of a ~5 800-row stack and dense R_o included, seconds per update -- against the device on NINE consecutive steady-state
+    Q of a ~5 800-row stack and dense R_o included, seconds per update -- against the device on ELEVEN consecutive steady-state
     updates of FOUR trajectories (the reference's filters on host threads; about four in ten of these frames carry a
     motion-rejected track, on which the reference is undefined -- defect D1 -- and are skipped), the section-3.4 metric at 1e-3."""
-    N, F, nf = 30, 200, 39
+    N, F, nf = 30, 200, 41
     trs = [sc.Trajectory(3, g, N, F, nf) for g in range(4)]
-    env, n = _steady_state_vs_reference(capi, po, trs, N, F, 9, 32, capi.F32, warm_mode=po.GRAM)
+    env, n = _steady_state_vs_reference(capi, po, trs, N, F, 11, 32, capi.F32, warm_mode=po.GRAM)
     assert n >= 20 and H.worst(env) < 1e-3, (n, env)
 
 
