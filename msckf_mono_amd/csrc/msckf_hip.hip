@@ -199,7 +199,11 @@ struct Batch : BatchBase {
   std::vector<void*> allocs;
   // pinned host staging of the per-call inputs (single-filter API): filled, copied asynchronously, reused only after
   // ev_stage says the previous copy has left it -- the calls themselves do not wait for the device
-  unsigned char* h_stage = nullptr; size_t h_stage_bytes = 0; hipEvent_t ev_stage = nullptr; bool stage_busy = false;
+  // (a ring of NSTG areas: a call takes the next one and only waits if the copy made out of it NSTG calls ago is still in
+  // flight -- with a single area every propagate() of the per-sample API waited for the previous sample's copy)
+  static constexpr int NSTG = 8;
+  unsigned char* h_stage[NSTG] = {nullptr}; size_t h_stage_bytes[NSTG] = {0}; hipEvent_t ev_stage[NSTG] = {nullptr}; bool stage_busy[NSTG] = {false};
+  int stage_cur = 0;
   // host mirror of ncam[] (every call that changes the window size updates it) and, per scenario cell, the largest camera
   // slot its work-list touches: run_frames overlaps k_feature with propagate + augment when no track sees the newest camera
   std::vector<int> h_ncam, h_maxslot;
@@ -270,7 +274,7 @@ struct Batch : BatchBase {
     feature_device_setup(); qr_device_setup(); kalman_device_setup(); gram_device_setup();   // per device: constant tables, dynamic-LDS limits
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&ev_stage, hipEventDisableTiming));
+    for (int i = 0; i < NSTG; ++i) HIPCHK(hipEventCreateWithFlags(&ev_stage[i], hipEventDisableTiming));
     stx[0] = st;
     for (int i = 1; i < MAXS; ++i) HIPCHK(hipStreamCreateWithFlags(&stx[i], hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
@@ -341,28 +345,30 @@ struct Batch : BatchBase {
     for (int i = 1; i < MAXS; ++i) { if (stx[i]) hipStreamDestroy(stx[i]); if (ev_join[i]) hipEventDestroy(ev_join[i]); }
     for (int i = 0; i < MAXS; ++i) { if (sty[i]) hipStreamDestroy(sty[i]); if (ev_fa[i]) hipEventDestroy(ev_fa[i]); if (ev_fb[i]) hipEventDestroy(ev_fb[i]); }
     if (ev_fork) hipEventDestroy(ev_fork);
-    if (ev_stage) hipEventDestroy(ev_stage);
+    for (int i = 0; i < NSTG; ++i) if (ev_stage[i]) hipEventDestroy(ev_stage[i]);
     unpin_host();
     for (int k = 0; k < RING_MAX; ++k) { if (ev_up[k]) hipEventDestroy(ev_up[k]); for (int i = 0; i < MAXS; ++i) if (ev_use[k][i]) hipEventDestroy(ev_use[k][i]); if (sg_blk[k]) hipFree(sg_blk[k]); }
     if (stc) hipStreamDestroy(stc);
 
-    if (h_stage) hipHostFree(h_stage);
+    for (int i = 0; i < NSTG; ++i) if (h_stage[i]) hipHostFree(h_stage[i]);
     if (st) hipStreamDestroy(st);
   }
   // pinned staging area of at least `bytes`, safe to overwrite (the previous asynchronous copy out of it has finished)
   int stage_acquire(size_t bytes, unsigned char** out) {
-    if (stage_busy) { HIPCHK(hipEventSynchronize(ev_stage)); stage_busy = false; }
-    if (bytes > h_stage_bytes) {
-      if (h_stage) HIPCHK(hipHostFree(h_stage));
-      h_stage = nullptr; h_stage_bytes = 0;
-      const size_t nb = std::max<size_t>(bytes, 1 << 16);
-      HIPCHK(hipHostMalloc((void**)&h_stage, nb, hipHostMallocDefault));
-      h_stage_bytes = nb;
+    stage_cur = (stage_cur + 1) % NSTG;
+    const int k = stage_cur;
+    if (stage_busy[k]) { HIPCHK(hipEventSynchronize(ev_stage[k])); stage_busy[k] = false; }
+    if (bytes > h_stage_bytes[k]) {
+      if (h_stage[k]) HIPCHK(hipHostFree(h_stage[k]));
+      h_stage[k] = nullptr; h_stage_bytes[k] = 0;
+      const size_t nb = std::max<size_t>(bytes, 1 << 12);
+      HIPCHK(hipHostMalloc((void**)&h_stage[k], nb, hipHostMallocDefault));
+      h_stage_bytes[k] = nb;
     }
-    *out = h_stage;
+    *out = h_stage[k];
     return 0;
   }
-  int stage_release() { HIPCHK(hipEventRecord(ev_stage, st)); stage_busy = true; return 0; }
+  int stage_release() { HIPCHK(hipEventRecord(ev_stage[stage_cur], st)); stage_busy[stage_cur] = true; return 0; }
   void use_single_worklists() {
     d.trk_n = wl_n; d.trk_M = wl_M; d.trk_slots = wl_slots; d.trk_obs = wl_obs; d.trk_off = nullptr;
     d.wl_stride_n = 1; d.wl_stride_f = f_cap; d.wl_stride_o = (long)f_cap * m_cap;
