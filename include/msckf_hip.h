@@ -37,7 +37,8 @@
  * source under two roundings, tests/test_ref_vs_oracle.py).  tail_tol > 0 treats such a tail (below tail_tol * |column|) as
  * the zero it is in exact arithmetic -- the reference's algorithm in its exact-arithmetic limit, reproducible to rounding
  * and as close to either rounding of the reference as they are to each other; tail_tol = 0 is msckf.h's rule to the
- * letter.  Mode 1 pre-whitens every observation row by 1/sigma_u resp. 1/sigma_v and runs the filter with unit noise (the
+ * letter (where rows exist below the first 15 + 6N the tail comes out of an f64 Gram matrix, which resolves it to ~1e-4 of
+ * the column at best: tail_tol is taken no finer than 3e-4 there).  Mode 1 pre-whitens every observation row by 1/sigma_u resp. 1/sigma_v and runs the filter with unit noise (the
  * full generalized-least-squares update: statistically the better estimator, but not the reference's).
  */
 #ifndef MSCKF_HIP_H
@@ -209,14 +210,14 @@ int msckf_hip_set_feature_overlap(msckf_hip_handle h, int on);
  * R_o_j = A_j^T R_j A_j / HouseholderQR in column order / R_n = Q_1^T R_o Q_1 on the device (msckf.h:423-431, 1343-1366;
  * f64, one workgroup per trajectory), its result handed to the update as the information matrix
  * [T_H | r_n]^T R_n^-1 [T_H | r_n]; mode 1 rows pre-whitened by 1/sigma (generalized least squares).  tail_tol: zero-tail tolerance of mode 0, < 0 = default (1e-10 double, 8e-4 float), 0 = the reference's
- * rule to the letter.  Applies to every trajectory of the handle, initialized or not.  -ENOMEM when the stack does not fit
- * (f_cap (2 m_cap - 3) x (6 n_cap + 1) doubles per trajectory). */
+ * rule to the letter.  Applies to every trajectory of the handle, initialized or not.  -ENOMEM when the work space (about
+ * sixteen (6 n_cap)^2 matrices of doubles per trajectory) does not fit. */
 int msckf_hip_set_anisotropic_noise(msckf_hip_handle h, int mode, double tail_tol);
 /* last marginalize of trajectory b on the literal route: out[0..5] = stacked rows m, kept rows r of R (msckf.h:1347),
- * Householder steps that reflected, steps whose tail fell under tail_tol, route taken (1: from the Cholesky factor of
- * H_o^T H_o minus the rows handed through -- the usual shape of a stack; 2: the reflector sweep over the dense stack),
- * rows handed through verbatim (15 + 6 x leading cameras nobody saw), and of the shape check of route 1: -100 log10 of the
- * smallest pivot / |column|^2 taken as independent and of the largest taken as dependent. */
+ * Householder steps that reflected, steps whose non-zero tail fell under tail_tol, route taken (3: the sequence of steps on
+ * the compressed representation -- first 15 + 6N rows explicit, the rest through their Gram matrix; 2: the sweep over the
+ * dense stack, environment MSCKF_HIP_LITERAL_ROUTE=1 at create time), leading steps that meet the zero IMU columns (15);
+ * out[6..7] reserved. */
 int msckf_hip_literal_info(msckf_hip_handle h, int b, int* out8);
 
 #ifdef __cplusplus

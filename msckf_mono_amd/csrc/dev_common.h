@@ -50,12 +50,12 @@ enum { STAT_ERR_NCAP = 1, STAT_ERR_PIVOT = 2 };
 // work space of the literal anisotropic compression (kernels_literal.hip / literal_core.h), per trajectory; null when no
 // trajectory of the batch uses it
 struct LitBufs {
-  double* X = nullptr; double* tau = nullptr; double* Vf = nullptr; double* Tf = nullptr; double* TH = nullptr; double* G = nullptr; double* Z = nullptr; double* W = nullptr;
+  double* X = nullptr; double* tau = nullptr; double* Vf = nullptr; double* Tf = nullptr; double* TH = nullptr; double* G = nullptr; double* Z = nullptr; double* W2 = nullptr;
   int* row0 = nullptr; int* obs0 = nullptr; int* otrk = nullptr; int* kept = nullptr; int* info = nullptr;
   long long* tim = nullptr;   // [B][16] phase stamps of k_literal (100 MHz wall clock), only with MSCKF_HIP_LITERAL_TIMERS=1
   int ldx = 0, r_cap = 0, ldg = 0, ldz = 0, kept_stride = 0;
-  long w_stride = 0;
-  int route = 0;     // 0: fast where the stack has the shape for it, else general; 1: general only; 2: fast only (tests)
+  long w2_stride = 0;
+  int route = 0;     // 0: the compact route; 1: the sweep over the dense stack (X, G allocated only then)
   double tol = 0;
 };
 

@@ -3,11 +3,11 @@
 // (rows 0..14 of H_o verbatim), R_n = Q_1^T R_o Q_1 (msckf.h:423-431, 1343-1366) -- see literal_core.h, which holds the
 // algorithm (shared with the host build that tests/test_literal_core.py checks against the oracle on the CPU).
 //
-// One workgroup of 1024 threads per trajectory, f64.  Two routes (literal_core.h): where the stack has the usual shape --
-// every later Householder step reflects until the gauge columns -- the compression follows from the Cholesky factor of
-// H_o^T H_o (k_gram's f64 Gram matrix) minus the rows handed through, plus row solves for the u-rows of A Q_1: no m x n
-// stack is built; otherwise (few rows, a dependent column in the middle of the sweep: the shape is checked on the
-// factorization) the reference's sequence runs to the letter on the dense stack in global memory.  The output is the
+// One workgroup of 1024 threads per trajectory, f64.  The reference's sequence of Householder steps runs on a compressed
+// representation (literal_core.h, literal_compact): the rows that can become pivot rows (the first 15 + 6N) explicitly, all
+// the others through their Gram matrix -- k_gram's f64 H_o^T H_o minus the explicit rows -- so that a step costs O(n^2)
+// instead of a pass over the m x n stack, which is never built (the sweep over the dense stack, literal_general, stays
+// selectable with MSCKF_HIP_LITERAL_ROUTE=1 for tests and A/B runs: 146 ms against ~10 per update at a 30-camera window).  The output is the
 // information matrix Lam^ = [T_H | r_n]^T R_n^-1 [T_H | r_n] in the place where k_gram leaves H_o^T H_o, so that the blocked
 // Cholesky and the Kalman stage run unchanged with sigma^2 = 1.
 #include "dev_common.h"
@@ -42,19 +42,18 @@ __global__ __launch_bounds__(1024) void k_literal(Dev<S> d, int b0, int nb) {
   a.Hx = d.trk_Hx + (long)b * d.f_cap * d.m_cap * 12;
   a.rw = d.trk_rw + (long)b * d.f_cap * 2 * d.m_cap;
   a.u_var = (double)prm[PRM_UVAR]; a.v_var = (double)prm[PRM_VVAR]; a.tol = L.tol;
-  a.ldx = L.ldx; a.X = L.X + (long)b * L.ldx * n1;
-  a.tau = L.tau + (long)b * n1;
+  a.ldx = L.ldx; a.X = L.X ? L.X + (long)b * L.ldx * n1 : nullptr;
+  a.tau = L.tau + (long)b * (2 * n1 + 2);
   a.Vf = L.Vf + (long)b * d.f_cap * 2 * d.m_cap * 3; a.Tf = L.Tf + (long)b * d.f_cap * 9;
   a.row0 = L.row0 + (long)b * (d.f_cap + 1); a.obs0 = L.obs0 + (long)b * (d.f_cap + 1); a.otrk = L.otrk + (long)b * L.ldg;
   a.kept = L.kept + (long)b * L.kept_stride;
   a.r_cap = L.r_cap; a.TH = L.TH + (long)b * L.r_cap * n1;
-  a.ldg = L.ldg; a.G = L.G + (long)b * L.ldg * L.r_cap;
+  a.ldg = L.ldg; a.G = L.G ? L.G + (long)b * L.ldg * L.r_cap : nullptr;
   a.ldz = L.ldz; a.Z = L.Z + (long)b * L.ldz * L.ldz;
   a.Lam = d.Lam + (long)b * d.ldR * d.ldR; a.ldL = d.ldR;
   a.info = L.info + (long)b * 8;
   a.LamIn = a.Lam; a.lam_part = d.lam_part; a.gram_parts = (d.compress == 3 && d.ldR <= 192 && d.lam_part > 0) ? (d.gram_parts >= 3 ? d.gram_parts : 3) : 1;
-  a.inv = d.trk_inv + (long)b * d.f_cap * d.n_cap; a.inv_stride = d.n_cap;
-  a.W = L.W + (long)b * L.w_stride;
+  a.W2 = L.W2 + (long)b * L.w2_stride;
   lit::literal_compress(c, a, L.route);
   // the blocked Cholesky adds the split-K copies of Lam^ that k_gram leaves (Dev::lam_part apart): none here
   if (d.lam_part) {
@@ -71,7 +70,7 @@ __global__ __launch_bounds__(1024) void k_literal(Dev<S> d, int b0, int nb) {
 
 template <class S>
 void launch_literal(const Dev<S>& d, int b0, int nb, hipStream_t st) {
-  if (nb <= 0 || !d.lit.X) return;
+  if (nb <= 0 || !d.lit.W2) return;
   hipLaunchKernelGGL(k_literal<S>, dim3(nb), dim3(1024), LIT_LDS_DOUBLES * sizeof(double), st, d, b0, nb);
 }
 template void launch_literal<float>(const Dev<float>&, int, int, hipStream_t);

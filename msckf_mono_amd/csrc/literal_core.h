@@ -24,6 +24,11 @@
 // tol * max|R| (exactly zero in exact arithmetic): the reference's algorithm in its exact-arithmetic limit, reproducible to
 // rounding.  tol = 0 is the reference's rule to the letter (tail^2 <= numeric_limits::min).
 //
+// Two routes compute the same thing.  literal_general builds the dense stack and sweeps the reflectors over it, exactly as
+// written above: O(m n) memory passes per step -- the definition, kept for tests and A/B runs.  literal_compact (default)
+// runs the SAME sequence of Householder steps on a compressed representation (the rows that can become pivot rows
+// explicitly, the rest through their Gram matrix) in O(n^2) per step; see there.
+//
 // Written once for two compilers: hipcc (kernels_literal.hip: one workgroup per trajectory, phases separated by barriers)
 // and g++ -DLIT_HOST (tests/cpp/literal_host.cpp: the same phases run serially, checked against the oracle on the CPU).
 // All arithmetic in f64 whatever the filter's scalar type.
@@ -166,7 +171,7 @@ struct Args {
   double u_var, v_var, tol;
   // ---- work space (f64), all per trajectory
   int ldx;                  // row capacity of X (>= stacked rows m)
-  double* X;                // [ldx x (n + 1)] column-major: [H_o(:, 15:) | r_o], then R / reflectors, then Q'
+  double* X;                // dense route only: [ldx x (n + 1)] column-major: [H_o(:, 15:) | r_o], then R / reflectors, then Q'
   double* tau;              // [n]
   double* Vf;               // [F][2 m_cap][3] reflectors of H_f_j (unit lower trapezoidal, implicit ones) -> A_j
   double* Tf;               // [F][9] compact-WY T of those
@@ -177,18 +182,17 @@ struct Args {
   int r_cap;                // >= n + 15 (row capacity of TH / G / Z)
   double* TH;               // [r_cap x (n + 1)] column-major: kept rows of [R | Q^T r_o]
   int ldg;                  // row capacity of G (>= stacked observations)
-  double* G;                // [ldg x r_cap] column-major: u-rows of A Q_1   (R_n = v' I + (u' - v') G^T G)
+  double* G;                // dense route only: [ldg x r_cap] column-major: u-rows of A Q_1   (R_n = v' I + (u' - v') G^T G)
   int ldz;                  // r_cap + n + 1
   double* Z;                // [ldz x ldz] column-major lower triangle: [[R_n, .], [TH^T, 0]] -> Schur complement -Lam^
-  // ---- fast path only (literal_compress_fast): H_o^T H_o as k_gram left it, the slot -> observation map, scratch
+  // ---- compact route: H_o^T H_o as k_gram left it, scratch
   const double* LamIn;      // [H_o | r_o]^T [H_o | r_o], element (hi, lo), lo <= hi <= n, at LamIn[hi * ldL + lo] (+ split-K copies)
   long lam_part; int gram_parts;   // copies of LamIn lam_part doubles apart: block column lo / 64 came in min(lo / 64 + parts - 2, parts) partial sums
-  const signed char* inv; int inv_stride;   // observation index of camera slot s in track t at inv[t * inv_stride + s], -1 = not observed
-  double* W;                // scratch: (n + 1)^2 + ZCAP (n + 1) + ZCAP 2 m_cap + F 18 m_cap + 3 ldg doubles
+  double* W2;               // scratch of the compact route: compact_ws_doubles(6 n_cap, m_cap, r_cap)
   // ---- outputs
   double* Lam; int ldL;     // Lam^(hi, lo), lo <= hi <= n, at Lam[hi * ldL + lo]  (what k_chol_mfma / lam_hat read)
-  int* info;                // [8]: stacked rows m, kept rows r, reflected steps, steps skipped by the tolerance, route (1 fast, 2 general), rows handed
-                            // through verbatim, fast route's shape check: -100 log10 of the smallest independent / the largest dependent pivot ratio
+  int* info;                // [8]: stacked rows m, kept rows r, reflected steps, steps skipped by the tolerance, route (3 compact, 2 dense sweep),
+                            // leading steps that reflect nothing (15), 0, 0
 };
 
 template <class HT> LIT_FN int first_obs(const Args<HT>& a, int t) { return a.off ? a.off[t] : t * a.m_cap; }
@@ -247,16 +251,27 @@ LIT_FN void track_null_space(const Args<HT>& a, int t) {
   T[5] = -tau[2] * T[4] * d12;                       // T(1,2)
 }
 
+template <class HT> LIT_FN void information_from_rn(const Ctx& c, const Args<HT>& a, int n, int nr);
+
 // Tail of both routes: R_n = v' I + (u' - v') G^T G (msckf.h:1366), then Z = [[R_n, .], [[T_H | r_n]^T, 0]] (lower triangle);
 // eliminating the nr pivots of R_n leaves -[T_H | r_n]^T R_n^-1 [T_H | r_n] in the trailing block = -Lam^.
 template <class HT>
 LIT_FN void information_from_compressed(const Ctx& c, const Args<HT>& a, int n, int nr, int mobs) {
-  const int rc = a.r_cap;
-  const int nz = nr + n + 1;
   const long ldz = a.ldz;
   double* Z = a.Z;
   const double dlt = a.u_var - a.v_var;
   syrk_lower(c, a.G, a.ldg, nr, mobs, [&](int i, int j, double sgg) { Z[i + ldz * j] = dlt * sgg + (i == j ? a.v_var : 0.0); });
+  barrier(c);
+  information_from_rn(c, a, n, nr);
+}
+
+// Z(0:nr, 0:nr) holds the lower triangle of R_n: append [T_H | r_n]^T, eliminate, store Lam^
+template <class HT>
+LIT_FN void information_from_rn(const Ctx& c, const Args<HT>& a, int n, int nr) {
+  const int rc = a.r_cap;
+  const int nz = nr + n + 1;
+  const long ldz = a.ldz;
+  double* Z = a.Z;
   par_for(c, (long)(n + 1) * nz, [&](long e) {
     const int j = (int)(e / (n + 1)), cc = (int)(e - (long)j * (n + 1));
     Z[(nr + cc) + ldz * j] = j < nr ? a.TH[j + (long)rc * cc] : 0.0;
@@ -484,25 +499,7 @@ LIT_FN void literal_general(const Ctx& c, const Args<HT>& a, const int m, const 
   information_from_compressed(c, a, n, nr, mobs);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// The fast route, for the usual shape of a stack: many more rows than columns, every camera of the window (but for leading
-// ones nobody saw) observed, rank deficiency only in the window's gauge directions.  Then HouseholderQR(H_o) does nothing
-// special after handing through the first z = 15 + 6 c0 rows (c0 = leading cameras without an observation): every later
-// step reflects until the columns that depend on the previous ones are reached, and those are the last ones, whose steps
-// find nothing but zeros below (rows dropped).  So Q_1 = [e_0 .. e_(z-1) | Q'] with Q' ANY orthonormal basis of the column
-// space of H' = H_o(z:, :), and the update depends on Q_1 only through its span (T_H, r_n, R_n transform together under a
-// rotation of the kept rows).  With H' = Q' R':
-//     R'      = chol(H'^T H'),  H'^T H' = H_o^T H_o - H_o(:z)^T H_o(:z);  H_o^T H_o is what k_gram accumulates in f64
-//               (sum_j [H_x | r]^T (I - Q_f Q_f^T) [H_x | r]: independent of the null-space basis)
-//     Q'^T r' = R'^-T H'^T r'                         (the augmented column of the same factorization)
-//     u-rows of A Q_1 = [ u-rows of A(:, :z) | (u-rows of A_b A_b^T H_x) R'^-1 ],  A_b = the columns of A below row z:
-//               A_b A_b^T = I - Q_f(:, :d) Q_f(:, :d)^T per track, d = 3 + (rows of the track among the first z)
-// -- no m x n stack, no reflector sweep: O(n^3 + (sum M) n^2) instead of O(m n^2) passes over 8 MB per trajectory.
-// Whether the stack has that shape is checked on the factorization itself (a column found dependent -- pivot below
-// tol^2 |column|^2, the Householder tail rule in Gram form -- followed by an independent one, or a pivot too close to the
-// threshold to call, or m <= z, or z > LIT_ZCAP): if not, the caller runs literal_general.  Returns whether it applied.
-constexpr int LIT_ZCAP = 63;
-
+// H_o^T H_o as k_gram left it: the lower triangle in up to `gram_parts` partial sums
 template <class HT>
 LIT_FN double lam_in(const Args<HT>& a, int hi, int lo) {   // hi >= lo
   const double* p = a.LamIn + (long)hi * a.ldL + lo;
@@ -514,303 +511,319 @@ LIT_FN double lam_in(const Args<HT>& a, int hi, int lo) {   // hi >= lo
   return v;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The compact route: HouseholderQR(H_o) in the reference's order, STEP BY STEP, for any shape of stack, without the stack.
+// Only the rows 0 .. e-1, e = min(m, 15 + n), can ever be pivot rows (step 15 + k pivots on row 15 + k): they are kept
+// explicitly (E, e x (n + 1)).  Of the rows below (B) a reflector needs only inner products of columns -- the Gram matrix
+// Gb = B^T B = [H_o | r_o]^T [H_o | r_o] - E^T E, which k_gram already accumulates in f64 -- and leaves B as B0 Y for a
+// coefficient matrix Y it updates by column operations:
+//     |tail|^2 = sum_(i>p) E(i,k)^2 + Gb(k,k)                        v = [.. 1 | E(i>p,k) | B(:,k)] / (c0 - beta)
+//     v^T x_j  = E(p,j) + sum_(i>p) v_i E(i,j) + Gb(k,j) / (c0-beta)  s_j = tau v^T x_j,  a_j = s_j / (c0 - beta)
+//     E(p,j) -= s_j,  E(i>p,j) -= s_j v_i,  B(:,j) -= a_j B(:,k):   Y(:,j) -= a_j Y(:,k),
+//     Gb(j,l) -= a_l Gb(j,k) + a_j Gb(k,l) - a_j a_l Gb(k,k)
+// -- the same numbers as the sweep over the dense stack (literal_general), O(e n + n^2) per step instead of O(m n).  A
+// vector of the stack's row space is then [t ; B0 y]: the columns of Q_1 = H_0 H_1 .. e_row are built in that form from the
+// stored reflectors (v^T [t ; B0 y] = v_E^T t + (Gb0 y_v)^T y), and the u-rows of A Q_1 that R_n = Q_1^T R_o Q_1 needs are
+//     G = G_E Tq + Hu Yq,   G_E(:, i) = u-rows of A e_i (explicit rows),  Hu = u-rows of A_B A_B^T H_x (rows in B),
+// so that G^T G = Tq^T (G_E^T G_E) Tq + Tq^T (G_E^T Hu) Yq + (.)^T + Yq^T (Hu^T Hu) Yq with three small matrices accumulated
+// per track (Hu^T Hu is block-local: a track touches its own cameras' columns).  Nothing of size m x n exists.
+LIT_FN long compact_ws_doubles(int n, int m_cap, int r_cap) {
+  const long n1 = n + 1, ec = 15 + n;
+  return ec * n1 + ec * 2L * m_cap + n1 * n1 + 4L * n * n + ec * (long)r_cap + (long)n * r_cap + ec * ec + ec * (long)n + ec * (long)r_cap + (long)n * r_cap + (long)m_cap * 6 * m_cap + 64;
+}
+
 template <class HT>
-LIT_FN bool literal_fast(const Ctx& c, const Args<HT>& a, const int m, const int mobs) {
-  const int n = 6 * a.N, F = a.F, n1 = n + 1;
-  double* C = a.W;                              // (n + 1)^2 column-major, lower triangle: Lam' -> L = R'^T (row n: Q'^T r')
-  double* Xt = C + (long)n1 * n1;               // [LIT_ZCAP][n + 1] row-major: rows 0..z-1 of [H_o | r_o]
-  double* At = Xt + (long)LIT_ZCAP * n1;        // [LIT_ZCAP][2 m_cap]: column i - row0 of A_j, for the z top rows
-  double* Bt = At + (long)LIT_ZCAP * 2 * a.m_cap;   // [F][3][6 m_cap]: rows 0..2 of Q_f^T H_x_j (compact: column 6 o + kk)
-  double* Qfu = Bt + (long)F * 18 * a.m_cap;    // [ldg][3]: Q_f(2o, 0..2) per stacked observation
-  double* dcol = a.tau;                         // [n] |column|^2 of H_o (incl. the top rows)
+LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const int mobs) {
+  const int n = 6 * a.N, F = a.F, n1 = n + 1, D = 15 + n;
+  const int e = m < D ? m : D;                  // explicit rows
+  const int steps_total = e, msteps = steps_total - 15 > 0 ? steps_total - 15 : 0;
+  const long ec = 15 + n, rc = a.r_cap;
+  double* E = a.W2;                             // [ec x n1] column-major (leading dimension ec)
+  double* At = E + ec * n1;                     // [ec][2 m_cap]: a_i = A_j e_(i - row0) for the explicit rows
+  double* Gb = At + ec * 2L * a.m_cap;          // [n1 x n1] symmetric, both triangles
+  double* Gb0 = Gb + (long)n1 * n1;             // [n x n] Gb before the sweep (Jacobian columns)
+  double* Y = Gb0 + (long)n * n;                // [n x n] B = B0 Y
+  double* Yv = Y + (long)n * n;                 // [n x n] column k: B-part of reflector k in coordinates of B0's columns
+  double* Gv = Yv + (long)n * n;                // [n x n] column k: Gb0 Yv(:, k)
+  double* Tq = Gv + (long)n * n;                // [ec x rc] explicit-row part of the kept columns of Q
+  double* Yq = Tq + ec * rc;                    // [n x rc] B-part of the kept columns of Q (coordinates of B0's columns)
+  double* See = Yq + (long)n * rc;              // [ec x ec] G_E^T G_E
+  double* Seb = See + ec * ec;                  // [ec x n] G_E^T Hu
+  double* P1 = Seb + ec * n;                    // [ec x rc] See Tq + Seb Yq
+  double* P3 = P1 + ec * rc;                    // [n x rc] Gam Yq + Seb^T Tq
+  double* Hh = P3 + (long)n * rc;               // [m_cap][6 m_cap] u-rows of one track's projected Jacobian (compact columns)
+  double* Gam = Gv;                             // Hu^T Hu reuses Gv's space once the columns of Q are built
   const int ks = n + 16;
-  int* flag = a.kept + ks;                      // [ks] kept flags of top rows
-  int* skip = a.kept + 2 * ks;                  // [ks] column found dependent
-  int* kidx = a.kept + 3 * ks;                  // [ks] ordinal of a column among the independent ones, -1
-  int* topt = a.kept + 4 * ks;                  // [LIT_ZCAP + 1] track of top row i
-  int* shared = a.kept + 5 * ks;                // z, ok, r', skipped-active count
+  int* flag = a.kept + ks;
+  int* topt = a.kept + 2 * ks;                  // [ec] track of explicit row i
   tick(c, 1);
-  // ---- z and the tracks of the top rows
+  // ---- explicit rows: a_i = Q_f e_(3 + i - row0) and row i of [H_o | r_o] (msckf.h:957, :430)
   if (first_thread(c)) {
-    unsigned long long seen = 0;
-    for (int t = 0; t < F; ++t)
-      if (a.status[t] & a.inc_bit) for (int o = 0; o < a.M[t]; ++o) seen |= 1ull << (a.slots[first_obs(a, t) + o] & 63);
-    int c0 = 0;
-    while (c0 < a.N && !((seen >> c0) & 1ull)) ++c0;
-    const int z = 15 + 6 * c0;
-    int ok = (z <= LIT_ZCAP && m > z && a.LamIn != nullptr) ? 1 : 0;
-    if (ok) {
-      int t = 0;
-      for (int i = 0; i < z; ++i) {
-        while (!(a.status[t] & a.inc_bit) || a.row0[t] + 2 * a.M[t] - 3 <= i) ++t;
-        topt[i] = t;
-      }
+    int t = 0;
+    for (int i = 0; i < e; ++i) {
+      while (!(a.status[t] & a.inc_bit) || a.row0[t] + 2 * a.M[t] - 3 <= i) ++t;
+      topt[i] = t;
     }
-    shared[0] = z; shared[1] = ok;
   }
+  par_for(c, (long)e * n1, [&](long x) { const long j = x / e, i = x - j * e; E[i + ec * j] = 0.0; });
   barrier(c);
-  const int z = shared[0];
-  if (!shared[1]) return false;
-  // ---- a_i = A_j e_(i - row0) = Q_f e_(3 + i - row0), the top rows of [H_o | r_o] (msckf.h:957, :430)
-  par_for(c, (long)z * n1, [&](long e) { Xt[e] = 0.0; });
-  barrier(c);
-  par_for(c, z, [&](long i) {
+  par_for(c, e, [&](long i) {
     const int t = topt[i], M = a.M[t], R2 = 2 * M, q = 3 + (int)i - a.row0[t];
     const double* V = a.Vf + (long)t * 2 * a.m_cap * 3;
     const double* T = a.Tf + (long)t * 9;
     double* ai = At + i * 2 * a.m_cap;
     double sv[3], w[3];
     for (int p = 0; p < 3; ++p) sv[p] = vf_at(V, q, p);
-    for (int p = 0; p < 3; ++p) { double x = 0; for (int qq = p; qq < 3; ++qq) x += T[p * 3 + qq] * sv[qq]; w[p] = x; }   // T V(q, :)^T
+    for (int p = 0; p < 3; ++p) { double x = 0; for (int qq = p; qq < 3; ++qq) x += T[p * 3 + qq] * sv[qq]; w[p] = x; }
     for (int r = 0; r < R2; ++r) ai[r] = (r == q ? 1.0 : 0.0) - (vf_at(V, r, 0) * w[0] + vf_at(V, r, 1) * w[1] + vf_at(V, r, 2) * w[2]);
     const HT* hx = a.Hx + (long)t * a.m_cap * 12;
     const HT* rr = a.rw + (long)t * 2 * a.m_cap;
-    double* xr = Xt + i * n1;
     double sr = 0;
     for (int o = 0; o < M; ++o) {
       const int col = 6 * a.slots[first_obs(a, t) + o];
-      for (int kk = 0; kk < 6; ++kk) xr[col + kk] = ai[2 * o] * (double)hx[o * 12 + kk] + ai[2 * o + 1] * (double)hx[o * 12 + 6 + kk];
+      for (int kk = 0; kk < 6; ++kk) E[i + ec * (col + kk)] = ai[2 * o] * (double)hx[o * 12 + kk] + ai[2 * o + 1] * (double)hx[o * 12 + 6 + kk];
       sr += ai[2 * o] * (double)rr[2 * o] + ai[2 * o + 1] * (double)rr[2 * o + 1];
     }
-    xr[n] = sr;
+    E[i + ec * n] = sr;
   });
   barrier(c);
   tick(c, 2);
-  // ---- Lam' = H_o^T H_o - (top rows)^T (top rows), lower triangle incl. row n
-  par_for(c, (long)n1 * n1, [&](long e) {
-    const int lo = (int)(e / n1), hi = (int)(e - (long)lo * n1);
+  // ---- Gb = [H_o | r_o]^T [H_o | r_o] - E^T E (zero when every row is explicit), Y = I
+  par_for(c, (long)n1 * n1, [&](long x) {
+    const int lo = (int)(x / n1), hi = (int)(x - (long)lo * n1);
     if (hi < lo) return;
-    const double full = (hi == n && lo == n) ? 0.0 : lam_in(a, hi, lo);
-    double s = 0;
-    for (int i = 0; i < z; ++i) s += Xt[i * n1 + hi] * Xt[i * n1 + lo];
-    C[hi + (long)n1 * lo] = full - s;
-    if (hi == lo && hi < n) dcol[hi] = full;
+    double v = 0.0;
+    if (m > e) {
+      const double full = (hi == n && lo == n) ? 0.0 : lam_in(a, hi, lo);
+      double sacc = 0;
+      for (int i = 0; i < e; ++i) sacc += E[i + ec * hi] * E[i + ec * lo];
+      v = full - sacc;
+    }
+    Gb[hi + (long)n1 * lo] = v; Gb[lo + (long)n1 * hi] = v;
+    if (hi < n) { Gb0[hi + (long)n * lo] = v; Gb0[lo + (long)n * hi] = v; }
   });
+  par_for(c, (long)n * n, [&](long x) { const long j = x / n, i = x - j * n; Y[x] = i == j ? 1.0 : 0.0; Yv[x] = 0.0; });
   barrier(c);
   tick(c, 3);
-  // ---- Cholesky with the zero-tail rule in Gram form: the pivot of column k IS |tail|^2 of Householder step 15 + k
-  // The pivot of column k is |tail|^2 of Householder step 15 + k, so the Householder rule itself decides: dependent iff
-  // pivot <= tol^2 |column|^2.  What the f64 Gram matrix resolves (measured over the benchmark's sequences at a 30-camera
-  // window): exactly dependent columns come out at 3e-11 |column|^2 in good geometry and up to 3e-8 in the weakest (small
-  // earlier pivots amplify the rounding), columns that depend on the others only up to the float rounding of H_x at up to
-  // 2e-7, independent ones from 2e-6.  Hence tol^2 no finer than 1e-7 here, and a pivot within 10 % of the threshold is left
-  // to the general route's tail test.
-  // (Float Jacobians: the two populations overlap in weak geometry -- whichever way such a column is called is inside the
-  // float filter's own rounding, so the threshold decides and nothing is handed to the general route.)
-  const double t2a = a.tol * a.tol, lo2 = t2a > 1e-7 ? t2a : 1e-7, band = sizeof(HT) == 4 ? 0.0 : 0.1 * lo2;
-  int ok = 1, seen_dep = 0;
-  double min_ind = 1.0, max_dep = 1e-300;
-  for (int k = 0; k < n; ++k) {
-    double* ck = C + (long)n1 * k;
-    const double piv = ck[k], dk = dcol[k];
-    if (dk > 0.0) { const double ratio = piv / dk; if (ratio > lo2) min_ind = ratio < min_ind ? ratio : min_ind; else if (ratio > max_dep) max_dep = ratio; }
-    bool indep = dk > 0.0 && piv > lo2 * dk;
-    if (dk > 0.0 && fabs(piv / dk - lo2) < band) ok = 0;                         // too close to call
-    // float Jacobians: once the dependent columns have begun, a pivot that clears the threshold by less than a factor 30 is
-    // the same rounding of H_x that the threshold is there to catch (a column that is really independent again -- a stack
-    // for the general route -- clears it by orders of magnitude)
-    if (sizeof(HT) == 4 && indep && seen_dep && piv < 30 * lo2 * dk) indep = false;
-    if (dk > 0.0 && !indep) seen_dep = 1;
+  // ---- the sweep (msckf.h:1343): steps 0..14 meet the zero IMU columns; step 15 + k works on camera column k, pivot row 15 + k
+  const double tol2 = a.tol * a.tol;
+  int n_reflect = 0, n_skip_tol = 0;
+  for (int k = 0; k < msteps; ++k) {
+    const int p = 15 + k;
+    double* ek = E + ec * k;
+    const double gkk = Gb[k + (long)n1 * k] > 0.0 ? Gb[k + (long)n1 * k] : 0.0;
+    const double tail2 = wg_sum(c, p + 1, e, [&](long i) { return ek[i] * ek[i]; }) + gkk;
+    double zero2 = 2.2250738585072014e-308;
+    if (a.tol > 0) {
+      // The part of the tail that lives in B comes out of the Gram matrix, which resolves |tail|^2 to ~1e-8 |column|^2 at
+      // best (measured over the benchmark's sequences: exactly dependent columns leave 3e-11 .. 3e-8, independent ones 2e-6
+      // and more): no finer a threshold than 1e-7 while rows below the explicit ones exist
+      const double head2 = wg_sum(c, 0, p + 1, [&](long i) { return ek[i] * ek[i]; });
+      const double t2 = (m > e && tol2 < 1e-7) ? 1e-7 : tol2;
+      const double z = t2 * (head2 + tail2);
+      zero2 = z > zero2 ? z : zero2;
+    }
+    const double c0 = ek[p];
     barrier(c);
-    if (!indep) {
-      if (first_thread(c)) skip[k] = 1;
-      par_for(c, n1 - k, [&](long i) { ck[k + i] = 0.0; });
+    if (tail2 <= zero2) {
+      if (tail2 > 2.2250738585072014e-308) ++n_skip_tol;
+      if (first_thread(c)) a.tau[k] = 0.0;
+      par_for(c, e - (p + 1), [&](long i) { ek[p + 1 + i] = 0.0; });
       barrier(c);
       continue;
     }
-    const double dinv = 1.0 / sqrt(piv);
-    if (first_thread(c)) skip[k] = 0;
-    par_for(c, n1 - k, [&](long i) { ck[k + i] *= dinv; });       // column k of L (the diagonal becomes sqrt(piv))
+    ++n_reflect;
+    double beta = sqrt(c0 * c0 + tail2);
+    if (c0 >= 0.0) beta = -beta;
+    const double dn = 1.0 / (c0 - beta), tk = (beta - c0) / beta;
+    par_for(c, e - (p + 1), [&](long i) { ek[p + 1 + i] *= dn; });
+    par_for(c, n, [&](long i) { Yv[i + (long)n * k] = Y[i + (long)n * k] * dn; });
+    if (first_thread(c)) { ek[p] = beta; a.tau[k] = tk; }
     barrier(c);
-    wave_for(c, k + 1, n, [&](long j) {
-      const double ljk = ck[j];
-      if (ljk == 0.0) return;
-      double* cj = C + (long)n1 * j;
-      lane_for(c, j, n1, [&](long i) { cj[i] -= ck[i] * ljk; });
+    // a_j for the columns to the right (r_o rides along as column n); kept in tau's tail [n .. 2n]
+    double* aj = a.tau + n1;
+    wave_for(c, k + 1, n1, [&](long j) {
+      double* ej = E + ec * j;
+      double sdot = wave_sum_range(c, p + 1, e, [&](long i) { return ek[i] * ej[i]; });
+      sdot = (sdot + ej[p] + Gb[k + (long)n1 * j] * dn) * tk;
+      lane_for(c, p + 1, e, [&](long i) { ej[i] -= sdot * ek[i]; });
+      if (first_lane(c)) { ej[p] -= sdot; aj[j] = sdot * dn; }
+    });
+    barrier(c);
+    // B(:, j) -= a_j B(:, k): Gram and coefficients (columns k+1 .. n; Y only over the Jacobian columns)
+    par_for(c, (long)(n1 - k - 1) * (n1 - k - 1), [&](long x) {
+      const int w = n1 - k - 1, jl = (int)(x / w), il = (int)(x - (long)jl * w), j = k + 1 + jl, l = k + 1 + il;
+      if (l < j) return;
+      const double v = Gb[l + (long)n1 * j] - aj[l] * Gb[j + (long)n1 * k] - aj[j] * Gb[l + (long)n1 * k] + aj[j] * aj[l] * gkk;
+      Gb[l + (long)n1 * j] = v; Gb[j + (long)n1 * l] = v;
+    });
+    par_for(c, (long)(n - k - 1) * (k + 1), [&](long x) {
+      const int jl = (int)(x / (k + 1)), i = (int)(x - (long)jl * (k + 1)), j = k + 1 + jl;
+      Y[i + (long)n * j] -= aj[j] * Y[i + (long)n * k];       // column k of Y has its support in rows 0..k
     });
     barrier(c);
   }
   tick(c, 4);
-  // ---- shape of the stack: the dependent columns must be the last of the observed ones
-  if (first_thread(c)) {
-    int rp = 0, nsk = 0, seen_skip = 0;
-    for (int k = 0; k < n; ++k) {
-      if (dcol[k] > 0.0) {
-        if (skip[k]) { seen_skip = 1; ++nsk; }
-        else if (seen_skip) ok = 0;
-      }
-      kidx[k] = skip[k] ? -1 : rp;
-      if (!skip[k]) ++rp;
-    }
-    shared[1] = ok; shared[2] = rp; shared[3] = nsk;
-    a.info[6] = (int)(-100.0 * log10(min_ind)); a.info[7] = (int)(-100.0 * log10(max_dep));
-  }
-  barrier(c);
-  if (!shared[1]) return false;
-  const int rp = shared[2];
-  // ---- rows that are kept (msckf.h:1345-1348) and [T_H | r_n]
+  // ---- rows of R that are kept (msckf.h:1345-1348) and [T_H | r_n]
   double rmax = 0;
-  if (a.tol > 0) {
-    const double r1 = wg_max(c, 0, (long)z * n, [&](long e) { const long i = e / n, j = e - i * n; return (j + 15 >= i) ? fabs(Xt[i * n1 + j]) : 0.0; });
-    const double r2 = wg_max(c, 0, (long)n * n, [&](long e) { const long k = e / n, j = e - k * n; return (j >= k && !skip[k]) ? fabs(C[j + (long)n1 * k]) : 0.0; });
-    rmax = r1 > r2 ? r1 : r2;
-  }
+  if (a.tol > 0) rmax = wg_max(c, 0, (long)steps_total * n, [&](long x) { const long j = x / steps_total, i = x - j * steps_total; return (j + 15 >= i) ? fabs(E[i + ec * j]) : 0.0; });
   barrier(c);
-  par_for(c, z, [&](long i) {
+  par_for(c, steps_total, [&](long i) {
     int any = 0;
     const int c_lo = i >= 15 ? (int)i - 15 : 0;
-    for (int j = c_lo; j < n && !any; ++j) { const double v = fabs(Xt[i * n1 + j]); any = a.tol > 0 ? (v > a.tol * rmax) : (v != 0.0); }
+    for (int j = c_lo; j < n && !any; ++j) { const double v = fabs(E[i + ec * j]); any = a.tol > 0 ? (v > a.tol * rmax) : (v != 0.0); }
     flag[i] = any;
   });
   barrier(c);
   if (first_thread(c)) {
     int nr = 0;
-    for (int i = 0; i < z; ++i) if (flag[i]) a.kept[nr++] = i;
-    shared[4] = nr;                                   // kept top rows
-    for (int k = 0; k < n; ++k) if (!skip[k]) a.kept[nr++] = z + k;   // (row labels only: z + column)
-    a.info[1] = nr; a.info[2] = rp; a.info[3] = shared[3]; a.info[4] = 1; a.info[5] = z;
+    for (int i = 0; i < steps_total; ++i) if (flag[i]) a.kept[nr++] = i;
+    a.info[1] = nr; a.info[2] = n_reflect; a.info[3] = n_skip_tol; a.info[4] = 3; a.info[5] = steps_total - msteps;
   }
   barrier(c);
-  const int nr = a.info[1], ztk = shared[4];
-  const int rc = a.r_cap;
-  par_for(c, (long)nr * n1, [&](long e) {
-    const int j = (int)(e / nr), k = (int)(e - (long)j * nr);
-    double v;
-    if (k < ztk) { const int row = a.kept[k]; v = (j < n && j + 15 < row) ? 0.0 : Xt[row * n1 + j]; }
-    else { const int col = a.kept[k] - z; v = j >= col ? C[j + (long)n1 * col] : 0.0; }
-    a.TH[k + (long)rc * j] = v;
+  const int nr = a.info[1];
+  par_for(c, (long)nr * n1, [&](long x) {
+    const int j = (int)(x / nr), k = (int)(x - (long)j * nr), row = a.kept[k];
+    double v = E[row + ec * j];
+    if (j < n && j + 15 < row) v = 0.0;
+    a.TH[k + rc * j] = v;
   });
-  // ---- G, top columns: u-rows of A e_i (non-zero inside the row's own track)
-  par_for(c, (long)ztk * mobs, [&](long e) {
-    const int k = (int)(e / mobs), g = (int)(e - (long)k * mobs), i = a.kept[k], t = topt[i];
-    const int o = g - a.obs0[t];
-    a.G[(long)a.ldg * k + g] = (a.otrk[g] == t) ? At[i * 2 * a.m_cap + 2 * o] : 0.0;
-  });
-  tick(c, 5);
-  // ---- rows 0..2 of Q_f^T H_x_j per track and Q_f(2o, 0..2) per observation: with them a u-row of the projected Jacobian
-  // is three products per entry for every track that has no row among the first z (d = 3)
-  par_for(c, (long)F * 6 * a.m_cap, [&](long e) {
-    const int t = (int)(e / (6 * a.m_cap)), cc = (int)(e - (long)t * 6 * a.m_cap);
-    if (!(a.status[t] & a.inc_bit) || cc >= 6 * a.M[t]) return;
-    const double* V = a.Vf + (long)t * 2 * a.m_cap * 3;
-    const double* T = a.Tf + (long)t * 9;
-    const HT* hx = a.Hx + (long)t * a.m_cap * 12;
-    const int op = cc / 6, kk = cc - 6 * op;
-    const double h0 = (double)hx[op * 12 + kk], h1 = (double)hx[op * 12 + 6 + kk];
-    double sv[3], w[3];
-    for (int p2 = 0; p2 < 3; ++p2) sv[p2] = vf_at(V, 2 * op, p2) * h0 + vf_at(V, 2 * op + 1, p2) * h1;
-    for (int q = 0; q < 3; ++q) { double x = 0; for (int p2 = 0; p2 <= q; ++p2) x += T[p2 * 3 + q] * sv[p2]; w[q] = x; }
-    for (int q = 0; q < 3; ++q) {
-      const double hq = q == 2 * op ? h0 : (q == 2 * op + 1 ? h1 : 0.0);
-      Bt[((long)t * 3 + q) * 6 * a.m_cap + cc] = hq - (vf_at(V, q, 0) * w[0] + vf_at(V, q, 1) * w[1] + vf_at(V, q, 2) * w[2]);
-    }
-  });
-  par_for(c, mobs, [&](long g) {
-    const int t = a.otrk[g], o = (int)g - a.obs0[t];
-    const double* V = a.Vf + (long)t * 2 * a.m_cap * 3;
-    const double* T = a.Tf + (long)t * 9;
-    double tv[3];
-    for (int p2 = 0; p2 < 3; ++p2) tv[p2] = vf_at(V, 2 * o, 0) * T[0 * 3 + p2] + vf_at(V, 2 * o, 1) * T[1 * 3 + p2] + vf_at(V, 2 * o, 2) * T[2 * 3 + p2];
-    for (int q = 0; q < 3; ++q) Qfu[g * 3 + q] = (q == 2 * o ? 1.0 : 0.0) - (tv[0] * vf_at(V, q, 0) + tv[1] * vf_at(V, q, 1) + tv[2] * vf_at(V, q, 2));
+  // ---- Gv(:, k) = Gb0 Yv(:, k) for the reflectors that exist (Yv(:, k) has its support in rows 0..k)
+  par_for(c, (long)n * msteps, [&](long x) {
+    const int k = (int)(x / n), i = (int)(x - (long)k * n);
+    double sacc = 0;
+    if (a.tau[k] != 0.0 && m > e) for (int l = 0; l <= k; ++l) sacc += Gb0[i + (long)n * l] * Yv[l + (long)n * k];
+    Gv[i + (long)n * k] = sacc;
   });
   barrier(c);
-  // ---- G, the other columns: x = (u-row of A_b A_b^T H_x) R'^-1 per stacked observation, 16 columns at a time
-  par_for(c, mobs, [&](long g) {
-    const int t = a.otrk[g], o = (int)g - a.obs0[t], M = a.M[t], R2 = 2 * M, rho = R2 - 3;
-    int kt = z - a.row0[t]; kt = kt < 0 ? 0 : (kt > rho ? rho : kt);
-    const int d = 3 + kt;
-    const double* V = a.Vf + (long)t * 2 * a.m_cap * 3;
-    const double* T = a.Tf + (long)t * 9;
-    const HT* hx = a.Hx + (long)t * a.m_cap * 12;
-    const signed char* inv = a.inv + (long)t * a.inv_stride;
-    double* gout = a.G + (long)a.ldg * ztk + g;
-    if (d >= R2) { for (int k = 0; k < rp; ++k) gout[(long)a.ldg * k] = 0.0; return; }
-    double tv[3], Sd[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, ev[3];
-    for (int p = 0; p < 3; ++p) tv[p] = vf_at(V, 2 * o, 0) * T[0 * 3 + p] + vf_at(V, 2 * o, 1) * T[1 * 3 + p] + vf_at(V, 2 * o, 2) * T[2 * 3 + p];
-    for (int q = 0; q < d; ++q) for (int p1 = 0; p1 < 3; ++p1) for (int p = 0; p < 3; ++p) Sd[p1][p] += vf_at(V, q, p1) * vf_at(V, q, p);
-    for (int p = 0; p < 3; ++p) ev[p] = (2 * o < d ? vf_at(V, 2 * o, p) : 0.0) - (tv[0] * Sd[0][p] + tv[1] * Sd[1][p] + tv[2] * Sd[2][p]);
-    auto qf = [&](int q) -> double { return (q == 2 * o ? 1.0 : 0.0) - (tv[0] * vf_at(V, q, 0) + tv[1] * vf_at(V, q, 1) + tv[2] * vf_at(V, q, 2)); };   // Q_f(2o, q)
-    auto hhat = [&](int col) -> double {
-      const int slot = col / 6, kk = col - 6 * slot, op = inv[slot];
-      if (op < 0) return 0.0;
-      const double h0 = (double)hx[op * 12 + kk], h1 = (double)hx[op * 12 + 6 + kk];
-      double sv[3], val = op == o ? h0 : 0.0;
-      for (int p = 0; p < 3; ++p) sv[p] = vf_at(V, 2 * op, p) * h0 + vf_at(V, 2 * op + 1, p) * h1;
-      for (int q = 0; q < 3; ++q) { double w = 0; for (int p = 0; p <= q; ++p) w += T[p * 3 + q] * sv[p]; val += ev[q] * w; }
-      if (2 * op < d) val -= qf(2 * op) * h0;
-      if (2 * op + 1 < d) val -= qf(2 * op + 1) * h1;
-      return val;
-    };
-    int smin = 1 << 30;
-    for (int o2 = 0; o2 < M; ++o2) { const int sl = a.slots[first_obs(a, t) + o2]; smin = sl < smin ? sl : smin; }
-    const int cb0 = (6 * smin / 16) * 16;
-    for (int k = 0; k < n; ++k) if (k < cb0 && kidx[k] >= 0) gout[(long)a.ldg * kidx[k]] = 0.0;
-    for (int cb = cb0; cb < n; cb += 16) {
-      double acc[16];
-      if (d == 3) {
-        const double q0 = Qfu[g * 3], q1 = Qfu[g * 3 + 1], q2 = Qfu[g * 3 + 2];
-        const double* b0 = Bt + (long)t * 3 * 6 * a.m_cap; const double* b1 = b0 + 6 * a.m_cap; const double* b2 = b1 + 6 * a.m_cap;
-        for (int j = 0; j < 16; ++j) {
-          const int col = cb + j;
-          double val = 0.0;
-          if (col < n) {
-            const int slot = col / 6, kk = col - 6 * slot, op = inv[slot];
-            if (op >= 0) { const int cc = 6 * op + kk; val = (op == o ? (double)hx[op * 12 + kk] : 0.0) - (q0 * b0[cc] + q1 * b1[cc] + q2 * b2[cc]); }
-          }
-          acc[j] = val;
-        }
-      } else {
-        for (int j = 0; j < 16; ++j) acc[j] = cb + j < n ? hhat(cb + j) : 0.0;
-      }
-      // four earlier columns per pass: their x and their rows of R' are requested together (one column per pass left every
-      // load waiting for the previous one's use: 8 of the fast route's 15 ms); a dependent column contributes x = 0
-      const int nj = n - cb < 16 ? n - cb : 16;
-      int cp = cb0;
-      for (; cp + 4 <= cb; cp += 4) {
-        const int k0 = kidx[cp], k1 = kidx[cp + 1], k2 = kidx[cp + 2], k3 = kidx[cp + 3];
-        const double x0 = k0 >= 0 ? gout[(long)a.ldg * k0] : 0.0, x1 = k1 >= 0 ? gout[(long)a.ldg * k1] : 0.0;
-        const double x2 = k2 >= 0 ? gout[(long)a.ldg * k2] : 0.0, x3 = k3 >= 0 ? gout[(long)a.ldg * k3] : 0.0;
-        const double* r0 = C + (long)n1 * cp + cb; const double* r1 = r0 + n1; const double* r2 = r1 + n1; const double* r3 = r2 + n1;   // R'(cp + i, cb + j)
-        if (nj == 16) {
-#pragma unroll
-          for (int j = 0; j < 16; ++j) acc[j] -= x0 * r0[j] + x1 * r1[j] + x2 * r2[j] + x3 * r3[j];
-        } else {
-          for (int j = 0; j < nj; ++j) acc[j] -= x0 * r0[j] + x1 * r1[j] + x2 * r2[j] + x3 * r3[j];
-        }
-      }
-      for (; cp < cb; ++cp) {
-        if (kidx[cp] < 0) continue;
-        const double xc = gout[(long)a.ldg * kidx[cp]];
-        const double* rrow = C + (long)n1 * cp + cb;          // R'(cp, cb + j)
-        for (int j = 0; j < nj; ++j) acc[j] -= xc * rrow[j];
-      }
-      for (int j = 0; j < 16; ++j) {
-        const int col = cb + j;
-        if (col >= n || kidx[col] < 0) continue;
-        const double* rrow = C + (long)n1 * col + cb;
-        const double x = acc[j] / rrow[j];
-        gout[(long)a.ldg * kidx[col]] = x;
-        for (int j2 = j + 1; j2 < 16; ++j2) if (cb + j2 < n) acc[j2] -= x * rrow[j2];
-      }
+  tick(c, 5);
+  // ---- kept columns of Q = H_0 H_1 ..: q = H_0 .. H_k e_(15 + k) as [t ; B0 y]; a column of a row < 15 is e_row itself
+  par_for(c, nr, [&](long ka) {
+    const int row = a.kept[ka];
+    double* t = Tq + ec * ka; double* y = Yq + (long)n * ka;
+    for (int i = 0; i < e; ++i) t[i] = 0.0;
+    for (int i = 0; i < n; ++i) y[i] = 0.0;
+    t[row] = 1.0;
+    if (row < 15) return;
+    for (int j = row - 15; j >= 0; --j) {
+      const double tj = a.tau[j];
+      if (tj == 0.0) continue;
+      const int pj = 15 + j;
+      const double* ej = E + ec * j;
+      double dot = t[pj];
+      for (int i = pj + 1; i < e; ++i) dot += ej[i] * t[i];
+      if (m > e) for (int i = 0; i < n; ++i) dot += Gv[i + (long)n * j] * y[i];
+      const double al = tj * dot;
+      if (al == 0.0) continue;
+      t[pj] -= al;
+      for (int i = pj + 1; i < e; ++i) t[i] -= al * ej[i];
+      if (m > e) for (int i = 0; i <= j; ++i) y[i] -= al * Yv[i + (long)n * j];
     }
   });
   barrier(c);
   tick(c, 6);
-  information_from_compressed(c, a, n, nr, mobs);
+  // ---- G_E^T G_E, G_E^T Hu, Hu^T Hu, track by track (Gam takes Gv's place)
+  par_for(c, ec * ec, [&](long x) { See[x] = 0.0; });
+  par_for(c, ec * (long)n, [&](long x) { Seb[x] = 0.0; });
+  par_for(c, (long)n * n, [&](long x) { Gam[x] = 0.0; });
+  barrier(c);
+  for (int t = 0; t < F; ++t) {
+    if (!(a.status[t] & a.inc_bit)) continue;
+    const int M = a.M[t], R2 = 2 * M, rho = R2 - 3, r0 = a.row0[t];
+    int kE = e - r0; kE = kE < 0 ? 0 : (kE > rho ? rho : kE);      // rows of the track that are explicit
+    const int d = 3 + kE;
+    const double* V = a.Vf + (long)t * 2 * a.m_cap * 3;
+    const double* T = a.Tf + (long)t * 9;
+    const HT* hx = a.Hx + (long)t * a.m_cap * 12;
+    const int so = first_obs(a, t);
+    // See block of the track's explicit rows: sum over the observations of a_i(2o) a_i'(2o)
+    par_for(c, (long)kE * kE, [&](long x) {
+      const int i2 = (int)(x / kE), i1 = (int)(x - (long)i2 * kE);
+      double sacc = 0;
+      for (int o = 0; o < M; ++o) sacc += At[(long)(r0 + i1) * 2 * a.m_cap + 2 * o] * At[(long)(r0 + i2) * 2 * a.m_cap + 2 * o];
+      See[(r0 + i1) + ec * (r0 + i2)] = sacc;
+    });
+    if (d < R2 && m > e) {
+      // u-rows of (I - Q_f(:, :d) Q_f(:, :d)^T) H_x_j in compact columns 6 o' + kk
+      par_for(c, (long)M * 6 * M, [&](long x) {
+        const int o = (int)(x / (6 * M)), cc = (int)(x - (long)o * 6 * M), op = cc / 6, kk = cc - 6 * op;
+        double tv[3], ev[3] = {0, 0, 0};
+        for (int p2 = 0; p2 < 3; ++p2) tv[p2] = vf_at(V, 2 * o, 0) * T[0 * 3 + p2] + vf_at(V, 2 * o, 1) * T[1 * 3 + p2] + vf_at(V, 2 * o, 2) * T[2 * 3 + p2];
+        auto qf = [&](int q) -> double { return (q == 2 * o ? 1.0 : 0.0) - (tv[0] * vf_at(V, q, 0) + tv[1] * vf_at(V, q, 1) + tv[2] * vf_at(V, q, 2)); };
+        for (int q = 0; q < d; ++q) { const double f = qf(q); for (int p2 = 0; p2 < 3; ++p2) ev[p2] += f * vf_at(V, q, p2); }
+        const double h0 = (double)hx[op * 12 + kk], h1 = (double)hx[op * 12 + 6 + kk];
+        double sv[3], val = op == o ? h0 : 0.0;
+        for (int p2 = 0; p2 < 3; ++p2) sv[p2] = vf_at(V, 2 * op, p2) * h0 + vf_at(V, 2 * op + 1, p2) * h1;
+        for (int q = 0; q < 3; ++q) { double w = 0; for (int p2 = 0; p2 <= q; ++p2) w += T[p2 * 3 + q] * sv[p2]; val += ev[q] * w; }
+        if (2 * op < d) val -= qf(2 * op) * h0;
+        if (2 * op + 1 < d) val -= qf(2 * op + 1) * h1;
+        Hh[o * 6 * a.m_cap + cc] = val;
+      });
+      barrier(c);
+      par_for(c, (long)6 * M * 6 * M, [&](long x) {
+        const int c2 = (int)(x / (6 * M)), c1 = (int)(x - (long)c2 * 6 * M);
+        if (c1 < c2) return;
+        double sacc = 0;
+        for (int o = 0; o < M; ++o) sacc += Hh[o * 6 * a.m_cap + c1] * Hh[o * 6 * a.m_cap + c2];
+        const int g1 = 6 * a.slots[so + c1 / 6] + c1 % 6, g2 = 6 * a.slots[so + c2 / 6] + c2 % 6;
+        Gam[g1 + (long)n * g2] += sacc;
+        if (g1 != g2) Gam[g2 + (long)n * g1] += sacc;
+      });
+      par_for(c, (long)kE * 6 * M, [&](long x) {
+        const int cc = (int)(x / kE), i1 = (int)(x - (long)cc * kE);
+        double sacc = 0;
+        for (int o = 0; o < M; ++o) sacc += At[(long)(r0 + i1) * 2 * a.m_cap + 2 * o] * Hh[o * 6 * a.m_cap + cc];
+        Seb[(r0 + i1) + ec * (6 * a.slots[so + cc / 6] + cc % 6)] = sacc;
+      });
+    }
+    barrier(c);
+  }
+  tick(c, 7);
+  // ---- G^T G = Tq^T (See Tq + Seb Yq) + Yq^T (Seb^T Tq + Gam Yq)
+  par_for(c, (long)e * nr, [&](long x) {
+    const int ka = (int)(x / e), i = (int)(x - (long)ka * e);
+    const double* t = Tq + ec * ka; const double* y = Yq + (long)n * ka;
+    double sacc = 0;
+    for (int l = 0; l < e; ++l) sacc += See[i + ec * l] * t[l];
+    if (m > e) for (int l = 0; l < n; ++l) sacc += Seb[i + ec * l] * y[l];
+    P1[i + ec * ka] = sacc;
+  });
+  par_for(c, (long)n * nr, [&](long x) {
+    const int ka = (int)(x / n), i = (int)(x - (long)ka * n);
+    const double* t = Tq + ec * ka; const double* y = Yq + (long)n * ka;
+    double sacc = 0;
+    if (m > e) {
+      for (int l = 0; l < e; ++l) sacc += Seb[l + ec * i] * t[l];
+      for (int l = 0; l < n; ++l) sacc += Gam[i + (long)n * l] * y[l];
+    }
+    P3[i + (long)n * ka] = sacc;
+  });
+  barrier(c);
+  const long ldz = a.ldz;
+  const double dlt = a.u_var - a.v_var;
+  par_for(c, (long)nr * nr, [&](long x) {
+    const int kb = (int)(x / nr), ka = (int)(x - (long)kb * nr);
+    if (ka < kb) return;
+    const double* ta = Tq + ec * ka; const double* ya = Yq + (long)n * ka;
+    double sacc = 0;
+    for (int l = 0; l < e; ++l) sacc += ta[l] * P1[l + ec * kb];
+    if (m > e) for (int l = 0; l < n; ++l) sacc += ya[l] * P3[l + (long)n * kb];
+    a.Z[ka + ldz * kb] = dlt * sacc + (ka == kb ? a.v_var : 0.0);
+  });
+  barrier(c);
+  tick(c, 8);
+  information_from_rn(c, a, n, nr);
   tick(c, 9);
-  return true;
 }
 
-// route: 0 = fast when the stack has the shape for it, else general; 1 = general; 2 = fast only (tests: Lam^ is left
-// untouched and info[4] = 0 when the shape check fails)
+// route: 0 (default) = the compact route; 1 = the sweep over the dense stack (needs its work space X, G: tests and A/B runs)
 template <class HT>
 LIT_FN void literal_compress(const Ctx& c, const Args<HT>& a, const int route = 0) {
   tick(c, 0);
   const int m = prepare(c, a);
   if (m <= 0) return;
   const int mobs = a.obs0[a.F];
-  if (route != 1 && literal_fast(c, a, m, mobs)) return;
-  if (route == 2) return;
+  if (route != 1 || !a.X || !a.G) { literal_compact(c, a, m, mobs); return; }
   literal_general(c, a, m, mobs);
 }
 

@@ -216,7 +216,7 @@ struct Batch : BatchBase {
   // anisotropic pixel noise (u_var' != v_var'): 0 = the reference's construction R_o_j = A_j^T R_j A_j, R_n = Q_1^T R_o Q_1 on
   // the device (kernels_literal.hip; default), 1 = rows pre-whitened by 1/sigma (generalized least squares, unit noise)
   int aniso_mode = 0;
-  int lit_route = 0;         // 0 fast where the stack has the shape for it, else general; 1 general only; 2 fast only (tests)
+  int lit_route = 0;         // 0 the compact route; 1 the sweep over the dense stack (tests, A/B)
   double lit_tol = -1;       // zero-tail tolerance of the literal route; < 0: 1e-10 (double) / 8e-4 (float: H_x is float-rounded)
   std::vector<double> h_uv;  // [B][2] u_var', v_var' as initialize() got them
   // Host mirror of the IMU state for the single-filter API: getImuState() is called once per IMU sample by the reference's
@@ -300,7 +300,7 @@ struct Batch : BatchBase {
     rc |= dalloc(&d.imu, Bz * IMU_STRIDE); rc |= dalloc(&d.cam, Bz * n_cap * CAM_STRIDE); rc |= dalloc(&d.prm, Bz * PRM_STRIDE);
     rc |= dalloc(&d.P, Bz * pl); rc |= dalloc(&P_spare, Bz * pl); d.Pout = nullptr; d.fuse_drop = nullptr; d.ncam_defer = 0;
     if (const char* e = getenv("MSCKF_HIP_FUSE_PRUNE")) fuse_prune = atoi(e) != 0;
-    if (const char* e = getenv("MSCKF_HIP_LITERAL_ROUTE")) lit_route = atoi(e);   // A/B runs and tests: 1 general route only, 2 fast route only
+    if (const char* e = getenv("MSCKF_HIP_LITERAL_ROUTE")) lit_route = atoi(e);   // A/B runs and tests: 1 = the sweep over the dense stack
     rc |= dalloc(&d.ncam, Bz); rc |= dalloc(&d.n_resid, Bz);
     rc |= dalloc(&d.trk_status, TF); rc |= dalloc(&d.trk_pf, TF * 4); rc |= dalloc(&d.trk_gamma, TF);
     d.h16 = h16 ? 1 : 0; d.trk_Hx = nullptr; d.trk_Hx16 = nullptr;
@@ -413,29 +413,32 @@ struct Batch : BatchBase {
     if (u == v) { out5[0] = 1; out5[1] = 1; out5[2] = (S)u; out5[3] = (S)u; out5[4] = 0; }
     else if (aniso_mode == 0 && !h16 && d.trk_B) { out5[0] = 1; out5[1] = 1; out5[2] = 1; out5[3] = (S)u; out5[4] = 1; lit = true; }
     else { out5[0] = (S)(1.0 / std::sqrt(u)); out5[1] = (S)(1.0 / std::sqrt(v)); out5[2] = 1; out5[3] = 1; out5[4] = 0; }
-    if (lit && !d.lit.X) { const int rc = lit_alloc(); if (rc) return rc; }
+    if (lit && !d.lit.W2) { const int rc = lit_alloc(); if (rc) return rc; }
     if (lit != was) { n_lit += lit ? 1 : -1; h_lit[b] = lit ? 1 : 0; }
     return 0;
   }
-  // work space of kernels_literal.hip: the dense stack [H_o | r_o] (f_cap (2 m_cap - 3) rows x (6 n_cap + 1) columns, f64) per
-  // trajectory and the small matrices of its tail; only allocated when a trajectory has u_var' != v_var' on the literal route
+  // work space of kernels_literal.hip (a few (6 n_cap)^2 matrices per trajectory); only allocated when a trajectory has
+  // u_var' != v_var' on the literal route
   int lit_alloc() {
     LitBufs& L = d.lit;
     const size_t Bz = B, n1 = (size_t)d.n6cap + 1;
     L.ldx = ((f_cap * std::max(2 * m_cap - 3, 1) + 7) / 8) * 8;
-    L.r_cap = d.n6cap + 63; L.ldg = f_cap * m_cap + 8; L.ldz = L.r_cap + (int)n1; L.kept_stride = 6 * (d.n6cap + 16) + 64;   // 63 = LIT_ZCAP (literal_core.h)
-    L.w_stride = (long)(n1 * n1 + 63 * n1 + 63 * 2 * (size_t)m_cap + (size_t)f_cap * 18 * m_cap + 3 * (size_t)L.ldg);
+    L.r_cap = d.n6cap + 15; L.ldg = f_cap * m_cap + 8; L.ldz = L.r_cap + (int)n1; L.kept_stride = 6 * (d.n6cap + 16) + 64;
     L.tol = lit_tol >= 0 ? lit_tol : (sizeof(S) == 4 ? 8e-4 : 1e-10);
     L.route = lit_route;
     int rc = 0;
-    rc |= dalloc(&L.X, Bz * L.ldx * n1); rc |= dalloc(&L.tau, Bz * n1);
+    rc |= dalloc(&L.tau, Bz * (2 * n1 + 2));
     rc |= dalloc(&L.Vf, Bz * f_cap * 2 * m_cap * 3); rc |= dalloc(&L.Tf, Bz * f_cap * 9);
     rc |= dalloc(&L.row0, Bz * (f_cap + 1)); rc |= dalloc(&L.obs0, Bz * (f_cap + 1)); rc |= dalloc(&L.otrk, Bz * L.ldg); rc |= dalloc(&L.kept, Bz * L.kept_stride);
-    rc |= dalloc(&L.TH, Bz * L.r_cap * n1); rc |= dalloc(&L.G, Bz * (size_t)L.ldg * L.r_cap); rc |= dalloc(&L.Z, Bz * (size_t)L.ldz * L.ldz);
-    rc |= dalloc(&L.W, Bz * (size_t)L.w_stride);
+    rc |= dalloc(&L.TH, Bz * L.r_cap * n1); rc |= dalloc(&L.Z, Bz * (size_t)L.ldz * L.ldz);
+    { const long nn = d.n6cap, ecc = 15 + nn, rcc = L.r_cap;   // = lit::compact_ws_doubles(6 n_cap, m_cap, r_cap), literal_core.h
+      L.w2_stride = ecc * (nn + 1) + ecc * 2L * m_cap + (nn + 1) * (nn + 1) + 4L * nn * nn + ecc * rcc + nn * rcc + ecc * ecc + ecc * nn + ecc * rcc + nn * rcc + (long)m_cap * 6 * m_cap + 64; }
+    rc |= dalloc(&L.W2, Bz * (size_t)L.w2_stride);
+    // the sweep over the dense stack (MSCKF_HIP_LITERAL_ROUTE=1: tests, A/B runs) needs the stack itself and the u-rows of A Q_1
+    if (lit_route == 1) { rc |= dalloc(&L.X, Bz * L.ldx * n1); rc |= dalloc(&L.G, Bz * (size_t)L.ldg * L.r_cap); }
     rc |= dalloc(&L.info, Bz * 8);
     if (const char* e = getenv("MSCKF_HIP_LITERAL_TIMERS")) if (atoi(e)) rc |= dalloc(&L.tim, Bz * 16);
-    if (rc) { L.X = nullptr; return fail(-ENOMEM, "work space of the literal anisotropic route (msckf_hip_set_anisotropic_noise(h, 1, 0) selects pre-whitening)"); }
+    if (rc) { L.W2 = nullptr; return fail(-ENOMEM, "work space of the literal anisotropic route (msckf_hip_set_anisotropic_noise(h, 1, 0) selects pre-whitening)"); }
     return 0;
   }
   int set_aniso(int mode, double tol) override {
@@ -464,7 +467,7 @@ struct Batch : BatchBase {
       long long t[16];
       HIPCHK(hipMemcpyAsync(t, d.lit.tim + (size_t)b * 16, sizeof(t), hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
-      std::fprintf(stderr, "[k_literal b=%d] us: prepare %.0f top %.0f lam' %.0f chol %.0f shape+TH %.0f row solves %.0f  G^T G %.0f eliminate %.0f store %.0f\n", b,
+      std::fprintf(stderr, "[k_literal b=%d] us: prepare %.0f explicit rows %.0f Gram %.0f sweep %.0f kept+Gv %.0f Q columns %.0f per-track sums %.0f G^T G %.0f eliminate+store %.0f\n", b,
                    (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01, (t[5] - t[4]) * 0.01, (t[6] - t[5]) * 0.01,
                    (t[7] - t[6]) * 0.01, (t[8] - t[7]) * 0.01, (t[9] - t[8]) * 0.01);
     }

@@ -7,7 +7,7 @@
 #define LIT_HOST
 #include "../../msckf_mono_amd/csrc/literal_core.h"
 
-// route: 0 fast when the stack has the shape for it, else general; 1 general; 2 fast only.  LamIn: [H_o | r_o]^T [H_o | r_o]
+// route: 0 the compact route; 1 the sweep over the dense stack.  LamIn: [H_o | r_o]^T [H_o | r_o]
 // ((6N+1)^2, element (hi, lo) at hi * (6N+1) + lo; what k_gram accumulates on the device), may be null for route 1.
 extern "C" int lit_host_compress(int F, int m_cap, int N, const int* included, const int* M, const int* slots /*[F][m_cap]*/,
                                  const double* Hx /*[F][m_cap][12]*/, const double* rw /*[F][2 m_cap]*/, double u_var, double v_var,
@@ -21,21 +21,18 @@ extern "C" int lit_host_compress(int F, int m_cap, int N, const int* included, c
   a.F = F; a.m_cap = m_cap; a.N = N; a.status = included; a.inc_bit = 1; a.M = M; a.slots = slots; a.off = nullptr;
   a.Hx = Hx; a.rw = rw; a.u_var = u_var; a.v_var = v_var; a.tol = tol;
   a.ldx = m + 8;
-  std::vector<double> X((size_t)a.ldx * (n + 1)), tau(n + 1), Vf((size_t)F * 2 * m_cap * 3), Tf((size_t)F * 9);
+  std::vector<double> X((size_t)a.ldx * (n + 1)), tau(2 * (n + 1) + 2), Vf((size_t)F * 2 * m_cap * 3), Tf((size_t)F * 9);
   std::vector<int> row0(F + 1), obs0(F + 1), kept(6 * (n + 16) + 64), otrk(mobs + 8);
   a.X = X.data(); a.tau = tau.data(); a.Vf = Vf.data(); a.Tf = Tf.data(); a.row0 = row0.data(); a.obs0 = obs0.data(); a.kept = kept.data();
   a.otrk = otrk.data();
-  a.r_cap = n + LIT_ZCAP;
+  a.r_cap = n + 15;
   std::vector<double> TH((size_t)a.r_cap * (n + 1)), G((size_t)(mobs + 8) * a.r_cap);
   a.TH = TH.data(); a.ldg = mobs + 8; a.G = G.data();
   a.ldz = a.r_cap + n + 1;
   std::vector<double> Z((size_t)a.ldz * a.ldz);
   a.Z = Z.data();
-  std::vector<signed char> inv((size_t)F * 64, (signed char)-1);
-  for (int t = 0; t < F; ++t) for (int o = 0; o < M[t]; ++o) inv[(size_t)t * 64 + slots[(size_t)t * m_cap + o]] = (signed char)o;
-  a.inv = inv.data(); a.inv_stride = 64;
-  std::vector<double> W((size_t)(n + 1) * (n + 1) + (size_t)LIT_ZCAP * (n + 1) + (size_t)LIT_ZCAP * 2 * m_cap + (size_t)F * 18 * m_cap + 3 * (size_t)(mobs + 8));
-  a.W = W.data();
+  std::vector<double> W2((size_t)compact_ws_doubles(n, m_cap, a.r_cap));
+  a.W2 = W2.data();
   a.LamIn = LamIn; a.lam_part = 0; a.gram_parts = 1;
   a.Lam = Lam; a.ldL = n + 1; a.info = info8;
   Ctx c;

@@ -50,31 +50,28 @@ def _aniso(N, F, nf, traj, cfgid=2):
 
 @pytest.mark.parametrize("N,F,nf,traj", [(8, 24, 14, 5), (8, 24, 14, 6), (10, 50, 16, 7), (6, 6, 12, 3)])
 def test_literal_route_double_vs_restatement_every_frame(capi, po, N, F, nf, traj):
-    """free-running, double: device (literal, default tolerance 1e-10) vs the restatement with the same tolerance, 1e-6 on
-    every field after every frame; the kept rows of R agree (msckf.h:1347)."""
+    """free-running, double: device (literal, default tolerance 1e-10; the compact route: no stack) vs the restatement with
+    the same tolerance, 1e-6 on every field after every frame; the kept rows of R agree (msckf.h:1347).  Trajectory 6 has an
+    update whose stack has a dependent column in the middle of the sweep, (6, 6) stacks with fewer rows than columns."""
     tr = _aniso(N, F, nf, traj)
     o = po.Oracle(po.F64, po.LEAN); o.setTinyRowTol(1e-10); o.initialize(tr.cfg, tr.imu0)
     bt = capi.Batch(1, N, F, max(N, 4), capi.F64); bt.initialize(0, tr.cfg, tr.imu0)
     updates = 0
-    routes = []
     for k in range(nf):
         H.oracle_frame(o, tr, k, N); H.device_frame(bt, 0, tr, k, N)
         e = _errs(bt, 0, o)
         assert H.worst(e) < 1e-6, (k, e)
         if o.lastStats()["m_rows"]:
             info = bt.literal_info(0)
-            assert info["m_rows"] == o.lastStats()["m_rows"] and abs(info["kept_rows"] - o.lastStats()["r_rows"]) <= (1 if info["route"] == 1 else 0), (k, info, o.lastStats())
-            routes.append(info["route"])
+            assert info["m_rows"] == o.lastStats()["m_rows"] and info["kept_rows"] == o.lastStats()["r_rows"] and info["route"] == 3, (k, info, o.lastStats())
             updates += 1
     assert updates >= nf - 4
-    if F >= 24:
-        assert routes.count(1) >= len(routes) - 2      # the usual shape of a stack: no reflector sweep
     bt.close()
 
 
 def test_literal_general_route_alone_on_the_device(capi, po, monkeypatch):
-    """MSCKF_HIP_LITERAL_ROUTE=1: the reflector sweep over the dense stack on every update (the default takes it only where
-    the stack has not the usual shape), against the restatement at 1e-6 like the default above."""
+    """MSCKF_HIP_LITERAL_ROUTE=1: the reflector sweep over the dense stack (the definition: literal_general) instead of the
+    default compact route, against the restatement at 1e-6 like the default above."""
     monkeypatch.setenv("MSCKF_HIP_LITERAL_ROUTE", "1")
     N, F, nf = 10, 50, 16
     tr = _aniso(N, F, nf, 7)
@@ -177,7 +174,7 @@ def test_literal_route_cfg3_window_float(capi, po):
         e = _errs(bt2, 0, o)
         assert H.worst(e) < 1e-3, (k, e)
         info = bt2.literal_info(0)
-        assert info["m_rows"] == o.lastStats()["m_rows"] > 4000 and abs(info["kept_rows"] - o.lastStats()["r_rows"]) <= 1 and info["route"] == 1
+        assert info["m_rows"] == o.lastStats()["m_rows"] > 4000 and abs(info["kept_rows"] - o.lastStats()["r_rows"]) <= 2 and info["route"] == 3
         n += 1
     assert n >= 1
     bt.close()
