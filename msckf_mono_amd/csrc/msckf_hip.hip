@@ -467,9 +467,9 @@ struct Batch : BatchBase {
       long long t[16];
       HIPCHK(hipMemcpyAsync(t, d.lit.tim + (size_t)b * 16, sizeof(t), hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
-      std::fprintf(stderr, "[k_literal b=%d] us: prepare %.0f explicit rows %.0f Gram %.0f sweep %.0f kept+Gv %.0f Q columns %.0f per-track sums %.0f G^T G %.0f eliminate+store %.0f\n", b,
+      std::fprintf(stderr, "[k_literal b=%d] us: prepare %.0f explicit rows %.0f Gram %.0f sweep %.0f kept+Gv %.0f Q columns %.0f per-track sums %.0f G^T G %.0f Z fill %.0f eliminate %.0f store %.0f\n", b,
                    (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01, (t[5] - t[4]) * 0.01, (t[6] - t[5]) * 0.01,
-                   (t[7] - t[6]) * 0.01, (t[8] - t[7]) * 0.01, (t[9] - t[8]) * 0.01);
+                   (t[7] - t[6]) * 0.01, (t[8] - t[7]) * 0.01, (t[10] - t[8]) * 0.01, (t[11] - t[10]) * 0.01, (t[9] - t[11]) * 0.01);
     }
     return 0;
   }
