@@ -51,7 +51,7 @@ enum { STAT_ERR_NCAP = 1, STAT_ERR_PIVOT = 2 };
 // trajectory of the batch uses it
 struct LitBufs {
   double* X = nullptr; double* tau = nullptr; double* Vf = nullptr; double* Tf = nullptr; double* TH = nullptr; double* G = nullptr; double* Z = nullptr; double* W2 = nullptr;
-  int* row0 = nullptr; int* obs0 = nullptr; int* otrk = nullptr; int* hoff = nullptr; int* kept = nullptr; int* info = nullptr;
+  int* row0 = nullptr; int* obs0 = nullptr; int* otrk = nullptr; int* kept = nullptr; int* info = nullptr;
   long long* tim = nullptr;   // [B][16] phase stamps of k_literal (100 MHz wall clock), only with MSCKF_HIP_LITERAL_TIMERS=1
   int ldx = 0, r_cap = 0, ldg = 0, ldz = 0, kept_stride = 0;
   long w2_stride = 0;

@@ -178,8 +178,6 @@ struct Args {
   int* row0;                // [F + 1] first stacked row of track t (list order), row0[F] = m
   int* obs0;                // [F + 1] first observation index of track t among the stacked tracks
   int* otrk;                // [ldg] track of stacked observation g
-  int* hoff;                // [F + 1] compact route: offset of track t's projected Jacobian rows in its scratch
-  const signed char* inv; int inv_stride;   // observation index of camera slot s in track t at inv[t * inv_stride + s], -1 = not observed
   int* kept;                // [6 (n + 16) + 64] kept rows of R (msckf.h:1347) + flag / index scratch behind them
   int r_cap;                // >= n + 15 (row capacity of TH / G / Z)
   double* TH;               // [r_cap x (n + 1)] column-major: kept rows of [R | Q^T r_o]
@@ -531,7 +529,7 @@ LIT_FN double lam_in(const Args<HT>& a, int hi, int lo) {   // hi >= lo
 // per track (Hu^T Hu is block-local: a track touches its own cameras' columns).  Nothing of size m x n exists.
 LIT_FN long compact_ws_doubles(int n, int m_cap, int r_cap, int ldg) {
   const long n1 = n + 1, ec = 15 + n;
-  return ec * n1 + ec * 2L * m_cap + n1 * n1 + 4L * n * n + 2 * (ec * (long)r_cap + (long)n * r_cap) + ec * ec + ec * (long)n + ec * (long)r_cap + (long)n * r_cap + (long)ldg * 6 * m_cap + 64;
+  return ec * n1 + ec * 2L * m_cap + n1 * n1 + 4L * n * n + 2 * (ec * (long)r_cap + (long)n * r_cap) + ec * ec + ec * (long)n + ec * (long)r_cap + (long)n * r_cap + (long)ldg * n + 64;
 }
 
 template <class HT>
@@ -555,7 +553,7 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
   double* P3 = P1 + ec * rc;                    // [n x rc] Gam Yq + Seb^T Tq
   double* TqT = P3 + (long)n * rc;              // [rc x ec] Tq transposed (the last product reads it along the kept columns)
   double* YqT = TqT + rc * ec;                  // [rc x n]
-  double* Hh = YqT + rc * (long)n;              // [ldg x 6 m_cap] u-rows of every track's projected Jacobian ([compact column][observation] per track)
+  double* Hh = YqT + rc * (long)n;              // [ldg x n] u-rows of every track's projected Jacobian (stacked observations x state columns)
   double* Gam = Gv;                             // Hu^T Hu reuses Gv's space once the columns of Q are built
   const int ks = n + 16;
   int* flag = a.kept + ks;
@@ -730,86 +728,64 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
     }
   }
   tick(c, 6);
-  // ---- G_E^T G_E, G_E^T Hu, Hu^T Hu (Gam takes Gv's place).  Hu of every track first (one wavefront per track, stored
-  // per track as [compact column 6 o' + kk][observation]), then one thread per entry of Hu^T Hu summing over the tracks that
-  // see both cameras, in list order: no track-by-track barriers (13 of this route's 38 ms), no atomics, the same bits every run
-  double* HhT = Hh;
-  if (first_thread(c)) {
-    int off = 0;
-    for (int t = 0; t < F; ++t) {
-      a.hoff[t] = off;
-      if ((a.status[t] & a.inc_bit) && m > e) {
-        const int M = a.M[t], rho = 2 * M - 3, r0 = a.row0[t];
-        int kE = e - r0; kE = kE < 0 ? 0 : (kE > rho ? rho : kE);
-        if (3 + kE < 2 * M) off += 6 * M * M;
-      }
-    }
-    a.hoff[F] = off;
-  }
+  // ---- G_E^T G_E, G_E^T Hu, Hu^T Hu (Gam takes Gv's place).  Hu -- the u-rows of every track's projected Jacobian -- is
+  // laid out once as a dense (stacked observations) x n matrix (one wavefront per track), and Hu^T Hu is then the same
+  // LDS-staged product as G^T G of the dense route: Hu is read once.  (Track by track with two barriers each: 13 ms; one
+  // thread per entry gathering over the tracks: 26 ms; this: ~3 ms.)
+  double* Hu = Hh;                                      // [ldg x n] column-major
+  const long ldh = a.ldg;
   par_for(c, ec * ec, [&](long x) { See[x] = 0.0; });
   par_for(c, ec * (long)n, [&](long x) { Seb[x] = 0.0; });
+  par_for(c, (long)mobs * n, [&](long x) { const long j = x / mobs, g = x - j * mobs; Hu[g + ldh * j] = 0.0; });
   barrier(c);
-  wave_for(c, 0, F, [&](long t) {
-    if (a.hoff[t + 1] == a.hoff[t]) return;
-    const int M = a.M[t], rho = 2 * M - 3, r0 = a.row0[t];
-    int kE = e - r0; kE = kE < 0 ? 0 : (kE > rho ? rho : kE);      // rows of the track that are explicit
-    const int d = 3 + kE;
-    const double* V = a.Vf + (long)t * 2 * a.m_cap * 3;
-    const double* T = a.Tf + (long)t * 9;
-    const HT* hx = a.Hx + (long)t * a.m_cap * 12;
-    double* out = HhT + a.hoff[t];
-    // u-rows of (I - Q_f(:, :d) Q_f(:, :d)^T) H_x_j in compact columns 6 o' + kk
-    lane_for(c, 0, (long)M * 6 * M, [&](long x) {
-      const int cc = (int)(x / M), o = (int)(x - (long)cc * M), op = cc / 6, kk = cc - 6 * op;
-      double tv[3], ev[3] = {0, 0, 0};
-      for (int p2 = 0; p2 < 3; ++p2) tv[p2] = vf_at(V, 2 * o, 0) * T[0 * 3 + p2] + vf_at(V, 2 * o, 1) * T[1 * 3 + p2] + vf_at(V, 2 * o, 2) * T[2 * 3 + p2];
-      auto qf = [&](int q) -> double { return (q == 2 * o ? 1.0 : 0.0) - (tv[0] * vf_at(V, q, 0) + tv[1] * vf_at(V, q, 1) + tv[2] * vf_at(V, q, 2)); };
-      for (int q = 0; q < d; ++q) { const double f = qf(q); for (int p2 = 0; p2 < 3; ++p2) ev[p2] += f * vf_at(V, q, p2); }
-      const double h0 = (double)hx[op * 12 + kk], h1 = (double)hx[op * 12 + 6 + kk];
-      double sv[3], val = op == o ? h0 : 0.0;
-      for (int p2 = 0; p2 < 3; ++p2) sv[p2] = vf_at(V, 2 * op, p2) * h0 + vf_at(V, 2 * op + 1, p2) * h1;
-      for (int q = 0; q < 3; ++q) { double w = 0; for (int p2 = 0; p2 <= q; ++p2) w += T[p2 * 3 + q] * sv[p2]; val += ev[q] * w; }
-      if (2 * op < d) val -= qf(2 * op) * h0;
-      if (2 * op + 1 < d) val -= qf(2 * op + 1) * h1;
-      out[(long)cc * M + o] = val;
+  if (m > e)
+    wave_for(c, 0, F, [&](long t) {
+      if (!(a.status[t] & a.inc_bit)) return;
+      const int M = a.M[t], rho = 2 * M - 3, r0 = a.row0[t];
+      int kE = e - r0; kE = kE < 0 ? 0 : (kE > rho ? rho : kE);      // rows of the track that are explicit
+      const int d = 3 + kE;
+      if (d >= 2 * M) return;                                          // every row of the track is explicit: nothing of it in B
+      const double* V = a.Vf + (long)t * 2 * a.m_cap * 3;
+      const double* T = a.Tf + (long)t * 9;
+      const HT* hx = a.Hx + (long)t * a.m_cap * 12;
+      const int so = first_obs(a, t), g0 = a.obs0[t];
+      // u-rows of (I - Q_f(:, :d) Q_f(:, :d)^T) H_x_j, scattered to the state columns of the track's cameras
+      lane_for(c, 0, (long)M * 6 * M, [&](long x) {
+        const int cc = (int)(x / M), o = (int)(x - (long)cc * M), op = cc / 6, kk = cc - 6 * op;
+        double tv[3], ev[3] = {0, 0, 0};
+        for (int p2 = 0; p2 < 3; ++p2) tv[p2] = vf_at(V, 2 * o, 0) * T[0 * 3 + p2] + vf_at(V, 2 * o, 1) * T[1 * 3 + p2] + vf_at(V, 2 * o, 2) * T[2 * 3 + p2];
+        auto qf = [&](int q) -> double { return (q == 2 * o ? 1.0 : 0.0) - (tv[0] * vf_at(V, q, 0) + tv[1] * vf_at(V, q, 1) + tv[2] * vf_at(V, q, 2)); };
+        for (int q = 0; q < d; ++q) { const double f = qf(q); for (int p2 = 0; p2 < 3; ++p2) ev[p2] += f * vf_at(V, q, p2); }
+        const double h0 = (double)hx[op * 12 + kk], h1 = (double)hx[op * 12 + 6 + kk];
+        double sv[3], val = op == o ? h0 : 0.0;
+        for (int p2 = 0; p2 < 3; ++p2) sv[p2] = vf_at(V, 2 * op, p2) * h0 + vf_at(V, 2 * op + 1, p2) * h1;
+        for (int q = 0; q < 3; ++q) { double w = 0; for (int p2 = 0; p2 <= q; ++p2) w += T[p2 * 3 + q] * sv[p2]; val += ev[q] * w; }
+        if (2 * op < d) val -= qf(2 * op) * h0;
+        if (2 * op + 1 < d) val -= qf(2 * op + 1) * h1;
+        Hu[(g0 + o) + ldh * (6 * a.slots[so + op] + kk)] = val;
+      });
     });
-  });
   barrier(c);
-  par_for(c, (long)n * n, [&](long x) {
-    const int g2 = (int)(x / n), g1 = (int)(x - (long)g2 * n);
-    if (g1 < g2) return;
-    const int s1 = g1 / 6, k1 = g1 - 6 * s1, s2 = g2 / 6, k2 = g2 - 6 * s2;
-    double sacc = 0;
-    for (int t = 0; t < F; ++t) {
-      if (a.hoff[t + 1] == a.hoff[t]) continue;
-      const signed char* iv = a.inv + (long)t * a.inv_stride;
-      const int o1 = iv[s1], o2 = iv[s2];
-      if (o1 < 0 || o2 < 0) continue;
-      const int M = a.M[t];
-      const double* p1 = HhT + a.hoff[t] + (long)(6 * o1 + k1) * M; const double* p2 = HhT + a.hoff[t] + (long)(6 * o2 + k2) * M;
-      for (int o = 0; o < M; ++o) sacc += p1[o] * p2[o];
-    }
-    Gam[g1 + (long)n * g2] = sacc; Gam[g2 + (long)n * g1] = sacc;
-  });
+  if (m > e) syrk_lower(c, Hu, ldh, n, mobs, [&](int i, int j, double sv2) { Gam[i + (long)n * j] = sv2; Gam[j + (long)n * i] = sv2; });
+  else par_for(c, (long)n * n, [&](long x) { Gam[x] = 0.0; });
   // the tracks that own explicit rows: G_E^T G_E blocks, and G_E^T Hu for the one with rows on both sides of e
   for (int t = topt[0]; t <= topt[e - 1]; ++t) {
     if (!(a.status[t] & a.inc_bit)) continue;
-    const int M = a.M[t], rho = 2 * M - 3, r0 = a.row0[t];
+    const int M = a.M[t], rho = 2 * M - 3, r0 = a.row0[t], g0 = a.obs0[t];
     int kE = e - r0; kE = kE < 0 ? 0 : (kE > rho ? rho : kE);
-    const int so = first_obs(a, t);
     par_for(c, (long)kE * kE, [&](long x) {
       const int i2 = (int)(x / kE), i1 = (int)(x - (long)i2 * kE);
       double sacc = 0;
       for (int o = 0; o < M; ++o) sacc += At[(long)(r0 + i1) * 2 * a.m_cap + 2 * o] * At[(long)(r0 + i2) * 2 * a.m_cap + 2 * o];
       See[(r0 + i1) + ec * (r0 + i2)] = sacc;
     });
-    if (a.hoff[t + 1] > a.hoff[t])
-      par_for(c, (long)kE * 6 * M, [&](long x) {
-        const int cc = (int)(x / kE), i1 = (int)(x - (long)cc * kE);
-        const double* hh = HhT + a.hoff[t] + (long)cc * M;
+    if (m > e && kE < rho)
+      par_for(c, (long)kE * n, [&](long x) {
+        const int col = (int)(x / kE), i1 = (int)(x - (long)col * kE);
+        const double* hh = Hu + g0 + ldh * col;
         double sacc = 0;
         for (int o = 0; o < M; ++o) sacc += At[(long)(r0 + i1) * 2 * a.m_cap + 2 * o] * hh[o];
-        Seb[(r0 + i1) + ec * (6 * a.slots[so + cc / 6] + cc % 6)] = sacc;
+        Seb[(r0 + i1) + ec * col] = sacc;
       });
   }
   barrier(c);

@@ -32,11 +32,6 @@ extern "C" int lit_host_compress(int F, int m_cap, int N, const int* included, c
   std::vector<double> Z((size_t)a.ldz * a.ldz);
   a.Z = Z.data();
   std::vector<double> W2((size_t)compact_ws_doubles(n, m_cap, a.r_cap, a.ldg));
-  std::vector<int> hoff(F + 1);
-  a.hoff = hoff.data();
-  std::vector<signed char> inv((size_t)F * 64, (signed char)-1);
-  for (int t = 0; t < F; ++t) for (int o = 0; o < M[t]; ++o) inv[(size_t)t * 64 + slots[(size_t)t * m_cap + o]] = (signed char)o;
-  a.inv = inv.data(); a.inv_stride = 64;
   a.W2 = W2.data();
   a.LamIn = LamIn; a.lam_part = 0; a.gram_parts = 1;
   a.Lam = Lam; a.ldL = n + 1; a.info = info8;
