@@ -65,6 +65,15 @@ template <class ST> LIT_FN void syrk_lower(const Ctx&, const double* G, long ldg
       st(i, j, s);
     }
 }
+// A^T B for A (kd x ma) and B (kd x nb), both column-major with the contraction index along the columns: st(i, j, value)
+template <class ST> LIT_FN void atb(const Ctx&, const double* A, long lda, int ma, const double* B, long ldb, int nb, int kd, ST st) {
+  for (int j = 0; j < nb; ++j)
+    for (int i = 0; i < ma; ++i) {
+      double s = 0;
+      for (int l = 0; l < kd; ++l) s += A[l + lda * i] * B[l + ldb * j];
+      st(i, j, s);
+    }
+}
 LIT_FN bool first_lane(const Ctx&) { return true; }
 LIT_FN bool first_thread(const Ctx&) { return true; }
 LIT_FN void tick(const Ctx&, int) {}
@@ -146,6 +155,42 @@ template <class ST> LIT_FN void syrk_lower(const Ctx& c, const double* G, long l
     if (e < ntl)
       for (int qi = 0; qi < 4; ++qi)
         for (int qj = 0; qj < 4; ++qj) { const int i = 4 * ti + qi, j = 4 * tj + qj; if (i < nr && j <= i) st(i, j, acc[qi * 4 + qj]); }
+  }
+  __syncthreads();
+}
+// A^T B with chunks of the contraction index staged in LDS ([row][column of A | column of B]), one 4 x 4 tile of the result
+// per thread and pass (the operands are read from global memory once per pass)
+template <class ST> LIT_FN void atb(const Ctx& c, const double* A, long lda, int ma, const double* B, long ldb, int nb, int kd, ST st) {
+  const int ta = (ma + 3) / 4, tb = (nb + 3) / 4, ntl = ta * tb, ldl = (ma + nb) | 1;
+  const int rows = c.lds_doubles / ldl;
+  for (int e0 = 0; e0 < ntl; e0 += c.nt) {
+    const int e = e0 + c.tid, ti = e < ntl ? e % ta : 0, tj = e < ntl ? e / ta : 0;
+    double acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0;
+    for (int l0 = 0; l0 < kd; l0 += rows) {
+      const int nrow = kd - l0 < rows ? kd - l0 : rows;
+      __syncthreads();
+      for (long x = c.tid; x < (long)nrow * ma; x += c.nt) { const int k = (int)(x / nrow), l = (int)(x - (long)k * nrow); c.lds[l * ldl + k] = A[l0 + l + lda * k]; }
+      for (long x = c.tid; x < (long)nrow * nb; x += c.nt) { const int k = (int)(x / nrow), l = (int)(x - (long)k * nrow); c.lds[l * ldl + ma + k] = B[l0 + l + ldb * k]; }
+      __syncthreads();
+      if (e < ntl) {
+        const double* li = c.lds + 4 * ti; const double* lj = c.lds + ma + 4 * tj;
+        const int i3 = 4 * ti + 3 < ma ? 3 : ma - 1 - 4 * ti, j3 = 4 * tj + 3 < nb ? 3 : nb - 1 - 4 * tj;
+        for (int l = 0; l < nrow; ++l) {
+          const double* ri = li + l * ldl; const double* rj = lj + l * ldl;
+          const double x0 = ri[0], x1 = ri[i3 < 1 ? i3 : 1], x2 = ri[i3 < 2 ? i3 : 2], x3 = ri[i3];
+          const double y0 = rj[0], y1 = rj[j3 < 1 ? j3 : 1], y2 = rj[j3 < 2 ? j3 : 2], y3 = rj[j3];
+          acc[0] += x0 * y0; acc[1] += x0 * y1; acc[2] += x0 * y2; acc[3] += x0 * y3;
+          acc[4] += x1 * y0; acc[5] += x1 * y1; acc[6] += x1 * y2; acc[7] += x1 * y3;
+          acc[8] += x2 * y0; acc[9] += x2 * y1; acc[10] += x2 * y2; acc[11] += x2 * y3;
+          acc[12] += x3 * y0; acc[13] += x3 * y1; acc[14] += x3 * y2; acc[15] += x3 * y3;
+        }
+      }
+    }
+    if (e < ntl)
+      for (int qi = 0; qi < 4; ++qi)
+        for (int qj = 0; qj < 4; ++qj) { const int i = 4 * ti + qi, j = 4 * tj + qj; if (i < ma && j < nb) st(i, j, acc[qi * 4 + qj]); }
   }
   __syncthreads();
 }
@@ -803,31 +848,32 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
     if (m > e && r0 + rho > e) for (int l = 0; l < n; ++l) sacc += Seb[i + ec * l] * y[l];
     P1[i + ec * ka] = sacc;
   });
-  par_for(c, (long)n * nr, [&](long x) {
-    const int ka = (int)(x / n), i = (int)(x - (long)ka * n);
-    const double* t = Tq + ec * ka; const double* y = Yq + (long)n * ka;
-    double sacc = 0;
-    if (m > e) {
-      const int ts = topt[e - 1], rs = a.row0[ts];       // the track of the last explicit row: the only one that can straddle
-      if (rs + 2 * a.M[ts] - 3 > e) for (int l = rs; l < e; ++l) sacc += Seb[l + ec * i] * t[l];
-      for (int l = 0; l < n; ++l) sacc += Gam[i + (long)n * l] * y[l];
-    }
-    P3[i + (long)n * ka] = sacc;
-  });
+  // P3 = Gam Yq (+ Seb^T Tq from the rows of the one track that has rows on both sides of e); G^T G = Tq^T P1 + Yq^T P3:
+  // LDS-staged products (one load per product from global memory took 6 of this route's 27 ms)
+  if (m > e) atb(c, Gam, n, n, Yq, n, nr, n, [&](int i, int ka, double v) { P3[i + (long)n * ka] = v; });
+  else par_for(c, (long)n * nr, [&](long x) { P3[x] = 0.0; });
+  barrier(c);
+  if (m > e) {
+    const int ts = topt[e - 1], rs = a.row0[ts];       // the track of the last explicit row: the only one that can straddle
+    if (rs + 2 * a.M[ts] - 3 > e)
+      par_for(c, (long)n * nr, [&](long x) {
+        const int ka = (int)(x / n), i = (int)(x - (long)ka * n);
+        const double* t = Tq + ec * ka;
+        double sacc = 0;
+        for (int l = rs; l < e; ++l) sacc += Seb[l + ec * i] * t[l];
+        P3[i + (long)n * ka] += sacc;
+      });
+  }
   barrier(c);
   const long ldz = a.ldz;
   const double dlt = a.u_var - a.v_var;
-  par_for(c, (long)e * nr, [&](long x) { const int i = (int)(x / nr), ka = (int)(x - (long)i * nr); TqT[ka + rc * i] = Tq[i + ec * ka]; });
-  par_for(c, (long)n * nr, [&](long x) { const int i = (int)(x / nr), ka = (int)(x - (long)i * nr); YqT[ka + rc * i] = Yq[i + (long)n * ka]; });
+  atb(c, Tq, ec, nr, P1, ec, nr, e, [&](int ka, int kb, double v) { if (ka >= kb) a.Z[ka + ldz * kb] = v; });
+  barrier(c);
+  if (m > e) atb(c, Yq, n, nr, P3, n, nr, n, [&](int ka, int kb, double v) { if (ka >= kb) a.Z[ka + ldz * kb] += v; });
   barrier(c);
   par_for(c, (long)nr * nr, [&](long x) {
     const int kb = (int)(x / nr), ka = (int)(x - (long)kb * nr);
-    if (ka < kb) return;
-    const double* p1 = P1 + ec * kb; const double* p3 = P3 + (long)n * kb;
-    double sacc = 0;
-    for (int l = 0; l < e; ++l) sacc += TqT[ka + rc * l] * p1[l];          // consecutive threads: consecutive ka
-    if (m > e) for (int l = 0; l < n; ++l) sacc += YqT[ka + rc * l] * p3[l];
-    a.Z[ka + ldz * kb] = dlt * sacc + (ka == kb ? a.v_var : 0.0);
+    if (ka >= kb) a.Z[ka + ldz * kb] = dlt * a.Z[ka + ldz * kb] + (ka == kb ? a.v_var : 0.0);
   });
   barrier(c);
   tick(c, 8);
