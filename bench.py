@@ -216,7 +216,7 @@ def main():
                     help="time the windows with resident inputs only (profiling runs: `value` is then the resident-input rate and says so)")
     ap.add_argument("--ring", type=int, default=6, help="device staging sets of the streamed-input run (2..8)")
     ap.add_argument("--upload-mode", type=int, default=0, help="0 host hand-over of uploaded frames (default), 1 device-side event waits")
-    ap.add_argument("--compression", type=int, default=-1, help="msckf_hip_set_compression route (A/B runs; -1 = library default, 0 TSQR, information form with 1 k_chol_T / 2 k_chol_blk / 3 k_chol_mfma)")
+    ap.add_argument("--compression", type=int, default=-1, help="msckf_hip_set_compression route (A/B runs; -1 = library default, 0 TSQR, 3 information form with the blocked matrix-core Cholesky)")
     ap.add_argument("--cov-form", type=int, default=0, help="msckf_hip_set_covariance_update form (A/B runs; 0 = square-root gain, blocked solve (default), 1 Joseph, 2 square-root gain, register-resident solve)")
     ap.add_argument("--no-pin", action="store_true", help="leave the uploading / enqueue threads where the scheduler puts them (default: one core each on the GPU's NUMA node)")
     ap.add_argument("--aniso-mode", type=int, default=0, help="u_var' != v_var' (cfg4): 0 the reference's literal R_n = Q_1^T R_o Q_1 on the device (default), 1 rows pre-whitened (GLS)")

@@ -189,11 +189,12 @@ int msckf_hip_set_host_affinity(msckf_hip_handle h, const int* cpus, int n);
  * forming S.  Same decisions as the reference; the reported gamma of such a track is the bound (status bit 32). */
 int msckf_hip_set_gate_early_accept(msckf_hip_handle h, int on);
 /* Compression of the stacked Jacobian (HouseholderQR + Q_1^T r_o of measurementUpdate, msckf.h:1338-1366):
- * -1 default for the window size, 0 Householder TSQR (kernels_qr.hip), 1 information form [T | r_n] = chol(H_o^T H_o)
- * accumulated in f64 (kernels_gram.hip) with the register-resident Cholesky k_chol_T, 2 the same with k_chol_blk, 3 with
- * the blocked matrix-core Cholesky k_chol_mfma (kernels_chol.hip; the default, and the only factorization for windows of
- * more than 31 cameras, 6 n_cap + 1 > 192, where it runs in two levels).  The information form needs 6 n_cap + 1 <= 384 and
- * f_cap <= 1024 (-ENOTSUP otherwise).  All routes give the reference's update (tests keep them together). */
+ * -1 default for the window size, 0 Householder TSQR (kernels_qr.hip), 3 information form: [T | r_n] = chol(H_o^T H_o),
+ * accumulated in f64 on the matrix cores (kernels_gram.hip) and factored by the blocked matrix-core Cholesky k_chol_mfma
+ * (kernels_chol.hip; the default; two levels for windows of more than 31 cameras, 6 n_cap + 1 > 192).  1 and 2 selected the
+ * register-resident factorizations of rounds 1-2, which are gone: they are accepted and mean 3.  The information form needs
+ * 6 n_cap + 1 <= 384 and f_cap <= 1024 (-ENOTSUP otherwise).  Both routes give the reference's update (tests keep them
+ * together). */
 int msckf_hip_set_compression(msckf_hip_handle h, int route);
 /* Covariance update of measurementUpdate (msckf.h:1368-1418): 0 (default) the square-root gain form -- S = L L^T,
  * W = P T_H^T L^-T, dx = W L^-1 r_n, P <- P - W W^T (= (I - K T_H) P, written symmetrically); 1 the reference's literal

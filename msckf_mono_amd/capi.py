@@ -284,8 +284,8 @@ class Batch:
         _chk(self.L.msckf_hip_set_streams(self.h, int(n)))
 
     def set_compression(self, route):
-        """-1 default for the window size; 0 Householder TSQR; information form chol(H_o^T H_o) with 1 the register-resident
-        Cholesky k_chol_T, 2 k_chol_blk, 3 the blocked matrix-core Cholesky k_chol_mfma (the default where it fits)"""
+        """-1 default for the window size; 0 Householder TSQR; 3 information form chol(H_o^T H_o) with the blocked matrix-core
+        Cholesky k_chol_mfma (the default where it fits; 1 and 2 named retired factorizations and mean 3)"""
         _chk(self.L.msckf_hip_set_compression(self.h, int(route)))
 
     def set_covariance_update(self, form):

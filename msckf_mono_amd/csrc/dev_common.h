@@ -107,7 +107,7 @@ struct Dev {
   //   trk_inv[B*f_cap][n_cap]   i8    observation index of camera slot s in the track, -1 = not observed
   //   Dg     [B][n_cap][28]     f64   per camera slot: upper triangle of sum h^T h (21) and sum h^T r (6)
   //   Lam    [B][ldR][ldR]      f64   sum B^T B, upper 64x64 tiles
-  int compress;   // 0 Householder TSQR; information form with 1 k_chol_T, 2 k_chol_blk, 3 k_chol_mfma (kernels_chol.hip)
+  int compress;   // 0 Householder TSQR; != 0 (3) information form: k_gram + blocked matrix-core Cholesky (kernels_chol.hip)
   double* trk_B; S* trk_rw; signed char* trk_inv; double* Dg; double* Lam;
   // split-K SYRK (kernels_gram.hip): gram_parts == 3: tiles of block row ti are summed by min(ti + 1, 3) workgroups into copies
   // of Lam^ that lie lam_part doubles apart; the blocked Cholesky adds the copies while loading.  lam_part == 0: one copy only

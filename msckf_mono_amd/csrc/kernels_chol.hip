@@ -3,7 +3,7 @@
 // Two uses, one kernel template:
 //   GRAM (T = double): [T_H | r_n] = chol(Lam^), Lam^ = [H_o | r_o]^T [H_o | r_o] accumulated by k_gram -- the
 //        compression of the stacked Jacobian (HouseholderQR + Q_1^T r_o of measurementUpdate, msckf.h:1338-1366) in
-//        information form; semi-definite pivot skipping as in k_chol_T (a direction the stack says nothing about gives
+//        information form; semi-definite pivot skipping (a direction the stack says nothing about gives
 //        a zero row of T_H).
 //   GAIN (T = float):  S = L L^T for S = T_H P T_H^T + R_n (msckf.h:1369) with the rows [P T_H^T ; r_n^T] appended, which
 //        the factorization turns into W = P T_H^T L^-T and z^T = (L^-1 r_n)^T; dx = K r_n = W z (msckf.h:1370-1373 without
@@ -16,7 +16,7 @@
 //       and runs the SAME eliminations on the rows of the identity: that yields M with  y = x M  for the forward
 //       substitution of any row x against the block (zero columns for skipped pivots included);
 //   (3) all wavefronts form the panel below the diagonal as L21 = A21 M on the matrix cores (the per-row substitution of
-//       the older k_chol_blk -- 136 dependent FMAs fed by LDS reads per thread -- is gone);
+//       round 2's kernel -- 136 dependent FMAs fed by LDS reads per thread -- is gone);
 //   (4) finished rows of T_H / columns of W go to global memory, dx accumulates;
 //   (5) rank-16 update of the trailing blocks, operands straight from the LDS panel.
 // 12 panels x 4 barriers instead of 180 steps x (LDS exchange + barrier); the O(n^3) part runs at MFMA rate.
@@ -169,8 +169,10 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0, int nb) {
           const int k0 = 16 * (kb0 + u) + 4 * gq;
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4) {
-            const bool ok = k0 + s4 < n;
-            sacc = Mf<T>::mma(ok ? a4[u][s4] : T(0), ok ? bv[u][s4] : T(0), sacc);
+            // T_H is upper triangular: the part of row 16 i + rr left of its diagonal is masked here rather than trusted to be an
+            // exact zero in whatever route produced Rbuf (the k-blocks start at kb = i, so only the diagonal block has such entries)
+            const bool ok = k0 + s4 < n, upper = k0 + s4 >= 16 * i + rr;   // (the A operand's row is 16 i + rr; B's lane index is a column)
+            sacc = Mf<T>::mma(ok && upper ? a4[u][s4] : T(0), ok ? bv[u][s4] : T(0), sacc);
           }
         }
       }
@@ -230,8 +232,9 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0, int nb) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's stores have been acknowledged
       __syncthreads();
       // The wait is BOUNDED: nothing guarantees that the siblings are resident (another process or slice may hold the CUs they
-      // need while this part holds its own), so after ~1 ms without them this part forms the missing blocks itself -- the same
-      // instruction sequence its sibling would have run, the same bits; the split is a speed-up, never a dependency.
+      // need while this part holds its own), so after 20 000 polls (agent-scope load + s_sleep: some tens of milliseconds)
+      // without them this part forms the missing blocks itself -- the same instruction sequence its sibling would have run, the
+      // same bits; the split is a speed-up, never a dependency (tests force the fall-back with gain_fused_s == 3).
       __shared__ int s_all_here;
       if (tid == 0) {
         unsigned* bar = d.gain_bar + (long)b * 32;
@@ -720,6 +723,9 @@ bool launch_chol_gain_large(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   return true;
 }
 
+// (Measured and rejected, round 4: the factorizations padded with unused dynamic LDS so that they have their compute unit to
+// themselves -- the gain factorization leaves 128 registers per SIMD free, room for one k_feature wavefront of another slice
+// each, sharing the LDS pipe its pivot chain runs on: 200.9 k / 199.4 k -> 202.3 k updates/s in four slices, inside the noise.)
 template <class S>
 bool launch_chol_gram(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0) return true;

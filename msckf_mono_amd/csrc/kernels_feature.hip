@@ -1080,6 +1080,9 @@ void launch_feature(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   const dim3 grid(xcd_grid(nb, d.f_cap));
   constexpr int ALL_LO = -0x7fffffff, ALL_HI = 0x7fffffff, M_REG = 30;   // 2 * 30 + 4 = 64: the register-resident gate factorization
   if (d.m_cap <= M_REG) {
+    // (measured and rejected, round 4: the tracks of at most 12 / 16 / 20 observations in a launch of their own with the LDS sized
+    // for them -- five wavefronts per SIMD instead of four for those: 183 k -> 172 k updates/s on one stream, 201 k -> 199 k in four
+    // slices; the second launch's tail costs more than the occupancy gives.  cfg5's windows are another matter, below)
     hipLaunchKernelGGL((k_feature<S, false>), grid, dim3(64), feature_lds_bytes(d.m_cap, sizeof(S)), st, d, b0, nb, d.m_cap, ALL_LO, ALL_HI);
     return;
   }

@@ -23,7 +23,7 @@
 
 namespace msckf {
 
-enum { OP_PHT = 0, OP_S, OP_W, OP_K, OP_A, OP_AP, OP_X, OP_KE, OP_DOWN,
+enum { OP_PHT = 0, OP_S, OP_W, OP_K, OP_A, OP_AP, OP_X, OP_RETIRED7 /* (K = W E^T of the split Joseph solve; the number stays: kernel names in profiles) */, OP_DOWN,
        OP_PHTT };   // PHt = P[:,15:] T^T written ONLY as its row-major copy (float MFMA kernel): all the blocked gain solve reads
 
 template <class S>
@@ -51,7 +51,7 @@ __device__ __forceinline__ KView<S> make_view(const Dev<S>& d, int b) {
 template <class S, int OP> __device__ __forceinline__ void op_dims(const KView<S>& v, int& M, int& N, int& K) {
   if (OP == OP_PHT) { M = v.D; N = v.n; K = v.n; }
   else if (OP == OP_S) { M = v.n; N = v.n; K = v.n; }
-  else if (OP == OP_W || OP == OP_K || OP == OP_KE) { M = v.D; N = v.n; K = v.n; }
+  else if (OP == OP_W || OP == OP_K) { M = v.D; N = v.n; K = v.n; }
   else if (OP == OP_A) { M = v.D; N = v.D; K = v.n; }
   else if (OP == OP_AP) { M = v.D; N = v.D; K = v.D; }
   else if (OP == OP_DOWN) { M = v.D; N = v.D; K = v.n; }
@@ -61,7 +61,7 @@ template <class S, int OP> __device__ __forceinline__ S op_a(const KView<S>& v, 
   if (OP == OP_PHT) return v.P[(long)(15 + k) * v.ld + i];
   if (OP == OP_S) return k >= i ? v.R0[(long)i * v.ldR + k] : S(0);
   if (OP == OP_W) return v.PHt[(long)k * v.ld + i];
-  if (OP == OP_K || OP == OP_KE) return v.W[(long)k * v.ld + i];
+  if (OP == OP_K) return v.W[(long)k * v.ld + i];
   if (OP == OP_A) return v.K[(long)k * v.ld + i];
   if (OP == OP_AP) return v.A[(long)k * v.ld + i];
   if (OP == OP_DOWN) return v.W[(long)k * v.ld + i];
@@ -72,7 +72,6 @@ template <class S, int OP> __device__ __forceinline__ S op_b(const KView<S>& v, 
   if (OP == OP_S) return v.PHt[(long)j * v.ld + 15 + k];
   if (OP == OP_W) return k <= j ? v.Linv[(long)k * v.ldn + j] : S(0);             // Linv(j,k)
   if (OP == OP_K) return j <= k ? v.Linv[(long)j * v.ldn + k] : S(0);             // Linv(k,j)
-  if (OP == OP_KE) return k >= j ? v.Linv[(long)k * v.ldn + j] : S(0);            // E(j,k), E = L^-T upper triangular
   if (OP == OP_A) return (j >= 15 && j - 15 >= k) ? v.R0[(long)k * v.ldR + (j - 15)] : S(0);   // T_H[k][j]
   if (OP == OP_AP) return v.P[(long)j * v.ld + k];
   if (OP == OP_DOWN) return v.W[(long)k * v.ld + j];
@@ -87,7 +86,7 @@ template <class S, int OP> __device__ __forceinline__ void op_store(const KView<
     }
   }
   else if (OP == OP_W) v.W[(long)j * v.ld + i] = acc;
-  else if (OP == OP_K || OP == OP_KE) v.K[(long)j * v.ld + i] = acc;
+  else if (OP == OP_K) v.K[(long)j * v.ld + i] = acc;
   else if (OP == OP_A) v.A[(long)j * v.ld + i] = (i == j ? S(1) : S(0)) - acc;
   else if (OP == OP_AP) v.AP[(long)j * v.ld + i] = acc;
   else if (OP == OP_DOWN) {   // P <- P - W W^T, called for i <= j only: both triangles get the same value
@@ -98,59 +97,6 @@ template <class S, int OP> __device__ __forceinline__ void op_store(const KView<
   else v.X[(long)j * v.ld + i] = acc;
 }
 
-template <class S, int OP>
-__global__ __launch_bounds__(256) void k_gemm(Dev<S> d, int b0) {
-  const int b = b0 + blockIdx.z;
-  const int mrows_ = d.stats[(long)b * STAT_STRIDE + STAT_MROWS];   // loaded together with the window size (independent scalar loads, one wait)
-  const KView<S> v = make_view(d, b);
-  if (mrows_ == 0) return;
-  if (OP == OP_DOWN && blockIdx.x == 0 && blockIdx.y == 0) inject_from_dx<S>(d, b, threadIdx.x, 256);
-  int M, N, K;
-  op_dims<S, OP>(v, M, N, K);
-  const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
-  if (i0 >= M || j0 >= N) return;
-  __shared__ S sA[16][65];
-  __shared__ S sB[16][65];
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  S acc[4][4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[r][c] = 0;
-  for (int k0 = 0; k0 < K; k0 += 16) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int ii = tid & 63, kk = (tid >> 6) + 4 * q;
-      const int gi = i0 + ii, gk = k0 + kk;
-      sA[kk][ii] = (gi < M && gk < K) ? op_a<S, OP>(v, gi, gk) : S(0);
-      const int kb = tid & 15, jj = (tid >> 4) + 16 * q;
-      const int gj = j0 + jj, gk2 = k0 + kb;
-      sB[kb][jj] = (gj < N && gk2 < K) ? op_b<S, OP>(v, gk2, gj) : S(0);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      S a[4], bb[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) a[r] = sA[kk][4 * ty + r];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) bb[c] = sB[kk][4 * tx + c];
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[r][c] += a[r] * bb[c];
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int gi = i0 + 4 * ty + r, gj = j0 + 4 * tx + c;
-      if (gi < M && gj < N) op_store<S, OP>(v, gi, gj, acc[r][c]);
-    }
-}
-
 // f32 tile GEMM on the matrix cores: v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate -- bit-identical to an fmaf
 // chain, MI355X_MICROARCH.md).  64 x 64 output tile per workgroup, one 32 x 32 accumulator per wavefront.  The
 // product is formed transposed (MFMA "A" operand = B-tile, "B" operand = A-tile) so that the accumulator's
@@ -159,7 +105,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Operand-B staging order per product: true when the B element (k, j) is contiguous in j (then lanes run along j),
 // false when it is contiguous in k (lanes run along k) -- keeps the global loads of the tile coalesced.
-template <int OP> struct BContigJ { static constexpr bool value = (OP == OP_KE || OP == OP_A || OP == OP_X || OP == OP_W || OP == OP_DOWN); };
+template <int OP> struct BContigJ { static constexpr bool value = (OP == OP_A || OP == OP_X || OP == OP_W || OP == OP_DOWN); };
 
 // Operand access split into {address, validity, scale} so that the prefetch is branch-free: every load of a
 // k-tile is issued unconditionally from a clamped address (all in flight together -- a conditional per element makes
@@ -168,7 +114,7 @@ template <int OP> __device__ __forceinline__ const float* opa_ptr(const KView<fl
   if (OP == OP_PHT) return v.P + (long)(15 + k) * v.ld + i;
   if (OP == OP_S) return v.R0 + (long)i * v.ldR + k;
   if (OP == OP_W) return v.PHt + (long)k * v.ld + i;
-  if (OP == OP_K || OP == OP_KE) return v.W + (long)k * v.ld + i;
+  if (OP == OP_K) return v.W + (long)k * v.ld + i;
   if (OP == OP_A) return v.K + (long)k * v.ld + i;
   if (OP == OP_AP) return v.A + (long)k * v.ld + i;
   if (OP == OP_DOWN) return v.W + (long)k * v.ld + i;
@@ -184,7 +130,6 @@ template <int OP> __device__ __forceinline__ const float* opb_ptr(const KView<fl
   if (OP == OP_S) return v.PHt + (long)j * v.ld + 15 + k;
   if (OP == OP_W) return v.Linv + (long)k * v.ldn + j;
   if (OP == OP_K) return v.Linv + (long)j * v.ldn + k;
-  if (OP == OP_KE) return v.Linv + (long)k * v.ldn + j;
   if (OP == OP_A) return v.R0 + (long)k * v.ldR + (j >= 15 ? j - 15 : 0);
   if (OP == OP_AP) return v.P + (long)j * v.ld + k;
   if (OP == OP_DOWN) return v.W + (long)k * v.ld + j;
@@ -194,7 +139,6 @@ template <int OP> __device__ __forceinline__ float opb_fix(const KView<float>& v
   if (OP == OP_PHT) return k >= j ? x : 0.f;
   if (OP == OP_W) return k <= j ? x : 0.f;
   if (OP == OP_K) return j <= k ? x : 0.f;
-  if (OP == OP_KE) return k >= j ? x : 0.f;
   if (OP == OP_A) return (j >= 15 && j - 15 >= k) ? x : 0.f;
   return x;
 }
@@ -327,7 +271,7 @@ __global__ __launch_bounds__(256) void k_gemm_mfma(Dev<float> d, int b0, int nb,
   };
   // triangular operands: T, E = L^-T are upper triangular, so whole k-tiles of the product are zero
   int kbeg = 0;
-  if (OP == OP_PHT || OP == OP_KE) kbeg = (j0 / GT) * GT;            // B(k, j) = T[j][k] / E(j, k): zero for k < j
+  if (OP == OP_PHT) kbeg = (j0 / GT) * GT;                           // B(k, j) = T[j][k]: zero for k < j
   if (OP == OP_S) kbeg = (i0 / GT) * GT;                             // A(i, k) = T[i][k]: zero for k < i
   if (OP == OP_A) K = min(K, max(j0 + 64 - 15, 0));                  // B(k, j) = T_H[k][j]: zero for k > j - 15
   GM_TICK(0);
@@ -492,7 +436,7 @@ __global__ __launch_bounds__(256) void k_gemm_mfma64(Dev<double> d, int b0) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) acc[a][c] = f64x4{0.0, 0.0, 0.0, 0.0};
   int kbeg = 0;
-  if (OP == OP_PHT || OP == OP_KE) kbeg = (j0 / KT) * KT;
+  if (OP == OP_PHT) kbeg = (j0 / KT) * KT;
   if (OP == OP_S) kbeg = (i0 / KT) * KT;
   if (OP == OP_A) K = min(K, max(j0 + 64 - 15, 0));
   for (int k0 = kbeg; k0 < K; k0 += KT) {
@@ -755,98 +699,6 @@ __global__ __launch_bounds__(256) void k_gain(Dev<S> d, int b0) {
 #pragma unroll
       for (int y = 0; y < G; ++y) sm += sDx[y][i];
       d.dx[(long)b * d.ld + i] = sm;
-    }
-  }
-}
-
-// Split variant of the gain solve: NPART (4 or 8) workgroups per trajectory.  Every workgroup factors S = L L^T in registers
-// (redundantly, 78 blocks) and carries 1/NPART of the appended rows [PHt ; I] through the same eliminations,
-// which turns them into [W ; E] = [PHt L^-T ; L^-T].  K = PHt S^-1 = W E^T is then one MFMA GEMM (OP_KE) instead of
-// the backward sweep of k_gain: half the sequential steps, four times the workgroups.
-template <class S, int NBN, int NPART>
-__global__ __launch_bounds__(256) void k_gain_split(Dev<S> d, int b0) {
-  constexpr int G = 16, NBD = NBN + 1, NBA = NBD + NBN, NBQ = (NBA + NPART - 1) / NPART;
-  const int b = b0 + blockIdx.y, part = blockIdx.x, tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  const int mrows_ = d.stats[(long)b * STAT_STRIDE + STAT_MROWS];   // loaded together with the window size (independent scalar loads, one wait)
-  const KView<S> v = make_view(d, b);
-  if (mrows_ == 0) return;
-  const int n = v.n, D = v.D;
-  __shared__ S sCol[2][G * NBN];
-  __shared__ S sW[2][G * NBQ];
-  S A[NBN][NBN], Wm[NBQ][NBN];
-#pragma unroll
-  for (int a = 0; a < NBN; ++a)
-#pragma unroll
-    for (int bb = 0; bb < NBN; ++bb) {
-      const int i = G * a + tx, j = G * bb + ty;
-      A[a][bb] = (a >= bb && i < n && j < n) ? v.Sm[(long)j * v.ldn + i] : S(0);
-    }
-#pragma unroll
-  for (int a = 0; a < NBQ; ++a) {
-    const int ab = part * NBQ + a;          // appended row block: [0,NBD) rows of PHt, [NBD,NBA) rows of I
-#pragma unroll
-    for (int bb = 0; bb < NBN; ++bb) {
-      const int j = G * bb + ty;
-      S val = 0;
-      if (ab < NBD) { const int i = G * ab + tx; if (i < D && j < n) val = v.PHt[(long)j * v.ld + i]; }
-      else if (ab < NBA) { const int r = G * (ab - NBD) + tx; if (r == j && r < n) val = S(1); }
-      Wm[a][bb] = val;
-    }
-  }
-  int buf = 0;
-#pragma unroll
-  for (int kb = 0; kb < NBN; ++kb) {
-    const int kk_hi = min(G, n - G * kb);
-    for (int kk = 0; kk < kk_hi; ++kk) {
-      const int k = G * kb + kk;
-      if (ty == kk) {
-#pragma unroll
-        for (int a = kb; a < NBN; ++a) sCol[buf][G * a + tx] = A[a][kb];
-#pragma unroll
-        for (int a = 0; a < NBQ; ++a) sW[buf][G * a + tx] = Wm[a][kb];
-      }
-      __syncthreads();
-      const S dkk = sCol[buf][k];
-      const S dpos = dkk > S(0) ? dkk : Lim<S>::tiny();
-      if (!(dkk > S(0)) && tid == 0) atomicOr(&d.stats[(long)b * STAT_STRIDE + STAT_ERR], STAT_ERR_PIVOT);   // S not positive definite: reported, run continues
-      const S dinv = fast_rsqrt(dpos);
-      const S dd = dpos * dinv;
-      S li[NBN], lj[NBN], wi[NBQ];
-#pragma unroll
-      for (int a = kb; a < NBN; ++a) li[a] = (a > kb || tx > kk) ? sCol[buf][G * a + tx] * dinv : S(0);
-#pragma unroll
-      for (int bb = kb; bb < NBN; ++bb) lj[bb] = (bb > kb || ty > kk) ? sCol[buf][G * bb + ty] * dinv : S(0);
-#pragma unroll
-      for (int a = 0; a < NBQ; ++a) wi[a] = sW[buf][G * a + tx] * dinv;
-#pragma unroll
-      for (int a = kb; a < NBN; ++a)
-#pragma unroll
-        for (int bb = kb; bb <= a; ++bb) A[a][bb] -= li[a] * lj[bb];
-#pragma unroll
-      for (int a = 0; a < NBQ; ++a)
-#pragma unroll
-        for (int bb = kb; bb < NBN; ++bb) Wm[a][bb] -= wi[a] * lj[bb];
-      if (ty == kk) {
-#pragma unroll
-        for (int a = kb; a < NBN; ++a) {
-          if (a > kb || tx > kk) A[a][kb] = li[a];
-          else if (a == kb && tx == kk) A[a][kb] = dd;
-        }
-#pragma unroll
-        for (int a = 0; a < NBQ; ++a) Wm[a][kb] = wi[a];
-      }
-      buf ^= 1;
-    }
-  }
-#pragma unroll
-  for (int a = 0; a < NBQ; ++a) {
-    const int ab = part * NBQ + a;
-#pragma unroll
-    for (int bb = 0; bb < NBN; ++bb) {
-      const int j = G * bb + ty;
-      if (j >= n) continue;
-      if (ab < NBD) { const int i = G * ab + tx; if (i < D) v.W[(long)j * v.ld + i] = Wm[a][bb]; }
-      else if (ab < NBA) { const int r = G * (ab - NBD) + tx; if (r < n) v.Linv[(long)j * v.ldn + r] = Wm[a][bb]; }   // E(r,j), upper triangular
     }
   }
 }
@@ -1129,23 +981,16 @@ void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   // ---- Joseph form (the reference's literal sequence)
   // K = PHt S^-1: register-resident factor/solve when the window fits the 16x16 thread grid, otherwise
   // Cholesky + triangular inverse (LDS or global) followed by two GEMMs.
-  bool split = false;
   if (nbn <= nbn_max) {
     if (nbn <= 4) hipLaunchKernelGGL((k_gain<S, 4>), dim3(nb), dim3(256), 0, st, d, b0);
     else if (nbn <= 8) hipLaunchKernelGGL((k_gain<S, 8>), dim3(nb), dim3(256), 0, st, d, b0);
-    else if (sizeof(S) == 4 && nb <= 128) {   // few trajectories: 4 workgroups each + one MFMA GEMM
-      if (nb <= 64) hipLaunchKernelGGL((k_gain_split<S, 12, 8>), dim3(8, nb), dim3(256), 0, st, d, b0);
-      else hipLaunchKernelGGL((k_gain_split<S, 12, 4>), dim3(4, nb), dim3(256), 0, st, d, b0);
-      gemm<S, OP_KE>(d, b0, nb, D, n, st);
-      split = true;
-    }
     else hipLaunchKernelGGL((k_gain<S, 12>), dim3(nb), dim3(256), 0, st, d, b0);
   } else {
     chol_inv();
     gemm<S, OP_W>(d, b0, nb, D, n, st);
     gemm<S, OP_K>(d, b0, nb, D, n, st);
   }
-  if (nbn <= nbn_max && !split) hipLaunchKernelGGL((k_inject<S, true>), dim3(nb), dim3(256), (size_t)d.ld * sizeof(S), st, d, b0);
+  if (nbn <= nbn_max) hipLaunchKernelGGL((k_inject<S, true>), dim3(nb), dim3(256), (size_t)d.ld * sizeof(S), st, d, b0);
   else hipLaunchKernelGGL((k_inject<S, false>), dim3(nb), dim3(256), (size_t)(d.ld + d.n6cap) * sizeof(S), st, d, b0);
   gemm<S, OP_A>(d, b0, nb, D, D, st);
   gemm<S, OP_AP>(d, b0, nb, D, D, st);

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(1024) void k_literal(Dev<S> d, int b0, int nb) {
   a.ldz = L.ldz; a.Z = L.Z + (long)b * L.ldz * L.ldz;
   a.Lam = d.Lam + (long)b * d.ldR * d.ldR; a.ldL = d.ldR;
   a.info = L.info + (long)b * 8;
-  a.LamIn = a.Lam; a.lam_part = d.lam_part; a.gram_parts = (d.compress == 3 && d.ldR <= 192 && d.lam_part > 0) ? (d.gram_parts >= 3 ? d.gram_parts : 3) : 1;
+  a.LamIn = a.Lam; a.lam_part = d.lam_part; a.gram_parts = (d.compress && d.ldR <= 192 && d.lam_part > 0) ? (d.gram_parts >= 3 ? d.gram_parts : 3) : 1;
   a.W2 = L.W2 + (long)b * L.w2_stride;
   lit::literal_compress(c, a, L.route);
   // the blocked Cholesky adds the split-K copies of Lam^ that k_gram leaves (Dev::lam_part apart): none here

@@ -212,7 +212,7 @@ struct Batch : BatchBase {
   int fuse_prune = 1;     // run_frames: prune rides on the downdate (MSCKF_HIP_FUSE_PRUNE=0: separate k_prune_inplace launch)
   int overlap_feature = 0;   // measured on MI355X at cfg3: 100 k -> 82 k updates/s with the overlap on (k_feature floods the CUs the
                              // latency-bound propagate/augment workgroups need); kept selectable, off by default
-  int compress_route = -1;   // -1 default, 0 Householder TSQR, 1 information form, 2 information form + blocked Cholesky
+  int compress_route = -1;   // -1 default, 0 Householder TSQR, != 0 information form + blocked matrix-core Cholesky
   // anisotropic pixel noise (u_var' != v_var'): 0 = the reference's construction R_o_j = A_j^T R_j A_j, R_n = Q_1^T R_o Q_1 on
   // the device (kernels_literal.hip; default), 1 = rows pre-whitened by 1/sigma (generalized least squares, unit noise)
   int aniso_mode = 0;
@@ -251,8 +251,18 @@ struct Batch : BatchBase {
   int ring = 6, up_mode = 0;   // up_mode 0: the host threads hand frames over (no device-side cross-stream wait); 1: hipStreamWaitEvent
   hipStream_t stc = nullptr; hipEvent_t ev_up[RING_MAX] = {nullptr}; hipEvent_t ev_use[RING_MAX][MAXS] = {{nullptr}};
   unsigned char* sg_blk[RING_MAX] = {nullptr}; size_t sg_bytes = 0;
-  struct PinFrame { unsigned char* p = nullptr; size_t bytes = 0, off_obs = 0; };
-  std::vector<PinFrame> pinf; std::vector<void*> pin_chunks;
+  struct PinFrame { unsigned char* p = nullptr; size_t bytes = 0, off_obs = 0; int chunk = -1; };
+  struct PinChunk { void* p = nullptr; int live = 0; };   // page-locked block of several frames; freed when its last frame is invalidated
+  std::vector<PinFrame> pinf; std::vector<PinChunk> pin_chunks;
+  void unpin_frame(int f) {
+    const int c = pinf[f].chunk;
+    if (c >= 0 && c < (int)pin_chunks.size() && pin_chunks[c].p && --pin_chunks[c].live == 0) {
+      if (stc) (void)hipStreamSynchronize(stc);     // the last copy out of the block has completed
+      (void)hipHostFree(pin_chunks[c].p);
+      pin_chunks[c].p = nullptr;
+    }
+    pinf[f] = PinFrame();
+  }
   size_t pk_rd = 0, pk_n = 0, pk_drop = 0, pk_M = 0, pk_off = 0, pk_slots = 0;   // section offsets (256-byte aligned); obs follows the frame's slots
   Workers workers;   // enqueue threads of the slices
   // profiling
@@ -402,6 +412,17 @@ struct Batch : BatchBase {
     return false;
   }
   int chk(int b) const { return (b < 0 || b >= B) ? -EINVAL : 0; }
+  // A run_frames / run_frames_streamed call that failed after some of its frames were enqueued leaves the slices at different
+  // frames: which covariance buffer is current (the fused prune flips them per frame) and whether a window size is still
+  // deferred differ per slice, and nothing can put that right.  The handle refuses further work instead of answering from a
+  // stale buffer; the caller destroys it.
+  bool poisoned = false;
+  int poison(int rc, const std::string& msg) {
+    (void)hipDeviceSynchronize();
+    poisoned = true;
+    return fail(rc, msg + " -- frames of this call were already enqueued: the filter states of this handle are undefined, destroy it");
+  }
+#define POISON_GUARD() do { if (poisoned) return fail(-EIO, "handle unusable after a failed run_frames call (destroy it)"); } while (0)
   int chk_range(int b0, int nb) const { return (b0 < 0 || nb < 0 || b0 + nb > B) ? -EINVAL : 0; }
 
   // The five derived noise parameters PRM_WU .. PRM_LIT of trajectory b for the batch's anisotropic-noise mode
@@ -474,6 +495,7 @@ struct Batch : BatchBase {
     return 0;
   }
   int init(int b, const double* cam, const double* noise, const double* params, const double* imu) override {
+    POISON_GUARD();
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
     if (!(noise[0] > 0) || !(noise[1] > 0)) return fail(-EINVAL, "u_var_prime / v_var_prime must be positive");
     HIPCHK(hipSetDevice(device));
@@ -548,6 +570,7 @@ struct Batch : BatchBase {
   }
   void invalidate_imu(int b0, int nb) { for (int b = b0; b < b0 + nb && b < B; ++b) h_imu_ok[b] = 0; }
   int propagate(int b0, int nb, const double* rd, int K, bool mirror) override {
+    POISON_GUARD();
     if (chk_range(b0, nb)) return fail(-EINVAL, "trajectory range out of bounds");
     if (K < 0) return fail(-EINVAL, "negative sample count");
     if (mirror && nb == 1) { if (h_imu_ok[b0]) for (int k = 0; k < K; ++k) host_rk(h_imu.data() + (size_t)b0 * IMU_STRIDE, rd + (size_t)k * RD_STRIDE); }
@@ -572,6 +595,7 @@ struct Batch : BatchBase {
     return 0;
   }
   int augment(int b0, int nb) override {
+    POISON_GUARD();
     if (chk_range(b0, nb)) return fail(-EINVAL, "trajectory range out of bounds");
     HIPCHK(hipSetDevice(device));
     launch_augment<S>(d, b0, nb, st);
@@ -638,7 +662,7 @@ struct Batch : BatchBase {
   void launch_update(const Dev<S>& vin, int b0, int nb, hipStream_t q, bool feature_done = false) {
     invalidate_imu(b0, nb);            // the update corrects the IMU state on the device (msckf.h:1376-1383)
     Dev<S> v = vin;
-    if (compress_route >= 0) v.compress = (compress_route && d.trk_B) ? compress_route : 0;
+    if (compress_route >= 0) v.compress = (compress_route && d.trk_B) ? 3 : 0;
     if (n_lit > 0 && !v.compress) v.compress = d.compress;   // the literal route hands over an information matrix: Cholesky tail
     if (!feature_done) { stage_begin(2, q); launch_feature<S>(v, b0, nb, q); stage_end(2, q); }
     // information form: k_select and the block-diagonal reduction share a launch (both only read k_feature's outputs)
@@ -658,6 +682,7 @@ struct Batch : BatchBase {
     stage_begin(5, q); launch_kalman<S>(v, b0, nb, q); stage_end(5, q);
   }
   int marginalize(int b0, int nb) override {
+    POISON_GUARD();
     if (chk_range(b0, nb)) return fail(-EINVAL, "trajectory range out of bounds");
     HIPCHK(hipSetDevice(device));
     use_single_worklists();
@@ -691,6 +716,7 @@ struct Batch : BatchBase {
     return F;
   }
   int marginalize_given(int b) override {
+    POISON_GUARD();
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
     HIPCHK(hipSetDevice(device));
     use_single_worklists();
@@ -701,6 +727,7 @@ struct Batch : BatchBase {
     return 0;
   }
   int prune_keep(int b, const std::vector<int>& keep) override {
+    POISON_GUARD();
     HIPCHK(hipSetDevice(device));
     const int nk = (int)keep.size();
     if (nk) HIPCHK(hipMemcpyAsync(d.keep + (size_t)b * n_cap, keep.data(), nk * sizeof(int), hipMemcpyHostToDevice, st));
@@ -713,6 +740,7 @@ struct Batch : BatchBase {
   }
   int drop_oldest(int b0, int nb, int n) override;
   int get_ncam(int b, int* n) override {
+    POISON_GUARD();
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipMemcpyAsync(n, d.ncam + b, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -720,6 +748,7 @@ struct Batch : BatchBase {
     return 0;
   }
   int get_imu(int b, double* o) override {
+    POISON_GUARD();
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
     S* tmp = h_imu.data() + (size_t)b * IMU_STRIDE;
     if (!h_imu_ok[b]) {
@@ -742,6 +771,7 @@ struct Batch : BatchBase {
     return 0;
   }
   int get_cams(int b, double* o, int cap, int* nout) override {
+    POISON_GUARD();
     int n = 0;
     int rc = get_ncam(b, &n);
     if (rc) return rc;
@@ -763,6 +793,7 @@ struct Batch : BatchBase {
     return 0;
   }
   int get_cov(int b, double* P, int ldo) override {
+    POISON_GUARD();
     int n = 0;
     int rc = get_ncam(b, &n);
     if (rc) return rc;
@@ -802,6 +833,7 @@ struct Batch : BatchBase {
     return 0;
   }
   int stats(int b, int* out) override {
+    POISON_GUARD();
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
     HIPCHK(hipSetDevice(device));
     int tmp[STAT_STRIDE];
@@ -818,6 +850,7 @@ struct Batch : BatchBase {
   // -- IMU / camera states, parameters, covariance, window size, counters, flags -- and the host-side track bookkeeping;
   // work buffers and a resident scenario are not state and are not copied
   int copy_from(BatchBase* src) override {
+    POISON_GUARD();
     Batch<S>* o = dynamic_cast<Batch<S>*>(src);
     if (!o || o->B != B || o->n_cap != n_cap || o->f_cap != f_cap || o->m_cap != m_cap || o->h16 != h16)
       return fail(-EINVAL, "copy_state: handles differ in shape or dtype");
@@ -941,7 +974,7 @@ struct Batch : BatchBase {
     for (size_t e = 0; e < tot; ++e) { mx = std::max(mx, slots[e]); c_obs[cell][2 * e] = (S)obs[2 * e]; c_obs[cell][2 * e + 1] = (S)obs[2 * e + 1]; }
     h_maxslot[cell] = mx;
     committed = false;               // offsets move: the resident copy and the frame's page-locked block are stale until the next commit
-    pinf[f] = PinFrame();
+    unpin_frame(f);                  // (its chunk is released with the last of its frames: patch -> commit -> stream cycles do not grow)
     return 0;
   }
   // H2D of everything staged.  The host copy is kept, so cells may be patched with scenario_set and committed again.
@@ -1030,7 +1063,10 @@ struct Batch : BatchBase {
         for (int f : todo) pinf[f] = PinFrame();
         return fail(-ENOMEM, "could not page-lock the frames to stream (run_frames on the resident scenario is unaffected)");
       }
-      pin_chunks.push_back(chunk);
+      int ci = -1;
+      for (size_t q = 0; q < pin_chunks.size(); ++q) if (!pin_chunks[q].p) { ci = (int)q; break; }
+      if (ci < 0) { pin_chunks.push_back(PinChunk()); ci = (int)pin_chunks.size() - 1; }
+      pin_chunks[ci].p = chunk; pin_chunks[ci].live = (int)todo.size();
       size_t o = 0;
       for (int f : todo) {
         unsigned char* blk = chunk + o;
@@ -1047,7 +1083,7 @@ struct Batch : BatchBase {
           if (n) { std::memcpy(hs + e, c_slots[cell].data(), n * sizeof(int)); std::memcpy(ho + 2 * e, c_obs[cell].data(), 2 * n * sizeof(S)); }
           e += n;
         }
-        pinf[f].p = blk;
+        pinf[f].p = blk; pinf[f].chunk = ci;
         o += pinf[f].bytes;
       }
     }
@@ -1063,7 +1099,7 @@ struct Batch : BatchBase {
   int run_frames(int f0, int f1) override;
   int run_frames_streamed(int f0, int f1) override;
   void unpin_host() {
-    for (void* q : pin_chunks) hipHostFree(q);
+    for (auto& q : pin_chunks) if (q.p) hipHostFree(q.p);
     pin_chunks.clear();
     for (auto& pf : pinf) pf = PinFrame();
   }
@@ -1107,7 +1143,7 @@ struct Batch : BatchBase {
     return 0;
   }
   int set_compression(int route) override {
-    if (route < -1 || route > 3) return fail(-EINVAL, "route: -1 default, 0 Householder TSQR, information form with 1 register / 2 blocked / 3 blocked + MFMA panel Cholesky");
+    if (route < -1 || route > 3) return fail(-EINVAL, "route: -1 default, 0 Householder TSQR, 1..3 information form (blocked matrix-core Cholesky; 1 and 2 named retired factorizations)");
     if (route >= 1 && !d.trk_B) return fail(-ENOTSUP, "information form not available for this window size (6 n_cap + 1 > 384 or f_cap > 1024)");
     compress_route = route;
     return 0;
@@ -1158,6 +1194,7 @@ struct Batch : BatchBase {
 
 template <class S>
 int Batch<S>::drop_oldest(int b0, int nb, int n) {
+  POISON_GUARD();
   if (chk_range(b0, nb)) return fail(-EINVAL, "trajectory range out of bounds");
   HIPCHK(hipSetDevice(device));
   launch_prune<S>(d, b0, nb, st, nullptr, std::max(n, 0));
@@ -1168,6 +1205,7 @@ int Batch<S>::drop_oldest(int b0, int nb, int n) {
 
 template <class S>
 int Batch<S>::run_frames(int f0, int f1) {
+  POISON_GUARD();
   if (f0 < 0 || f1 > sc_frames || f0 > f1) return fail(-EINVAL, "frame range out of bounds");
   if (!committed) return fail(-EINVAL, "scenario not committed");
   HIPCHK(hipSetDevice(device));
@@ -1213,7 +1251,7 @@ int Batch<S>::run_frames(int f0, int f1) {
         (void)hipEventRecord(ev_fa[hh], q);
         (void)hipStreamWaitEvent(sty[hh], ev_fa[hh], 0);
         Dev<S> v2 = v; v2.ncam_bias = 1;
-        if (compress_route >= 0) v2.compress = (compress_route && d.trk_B) ? compress_route : 0;
+        if (compress_route >= 0) v2.compress = (compress_route && d.trk_B) ? 3 : 0;
         launch_feature<S>(v2, b0, nb, sty[hh]);
         (void)hipEventRecord(ev_fb[hh], sty[hh]);
       }
@@ -1251,9 +1289,9 @@ int Batch<S>::run_frames(int f0, int f1) {
     workers.wait();
   }
   rc = join_slices(nh, qs);
-  if (rc) return rc;
+  if (rc) return poison(rc, "joining the slices' streams failed");
   for (int i = 0; i < nh; ++i)
-    if (slice_rc[i]) return fail(-EIO, std::string("kernel launch failed on slice ") + std::to_string(i) + ": " + hipGetErrorString((hipError_t)slice_rc[i]));
+    if (slice_rc[i]) return poison(-EIO, std::string("kernel launch failed on slice ") + std::to_string(i) + ": " + hipGetErrorString((hipError_t)slice_rc[i]));
   commit_buffer_parity(f0, f1);
   return 0;
 }
@@ -1268,6 +1306,7 @@ int Batch<S>::run_frames(int f0, int f1) {
 // the device-side hipStreamWaitEvent protocol, for comparison.
 template <class S>
 int Batch<S>::run_frames_streamed(int f0, int f1) {
+  POISON_GUARD();
   if (f0 < 0 || f1 > sc_frames || f0 > f1) return fail(-EINVAL, "frame range out of bounds");
   if (!committed) return fail(-EINVAL, "scenario not committed");
   HIPCHK(hipSetDevice(device));
@@ -1362,12 +1401,12 @@ int Batch<S>::run_frames_streamed(int f0, int f1) {
   if (rc_up) failed.store(1);
   workers.wait();
   if (repin) (void)pthread_setaffinity_np(pthread_self(), sizeof(old_mask), &old_mask);
-  if (rc_up) return fail(rc_up, "input upload failed");
+  if (rc_up) return poison(rc_up, "input upload failed");
   rc = join_slices(nh, qs);
-  if (rc) return rc;
-  HIPCHK(hipEventRecord(ev_join[1], stc)); HIPCHK(hipStreamWaitEvent(st, ev_join[1], 0));
+  if (rc) return poison(rc, "joining the slices' streams failed");
+  if (hipEventRecord(ev_join[1], stc) != hipSuccess || hipStreamWaitEvent(st, ev_join[1], 0) != hipSuccess) return poison(-EIO, "joining the copy stream failed");
   for (int i = 0; i < nh; ++i)
-    if (slice_rc[i]) return fail(-EIO, std::string("kernel launch failed on slice ") + std::to_string(i) + ": " + hipGetErrorString((hipError_t)slice_rc[i]));
+    if (slice_rc[i]) return poison(-EIO, std::string("kernel launch failed on slice ") + std::to_string(i) + ": " + hipGetErrorString((hipError_t)slice_rc[i]));
   commit_buffer_parity(f0, f1);
   return 0;
 }

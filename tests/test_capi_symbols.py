@@ -40,7 +40,7 @@ def test_every_declared_symbol_is_exported(hip_lib):
 
 def test_library_contains_gfx950_code_object(hip_lib):
     data = open(hip_lib.LIB_PATH, "rb").read()
-    assert b"gfx950" in data and all(k in data for k in (b"k_qr_update", b"k_feature", b"k_gram", b"k_chol_T", b"k_gemm_mfma", b"k_gain_split"))
+    assert b"gfx950" in data and all(k in data for k in (b"k_qr_update", b"k_feature", b"k_gram", b"k_chol_mfma", b"k_gemm_mfma", b"k_literal"))
 
 
 def test_create_fails_loudly_without_gpu(hip_lib):

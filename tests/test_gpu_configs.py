@@ -338,7 +338,7 @@ def test_low_parallax_double_both_routes_vs_oracle(capi, po):
             conds.append(s[0] / s[-1])
             return super().measurement_update(Hm, r, R)
 
-    for route in (1, 0):
+    for route in (3, 0):
         o = po.Oracle(po.F64, po.LEAN)
         o.initialize(tr.cfg, tr.imu0)
         bt = capi.Batch(1, N, F, N, capi.F64)

@@ -203,13 +203,6 @@ def test_batched_range_equals_single(capi):
         assert np.array_equal(one.imu_state(b), big.imu_state(b))
 
 
-def _same_but_r_rows(a, b):
-    """r_rows counts the pivots of the Gram matrix above a rounding-level tolerance (64 eps of the original diagonal): a
-    gauge direction whose pivot is rounding noise can fall on either side of it in two factorization kernels."""
-    strip = lambda st: {k: v for k, v in st.items() if k != "r_rows"}
-    return strip(a) == strip(b) and abs(a["r_rows"] - b["r_rows"]) <= 1
-
-
 @pytest.mark.parametrize("prec", ["f64", "f32"])
 def test_information_form_equals_householder_route(capi, prec):
     """The library has two compression routes for the stacked Jacobian: the information form (default: H_o^T H_o
@@ -220,7 +213,7 @@ def test_information_form_equals_householder_route(capi, prec):
     tr = sc.Trajectory(2, 7, N, F, nf)
     cd = capi.F64 if prec == "f64" else capi.F32
     res = {}
-    for route in (0, 1, 2, 3):            # information form with 1 k_chol_T, 2 k_chol_blk, 3 k_chol_mfma (kernels_chol.hip)
+    for route in (0, 3):                  # 3: information form, blocked matrix-core Cholesky (kernels_chol.hip)
         bt = capi.Batch(1, N, F, N, cd)
         bt.set_compression(route)
         bt.initialize(0, tr.cfg, tr.imu0)
@@ -228,16 +221,10 @@ def test_information_form_equals_householder_route(capi, prec):
             H.device_frame(bt, 0, tr, k, N)
         res[route] = (bt.imu_state(0), bt.cam_states(0)[0], bt.covariance(0), bt.last_stats(0))
         bt.close()
-    e = H.state_errors(res[1][0], res[0][0], res[1][1], res[0][1], res[1][2], res[0][2])
+    e = H.state_errors(res[3][0], res[0][0], res[3][1], res[0][1], res[3][2], res[0][2])
     assert H.worst(e) < (1e-8 if prec == "f64" else 3e-4), e
-    e2 = H.state_errors(res[2][0], res[1][0], res[2][1], res[1][1], res[2][2], res[1][2])
-    assert H.worst(e2) < (1e-9 if prec == "f64" else 3e-4), e2
-    assert _same_but_r_rows(res[2][3], res[1][3])
-    e3 = H.state_errors(res[3][0], res[1][0], res[3][1], res[1][1], res[3][2], res[1][2])
-    assert H.worst(e3) < (1e-9 if prec == "f64" else 3e-4), e3
-    assert _same_but_r_rows(res[3][3], res[1][3])
-    assert res[1][3]["m_rows"] == res[0][3]["m_rows"] > 0
-    assert res[1][3]["r_rows"] < res[0][3]["r_rows"] == 6 * N            # gauge directions skipped
+    assert res[3][3]["m_rows"] == res[0][3]["m_rows"] > 0
+    assert res[3][3]["r_rows"] < res[0][3]["r_rows"] == 6 * N            # gauge directions skipped
 
 
 @pytest.mark.parametrize("prec,N,F", [("f64", 8, 24), ("f64", 26, 60), ("f32", 12, 40), ("f32", 30, 120), ("f64", 36, 80), ("f32", 44, 100), ("f64", 60, 120), ("f32", 32, 80), ("f32", 33, 80)])
