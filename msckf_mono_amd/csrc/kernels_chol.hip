@@ -24,7 +24,13 @@
 
 #include "dev_common.h"
 
+
 namespace msckf {
+
+// max(x, lo) as ONE instruction (v_max; NaN -> lo): the library fmax goes through a canonicalizing v_max x, x first, and this
+// sits on the pivot chain
+__device__ __forceinline__ float clamp_min(float x, float lo) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(lo)); return r; }
+__device__ __forceinline__ double clamp_min(double x, double lo) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(lo)); return r; }
 
 typedef double cd4 __attribute__((ext_vector_type(4)));
 typedef float cf4 __attribute__((ext_vector_type(4)));
@@ -381,6 +387,25 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0, int nb) {
   // cycles (profiles/r03_aj_*).  So the crossbar latency is not what a pivot step waits for either.
   // And the hardware v_rsq_f32 without its Newton step (three dependent operations less per pivot): 60.5 k -> 57.9 k cycles, but
   // the float square-root-gain vs Joseph comparison fails its 1e-3 -- the seed is not accurate enough for 180 pivots in a row.
+  // Round 4, the pivot step (profiles/r04_n_*): ~80 instructions per pivot in f64 -> ~55 by (i) no masks on the updates -- a
+  // multiplier that must not act is a zero: L(r, k) = 0 above the diagonal, hence L(j, k) = 0 for j < k; column k itself (j = k,
+  // register qk of group gk) is updated with garbage and then overwritten with its finished values; entries above the diagonal
+  // pick up finite garbage that nothing reads (the store at the end masks them); (ii) crossbar addresses formed once, the pivot's
+  // group through the instruction's offset field; (iii) the column masked BEFORE it is scaled, i.e. while the reciprocal square
+  // root is under way, the diagonal lane scaling its own pivot (no second broadcast); (iv) the clamp of a non-positive pivot as one
+  // v_max.  Diagonal blocks 90 k -> 77 k cycles (f64), 61 k -> 55 k (f32); 200 k -> 204 k updates/s in four slices, 182.5 k ->
+  // 186.6 k on one stream; same values in every entry that is used.  Measured and rejected on the way: finished columns written
+  // straight to the LDS panel inside the loop (the exec-masked stores and their share of lgkmcnt cost more than the select they
+  // remove: f32 55 k -> 65 k, and the f64 instance spills); ONE Newton step for the f64 pivot of a float filter (77 k -> 69 k,
+  // +2 %, but the 60-camera float filter leaves the Householder route by more than the test's tolerance: Lam^ carries the
+  // SQUARED condition of the stack); the rank-1 update from the unscaled column with 1 / piv from v_rcp + Newton, which takes the
+  // crossbar round trip out of the chain altogether (same speed as this form
+  // and the float square-root-gain vs Joseph comparison at 44 cameras fails its 1e-3); 1 / sqrt(piv) broadcast as its two
+  // factors (seed, last Newton factor) with the next pivot's seed started right behind the one FMA it waits for, finished columns
+  // in registers of their own, every select beside the chain (eight dependent operations per pivot instead of eleven: f32
+  // 55 k -> 58 k, f64 unchanged).  So neither the crossbar round trip nor the number of dependent operations sets the ~290 (f32)
+  // / ~400 (f64) cycles of a pivot step on a compute unit whose other fifteen wavefronts are at work (230 / 330 with them idle);
+  // what did pay was the number of instructions.
   auto diag = [&](auto pc) __attribute__((always_inline)) {
     constexpr int p = decltype(pc)::value;
     T (*sP)[LP] = sPP[p & 1];
@@ -391,43 +416,48 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0, int nb) {
       T x[4], v[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) { x[q] = sP[16 * p + r][4 * q + g]; v[q] = (4 * q + g == r) ? T(1) : T(0); }
-      const T d0 = GRAMLIKE ? sD0[16 * p + r] : T(0);
+      const T told0 = GRAMLIKE ? tol * sD0[16 * p + r] : T(0);
+      // crossbar byte addresses, formed once: lane (row, group 0); the pivot's group comes in through the instruction's offset field
+      const int a_r = 4 * r;
+      int a_q[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a_q[q] = 4 * ((4 * q + g) & 15);
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
         const int gk = k & 3, qk = k >> 2, src = 16 * gk + k;     // pivot (k, k) lives in lane src, register x[qk]
+        const T xk = x[qk];
         bool skip_l;
-        T piv = x[qk];
-        if (GRAMLIKE) skip_l = (k >= kcount) || !(piv > tol * d0);
-        else { skip_l = k >= kcount; badpiv = badpiv || (lane == src && k < kcount && !(piv > T(0))); piv = piv > T(0) ? piv : Lim<T>::tiny(); }
+        T piv = xk;
+        if (GRAMLIKE) skip_l = (k >= kcount) || !(piv > told0);
+        else { skip_l = k >= kcount; badpiv = badpiv || (lane == src && k < kcount && !(piv > T(0))); piv = clamp_min(piv, Lim<T>::tiny()); }
+        // column k before scaling, L(r, k) = 0 above the diagonal: formed while the reciprocal square root is under way (the
+        // diagonal lane takes the clamped pivot: piv dinv = sqrt(pivot))
+        const T pre = r > k ? xk : (r == k ? piv : T(0));
         const T dinv_l = skip_l ? T(0) : fast_rsqrt(piv);
         const T dinv = wave_bcast(dinv_l, src);
-        const T pv = wave_bcast(piv, src);
         if (GRAMLIKE && k < kcount && dinv == T(0)) ++nskip;
-        // column k of L (valid in the lanes of group gk): L(r, k)
-        const T c_own = (r == k) ? pv * dinv : (r > k ? x[qk] * dinv : T(0));
-        const T vk_own = v[qk] * dinv;
-        if (g == gk) { x[qk] = c_own; v[qk] = vk_own; }
-        // all crossbar reads of the step are issued back to back, then one wait (left to itself the scheduler pairs them with
-        // the FMAs: three ds_bpermute latencies per pivot instead of one; diagonal blocks 100 k -> 94 k cycles in f64, 66 k ->
-        // 64 k in f32)
-        const T c = __shfl(c_own, 16 * gk + r, 64);     // L(r, k) for every group
-        const T vk = __shfl(vk_own, 16 * gk + r, 64);   // v(r, k)
+        // No masks on the updates below -- a multiplier that must not act is a zero: L(r, k) = 0 above the diagonal, hence
+        // L(j, k) = 0 for j < k; column k itself (j = k: register qk of group gk) is updated with garbage and then overwritten
+        // with its finished values.  Entries above the diagonal of the block pick up finite garbage that nothing reads (the
+        // store at the end masks them).
+        const T c_src = pre * dinv;
+        const T vs = v[qk] * dinv;
+        const T c = lane_gather(c_src, a_r + 64 * gk);      // L(r, k) for every group
+        const T vk = lane_gather(vs, a_r + 64 * gk);        // v(r, k)
         T ljk[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          if (4 * q + 3 <= k) continue;                 // compile-time: all of this register's columns are <= k
-          ljk[q] = __shfl(c_own, 16 * gk + ((4 * q + g) & 15), 64);   // L(j, k)
+          if (4 * q + 3 <= k) continue;                     // compile-time: all of this register's columns are <= k
+          ljk[q] = lane_gather(c_src, a_q[q] + 64 * gk);    // L(j, k), j = 4 q + g
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           if (4 * q + 3 <= k) continue;
-          const int j = 4 * q + g;
-          if (j > k) {
-            if (r >= j) x[q] -= c * ljk[q];
-            v[q] -= vk * ljk[q];
-          }
+          x[q] -= c * ljk[q];
+          v[q] -= vk * ljk[q];
         }
+        if (g == gk) { x[qk] = c_src; v[qk] = vs; }
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) { const int j = 4 * q + g; sP[16 * p + r][j] = j <= r ? x[q] : T(0); sM[r][j] = v[q]; }
