@@ -66,10 +66,14 @@ constexpr int CH_SPLIT = 192;   // columns of level A
 // phase timers of the -DMSCKF_ABLATE build: shader-clock cycles of workgroup 0's thread 0 per phase, summed over launches
 // [mode][0 load, 1 panel->LDS, 2 diagonal block, 3 L21, 4 outputs, 5 trailing update, 6 launches]
 __device__ unsigned long long g_chol_cycles[2][8];
+// GAIN, the load phase in detail, per part: [part][0 own S blocks formed, 1 published, 2 rendezvous, 3 siblings' blocks read, 4 rest of the set-up, 5 launches]
+__device__ unsigned long long g_chol_sub[4][8];
+#define CH_SUB(slot) do { if (MODE == CH_GAIN && tid == 0 && bi_ == 0) { const long long t_ = clock64(); atomicAdd(&g_chol_sub[part & 3][slot], (unsigned long long)(t_ - tsub)); tsub = t_; } } while (0)
 __device__ int g_chol_dbg = 0;   // ablation: 1 the other wavefronts skip outputs / trailing update while wavefront 0 factors the next diagonal block (wrong results, timing only)
 #define CH_TICK(slot) do { if (tid == 0) { const long long t_ = clock64(); cyc[slot] += t_ - tlast; tlast = t_; } } while (0)
 #else
 #define CH_TICK(slot) do {} while (0)
+#define CH_SUB(slot) do {} while (0)
 #endif
 
 // NB: 16-column blocks of the factored matrix; NA: appended 16-row blocks held by ONE workgroup (GAIN), 0 for GRAM
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0, int nb) {
   };
   static_assert(GRAMLIKE ? sizeof(T) == 8 : sizeof(T) == sizeof(SO), "the accumulators are loaded without conversion");
 #ifdef MSCKF_ABLATE
-  long long cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+  long long cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64(), tsub = tlast;
 #endif
   // S = T_H (P T_H^T)[15:, :] + sigma^2 I (msckf.h:1369) is formed HERE, straight into the accumulators, instead of being
   // loaded: block (i, j) = sum over the k-blocks kb >= i (T_H is upper triangular) of T(16 i .., k) PHt(15 + k, 16 j ..),
@@ -215,10 +219,15 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0, int nb) {
           }
       }
     }
+  // (Measured and rejected, round 4: the 78 blocks dealt out by cost over the 64 wavefronts of the four parts whatever their
+  // accumulator layout -- no wavefront with more than two passes of six k-blocks, every part equally loaded: forming + publishing
+  // takes the same ~20 k cycles -- 48 KB of operands per pass through one CU's vector memory path and the write-through of the
+  // published blocks, not the number of passes, set it; profiles/r04_o_*.)
   // The product S is MFMA-bound on the one CU a part runs on (11.6 MFLOP against 256 FLOP/cycle: ~46 k cycles when every part
   // forms all of it).  Split: a part forms the blocks s_owner() gives it (the costly block rows -- many k-blocks -- spread over
   // the parts), publishes them in Smat with agent-scope stores (write-through: the siblings may sit on another XCD), the parts
   // of the trajectory meet at a counter barrier, and each reads the blocks it did not form.
+  CH_SUB(0);
   if constexpr (MODE == CH_GAIN) {
     if (d.gain_fused_s >= 2) {
       T* Sg = reinterpret_cast<T*>(Sm);
@@ -237,6 +246,7 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0, int nb) {
         }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's stores have been acknowledged
       __syncthreads();
+      CH_SUB(1);
       // The wait is BOUNDED: nothing guarantees that the siblings are resident (another process or slice may hold the CUs they
       // need while this part holds its own), so after 20 000 polls (agent-scope load + s_sleep: some tens of milliseconds)
       // without them this part forms the missing blocks itself -- the same instruction sequence its sibling would have run, the
@@ -259,6 +269,7 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0, int nb) {
         s_all_here = here;
       }
       __syncthreads();
+      CH_SUB(2);
       const bool all_here = s_all_here != 0;
 #pragma unroll
       for (int ii = 0; ii < HR; ++ii)
@@ -276,6 +287,10 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0, int nb) {
         }
     }
   }
+#ifdef MSCKF_ABLATE
+  if (MODE == CH_GAIN) { __builtin_amdgcn_s_waitcnt(0); }
+#endif
+  CH_SUB(3);
 #pragma unroll
   for (int ii = 0; ii < HR; ++ii)
 #pragma unroll
@@ -563,6 +578,7 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0, int nb) {
     }
   };
   __syncthreads();
+  CH_SUB(4);
   CH_TICK(0);
   if (n > 0) {
     drop(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -605,6 +621,7 @@ __global__ __launch_bounds__(1024) void k_chol_mfma(Dev<SO> d, int b0, int nb) {
     for (int q = 0; q < 6; ++q) atomicAdd(&g_chol_cycles[MODE == CH_GAIN ? 1 : 0][q], (unsigned long long)cyc[q]);
     atomicAdd(&g_chol_cycles[MODE == CH_GAIN ? 1 : 0][6], 1ull);
   }
+  if (MODE == CH_GAIN && tid == 0 && bi_ == 0) atomicAdd(&g_chol_sub[part & 3][5], 1ull);
 #endif
   if (!GRAMLIKE && w == 0 && __any(badpiv ? 1 : 0) && lane == 0) atomicOr(&st[STAT_ERR], STAT_ERR_PIVOT);
   if (MODE == CH_GRAM || MODE == CH_GRAM_A) { if (tid == 0) st[STAT_RROWS] = nfull - nskip; }
@@ -793,6 +810,10 @@ bool launch_chol_gain(const Dev<float>& d, int b0, int nb, hipStream_t st) {
 
 #ifdef MSCKF_ABLATE
 void chol_debug_set(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chol_dbg), &v, sizeof(int)); }
+void chol_sub_read(unsigned long long* out32, int reset) {
+  (void)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_chol_sub), sizeof(unsigned long long) * 32);
+  if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chol_sub), z, sizeof(z)); }
+}
 void chol_cycles_read(unsigned long long* out16, int reset) {
   (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_chol_cycles), sizeof(unsigned long long) * 16);
   if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chol_cycles), z, sizeof(z)); }

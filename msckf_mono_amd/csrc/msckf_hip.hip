@@ -1700,7 +1700,7 @@ BatchBase* H(msckf_hip_handle h) { return reinterpret_cast<BatchBase*>(h); }
 }  // namespace
 
 #ifdef MSCKF_ABLATE
-namespace msckf { void qr_debug_set(int idx, int val); void feat_debug_set(int val); extern int g_gram_dbg; void chol_cycles_read(unsigned long long* out16, int reset); void chol_debug_set(int v); void prop_cycles_read(unsigned long long* out8, int reset); void gram_cycles_read(unsigned long long* out40, int reset); void gemm_cycles_read(unsigned long long* out16, int reset); void gemm_trace_read(unsigned long long* out); }
+namespace msckf { void qr_debug_set(int idx, int val); void feat_debug_set(int val); extern int g_gram_dbg; void chol_cycles_read(unsigned long long* out16, int reset); void chol_sub_read(unsigned long long* out32, int reset); void chol_debug_set(int v); void prop_cycles_read(unsigned long long* out8, int reset); void gram_cycles_read(unsigned long long* out40, int reset); void gemm_cycles_read(unsigned long long* out16, int reset); void gemm_trace_read(unsigned long long* out); }
 #endif
 
 extern "C" {
@@ -1714,6 +1714,7 @@ void msckf_hip_debug_set(int idx, int val) {
   msckf::qr_debug_set(idx, val);
 }
 void msckf_hip_debug_chol_cycles(unsigned long long* out16, int reset) { msckf::chol_cycles_read(out16, reset); }
+void msckf_hip_debug_chol_sub(unsigned long long* out32, int reset) { msckf::chol_sub_read(out32, reset); }
 void msckf_hip_debug_prop_cycles(unsigned long long* out8, int reset) { msckf::prop_cycles_read(out8, reset); }
 void msckf_hip_debug_gram_cycles(unsigned long long* out40, int reset) { msckf::gram_cycles_read(out40, reset); }
 void msckf_hip_debug_gemm_cycles(unsigned long long* out16, int reset) { msckf::gemm_cycles_read(out16, reset); }

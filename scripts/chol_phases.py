@@ -33,6 +33,8 @@ g40 = (C.c_ulonglong * 40)()
 bt.L.msckf_hip_debug_gram_cycles(g40, 1)
 m16 = (C.c_ulonglong * 16)()
 bt.L.msckf_hip_debug_gemm_cycles(m16, 1)
+if hasattr(bt.L, "msckf_hip_debug_chol_sub"):
+    bt.L.msckf_hip_debug_chol_sub((C.c_ulonglong * 32)(), 1)
 bt.run_frames(32, nf); bt.sync()
 bt.L.msckf_hip_debug_chol_cycles(out, 1)
 names = ["load", "panel->LDS", "diag block", "L21", "outputs", "trailing"]
@@ -40,6 +42,13 @@ for m, nm in enumerate(("GRAM f64", "GAIN f32")):
     v = np.array(out[8 * m:8 * m + 8], dtype=np.float64)
     n = max(v[6], 1)
     print(nm, "launches", int(v[6]), {a: int(c / n) for a, c in zip(names, v[:6])}, "total cycles/launch", int(v[:6].sum() / n))
+sub = (C.c_ulonglong * 32)()
+if hasattr(bt.L, "msckf_hip_debug_chol_sub"):
+    bt.L.msckf_hip_debug_chol_sub(sub, 1)
+    sv = np.array(sub, dtype=np.float64).reshape(4, 8)
+    for part in range(4):
+        if sv[part, 5] > 0:
+            print("GAIN load phase, part", part, {a: int(c / sv[part, 5]) for a, c in zip(["own S blocks", "publish", "rendezvous", "read siblings", "masks + rest"], sv[part, :5])})
 bt.L.msckf_hip_debug_prop_cycles(po8, 1)
 v = np.array(po8, dtype=np.float64); n = max(v[5], 1)
 print("k_propagate launches", int(v[5]), {a: int(c / n) for a, c in zip(["load", "state chain", "Phi series", "P_II/Phi_tot chains", "write back + P_IC"], v[:5])}, "total", int(v[:5].sum() / n))
