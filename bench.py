@@ -203,8 +203,8 @@ def self_launch_if_needed(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)     # the driver's invocation: --steps 20 --warmup 5
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg3")
     ap.add_argument("--trajectories", type=int, default=0, help="trajectories per GPU (default: the configuration's)")
     ap.add_argument("--repeats", type=int, default=-1, help="timed K-step windows in all (default: until >= 0.5 s of timed region, 3..12)")
