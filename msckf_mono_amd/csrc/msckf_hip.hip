@@ -213,6 +213,7 @@ struct Batch : BatchBase {
   int overlap_feature = 0;   // measured on MI355X at cfg3: 100 k -> 82 k updates/s with the overlap on (k_feature floods the CUs the
                              // latency-bound propagate/augment workgroups need); kept selectable, off by default
   int compress_route = -1;   // -1 default, 0 Householder TSQR, != 0 information form + blocked matrix-core Cholesky
+  int test_fail_upload = -1;  // test hook (MSCKF_HIP_TEST_FAIL_UPLOAD): run_frames_streamed pretends that this frame's copy failed
   // anisotropic pixel noise (u_var' != v_var'): 0 = the reference's construction R_o_j = A_j^T R_j A_j, R_n = Q_1^T R_o Q_1 on
   // the device (kernels_literal.hip; default), 1 = rows pre-whitened by 1/sigma (generalized least squares, unit noise)
   int aniso_mode = 0;
@@ -310,6 +311,7 @@ struct Batch : BatchBase {
     rc |= dalloc(&d.imu, Bz * IMU_STRIDE); rc |= dalloc(&d.cam, Bz * n_cap * CAM_STRIDE); rc |= dalloc(&d.prm, Bz * PRM_STRIDE);
     rc |= dalloc(&d.P, Bz * pl); rc |= dalloc(&P_spare, Bz * pl); d.Pout = nullptr; d.fuse_drop = nullptr; d.ncam_defer = 0;
     if (const char* e = getenv("MSCKF_HIP_FUSE_PRUNE")) fuse_prune = atoi(e) != 0;
+    if (const char* e = getenv("MSCKF_HIP_TEST_FAIL_UPLOAD")) test_fail_upload = atoi(e);   // test hook: the upload of this frame fails
     if (const char* e = getenv("MSCKF_HIP_LITERAL_ROUTE")) lit_route = atoi(e);   // A/B runs and tests: 1 = the sweep over the dense stack
     rc |= dalloc(&d.ncam, Bz); rc |= dalloc(&d.n_resid, Bz);
     rc |= dalloc(&d.trk_status, TF); rc |= dalloc(&d.trk_pf, TF * 4); rc |= dalloc(&d.trk_gamma, TF);
@@ -1393,7 +1395,7 @@ int Batch<S>::run_frames_streamed(int f0, int f1) {
         const hipError_t e = mode == 0 ? hipEventSynchronize(ev_use[k][i]) : hipStreamWaitEvent(stc, ev_use[k][i], 0);
         if (e != hipSuccess) rc_up = -EIO;
       }
-    if (!rc_up && hipMemcpyAsync(sg_blk[k], pinf[f].p, pinf[f].bytes, hipMemcpyHostToDevice, stc) != hipSuccess) rc_up = -EIO;
+    if (!rc_up && (f == test_fail_upload || hipMemcpyAsync(sg_blk[k], pinf[f].p, pinf[f].bytes, hipMemcpyHostToDevice, stc) != hipSuccess)) rc_up = -EIO;
     if (!rc_up && (mode == 0 ? hipStreamSynchronize(stc) : hipEventRecord(ev_up[k], stc)) != hipSuccess) rc_up = -EIO;
     if (rc_up) failed.store(1);
     up_rdy.store(f + 1, std::memory_order_release);

@@ -366,3 +366,38 @@ def test_low_parallax_double_both_routes_vs_oracle(capi, po):
         if len(tw.cam_array()) == N:
             tw.drop_oldest(1)
     assert conds and max(conds) > 5e3, conds
+
+
+def test_failed_streamed_run_makes_the_handle_unusable(capi, monkeypatch):
+    """A run_frames_streamed call that fails after some of its frames were enqueued (here: the copy of frame 11 is made to
+    fail, msckf_mono_amd/csrc/msckf_hip.hip: MSCKF_HIP_TEST_FAIL_UPLOAD) leaves the slices at different frames -- which
+    covariance buffer is current differs per slice.  The call returns -EIO, and so does everything that would read or advance
+    the filters afterwards; a fresh handle is unaffected.  Also: a scenario patched and re-committed several times streams
+    from re-pinned blocks (the page-locked chunks are released with the last of their frames)."""
+    N, F, nf, B = 8, 24, 16, 2
+    trajs = [sc.Trajectory(2, 30 + b, N, F, nf) for b in range(B)]
+    monkeypatch.setenv("MSCKF_HIP_TEST_FAIL_UPLOAD", "11")
+    bad = _resident_batch(capi, trajs, N, F, nf, N, capi.F32, streams=2)
+    monkeypatch.delenv("MSCKF_HIP_TEST_FAIL_UPLOAD")
+    bad.run_frames(0, 8); bad.sync()
+    with pytest.raises(capi.HipError, match=r"\(-5\).*undefined"):
+        bad.run_frames_streamed(8, 14)
+    for call in (lambda: bad.imu_state(0), lambda: bad.covariance(1), lambda: bad.run_frames(14, 15), lambda: bad.run_frames_streamed(14, 15)):
+        with pytest.raises(capi.HipError, match=r"\(-5\).*unusable"):
+            call()
+    bad.close()
+    good = _resident_batch(capi, trajs, N, F, nf, N, capi.F32, streams=2)
+    ref = _resident_batch(capi, trajs, N, F, nf, N, capi.F32, streams=2)
+    ref.run_frames(0, nf); ref.sync()
+    good.run_frames(0, 8)
+    for rnd in range(3):                      # patch a frame that was already pinned (same contents), commit, stream on
+        good.run_frames_streamed(8 + 2 * rnd, 10 + 2 * rnd)
+        for k in (8 + 2 * rnd, 9 + 2 * rnd, 14):      # the two frames of the block just streamed (-> its chunk is released) and one ahead
+            for b, tr in enumerate(trajs):
+                fr = tr.frames[k]
+                good.scenario_set(k, b, tr.imu_for_frame(k), fr["M"], fr["slots"], fr["obs"], 1 if fr["Nw"] == N else 0)
+        good.scenario_commit()
+    good.run_frames_streamed(14, nf); good.sync()
+    for b in range(B):
+        assert np.array_equal(good.imu_state(b), ref.imu_state(b)) and np.array_equal(good.covariance(b), ref.covariance(b))
+    good.close(); ref.close()
