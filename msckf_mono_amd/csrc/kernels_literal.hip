@@ -25,7 +25,7 @@ __global__ __launch_bounds__(1024) void k_literal(Dev<S> d, int b0, int nb) {
   if (prm[PRM_LIT] == S(0)) return;                          // isotropic (or pre-whitened) trajectory: k_gram's Lam^ stands
   int* st = d.stats + (long)b * STAT_STRIDE;
   if (st[STAT_MROWS] == 0) return;
-  __shared__ double red[20];
+  __shared__ double red[40];                                 // two reductions at a time (literal_core.h: wg_sum2): 2 x 16 wavefronts
   extern __shared__ double lit_lds[];
   lit::Ctx c;
   c.tid = threadIdx.x; c.nt = blockDim.x; c.lane = threadIdx.x & 63; c.wave = threadIdx.x >> 6; c.nw = blockDim.x >> 6; c.red = red; c.tim = d.lit.tim ? d.lit.tim + (long)b * 16 : nullptr; c.lds = lit_lds; c.lds_doubles = LIT_LDS_DOUBLES;

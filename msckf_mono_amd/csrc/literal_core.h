@@ -42,15 +42,27 @@ namespace lit {
 
 #ifdef LIT_HOST
 #define LIT_FN inline
-struct Ctx { int tid = 0, nt = 1, lane = 0, wave = 0, nw = 1; double* red = nullptr; };
+struct Ctx { int tid = 0, nt = 1, lane = 0, wave = 0, nw = 1; double* red = nullptr; double* lds = nullptr; int lds_doubles = 0; };   // lds: the device's staging area, a heap block here
 LIT_FN void barrier(const Ctx&) {}
 template <class F> LIT_FN void par_for(const Ctx&, long n, F f) { for (long i = 0; i < n; ++i) f(i); }
 template <class F> LIT_FN double wg_sum(const Ctx&, long lo, long hi, F f) { double s = 0; for (long i = lo; i < hi; ++i) s += f(i); return s; }
 template <class F> LIT_FN double wg_max(const Ctx&, long lo, long hi, F f) { double s = 0; for (long i = lo; i < hi; ++i) { const double v = f(i); s = v > s ? v : s; } return s; }
+// two sums over one range in one reduction: f(i, a, b) adds item i's contributions to a and b
+template <class F> LIT_FN void wg_sum2(const Ctx&, long lo, long hi, double& sa, double& sb, F f) { sa = 0; sb = 0; for (long i = lo; i < hi; ++i) f(i, sa, sb); }
 // wave_for: item j is handled by one whole wavefront; inside, lane_for / wave_sum spread a row range over its lanes
 template <class F> LIT_FN void wave_for(const Ctx&, long lo, long hi, F f) { for (long j = lo; j < hi; ++j) f(j); }
 template <class F> LIT_FN void lane_for(const Ctx&, long lo, long hi, F f) { for (long i = lo; i < hi; ++i) f(i); }
 template <class F> LIT_FN double wave_sum_range(const Ctx&, long lo, long hi, F f) { double s = 0; for (long i = lo; i < hi; ++i) s += f(i); return s; }
+// row_for: item j is handled by one ROW of a wavefront (16 lanes; four items per wavefront at a time); inside, rowlane_for /
+// row_sum_range spread a range over the row's lanes
+template <class F> LIT_FN void row_for(const Ctx&, long lo, long hi, F f) { for (long j = lo; j < hi; ++j) f(j); }
+template <class F> LIT_FN void rowlane_for(const Ctx&, long lo, long hi, F f) { for (long i = lo; i < hi; ++i) f(i); }
+template <class F> LIT_FN double row_sum_range(const Ctx&, long lo, long hi, F f) { double s = 0; for (long i = lo; i < hi; ++i) s += f(i); return s; }
+LIT_FN bool first_rowlane(const Ctx&) { return true; }
+// rowlane_update: x(i) <- upd(i) over a range, where upd reads what it needs of item i (the device version reads four items
+// before it writes the first: a store followed by the next item's loads is a full memory round trip when the compiler cannot
+// rule out that they alias)
+template <class FU, class FS> LIT_FN void rowlane_update(const Ctx&, long lo, long hi, FU upd, FS st) { for (long i = lo; i < hi; ++i) st(i, upd(i)); }
 // NV sums over a row range at once: f(i, v) adds row i's contribution to v[0..NV)
 template <int NV, class F> LIT_FN void wave_sum_vec(const Ctx&, long lo, long hi, double (&out)[NV], F f) {
   for (int k = 0; k < NV; ++k) out[k] = 0;
@@ -76,6 +88,9 @@ template <class ST> LIT_FN void atb(const Ctx&, const double* A, long lda, int m
 }
 LIT_FN bool first_lane(const Ctx&) { return true; }
 LIT_FN bool first_thread(const Ctx&) { return true; }
+template <class ST> LIT_FN void atb_lower(const Ctx& c, const double* A, long lda, int ma, const double* B, long ldb, int kd, ST st) {
+  atb(c, A, lda, ma, B, ldb, ma, kd, [&](int i, int j, double v) { if (i >= j) st(i, j, v); });
+}
 LIT_FN void tick(const Ctx&, int) {}
 #else
 #define LIT_FN __device__ __forceinline__
@@ -92,6 +107,16 @@ template <class F> LIT_FN double wg_sum(const Ctx& c, long lo, long hi, F f) {
   double t = 0;
   for (int w = 0; w < c.nw; ++w) t += c.red[w];   // same order in every thread: a uniform value
   return t;
+}
+template <class F> LIT_FN void wg_sum2(const Ctx& c, long lo, long hi, double& sa, double& sb, F f) {
+  double a = 0, b = 0;
+  for (long i = lo + c.tid; i < hi; i += c.nt) f(i, a, b);
+  a = wave_sum(a); b = wave_sum(b);
+  __syncthreads();                       // red may still be read from the previous reduction
+  if (c.lane == 0) { c.red[c.wave] = a; c.red[c.nw + c.wave] = b; }
+  __syncthreads();
+  sa = 0; sb = 0;
+  for (int w = 0; w < c.nw; ++w) { sa += c.red[w]; sb += c.red[c.nw + w]; }
 }
 template <class F> LIT_FN double wg_max(const Ctx& c, long lo, long hi, F f) {
   double s = 0;
@@ -111,6 +136,29 @@ template <class F> LIT_FN double wave_sum_range(const Ctx& c, long lo, long hi, 
   for (long i = lo + c.lane; i < hi; i += 64) s += f(i);
   return wave_sum(s);
 }
+// A column per ROW of a wavefront (16 lanes) instead of per wavefront: four columns of a wavefront have their loads in flight
+// together, and a workgroup walks 64 columns at a time -- the per-column steps (dot product -> update) are chains of dependent
+// global round trips, and a wavefront that takes its columns one after the other pays every one of them (sweep: 5.1 -> ms,
+// columns of Q: 3.3 -> ms at a 30-camera window)
+template <class F> LIT_FN void row_for(const Ctx& c, long lo, long hi, F f) { for (long j = lo + 4 * c.wave + (c.lane >> 4); j < hi; j += 4 * c.nw) f(j); }
+template <class F> LIT_FN void rowlane_for(const Ctx& c, long lo, long hi, F f) { for (long i = lo + (c.lane & 15); i < hi; i += 16) f(i); }
+template <class F> LIT_FN double row_sum_range(const Ctx& c, long lo, long hi, F f) {
+  double s = 0;
+  for (long i = lo + (c.lane & 15); i < hi; i += 16) s += f(i);
+  // the four DPP steps inside a row of 16 lanes: every lane of the row ends up with the row's sum (dev_common.h: wave_sum's first half)
+  s += dpp_x<DPP_QUAD_X1>(s); s += dpp_x<DPP_QUAD_X2>(s); s += dpp_x<DPP_HALF_MIRROR>(s); s += dpp_x<DPP_ROW_MIRROR>(s);
+  return s;
+}
+LIT_FN bool first_rowlane(const Ctx& c) { return (c.lane & 15) == 0; }
+template <class FU, class FS> LIT_FN void rowlane_update(const Ctx& c, long lo, long hi, FU upd, FS st) {
+  for (long i0 = lo + (c.lane & 15); i0 < hi; i0 += 64) {
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const long i = i0 + 16 * u; v[u] = i < hi ? upd(i) : 0.0; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const long i = i0 + 16 * u; if (i < hi) st(i, v[u]); }
+  }
+}
 template <int NV, class F> LIT_FN void wave_sum_vec(const Ctx& c, long lo, long hi, double (&out)[NV], F f) {
   double v[NV];
 #pragma unroll
@@ -123,51 +171,68 @@ template <int NV, class F> LIT_FN void wave_sum_vec(const Ctx& c, long lo, long 
 // one 4 x 4 tile of the lower triangle (a second pass takes the tiles beyond the thread count) and keeps its sixteen sums in
 // registers across the chunks.  (One wavefront per tile with lanes along the rows re-read eight columns per tile: 220 MB per
 // trajectory at a 30-camera window, and at 128 trajectories per launch the step was bound by that traffic.)
-template <class ST> LIT_FN void syrk_lower(const Ctx& c, const double* G, long ldg, int nr, int mobs, ST st) {
-  const int ntile = (nr + 3) / 4, ntl = ntile * (ntile + 1) / 2, ldl = nr | 1;
+template <int TS, class ST> LIT_FN void syrk_lower_ts(const Ctx& c, const double* G, long ldg, int nr, int mobs, ST st) {
+  const int ntile = (nr + TS - 1) / TS, ntl = ntile * (ntile + 1) / 2, ldl = nr | 1;
   const int rows = c.lds_doubles / ldl;          // rows of G per chunk
   for (int e0 = 0; e0 < ntl; e0 += c.nt) {
     const int e = e0 + c.tid;
     int ti = 0, tj = 0;
     if (e < ntl) { ti = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5); while (ti * (ti + 1) / 2 > e) --ti; while ((ti + 1) * (ti + 2) / 2 <= e) ++ti; tj = e - ti * (ti + 1) / 2; }
-    double acc[16];
+    double acc[TS * TS];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k] = 0;
+    for (int k = 0; k < TS * TS; ++k) acc[k] = 0;
     for (int o0 = 0; o0 < mobs; o0 += rows) {
       const int nrow = mobs - o0 < rows ? mobs - o0 : rows;
       __syncthreads();
       for (long x = c.tid; x < (long)nrow * nr; x += c.nt) { const int k = (int)(x / nrow), o = (int)(x - (long)k * nrow); c.lds[o * ldl + k] = G[o0 + o + ldg * k]; }
       __syncthreads();
       if (e < ntl) {
-        const double* li = c.lds + 4 * ti; const double* lj = c.lds + 4 * tj;
-        const int i3 = 4 * ti + 3 < nr ? 3 : nr - 1 - 4 * ti, j3 = 4 * tj + 3 < nr ? 3 : nr - 1 - 4 * tj;   // clamp inside the matrix (edge tiles)
+        const double* li = c.lds + TS * ti; const double* lj = c.lds + TS * tj;
+        int io[TS], jo[TS];                       // offsets clamped inside the matrix (edge tiles)
+#pragma unroll
+        for (int q = 0; q < TS; ++q) { io[q] = TS * ti + q < nr ? q : nr - 1 - TS * ti; jo[q] = TS * tj + q < nr ? q : nr - 1 - TS * tj; }
         for (int o = 0; o < nrow; ++o) {
           const double* ri = li + o * ldl; const double* rj = lj + o * ldl;
-          const double x0 = ri[0], x1 = ri[i3 < 1 ? i3 : 1], x2 = ri[i3 < 2 ? i3 : 2], x3 = ri[i3];
-          const double y0 = rj[0], y1 = rj[j3 < 1 ? j3 : 1], y2 = rj[j3 < 2 ? j3 : 2], y3 = rj[j3];
-          acc[0] += x0 * y0; acc[1] += x0 * y1; acc[2] += x0 * y2; acc[3] += x0 * y3;
-          acc[4] += x1 * y0; acc[5] += x1 * y1; acc[6] += x1 * y2; acc[7] += x1 * y3;
-          acc[8] += x2 * y0; acc[9] += x2 * y1; acc[10] += x2 * y2; acc[11] += x2 * y3;
-          acc[12] += x3 * y0; acc[13] += x3 * y1; acc[14] += x3 * y2; acc[15] += x3 * y3;
+          double xv[TS], yv[TS];
+#pragma unroll
+          for (int q = 0; q < TS; ++q) { xv[q] = ri[io[q]]; yv[q] = rj[jo[q]]; }
+#pragma unroll
+          for (int qi = 0; qi < TS; ++qi)
+#pragma unroll
+            for (int qj = 0; qj < TS; ++qj) acc[qi * TS + qj] += xv[qi] * yv[qj];
         }
       }
     }
     if (e < ntl)
-      for (int qi = 0; qi < 4; ++qi)
-        for (int qj = 0; qj < 4; ++qj) { const int i = 4 * ti + qi, j = 4 * tj + qj; if (i < nr && j <= i) st(i, j, acc[qi * 4 + qj]); }
+#pragma unroll
+      for (int qi = 0; qi < TS; ++qi)
+#pragma unroll
+        for (int qj = 0; qj < TS; ++qj) { const int i = TS * ti + qi, j = TS * tj + qj; if (i < nr && j <= i) st(i, j, acc[qi * TS + qj]); }
   }
   __syncthreads();
 }
+// 4 x 4 tiles per thread; 5 x 5 when the 4 x 4 tiles outnumber the threads (a second pass re-stages the whole of G: the Gram
+// matrix of 180 columns is 1 035 tiles for 1 024 threads)
+template <class ST> LIT_FN void syrk_lower(const Ctx& c, const double* G, long ldg, int nr, int mobs, ST st) {
+  const int nt4 = (nr + 3) / 4;
+  if (nt4 * (nt4 + 1) / 2 <= c.nt) syrk_lower_ts<4>(c, G, ldg, nr, mobs, st);
+  else syrk_lower_ts<5>(c, G, ldg, nr, mobs, st);
+}
 // A^T B with chunks of the contraction index staged in LDS ([row][column of A | column of B]), one 4 x 4 tile of the result
 // per thread and pass (the operands are read from global memory once per pass)
-template <class ST> LIT_FN void atb(const Ctx& c, const double* A, long lda, int ma, const double* B, long ldb, int nb, int kd, ST st) {
-  const int ta = (ma + 3) / 4, tb = (nb + 3) / 4, ntl = ta * tb, ldl = (ma + nb) | 1;
+template <int TS, bool LOWER, class ST> LIT_FN void atb_ts(const Ctx& c, const double* A, long lda, int ma, const double* B, long ldb, int nb, int kd, ST st) {
+  const int ta = (ma + TS - 1) / TS, tb = (nb + TS - 1) / TS, ntl = LOWER ? ta * (ta + 1) / 2 : ta * tb, ldl = (ma + nb) | 1;
   const int rows = c.lds_doubles / ldl;
   for (int e0 = 0; e0 < ntl; e0 += c.nt) {
-    const int e = e0 + c.tid, ti = e < ntl ? e % ta : 0, tj = e < ntl ? e / ta : 0;
-    double acc[16];
+    const int e = e0 + c.tid;
+    int ti = 0, tj = 0;
+    if (e < ntl) {
+      if (LOWER) { ti = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5); while (ti * (ti + 1) / 2 > e) --ti; while ((ti + 1) * (ti + 2) / 2 <= e) ++ti; tj = e - ti * (ti + 1) / 2; }
+      else { ti = e % ta; tj = e / ta; }
+    }
+    double acc[TS * TS];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k] = 0;
+    for (int k = 0; k < TS * TS; ++k) acc[k] = 0;
     for (int l0 = 0; l0 < kd; l0 += rows) {
       const int nrow = kd - l0 < rows ? kd - l0 : rows;
       __syncthreads();
@@ -175,24 +240,41 @@ template <class ST> LIT_FN void atb(const Ctx& c, const double* A, long lda, int
       for (long x = c.tid; x < (long)nrow * nb; x += c.nt) { const int k = (int)(x / nrow), l = (int)(x - (long)k * nrow); c.lds[l * ldl + ma + k] = B[l0 + l + ldb * k]; }
       __syncthreads();
       if (e < ntl) {
-        const double* li = c.lds + 4 * ti; const double* lj = c.lds + ma + 4 * tj;
-        const int i3 = 4 * ti + 3 < ma ? 3 : ma - 1 - 4 * ti, j3 = 4 * tj + 3 < nb ? 3 : nb - 1 - 4 * tj;
+        const double* li = c.lds + TS * ti; const double* lj = c.lds + ma + TS * tj;
+        int io[TS], jo[TS];                       // offsets clamped inside the matrices (edge tiles)
+#pragma unroll
+        for (int q = 0; q < TS; ++q) { io[q] = TS * ti + q < ma ? q : ma - 1 - TS * ti; jo[q] = TS * tj + q < nb ? q : nb - 1 - TS * tj; }
         for (int l = 0; l < nrow; ++l) {
           const double* ri = li + l * ldl; const double* rj = lj + l * ldl;
-          const double x0 = ri[0], x1 = ri[i3 < 1 ? i3 : 1], x2 = ri[i3 < 2 ? i3 : 2], x3 = ri[i3];
-          const double y0 = rj[0], y1 = rj[j3 < 1 ? j3 : 1], y2 = rj[j3 < 2 ? j3 : 2], y3 = rj[j3];
-          acc[0] += x0 * y0; acc[1] += x0 * y1; acc[2] += x0 * y2; acc[3] += x0 * y3;
-          acc[4] += x1 * y0; acc[5] += x1 * y1; acc[6] += x1 * y2; acc[7] += x1 * y3;
-          acc[8] += x2 * y0; acc[9] += x2 * y1; acc[10] += x2 * y2; acc[11] += x2 * y3;
-          acc[12] += x3 * y0; acc[13] += x3 * y1; acc[14] += x3 * y2; acc[15] += x3 * y3;
+          double xv[TS], yv[TS];
+#pragma unroll
+          for (int q = 0; q < TS; ++q) { xv[q] = ri[io[q]]; yv[q] = rj[jo[q]]; }
+#pragma unroll
+          for (int qi = 0; qi < TS; ++qi)
+#pragma unroll
+            for (int qj = 0; qj < TS; ++qj) acc[qi * TS + qj] += xv[qi] * yv[qj];
         }
       }
     }
     if (e < ntl)
-      for (int qi = 0; qi < 4; ++qi)
-        for (int qj = 0; qj < 4; ++qj) { const int i = 4 * ti + qi, j = 4 * tj + qj; if (i < ma && j < nb) st(i, j, acc[qi * 4 + qj]); }
+#pragma unroll
+      for (int qi = 0; qi < TS; ++qi)
+#pragma unroll
+        for (int qj = 0; qj < TS; ++qj) { const int i = TS * ti + qi, j = TS * tj + qj; if (i < ma && j < nb && (!LOWER || i >= j)) st(i, j, acc[qi * TS + qj]); }
   }
   __syncthreads();
+}
+// 4 x 4 tiles per thread, 5 x 5 when that saves a pass over the operands (every pass re-stages A and B); atb_lower: only the
+// entries (i, j), i >= j, of a square result (half the tiles)
+template <class ST> LIT_FN void atb(const Ctx& c, const double* A, long lda, int ma, const double* B, long ldb, int nb, int kd, ST st) {
+  const int t4 = ((ma + 3) / 4) * ((nb + 3) / 4), t5 = ((ma + 4) / 5) * ((nb + 4) / 5);
+  if ((t4 + c.nt - 1) / c.nt <= (t5 + c.nt - 1) / c.nt) atb_ts<4, false>(c, A, lda, ma, B, ldb, nb, kd, st);
+  else atb_ts<5, false>(c, A, lda, ma, B, ldb, nb, kd, st);
+}
+template <class ST> LIT_FN void atb_lower(const Ctx& c, const double* A, long lda, int ma, const double* B, long ldb, int kd, ST st) {
+  const int a4 = (ma + 3) / 4, a5 = (ma + 4) / 5, t4 = a4 * (a4 + 1) / 2, t5 = a5 * (a5 + 1) / 2;
+  if ((t4 + c.nt - 1) / c.nt <= (t5 + c.nt - 1) / c.nt) atb_ts<4, true>(c, A, lda, ma, B, ldb, ma, kd, st);
+  else atb_ts<5, true>(c, A, lda, ma, B, ldb, ma, kd, st);
 }
 LIT_FN bool first_lane(const Ctx& c) { return c.lane == 0; }
 LIT_FN bool first_thread(const Ctx& c) { return c.tid == 0; }
@@ -323,18 +405,64 @@ LIT_FN void information_from_rn(const Ctx& c, const Args<HT>& a, int n, int nr) 
   });
   barrier(c);
   tick(c, 10);
-  for (int k = 0; k < nr; ++k) {
-    const double dk = Z[k + ldz * k];
-    const double dinv = 1.0 / dk;
-    // one wavefront per trailing column j, lanes along its rows i >= j: Z(i, j) -= Z(i, k) Z(j, k) / d
-    const double* zk = Z + ldz * k;
-    wave_for(c, k + 1, nz, [&](long j) {
-      const double ljk = zk[j] * dinv;
-      if (ljk == 0.0) return;
-      double* zj = Z + ldz * j;
-      lane_for(c, j, nz, [&](long i) { zj[i] -= zk[i] * ljk; });
-    });
-    barrier(c);
+  // Elimination of the nr pivots, Z(i, j) -= Z(i, k) (Z(j, k) / d_k) for i >= j > k, in panels of PB pivots: the panel's columns
+  // (rows k0 .., all that is left of them) are staged in LDS and eliminated against each other there, then ONE pass over the
+  // trailing triangle in global memory applies the panel's PB updates to every element, in pivot order -- the same operands,
+  // the same operations in the same order as pivot by pivot (which took a barrier and ~20 dependent global round trips per pivot:
+  // 3.4 ms of 182 pivots on a 363-square matrix; this form: 12 passes).  The eliminated columns are not written back (only the
+  // trailing block is read afterwards).
+  {
+    int PB = 16;
+    while (PB > 1 && (long)(nz + 1) * PB + PB > c.lds_doubles) PB >>= 1;
+    double* sD = c.lds;                                   // [PB] 1 / d_k of the panel's pivots
+    double* sP = c.lds + PB;                              // [rows k0 .. nz)[PB], row-major with PB + (PB < 16 ? 0 : 1) padding
+    const int ldp = PB + (PB >= 16 ? 1 : 0);
+    if ((long)(nz + 1) * ldp + PB > c.lds_doubles) PB = 0;   // (cannot happen with the sizes the callers allocate: fall back below)
+    for (int k0 = 0; PB > 0 && k0 < nr; k0 += PB) {
+      const int pb = nr - k0 < PB ? nr - k0 : PB, mrow = nz - k0;
+      // stage: element (k0 + i, k0 + cc); inside the panel's diagonal block the upper half is filled from the mirror image
+      par_for(c, (long)mrow * pb, [&](long e) {
+        const int cc = (int)(e / mrow), i = (int)(e - (long)cc * mrow);
+        sP[(long)i * ldp + cc] = i >= cc ? Z[(k0 + i) + ldz * (k0 + cc)] : Z[(k0 + cc) + ldz * (k0 + i)];
+      });
+      barrier(c);
+      for (int cc = 0; cc < pb; ++cc) {
+        // column cc against the panel's later columns: rows i >= c2 of column c2 > cc
+        const double dinv = 1.0 / sP[(long)cc * ldp + cc];
+        if (first_thread(c)) sD[cc] = dinv;
+        const int nc = pb - 1 - cc;
+        par_for(c, (long)mrow * nc, [&](long e) {
+          const int q = (int)(e / mrow), i = (int)(e - (long)q * mrow), c2 = cc + 1 + q;
+          if (i < c2) return;
+          const double ljk = sP[(long)c2 * ldp + cc] * dinv;
+          sP[(long)i * ldp + c2] -= sP[(long)i * ldp + cc] * ljk;
+        });
+        barrier(c);
+      }
+      // trailing triangle: columns j >= k0 + pb, rows i >= j (a rectangle of indices, the upper half skipped)
+      const int j0 = k0 + pb, mt = nz - j0;
+      par_for(c, (long)mt * mt, [&](long e) {
+        const int jj = (int)(e / mt), ii = (int)(e - (long)jj * mt);
+        if (ii < jj) return;
+        const double* pi = sP + (long)(pb + ii) * ldp; const double* pj = sP + (long)(pb + jj) * ldp;
+        double z = Z[(j0 + ii) + ldz * (j0 + jj)];
+        for (int cc = 0; cc < pb; ++cc) z -= pi[cc] * (pj[cc] * sD[cc]);
+        Z[(j0 + ii) + ldz * (j0 + jj)] = z;
+      });
+      barrier(c);
+    }
+    if (PB == 0)
+      for (int k = 0; k < nr; ++k) {
+        const double dinv = 1.0 / Z[k + ldz * k];
+        const double* zk = Z + ldz * k;
+        wave_for(c, k + 1, nz, [&](long j) {
+          const double ljk = zk[j] * dinv;
+          if (ljk == 0.0) return;
+          double* zj = Z + ldz * j;
+          lane_for(c, j, nz, [&](long i) { zj[i] -= zk[i] * ljk; });
+        });
+        barrier(c);
+      }
   }
   tick(c, 11);
   // ---- Lam^ (lower triangle incl. row n) where the blocked Cholesky reads it
@@ -636,19 +764,15 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
   barrier(c);
   tick(c, 2);
   // ---- Gb = [H_o | r_o]^T [H_o | r_o] - E^T E (zero when every row is explicit), Y = I
-  par_for(c, (long)n1 * n1, [&](long x) {
-    const int lo = (int)(x / n1), hi = (int)(x - (long)lo * n1);
-    if (hi < lo) return;
-    double v = 0.0;
-    if (m > e) {
-      const double full = (hi == n && lo == n) ? 0.0 : lam_in(a, hi, lo);
-      double sacc = 0;
-      for (int i = 0; i < e; ++i) sacc += E[i + ec * hi] * E[i + ec * lo];
-      v = full - sacc;
-    }
+  // (E^T E through the LDS-staged product: one thread per entry walking two columns of E in global memory took 1.9 ms)
+  auto gb_store = [&](int hi, int lo, double ete) {
+    const double full = (hi == n && lo == n) ? 0.0 : lam_in(a, hi, lo);
+    const double v = m > e ? full - ete : 0.0;
     Gb[hi + (long)n1 * lo] = v; Gb[lo + (long)n1 * hi] = v;
     if (hi < n) { Gb0[hi + (long)n * lo] = v; Gb0[lo + (long)n * hi] = v; }
-  });
+  };
+  if (m > e) syrk_lower(c, E, ec, n1, e, gb_store);
+  else par_for(c, (long)n1 * n1, [&](long x) { const int lo = (int)(x / n1), hi = (int)(x - (long)lo * n1); if (hi >= lo) gb_store(hi, lo, 0.0); });
   par_for(c, (long)n * n, [&](long x) { const long j = x / n, i = x - j * n; Y[x] = i == j ? 1.0 : 0.0; Yv[x] = 0.0; });
   barrier(c);
   tick(c, 3);
@@ -659,7 +783,10 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
     const int p = 15 + k;
     double* ek = E + ec * k;
     const double gkk = Gb[k + (long)n1 * k] > 0.0 ? Gb[k + (long)n1 * k] : 0.0;
-    const double tail2 = wg_sum(c, p + 1, e, [&](long i) { return ek[i] * ek[i]; }) + gkk;
+    // |head|^2 (rows 0 .. p) and |tail|^2 (rows below p, + the Gram entry for the rows in B) of column k in one reduction
+    double head2, tail2;
+    wg_sum2(c, 0, e, head2, tail2, [&](long i, double& hs, double& ts) { const double v = ek[i] * ek[i]; if (i <= p) hs += v; else ts += v; });
+    tail2 += gkk;
     double zero2 = 2.2250738585072014e-308;
     // The part of the tail that lives in B comes out of the Gram matrix, which resolves |tail|^2 to ~1e-8 |column|^2 at best
     // (measured over the benchmark's sequences: exactly dependent columns leave 3e-11 .. 3e-8, independent ones 2e-6 and
@@ -667,12 +794,10 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
     // reference's rule to the letter, which only the sweep over the dense stack can honour
     const double t2 = (m > e && tol2 < 1e-7) ? 1e-7 : tol2;
     if (t2 > 0) {
-      const double head2 = wg_sum(c, 0, p + 1, [&](long i) { return ek[i] * ek[i]; });
       const double z = t2 * (head2 + tail2);
       zero2 = z > zero2 ? z : zero2;
     }
     const double c0 = ek[p];
-    barrier(c);
     if (tail2 <= zero2) {
       if (tail2 > 2.2250738585072014e-308) ++n_skip_tol;
       if (first_thread(c)) a.tau[k] = 0.0;
@@ -684,30 +809,34 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
     double beta = sqrt(c0 * c0 + tail2);
     if (c0 >= 0.0) beta = -beta;
     const double dn = 1.0 / (c0 - beta), tk = (beta - c0) / beta;
+    // a_j for the columns to the right (r_o rides along as column n); kept in tau's tail [n .. 2n].  The reflector's entries
+    // are ek[i] dn, formed on the fly from the unscaled column (the same product the store below rounds): column k itself is
+    // scaled, and Yv, beta, tau are written, in the NEXT phase, which does not read E -- one phase and one barrier less per step
+    double* aj = a.tau + n1;
+    row_for(c, k + 1, n1, [&](long j) {
+      double* ej = E + ec * j;
+      double sdot = row_sum_range(c, p + 1, e, [&](long i) { return (ek[i] * dn) * ej[i]; });
+      sdot = (sdot + ej[p] + Gb[j + (long)n1 * k] * dn) * tk;
+      rowlane_update(c, p + 1, e, [&](long i) { return ej[i] - sdot * (ek[i] * dn); }, [&](long i, double v) { ej[i] = v; });
+      if (first_rowlane(c)) { ej[p] -= sdot; aj[j] = sdot * dn; }
+    });
+    barrier(c);
     par_for(c, e - (p + 1), [&](long i) { ek[p + 1 + i] *= dn; });
     par_for(c, n, [&](long i) { Yv[i + (long)n * k] = Y[i + (long)n * k] * dn; });
     if (first_thread(c)) { ek[p] = beta; a.tau[k] = tk; }
-    barrier(c);
-    // a_j for the columns to the right (r_o rides along as column n); kept in tau's tail [n .. 2n]
-    double* aj = a.tau + n1;
-    wave_for(c, k + 1, n1, [&](long j) {
-      double* ej = E + ec * j;
-      double sdot = wave_sum_range(c, p + 1, e, [&](long i) { return ek[i] * ej[i]; });
-      sdot = (sdot + ej[p] + Gb[k + (long)n1 * j] * dn) * tk;
-      lane_for(c, p + 1, e, [&](long i) { ej[i] -= sdot * ek[i]; });
-      if (first_lane(c)) { ej[p] -= sdot; aj[j] = sdot * dn; }
-    });
-    barrier(c);
-    // B(:, j) -= a_j B(:, k): Gram and coefficients (columns k+1 .. n; Y only over the Jacobian columns)
-    par_for(c, (long)(n1 - k - 1) * (n1 - k - 1), [&](long x) {
-      const int w = n1 - k - 1, jl = (int)(x / w), il = (int)(x - (long)jl * w), j = k + 1 + jl, l = k + 1 + il;
-      if (l < j) return;
-      const double v = Gb[l + (long)n1 * j] - aj[l] * Gb[j + (long)n1 * k] - aj[j] * Gb[l + (long)n1 * k] + aj[j] * aj[l] * gkk;
-      Gb[l + (long)n1 * j] = v; Gb[j + (long)n1 * l] = v;
-    });
-    par_for(c, (long)(n - k - 1) * (k + 1), [&](long x) {
-      const int jl = (int)(x / (k + 1)), i = (int)(x - (long)jl * (k + 1)), j = k + 1 + jl;
-      Y[i + (long)n * j] -= aj[j] * Y[i + (long)n * k];       // column k of Y has its support in rows 0..k
+    // B(:, j) -= a_j B(:, k): Gram and coefficients (columns k+1 .. n; Y only over the Jacobian columns).  One row of a
+    // wavefront per column j, its lanes along l >= j / along the rows of Y: contiguous loads and stores, no index divisions,
+    // and only the lower triangle of Gb is kept up to date (every reader asks for (hi, lo)) -- one thread per entry with the
+    // mirror image stored too took most of the sweep's 27 us per step (a memory round trip per entry: a store, then the next
+    // entry's loads)
+    row_for(c, k + 1, n1, [&](long j) {
+      const double cj = Gb[j + (long)n1 * k], ajj = aj[j];
+      double* gj = Gb + (long)n1 * j; const double* gk = Gb + (long)n1 * k;
+      rowlane_update(c, j, n1, [&](long l) { return gj[l] - aj[l] * cj - ajj * gk[l] + ajj * aj[l] * gkk; }, [&](long l, double v) { gj[l] = v; });
+      if (j < n) {
+        double* yj = Y + (long)n * j; const double* yk = Y + (long)n * k;
+        rowlane_update(c, 0, k + 1, [&](long i) { return yj[i] - ajj * yk[i]; }, [&](long i, double v) { yj[i] = v; });   // column k of Y has its support in rows 0..k
+      }
     });
     barrier(c);
   }
@@ -760,14 +889,14 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
       if (tj == 0.0 || ka0 >= nr) continue;
       const double* ej = E + ec * j;
       const double* gvj = Gv + (long)n * j; const double* yvj = Yv + (long)n * j;
-      wave_for(c, ka0, nr, [&](long ka) {
+      row_for(c, ka0, nr, [&](long ka) {
         double* t = Tq + ec * ka; double* y = Yq + (long)n * ka;
-        double dot = wave_sum_range(c, pj + 1, e, [&](long i) { return ej[i] * t[i]; });
-        if (m > e) dot += wave_sum_range(c, 0, n, [&](long i) { return gvj[i] * y[i]; });
+        double dot = row_sum_range(c, pj + 1, e, [&](long i) { return ej[i] * t[i]; });
+        if (m > e) dot += row_sum_range(c, 0, n, [&](long i) { return gvj[i] * y[i]; });
         const double al = tj * (dot + t[pj]);
-        lane_for(c, pj + 1, e, [&](long i) { t[i] -= al * ej[i]; });
-        if (m > e) lane_for(c, 0, j + 1, [&](long i) { y[i] -= al * yvj[i]; });
-        if (first_lane(c)) t[pj] -= al;
+        rowlane_update(c, pj + 1, e, [&](long i) { return t[i] - al * ej[i]; }, [&](long i, double v) { t[i] = v; });
+        if (m > e) rowlane_update(c, 0, j + 1, [&](long i) { return y[i] - al * yvj[i]; }, [&](long i, double v) { y[i] = v; });
+        if (first_rowlane(c)) t[pj] -= al;
       });
       barrier(c);
     }
@@ -867,9 +996,9 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
   barrier(c);
   const long ldz = a.ldz;
   const double dlt = a.u_var - a.v_var;
-  atb(c, Tq, ec, nr, P1, ec, nr, e, [&](int ka, int kb, double v) { if (ka >= kb) a.Z[ka + ldz * kb] = v; });
+  atb_lower(c, Tq, ec, nr, P1, ec, e, [&](int ka, int kb, double v) { a.Z[ka + ldz * kb] = v; });
   barrier(c);
-  if (m > e) atb(c, Yq, n, nr, P3, n, nr, n, [&](int ka, int kb, double v) { if (ka >= kb) a.Z[ka + ldz * kb] += v; });
+  if (m > e) atb_lower(c, Yq, n, nr, P3, n, n, [&](int ka, int kb, double v) { a.Z[ka + ldz * kb] += v; });
   barrier(c);
   par_for(c, (long)nr * nr, [&](long x) {
     const int kb = (int)(x / nr), ka = (int)(x - (long)kb * nr);
