@@ -211,9 +211,61 @@ template <int TS, class ST> LIT_FN void syrk_lower_ts(const Ctx& c, const double
   }
   __syncthreads();
 }
+// The same product on the f64 matrix cores (v_mfma_f64_16x16x4_f64) for up to 192 columns and sixteen wavefronts: the 16 x 16
+// blocks of the lower triangle (78 at 180 columns) are dealt round-robin to the wavefronts, five accumulators each; a chunk of
+// rows is staged [row][column] (zero beyond the matrix, row stride 208: rows k and k + 1 half the banks apart) and every MFMA
+// takes its two operands straight from there.  The tile version is bound by its LDS reads (ten 8-byte reads per 25 FMAs and
+// thread: 2.3 ms for the 3 200 x 180 H_u of a 30-camera window); an MFMA reads two operands per 1 024 FMAs.
+typedef double lit_v4d __attribute__((ext_vector_type(4)));
+template <class ST> LIT_FN void syrk_lower_mfma(const Ctx& c, const double* G, long ldg, int nr, int mobs, ST st) {
+  constexpr int LDL = 208, MAXB = 5;
+  const int nbk = (nr + 15) / 16, nblk = nbk * (nbk + 1) / 2;
+  const int rows = (c.lds_doubles / LDL) & ~3;                 // rows of G per chunk (a multiple of the MFMA's k = 4)
+  int bi[MAXB], bj[MAXB];
+  lit_v4d acc[MAXB];
+#pragma unroll
+  for (int q = 0; q < MAXB; ++q) {
+    const int e = c.wave + c.nw * q;
+    int ti = 0, tj = 0;
+    if (e < nblk) { ti = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5); while (ti * (ti + 1) / 2 > e) --ti; while ((ti + 1) * (ti + 2) / 2 <= e) ++ti; tj = e - ti * (ti + 1) / 2; }
+    bi[q] = ti; bj[q] = tj;
+    acc[q] = lit_v4d{0.0, 0.0, 0.0, 0.0};
+  }
+  const int lr = c.lane & 15, lk = c.lane >> 4;
+  for (int o0 = 0; o0 < mobs; o0 += rows) {
+    const int nrow = mobs - o0 < rows ? mobs - o0 : rows, nrow4 = (nrow + 3) & ~3;
+    __syncthreads();
+    for (long x = c.tid; x < (long)nrow4 * (16 * nbk); x += c.nt) {
+      const int k = (int)(x / nrow4), o = (int)(x - (long)k * nrow4);
+      c.lds[o * LDL + k] = (o < nrow && k < nr) ? G[o0 + o + ldg * k] : 0.0;
+    }
+    __syncthreads();
+    for (int k0 = 0; k0 < nrow4; k0 += 4) {
+      const double* row = c.lds + (k0 + lk) * LDL + lr;
+#pragma unroll
+      for (int q = 0; q < MAXB; ++q) {
+        if (c.wave + c.nw * q >= nblk) break;
+        // C(i, j) += sum_k G(k, 16 bi + i) G(k, 16 bj + j): the A operand's lane index runs along i, the B operand's along j
+        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(row[16 * bi[q]], row[16 * bj[q]], acc[q], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < MAXB; ++q) {
+    if (c.wave + c.nw * q >= nblk) break;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                              // C/D layout: row = (lane >> 4) + 4 r, column = lane & 15
+      const int i = 16 * bi[q] + lk + 4 * r, j = 16 * bj[q] + lr;
+      if (i < nr && j <= i) st(i, j, acc[q][r]);
+    }
+  }
+  __syncthreads();
+}
 // 4 x 4 tiles per thread; 5 x 5 when the 4 x 4 tiles outnumber the threads (a second pass re-stages the whole of G: the Gram
-// matrix of 180 columns is 1 035 tiles for 1 024 threads)
+// matrix of 180 columns is 1 035 tiles for 1 024 threads); the matrix cores for tall operands
 template <class ST> LIT_FN void syrk_lower(const Ctx& c, const double* G, long ldg, int nr, int mobs, ST st) {
+  const int nbk = (nr + 15) / 16;
+  if (mobs >= 256 && c.nw == 16 && nbk * (nbk + 1) / 2 <= 5 * 16 && 8 * 208 <= c.lds_doubles) { syrk_lower_mfma(c, G, ldg, nr, mobs, st); return; }
   const int nt4 = (nr + 3) / 4;
   if (nt4 * (nt4 + 1) / 2 <= c.nt) syrk_lower_ts<4>(c, G, ldg, nr, mobs, st);
   else syrk_lower_ts<5>(c, G, ldg, nr, mobs, st);
@@ -702,7 +754,7 @@ LIT_FN double lam_in(const Args<HT>& a, int hi, int lo) {   // hi >= lo
 // per track (Hu^T Hu is block-local: a track touches its own cameras' columns).  Nothing of size m x n exists.
 LIT_FN long compact_ws_doubles(int n, int m_cap, int r_cap, int ldg) {
   const long n1 = n + 1, ec = 15 + n;
-  return ec * n1 + ec * 2L * m_cap + n1 * n1 + 4L * n * n + 2 * (ec * (long)r_cap + (long)n * r_cap) + ec * ec + ec * (long)n + ec * (long)r_cap + (long)n * r_cap + (long)ldg * n + 64;
+  return ec * n1 + ec * 2L * m_cap + n1 * n1 + 4L * n * n + 2 * (ec * (long)r_cap + (long)n * r_cap) + ec * ec + 2 * ec * (long)n + ec * (long)r_cap + (long)n * r_cap + (long)ldg * n + 64;
 }
 
 template <class HT>
@@ -722,7 +774,8 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
   double* Yq = Tq + ec * rc;                    // [n x rc] B-part of the kept columns of Q (coordinates of B0's columns)
   double* See = Yq + (long)n * rc;              // [ec x ec] G_E^T G_E
   double* Seb = See + ec * ec;                  // [ec x n] G_E^T Hu
-  double* P1 = Seb + ec * n;                    // [ec x rc] See Tq + Seb Yq
+  double* SebT = Seb + ec * n;                  // [n x ec] the same transposed (each of the two products that use it reads it along its contraction index)
+  double* P1 = SebT + ec * n;                   // [ec x rc] See Tq + Seb Yq
   double* P3 = P1 + ec * rc;                    // [n x rc] Gam Yq + Seb^T Tq
   double* TqT = P3 + (long)n * rc;              // [rc x ec] Tq transposed (the last product reads it along the kept columns)
   double* YqT = TqT + rc * ec;                  // [rc x n]
@@ -866,12 +919,10 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
     a.TH[k + rc * j] = v;
   });
   // ---- Gv(:, k) = Gb0 Yv(:, k) for the reflectors that exist (Yv(:, k) has its support in rows 0..k)
-  par_for(c, (long)n * msteps, [&](long x) {
-    const int k = (int)(x / n), i = (int)(x - (long)k * n);
-    double sacc = 0;
-    if (a.tau[k] != 0.0 && m > e) for (int l = 0; l <= k; ++l) sacc += Gb0[i + (long)n * l] * Yv[l + (long)n * k];
-    Gv[i + (long)n * k] = sacc;
-  });
+  // (as a product: Yv is zero below its diagonal and in the columns of the steps that did not reflect, Gb0 is symmetric; one
+  // thread per entry walking a column of Yv paid a memory round trip per term: 0.7 ms)
+  if (m > e && msteps > 0) atb(c, Gb0, n, n, Yv, n, msteps, n, [&](int i, int k, double v) { Gv[i + (long)n * k] = v; });
+  else par_for(c, (long)n * msteps, [&](long x) { Gv[x] = 0.0; });
   barrier(c);
   tick(c, 5);
   // ---- kept columns of Q = H_0 H_1 ..: q = H_0 .. H_k e_(15 + k) as [t ; B0 y]; a column of a row < 15 is e_row itself.
@@ -909,11 +960,12 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
   double* Hu = Hh;                                      // [ldg x n] column-major
   const long ldh = a.ldg;
   par_for(c, ec * ec, [&](long x) { See[x] = 0.0; });
-  par_for(c, ec * (long)n, [&](long x) { Seb[x] = 0.0; });
+  par_for(c, ec * (long)n, [&](long x) { Seb[x] = 0.0; SebT[x] = 0.0; });
   par_for(c, (long)mobs * n, [&](long x) { const long j = x / mobs, g = x - j * mobs; Hu[g + ldh * j] = 0.0; });
   barrier(c);
+  tick(c, 12);
   if (m > e)
-    wave_for(c, 0, F, [&](long t) {
+    row_for(c, 0, F, [&](long t) {                         // a row of 16 lanes per track: 64 tracks of the workgroup at a time
       if (!(a.status[t] & a.inc_bit)) return;
       const int M = a.M[t], rho = 2 * M - 3, r0 = a.row0[t];
       int kE = e - r0; kE = kE < 0 ? 0 : (kE > rho ? rho : kE);      // rows of the track that are explicit
@@ -923,25 +975,36 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
       const double* T = a.Tf + (long)t * 9;
       const HT* hx = a.Hx + (long)t * a.m_cap * 12;
       const int so = first_obs(a, t), g0 = a.obs0[t];
-      // u-rows of (I - Q_f(:, :d) Q_f(:, :d)^T) H_x_j, scattered to the state columns of the track's cameras
-      lane_for(c, 0, (long)M * 6 * M, [&](long x) {
-        const int cc = (int)(x / M), o = (int)(x - (long)cc * M), op = cc / 6, kk = cc - 6 * op;
+      // u-rows of (I - Q_f(:, :d) Q_f(:, :d)^T) H_x_j, scattered to the state columns of the track's cameras: lane = observation o
+      // (what depends on o alone -- e_o^T Q_f(:, :d) Q_f(:, :d)^T in the reflectors' coordinates -- is formed once per lane, not
+      // once per entry: one lane per entry redid it 6 M times, 1.3 ms of this phase), the 6 M columns in a loop; consecutive
+      // lanes write consecutive rows of H_u
+      rowlane_for(c, 0, M, [&](long ol) {
+        const int o = (int)ol;
         double tv[3], ev[3] = {0, 0, 0};
         for (int p2 = 0; p2 < 3; ++p2) tv[p2] = vf_at(V, 2 * o, 0) * T[0 * 3 + p2] + vf_at(V, 2 * o, 1) * T[1 * 3 + p2] + vf_at(V, 2 * o, 2) * T[2 * 3 + p2];
         auto qf = [&](int q) -> double { return (q == 2 * o ? 1.0 : 0.0) - (tv[0] * vf_at(V, q, 0) + tv[1] * vf_at(V, q, 1) + tv[2] * vf_at(V, q, 2)); };
         for (int q = 0; q < d; ++q) { const double f = qf(q); for (int p2 = 0; p2 < 3; ++p2) ev[p2] += f * vf_at(V, q, p2); }
-        const double h0 = (double)hx[op * 12 + kk], h1 = (double)hx[op * 12 + 6 + kk];
-        double sv[3], val = op == o ? h0 : 0.0;
-        for (int p2 = 0; p2 < 3; ++p2) sv[p2] = vf_at(V, 2 * op, p2) * h0 + vf_at(V, 2 * op + 1, p2) * h1;
-        for (int q = 0; q < 3; ++q) { double w = 0; for (int p2 = 0; p2 <= q; ++p2) w += T[p2 * 3 + q] * sv[p2]; val += ev[q] * w; }
-        if (2 * op < d) val -= qf(2 * op) * h0;
-        if (2 * op + 1 < d) val -= qf(2 * op + 1) * h1;
-        Hu[(g0 + o) + ldh * (6 * a.slots[so + op] + kk)] = val;
+        for (int op = 0; op < M; ++op) {
+          const double q0 = 2 * op < d ? qf(2 * op) : 0.0, q1 = 2 * op + 1 < d ? qf(2 * op + 1) : 0.0;
+          double* hrow = Hu + (g0 + o) + ldh * (6 * a.slots[so + op]);
+          for (int kk = 0; kk < 6; ++kk) {
+            const double h0 = (double)hx[op * 12 + kk], h1 = (double)hx[op * 12 + 6 + kk];
+            double sv[3], val = op == o ? h0 : 0.0;
+            for (int p2 = 0; p2 < 3; ++p2) sv[p2] = vf_at(V, 2 * op, p2) * h0 + vf_at(V, 2 * op + 1, p2) * h1;
+            for (int q = 0; q < 3; ++q) { double w = 0; for (int p2 = 0; p2 <= q; ++p2) w += T[p2 * 3 + q] * sv[p2]; val += ev[q] * w; }
+            if (2 * op < d) val -= q0 * h0;
+            if (2 * op + 1 < d) val -= q1 * h1;
+            hrow[ldh * kk] = val;
+          }
+        }
       });
     });
   barrier(c);
+  tick(c, 13);
   if (m > e) syrk_lower(c, Hu, ldh, n, mobs, [&](int i, int j, double sv2) { Gam[i + (long)n * j] = sv2; Gam[j + (long)n * i] = sv2; });
   else par_for(c, (long)n * n, [&](long x) { Gam[x] = 0.0; });
+  tick(c, 14);
   // the tracks that own explicit rows: G_E^T G_E blocks, and G_E^T Hu for the one with rows on both sides of e
   for (int t = topt[0]; t <= topt[e - 1]; ++t) {
     if (!(a.status[t] & a.inc_bit)) continue;
@@ -959,7 +1022,7 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
         const double* hh = Hu + g0 + ldh * col;
         double sacc = 0;
         for (int o = 0; o < M; ++o) sacc += At[(long)(r0 + i1) * 2 * a.m_cap + 2 * o] * hh[o];
-        Seb[(r0 + i1) + ec * col] = sacc;
+        Seb[(r0 + i1) + ec * col] = sacc; SebT[col + (long)n * (r0 + i1)] = sacc;
       });
   }
   barrier(c);
@@ -967,32 +1030,20 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
   // ---- G^T G = Tq^T (See Tq + Seb Yq) + Yq^T (Seb^T Tq + Gam Yq)
   // See is block diagonal (an explicit row meets only the rows of its own track) and Seb has rows only for the one track
   // that has rows on both sides of e
-  par_for(c, (long)e * nr, [&](long x) {
-    const int ka = (int)(x / e), i = (int)(x - (long)ka * e);
-    const double* t = Tq + ec * ka; const double* y = Yq + (long)n * ka;
-    const int tt = topt[i], r0 = a.row0[tt], rho = 2 * a.M[tt] - 3;
-    const int l1 = r0 + rho < e ? r0 + rho : e;
-    double sacc = 0;
-    for (int l = r0; l < l1; ++l) sacc += See[i + ec * l] * t[l];
-    if (m > e && r0 + rho > e) for (int l = 0; l < n; ++l) sacc += Seb[i + ec * l] * y[l];
-    P1[i + ec * ka] = sacc;
-  });
-  // P3 = Gam Yq (+ Seb^T Tq from the rows of the one track that has rows on both sides of e); G^T G = Tq^T P1 + Yq^T P3:
-  // LDS-staged products (one load per product from global memory took 6 of this route's 27 ms)
+  // All as LDS-staged products over the dense matrices (the entries outside See's blocks and Seb's rows are exact zeros: the
+  // sums are the same): one thread per entry with a loop over the rows of the entry's track paid a memory round trip per term
+  // (1.4 ms for P1 alone)
+  const int ts = topt[e - 1], rs = a.row0[ts];           // the track of the last explicit row: the only one that can straddle
+  const bool straddle = m > e && rs + 2 * a.M[ts] - 3 > e;
+  atb(c, See, ec, e, Tq, ec, nr, e, [&](int i, int ka, double v) { P1[i + ec * ka] = v; });
+  barrier(c);
+  tick(c, 15);
+  if (straddle) atb(c, SebT, n, e, Yq, n, nr, n, [&](int i, int ka, double v) { P1[i + ec * ka] += v; });
+  // P3 = Gam Yq (+ Seb^T Tq from the rows of the one track that has rows on both sides of e); G^T G = Tq^T P1 + Yq^T P3
   if (m > e) atb(c, Gam, n, n, Yq, n, nr, n, [&](int i, int ka, double v) { P3[i + (long)n * ka] = v; });
   else par_for(c, (long)n * nr, [&](long x) { P3[x] = 0.0; });
   barrier(c);
-  if (m > e) {
-    const int ts = topt[e - 1], rs = a.row0[ts];       // the track of the last explicit row: the only one that can straddle
-    if (rs + 2 * a.M[ts] - 3 > e)
-      par_for(c, (long)n * nr, [&](long x) {
-        const int ka = (int)(x / n), i = (int)(x - (long)ka * n);
-        const double* t = Tq + ec * ka;
-        double sacc = 0;
-        for (int l = rs; l < e; ++l) sacc += Seb[l + ec * i] * t[l];
-        P3[i + (long)n * ka] += sacc;
-      });
-  }
+  if (straddle) atb(c, Seb, ec, n, Tq, ec, nr, e, [&](int i, int ka, double v) { P3[i + (long)n * ka] += v; });
   barrier(c);
   const long ldz = a.ldz;
   const double dlt = a.u_var - a.v_var;
