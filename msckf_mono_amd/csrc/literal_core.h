@@ -754,7 +754,7 @@ LIT_FN double lam_in(const Args<HT>& a, int hi, int lo) {   // hi >= lo
 // per track (Hu^T Hu is block-local: a track touches its own cameras' columns).  Nothing of size m x n exists.
 LIT_FN long compact_ws_doubles(int n, int m_cap, int r_cap, int ldg) {
   const long n1 = n + 1, ec = 15 + n;
-  return ec * n1 + ec * 2L * m_cap + n1 * n1 + 4L * n * n + 2 * (ec * (long)r_cap + (long)n * r_cap) + ec * ec + 2 * ec * (long)n + ec * (long)r_cap + (long)n * r_cap + (long)ldg * n + 64;
+  return ec * n1 + ec * 2L * m_cap + n1 * n1 + 4L * n * n + 2 * (ec * (long)r_cap + (long)n * r_cap) + ec * ec + 4 * ec * (long)n + ec * (long)r_cap + (long)n * r_cap + (long)ldg * n + 64;
 }
 
 template <class HT>
@@ -779,7 +779,9 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
   double* P3 = P1 + ec * rc;                    // [n x rc] Gam Yq + Seb^T Tq
   double* TqT = P3 + (long)n * rc;              // [rc x ec] Tq transposed (the last product reads it along the kept columns)
   double* YqT = TqT + rc * ec;                  // [rc x n]
-  double* Hh = YqT + rc * (long)n;              // [ldg x n] u-rows of every track's projected Jacobian (stacked observations x state columns)
+  double* VE = YqT + rc * (long)n;              // [ec x n] explicit parts of the reflectors as a matrix (zero above the pivot row, 1 in it)
+  double* VET = VE + ec * (long)n;              // [n x ec] the same transposed
+  double* Hh = VET + ec * (long)n;              // [ldg x n] u-rows of every track's projected Jacobian (stacked observations x state columns)
   double* Gam = Gv;                             // Hu^T Hu reuses Gv's space once the columns of Q are built
   const int ks = n + 16;
   int* flag = a.kept + ks;
@@ -926,31 +928,54 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
   barrier(c);
   tick(c, 5);
   // ---- kept columns of Q = H_0 H_1 ..: q = H_0 .. H_k e_(15 + k) as [t ; B0 y]; a column of a row < 15 is e_row itself.
-  // Backward accumulation: reflector j (from the last one down) is applied to every kept column of a row >= 15 + j, one
-  // wavefront per column (one thread per column walking all its reflectors took 21 of this route's 57 ms)
-  par_for(c, (long)e * nr, [&](long x) { const int ka = (int)(x / e), i = (int)(x - (long)ka * e); Tq[i + ec * ka] = i == a.kept[ka] ? 1.0 : 0.0; });
-  par_for(c, (long)n * nr, [&](long x) { Yq[x] = 0.0; });
-  barrier(c);
+  // Compact WY form: Q = I - V T V^T with T^-1 = striu(V^T V) + diag(1 / tau) (V: the reflectors that exist, columns
+  // [explicit part ; B0 yv]; v_i^T v_j = VE_i^T VE_j + yv_i^T Gb0 yv_j), so that Q e_c = e_c - V X with T^-1 X = V^T e_c: two
+  // products for V^T V, one back substitution over the steps, two products for [Tq ; Yq].  (Reflector by reflector over every
+  // column that needs it -- a dot product and an update per column and step, each a chain of dependent global round trips --
+  // took 3.1 ms of 12 at a 30-camera window; one thread per column walking all its reflectors 21 ms.)
   {
-    int ka0 = nr;                                        // first kept column whose row is >= 15 + j
-    for (int j = msteps - 1; j >= 0; --j) {
-      const int pj = 15 + j;
-      while (ka0 > 0 && a.kept[ka0 - 1] >= pj) --ka0;
-      const double tj = a.tau[j];
-      if (tj == 0.0 || ka0 >= nr) continue;
-      const double* ej = E + ec * j;
-      const double* gvj = Gv + (long)n * j; const double* yvj = Yv + (long)n * j;
-      row_for(c, ka0, nr, [&](long ka) {
-        double* t = Tq + ec * ka; double* y = Yq + (long)n * ka;
-        double dot = row_sum_range(c, pj + 1, e, [&](long i) { return ej[i] * t[i]; });
-        if (m > e) dot += row_sum_range(c, 0, n, [&](long i) { return gvj[i] * y[i]; });
-        const double al = tj * (dot + t[pj]);
-        rowlane_update(c, pj + 1, e, [&](long i) { return t[i] - al * ej[i]; }, [&](long i, double v) { t[i] = v; });
-        if (m > e) rowlane_update(c, 0, j + 1, [&](long i) { return y[i] - al * yvj[i]; }, [&](long i, double v) { y[i] = v; });
-        if (first_rowlane(c)) t[pj] -= al;
+    const int ms = msteps;
+    double* YvT = Y;                    // [ms x n] (Y is free after the sweep)
+    double* Uc = Gb;                    // [ms x ms] column-major, strictly upper part: Uc(r, j) = v_r^T v_j, r < j (Gb is free after the sweep)
+    double* Wx = P1;                    // [ms x nr] V^T e_c, then X (P1 is formed later)
+    if (ms > 0) {
+      par_for(c, (long)e * ms, [&](long x) {
+        const int j = (int)(x / e), i = (int)(x - (long)j * e), pj = 15 + j;
+        const double v = a.tau[j] == 0.0 ? 0.0 : (i < pj ? 0.0 : (i == pj ? 1.0 : E[i + ec * j]));
+        VE[i + ec * j] = v; VET[j + (long)ms * i] = v;
+      });
+      par_for(c, (long)n * ms, [&](long x) { const int j = (int)(x / n), l = (int)(x - (long)j * n); YvT[j + (long)ms * l] = a.tau[j] == 0.0 ? 0.0 : Yv[l + (long)n * j]; });
+      par_for(c, (long)ms * nr, [&](long x) {
+        const int ka = (int)(x / ms), j = (int)(x - (long)ka * ms), pj = 15 + j, row = a.kept[ka];
+        Wx[x] = a.tau[j] == 0.0 ? 0.0 : (row < pj ? 0.0 : (row == pj ? 1.0 : E[row + ec * j]));
       });
       barrier(c);
+      syrk_lower(c, VE, ec, ms, e, [&](int i, int j, double v) { if (i > j) Uc[j + (long)ms * i] = v; });
+      if (m > e) atb_lower(c, Yv, n, ms, Gv, n, n, [&](int i, int j, double v) { if (i > j) Uc[j + (long)ms * i] += v; });
+      barrier(c);
+      // back substitution, last step first: X(j, :) = tau_j W(j, :), W(r, :) -= U(r, j) X(j, :) for r < j
+      for (int j = ms - 1; j >= 1; --j) {
+        const double tj = a.tau[j];
+        if (tj == 0.0) continue;
+        const double* uj = Uc + (long)ms * j;
+        row_for(c, 0, nr, [&](long ka) {
+          double* w = Wx + (long)ms * ka;
+          const double xj = tj * w[j];
+          if (xj == 0.0) return;
+          rowlane_update(c, 0, j, [&](long r) { return w[r] - uj[r] * xj; }, [&](long r, double v) { w[r] = v; });
+        });
+        barrier(c);
+      }
+      par_for(c, (long)ms * nr, [&](long x) { const int j = (int)(x % ms); Wx[x] *= a.tau[j]; });
+      barrier(c);
+      atb(c, VET, ms, e, Wx, ms, nr, ms, [&](int i, int ka, double v) { Tq[i + ec * ka] = (i == a.kept[ka] ? 1.0 : 0.0) - v; });
+      if (m > e) atb(c, YvT, ms, n, Wx, ms, nr, ms, [&](int l, int ka, double v) { Yq[l + (long)n * ka] = -v; });
+      else par_for(c, (long)n * nr, [&](long x) { Yq[x] = 0.0; });
+    } else {
+      par_for(c, (long)e * nr, [&](long x) { const int ka = (int)(x / e), i = (int)(x - (long)ka * e); Tq[i + ec * ka] = i == a.kept[ka] ? 1.0 : 0.0; });
+      par_for(c, (long)n * nr, [&](long x) { Yq[x] = 0.0; });
     }
+    barrier(c);
   }
   tick(c, 6);
   // ---- G_E^T G_E, G_E^T Hu, Hu^T Hu (Gam takes Gv's place).  Hu -- the u-rows of every track's projected Jacobian -- is

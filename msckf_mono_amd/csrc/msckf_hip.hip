@@ -455,7 +455,7 @@ struct Batch : BatchBase {
     rc |= dalloc(&L.row0, Bz * (f_cap + 1)); rc |= dalloc(&L.obs0, Bz * (f_cap + 1)); rc |= dalloc(&L.otrk, Bz * L.ldg); rc |= dalloc(&L.kept, Bz * L.kept_stride);
     rc |= dalloc(&L.TH, Bz * L.r_cap * n1); rc |= dalloc(&L.Z, Bz * (size_t)L.ldz * L.ldz);
     { const long nn = d.n6cap, ecc = 15 + nn, rcc = L.r_cap;   // = lit::compact_ws_doubles(6 n_cap, m_cap, r_cap), literal_core.h
-      L.w2_stride = ecc * (nn + 1) + ecc * 2L * m_cap + (nn + 1) * (nn + 1) + 4L * nn * nn + 2 * (ecc * rcc + nn * rcc) + ecc * ecc + 2 * ecc * nn + ecc * rcc + nn * rcc + (long)L.ldg * nn + 64; }
+      L.w2_stride = ecc * (nn + 1) + ecc * 2L * m_cap + (nn + 1) * (nn + 1) + 4L * nn * nn + 2 * (ecc * rcc + nn * rcc) + ecc * ecc + 4 * ecc * nn + ecc * rcc + nn * rcc + (long)L.ldg * nn + 64; }
     rc |= dalloc(&L.W2, Bz * (size_t)L.w2_stride);
     // the sweep over the dense stack (MSCKF_HIP_LITERAL_ROUTE=1: tests, A/B runs) needs the stack itself and the u-rows of A Q_1
     if (lit_route == 1) { rc |= dalloc(&L.X, Bz * L.ldx * n1); rc |= dalloc(&L.G, Bz * (size_t)L.ldg * L.r_cap); }
