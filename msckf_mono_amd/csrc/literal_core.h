@@ -1013,15 +1013,21 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
         for (int op = 0; op < M; ++op) {
           const double q0 = 2 * op < d ? qf(2 * op) : 0.0, q1 = 2 * op + 1 < d ? qf(2 * op + 1) : 0.0;
           double* hrow = Hu + (g0 + o) + ldh * (6 * a.slots[so + op]);
+          // everything of observation op is fetched before the first store (a store, then the next column's loads, is a memory
+          // round trip per column)
+          double hh[12], vv[6], val[6];
+          for (int x = 0; x < 12; ++x) hh[x] = (double)hx[op * 12 + x];
+          for (int p2 = 0; p2 < 3; ++p2) { vv[p2] = vf_at(V, 2 * op, p2); vv[3 + p2] = vf_at(V, 2 * op + 1, p2); }
           for (int kk = 0; kk < 6; ++kk) {
-            const double h0 = (double)hx[op * 12 + kk], h1 = (double)hx[op * 12 + 6 + kk];
-            double sv[3], val = op == o ? h0 : 0.0;
-            for (int p2 = 0; p2 < 3; ++p2) sv[p2] = vf_at(V, 2 * op, p2) * h0 + vf_at(V, 2 * op + 1, p2) * h1;
-            for (int q = 0; q < 3; ++q) { double w = 0; for (int p2 = 0; p2 <= q; ++p2) w += T[p2 * 3 + q] * sv[p2]; val += ev[q] * w; }
-            if (2 * op < d) val -= q0 * h0;
-            if (2 * op + 1 < d) val -= q1 * h1;
-            hrow[ldh * kk] = val;
+            const double h0 = hh[kk], h1 = hh[6 + kk];
+            double sv[3], vl = op == o ? h0 : 0.0;
+            for (int p2 = 0; p2 < 3; ++p2) sv[p2] = vv[p2] * h0 + vv[3 + p2] * h1;
+            for (int q = 0; q < 3; ++q) { double w = 0; for (int p2 = 0; p2 <= q; ++p2) w += T[p2 * 3 + q] * sv[p2]; vl += ev[q] * w; }
+            if (2 * op < d) vl -= q0 * h0;
+            if (2 * op + 1 < d) vl -= q1 * h1;
+            val[kk] = vl;
           }
+          for (int kk = 0; kk < 6; ++kk) hrow[ldh * kk] = val[kk];
         }
       });
     });
