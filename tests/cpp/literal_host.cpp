@@ -36,7 +36,10 @@ extern "C" int lit_host_compress(int F, int m_cap, int N, const int* included, c
   a.LamIn = LamIn; a.lam_part = 0; a.gram_parts = 1;
   a.Lam = Lam; a.ldL = n + 1; a.info = info8;
   Ctx c;
-  std::vector<double> stage(8000);                   // what the device has as LDS (kernels_literal.hip: LIT_LDS_DOUBLES)
+  // what the device has as LDS (kernels_literal.hip: LIT_LDS_DOUBLES); LIT_HOST_STAGE overrides the size (tests: the blocked
+  // elimination must give the same matrix with narrower panels and with none)
+  const char* se = getenv("LIT_HOST_STAGE");
+  std::vector<double> stage((size_t)(se ? atol(se) : 8000));
   c.lds = stage.data(); c.lds_doubles = (int)stage.size();
   literal_compress(c, a, route);
   if (TH_out) for (size_t i = 0; i < (size_t)(n + 15) * (n + 1); ++i) { const size_t col = i / (n + 15), row = i % (n + 15); TH_out[i] = TH[row + (size_t)a.r_cap * col]; }
