@@ -92,6 +92,11 @@ template <class ST> LIT_FN void atb_lower(const Ctx& c, const double* A, long ld
   atb(c, A, lda, ma, B, ldb, ma, kd, [&](int i, int j, double v) { if (i >= j) st(i, j, v); });
 }
 LIT_FN void tick(const Ctx&, int) {}
+// a section run by ONE wavefront with wave_sync between its dependent steps (no workgroup barrier inside)
+LIT_FN bool first_wave(const Ctx&) { return true; }
+LIT_FN void wave_sync(const Ctx&) {}
+// out[0 .. count) = the i in [0, n) with pred(i), ascending; returns count (uniform)
+template <class P> LIT_FN int compact_list(const Ctx&, int n, int* out, P pred) { int cnt = 0; for (int i = 0; i < n; ++i) if (pred(i)) out[cnt++] = i; return cnt; }
 #else
 #define LIT_FN __device__ __forceinline__
 struct Ctx { int tid, nt, lane, wave, nw; double* red; long long* tim; double* lds; int lds_doubles; };   // red: LDS scratch, nw + 2 doubles; tim: phase stamps (100 MHz) or null; lds: staging area
@@ -331,6 +336,29 @@ template <class ST> LIT_FN void atb_lower(const Ctx& c, const double* A, long ld
 LIT_FN bool first_lane(const Ctx& c) { return c.lane == 0; }
 LIT_FN bool first_thread(const Ctx& c) { return c.tid == 0; }
 LIT_FN void tick(const Ctx& c, int slot) { if (c.tim && c.tid == 0) c.tim[slot] = (long long)wall_clock64(); }
+LIT_FN bool first_wave(const Ctx& c) { return c.wave == 0; }
+// LDS hand-over between the lanes of one wavefront: the fences keep the compiler from moving reads above writes
+LIT_FN void wave_sync(const Ctx&) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+// stream compaction by the first wavefront (ballot + prefix popcount, 64 candidates per round); the count reaches the other
+// wavefronts through c.red.  A thread-0 loop (load flag, store index, next load) paid a memory round trip per candidate.
+template <class P> LIT_FN int compact_list(const Ctx& c, int n, int* out, P pred) {
+  __syncthreads();                       // red may still be read from the previous reduction
+  if (c.wave == 0) {
+    int cnt = 0;
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + c.lane;
+      const bool v = i < n && pred(i);
+      const unsigned long long mask = __ballot(v);
+      if (v) out[cnt + __popcll(mask & ((1ull << c.lane) - 1ull))] = i;
+      cnt += __popcll(mask);
+    }
+    if (c.lane == 0) c.red[0] = (double)cnt;
+  }
+  __syncthreads();
+  const int r = (int)c.red[0];
+  __syncthreads();
+  return r;
+}
 #endif
 
 // One trajectory's inputs (what k_feature / k_select left behind) and work space.  HT: scalar type of the Jacobian blocks.
@@ -368,6 +396,8 @@ struct Args {
   const double* LamIn;      // [H_o | r_o]^T [H_o | r_o], element (hi, lo), lo <= hi <= n, at LamIn[hi * ldL + lo] (+ split-K copies)
   long lam_part; int gram_parts;   // copies of LamIn lam_part doubles apart: block column lo / 64 came in min(lo / 64 + parts - 2, parts) partial sums
   double* W2;               // scratch of the compact route: compact_ws_doubles(6 n_cap, m_cap, r_cap)
+  const double* Gam; int ldGam;    // Gam(hi, lo), lo <= hi < n, at Gam[hi * ldGam + lo]: sum over the stacked tracks of H_x^T P D_u P H_x, P = I - Q_f Q_f^T
+                            // (the u-rows of every track's projected Jacobian, squared: independent of the null-space basis); gamma_rows / the caller's product
   // ---- outputs
   double* Lam; int ldL;     // Lam^(hi, lo), lo <= hi <= n, at Lam[hi * ldL + lo]  (what k_chol_mfma / lam_hat read)
   int* info;                // [8]: stacked rows m, kept rows r, reflected steps, steps skipped by the tolerance, route (3 compact, 2 dense sweep),
@@ -737,355 +767,663 @@ LIT_FN double lam_in(const Args<HT>& a, int hi, int lo) {   // hi >= lo
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The compact route: HouseholderQR(H_o) in the reference's order, STEP BY STEP, for any shape of stack, without the stack.
-// Only the rows 0 .. e-1, e = min(m, 15 + n), can ever be pivot rows (step 15 + k pivots on row 15 + k): they are kept
-// explicitly (E, e x (n + 1)).  Of the rows below (B) a reflector needs only inner products of columns -- the Gram matrix
-// Gb = B^T B = [H_o | r_o]^T [H_o | r_o] - E^T E, which k_gram already accumulates in f64 -- and leaves B as B0 Y for a
-// coefficient matrix Y it updates by column operations:
-//     |tail|^2 = sum_(i>p) E(i,k)^2 + Gb(k,k)                        v = [.. 1 | E(i>p,k) | B(:,k)] / (c0 - beta)
-//     v^T x_j  = E(p,j) + sum_(i>p) v_i E(i,j) + Gb(k,j) / (c0-beta)  s_j = tau v^T x_j,  a_j = s_j / (c0 - beta)
-//     E(p,j) -= s_j,  E(i>p,j) -= s_j v_i,  B(:,j) -= a_j B(:,k):   Y(:,j) -= a_j Y(:,k),
-//     Gb(j,l) -= a_l Gb(j,k) + a_j Gb(k,l) - a_j a_l Gb(k,k)
-// -- the same numbers as the sweep over the dense stack (literal_general), O(e n + n^2) per step instead of O(m n).  A
-// vector of the stack's row space is then [t ; B0 y]: the columns of Q_1 = H_0 H_1 .. e_row are built in that form from the
-// stored reflectors (v^T [t ; B0 y] = v_E^T t + (Gb0 y_v)^T y), and the u-rows of A Q_1 that R_n = Q_1^T R_o Q_1 needs are
-//     G = G_E Tq + Hu Yq,   G_E(:, i) = u-rows of A e_i (explicit rows),  Hu = u-rows of A_B A_B^T H_x (rows in B),
-// so that G^T G = Tq^T (G_E^T G_E) Tq + Tq^T (G_E^T Hu) Yq + (.)^T + Yq^T (Hu^T Hu) Yq with three small matrices accumulated
-// per track (Hu^T Hu is block-local: a track touches its own cameras' columns).  Nothing of size m x n exists.
-LIT_FN long compact_ws_doubles(int n, int m_cap, int r_cap, int ldg) {
+// The compact route (default): the reference's compression as a PROJECTION, without the stack and without Q.
+//
+// What the filter sees of (T_H, r_n, R_n) = (Q_1^T H_o, Q_1^T r_o, Q_1^T R_o Q_1) (msckf.h:1351-1366) is
+//     Lam^ = [T_H | r_n]^T R_n^-1 [T_H | r_n] = A^T Q_1 (Q_1^T R_o Q_1)^-1 Q_1^T A ,    A = [H_o | r_o],
+// which depends on Q_1 only through its range S:  Lam^ = A^T Bs (Bs^T R_o Bs)^-1 Bs^T A  for ANY basis Bs of S.  And S is
+//     span{ e_i : kept rows i < 15 }                  (the 15 zero IMU columns hand rows 0..14 through verbatim)
+//   + span{ x'_c : camera columns c whose step REFLECTED }     (x'_c = column c of H_o with its first 15 rows zeroed:
+//                                                               H_o = Q R, and R has no entry in a dropped row)
+//   + span{ q_h = H_15 H_16 .. e_h : handed-through rows h that are kept }   (a dependent column in the middle of the sweep
+//                                                               whose row still has entries to its right; rare -- typically the
+//                                                               oldest camera seen by one or two tracks -- but any number of them)
+// so the Householder sweep is needed only for its DECISIONS (which steps reflect, which rows are kept) and for the few q_h.
+// It runs on a compressed representation: the rows that can become pivot rows (the first e = min(m, 15 + n)) explicitly
+// (E), all rows from the pivot row down through their Gram matrix Gh, which a step downdates by the finished row of R:
+//     c0 = E(p, k),  |tail|^2 = Gh(k, k) - c0^2,   R(p, j) = Gh(k, j) / beta          (reflecting step; beta^2 = Gh(k, k))
+//     s_j = E(p, j) - R(p, j),  E(i > p, j) -= s_j v_i  (v_i = E(i, k) / (c0 - beta)),  Gh(j, l) -= R(p, j) R(p, l)
+//     a skipped step (zero tail) hands row p through: R(p, :) = E(p, :), the same downdate of Gh
+// -- no inner product over rows, no B = B0 Y coefficient matrix; Gh starts as k_gram's f64 H_o^T H_o minus the first 15 rows.
+// The steps run in panels of 16 staged in LDS: the 16 x 16 core by one wavefront, then one thread per row below the panel
+// (its 16 reflector entries) and per column to the right (its 16 entries of R and of s) -- each a short triangular recurrence
+// -- then ONE rank-16 pass over the trailing parts of E and Gh in global memory.  When every row is explicit (m <= 15 + n:
+// few tracks) the tails are summed exactly instead (the Gram matrix resolves a tail to ~1e-8 |column|^2 at best) by the plain
+// step-by-step sweep over E.
+//
+// With the basis in hand:  Bs^T A has rows E(i, :), Gh0(c, :) = (A^T A)(c, :) - first 15 rows, R(h, :);
+// Bs^T R_o Bs = v' Bs^T Bs + (u' - v') (G Bs)^T (G Bs), G = u-rows of blockdiag(A_j), and for a basis vector [t ; B0 y]
+// (B0: the rows below the explicit ones)  G b = G_E t~ + H_u y,  t~ = t - E0 y,  H_u = the u-rows of every track's projected
+// Jacobian (I - Q_f Q_f^T) H_x -- so that everything is made of three small matrices:  See = G_E^T G_E (block diagonal by
+// track), Xe = G_E^T H_u, Gam = H_u^T H_u (n x n, independent of the basis A_j: computed for all trajectories of a launch
+// on the matrix cores, kernels_literal.hip: k_lit_gamma).  For e_i and x'_c only the first 15 rows of t~ are non-zero and
+// y is a unit vector: Gam enters through its (C, C) submatrix, no product.  Lam^ then comes out of the blocked elimination
+// of Z = [[Bs^T R_o Bs, .], [(Bs^T A)^T, 0]] (information_from_rn).
+LIT_FN long compact_ws_doubles(int n, int m_cap, int r_cap, int /*ldg*/) {
   const long n1 = n + 1, ec = 15 + n;
-  return ec * n1 + ec * 2L * m_cap + n1 * n1 + 4L * n * n + 2 * (ec * (long)r_cap + (long)n * r_cap) + ec * ec + 4 * ec * (long)n + ec * (long)r_cap + (long)n * r_cap + (long)ldg * n + 64;
+  return 2 * ec * n1 + ec * 2L * m_cap + 2 * n1 * n1 + 2 * n1 + ec * ec + ec * (long)n + 15L * n + 4 * ec
+       + 3L * n * n + 2 * ec * (long)n + 2L * n * n + 128;
+}
+
+// row r of Q_f = (I - V T V^T)(:, 0:3) of a track, Z3 = T V(0:3, :)^T
+LIT_FN void qf_z3(const double* V, const double* T, double (&Z3)[9]) {
+  for (int p = 0; p < 3; ++p)
+    for (int cc = 0; cc < 3; ++cc) { double x = 0; for (int q = p; q < 3; ++q) x += T[p * 3 + q] * vf_at(V, cc, q); Z3[p * 3 + cc] = x; }
+}
+LIT_FN void qf_row(const double* V, const double (&Z3)[9], int r, double (&out)[3]) {
+  const double v0 = vf_at(V, r, 0), v1 = vf_at(V, r, 1), v2 = vf_at(V, r, 2);
+  for (int cc = 0; cc < 3; ++cc) out[cc] = (r == cc ? 1.0 : 0.0) - (v0 * Z3[cc] + v1 * Z3[3 + cc] + v2 * Z3[6 + cc]);
+}
+
+// The six rows a track contributes to Gam = Du - sum_j (B_j^T D_j + D_j^T B_j):  B = Q_f^T H_x (3 x n),
+// D = Q_u^T H_xu - W B / 2  (Q_u, H_xu: the u-rows of Q_f and H_x; W = Q_u^T Q_u), from the track's V, T; rows6 is
+// [6][ldc], only the columns of the track's cameras are written (the caller zeroed the rest).  Serial: the reference
+// implementation of what k_lit_pre does with a wavefront per track.
+template <class HT>
+LIT_FN void gamma_rows(const Args<HT>& a, int t, double* rows6, long ldc) {
+  const int M = a.M[t];
+  const double* V = a.Vf + (long)t * 2 * a.m_cap * 3;
+  const double* T = a.Tf + (long)t * 9;
+  const HT* hx = a.Hx + (long)t * a.m_cap * 12;
+  double Z3[9]; qf_z3(V, T, Z3);
+  double W[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int o = 0; o < M; ++o) { double q0[3]; qf_row(V, Z3, 2 * o, q0); for (int x = 0; x < 3; ++x) for (int y = 0; y < 3; ++y) W[x * 3 + y] += q0[x] * q0[y]; }
+  for (int o = 0; o < M; ++o) {
+    double q0[3], q1[3]; qf_row(V, Z3, 2 * o, q0); qf_row(V, Z3, 2 * o + 1, q1);
+    const int col = 6 * a.slots[first_obs(a, t) + o];
+    for (int kk = 0; kk < 6; ++kk) {
+      const double h0 = (double)hx[o * 12 + kk], h1 = (double)hx[o * 12 + 6 + kk];
+      double b[3], cu[3];
+      for (int x = 0; x < 3; ++x) { b[x] = q0[x] * h0 + q1[x] * h1; cu[x] = q0[x] * h0; }
+      for (int x = 0; x < 3; ++x) {
+        rows6[x * ldc + col + kk] = b[x];
+        rows6[(3 + x) * ldc + col + kk] = cu[x] - 0.5 * (W[x * 3 + 0] * b[0] + W[x * 3 + 1] * b[1] + W[x * 3 + 2] * b[2]);
+      }
+    }
+  }
+}
+
+// See / Xe for the explicit rows [i_lo, i_hi): See(i, i') = sum_o a_i[2o] a_i'[2o] inside a track, Xe(i, :) = (P D_u a_i)^T H_x
+template <class HT>
+LIT_FN void explicit_row_products(const Ctx& c, const Args<HT>& a, int e, int n, long ec, int i_lo, int i_hi, const int* topt, const double* At, double* See, double* Xe, double* G3) {
+  const int nrow = i_hi - i_lo;
+  if (nrow <= 0) return;
+  const long mc2 = 2L * a.m_cap;
+  par_for(c, (long)nrow * n, [&](long x) { const long j = x / nrow, i = i_lo + (x - j * nrow); Xe[i + ec * j] = 0.0; });
+  // g3_i = Q_f^T (D_u a_i)
+  par_for(c, nrow, [&](long ii) {
+    const int i = i_lo + (int)ii, t = topt[i], M = a.M[t];
+    const double* V = a.Vf + (long)t * 2 * a.m_cap * 3;
+    double Z3[9]; qf_z3(V, a.Tf + (long)t * 9, Z3);
+    double g[3] = {0, 0, 0};
+    for (int o = 0; o < M; ++o) { double q0[3]; qf_row(V, Z3, 2 * o, q0); const double au = At[i * mc2 + 2 * o]; for (int x = 0; x < 3; ++x) g[x] += q0[x] * au; }
+    for (int x = 0; x < 3; ++x) G3[i * 3 + x] = g[x];
+  });
+  barrier(c);
+  par_for(c, (long)nrow * a.m_cap, [&](long x) {
+    const int i = i_lo + (int)(x / a.m_cap), o = (int)(x % a.m_cap), t = topt[i];
+    if (o >= a.M[t]) return;
+    const double* V = a.Vf + (long)t * 2 * a.m_cap * 3;
+    double Z3[9]; qf_z3(V, a.Tf + (long)t * 9, Z3);
+    double q0[3], q1[3]; qf_row(V, Z3, 2 * o, q0); qf_row(V, Z3, 2 * o + 1, q1);
+    const double* g = G3 + i * 3;
+    const double w0 = At[i * mc2 + 2 * o] - (q0[0] * g[0] + q0[1] * g[1] + q0[2] * g[2]);
+    const double w1 = -(q1[0] * g[0] + q1[1] * g[1] + q1[2] * g[2]);
+    const HT* hx = a.Hx + (long)t * a.m_cap * 12 + o * 12;
+    double hh[12];
+    for (int kk = 0; kk < 12; ++kk) hh[kk] = (double)hx[kk];
+    const int col = 6 * a.slots[first_obs(a, t) + o];
+    for (int kk = 0; kk < 6; ++kk) Xe[i + ec * (col + kk)] = w0 * hh[kk] + w1 * hh[6 + kk];
+  });
+  // See: pairs of explicit rows of one track (rows of [i_lo, i_hi) against every explicit row of their track)
+  par_for(c, (long)nrow * e, [&](long x) {
+    const int i = i_lo + (int)(x / e), i2 = (int)(x % e);
+    const int t = topt[i];
+    double sacc = 0;
+    if (topt[i2] == t) { const int M = a.M[t]; for (int o = 0; o < M; ++o) sacc += At[i * mc2 + 2 * o] * At[i2 * mc2 + 2 * o]; }
+    See[i + ec * i2] = sacc; See[i2 + ec * i] = sacc;
+  });
+  barrier(c);
+}
+
+// One step of the sweep's per-column bookkeeping, shared by the three forms of the sweep
+struct SweepOut { int n_reflect, n_skip_tol; };
+
+// ---- the sweep when rows exist below the explicit ones, step by step (the definition of the blocked form; runs when the
+// staging area is too small for a panel)
+template <class HT>
+LIT_FN SweepOut sweep_gram_steps(const Ctx& c, const Args<HT>& a, int e, int n, int msteps, long ec, double* E, double* Gh, const double* Ld, double* Ac, double* dnv, int* refl, double* sv) {
+  const int n1 = n + 1;
+  const double tol2 = a.tol * a.tol, t2 = tol2 < 1e-7 ? 1e-7 : tol2;
+  SweepOut so = {0, 0};
+  double* rr = a.tau + n1;                         // [n1] the finished row of R
+  for (int k = 0; k < msteps; ++k) {
+    const int p = 15 + k;
+    double* ek = E + ec * k;
+    const double c0 = ek[p], gkk = Gh[k + (long)n1 * k] > 0.0 ? Gh[k + (long)n1 * k] : 0.0;
+    double tail2 = gkk - c0 * c0; tail2 = tail2 > 0.0 ? tail2 : 0.0;
+    double zero2 = t2 * Ld[k]; zero2 = zero2 > 2.2250738585072014e-308 ? zero2 : 2.2250738585072014e-308;
+    const bool reflect = tail2 > zero2;
+    barrier(c);                                    // everybody has read column k's state
+    double beta = 0, dn = 0, binv = 0;
+    if (reflect) {
+      ++so.n_reflect;
+      beta = sqrt(c0 * c0 + tail2); if (c0 >= 0.0) beta = -beta;
+      dn = 1.0 / (c0 - beta); binv = 1.0 / beta;
+      if (first_thread(c)) { a.tau[k] = (beta - c0) / beta; dnv[k] = dn; refl[k] = 1; }
+    } else {
+      if (tail2 > 2.2250738585072014e-308) ++so.n_skip_tol;
+      if (first_thread(c)) { a.tau[k] = 0.0; dnv[k] = 0.0; refl[k] = 0; }
+    }
+    // finished row p of R (columns k..n), s_j, the reflector's entries in place of column k's tail
+    par_for(c, n1 - k, [&](long jj) {
+      const int j = k + (int)jj;
+      const double ep = E[p + ec * j];
+      const double r = reflect ? (j == k ? beta : Gh[j + (long)n1 * k] * binv) : ep;
+      rr[j] = r;
+      sv[j] = reflect ? ep - r : 0.0;
+      if (j > k) Ac[j + (long)n1 * k] = reflect ? (ep - r) * dn : 0.0;
+    });
+    par_for(c, e - (p + 1), [&](long i) { ek[p + 1 + i] = reflect ? ek[p + 1 + i] * dn : 0.0; });
+    barrier(c);
+    // E(i > p, j > k) -= s_j v_i ;  E(p, j) = R(p, j) ;  Gh(j, l) -= R(p, j) R(p, l) for l >= j > k (lower triangle, column-major)
+    if (reflect) {
+      const int ni = e - (p + 1), nj = n1 - (k + 1);
+      par_for(c, (long)ni * nj, [&](long x) {
+        const int jj = (int)(x / ni), i = p + 1 + (int)(x - (long)jj * ni), j = k + 1 + jj;
+        E[i + ec * j] -= sv[j] * ek[i];
+      });
+    }
+    {
+      const int nj = n1 - (k + 1);
+      par_for(c, (long)nj * nj, [&](long x) {
+        const int lj = (int)(x / nj), li = (int)(x - (long)lj * nj);
+        if (li < lj) return;
+        const int j = k + 1 + li, l = k + 1 + lj;
+        Gh[j + (long)n1 * l] -= rr[j] * rr[l];
+      });
+    }
+    barrier(c);
+    par_for(c, n1 - k, [&](long jj) { const int j = k + (int)jj; E[p + ec * j] = rr[j]; });
+  }
+  barrier(c);
+  return so;
+}
+
+// ---- the same steps in panels of PB <= 16 staged in LDS
+template <class HT>
+LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n, int msteps, long ec, double* E, double* Gh, const double* Ld, double* Ac, double* dnv, int* refl, double* sv) {
+  const int n1 = n + 1;
+  int PB = 16;
+  auto need = [&](int pb) -> long { return (long)(e - 15) * (pb + 1) + 2L * pb * n1 + 2L * pb * pb + 8L * pb + 16; };
+  while (PB > 2 && need(PB) > c.lds_doubles) PB >>= 1;
+  if (need(PB) > c.lds_doubles) return sweep_gram_steps(c, a, e, n, msteps, ec, E, Gh, Ld, Ac, dnv, refl, sv);
+  const int ldc = PB + 1;
+  double* sEC = c.lds;                               // [(e - p0)][ldc]: E(p0 + r, k0 + q); its top PB x PB block is the panel's core
+  double* sEP = sEC + (long)(e - 15) * ldc;          // [PB][n1]: E(p0 + q, k0 + PB + jj) -> s_q(j)
+  double* sGP = sEP + (long)PB * n1;                 // [PB][n1]: Gh(k0 + q, k0 + PB + jj) -> R(p0 + q, j)
+  double* sG = sGP + (long)PB * n1;                  // [PB][PB] Gram block of the panel's columns (both triangles)
+  double* sS = sG + PB * PB;                         // [PB][PB] s_q(k0 + q'), q' > q
+  double* sDn = sS + PB * PB;                        // [PB] 1 / (c0 - beta)   (0: the step did not reflect)
+  double* sBi = sDn + PB;                            // [PB] 1 / beta
+  double* sTau = sBi + PB;                           // [PB]
+  double* sRf = sTau + PB;                           // [PB] 1.0 reflected / 0.0 skipped
+  double* sCnt = sRf + PB;                           // [2] counts of the panel
+  const double tol2 = a.tol * a.tol, t2 = tol2 < 1e-7 ? 1e-7 : tol2;
+  SweepOut so = {0, 0};
+  for (int k0 = 0; k0 < msteps; k0 += PB) {
+    const int pb = msteps - k0 < PB ? msteps - k0 : PB, p0 = 15 + k0;
+    const int nrow = e - p0;                         // rows p0 .. e-1
+    const int ntr = n1 - (k0 + pb);                  // trailing columns k0 + pb .. n
+    // ---- stage
+    par_for(c, (long)nrow * pb, [&](long x) { const int q = (int)(x / nrow), r = (int)(x - (long)q * nrow); sEC[(long)r * ldc + q] = E[(p0 + r) + ec * (k0 + q)]; });
+    par_for(c, (long)ntr * pb, [&](long x) {
+      const int q = (int)(x / ntr), jj = (int)(x - (long)q * ntr), j = k0 + pb + jj;
+      sEP[(long)q * n1 + jj] = E[(p0 + q) + ec * j];
+      sGP[(long)q * n1 + jj] = Gh[j + (long)n1 * (k0 + q)];
+    });
+    par_for(c, (long)pb * pb, [&](long x) {
+      const int q = (int)(x / pb), q2 = (int)(x - (long)q * pb), hi = q > q2 ? q : q2, lo = q > q2 ? q2 : q;
+      sG[q * PB + q2] = Gh[(k0 + hi) + (long)n1 * (k0 + lo)];
+    });
+    barrier(c);
+    // ---- core: the panel's columns against each other, one wavefront
+    if (first_wave(c)) {
+      int nref = 0, nskt = 0;
+      for (int q = 0; q < pb; ++q) {
+        const double c0 = sEC[(long)q * ldc + q], gq = sG[q * PB + q] > 0.0 ? sG[q * PB + q] : 0.0;
+        double tail2 = gq - c0 * c0; tail2 = tail2 > 0.0 ? tail2 : 0.0;
+        double zero2 = t2 * Ld[k0 + q]; zero2 = zero2 > 2.2250738585072014e-308 ? zero2 : 2.2250738585072014e-308;
+        const bool reflect = tail2 > zero2;
+        wave_sync(c);                                // every lane has read the step's inputs
+        if (reflect) {
+          ++nref;
+          double beta = sqrt(c0 * c0 + tail2); if (c0 >= 0.0) beta = -beta;
+          const double dn = 1.0 / (c0 - beta), binv = 1.0 / beta;
+          if (first_lane(c)) { sDn[q] = dn; sBi[q] = binv; sTau[q] = (beta - c0) / beta; sRf[q] = 1.0; }
+          lane_for(c, q, pb, [&](long q2) {
+            const double r = q2 == q ? beta : sG[q * PB + q2] * binv;
+            sS[q * PB + q2] = sEC[(long)q * ldc + q2] - r;
+            sEC[(long)q * ldc + q2] = r;
+          });
+          lane_for(c, q + 1, pb, [&](long r) { sEC[r * ldc + q] *= dn; });
+        } else {
+          if (tail2 > 2.2250738585072014e-308) ++nskt;
+          if (first_lane(c)) { sDn[q] = 0.0; sBi[q] = 0.0; sTau[q] = 0.0; sRf[q] = 0.0; }
+          lane_for(c, q, pb, [&](long q2) { sS[q * PB + q2] = 0.0; });
+          lane_for(c, q + 1, pb, [&](long r) { sEC[r * ldc + q] = 0.0; });
+        }
+        wave_sync(c);
+        const int nq = pb - (q + 1);
+        lane_for(c, 0, (long)nq * nq, [&](long x) {
+          const int r = q + 1 + (int)(x / nq), q2 = q + 1 + (int)(x % nq);
+          sEC[(long)r * ldc + q2] -= sEC[(long)r * ldc + q] * sS[q * PB + q2];
+          sG[r * PB + q2] -= sEC[(long)q * ldc + r] * sEC[(long)q * ldc + q2];
+        });
+        wave_sync(c);
+      }
+      if (first_lane(c)) { sCnt[0] = (double)nref; sCnt[1] = (double)nskt; }
+    }
+    barrier(c);
+    so.n_reflect += (int)sCnt[0]; so.n_skip_tol += (int)sCnt[1];
+    // ---- one thread per row below the panel (its reflector entries) and per column to the right (its entries of R and s)
+    par_for(c, (long)(nrow - pb) + ntr, [&](long x) {
+      double y[16], g[16];
+      if (x < nrow - pb) {
+        double* row = sEC + (long)(pb + x) * ldc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) y[q] = q < pb ? row[q] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          if (q >= pb) break;
+          const double vq = y[q] * sDn[q];             // 0 for a step that did not reflect
+#pragma unroll
+          for (int q2 = q + 1; q2 < 16; ++q2) if (q2 < pb) y[q2] -= vq * sS[q * PB + q2];
+          y[q] = vq;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) if (q < pb) row[q] = y[q];
+      } else {
+        const int jj = (int)(x - (nrow - pb));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { y[q] = q < pb ? sEP[(long)q * n1 + jj] : 0.0; g[q] = q < pb ? sGP[(long)q * n1 + jj] : 0.0; }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          if (q >= pb) break;
+          const bool rf = sRf[q] != 0.0;
+          const double r = rf ? g[q] * sBi[q] : y[q];
+          const double s = rf ? y[q] - r : 0.0;
+#pragma unroll
+          for (int q2 = q + 1; q2 < 16; ++q2)
+            if (q2 < pb) { g[q2] -= sEC[(long)q * ldc + q2] * r; y[q2] -= sEC[(long)q2 * ldc + q] * s; }
+          g[q] = r; y[q] = s;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) if (q < pb) { sEP[(long)q * n1 + jj] = y[q]; sGP[(long)q * n1 + jj] = g[q]; }
+      }
+    });
+    barrier(c);
+    // ---- results of the panel, and ONE pass over the trailing parts: E(i, j) -= sum_q v_q(i) s_q(j),  Gh(j, l) -= sum_q R_q(j) R_q(l)
+    par_for(c, pb, [&](long q) { a.tau[k0 + q] = sTau[q]; dnv[k0 + q] = sDn[q]; refl[k0 + q] = sRf[q] != 0.0 ? 1 : 0; });
+    par_for(c, (long)nrow * pb, [&](long x) { const int q = (int)(x / nrow), r = (int)(x - (long)q * nrow); E[(p0 + r) + ec * (k0 + q)] = sEC[(long)r * ldc + q]; });
+    par_for(c, (long)ntr * pb, [&](long x) {
+      const int q = (int)(x / ntr), jj = (int)(x - (long)q * ntr), j = k0 + pb + jj;
+      E[(p0 + q) + ec * j] = sGP[(long)q * n1 + jj];
+      Ac[j + (long)n1 * (k0 + q)] = sEP[(long)q * n1 + jj] * sDn[q];
+    });
+    par_for(c, (long)pb * pb, [&](long x) { const int q = (int)(x / pb), q2 = (int)(x - (long)q * pb); if (q2 > q) Ac[(k0 + q2) + (long)n1 * (k0 + q)] = sS[q * PB + q2] * sDn[q]; });
+    {
+      const int ni = nrow - pb, ti = (ni + 3) / 4, tj = (ntr + 3) / 4, ntE = ti * tj, ntG = tj * (tj + 1) / 2;
+      par_for(c, (long)ntE + ntG, [&](long x) {
+        double acc[16];
+#pragma unroll
+        for (int z = 0; z < 16; ++z) acc[z] = 0.0;
+        if (x < ntE) {
+          const int bj = (int)(x / ti), bi = (int)(x - (long)bj * ti), i0 = 4 * bi, j0 = 4 * bj;
+          int io[4], jo[4];
+#pragma unroll
+          for (int z = 0; z < 4; ++z) { io[z] = i0 + z < ni ? i0 + z : ni - 1; jo[z] = j0 + z < ntr ? j0 + z : ntr - 1; }
+          for (int q = 0; q < pb; ++q) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int z = 0; z < 4; ++z) { av[z] = sEC[(long)(pb + io[z]) * ldc + q]; bv[z] = sEP[(long)q * n1 + jo[z]]; }
+#pragma unroll
+            for (int zi = 0; zi < 4; ++zi)
+#pragma unroll
+              for (int zj = 0; zj < 4; ++zj) acc[zj * 4 + zi] += av[zi] * bv[zj];
+          }
+          double old[16];
+#pragma unroll
+          for (int zj = 0; zj < 4; ++zj)
+#pragma unroll
+            for (int zi = 0; zi < 4; ++zi) old[zj * 4 + zi] = E[(p0 + pb + io[zi]) + ec * (k0 + pb + jo[zj])];
+#pragma unroll
+          for (int zj = 0; zj < 4; ++zj)
+#pragma unroll
+            for (int zi = 0; zi < 4; ++zi) if (i0 + zi < ni && j0 + zj < ntr) E[(p0 + pb + i0 + zi) + ec * (k0 + pb + j0 + zj)] = old[zj * 4 + zi] - acc[zj * 4 + zi];
+        } else {
+          const int t = (int)(x - ntE);
+          int bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5); while (bi * (bi + 1) / 2 > t) --bi; while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+          const int bj = t - bi * (bi + 1) / 2, i0 = 4 * bi, j0 = 4 * bj;      // rows i0.. (>= columns j0..)
+          int io[4], jo[4];
+#pragma unroll
+          for (int z = 0; z < 4; ++z) { io[z] = i0 + z < ntr ? i0 + z : ntr - 1; jo[z] = j0 + z < ntr ? j0 + z : ntr - 1; }
+          for (int q = 0; q < pb; ++q) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int z = 0; z < 4; ++z) { av[z] = sGP[(long)q * n1 + io[z]]; bv[z] = sGP[(long)q * n1 + jo[z]]; }
+#pragma unroll
+            for (int zi = 0; zi < 4; ++zi)
+#pragma unroll
+              for (int zj = 0; zj < 4; ++zj) acc[zj * 4 + zi] += av[zi] * bv[zj];
+          }
+          double old[16];
+#pragma unroll
+          for (int zj = 0; zj < 4; ++zj)
+#pragma unroll
+            for (int zi = 0; zi < 4; ++zi) { const int hi = io[zi] > jo[zj] ? io[zi] : jo[zj], lo = io[zi] > jo[zj] ? jo[zj] : io[zi]; old[zj * 4 + zi] = Gh[(k0 + pb + hi) + (long)n1 * (k0 + pb + lo)]; }
+#pragma unroll
+          for (int zj = 0; zj < 4; ++zj)
+#pragma unroll
+            for (int zi = 0; zi < 4; ++zi) if (i0 + zi < ntr && j0 + zj <= i0 + zi) Gh[(k0 + pb + i0 + zi) + (long)n1 * (k0 + pb + j0 + zj)] = old[zj * 4 + zi] - acc[zj * 4 + zi];
+        }
+      });
+    }
+    barrier(c);
+  }
+  return so;
+}
+
+// ---- the sweep when every row is explicit (m <= 15 + n): tails and inner products summed over the rows themselves
+template <class HT>
+LIT_FN SweepOut sweep_explicit(const Ctx& c, const Args<HT>& a, int e, int n, int msteps, long ec, double* E, double* Ac, double* dnv, int* refl) {
+  const int n1 = n + 1;
+  const double tol2 = a.tol * a.tol;
+  SweepOut so = {0, 0};
+  for (int k = 0; k < msteps; ++k) {
+    const int p = 15 + k;
+    double* ek = E + ec * k;
+    double head2, tail2;
+    wg_sum2(c, 0, e, head2, tail2, [&](long i, double& hs, double& ts) { const double v = ek[i] * ek[i]; if (i <= p) hs += v; else ts += v; });
+    double zero2 = tol2 * (head2 + tail2); zero2 = zero2 > 2.2250738585072014e-308 ? zero2 : 2.2250738585072014e-308;
+    const double c0 = ek[p];
+    if (tail2 <= zero2) {
+      if (tail2 > 2.2250738585072014e-308) ++so.n_skip_tol;
+      if (first_thread(c)) { a.tau[k] = 0.0; dnv[k] = 0.0; refl[k] = 0; }
+      par_for(c, e - (p + 1), [&](long i) { ek[p + 1 + i] = 0.0; });
+      par_for(c, n1 - (k + 1), [&](long jj) { Ac[(k + 1 + jj) + (long)n1 * k] = 0.0; });
+      barrier(c);
+      continue;
+    }
+    ++so.n_reflect;
+    double beta = sqrt(c0 * c0 + tail2); if (c0 >= 0.0) beta = -beta;
+    const double dn = 1.0 / (c0 - beta), tk = (beta - c0) / beta;
+    row_for(c, k + 1, n1, [&](long j) {
+      double* ej = E + ec * j;
+      double sdot = row_sum_range(c, p + 1, e, [&](long i) { return (ek[i] * dn) * ej[i]; });
+      sdot = (sdot + ej[p]) * tk;
+      rowlane_update(c, p + 1, e, [&](long i) { return ej[i] - sdot * (ek[i] * dn); }, [&](long i, double v) { ej[i] = v; });
+      if (first_rowlane(c)) { ej[p] -= sdot; Ac[j + (long)n1 * k] = sdot * dn; }
+    });
+    barrier(c);
+    par_for(c, e - (p + 1), [&](long i) { ek[p + 1 + i] *= dn; });
+    if (first_thread(c)) { ek[p] = beta; a.tau[k] = tk; dnv[k] = dn; refl[k] = 1; }
+    barrier(c);
+  }
+  return so;
 }
 
 template <class HT>
 LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const int mobs) {
+  (void)mobs;
   const int n = 6 * a.N, F = a.F, n1 = n + 1, D = 15 + n;
   const int e = m < D ? m : D;                  // explicit rows
-  const int steps_total = e, msteps = steps_total - 15 > 0 ? steps_total - 15 : 0;
-  const long ec = 15 + n, rc = a.r_cap;
-  double* E = a.W2;                             // [ec x n1] column-major (leading dimension ec)
-  double* At = E + ec * n1;                     // [ec][2 m_cap]: a_i = A_j e_(i - row0) for the explicit rows
-  double* Gb = At + ec * 2L * a.m_cap;          // [n1 x n1] symmetric, both triangles
-  double* Gb0 = Gb + (long)n1 * n1;             // [n x n] Gb before the sweep (Jacobian columns)
-  double* Y = Gb0 + (long)n * n;                // [n x n] B = B0 Y
-  double* Yv = Y + (long)n * n;                 // [n x n] column k: B-part of reflector k in coordinates of B0's columns
-  double* Gv = Yv + (long)n * n;                // [n x n] column k: Gb0 Yv(:, k)
-  double* Tq = Gv + (long)n * n;                // [ec x rc] explicit-row part of the kept columns of Q
-  double* Yq = Tq + ec * rc;                    // [n x rc] B-part of the kept columns of Q (coordinates of B0's columns)
-  double* See = Yq + (long)n * rc;              // [ec x ec] G_E^T G_E
-  double* Seb = See + ec * ec;                  // [ec x n] G_E^T Hu
-  double* SebT = Seb + ec * n;                  // [n x ec] the same transposed (each of the two products that use it reads it along its contraction index)
-  double* P1 = SebT + ec * n;                   // [ec x rc] See Tq + Seb Yq
-  double* P3 = P1 + ec * rc;                    // [n x rc] Gam Yq + Seb^T Tq
-  double* TqT = P3 + (long)n * rc;              // [rc x ec] Tq transposed (the last product reads it along the kept columns)
-  double* YqT = TqT + rc * ec;                  // [rc x n]
-  double* VE = YqT + rc * (long)n;              // [ec x n] explicit parts of the reflectors as a matrix (zero above the pivot row, 1 in it)
-  double* VET = VE + ec * (long)n;              // [n x ec] the same transposed
-  double* Hh = VET + ec * (long)n;              // [ldg x n] u-rows of every track's projected Jacobian (stacked observations x state columns)
-  double* Gam = Gv;                             // Hu^T Hu reuses Gv's space once the columns of Q are built
+  const int msteps = e - 15 > 0 ? e - 15 : 0;
+  const bool gram = m > e;
+  const long ec = 15 + n, rc = a.r_cap, mc2 = 2L * a.m_cap;
+  double* E = a.W2;                             // [ec x n1] column-major: the explicit rows; ends as R (rows) and the reflectors' explicit parts (below the pivots)
+  double* E0 = E + ec * n1;                     // [ec x n1] the explicit rows as they were
+  double* At = E0 + ec * n1;                    // [ec][2 m_cap]: a_i = A_j e_(i - row0) for the explicit rows
+  double* Gh = At + ec * mc2;                   // [n1 x n1] lower triangle, column-major: Gram matrix of the rows from the pivot row down
+  double* Ac = Gh + (long)n1 * n1;              // [n1 x n1] Ac[j + n1 k] = s_j / (c0 - beta) of step k (column operations of the sweep), j > k
+  double* Ld = Ac + (long)n1 * n1;              // [n1] squared column norms
+  double* See = Ld + n1;                        // [ec x ec] G_E^T G_E (blocks of the tracks that own explicit rows)
+  double* Xe = See + ec * ec;                   // [ec x n] G_E^T H_u
+  double* Ut = Xe + ec * (long)n;               // [15 x n] See15 E15 / 2 - Xe15
+  double* G3 = Ut + 15L * n;                    // [ec][3]
+  double* W3 = G3 + 3 * ec;                     // [ec] s_j of the step at hand (step-by-step form of the sweep)
+  double* dnv = W3 + ec;                        // [n1]
+  double* Yk = dnv + n1 + 63;                   // [n x n] extras: Y(:, j), then Yv = Y dn
+  double* Gb0 = Yk + (long)n * n;               // [n x n] extras: Gram matrix of the rows below the explicit ones (leading block)
+  double* Gv = Gb0 + (long)n * n;               // [n x n] extras: Gb0 Yv
+  double* Th = Gv + (long)n * n;                // [ec x n] extras: t_h, then t~_h
+  double* Ph = Th + ec * (long)n;               // [ec x n] extras: See t~_h + Xe y_h
+  double* Yh = Ph + ec * (long)n;               // [n x n] extras: y_h
+  double* Qh = Yh + (long)n * n;                // [n x n] extras: Xe^T t~_h + Gam y_h
   const int ks = n + 16;
-  int* flag = a.kept + ks;
-  int* topt = a.kept + 2 * ks;                  // [ec] track of explicit row i
+  int* flag = a.kept + ks;                      // [e]
+  int* topt = a.kept + 2 * ks;                  // [e] track of explicit row i
+  int* refl = a.kept + 3 * ks;                  // [msteps]
+  int* bidx = a.kept + 4 * ks;                  // [<= e] the basis: kept rows < 15, reflected steps, kept handed-through rows
+  const double dlt = a.u_var - a.v_var;
   tick(c, 1);
   // ---- explicit rows: a_i = Q_f e_(3 + i - row0) and row i of [H_o | r_o] (msckf.h:957, :430)
-  if (first_thread(c)) {
-    int t = 0;
-    for (int i = 0; i < e; ++i) {
-      while (!(a.status[t] & a.inc_bit) || a.row0[t] + 2 * a.M[t] - 3 <= i) ++t;
-      topt[i] = t;
-    }
-  }
-  par_for(c, (long)e * n1, [&](long x) { const long j = x / e, i = x - j * e; E[i + ec * j] = 0.0; });
+  par_for(c, F, [&](long t) {
+    if (!(a.status[t] & a.inc_bit)) return;
+    const int r0 = a.row0[t], r1 = r0 + 2 * a.M[t] - 3;
+    for (int i = r0; i < r1 && i < e; ++i) topt[i] = (int)t;
+  });
+  par_for(c, (long)e * n1, [&](long x) { const long j = x / e, i = x - j * e; E[i + ec * j] = 0.0; E0[i + ec * j] = 0.0; });
   barrier(c);
   par_for(c, e, [&](long i) {
-    const int t = topt[i], M = a.M[t], R2 = 2 * M, q = 3 + (int)i - a.row0[t];
+    const int t = topt[i], q = 3 + (int)i - a.row0[t];
     const double* V = a.Vf + (long)t * 2 * a.m_cap * 3;
     const double* T = a.Tf + (long)t * 9;
-    double* ai = At + i * 2 * a.m_cap;
-    double sv[3], w[3];
+    double sv[3];
     for (int p = 0; p < 3; ++p) sv[p] = vf_at(V, q, p);
-    for (int p = 0; p < 3; ++p) { double x = 0; for (int qq = p; qq < 3; ++qq) x += T[p * 3 + qq] * sv[qq]; w[p] = x; }
-    for (int r = 0; r < R2; ++r) ai[r] = (r == q ? 1.0 : 0.0) - (vf_at(V, r, 0) * w[0] + vf_at(V, r, 1) * w[1] + vf_at(V, r, 2) * w[2]);
-    const HT* hx = a.Hx + (long)t * a.m_cap * 12;
-    const HT* rr = a.rw + (long)t * 2 * a.m_cap;
-    double sr = 0;
-    for (int o = 0; o < M; ++o) {
-      const int col = 6 * a.slots[first_obs(a, t) + o];
-      for (int kk = 0; kk < 6; ++kk) E[i + ec * (col + kk)] = ai[2 * o] * (double)hx[o * 12 + kk] + ai[2 * o + 1] * (double)hx[o * 12 + 6 + kk];
-      sr += ai[2 * o] * (double)rr[2 * o] + ai[2 * o + 1] * (double)rr[2 * o + 1];
-    }
-    E[i + ec * n] = sr;
+    for (int p = 0; p < 3; ++p) { double x = 0; for (int qq = p; qq < 3; ++qq) x += T[p * 3 + qq] * sv[qq]; G3[i * 3 + p] = x; }
   });
   barrier(c);
+  par_for(c, (long)e * a.m_cap, [&](long x) {
+    const int i = (int)(x / a.m_cap), o = (int)(x % a.m_cap), t = topt[i];
+    if (o >= a.M[t]) return;
+    const int q = 3 + i - a.row0[t];
+    const double* V = a.Vf + (long)t * 2 * a.m_cap * 3;
+    const double* w = G3 + i * 3;
+    const double a0 = (2 * o == q ? 1.0 : 0.0) - (vf_at(V, 2 * o, 0) * w[0] + vf_at(V, 2 * o, 1) * w[1] + vf_at(V, 2 * o, 2) * w[2]);
+    const double a1 = (2 * o + 1 == q ? 1.0 : 0.0) - (vf_at(V, 2 * o + 1, 0) * w[0] + vf_at(V, 2 * o + 1, 1) * w[1] + vf_at(V, 2 * o + 1, 2) * w[2]);
+    const HT* hx = a.Hx + (long)t * a.m_cap * 12 + o * 12;
+    double hh[12];
+    for (int kk = 0; kk < 12; ++kk) hh[kk] = (double)hx[kk];
+    const int col = 6 * a.slots[first_obs(a, t) + o];
+    At[i * mc2 + 2 * o] = a0; At[i * mc2 + 2 * o + 1] = a1;
+    for (int kk = 0; kk < 6; ++kk) { const double v = a0 * hh[kk] + a1 * hh[6 + kk]; E[i + ec * (col + kk)] = v; E0[i + ec * (col + kk)] = v; }
+  });
+  barrier(c);
+  par_for(c, e, [&](long i) {
+    const int t = topt[i], M = a.M[t];
+    const HT* rr = a.rw + (long)t * mc2;
+    double sr = 0;
+    for (int o = 0; o < M; ++o) sr += At[i * mc2 + 2 * o] * (double)rr[2 * o] + At[i * mc2 + 2 * o + 1] * (double)rr[2 * o + 1];
+    E[i + ec * n] = sr; E0[i + ec * n] = sr;
+  });
+  barrier(c);
+  const int e15 = e < 15 ? e : 15;
+  explicit_row_products(c, a, e, n, ec, 0, e15, topt, At, See, Xe, G3);
+  // Ut = See15 E15 / 2 - Xe15  (zero rows beyond e15)
+  par_for(c, 15L * n, [&](long x) {
+    const int cc = (int)(x / 15), l = (int)(x - 15L * cc);
+    double s = 0;
+    if (l < e15) { for (int l2 = 0; l2 < e15; ++l2) s += See[l + ec * l2] * E[l2 + ec * cc]; s = 0.5 * s - Xe[l + ec * cc]; }
+    Ut[l + 15L * cc] = s;
+  });
   tick(c, 2);
-  // ---- Gb = [H_o | r_o]^T [H_o | r_o] - E^T E (zero when every row is explicit), Y = I
-  // (E^T E through the LDS-staged product: one thread per entry walking two columns of E in global memory took 1.9 ms)
-  auto gb_store = [&](int hi, int lo, double ete) {
-    const double full = (hi == n && lo == n) ? 0.0 : lam_in(a, hi, lo);
-    const double v = m > e ? full - ete : 0.0;
-    Gb[hi + (long)n1 * lo] = v; Gb[lo + (long)n1 * hi] = v;
-    if (hi < n) { Gb0[hi + (long)n * lo] = v; Gb0[lo + (long)n * hi] = v; }
+  // ---- Gh = [H_o | r_o]^T [H_o | r_o] minus the first 15 rows (lower triangle; the corner (n, n) is never a pivot)
+  auto g0 = [&](int hi, int lo) -> double {      // Gram matrix of the rows from row 15 down, hi >= lo, lo < n
+    double s = lam_in(a, hi, lo);
+    for (int l = 0; l < e15; ++l) s -= E0[l + ec * hi] * E0[l + ec * lo];
+    return s;
   };
-  if (m > e) syrk_lower(c, E, ec, n1, e, gb_store);
-  else par_for(c, (long)n1 * n1, [&](long x) { const int lo = (int)(x / n1), hi = (int)(x - (long)lo * n1); if (hi >= lo) gb_store(hi, lo, 0.0); });
-  par_for(c, (long)n * n, [&](long x) { const long j = x / n, i = x - j * n; Y[x] = i == j ? 1.0 : 0.0; Yv[x] = 0.0; });
+  if (gram) {
+    par_for(c, (long)n1 * n1, [&](long x) {
+      const int lo = (int)(x / n1), hi = (int)(x - (long)lo * n1);
+      if (hi < lo) return;
+      Gh[hi + (long)n1 * lo] = (hi == n && lo == n) ? 0.0 : g0(hi, lo);
+    });
+    par_for(c, n, [&](long k) { Ld[k] = lam_in(a, (int)k, (int)k); });
+  }
   barrier(c);
   tick(c, 3);
   // ---- the sweep (msckf.h:1343): steps 0..14 meet the zero IMU columns; step 15 + k works on camera column k, pivot row 15 + k
-  const double tol2 = a.tol * a.tol;
-  int n_reflect = 0, n_skip_tol = 0;
-  for (int k = 0; k < msteps; ++k) {
-    const int p = 15 + k;
-    double* ek = E + ec * k;
-    const double gkk = Gb[k + (long)n1 * k] > 0.0 ? Gb[k + (long)n1 * k] : 0.0;
-    // |head|^2 (rows 0 .. p) and |tail|^2 (rows below p, + the Gram entry for the rows in B) of column k in one reduction
-    double head2, tail2;
-    wg_sum2(c, 0, e, head2, tail2, [&](long i, double& hs, double& ts) { const double v = ek[i] * ek[i]; if (i <= p) hs += v; else ts += v; });
-    tail2 += gkk;
-    double zero2 = 2.2250738585072014e-308;
-    // The part of the tail that lives in B comes out of the Gram matrix, which resolves |tail|^2 to ~1e-8 |column|^2 at best
-    // (measured over the benchmark's sequences: exactly dependent columns leave 3e-11 .. 3e-8, independent ones 2e-6 and
-    // more): no finer a threshold than 1e-7 while rows below the explicit ones exist -- also when tol = 0 asks for the
-    // reference's rule to the letter, which only the sweep over the dense stack can honour
-    const double t2 = (m > e && tol2 < 1e-7) ? 1e-7 : tol2;
-    if (t2 > 0) {
-      const double z = t2 * (head2 + tail2);
-      zero2 = z > zero2 ? z : zero2;
-    }
-    const double c0 = ek[p];
-    if (tail2 <= zero2) {
-      if (tail2 > 2.2250738585072014e-308) ++n_skip_tol;
-      if (first_thread(c)) a.tau[k] = 0.0;
-      par_for(c, e - (p + 1), [&](long i) { ek[p + 1 + i] = 0.0; });
-      barrier(c);
-      continue;
-    }
-    ++n_reflect;
-    double beta = sqrt(c0 * c0 + tail2);
-    if (c0 >= 0.0) beta = -beta;
-    const double dn = 1.0 / (c0 - beta), tk = (beta - c0) / beta;
-    // a_j for the columns to the right (r_o rides along as column n); kept in tau's tail [n .. 2n].  The reflector's entries
-    // are ek[i] dn, formed on the fly from the unscaled column (the same product the store below rounds): column k itself is
-    // scaled, and Yv, beta, tau are written, in the NEXT phase, which does not read E -- one phase and one barrier less per step
-    double* aj = a.tau + n1;
-    row_for(c, k + 1, n1, [&](long j) {
-      double* ej = E + ec * j;
-      double sdot = row_sum_range(c, p + 1, e, [&](long i) { return (ek[i] * dn) * ej[i]; });
-      sdot = (sdot + ej[p] + Gb[j + (long)n1 * k] * dn) * tk;
-      rowlane_update(c, p + 1, e, [&](long i) { return ej[i] - sdot * (ek[i] * dn); }, [&](long i, double v) { ej[i] = v; });
-      if (first_rowlane(c)) { ej[p] -= sdot; aj[j] = sdot * dn; }
-    });
-    barrier(c);
-    par_for(c, e - (p + 1), [&](long i) { ek[p + 1 + i] *= dn; });
-    par_for(c, n, [&](long i) { Yv[i + (long)n * k] = Y[i + (long)n * k] * dn; });
-    if (first_thread(c)) { ek[p] = beta; a.tau[k] = tk; }
-    // B(:, j) -= a_j B(:, k): Gram and coefficients (columns k+1 .. n; Y only over the Jacobian columns).  One row of a
-    // wavefront per column j, its lanes along l >= j / along the rows of Y: contiguous loads and stores, no index divisions,
-    // and only the lower triangle of Gb is kept up to date (every reader asks for (hi, lo)) -- one thread per entry with the
-    // mirror image stored too took most of the sweep's 27 us per step (a memory round trip per entry: a store, then the next
-    // entry's loads)
-    row_for(c, k + 1, n1, [&](long j) {
-      const double cj = Gb[j + (long)n1 * k], ajj = aj[j];
-      double* gj = Gb + (long)n1 * j; const double* gk = Gb + (long)n1 * k;
-      rowlane_update(c, j, n1, [&](long l) { return gj[l] - aj[l] * cj - ajj * gk[l] + ajj * aj[l] * gkk; }, [&](long l, double v) { gj[l] = v; });
-      if (j < n) {
-        double* yj = Y + (long)n * j; const double* yk = Y + (long)n * k;
-        rowlane_update(c, 0, k + 1, [&](long i) { return yj[i] - ajj * yk[i]; }, [&](long i, double v) { yj[i] = v; });   // column k of Y has its support in rows 0..k
-      }
-    });
-    barrier(c);
-  }
+  SweepOut so = {0, 0};
+  if (msteps > 0) so = gram ? sweep_gram_blocked(c, a, e, n, msteps, ec, E, Gh, Ld, Ac, dnv, refl, W3)
+                            : sweep_explicit(c, a, e, n, msteps, ec, E, Ac, dnv, refl);
+  barrier(c);
   tick(c, 4);
-  // ---- rows of R that are kept (msckf.h:1345-1348) and [T_H | r_n]
+  // ---- rows of R that are kept (msckf.h:1345-1348): a row with an entry above tol * max|R| in its upper-triangular part
   double rmax = 0;
-  if (a.tol > 0) rmax = wg_max(c, 0, (long)steps_total * n, [&](long x) { const long j = x / steps_total, i = x - j * steps_total; return (j + 15 >= i) ? fabs(E[i + ec * j]) : 0.0; });
+  if (a.tol > 0) rmax = wg_max(c, 0, (long)e * n, [&](long x) { const long j = x / e, i = x - j * e; return (j + 15 >= i) ? fabs(E[i + ec * j]) : 0.0; });
+  par_for(c, e, [&](long i) { flag[i] = 0; });
   barrier(c);
-  par_for(c, steps_total, [&](long i) {
-    int any = 0;
-    const int c_lo = i >= 15 ? (int)i - 15 : 0;
-    for (int j = c_lo; j < n && !any; ++j) { const double v = fabs(E[i + ec * j]); any = a.tol > 0 ? (v > a.tol * rmax) : (v != 0.0); }
-    flag[i] = any;
+  par_for(c, n, [&](long j) {                    // a thread per column (contiguous); every writer of a flag writes 1
+    const int i_hi = (int)j + 15 < e - 1 ? (int)j + 15 : e - 1;
+    for (int i = 0; i <= i_hi; ++i) { const double v = fabs(E[i + ec * j]); if (a.tol > 0 ? (v > a.tol * rmax) : (v != 0.0)) flag[i] = 1; }
   });
   barrier(c);
-  if (first_thread(c)) {
-    int nr = 0;
-    for (int i = 0; i < steps_total; ++i) if (flag[i]) a.kept[nr++] = i;
-    a.info[1] = nr; a.info[2] = n_reflect; a.info[3] = n_skip_tol; a.info[4] = 3; a.info[5] = steps_total - msteps;
-  }
-  barrier(c);
-  const int nr = a.info[1];
-  par_for(c, (long)nr * n1, [&](long x) {
-    const int j = (int)(x / nr), k = (int)(x - (long)j * nr), row = a.kept[k];
-    double v = E[row + ec * j];
-    if (j < n && j + 15 < row) v = 0.0;
-    a.TH[k + rc * j] = v;
-  });
-  // ---- Gv(:, k) = Gb0 Yv(:, k) for the reflectors that exist (Yv(:, k) has its support in rows 0..k)
-  // (as a product: Yv is zero below its diagonal and in the columns of the steps that did not reflect, Gb0 is symmetric; one
-  // thread per entry walking a column of Yv paid a memory round trip per term: 0.7 ms)
-  if (m > e && msteps > 0) atb(c, Gb0, n, n, Yv, n, msteps, n, [&](int i, int k, double v) { Gv[i + (long)n * k] = v; });
-  else par_for(c, (long)n * msteps, [&](long x) { Gv[x] = 0.0; });
+  const int nr_kept = compact_list(c, e, a.kept, [&](int i) { return flag[i] != 0; });
+  const int na = compact_list(c, e15, bidx, [&](int i) { return flag[i] != 0; });
+  // (a step that reflected with a pivot below tol * max|R| loses its row like any other: its column then lies in the span of
+  // the basis to within the tolerance, and is left out of it)
+  const int nb = compact_list(c, msteps, bidx + na, [&](int k) { return refl[k] != 0 && flag[15 + k] != 0; });
+  const int nh = compact_list(c, msteps, bidx + na + nb, [&](int k) { return refl[k] == 0 && flag[15 + k] != 0; });   // steps whose row was handed through and kept
+  const int nr = na + nb + nh;
+  if (first_thread(c)) { a.info[1] = nr_kept; a.info[2] = so.n_reflect; a.info[3] = so.n_skip_tol; a.info[4] = 3; a.info[5] = e - msteps; a.info[6] = nh; }
   barrier(c);
   tick(c, 5);
-  // ---- kept columns of Q = H_0 H_1 ..: q = H_0 .. H_k e_(15 + k) as [t ; B0 y]; a column of a row < 15 is e_row itself.
-  // Compact WY form: Q = I - V T V^T with T^-1 = striu(V^T V) + diag(1 / tau) (V: the reflectors that exist, columns
-  // [explicit part ; B0 yv]; v_i^T v_j = VE_i^T VE_j + yv_i^T Gb0 yv_j), so that Q e_c = e_c - V X with T^-1 X = V^T e_c: two
-  // products for V^T V, one back substitution over the steps, two products for [Tq ; Yq].  (Reflector by reflector over every
-  // column that needs it -- a dot product and an update per column and step, each a chain of dependent global round trips --
-  // took 3.1 ms of 12 at a 30-camera window; one thread per column walking all its reflectors 21 ms.)
-  {
-    const int ms = msteps;
-    double* YvT = Y;                    // [ms x n] (Y is free after the sweep)
-    double* Uc = Gb;                    // [ms x ms] column-major, strictly upper part: Uc(r, j) = v_r^T v_j, r < j (Gb is free after the sweep)
-    double* Wx = P1;                    // [ms x nr] V^T e_c, then X (P1 is formed later)
-    if (ms > 0) {
-      par_for(c, (long)e * ms, [&](long x) {
-        const int j = (int)(x / e), i = (int)(x - (long)j * e), pj = 15 + j;
-        const double v = a.tau[j] == 0.0 ? 0.0 : (i < pj ? 0.0 : (i == pj ? 1.0 : E[i + ec * j]));
-        VE[i + ec * j] = v; VET[j + (long)ms * i] = v;
-      });
-      par_for(c, (long)n * ms, [&](long x) { const int j = (int)(x / n), l = (int)(x - (long)j * n); YvT[j + (long)ms * l] = a.tau[j] == 0.0 ? 0.0 : Yv[l + (long)n * j]; });
-      par_for(c, (long)ms * nr, [&](long x) {
-        const int ka = (int)(x / ms), j = (int)(x - (long)ka * ms), pj = 15 + j, row = a.kept[ka];
-        Wx[x] = a.tau[j] == 0.0 ? 0.0 : (row < pj ? 0.0 : (row == pj ? 1.0 : E[row + ec * j]));
-      });
-      barrier(c);
-      syrk_lower(c, VE, ec, ms, e, [&](int i, int j, double v) { if (i > j) Uc[j + (long)ms * i] = v; });
-      if (m > e) atb_lower(c, Yv, n, ms, Gv, n, n, [&](int i, int j, double v) { if (i > j) Uc[j + (long)ms * i] += v; });
-      barrier(c);
-      // back substitution, last step first: X(j, :) = tau_j W(j, :), W(r, :) -= U(r, j) X(j, :) for r < j
-      for (int j = ms - 1; j >= 1; --j) {
-        const double tj = a.tau[j];
-        if (tj == 0.0) continue;
-        const double* uj = Uc + (long)ms * j;
-        row_for(c, 0, nr, [&](long ka) {
-          double* w = Wx + (long)ms * ka;
-          const double xj = tj * w[j];
-          if (xj == 0.0) return;
-          rowlane_update(c, 0, j, [&](long r) { return w[r] - uj[r] * xj; }, [&](long r, double v) { w[r] = v; });
-        });
-        barrier(c);
+  // ---- the kept handed-through rows: q_h = H_first .. H_(k_h - 1) e_h as [t ; B0 y] (the reflectors of the steps before k_h,
+  // last one first); reflector j is [0 .. 1 (row 15 + j) | E(i, j) below | B0 Y(:, j) dn_j] with Y = (I + A)^-1 the column
+  // operations of the sweep (A(i, j) = Ac[j + n1 i])
+  if (nh > 0) {
+    const int* hk = bidx + na + nb;               // steps k_h, ascending
+    const int kmax = hk[nh - 1];                  // reflectors 0 .. kmax - 1 can act
+    // Y(r, j) = [r == j] - sum_(i < j) Y(r, i) A(i, j): a row's entries follow from the row's earlier ones
+    par_for(c, kmax, [&](long r) {
+      for (int j = (int)r; j < kmax; ++j) {
+        double s = j == r ? 1.0 : 0.0;
+        if (refl[j]) for (int i = (int)r; i < j; ++i) if (refl[i]) s -= Yk[r + (long)n * i] * Ac[j + (long)n1 * i];
+        Yk[r + (long)n * j] = refl[j] ? s : 0.0;
       }
-      par_for(c, (long)ms * nr, [&](long x) { const int j = (int)(x % ms); Wx[x] *= a.tau[j]; });
-      barrier(c);
-      atb(c, VET, ms, e, Wx, ms, nr, ms, [&](int i, int ka, double v) { Tq[i + ec * ka] = (i == a.kept[ka] ? 1.0 : 0.0) - v; });
-      if (m > e) atb(c, YvT, ms, n, Wx, ms, nr, ms, [&](int l, int ka, double v) { Yq[l + (long)n * ka] = -v; });
-      else par_for(c, (long)n * nr, [&](long x) { Yq[x] = 0.0; });
-    } else {
-      par_for(c, (long)e * nr, [&](long x) { const int ka = (int)(x / e), i = (int)(x - (long)ka * e); Tq[i + ec * ka] = i == a.kept[ka] ? 1.0 : 0.0; });
-      par_for(c, (long)n * nr, [&](long x) { Yq[x] = 0.0; });
-    }
+    });
+    par_for(c, (long)kmax * kmax, [&](long x) {
+      const int lo = (int)(x / kmax), hi = (int)(x - (long)lo * kmax);
+      if (hi < lo) return;
+      double s = 0;
+      if (gram) { s = lam_in(a, hi, lo); for (int i = 0; i < e; ++i) s -= E0[i + ec * hi] * E0[i + ec * lo]; }
+      Gb0[hi + (long)n * lo] = s; Gb0[lo + (long)n * hi] = s;
+    });
+    barrier(c);
+    par_for(c, (long)kmax * kmax, [&](long x) { const int j = (int)(x / kmax), r = (int)(x - (long)j * kmax); if (r <= j) Yk[r + (long)n * j] *= dnv[j]; });   // Yv
+    barrier(c);
+    par_for(c, (long)kmax * kmax, [&](long x) {
+      const int j = (int)(x / kmax), r = (int)(x - (long)j * kmax);
+      double s = 0;
+      for (int l = 0; l <= j; ++l) s += Gb0[r + (long)n * l] * Yk[l + (long)n * j];
+      Gv[r + (long)n * j] = s;
+    });
+    par_for(c, (long)e * nh, [&](long x) { const int ah = (int)(x / e), i = (int)(x - (long)ah * e); Th[i + ec * ah] = i == 15 + hk[ah] ? 1.0 : 0.0; });
+    par_for(c, (long)n * nh, [&](long x) { Yh[x] = 0.0; });
+    barrier(c);
+    wave_for(c, 0, nh, [&](long ah) {
+      double* t = Th + ec * ah; double* y = Yh + (long)n * ah;
+      for (int j = hk[ah] - 1; j >= 0; --j) {
+        if (!refl[j]) continue;
+        const int pj = 15 + j;
+        const double* ej = E + ec * j;
+        const double d1 = wave_sum_range(c, 0, e, [&](long i) { return i < pj ? 0.0 : (i == pj ? t[i] : ej[i] * t[i]); });
+        const double d2 = wave_sum_range(c, 0, kmax, [&](long l) { return Gv[l + (long)n * j] * y[l]; });
+        const double al = a.tau[j] * (d1 + d2);
+        lane_for(c, 0, e, [&](long i) { if (i >= pj) t[i] -= al * (i == pj ? 1.0 : ej[i]); });
+        lane_for(c, 0, kmax, [&](long l) { if (l <= j) y[l] -= al * Yk[l + (long)n * j]; });
+      }
+    });
+    barrier(c);
+    // t~ = t - E0 y ; the full See / Xe (the first 15 rows exist already)
+    par_for(c, (long)e * nh, [&](long x) {
+      const int ah = (int)(x / e), i = (int)(x - (long)ah * e);
+      double s = Th[i + ec * ah];
+      for (int l = 0; l < kmax; ++l) s -= E0[i + ec * l] * Yh[l + (long)n * ah];
+      Th[i + ec * ah] = s;
+    });
+    explicit_row_products(c, a, e, n, ec, e15, e, topt, At, See, Xe, G3);
+    barrier(c);
+    par_for(c, (long)e * nh, [&](long x) {
+      const int ah = (int)(x / e), i = (int)(x - (long)ah * e), t = topt[i];
+      double s = 0;
+      const int r0 = a.row0[t]; int r1 = r0 + 2 * a.M[t] - 3; r1 = r1 < e ? r1 : e;
+      for (int i2 = r0; i2 < r1; ++i2) s += See[i + ec * i2] * Th[i2 + ec * ah];
+      for (int l = 0; l < kmax; ++l) s += Xe[i + ec * l] * Yh[l + (long)n * ah];
+      Ph[i + ec * ah] = s;
+    });
+    par_for(c, (long)n * nh, [&](long x) {
+      const int ah = (int)(x / n), cc = (int)(x - (long)ah * n);
+      double s = 0;
+      for (int i = 0; i < e; ++i) s += Xe[i + ec * cc] * Th[i + ec * ah];
+      for (int l = 0; l < kmax; ++l) { const int hi = cc > l ? cc : l, lo = cc > l ? l : cc; s += a.Gam[(long)hi * a.ldGam + lo] * Yh[l + (long)n * ah]; }
+      Qh[cc + (long)n * ah] = s;
+    });
     barrier(c);
   }
   tick(c, 6);
-  // ---- G_E^T G_E, G_E^T Hu, Hu^T Hu (Gam takes Gv's place).  Hu -- the u-rows of every track's projected Jacobian -- is
-  // laid out once as a dense (stacked observations) x n matrix (one wavefront per track), and Hu^T Hu is then the same
-  // LDS-staged product as G^T G of the dense route: Hu is read once.  (Track by track with two barriers each: 13 ms; one
-  // thread per entry gathering over the tracks: 26 ms; this: ~3 ms.)
-  double* Hu = Hh;                                      // [ldg x n] column-major
-  const long ldh = a.ldg;
-  par_for(c, ec * ec, [&](long x) { See[x] = 0.0; });
-  par_for(c, ec * (long)n, [&](long x) { Seb[x] = 0.0; SebT[x] = 0.0; });
-  par_for(c, (long)mobs * n, [&](long x) { const long j = x / mobs, g = x - j * mobs; Hu[g + ldh * j] = 0.0; });
-  barrier(c);
-  tick(c, 12);
-  if (m > e)
-    row_for(c, 0, F, [&](long t) {                         // a row of 16 lanes per track: 64 tracks of the workgroup at a time
-      if (!(a.status[t] & a.inc_bit)) return;
-      const int M = a.M[t], rho = 2 * M - 3, r0 = a.row0[t];
-      int kE = e - r0; kE = kE < 0 ? 0 : (kE > rho ? rho : kE);      // rows of the track that are explicit
-      const int d = 3 + kE;
-      if (d >= 2 * M) return;                                          // every row of the track is explicit: nothing of it in B
-      const double* V = a.Vf + (long)t * 2 * a.m_cap * 3;
-      const double* T = a.Tf + (long)t * 9;
-      const HT* hx = a.Hx + (long)t * a.m_cap * 12;
-      const int so = first_obs(a, t), g0 = a.obs0[t];
-      // u-rows of (I - Q_f(:, :d) Q_f(:, :d)^T) H_x_j, scattered to the state columns of the track's cameras: lane = observation o
-      // (what depends on o alone -- e_o^T Q_f(:, :d) Q_f(:, :d)^T in the reflectors' coordinates -- is formed once per lane, not
-      // once per entry: one lane per entry redid it 6 M times, 1.3 ms of this phase), the 6 M columns in a loop; consecutive
-      // lanes write consecutive rows of H_u
-      rowlane_for(c, 0, M, [&](long ol) {
-        const int o = (int)ol;
-        double tv[3], ev[3] = {0, 0, 0};
-        for (int p2 = 0; p2 < 3; ++p2) tv[p2] = vf_at(V, 2 * o, 0) * T[0 * 3 + p2] + vf_at(V, 2 * o, 1) * T[1 * 3 + p2] + vf_at(V, 2 * o, 2) * T[2 * 3 + p2];
-        auto qf = [&](int q) -> double { return (q == 2 * o ? 1.0 : 0.0) - (tv[0] * vf_at(V, q, 0) + tv[1] * vf_at(V, q, 1) + tv[2] * vf_at(V, q, 2)); };
-        for (int q = 0; q < d; ++q) { const double f = qf(q); for (int p2 = 0; p2 < 3; ++p2) ev[p2] += f * vf_at(V, q, p2); }
-        for (int op = 0; op < M; ++op) {
-          const double q0 = 2 * op < d ? qf(2 * op) : 0.0, q1 = 2 * op + 1 < d ? qf(2 * op + 1) : 0.0;
-          double* hrow = Hu + (g0 + o) + ldh * (6 * a.slots[so + op]);
-          // everything of observation op is fetched before the first store (a store, then the next column's loads, is a memory
-          // round trip per column)
-          double hh[12], vv[6], val[6];
-          for (int x = 0; x < 12; ++x) hh[x] = (double)hx[op * 12 + x];
-          for (int p2 = 0; p2 < 3; ++p2) { vv[p2] = vf_at(V, 2 * op, p2); vv[3 + p2] = vf_at(V, 2 * op + 1, p2); }
-          for (int kk = 0; kk < 6; ++kk) {
-            const double h0 = hh[kk], h1 = hh[6 + kk];
-            double sv[3], vl = op == o ? h0 : 0.0;
-            for (int p2 = 0; p2 < 3; ++p2) sv[p2] = vv[p2] * h0 + vv[3 + p2] * h1;
-            for (int q = 0; q < 3; ++q) { double w = 0; for (int p2 = 0; p2 <= q; ++p2) w += T[p2 * 3 + q] * sv[p2]; vl += ev[q] * w; }
-            if (2 * op < d) vl -= q0 * h0;
-            if (2 * op + 1 < d) vl -= q1 * h1;
-            val[kk] = vl;
-          }
-          for (int kk = 0; kk < 6; ++kk) hrow[ldh * kk] = val[kk];
+  // ---- Z(0:nr, 0:nr) = Bs^T R_o Bs (lower triangle) and TH = Bs^T A for the basis [e_i | x'_c | q_h]
+  {
+    const long ldz = a.ldz;
+    par_for(c, (long)nr * nr, [&](long x) {
+      const int kb = (int)(x / nr), ka = (int)(x - (long)kb * nr);
+      if (ka < kb) return;
+      double val;
+      if (ka < na) {                               // (e_i, e_i')
+        const int i = bidx[ka], i2 = bidx[kb];
+        val = (i == i2 ? a.v_var : 0.0) + dlt * See[i + ec * i2];
+      } else if (ka < na + nb) {
+        const int cc = bidx[ka];
+        if (kb < na) {                             // (x'_c, e_i)
+          const int i = bidx[kb];
+          double s = Xe[i + ec * cc];
+          for (int l = 0; l < e15; ++l) s -= See[i + ec * l] * E0[l + ec * cc];
+          val = dlt * s;
+        } else {                                   // (x'_c, x'_c'), c > c'
+          const int c2 = bidx[kb];
+          double s = a.Gam[(long)cc * a.ldGam + c2];
+          for (int l = 0; l < e15; ++l) s += E0[l + ec * cc] * Ut[l + 15L * c2] + Ut[l + 15L * cc] * E0[l + ec * c2];
+          val = a.v_var * g0(cc, c2) + dlt * s;
         }
-      });
+      } else {
+        const int ah = ka - na - nb, h = 15 + bidx[ka];
+        if (kb < na) val = dlt * Ph[bidx[kb] + ec * ah];                 // (q_h, e_i)
+        else if (kb < na + nb) {                   // (q_h, x'_c): q_h^T x'_c = R(h, c)
+          const int cc = bidx[kb];
+          double s = Qh[cc + (long)n * ah];
+          for (int l = 0; l < e15; ++l) s -= E0[l + ec * cc] * Ph[l + ec * ah];
+          val = a.v_var * (cc + 15 >= h ? E[h + ec * cc] : 0.0) + dlt * s;
+        } else {                                   // (q_h, q_h')
+          const int a2 = kb - na - nb;
+          double s = 0;
+          for (int i = 0; i < e; ++i) s += Th[i + ec * a2] * Ph[i + ec * ah];
+          for (int l = 0; l < n; ++l) s += Yh[l + (long)n * a2] * Qh[l + (long)n * ah];
+          val = (ah == a2 ? a.v_var : 0.0) + dlt * s;
+        }
+      }
+      a.Z[ka + ldz * kb] = val;
     });
-  barrier(c);
-  tick(c, 13);
-  if (m > e) syrk_lower(c, Hu, ldh, n, mobs, [&](int i, int j, double sv2) { Gam[i + (long)n * j] = sv2; Gam[j + (long)n * i] = sv2; });
-  else par_for(c, (long)n * n, [&](long x) { Gam[x] = 0.0; });
-  tick(c, 14);
-  // the tracks that own explicit rows: G_E^T G_E blocks, and G_E^T Hu for the one with rows on both sides of e
-  for (int t = topt[0]; t <= topt[e - 1]; ++t) {
-    if (!(a.status[t] & a.inc_bit)) continue;
-    const int M = a.M[t], rho = 2 * M - 3, r0 = a.row0[t], g0 = a.obs0[t];
-    int kE = e - r0; kE = kE < 0 ? 0 : (kE > rho ? rho : kE);
-    par_for(c, (long)kE * kE, [&](long x) {
-      const int i2 = (int)(x / kE), i1 = (int)(x - (long)i2 * kE);
-      double sacc = 0;
-      for (int o = 0; o < M; ++o) sacc += At[(long)(r0 + i1) * 2 * a.m_cap + 2 * o] * At[(long)(r0 + i2) * 2 * a.m_cap + 2 * o];
-      See[(r0 + i1) + ec * (r0 + i2)] = sacc;
+    par_for(c, (long)nr * n1, [&](long x) {
+      const int j = (int)(x / nr), k = (int)(x - (long)j * nr);
+      double val;
+      if (k < na) val = E0[bidx[k] + ec * j];
+      else if (k < na + nb) { const int cc = bidx[k]; val = cc >= j ? g0(cc, j) : g0(j, cc); }
+      else { const int h = 15 + bidx[k]; val = (j == n || j + 15 >= h) ? E[h + ec * j] : 0.0; }
+      a.TH[k + rc * j] = val;
     });
-    if (m > e && kE < rho)
-      par_for(c, (long)kE * n, [&](long x) {
-        const int col = (int)(x / kE), i1 = (int)(x - (long)col * kE);
-        const double* hh = Hu + g0 + ldh * col;
-        double sacc = 0;
-        for (int o = 0; o < M; ++o) sacc += At[(long)(r0 + i1) * 2 * a.m_cap + 2 * o] * hh[o];
-        Seb[(r0 + i1) + ec * col] = sacc; SebT[col + (long)n * (r0 + i1)] = sacc;
-      });
   }
-  barrier(c);
-  tick(c, 7);
-  // ---- G^T G = Tq^T (See Tq + Seb Yq) + Yq^T (Seb^T Tq + Gam Yq)
-  // See is block diagonal (an explicit row meets only the rows of its own track) and Seb has rows only for the one track
-  // that has rows on both sides of e
-  // All as LDS-staged products over the dense matrices (the entries outside See's blocks and Seb's rows are exact zeros: the
-  // sums are the same): one thread per entry with a loop over the rows of the entry's track paid a memory round trip per term
-  // (1.4 ms for P1 alone)
-  const int ts = topt[e - 1], rs = a.row0[ts];           // the track of the last explicit row: the only one that can straddle
-  const bool straddle = m > e && rs + 2 * a.M[ts] - 3 > e;
-  atb(c, See, ec, e, Tq, ec, nr, e, [&](int i, int ka, double v) { P1[i + ec * ka] = v; });
-  barrier(c);
-  tick(c, 15);
-  if (straddle) atb(c, SebT, n, e, Yq, n, nr, n, [&](int i, int ka, double v) { P1[i + ec * ka] += v; });
-  // P3 = Gam Yq (+ Seb^T Tq from the rows of the one track that has rows on both sides of e); G^T G = Tq^T P1 + Yq^T P3
-  if (m > e) atb(c, Gam, n, n, Yq, n, nr, n, [&](int i, int ka, double v) { P3[i + (long)n * ka] = v; });
-  else par_for(c, (long)n * nr, [&](long x) { P3[x] = 0.0; });
-  barrier(c);
-  if (straddle) atb(c, Seb, ec, n, Tq, ec, nr, e, [&](int i, int ka, double v) { P3[i + (long)n * ka] += v; });
-  barrier(c);
-  const long ldz = a.ldz;
-  const double dlt = a.u_var - a.v_var;
-  atb_lower(c, Tq, ec, nr, P1, ec, e, [&](int ka, int kb, double v) { a.Z[ka + ldz * kb] = v; });
-  barrier(c);
-  if (m > e) atb_lower(c, Yq, n, nr, P3, n, n, [&](int ka, int kb, double v) { a.Z[ka + ldz * kb] += v; });
-  barrier(c);
-  par_for(c, (long)nr * nr, [&](long x) {
-    const int kb = (int)(x / nr), ka = (int)(x - (long)kb * nr);
-    if (ka >= kb) a.Z[ka + ldz * kb] = dlt * a.Z[ka + ldz * kb] + (ka == kb ? a.v_var : 0.0);
-  });
   barrier(c);
   tick(c, 8);
   information_from_rn(c, a, n, nr);

@@ -35,11 +35,36 @@ extern "C" int lit_host_compress(int F, int m_cap, int N, const int* included, c
   a.W2 = W2.data();
   a.LamIn = LamIn; a.lam_part = 0; a.gram_parts = 1;
   a.Lam = Lam; a.ldL = n + 1; a.info = info8;
+  // Gam = sum over the stacked tracks of (u-rows of the projected Jacobian)^T (the same): on the device k_lit_pre writes six
+  // rows per track (a wavefront per track) and k_lit_gamma multiplies them on the matrix cores; here the serial reference of the
+  // rows (literal_core.h: gamma_rows, after the tracks' null spaces) and plain loops
+  std::vector<double> Gam((size_t)(n + 1) * (n + 1), 0.0);
+  a.Gam = Gam.data(); a.ldGam = n + 1;
+  if (route != 1) {
+    std::vector<double> rows((size_t)6 * (n + 8));
+    const long ldc = n + 8;
+    for (int t = 0; t < F; ++t) {
+      if (!included[t]) continue;
+      track_null_space(a, t);
+      std::fill(rows.begin(), rows.end(), 0.0);
+      gamma_rows(a, t, rows.data(), ldc);
+      for (int o = 0; o < M[t]; ++o) {                       // Du: u-row of the observation's 2 x 6 block, squared
+        const int col = 6 * slots[(size_t)t * m_cap + o];
+        for (int x = 0; x < 6; ++x) for (int y = 0; y <= x; ++y) Gam[(size_t)(col + x) * (n + 1) + col + y] += Hx[((size_t)t * m_cap + o) * 12 + x] * Hx[((size_t)t * m_cap + o) * 12 + y];
+      }
+      for (int hi = 0; hi < n; ++hi)
+        for (int lo = 0; lo <= hi; ++lo) {
+          double sacc = 0;
+          for (int x = 0; x < 3; ++x) sacc += rows[x * ldc + hi] * rows[(3 + x) * ldc + lo] + rows[(3 + x) * ldc + hi] * rows[x * ldc + lo];
+          Gam[(size_t)hi * (n + 1) + lo] -= sacc;
+        }
+    }
+  }
   Ctx c;
   // what the device has as LDS (kernels_literal.hip: LIT_LDS_DOUBLES); LIT_HOST_STAGE overrides the size (tests: the blocked
   // elimination must give the same matrix with narrower panels and with none)
   const char* se = getenv("LIT_HOST_STAGE");
-  std::vector<double> stage((size_t)(se ? atol(se) : 8000));
+  std::vector<double> stage((size_t)(se ? atol(se) : 12000));
   c.lds = stage.data(); c.lds_doubles = (int)stage.size();
   literal_compress(c, a, route);
   if (TH_out) for (size_t i = 0; i < (size_t)(n + 15) * (n + 1); ++i) { const size_t col = i / (n + 15), row = i % (n + 15); TH_out[i] = TH[row + (size_t)a.r_cap * col]; }
