@@ -209,6 +209,7 @@ def main():
     ap.add_argument("--trajectories", type=int, default=0, help="trajectories per GPU (default: the configuration's)")
     ap.add_argument("--repeats", type=int, default=-1, help="timed K-step windows in all (default: until >= 0.5 s of timed region, 3..12)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="default run only: skip the short passes of BASELINE's other configurations (other_configs in the JSON line)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--streams", type=int, default=4, help="HIP streams for the timed region (slices of the batch run concurrently)")
     ap.add_argument("--no-early-accept-pass", action="store_true", help="skip the extra measurement with the gate early accept (profiling runs)")

@@ -52,6 +52,10 @@ enum { STAT_ERR_NCAP = 1, STAT_ERR_PIVOT = 2 };
 struct LitBufs {
   double* X = nullptr; double* tau = nullptr; double* Vf = nullptr; double* Tf = nullptr; double* TH = nullptr; double* G = nullptr; double* Z = nullptr; double* W2 = nullptr;
   int* row0 = nullptr; int* obs0 = nullptr; int* otrk = nullptr; int* kept = nullptr; int* info = nullptr;
+  double* BD = nullptr;       // [B][f_cap][6][ldR] per track: Q_f^T H_x (3 rows) and D (3 rows), inside the track's slot range (k_lit_pre -> k_lit_gamma)
+  double* Gam = nullptr;      // [B][ldR][ldR] lower triangle, (hi, lo) at hi * ldR + lo: sum over the stacked tracks of (u-rows of the projected Jacobian)^T (the same)
+  double* Du = nullptr;       // [B][n_cap][24] per camera slot: upper triangle of sum h_u^T h_u (21)
+  int serial = 0;             // MSCKF_HIP_LITERAL_SERIAL=1: k_lit_pre's per-track part on one lane with literal_core.h's serial reference (A/B runs)
   long long* tim = nullptr;   // [B][16] phase stamps of k_literal (100 MHz wall clock), only with MSCKF_HIP_LITERAL_TIMERS=1
   int ldx = 0, r_cap = 0, ldg = 0, ldz = 0, kept_stride = 0;
   long w2_stride = 0;
@@ -413,6 +417,8 @@ void feature_device_setup();
 void qr_device_setup();
 void kalman_device_setup();
 void gram_device_setup();
+void literal_device_setup();
+long lit_ws_doubles(int n6, int m_cap, int r_cap);   // per-trajectory scratch of k_literal (doubles)
 
 }  // namespace msckf
 #endif

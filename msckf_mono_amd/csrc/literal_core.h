@@ -42,6 +42,7 @@ namespace lit {
 
 #ifdef LIT_HOST
 #define LIT_FN inline
+#define LIT_HD inline
 struct Ctx { int tid = 0, nt = 1, lane = 0, wave = 0, nw = 1; double* red = nullptr; double* lds = nullptr; int lds_doubles = 0; };   // lds: the device's staging area, a heap block here
 LIT_FN void barrier(const Ctx&) {}
 template <class F> LIT_FN void par_for(const Ctx&, long n, F f) { for (long i = 0; i < n; ++i) f(i); }
@@ -99,6 +100,7 @@ LIT_FN void wave_sync(const Ctx&) {}
 template <class P> LIT_FN int compact_list(const Ctx&, int n, int* out, P pred) { int cnt = 0; for (int i = 0; i < n; ++i) if (pred(i)) out[cnt++] = i; return cnt; }
 #else
 #define LIT_FN __device__ __forceinline__
+#define LIT_HD __host__ __device__ inline
 struct Ctx { int tid, nt, lane, wave, nw; double* red; long long* tim; double* lds; int lds_doubles; };   // red: LDS scratch, nw + 2 doubles; tim: phase stamps (100 MHz) or null; lds: staging area
 LIT_FN void barrier(const Ctx&) { __syncthreads(); }
 template <class F> LIT_FN void par_for(const Ctx& c, long n, F f) { for (long i = c.tid; i < n; i += c.nt) f(i); }
@@ -799,7 +801,7 @@ LIT_FN double lam_in(const Args<HT>& a, int hi, int lo) {   // hi >= lo
 // on the matrix cores, kernels_literal.hip: k_lit_gamma).  For e_i and x'_c only the first 15 rows of t~ are non-zero and
 // y is a unit vector: Gam enters through its (C, C) submatrix, no product.  Lam^ then comes out of the blocked elimination
 // of Z = [[Bs^T R_o Bs, .], [(Bs^T A)^T, 0]] (information_from_rn).
-LIT_FN long compact_ws_doubles(int n, int m_cap, int r_cap, int /*ldg*/) {
+LIT_HD long compact_ws_doubles(int n, int m_cap, int r_cap, int /*ldg*/) {
   const long n1 = n + 1, ec = 15 + n;
   return 2 * ec * n1 + ec * 2L * m_cap + 2 * n1 * n1 + 2 * n1 + ec * ec + ec * (long)n + 15L * n + 4 * ec
        + 3L * n * n + 2 * ec * (long)n + 2L * n * n + 128;
@@ -1432,9 +1434,10 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
 
 // route: 0 (default) = the compact route; 1 = the sweep over the dense stack (needs its work space X, G: tests and A/B runs)
 template <class HT>
-LIT_FN void literal_compress(const Ctx& c, const Args<HT>& a, const int route = 0) {
+LIT_FN void literal_compress(const Ctx& c, const Args<HT>& a, const int route = 0, const bool prepared = false) {
   tick(c, 0);
-  const int m = prepare(c, a);
+  // prepared: the offsets, V / T of every stacked track and the info block are there already (kernels_literal.hip: k_lit_pre)
+  const int m = prepared ? a.row0[a.F] : prepare(c, a);
   if (m <= 0) return;
   const int mobs = a.obs0[a.F];
   if (route != 1 || !a.X || !a.G) { literal_compact(c, a, m, mobs); return; }

@@ -282,7 +282,7 @@ struct Batch : BatchBase {
   }
   int create() {
     HIPCHK(hipSetDevice(device));
-    feature_device_setup(); qr_device_setup(); kalman_device_setup(); gram_device_setup();   // per device: constant tables, dynamic-LDS limits
+    feature_device_setup(); qr_device_setup(); kalman_device_setup(); gram_device_setup(); literal_device_setup();   // per device: constant tables, dynamic-LDS limits
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     for (int i = 0; i < NSTG; ++i) HIPCHK(hipEventCreateWithFlags(&ev_stage[i], hipEventDisableTiming));
@@ -454,12 +454,13 @@ struct Batch : BatchBase {
     rc |= dalloc(&L.Vf, Bz * f_cap * 2 * m_cap * 3); rc |= dalloc(&L.Tf, Bz * f_cap * 9);
     rc |= dalloc(&L.row0, Bz * (f_cap + 1)); rc |= dalloc(&L.obs0, Bz * (f_cap + 1)); rc |= dalloc(&L.otrk, Bz * L.ldg); rc |= dalloc(&L.kept, Bz * L.kept_stride);
     rc |= dalloc(&L.TH, Bz * L.r_cap * n1); rc |= dalloc(&L.Z, Bz * (size_t)L.ldz * L.ldz);
-    { const long nn = d.n6cap, ecc = 15 + nn, rcc = L.r_cap;   // = lit::compact_ws_doubles(6 n_cap, m_cap, r_cap), literal_core.h
-      L.w2_stride = ecc * (nn + 1) + ecc * 2L * m_cap + (nn + 1) * (nn + 1) + 4L * nn * nn + 2 * (ecc * rcc + nn * rcc) + ecc * ecc + 4 * ecc * nn + ecc * rcc + nn * rcc + (long)L.ldg * nn + 64; }
+    L.w2_stride = lit_ws_doubles(d.n6cap, m_cap, L.r_cap);
     rc |= dalloc(&L.W2, Bz * (size_t)L.w2_stride);
     // the sweep over the dense stack (MSCKF_HIP_LITERAL_ROUTE=1: tests, A/B runs) needs the stack itself and the u-rows of A Q_1
     if (lit_route == 1) { rc |= dalloc(&L.X, Bz * L.ldx * n1); rc |= dalloc(&L.G, Bz * (size_t)L.ldg * L.r_cap); }
     rc |= dalloc(&L.info, Bz * 8);
+    rc |= dalloc(&L.BD, Bz * f_cap * 6 * (size_t)d.ldR); rc |= dalloc(&L.Gam, Bz * (size_t)d.ldR * d.ldR); rc |= dalloc(&L.Du, Bz * n_cap * 24);
+    if (const char* e = getenv("MSCKF_HIP_LITERAL_SERIAL")) L.serial = atoi(e);
     if (const char* e = getenv("MSCKF_HIP_LITERAL_TIMERS")) if (atoi(e)) rc |= dalloc(&L.tim, Bz * 16);
     if (rc) { L.W2 = nullptr; return fail(-ENOMEM, "work space of the literal anisotropic route (msckf_hip_set_anisotropic_noise(h, 1, 0) selects pre-whitening)"); }
     return 0;
@@ -490,12 +491,9 @@ struct Batch : BatchBase {
       long long t[16];
       HIPCHK(hipMemcpyAsync(t, d.lit.tim + (size_t)b * 16, sizeof(t), hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
-      std::fprintf(stderr, "[k_literal b=%d] us: prepare %.0f explicit rows %.0f Gram %.0f sweep %.0f kept+Gv %.0f Q columns %.0f per-track sums %.0f G^T G %.0f Z fill %.0f eliminate %.0f store %.0f\n", b,
-                   (t[1] - t[0]) * 0.01, (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01, (t[5] - t[4]) * 0.01, (t[6] - t[5]) * 0.01,
-                   (t[7] - t[6]) * 0.01, (t[8] - t[7]) * 0.01, (t[10] - t[8]) * 0.01, (t[11] - t[10]) * 0.01, (t[9] - t[11]) * 0.01);
-      if (t[12] && t[13] && t[14] && t[15])
-        std::fprintf(stderr, "[k_literal b=%d] us: per-track sums = zero fill %.0f + H_u %.0f + H_u^T H_u %.0f + explicit tracks %.0f; G^T G = P1, P3 %.0f + rest\n", b,
-                     (t[12] - t[6]) * 0.01, (t[13] - t[12]) * 0.01, (t[14] - t[13]) * 0.01, (t[7] - t[14]) * 0.01, (t[15] - t[7]) * 0.01);
+      std::fprintf(stderr, "[k_literal b=%d] us: explicit rows %.0f Gram %.0f sweep %.0f kept %.0f handed-through rows %.0f basis products %.0f Z fill %.0f eliminate %.0f store %.0f total %.0f\n", b,
+                   (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01, (t[5] - t[4]) * 0.01, (t[6] - t[5]) * 0.01,
+                   (t[8] - t[6]) * 0.01, (t[10] - t[8]) * 0.01, (t[11] - t[10]) * 0.01, (t[9] - t[11]) * 0.01, (t[9] - t[0]) * 0.01);
     }
     return 0;
   }

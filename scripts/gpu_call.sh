@@ -1,28 +1,64 @@
-# One gpurun call that validates a tree and collects a round's evidence (from the repo root on the GPU box):
-#   TAG=r04_a PMC_COMMIT=$(git rev-parse --short HEAD) /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash scripts/gpu_call.sh'
-# ~6 GPU-minutes: GPU parity tests, smoke, default bench + cfg2 + cfg4 + cfg5, variant sweep, kernel stats + PMC passes.
+# One gpurun call, parametrised (from the repo root on the GPU box):
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'TAG=r05_a STEPS="lit_tests lit_timers cfg4" bash scripts/gpu_call.sh'
+# STEPS (any subset, run in this order):
+#   tests        the whole GPU suite (pytest -m gpu)            lit_tests   tests/test_gpu_literal.py + test_gpu_vs_reference.py only
+#   pytest:<args> pytest with the given arguments (one token: use commas for spaces)
+#   smoke        __graft_entry__.smoke()
+#   bench        default bench.py (cfg3, the driver's line)     cfgs        cfg2, cfg4 (literal + whitened), cfg5 as their own lines
+#   cfg4         bench.py --config cfg4 (literal route) only    lit_timers  phase timers of k_literal at B = 8 and 128 (cfg4 geometry)
+#   sweep        scripts/sweep_variants.py (streams / streamed) profile     scripts/profile_round.sh (kernel stats + PMC passes of cfg3)
+#   lit_profile  rocprofv3 kernel stats + PMC passes of bench.py --config cfg4 (literal route)
+#   cfg2_profile rocprofv3 kernel stats of bench.py --config cfg2
 # Outputs land in gpurun_out/$TAG; copy what is to be judged into profiles/ by hand (profiles/README.md lists them).
 cd /root/repo
 TAG=${TAG:-round}
+STEPS=${STEPS:-"tests smoke bench cfgs sweep profile"}
 O=gpurun_out/$TAG; mkdir -p $O
-timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $O/pytest.txt
-tail -4 $O/pytest.txt
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-python bench.py > $O/bench.json 2> $O/bench.err
-python bench.py --config cfg2 --steps 20 --warmup 5 > $O/bench_cfg2.json 2>/dev/null
-python bench.py --config cfg4 --steps 10 --warmup 3 --no-cpu-baseline --no-early-accept-pass > $O/bench_cfg4.json 2>/dev/null
-python bench.py --config cfg4 --steps 20 --warmup 5 --no-cpu-baseline --no-early-accept-pass --aniso-mode 1 > $O/bench_cfg4_whitened.json 2>/dev/null
-python bench.py --config cfg5 --steps 10 --warmup 3 --no-cpu-baseline --no-early-accept-pass > $O/bench_cfg5.json 2>/dev/null
-python - <<PY
-import json
-for f in ["bench", "bench_cfg2", "bench_cfg4", "bench_cfg4_whitened", "bench_cfg5"]:
+has() { case " $STEPS " in *" $1 "*) return 0;; esac; return 1; }
+summ() { python - "$@" <<PY
+import json, sys
+for f in sys.argv[1:]:
     try:
         j = json.loads(open("$O/%s.json" % f).read().strip().splitlines()[-1])
-        print(f, round(j["value"]), round(j.get("repeats", {}).get("median", 0)), round((j.get("resident_inputs") or {}).get("median", 0)), "frac", j["roofline"].get("frac"))
+        r = j.get("roofline", {})
+        print(f, round(j["value"]), "ms/step", round(j["ms_per_step"], 4), "median", round(j.get("repeats", {}).get("median", 0)), "min", round(j.get("repeats", {}).get("min", 0)), "kernel", r.get("kernel"), "frac", r.get("frac"), {k: round(x, 4) for k, x in (r.get("stage_ms_per_step") or {}).items()})
     except Exception as e:
         print(f, "failed", e)
 PY
-python scripts/sweep_variants.py --steps 20 --windows 5 "streams=4,streamed=0" "streams=4,streamed=1" "streams=1,streamed=0" > $O/sweep.txt 2>&1
-cut -c1-250 $O/sweep.txt
-TAG=$TAG PMC_COMMIT=${PMC_COMMIT:-unknown} bash scripts/profile_round.sh > $O/profile_round.log 2>&1
-head -12 $O/kernel_stats_tail20.md
+}
+for s in $STEPS; do case $s in pytest:*) a=${s#pytest:}; timeout 1800 python -m pytest ${a//,/ } 2>&1 | tail -15 > $O/pytest_sel.txt; tail -6 $O/pytest_sel.txt;; esac; done
+if has tests; then timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $O/pytest.txt; tail -4 $O/pytest.txt; fi
+if has lit_tests; then timeout 1500 python -m pytest tests/test_gpu_literal.py tests/test_gpu_vs_reference.py -m gpu -x -q 2>&1 | tail -12 > $O/pytest_lit.txt; tail -6 $O/pytest_lit.txt; fi
+if has smoke; then python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1; fi
+if has lit_timers; then MSCKF_HIP_LITERAL_TIMERS=1 python scripts/lit_timers.py 2>&1 | tail -14 | tee $O/lit_timers.txt; fi
+if has bench; then python bench.py > $O/bench.json 2> $O/bench.err; summ bench; fi
+if has cfg4; then python bench.py --config cfg4 --steps 10 --warmup 3 --no-cpu-baseline --no-early-accept-pass --no-other-configs > $O/bench_cfg4.json 2> $O/bench_cfg4.err; summ bench_cfg4; fi
+if has cfgs; then
+  python bench.py --config cfg2 --steps 20 --warmup 5 --no-other-configs > $O/bench_cfg2.json 2>/dev/null
+  python bench.py --config cfg4 --steps 10 --warmup 3 --no-cpu-baseline --no-early-accept-pass --no-other-configs > $O/bench_cfg4.json 2>/dev/null
+  python bench.py --config cfg4 --steps 20 --warmup 5 --no-cpu-baseline --no-early-accept-pass --no-other-configs --aniso-mode 1 > $O/bench_cfg4_whitened.json 2>/dev/null
+  python bench.py --config cfg5 --steps 10 --warmup 3 --no-cpu-baseline --no-early-accept-pass --no-other-configs > $O/bench_cfg5.json 2>/dev/null
+  summ bench_cfg2 bench_cfg4 bench_cfg4_whitened bench_cfg5
+fi
+if has sweep; then python scripts/sweep_variants.py --steps 20 --windows 5 "streams=4,streamed=0" "streams=4,streamed=1" "streams=1,streamed=0" > $O/sweep.txt 2>&1; cut -c1-250 $O/sweep.txt; fi
+if has profile; then TAG=$TAG PMC_COMMIT=${PMC_COMMIT:-unknown} bash scripts/profile_round.sh > $O/profile_round.log 2>&1; head -12 $O/kernel_stats_tail20.md; fi
+if has lit_profile || has cfg2_profile; then
+  cd /tmp && export TMPDIR=/tmp
+  if has lit_profile; then
+    C4="--config cfg4 --steps 6 --warmup 2 --no-cpu-baseline --no-early-accept-pass --no-upload-pass --no-other-configs --repeats 1 --streams 1"
+    rocprofv3 --kernel-trace --stats -d /tmp/q1 -o r -- python /root/repo/bench.py $C4 > /tmp/c1.log 2>&1
+    python /root/repo/scripts/rocpd_summary.py $(find /tmp/q1 -name "*.db" | head -1) /root/repo/$O/kernel_stats_cfg4_literal.md > /dev/null
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/q2 -o r -- python /root/repo/bench.py $C4 > /tmp/c2.log 2>&1
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/q3 -o r -- python /root/repo/bench.py $C4 > /tmp/c3.log 2>&1
+    rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD --kernel-trace -d /tmp/q4 -o r -- python /root/repo/bench.py $C4 > /tmp/c4.log 2>&1
+    rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_ACTIVE_INST_LDS --kernel-trace -d /tmp/q5 -o r -- python /root/repo/bench.py $C4 > /tmp/c5.log 2>&1
+    python /root/repo/scripts/rocpd_pmc.py /root/repo/$O/pmc_cfg4_literal.md $(find /tmp/q2 /tmp/q3 /tmp/q4 /tmp/q5 -name "*.db") > /dev/null
+    head -14 /root/repo/$O/kernel_stats_cfg4_literal.md
+  fi
+  if has cfg2_profile; then
+    rocprofv3 --kernel-trace --stats -d /tmp/q6 -o r -- python /root/repo/bench.py --config cfg2 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > /tmp/c6.log 2>&1
+    python /root/repo/scripts/rocpd_summary.py $(find /tmp/q6 -name "*.db" | head -1) /root/repo/$O/kernel_stats_cfg2_f64.md > /dev/null
+    head -14 /root/repo/$O/kernel_stats_cfg2_f64.md
+  fi
+  cd /root/repo
+fi
