@@ -96,6 +96,22 @@ def executed_flops_update(Ms, N, K_imu=K_IMU):
                 propagate=float(propagate), augment=float(augment))
 
 
+def literal_flops_update(Ms, N):
+    """FLOP (f64, 2 per FMA) of the literal anisotropic compression AS BUILT (kernels_literal.hip) for one update -> dict per launch.
+    k_lit_pre: pivoted QR of H_f (2M x 3) + six rows of 6M entries per track; k_lit_gamma: 12 contraction rows per pair of
+    tracks against the lower triangle of an n x n matrix (6 n^2 per track); k_literal: explicit rows (e x 12 M), the sweep on
+    [explicit rows ; Gram matrix] (per step a rank-1 update of each: 2 (e - p)(n + 1 - k) + (n + 1 - k)^2), the basis products
+    (~90 per entry of an r x r matrix) and the elimination of the r pivots of the (r + n + 1)-square Z (sum (nz - k)^2)."""
+    Ms = np.asarray(Ms, dtype=np.float64)
+    n = 6.0 * N; n1 = n + 1; e = 15 + n; r = e - 13
+    k = np.arange(int(n)); p = 15 + k
+    sweep = float(np.sum(2 * (e - p) * (n1 - k) + (n1 - k) ** 2))
+    nz = r + n1
+    elim = float(np.sum((nz - np.arange(int(r))) ** 2))
+    return dict(lit_pre=float(np.sum(2 * (2 * Ms) * 9 * 2 + 6 * 6 * Ms * 14)), lit_gamma=float(len(Ms) * 6 * n * n),
+                literal=float(e * 12 * np.mean(Ms) * 2 + sweep + 90 * r * r + elim))
+
+
 def alg_bytes_update(Ms, N, s=4, K_imu=K_IMU):
     D = 15 + 6 * N
     return 2 * D * D * s + float(np.sum(2 * np.asarray(Ms)) * s) + 7 * N * s + D * s + 7 * K_imu * s
@@ -210,6 +226,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=-1, help="timed K-step windows in all (default: until >= 0.5 s of timed region, 3..12)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="default run only: skip the short passes of BASELINE's other configurations (other_configs in the JSON line)")
+    ap.add_argument("--parity-samples", type=int, default=0, help="with --no-cpu-baseline: still run the CPU oracle on this many sampled trajectories for ate_vs_ref (0 = none)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--streams", type=int, default=4, help="HIP streams for the timed region (slices of the batch run concurrently)")
     ap.add_argument("--no-early-accept-pass", action="store_true", help="skip the extra measurement with the gate early accept (profiling runs)")
@@ -381,6 +398,9 @@ def main():
     pass_rate = float(np.mean([s["n_passed"] / max(s["n_tracks"], 1) for s in stats]))
     fl = dict(feature=0.0, compress=0.0, kalman=0.0, propagate=0.0, augment=0.0, gram=0.0)
     ex = dict(feature=0.0, compress_stage1=0.0, compress_merge=0.0, kalman=0.0, propagate=0.0, augment=0.0)
+    lit_on = (not c["iso"]) and args.aniso_mode == 0
+    if lit_on:
+        ex.update(lit_pre=0.0, lit_gamma=0.0, literal=0.0)
     by = 0.0
     up_bytes = 0.0
     for tr in trajs:
@@ -389,6 +409,8 @@ def main():
             for k2 in fl:
                 fl[k2] += one[k2] / (K * B_TRAJ)
             one = executed_flops_update(tr.frames[ff]["M"], N_WIN)
+            if lit_on:
+                one.update(literal_flops_update(tr.frames[ff]["M"], N_WIN))
             for k2 in ex:
                 ex[k2] += one[k2] / (K * B_TRAJ)
             by += alg_bytes_update(tr.frames[ff]["M"], N_WIN) / (K * B_TRAJ)
@@ -434,7 +456,7 @@ def main():
         # utilisation on EXECUTED work: the FLOP of the algorithm as built per stage / the stage's HIP-event time / the peak
         # of the arithmetic the stage runs in (f64 matrix cores for the information-form compression, f32 elsewhere)
         ex_peak = dict(feature=PEAK_F32_TFLOPS, compress_stage1=PEAK_F64_TFLOPS, compress_merge=PEAK_F64_TFLOPS, kalman=PEAK_F32_TFLOPS,
-                       propagate=PEAK_F32_TFLOPS, augment=PEAK_F32_TFLOPS)
+                       propagate=PEAK_F32_TFLOPS, augment=PEAK_F32_TFLOPS, lit_pre=PEAK_F64_TFLOPS, lit_gamma=PEAK_F64_TFLOPS, literal=PEAK_F64_TFLOPS)
         executed_model = {}
         for k2, flop in ex.items():
             t_ms = stage_ms.get(k2, 0.0)
@@ -456,12 +478,22 @@ def main():
             "k_propagate": dict(ms=stage_ms["propagate"], flops=fl["propagate"], bound="valu", peak=PEAK_F32_TFLOPS,
                                 why="sequential 15x15 chain per trajectory: latency bound"),
         }
+        if lit_on:      # the three launches of the literal anisotropic compression, each with its own event pair in the profiled pass
+            kernels["k_literal"] = dict(ms=stage_ms["literal"], flops=ex["literal"], bound="valu", peak=PEAK_F64_TFLOPS,
+                                        why="one workgroup per trajectory: explicit rows, the Householder sweep for its decisions in LDS panels of 16, "
+                                            "the basis products and the blocked elimination of R_n -- f64 vector arithmetic on 128 of 256 compute units, "
+                                            "bound by the panels' dependent phases (barriers, LDS and L2 round trips), not by arithmetic")
+            kernels["k_lit_gamma"] = dict(ms=stage_ms["lit_gamma"], flops=ex["lit_gamma"], bound="mfma", peak=PEAK_F64_TFLOPS,
+                                          why="H_u^T H_u as a sum of rank-6 terms per track on v_mfma_f64_16x16x4, operands straight from L2: load-latency bound")
+            kernels["k_lit_pre"] = dict(ms=stage_ms["lit_pre"], flops=ex["lit_pre"], bound="valu", peak=PEAK_F64_TFLOPS,
+                                        why="a wavefront per track: pivoted QR of a 2M x 3 block in registers + six rows of output: latency / store bound")
         dom = max(kernels, key=lambda k2: kernels[k2]["ms"])
         kd = kernels[dom]
         dom_flops = kd["flops"] * B_TRAJ
         achieved = dom_flops / (kd["ms"] * 1e-3) / 1e12 if kd["ms"] > 0 else 0.0
         pmc, pmc_meta = pmc_block(dom)
-        dom_stage = {"k_feature": "feature", "k_gram": "compress_stage1", "k_chol_mfma": "compress_merge", "k_propagate": "propagate"}[dom]
+        dom_stage = {"k_feature": "feature", "k_gram": "compress_stage1", "k_chol_mfma": "compress_merge", "k_propagate": "propagate",
+                     "k_literal": "literal", "k_lit_gamma": "lit_gamma", "k_lit_pre": "lit_pre"}[dom]
         frac = achieved / kd["peak"]
         whole_frac = f_update * value / 1e12 / world / PEAK_F32_TFLOPS
         out = {
@@ -518,17 +550,59 @@ def main():
                 "value": world * B_TRAJ * K / (early_ms * 1e-3 * K), "ms_per_step": early_ms,
                 "note": "same K steps measured again with msckf_hip_set_gate_early_accept(1): exact bound gamma <= |r_o|^2/sigma^2, identical results; not the headline value"},
         }
-        if not args.no_cpu_baseline and world == 1 and args.config != "cfg5":
-            out["cpu_baseline"] = cpu_baseline(trajs[0], fill + W, args.cpu_seconds, N_WIN)
-            out.update(ate_vs_reference(trajs, sample, p_dev_sample, f_end_timed, N_WIN, anisotropic=not c["iso"], literal=args.aniso_mode == 0))
+        if world == 1 and args.config != "cfg5":
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(trajs[0], fill + W, args.cpu_seconds, N_WIN)
+            if not args.no_cpu_baseline or args.parity_samples > 0:
+                smp = sample if args.no_cpu_baseline is False else sample[:max(1, args.parity_samples)]
+                out.update(ate_vs_reference(trajs, smp, p_dev_sample, f_end_timed, N_WIN, anisotropic=not c["iso"], literal=args.aniso_mode == 0))
         elif args.config == "cfg5":
             out["cpu_baseline"] = None
             out["cpu_baseline_note"] = ("not run at this size: one update of the reference's algorithm on a 60-camera / 500-track window builds a "
                                         "~28 000 x 28 000 Q (minutes and > 3 GB per filter); parity at this geometry is held by the -m gpu tests")
+        # BASELINE.json's other configurations, shortened, in the same line (the default run only: cfg3, one GPU)
+        if args.config == "cfg3" and world == 1 and streamed and not args.no_other_configs and args.trajectories <= 0:
+            bt.close()
+            out["other_configs"] = run_other_configs()
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_other_configs():
+    """Short passes of BASELINE.json's other configurations after the default (cfg3) measurement, each as its own process of this
+    script: cfg2 (one double filter through the shim), cfg4 on the literal anisotropic route and pre-whitened, cfg5 (60-camera
+    window, fp16 Jacobian) -> {name: {value, ms_per_step, dtype, workload, roofline: {kernel, frac, peak, bound}, parity, wall_s}}.
+    A pass that fails or runs over its limit is reported as such; it never takes the headline line with it."""
+    import subprocess
+    lit = ["--config", "cfg4", "--steps", "10", "--warmup", "3", "--repeats", "3", "--no-cpu-baseline", "--no-early-accept-pass", "--parity-samples", "2"]
+    specs = [("cfg2", ["--config", "cfg2", "--steps", "20", "--warmup", "5", "--repeats", "3", "--no-cpu-baseline"]),
+             ("cfg4_literal", lit), ("cfg4_whitened", lit + ["--aniso-mode", "1"]),
+             ("cfg5", ["--config", "cfg5", "--steps", "5", "--warmup", "2", "--repeats", "2", "--no-cpu-baseline", "--no-early-accept-pass"])]
+    res = {}
+    for name, extra in specs:
+        t0 = time.time()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-other-configs"] + extra, capture_output=True, text=True, timeout=300)
+            j = json.loads(r.stdout.strip().splitlines()[-1])
+            rf = j.get("roofline") or {}
+            if name == "cfg2":
+                parity = j.get("parity")
+            elif name == "cfg5":
+                parity = "no CPU leg at this size (cpu_baseline_note); held by tests/test_gpu_configs.py and tests/test_gpu_vs_reference.py (-m gpu)"
+            else:
+                parity = {k2: j.get(k2) for k2 in ("ate_vs_ref_m", "ate_vs_ref_is", "ate_vs_ref_literal_m", "ate_vs_ref_whitened_m", "ate_vs_ref_note")}
+            res[name] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"], "dtype": j["dtype"],
+                         "workload": j["config"]["workload"], "noise": j["config"].get("noise"),
+                         "repeats_median": (j.get("repeats") or {}).get("median"),
+                         "roofline": {"kernel": rf.get("kernel"), "frac": rf.get("frac"), "peak": rf.get("peak"), "bound": rf.get("bound"),
+                                      "kernel_ms": rf.get("kernel_ms_per_step", rf.get("kernel_ms_per_update")), "stage_ms_per_step": rf.get("stage_ms_per_step", rf.get("stage_ms_per_update"))},
+                         "latency_us": (j.get("latency_us") or {}).get("per_update_mean"),
+                         "parity": parity, "wall_s": time.time() - t0}
+        except Exception as ex_:
+            res[name] = {"error": repr(ex_)[:300], "wall_s": time.time() - t0}
+    return res
 
 
 def run_cfg2(args):
@@ -661,7 +735,7 @@ def run_cfg2(args):
         "latency_us": {"per_update_mean": float(frame_us.mean()), "per_update_median": float(np.median(frame_us)), "per_update_max": float(frame_us.max()),
                        "stage_mean": first["stage_us"],
                        "note": "host wall clock around each call of the shim, as the reference's StageTiming (asl_msckf.cpp:229-296); imu_prop = 10 x "
-                               "(propagate + by-value getImuState: a device round trip each); read_state = getImuState + getNumCamStates after the image"},
+                               "(propagate + by-value getImuState, answered from the library's host copy of the IMU state: no device round trip); read_state = getImuState + getNumCamStates after the image"},
         "repeats": {"runs": len(rep_vals), "values": rep_vals, "median": float(np.median(rep_vals)), "min": float(np.min(rep_vals)), "max": float(np.max(rep_vals)),
                     "note": "value = the first run; every run replays fill + warm-up untimed and times the same K frames"},
         "roofline": {"bound": "mfma" if dom_stage != "feature" else "valu", "kernel": dom_kernel, "achieved": model[dom_stage]["tflops"], "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s",
@@ -750,6 +824,9 @@ def ate_vs_reference(trajs, sample, p_dev, n_run, N, anisotropic=False, literal=
            "ate_vs_ref_note": "%d sampled trajectories, free-running from frame 0 to the end of the timed window (%d frames), float CPU oracle "
                               "vs HIP path, %.1f s wall" % (len(sample), n_run, time.time() - t0)}
     if anisotropic:
+        out["ate_vs_ref_note"] += ("; anisotropic noise: the reference's own update is defined only to its rounding envelope there (two roundings of its "
+                                   "source differ by 1e-4 .. 4e-4 on the gyro bias per update, DESIGN.md 3.3) -- the restatement compared here takes the "
+                                   "exact-arithmetic limit of its zero-tail rule (tolerance 8e-4 in float), as the device's literal route does")
         out["ate_vs_ref_literal_m"] = rms([p_dev[b] - res[b] for b in sample])
         out["ate_vs_ref_whitened_m"] = rms([p_dev[b] - resw[b] for b in sample])
         out["ate_vs_ref_is"] = "literal restatement (zero-tail tolerance 8e-4)" if literal else "pre-whitened restatement"

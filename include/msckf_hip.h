@@ -172,6 +172,10 @@ int msckf_hip_sync(msckf_hip_handle h);
  * augmentState separately; otherwise they share one launch.) */
 int msckf_hip_profile_enable(msckf_hip_handle h, int on);
 int msckf_hip_profile_read(msckf_hip_handle h, double* ms8, int* count8);
+/* The same with the stages beyond the first eight (cap >= 8 entries are written, unknown ones as zero): 8 k_lit_pre, 9 k_lit_gamma,
+ * 10 k_literal -- the three launches of the literal anisotropic compression (u_var' != v_var', msckf.h:423-431, 1343-1366;
+ * kernels_literal.hip), which a profiled run brackets one by one (stage 3 is then k_gram alone). */
+int msckf_hip_profile_read_ex(msckf_hip_handle h, double* ms, int* count, int cap);
 /* Milliseconds an event pair with nothing between its two records reads on the handle's stream (mean of 64 pairs): every
  * stage timer above brackets its launches with such a pair, so a single-kernel stage reads the kernel's duration plus
  * this.  (The reference's StageTiming message, asl_msckf.cpp:229-296, is host wall-clock and has no such term.) */
@@ -209,16 +213,16 @@ int msckf_hip_set_covariance_update(msckf_hip_handle h, int form);
 int msckf_hip_set_feature_overlap(msckf_hip_handle h, int on);
 /* Anisotropic pixel noise, u_var_prime != v_var_prime (see the header comment): mode 0 (default) the reference's
  * R_o_j = A_j^T R_j A_j / HouseholderQR in column order / R_n = Q_1^T R_o Q_1 on the device (msckf.h:423-431, 1343-1366;
- * f64, one workgroup per trajectory), its result handed to the update as the information matrix
- * [T_H | r_n]^T R_n^-1 [T_H | r_n]; mode 1 rows pre-whitened by 1/sigma (generalized least squares).  tail_tol: zero-tail tolerance of mode 0, < 0 = default (1e-10 double, 8e-4 float), 0 = the reference's
+ * f64: the Householder sweep for its decisions, the result as a projection onto range(Q_1), kernels_literal.hip), handed to the
+ * update as the information matrix [T_H | r_n]^T R_n^-1 [T_H | r_n]; mode 1 rows pre-whitened by 1/sigma (generalized least squares).  tail_tol: zero-tail tolerance of mode 0, < 0 = default (1e-10 double, 8e-4 float), 0 = the reference's
  * rule to the letter.  Applies to every trajectory of the handle, initialized or not.  -ENOMEM when the work space (about
  * sixteen (6 n_cap)^2 matrices of doubles per trajectory) does not fit. */
 int msckf_hip_set_anisotropic_noise(msckf_hip_handle h, int mode, double tail_tol);
 /* last marginalize of trajectory b on the literal route: out[0..5] = stacked rows m, kept rows r of R (msckf.h:1347),
  * Householder steps that reflected, steps whose non-zero tail fell under tail_tol, route taken (3: the sequence of steps on
  * the compressed representation -- first 15 + 6N rows explicit, the rest through their Gram matrix; 2: the sweep over the
- * dense stack, environment MSCKF_HIP_LITERAL_ROUTE=1 at create time), leading steps that meet the zero IMU columns (15);
- * out[6..7] reserved. */
+ * dense stack, environment MSCKF_HIP_LITERAL_ROUTE=1 at create time), leading steps that meet the zero IMU columns (15),
+ * kept rows that a dependent column handed through in the middle of the sweep (route 3); out[7] reserved. */
 int msckf_hip_literal_info(msckf_hip_handle h, int b, int* out8);
 
 #ifdef __cplusplus

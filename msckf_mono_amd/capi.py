@@ -30,7 +30,7 @@ SYMBOLS = [
     "msckf_hip_last_tracks", "msckf_hip_last_deltax", "msckf_hip_set_tracks", "msckf_hip_propagate_range",
     "msckf_hip_augment_range", "msckf_hip_marginalize_range", "msckf_hip_drop_oldest_range", "msckf_hip_scenario_alloc",
     "msckf_hip_scenario_set", "msckf_hip_scenario_commit", "msckf_hip_run_frames", "msckf_hip_run_frames_streamed", "msckf_hip_sync",
-    "msckf_hip_profile_enable", "msckf_hip_profile_read", "msckf_hip_profile_event_overhead", "msckf_hip_set_streams", "msckf_hip_set_gate_early_accept",
+    "msckf_hip_profile_enable", "msckf_hip_profile_read", "msckf_hip_profile_read_ex", "msckf_hip_profile_event_overhead", "msckf_hip_set_streams", "msckf_hip_set_gate_early_accept",
     "msckf_hip_scenario_pin", "msckf_hip_set_upload_ring", "msckf_hip_clear_error_flags",
     "msckf_hip_set_compression", "msckf_hip_set_covariance_update", "msckf_hip_set_feature_overlap", "msckf_hip_get_pruned_states", "msckf_hip_get_cam_meta", "msckf_hip_get_tracked_feature_ids",
     "msckf_hip_set_anisotropic_noise", "msckf_hip_literal_info", "msckf_hip_get_error_flags", "msckf_hip_copy_state", "msckf_hip_set_host_affinity",
@@ -308,7 +308,7 @@ class Batch:
     def literal_info(self, b):
         o = np.zeros(8, dtype=np.int32)
         _chk(self.L.msckf_hip_literal_info(self.h, int(b), o.ctypes.data_as(_ip)))
-        return dict(zip(["m_rows", "kept_rows", "reflected", "skipped_by_tolerance", "route", "rows_handed_through", "min_indep_mlog", "max_dep_mlog"], o.tolist()))
+        return dict(zip(["m_rows", "kept_rows", "reflected", "skipped_by_tolerance", "route", "leading_rows_handed_through", "kept_handed_through_rows", "spare"], o.tolist()))
 
     def profile_enable(self, on=True):
         _chk(self.L.msckf_hip_profile_enable(self.h, 1 if on else 0))
@@ -319,9 +319,9 @@ class Batch:
         return float(ms.value)
 
     def profile_read(self):
-        ms = np.zeros(8); cnt = np.zeros(8, dtype=np.int32)
-        _chk(self.L.msckf_hip_profile_read(self.h, ms.ctypes.data_as(_dp), cnt.ctypes.data_as(_ip)))
-        names = ["propagate", "augment", "feature", "compress_stage1", "compress_merge", "kalman", "prune", "select"]
+        ms = np.zeros(16); cnt = np.zeros(16, dtype=np.int32)
+        _chk(self.L.msckf_hip_profile_read_ex(self.h, ms.ctypes.data_as(_dp), cnt.ctypes.data_as(_ip), 16))
+        names = ["propagate", "augment", "feature", "compress_stage1", "compress_merge", "kalman", "prune", "select", "lit_pre", "lit_gamma", "literal"]
         return {n: (float(m), int(c)) for n, m, c in zip(names, ms, cnt)}
 
 

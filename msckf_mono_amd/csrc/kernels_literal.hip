@@ -381,6 +381,7 @@ __global__ __launch_bounds__(1024) void k_literal(Dev<S> d, int b0, int nb, int 
   lit::Ctx c;
   c.tid = threadIdx.x; c.nt = blockDim.x; c.lane = threadIdx.x & 63; c.wave = threadIdx.x >> 6; c.nw = blockDim.x >> 6; c.red = red; c.tim = d.lit.tim ? d.lit.tim + (long)b * 16 : nullptr; c.lds = lit_lds; c.lds_doubles = LIT_LDS_DOUBLES;
   const lit::Args<S> a = lit_args(d, bi, b);
+  if (c.tim && c.tid == 0) for (int q = 12; q < 16; ++q) c.tim[q] = 0;     // accumulating phase timers of the sweep's panels
   lit::literal_compress(c, a, d.lit.route, prepared != 0);
   // the blocked Cholesky adds the split-K copies of Lam^ that k_gram leaves (Dev::lam_part apart): none here
   if (d.lam_part) {
@@ -400,19 +401,23 @@ void literal_device_setup() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_literal<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LIT_LDS_DOUBLES * sizeof(double)));
 }
 
+// part: 0 all three launches; 1 k_lit_pre, 2 k_lit_gamma, 3 k_literal alone (the stage timers of a profiled run bracket each)
 template <class S>
-void launch_literal(const Dev<S>& d, int b0, int nb, hipStream_t st) {
+void launch_literal(const Dev<S>& d, int b0, int nb, hipStream_t st, int part) {
   if (nb <= 0 || !d.lit.W2) return;
   const bool dense = d.lit.route == 1;
-  if (!dense) {
+  if (!dense && (part == 0 || part == 1)) {
     const int items = d.f_cap + d.n_cap + 1;
     hipLaunchKernelGGL(k_lit_pre<S>, dim3(xcd_grid(nb, items)), dim3(64), 0, st, d, b0, nb, items, d.lit.serial);
+  }
+  if (!dense && (part == 0 || part == 2)) {
     const int T = (d.n6cap + 31) / 32, ntile = T * (T + 1) / 2;
     hipLaunchKernelGGL(k_lit_gamma<S>, dim3(xcd_grid(nb, ntile)), dim3(64), 0, st, d, b0, nb, ntile);
   }
-  hipLaunchKernelGGL(k_literal<S>, dim3(nb), dim3(1024), LIT_LDS_DOUBLES * sizeof(double), st, d, b0, nb, dense ? 0 : 1);
+  if (part == 0 || part == 3)
+    hipLaunchKernelGGL(k_literal<S>, dim3(nb), dim3(1024), LIT_LDS_DOUBLES * sizeof(double), st, d, b0, nb, dense ? 0 : 1);
 }
-template void launch_literal<float>(const Dev<float>&, int, int, hipStream_t);
-template void launch_literal<double>(const Dev<double>&, int, int, hipStream_t);
+template void launch_literal<float>(const Dev<float>&, int, int, hipStream_t, int);
+template void launch_literal<double>(const Dev<double>&, int, int, hipStream_t, int);
 
 }  // namespace msckf

@@ -93,6 +93,10 @@ template <class ST> LIT_FN void atb_lower(const Ctx& c, const double* A, long ld
   atb(c, A, lda, ma, B, ldb, ma, kd, [&](int i, int j, double v) { if (i >= j) st(i, j, v); });
 }
 LIT_FN void tick(const Ctx&, int) {}
+LIT_FN void tick_acc(const Ctx&, int, long long&) {}
+LIT_FN long long tick_now(const Ctx&) { return 0; }
+// par_for with a 32-bit index (the device divides 32-bit indices ~10x faster than 64-bit ones)
+template <class F> LIT_FN void par_for32(const Ctx&, int n, F f) { for (int i = 0; i < n; ++i) f(i); }
 // a section run by ONE wavefront with wave_sync between its dependent steps (no workgroup barrier inside)
 LIT_FN bool first_wave(const Ctx&) { return true; }
 LIT_FN void wave_sync(const Ctx&) {}
@@ -338,6 +342,10 @@ template <class ST> LIT_FN void atb_lower(const Ctx& c, const double* A, long ld
 LIT_FN bool first_lane(const Ctx& c) { return c.lane == 0; }
 LIT_FN bool first_thread(const Ctx& c) { return c.tid == 0; }
 LIT_FN void tick(const Ctx& c, int slot) { if (c.tim && c.tid == 0) c.tim[slot] = (long long)wall_clock64(); }
+// accumulating phase timer (phases that repeat per panel): slot += now - prev, prev = now
+LIT_FN void tick_acc(const Ctx& c, int slot, long long& prev) { if (c.tim && c.tid == 0) { const long long now = (long long)wall_clock64(); c.tim[slot] += now - prev; prev = now; } }
+LIT_FN long long tick_now(const Ctx& c) { return (c.tim && c.tid == 0) ? (long long)wall_clock64() : 0; }
+template <class F> LIT_FN void par_for32(const Ctx& c, int n, F f) { for (int i = c.tid; i < n; i += c.nt) f(i); }
 LIT_FN bool first_wave(const Ctx& c) { return c.wave == 0; }
 // LDS hand-over between the lanes of one wavefront: the fences keep the compiler from moving reads above writes
 LIT_FN void wave_sync(const Ctx&) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
@@ -479,59 +487,100 @@ LIT_FN void information_from_compressed(const Ctx& c, const Args<HT>& a, int n, 
 // Z(0:nr, 0:nr) holds the lower triangle of R_n: append [T_H | r_n]^T, eliminate, store Lam^
 template <class HT>
 LIT_FN void information_from_rn(const Ctx& c, const Args<HT>& a, int n, int nr) {
-  const int rc = a.r_cap;
-  const int nz = nr + n + 1;
+  const int rc = a.r_cap, n1 = n + 1;
+  const int nz = nr + n1;
   const long ldz = a.ldz;
   double* Z = a.Z;
-  par_for(c, (long)(n + 1) * nz, [&](long e) {
-    const int j = (int)(e / (n + 1)), cc = (int)(e - (long)j * (n + 1));
+  par_for32(c, n1 * nz, [&](int x) {
+    const int j = x / n1, cc = x - j * n1;
     Z[(nr + cc) + ldz * j] = j < nr ? a.TH[j + (long)rc * cc] : 0.0;
   });
   barrier(c);
   tick(c, 10);
-  // Elimination of the nr pivots, Z(i, j) -= Z(i, k) (Z(j, k) / d_k) for i >= j > k, in panels of PB pivots: the panel's columns
-  // (rows k0 .., all that is left of them) are staged in LDS and eliminated against each other there, then ONE pass over the
-  // trailing triangle in global memory applies the panel's PB updates to every element, in pivot order -- the same operands,
-  // the same operations in the same order as pivot by pivot (which took a barrier and ~20 dependent global round trips per pivot:
-  // 3.4 ms of 182 pivots on a 363-square matrix; this form: 12 passes).  The eliminated columns are not written back (only the
-  // trailing block is read afterwards).
+  // Elimination of the nr pivots, Z(i, j) -= Z(i, k) Z(j, k) / d_k for i >= j > k, in panels of PB pivots staged in LDS (all
+  // rows that are left of the panel's columns): the PB x PB diagonal block by ONE wavefront (no workgroup barrier between
+  // its pivots), then one thread per row below it takes the row through the panel's pivots (a triangular recurrence over its
+  // PB entries), then ONE pass over the trailing triangle in global memory, a 4 x 4 tile per thread, applies the panel's PB
+  // updates.  (Pivot by pivot: a barrier and ~20 dependent global round trips per pivot, 3.4 ms of 182 pivots on a 363-square
+  // matrix; panels with a barrier per pivot and one thread per trailing entry: 0.95 ms.)  The eliminated columns are not written
+  // back (only the trailing block is read afterwards).
   {
     int PB = 16;
-    while (PB > 1 && (long)(nz + 1) * PB + PB > c.lds_doubles) PB >>= 1;
+    while (PB > 1 && (long)(nz + 1) * (PB + 1) + 2 * PB > c.lds_doubles) PB >>= 1;
+    const int ldp = PB + 1;
     double* sD = c.lds;                                   // [PB] 1 / d_k of the panel's pivots
-    double* sP = c.lds + PB;                              // [rows k0 .. nz)[PB], row-major with PB + (PB < 16 ? 0 : 1) padding
-    const int ldp = PB + (PB >= 16 ? 1 : 0);
-    if ((long)(nz + 1) * ldp + PB > c.lds_doubles) PB = 0;   // (cannot happen with the sizes the callers allocate: fall back below)
+    double* sP = c.lds + 2 * PB;                          // [rows k0 .. nz)[ldp]: Z(k0 + r, k0 + q), unscaled
+    if ((long)(nz + 1) * ldp + 2 * PB > c.lds_doubles) PB = 0;   // (cannot happen with the sizes the callers allocate: fall back below)
     for (int k0 = 0; PB > 0 && k0 < nr; k0 += PB) {
       const int pb = nr - k0 < PB ? nr - k0 : PB, mrow = nz - k0;
-      // stage: element (k0 + i, k0 + cc); inside the panel's diagonal block the upper half is filled from the mirror image
-      par_for(c, (long)mrow * pb, [&](long e) {
-        const int cc = (int)(e / mrow), i = (int)(e - (long)cc * mrow);
-        sP[(long)i * ldp + cc] = i >= cc ? Z[(k0 + i) + ldz * (k0 + cc)] : Z[(k0 + cc) + ldz * (k0 + i)];
+      // stage: element (k0 + i, k0 + q); inside the panel's diagonal block the upper half is filled from the mirror image
+      par_for32(c, mrow * pb, [&](int x) {
+        const int q = x / mrow, i = x - q * mrow;
+        sP[(long)i * ldp + q] = i >= q ? Z[(k0 + i) + ldz * (k0 + q)] : Z[(k0 + q) + ldz * (k0 + i)];
       });
       barrier(c);
-      for (int cc = 0; cc < pb; ++cc) {
-        // column cc against the panel's later columns: rows i >= c2 of column c2 > cc
-        const double dinv = 1.0 / sP[(long)cc * ldp + cc];
-        if (first_thread(c)) sD[cc] = dinv;
-        const int nc = pb - 1 - cc;
-        par_for(c, (long)mrow * nc, [&](long e) {
-          const int q = (int)(e / mrow), i = (int)(e - (long)q * mrow), c2 = cc + 1 + q;
-          if (i < c2) return;
-          const double ljk = sP[(long)c2 * ldp + cc] * dinv;
-          sP[(long)i * ldp + c2] -= sP[(long)i * ldp + cc] * ljk;
-        });
-        barrier(c);
+      if (first_wave(c)) {
+        for (int q = 0; q < pb; ++q) {
+          const double dinv = 1.0 / sP[(long)q * ldp + q];
+          if (first_lane(c)) sD[q] = dinv;
+          const int nq = pb - 1 - q;
+          // rows r > q of the block, columns q2 in (q, r]
+          lane_for(c, 0, (long)nq * nq, [&](long x) {
+            const int r = q + 1 + (int)(x / nq), q2 = q + 1 + (int)(x % nq);
+            if (q2 > r) return;
+            sP[(long)r * ldp + q2] -= sP[(long)r * ldp + q] * (sP[(long)q2 * ldp + q] * dinv);
+          });
+          wave_sync(c);
+        }
       }
-      // trailing triangle: columns j >= k0 + pb, rows i >= j (a rectangle of indices, the upper half skipped)
-      const int j0 = k0 + pb, mt = nz - j0;
-      par_for(c, (long)mt * mt, [&](long e) {
-        const int jj = (int)(e / mt), ii = (int)(e - (long)jj * mt);
-        if (ii < jj) return;
-        const double* pi = sP + (long)(pb + ii) * ldp; const double* pj = sP + (long)(pb + jj) * ldp;
-        double z = Z[(j0 + ii) + ldz * (j0 + jj)];
-        for (int cc = 0; cc < pb; ++cc) z -= pi[cc] * (pj[cc] * sD[cc]);
-        Z[(j0 + ii) + ldz * (j0 + jj)] = z;
+      barrier(c);
+      // rows below the block: entry q2 of the row after the pivots q < q2 of the panel
+      par_for32(c, mrow - pb, [&](int x) {
+        double* row = sP + (long)(pb + x) * ldp;
+        double y[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) y[q] = q < pb ? row[q] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          if (q >= pb) break;
+          const double yq = y[q] * sD[q];
+#pragma unroll
+          for (int q2 = q + 1; q2 < 16; ++q2) if (q2 < pb) y[q2] -= yq * sP[(long)q2 * ldp + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) if (q < pb) row[q] = y[q];
+      });
+      barrier(c);
+      // trailing triangle: columns j >= k0 + pb, rows i >= j: Z(i, j) -= sum_q L(i, q) L(j, q) / d_q
+      const int j0 = k0 + pb, mt = nz - j0, tt = (mt + 3) / 4, ntile = tt * (tt + 1) / 2;
+      par_for32(c, ntile, [&](int t) {
+        int bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5); while (bi * (bi + 1) / 2 > t) --bi; while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+        const int bj = t - bi * (bi + 1) / 2, i0 = 4 * bi, c0 = 4 * bj;      // rows i0 .. (>= columns c0 ..)
+        int io[4], jo[4];
+#pragma unroll
+        for (int z = 0; z < 4; ++z) { io[z] = i0 + z < mt ? i0 + z : mt - 1; jo[z] = c0 + z < mt ? c0 + z : mt - 1; }
+        double acc[16];
+#pragma unroll
+        for (int z = 0; z < 16; ++z) acc[z] = 0.0;
+        for (int q = 0; q < pb; ++q) {
+          double av[4], bv[4];
+          const double dq = sD[q];
+#pragma unroll
+          for (int z = 0; z < 4; ++z) { av[z] = sP[(long)(pb + io[z]) * ldp + q]; bv[z] = sP[(long)(pb + jo[z]) * ldp + q] * dq; }
+#pragma unroll
+          for (int zi = 0; zi < 4; ++zi)
+#pragma unroll
+            for (int zj = 0; zj < 4; ++zj) acc[zj * 4 + zi] += av[zi] * bv[zj];
+        }
+        double old[16];
+#pragma unroll
+        for (int zj = 0; zj < 4; ++zj)
+#pragma unroll
+          for (int zi = 0; zi < 4; ++zi) { const int hi = io[zi] > jo[zj] ? io[zi] : jo[zj], lo = io[zi] > jo[zj] ? jo[zj] : io[zi]; old[zj * 4 + zi] = Z[(j0 + hi) + ldz * (j0 + lo)]; }
+#pragma unroll
+        for (int zj = 0; zj < 4; ++zj)
+#pragma unroll
+          for (int zi = 0; zi < 4; ++zi) if (i0 + zi < mt && c0 + zj <= i0 + zi) Z[(j0 + i0 + zi) + ldz * (j0 + c0 + zj)] = old[zj * 4 + zi] - acc[zj * 4 + zi];
       });
       barrier(c);
     }
@@ -550,8 +599,8 @@ LIT_FN void information_from_rn(const Ctx& c, const Args<HT>& a, int n, int nr) 
   }
   tick(c, 11);
   // ---- Lam^ (lower triangle incl. row n) where the blocked Cholesky reads it
-  par_for(c, (long)(n + 1) * (n + 1), [&](long e) {
-    const int hi = (int)(e / (n + 1)), lo = (int)(e - (long)hi * (n + 1));
+  par_for32(c, n1 * n1, [&](int x) {
+    const int hi = x / n1, lo = x - hi * n1;
     if (lo > hi) return;
     a.Lam[(long)hi * a.ldL + lo] = -Z[(nr + hi) + ldz * (nr + lo)];
   });
@@ -803,7 +852,7 @@ LIT_FN double lam_in(const Args<HT>& a, int hi, int lo) {   // hi >= lo
 // of Z = [[Bs^T R_o Bs, .], [(Bs^T A)^T, 0]] (information_from_rn).
 LIT_HD long compact_ws_doubles(int n, int m_cap, int r_cap, int /*ldg*/) {
   const long n1 = n + 1, ec = 15 + n;
-  return 2 * ec * n1 + ec * 2L * m_cap + 2 * n1 * n1 + 2 * n1 + ec * ec + ec * (long)n + 15L * n + 4 * ec
+  return 2 * ec * n1 + ec * 2L * m_cap + 3 * n1 * n1 + 34 * n1 + ec * ec + ec * (long)n + 15L * n + 4 * ec
        + 3L * n * n + 2 * ec * (long)n + 2L * n * n + 128;
 }
 
@@ -973,22 +1022,24 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
   double* sCnt = sRf + PB;                           // [2] counts of the panel
   const double tol2 = a.tol * a.tol, t2 = tol2 < 1e-7 ? 1e-7 : tol2;
   SweepOut so = {0, 0};
+  long long tprev = tick_now(c);       // phase timers over the panels: slots 12 stage, 13 core, 14 rows / columns, 15 results + trailing pass
   for (int k0 = 0; k0 < msteps; k0 += PB) {
     const int pb = msteps - k0 < PB ? msteps - k0 : PB, p0 = 15 + k0;
     const int nrow = e - p0;                         // rows p0 .. e-1
     const int ntr = n1 - (k0 + pb);                  // trailing columns k0 + pb .. n
     // ---- stage
-    par_for(c, (long)nrow * pb, [&](long x) { const int q = (int)(x / nrow), r = (int)(x - (long)q * nrow); sEC[(long)r * ldc + q] = E[(p0 + r) + ec * (k0 + q)]; });
-    par_for(c, (long)ntr * pb, [&](long x) {
-      const int q = (int)(x / ntr), jj = (int)(x - (long)q * ntr), j = k0 + pb + jj;
+    par_for32(c, nrow * pb, [&](int x) { const int q = x / nrow, r = x - q * nrow; sEC[(long)r * ldc + q] = E[(p0 + r) + ec * (k0 + q)]; });
+    par_for32(c, ntr * pb, [&](int x) {
+      const int q = x / ntr, jj = x - q * ntr, j = k0 + pb + jj;
       sEP[(long)q * n1 + jj] = E[(p0 + q) + ec * j];
       sGP[(long)q * n1 + jj] = Gh[j + (long)n1 * (k0 + q)];
     });
-    par_for(c, (long)pb * pb, [&](long x) {
-      const int q = (int)(x / pb), q2 = (int)(x - (long)q * pb), hi = q > q2 ? q : q2, lo = q > q2 ? q2 : q;
+    par_for32(c, pb * pb, [&](int x) {
+      const int q = x / pb, q2 = x - q * pb, hi = q > q2 ? q : q2, lo = q > q2 ? q2 : q;
       sG[q * PB + q2] = Gh[(k0 + hi) + (long)n1 * (k0 + lo)];
     });
     barrier(c);
+    tick_acc(c, 12, tprev);
     // ---- core: the panel's columns against each other, one wavefront
     if (first_wave(c)) {
       int nref = 0, nskt = 0;
@@ -1017,8 +1068,8 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
         }
         wave_sync(c);
         const int nq = pb - (q + 1);
-        lane_for(c, 0, (long)nq * nq, [&](long x) {
-          const int r = q + 1 + (int)(x / nq), q2 = q + 1 + (int)(x % nq);
+        lane_for(c, 0, (long)nq * nq, [&](long xl) {
+          const int x = (int)xl, r = q + 1 + x / nq, q2 = q + 1 + x % nq;
           sEC[(long)r * ldc + q2] -= sEC[(long)r * ldc + q] * sS[q * PB + q2];
           sG[r * PB + q2] -= sEC[(long)q * ldc + r] * sEC[(long)q * ldc + q2];
         });
@@ -1027,9 +1078,10 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
       if (first_lane(c)) { sCnt[0] = (double)nref; sCnt[1] = (double)nskt; }
     }
     barrier(c);
+    tick_acc(c, 13, tprev);
     so.n_reflect += (int)sCnt[0]; so.n_skip_tol += (int)sCnt[1];
     // ---- one thread per row below the panel (its reflector entries) and per column to the right (its entries of R and s)
-    par_for(c, (long)(nrow - pb) + ntr, [&](long x) {
+    par_for32(c, (nrow - pb) + ntr, [&](int x) {
       double y[16], g[16];
       if (x < nrow - pb) {
         double* row = sEC + (long)(pb + x) * ldc;
@@ -1046,7 +1098,7 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
 #pragma unroll
         for (int q = 0; q < 16; ++q) if (q < pb) row[q] = y[q];
       } else {
-        const int jj = (int)(x - (nrow - pb));
+        const int jj = x - (nrow - pb);
 #pragma unroll
         for (int q = 0; q < 16; ++q) { y[q] = q < pb ? sEP[(long)q * n1 + jj] : 0.0; g[q] = q < pb ? sGP[(long)q * n1 + jj] : 0.0; }
 #pragma unroll
@@ -1065,23 +1117,24 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
       }
     });
     barrier(c);
+    tick_acc(c, 14, tprev);
     // ---- results of the panel, and ONE pass over the trailing parts: E(i, j) -= sum_q v_q(i) s_q(j),  Gh(j, l) -= sum_q R_q(j) R_q(l)
-    par_for(c, pb, [&](long q) { a.tau[k0 + q] = sTau[q]; dnv[k0 + q] = sDn[q]; refl[k0 + q] = sRf[q] != 0.0 ? 1 : 0; });
-    par_for(c, (long)nrow * pb, [&](long x) { const int q = (int)(x / nrow), r = (int)(x - (long)q * nrow); E[(p0 + r) + ec * (k0 + q)] = sEC[(long)r * ldc + q]; });
-    par_for(c, (long)ntr * pb, [&](long x) {
-      const int q = (int)(x / ntr), jj = (int)(x - (long)q * ntr), j = k0 + pb + jj;
+    par_for32(c, pb, [&](int q) { a.tau[k0 + q] = sTau[q]; dnv[k0 + q] = sDn[q]; refl[k0 + q] = sRf[q] != 0.0 ? 1 : 0; });
+    par_for32(c, nrow * pb, [&](int x) { const int q = x / nrow, r = x - q * nrow; E[(p0 + r) + ec * (k0 + q)] = sEC[(long)r * ldc + q]; });
+    par_for32(c, ntr * pb, [&](int x) {
+      const int q = x / ntr, jj = x - q * ntr, j = k0 + pb + jj;
       E[(p0 + q) + ec * j] = sGP[(long)q * n1 + jj];
       Ac[j + (long)n1 * (k0 + q)] = sEP[(long)q * n1 + jj] * sDn[q];
     });
-    par_for(c, (long)pb * pb, [&](long x) { const int q = (int)(x / pb), q2 = (int)(x - (long)q * pb); if (q2 > q) Ac[(k0 + q2) + (long)n1 * (k0 + q)] = sS[q * PB + q2] * sDn[q]; });
+    par_for32(c, pb * pb, [&](int x) { const int q = x / pb, q2 = x - q * pb; if (q2 > q) Ac[(k0 + q2) + (long)n1 * (k0 + q)] = sS[q * PB + q2] * sDn[q]; });
     {
       const int ni = nrow - pb, ti = (ni + 3) / 4, tj = (ntr + 3) / 4, ntE = ti * tj, ntG = tj * (tj + 1) / 2;
-      par_for(c, (long)ntE + ntG, [&](long x) {
+      par_for32(c, ntE + ntG, [&](int x) {
         double acc[16];
 #pragma unroll
         for (int z = 0; z < 16; ++z) acc[z] = 0.0;
         if (x < ntE) {
-          const int bj = (int)(x / ti), bi = (int)(x - (long)bj * ti), i0 = 4 * bi, j0 = 4 * bj;
+          const int bj = x / ti, bi = x - bj * ti, i0 = 4 * bi, j0 = 4 * bj;
           int io[4], jo[4];
 #pragma unroll
           for (int z = 0; z < 4; ++z) { io[z] = i0 + z < ni ? i0 + z : ni - 1; jo[z] = j0 + z < ntr ? j0 + z : ntr - 1; }
@@ -1104,7 +1157,7 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
 #pragma unroll
             for (int zi = 0; zi < 4; ++zi) if (i0 + zi < ni && j0 + zj < ntr) E[(p0 + pb + i0 + zi) + ec * (k0 + pb + j0 + zj)] = old[zj * 4 + zi] - acc[zj * 4 + zi];
         } else {
-          const int t = (int)(x - ntE);
+          const int t = x - ntE;
           int bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5); while (bi * (bi + 1) / 2 > t) --bi; while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
           const int bj = t - bi * (bi + 1) / 2, i0 = 4 * bi, j0 = 4 * bj;      // rows i0.. (>= columns j0..)
           int io[4], jo[4];
@@ -1132,6 +1185,7 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
       });
     }
     barrier(c);
+    tick_acc(c, 15, tprev);
   }
   return so;
 }
@@ -1188,7 +1242,9 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
   double* At = E0 + ec * n1;                    // [ec][2 m_cap]: a_i = A_j e_(i - row0) for the explicit rows
   double* Gh = At + ec * mc2;                   // [n1 x n1] lower triangle, column-major: Gram matrix of the rows from the pivot row down
   double* Ac = Gh + (long)n1 * n1;              // [n1 x n1] Ac[j + n1 k] = s_j / (c0 - beta) of step k (column operations of the sweep), j > k
-  double* Ld = Ac + (long)n1 * n1;              // [n1] squared column norms
+  double* G0s = Ac + (long)n1 * n1;             // [n1 x n1] lower triangle, column-major: Gh as it starts (the Gram matrix of the rows from row 15 down)
+  double* Stg = G0s + (long)n1 * n1;            // [2][n1][16] stand-in for the LDS staging of the first 15 rows when the staging area is too small
+  double* Ld = Stg + 32L * n1;                  // [n1] squared column norms
   double* See = Ld + n1;                        // [ec x ec] G_E^T G_E (blocks of the tracks that own explicit rows)
   double* Xe = See + ec * ec;                   // [ec x n] G_E^T H_u
   double* Ut = Xe + ec * (long)n;               // [15 x n] See15 E15 / 2 - Xe15
@@ -1259,21 +1315,35 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
     if (l < e15) { for (int l2 = 0; l2 < e15; ++l2) s += See[l + ec * l2] * E[l2 + ec * cc]; s = 0.5 * s - Xe[l + ec * cc]; }
     Ut[l + 15L * cc] = s;
   });
+  barrier(c);
   tick(c, 2);
-  // ---- Gh = [H_o | r_o]^T [H_o | r_o] minus the first 15 rows (lower triangle; the corner (n, n) is never a pivot)
-  auto g0 = [&](int hi, int lo) -> double {      // Gram matrix of the rows from row 15 down, hi >= lo, lo < n
-    double s = lam_in(a, hi, lo);
-    for (int l = 0; l < e15; ++l) s -= E0[l + ec * hi] * E0[l + ec * lo];
-    return s;
-  };
-  if (gram) {
-    par_for(c, (long)n1 * n1, [&](long x) {
-      const int lo = (int)(x / n1), hi = (int)(x - (long)lo * n1);
-      if (hi < lo) return;
-      Gh[hi + (long)n1 * lo] = (hi == n && lo == n) ? 0.0 : g0(hi, lo);
+  // ---- Gh = [H_o | r_o]^T [H_o | r_o] minus the first 15 rows (lower triangle; the corner (n, n) is never a pivot), kept a
+  // second time (G0s) for the basis products; the first 15 rows staged [column][16]
+  double* sE = 32L * n1 <= c.lds_doubles ? c.lds : Stg;
+  double* sU = sE + 16L * n1;
+  auto stage15 = [&]() {
+    par_for32(c, 16 * n1, [&](int x) {
+      const int j = x >> 4, l = x & 15;
+      sE[x] = l < e15 ? E0[l + ec * j] : 0.0;
+      sU[x] = (l < 15 && j < n) ? Ut[l + 15L * j] : 0.0;
     });
-    par_for(c, n, [&](long k) { Ld[k] = lam_in(a, (int)k, (int)k); });
-  }
+    barrier(c);
+  };
+  stage15();
+  par_for32(c, n1 * n1, [&](int x) {
+    const int lo = x / n1, hi = x - lo * n1;
+    if (hi < lo) return;
+    double v = 0.0;
+    if (!(hi == n && lo == n)) {
+      v = lam_in(a, hi, lo);
+      const double* eh = sE + 16 * hi; const double* el = sE + 16 * lo;
+#pragma unroll
+      for (int l = 0; l < 15; ++l) v -= eh[l] * el[l];
+    }
+    G0s[hi + (long)n1 * lo] = v;
+    if (gram) Gh[hi + (long)n1 * lo] = v;
+  });
+  if (gram) par_for32(c, n, [&](int k) { Ld[k] = lam_in(a, k, k); });
   barrier(c);
   tick(c, 3);
   // ---- the sweep (msckf.h:1343): steps 0..14 meet the zero IMU columns; step 15 + k works on camera column k, pivot row 15 + k
@@ -1379,8 +1449,9 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
   // ---- Z(0:nr, 0:nr) = Bs^T R_o Bs (lower triangle) and TH = Bs^T A for the basis [e_i | x'_c | q_h]
   {
     const long ldz = a.ldz;
-    par_for(c, (long)nr * nr, [&](long x) {
-      const int kb = (int)(x / nr), ka = (int)(x - (long)kb * nr);
+    stage15();
+    par_for32(c, nr * nr, [&](int x) {
+      const int kb = x / nr, ka = x - kb * nr;
       if (ka < kb) return;
       double val;
       if (ka < na) {                               // (e_i, e_i')
@@ -1388,40 +1459,43 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
         val = (i == i2 ? a.v_var : 0.0) + dlt * See[i + ec * i2];
       } else if (ka < na + nb) {
         const int cc = bidx[ka];
+        const double* ec_ = sE + 16 * cc; const double* uc_ = sU + 16 * cc;
         if (kb < na) {                             // (x'_c, e_i)
           const int i = bidx[kb];
-          double s = Xe[i + ec * cc];
-          for (int l = 0; l < e15; ++l) s -= See[i + ec * l] * E0[l + ec * cc];
-          val = dlt * s;
-        } else {                                   // (x'_c, x'_c'), c > c'
+          double sacc = Xe[i + ec * cc];
+          for (int l = 0; l < e15; ++l) sacc -= See[i + ec * l] * ec_[l];
+          val = dlt * sacc;
+        } else {                                   // (x'_c, x'_c'), c >= c'
           const int c2 = bidx[kb];
-          double s = a.Gam[(long)cc * a.ldGam + c2];
-          for (int l = 0; l < e15; ++l) s += E0[l + ec * cc] * Ut[l + 15L * c2] + Ut[l + 15L * cc] * E0[l + ec * c2];
-          val = a.v_var * g0(cc, c2) + dlt * s;
+          const double* e2 = sE + 16 * c2; const double* u2 = sU + 16 * c2;
+          double sacc = a.Gam[(long)cc * a.ldGam + c2];
+#pragma unroll
+          for (int l = 0; l < 15; ++l) sacc += ec_[l] * u2[l] + uc_[l] * e2[l];
+          val = a.v_var * G0s[cc + (long)n1 * c2] + dlt * sacc;
         }
       } else {
         const int ah = ka - na - nb, h = 15 + bidx[ka];
         if (kb < na) val = dlt * Ph[bidx[kb] + ec * ah];                 // (q_h, e_i)
         else if (kb < na + nb) {                   // (q_h, x'_c): q_h^T x'_c = R(h, c)
           const int cc = bidx[kb];
-          double s = Qh[cc + (long)n * ah];
-          for (int l = 0; l < e15; ++l) s -= E0[l + ec * cc] * Ph[l + ec * ah];
-          val = a.v_var * (cc + 15 >= h ? E[h + ec * cc] : 0.0) + dlt * s;
+          double sacc = Qh[cc + (long)n * ah];
+          for (int l = 0; l < e15; ++l) sacc -= sE[16 * cc + l] * Ph[l + ec * ah];
+          val = a.v_var * (cc + 15 >= h ? E[h + ec * cc] : 0.0) + dlt * sacc;
         } else {                                   // (q_h, q_h')
           const int a2 = kb - na - nb;
-          double s = 0;
-          for (int i = 0; i < e; ++i) s += Th[i + ec * a2] * Ph[i + ec * ah];
-          for (int l = 0; l < n; ++l) s += Yh[l + (long)n * a2] * Qh[l + (long)n * ah];
-          val = (ah == a2 ? a.v_var : 0.0) + dlt * s;
+          double sacc = 0;
+          for (int i = 0; i < e; ++i) sacc += Th[i + ec * a2] * Ph[i + ec * ah];
+          for (int l = 0; l < n; ++l) sacc += Yh[l + (long)n * a2] * Qh[l + (long)n * ah];
+          val = (ah == a2 ? a.v_var : 0.0) + dlt * sacc;
         }
       }
       a.Z[ka + ldz * kb] = val;
     });
-    par_for(c, (long)nr * n1, [&](long x) {
-      const int j = (int)(x / nr), k = (int)(x - (long)j * nr);
+    par_for32(c, nr * n1, [&](int x) {
+      const int j = x / nr, k = x - j * nr;
       double val;
       if (k < na) val = E0[bidx[k] + ec * j];
-      else if (k < na + nb) { const int cc = bidx[k]; val = cc >= j ? g0(cc, j) : g0(j, cc); }
+      else if (k < na + nb) { const int cc = bidx[k]; val = cc >= j ? G0s[cc + (long)n1 * j] : G0s[j + (long)n1 * cc]; }
       else { const int h = 15 + bidx[k]; val = (j == n || j + 15 >= h) ? E[h + ec * j] : 0.0; }
       a.TH[k + rc * j] = val;
     });

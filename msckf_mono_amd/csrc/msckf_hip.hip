@@ -118,7 +118,7 @@ struct BatchBase {
   virtual int set_upload_ring(int depth, int mode) = 0;
   virtual int sync() = 0;
   virtual int prof_enable(int on) = 0;
-  virtual int prof_read(double* ms, int* cnt) = 0;
+  virtual int prof_read(double* ms, int* cnt, int cap) = 0;
   virtual int prof_event_overhead(double* ms) = 0;
   virtual int set_streams(int n) = 0;
   virtual int set_host_affinity(const int* cpus, int n) = 0;
@@ -134,7 +134,7 @@ struct BatchBase {
   virtual int lit_info(int b, int* out4) = 0;
 };
 
-constexpr int NSTAGE = 8;
+constexpr int NSTAGE = 11;   // 0..7: msckf_hip_profile_read; 8 k_lit_pre, 9 k_lit_gamma, 10 k_literal (msckf_hip_profile_read_ex)
 
 // Persistent enqueue threads of a batch (one per slice of run_frames / run_frames_streamed): a K-frame window is a few
 // milliseconds, creating and joining three std::threads per call was 1-2 % of it.
@@ -674,9 +674,12 @@ struct Batch : BatchBase {
       // anisotropic pixel noise, literal route: the information matrix of the reference's (T_H, r_n, R_n) replaces H_o^T H_o
       // for those trajectories (kernels_literal.hip)
       stage_begin(3, q);
-      launch_gram<S>(v, b0, nb, q, 3);                    // (the literal route's fast path starts from the same f64 Gram matrix)
-      if (n_lit > 0) launch_literal<S>(v, b0, nb, q);
+      launch_gram<S>(v, b0, nb, q, 3);                    // (the literal route starts from the same f64 Gram matrix)
       stage_end(3, q);
+      if (n_lit > 0) {
+        if (prof) for (int part = 1; part <= 3; ++part) { stage_begin(7 + part, q); launch_literal<S>(v, b0, nb, q, part); stage_end(7 + part, q); }
+        else launch_literal<S>(v, b0, nb, q);
+      }
       stage_begin(4, q); launch_gram<S>(v, b0, nb, q, 2); stage_end(4, q);
     } else {
       stage_begin(3, q); launch_compress<S>(v, b0, nb, q, 1); stage_end(3, q);
@@ -1179,7 +1182,7 @@ struct Batch : BatchBase {
     *ms = tot / reps;
     return 0;
   }
-  int prof_read(double* ms, int* cnt) override {
+  int prof_read(double* ms, int* cnt, int cap) override {
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamSynchronize(st));
     for (int s = 0; s < NSTAGE; ++s) {
@@ -1189,7 +1192,7 @@ struct Batch : BatchBase {
         prof_ms[s] += t; prof_cnt[s]++;
       }
       ev_used[s] = 0;
-      ms[s] = prof_ms[s]; cnt[s] = prof_cnt[s];
+      if (s < cap) { ms[s] = prof_ms[s]; cnt[s] = prof_cnt[s]; }
     }
     return 0;
   }
@@ -1880,7 +1883,8 @@ int msckf_hip_run_frames(msckf_hip_handle h, int f0, int f1) { return H(h)->run_
 int msckf_hip_run_frames_streamed(msckf_hip_handle h, int f0, int f1) { return H(h)->run_frames_streamed(f0, f1); }
 int msckf_hip_sync(msckf_hip_handle h) { return H(h)->sync(); }
 int msckf_hip_profile_enable(msckf_hip_handle h, int on) { return H(h)->prof_enable(on); }
-int msckf_hip_profile_read(msckf_hip_handle h, double* ms7, int* count7) { return H(h)->prof_read(ms7, count7); }
+int msckf_hip_profile_read(msckf_hip_handle h, double* ms7, int* count7) { return H(h)->prof_read(ms7, count7, 8); }
+int msckf_hip_profile_read_ex(msckf_hip_handle h, double* ms, int* count, int cap) { if (!h || !ms || !count || cap < 8) return fail(-EINVAL, "bad arguments"); for (int s = NSTAGE; s < cap; ++s) { ms[s] = 0; count[s] = 0; } return H(h)->prof_read(ms, count, cap); }
 int msckf_hip_profile_event_overhead(msckf_hip_handle h, double* ms) { if (!h || !ms) return fail(-EINVAL, "null argument"); return H(h)->prof_event_overhead(ms); }
 int msckf_hip_set_host_affinity(msckf_hip_handle h, const int* cpus, int n) { if (!h || (n > 0 && !cpus)) return fail(-EINVAL, "null argument"); return H(h)->set_host_affinity(cpus, n); }
 int msckf_hip_set_streams(msckf_hip_handle h, int n) { return H(h)->set_streams(n); }

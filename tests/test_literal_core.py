@@ -162,9 +162,10 @@ def test_compact_route_at_the_30_camera_window_equals_the_sweep_over_the_stack(l
 
 
 def test_blocked_elimination_is_independent_of_the_panel_width(lit, po, monkeypatch):
-    """The elimination of R_n (literal_core.h: information_from_rn) runs in panels staged in the device's LDS; the panel width
-    follows the size of that area (16 pivots at 62.5 KB, fewer when it is smaller, pivot by pivot when nothing fits).  Every
-    width applies the same operations in the same order: the information matrix of a 30-camera window must not move."""
+    """The elimination of R_n (literal_core.h: information_from_rn) and the sweep (sweep_gram_blocked) run in panels staged in
+    the device's LDS; the panel width follows the size of that area (16 at 94 KB, fewer when it is smaller, step by step when
+    nothing fits).  Every width applies the same eliminations (products grouped differently): the information matrix of a
+    30-camera window moves by rounding only."""
     N, F, nf = 30, 200, 32
     cfg = sc.filter_config(N, isotropic=False)
     tr = sc.Trajectory(4, 0, N, F, nf, cfg=cfg, path_id=0)
@@ -176,10 +177,10 @@ def test_blocked_elimination_is_independent_of_the_panel_width(lit, po, monkeypa
     su, sv = np.sqrt(u), np.sqrt(v)
     hx[:, :, 0:6] *= su; hx[:, :, 6:12] *= sv; r[:, 0::2] *= su; r[:, 1::2] *= sv
     ref = None
-    for stage in (8000, 3000, 400, 100):
+    for stage in (12000, 8000, 3000, 400, 100):
         monkeypatch.setenv("LIT_HOST_STAGE", str(stage))
         L_c, ic, _ = host_compress(lit, N, M, ps, sl, hx, r, u, v, 1e-10, route=0)
         if ref is None:
             ref = L_c
         else:
-            assert np.linalg.norm(L_c - ref) <= 1e-13 * np.linalg.norm(ref), stage
+            assert np.linalg.norm(L_c - ref) <= 1e-11 * np.linalg.norm(ref), stage
