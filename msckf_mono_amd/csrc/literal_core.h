@@ -95,6 +95,8 @@ template <class ST> LIT_FN void atb_lower(const Ctx& c, const double* A, long ld
 LIT_FN void tick(const Ctx&, int) {}
 LIT_FN void tick_acc(const Ctx&, int, long long&) {}
 LIT_FN long long tick_now(const Ctx&) { return 0; }
+LIT_FN double lit_rsqrt(double x) { return 1.0 / sqrt(x); }
+LIT_FN double lit_rcp(double x) { return 1.0 / x; }
 // par_for with a 32-bit index (the device divides 32-bit indices ~10x faster than 64-bit ones)
 template <class F> LIT_FN void par_for32(const Ctx&, int n, F f) { for (int i = 0; i < n; ++i) f(i); }
 // a section run by ONE wavefront with wave_sync between its dependent steps (no workgroup barrier inside)
@@ -345,6 +347,10 @@ LIT_FN void tick(const Ctx& c, int slot) { if (c.tim && c.tid == 0) c.tim[slot] 
 // accumulating phase timer (phases that repeat per panel): slot += now - prev, prev = now
 LIT_FN void tick_acc(const Ctx& c, int slot, long long& prev) { if (c.tim && c.tid == 0) { const long long now = (long long)wall_clock64(); c.tim[slot] += now - prev; prev = now; } }
 LIT_FN long long tick_now(const Ctx& c) { return (c.tim && c.tid == 0) ? (long long)wall_clock64() : 0; }
+// hardware seed + Newton steps (dev_common.h): the IEEE sqrt / division sequences are ~30 dependent instructions each, and the
+// panel cores are chains of them
+LIT_FN double lit_rsqrt(double x) { return fast_rsqrt(x); }
+LIT_FN double lit_rcp(double x) { return fast_rcp(x); }
 template <class F> LIT_FN void par_for32(const Ctx& c, int n, F f) { for (int i = c.tid; i < n; i += c.nt) f(i); }
 LIT_FN bool first_wave(const Ctx& c) { return c.wave == 0; }
 // LDS hand-over between the lanes of one wavefront: the fences keep the compiler from moving reads above writes
@@ -506,29 +512,28 @@ LIT_FN void information_from_rn(const Ctx& c, const Args<HT>& a, int n, int nr) 
   // back (only the trailing block is read afterwards).
   {
     int PB = 16;
-    while (PB > 1 && (long)(nz + 1) * (PB + 1) + 2 * PB > c.lds_doubles) PB >>= 1;
-    const int ldp = PB + 1;
+    const long ldr = (nz + 4) | 1;                        // panel storage [q][row]: rows contiguous (a thread's four rows are one 32-byte read, no bank conflicts)
+    while (PB > 1 && ldr * PB + 2 * PB > c.lds_doubles) PB >>= 1;
     double* sD = c.lds;                                   // [PB] 1 / d_k of the panel's pivots
-    double* sP = c.lds + 2 * PB;                          // [rows k0 .. nz)[ldp]: Z(k0 + r, k0 + q), unscaled
-    if ((long)(nz + 1) * ldp + 2 * PB > c.lds_doubles) PB = 0;   // (cannot happen with the sizes the callers allocate: fall back below)
+    double* sP = c.lds + 2 * PB;                          // [PB][ldr]: Z(k0 + r, k0 + q) at sP[q * ldr + r], unscaled
+    if (ldr * PB + 2 * PB > c.lds_doubles) PB = 0;        // (cannot happen with the sizes the callers allocate: fall back below)
     for (int k0 = 0; PB > 0 && k0 < nr; k0 += PB) {
       const int pb = nr - k0 < PB ? nr - k0 : PB, mrow = nz - k0;
       // stage: element (k0 + i, k0 + q); inside the panel's diagonal block the upper half is filled from the mirror image
       par_for32(c, mrow * pb, [&](int x) {
         const int q = x / mrow, i = x - q * mrow;
-        sP[(long)i * ldp + q] = i >= q ? Z[(k0 + i) + ldz * (k0 + q)] : Z[(k0 + q) + ldz * (k0 + i)];
+        sP[q * ldr + i] = i >= q ? Z[(k0 + i) + ldz * (k0 + q)] : Z[(k0 + q) + ldz * (k0 + i)];
       });
       barrier(c);
       if (first_wave(c)) {
         for (int q = 0; q < pb; ++q) {
-          const double dinv = 1.0 / sP[(long)q * ldp + q];
+          const double dinv = lit_rcp(sP[q * ldr + q]);
           if (first_lane(c)) sD[q] = dinv;
-          const int nq = pb - 1 - q;
-          // rows r > q of the block, columns q2 in (q, r]
-          lane_for(c, 0, (long)nq * nq, [&](long x) {
-            const int r = q + 1 + (int)(x / nq), q2 = q + 1 + (int)(x % nq);
-            if (q2 > r) return;
-            sP[(long)r * ldp + q2] -= sP[(long)r * ldp + q] * (sP[(long)q2 * ldp + q] * dinv);
+          // rows r > q of the block, columns q2 in (q, r]: lane = (row offset mod 4, column offset)
+          lane_for(c, 0, 64, [&](long ln) {
+            const int q2 = q + 1 + ((int)ln & 15);
+            for (int r = q + 1 + ((int)ln >> 4); r < pb; r += 4)
+              if (q2 <= r) sP[q2 * ldr + r] -= sP[q * ldr + r] * (sP[q * ldr + q2] * dinv);
           });
           wave_sync(c);
         }
@@ -536,26 +541,30 @@ LIT_FN void information_from_rn(const Ctx& c, const Args<HT>& a, int n, int nr) 
       barrier(c);
       // rows below the block: entry q2 of the row after the pivots q < q2 of the panel
       par_for32(c, mrow - pb, [&](int x) {
-        double* row = sP + (long)(pb + x) * ldp;
+        const int r = pb + x;
         double y[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) y[q] = q < pb ? row[q] : 0.0;
+        for (int q = 0; q < 16; ++q) y[q] = q < pb ? sP[q * ldr + r] : 0.0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           if (q >= pb) break;
           const double yq = y[q] * sD[q];
 #pragma unroll
-          for (int q2 = q + 1; q2 < 16; ++q2) if (q2 < pb) y[q2] -= yq * sP[(long)q2 * ldp + q];
+          for (int q2 = q + 1; q2 < 16; ++q2) if (q2 < pb) y[q2] -= yq * sP[q * ldr + q2];
         }
 #pragma unroll
-        for (int q = 0; q < 16; ++q) if (q < pb) row[q] = y[q];
+        for (int q = 0; q < 16; ++q) if (q < pb) sP[q * ldr + r] = y[q];
       });
       barrier(c);
-      // trailing triangle: columns j >= k0 + pb, rows i >= j: Z(i, j) -= sum_q L(i, q) L(j, q) / d_q
+      // trailing triangle: columns j >= k0 + pb, rows i >= j: Z(i, j) -= sum_q L(i, q) L(j, q) / d_q; tiles numbered down the
+      // tile columns (consecutive threads: consecutive rows of the column-major Z)
       const int j0 = k0 + pb, mt = nz - j0, tt = (mt + 3) / 4, ntile = tt * (tt + 1) / 2;
       par_for32(c, ntile, [&](int t) {
-        int bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5); while (bi * (bi + 1) / 2 > t) --bi; while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
-        const int bj = t - bi * (bi + 1) / 2, i0 = 4 * bi, c0 = 4 * bj;      // rows i0 .. (>= columns c0 ..)
+        const double w2 = 2.0 * tt + 1.0;
+        int bj = (int)((w2 - sqrt(w2 * w2 - 8.0 * t)) * 0.5);
+        while (bj > 0 && bj * tt - bj * (bj - 1) / 2 > t) --bj;
+        while ((bj + 1) * tt - (bj + 1) * bj / 2 <= t) ++bj;
+        const int bi = bj + (t - (bj * tt - bj * (bj - 1) / 2)), i0 = 4 * bi, c0 = 4 * bj;      // rows i0 .. (>= columns c0 ..)
         int io[4], jo[4];
 #pragma unroll
         for (int z = 0; z < 4; ++z) { io[z] = i0 + z < mt ? i0 + z : mt - 1; jo[z] = c0 + z < mt ? c0 + z : mt - 1; }
@@ -565,8 +574,9 @@ LIT_FN void information_from_rn(const Ctx& c, const Args<HT>& a, int n, int nr) 
         for (int q = 0; q < pb; ++q) {
           double av[4], bv[4];
           const double dq = sD[q];
+          const double* col = sP + q * ldr + pb;
 #pragma unroll
-          for (int z = 0; z < 4; ++z) { av[z] = sP[(long)(pb + io[z]) * ldp + q]; bv[z] = sP[(long)(pb + jo[z]) * ldp + q] * dq; }
+          for (int z = 0; z < 4; ++z) { av[z] = col[io[z]]; bv[z] = col[jo[z]] * dq; }
 #pragma unroll
           for (int zi = 0; zi < 4; ++zi)
 #pragma unroll
@@ -1006,12 +1016,12 @@ template <class HT>
 LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n, int msteps, long ec, double* E, double* Gh, const double* Ld, double* Ac, double* dnv, int* refl, double* sv) {
   const int n1 = n + 1;
   int PB = 16;
-  auto need = [&](int pb) -> long { return (long)(e - 15) * (pb + 1) + 2L * pb * n1 + 2L * pb * pb + 8L * pb + 16; };
+  const long lde = (e - 15 + 4) | 1;                 // the panel's columns [q][row]: rows contiguous (a thread's four rows are one 32-byte read, no bank conflicts)
+  auto need = [&](int pb) -> long { return lde * pb + 2L * pb * n1 + 2L * pb * pb + 8L * pb + 16; };
   while (PB > 2 && need(PB) > c.lds_doubles) PB >>= 1;
   if (need(PB) > c.lds_doubles) return sweep_gram_steps(c, a, e, n, msteps, ec, E, Gh, Ld, Ac, dnv, refl, sv);
-  const int ldc = PB + 1;
-  double* sEC = c.lds;                               // [(e - p0)][ldc]: E(p0 + r, k0 + q); its top PB x PB block is the panel's core
-  double* sEP = sEC + (long)(e - 15) * ldc;          // [PB][n1]: E(p0 + q, k0 + PB + jj) -> s_q(j)
+  double* sEC = c.lds;                               // [PB][lde]: E(p0 + r, k0 + q) at sEC[q * lde + r]; rows r < PB x the PB columns are the panel's core
+  double* sEP = sEC + lde * PB;                      // [PB][n1]: E(p0 + q, k0 + PB + jj) -> s_q(j)
   double* sGP = sEP + (long)PB * n1;                 // [PB][n1]: Gh(k0 + q, k0 + PB + jj) -> R(p0 + q, j)
   double* sG = sGP + (long)PB * n1;                  // [PB][PB] Gram block of the panel's columns (both triangles)
   double* sS = sG + PB * PB;                         // [PB][PB] s_q(k0 + q'), q' > q
@@ -1028,7 +1038,7 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
     const int nrow = e - p0;                         // rows p0 .. e-1
     const int ntr = n1 - (k0 + pb);                  // trailing columns k0 + pb .. n
     // ---- stage
-    par_for32(c, nrow * pb, [&](int x) { const int q = x / nrow, r = x - q * nrow; sEC[(long)r * ldc + q] = E[(p0 + r) + ec * (k0 + q)]; });
+    par_for32(c, nrow * pb, [&](int x) { const int q = x / nrow, r = x - q * nrow; sEC[(q) * lde + (r)] = E[(p0 + r) + ec * (k0 + q)]; });
     par_for32(c, ntr * pb, [&](int x) {
       const int q = x / ntr, jj = x - q * ntr, j = k0 + pb + jj;
       sEP[(long)q * n1 + jj] = E[(p0 + q) + ec * j];
@@ -1044,34 +1054,37 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
     if (first_wave(c)) {
       int nref = 0, nskt = 0;
       for (int q = 0; q < pb; ++q) {
-        const double c0 = sEC[(long)q * ldc + q], gq = sG[q * PB + q] > 0.0 ? sG[q * PB + q] : 0.0;
+        const double c0 = sEC[(q) * lde + (q)], gq = sG[q * PB + q] > 0.0 ? sG[q * PB + q] : 0.0;
         double tail2 = gq - c0 * c0; tail2 = tail2 > 0.0 ? tail2 : 0.0;
         double zero2 = t2 * Ld[k0 + q]; zero2 = zero2 > 2.2250738585072014e-308 ? zero2 : 2.2250738585072014e-308;
         const bool reflect = tail2 > zero2;
         wave_sync(c);                                // every lane has read the step's inputs
         if (reflect) {
           ++nref;
-          double beta = sqrt(c0 * c0 + tail2); if (c0 >= 0.0) beta = -beta;
-          const double dn = 1.0 / (c0 - beta), binv = 1.0 / beta;
-          if (first_lane(c)) { sDn[q] = dn; sBi[q] = binv; sTau[q] = (beta - c0) / beta; sRf[q] = 1.0; }
+          const double g2 = c0 * c0 + tail2, rs = lit_rsqrt(g2);
+          const double binv = c0 >= 0.0 ? -rs : rs, beta = g2 * binv;      // beta = -sign(c0) sqrt(g2)
+          const double dn = lit_rcp(c0 - beta);
+          if (first_lane(c)) { sDn[q] = dn; sBi[q] = binv; sTau[q] = (beta - c0) * binv; sRf[q] = 1.0; }
           lane_for(c, q, pb, [&](long q2) {
             const double r = q2 == q ? beta : sG[q * PB + q2] * binv;
-            sS[q * PB + q2] = sEC[(long)q * ldc + q2] - r;
-            sEC[(long)q * ldc + q2] = r;
+            sS[q * PB + q2] = sEC[(q2) * lde + (q)] - r;
+            sEC[(q2) * lde + (q)] = r;
           });
-          lane_for(c, q + 1, pb, [&](long r) { sEC[r * ldc + q] *= dn; });
+          lane_for(c, q + 1, pb, [&](long r) { sEC[q * lde + r] *= dn; });
         } else {
           if (tail2 > 2.2250738585072014e-308) ++nskt;
           if (first_lane(c)) { sDn[q] = 0.0; sBi[q] = 0.0; sTau[q] = 0.0; sRf[q] = 0.0; }
           lane_for(c, q, pb, [&](long q2) { sS[q * PB + q2] = 0.0; });
-          lane_for(c, q + 1, pb, [&](long r) { sEC[r * ldc + q] = 0.0; });
+          lane_for(c, q + 1, pb, [&](long r) { sEC[q * lde + r] = 0.0; });
         }
         wave_sync(c);
-        const int nq = pb - (q + 1);
-        lane_for(c, 0, (long)nq * nq, [&](long xl) {
-          const int x = (int)xl, r = q + 1 + x / nq, q2 = q + 1 + x % nq;
-          sEC[(long)r * ldc + q2] -= sEC[(long)r * ldc + q] * sS[q * PB + q2];
-          sG[r * PB + q2] -= sEC[(long)q * ldc + r] * sEC[(long)q * ldc + q2];
+        lane_for(c, 0, 64, [&](long ln) {              // lane = (row offset mod 4, column offset)
+          const int q2 = q + 1 + ((int)ln & 15);
+          if (q2 >= pb) return;
+          for (int r = q + 1 + ((int)ln >> 4); r < pb; r += 4) {
+            sEC[q2 * lde + r] -= sEC[q * lde + r] * sS[q * PB + q2];
+            sG[r * PB + q2] -= sEC[r * lde + q] * sEC[q2 * lde + q];
+          }
         });
         wave_sync(c);
       }
@@ -1084,9 +1097,9 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
     par_for32(c, (nrow - pb) + ntr, [&](int x) {
       double y[16], g[16];
       if (x < nrow - pb) {
-        double* row = sEC + (long)(pb + x) * ldc;
+        const int rr = pb + x;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) y[q] = q < pb ? row[q] : 0.0;
+        for (int q = 0; q < 16; ++q) y[q] = q < pb ? sEC[q * lde + rr] : 0.0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           if (q >= pb) break;
@@ -1096,7 +1109,7 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
           y[q] = vq;
         }
 #pragma unroll
-        for (int q = 0; q < 16; ++q) if (q < pb) row[q] = y[q];
+        for (int q = 0; q < 16; ++q) if (q < pb) sEC[q * lde + rr] = y[q];
       } else {
         const int jj = x - (nrow - pb);
 #pragma unroll
@@ -1109,7 +1122,7 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
           const double s = rf ? y[q] - r : 0.0;
 #pragma unroll
           for (int q2 = q + 1; q2 < 16; ++q2)
-            if (q2 < pb) { g[q2] -= sEC[(long)q * ldc + q2] * r; y[q2] -= sEC[(long)q2 * ldc + q] * s; }
+            if (q2 < pb) { g[q2] -= sEC[(q2) * lde + (q)] * r; y[q2] -= sEC[(q) * lde + (q2)] * s; }
           g[q] = r; y[q] = s;
         }
 #pragma unroll
@@ -1120,7 +1133,7 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
     tick_acc(c, 14, tprev);
     // ---- results of the panel, and ONE pass over the trailing parts: E(i, j) -= sum_q v_q(i) s_q(j),  Gh(j, l) -= sum_q R_q(j) R_q(l)
     par_for32(c, pb, [&](int q) { a.tau[k0 + q] = sTau[q]; dnv[k0 + q] = sDn[q]; refl[k0 + q] = sRf[q] != 0.0 ? 1 : 0; });
-    par_for32(c, nrow * pb, [&](int x) { const int q = x / nrow, r = x - q * nrow; E[(p0 + r) + ec * (k0 + q)] = sEC[(long)r * ldc + q]; });
+    par_for32(c, nrow * pb, [&](int x) { const int q = x / nrow, r = x - q * nrow; E[(p0 + r) + ec * (k0 + q)] = sEC[(q) * lde + (r)]; });
     par_for32(c, ntr * pb, [&](int x) {
       const int q = x / ntr, jj = x - q * ntr, j = k0 + pb + jj;
       E[(p0 + q) + ec * j] = sGP[(long)q * n1 + jj];
@@ -1141,7 +1154,7 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
           for (int q = 0; q < pb; ++q) {
             double av[4], bv[4];
 #pragma unroll
-            for (int z = 0; z < 4; ++z) { av[z] = sEC[(long)(pb + io[z]) * ldc + q]; bv[z] = sEP[(long)q * n1 + jo[z]]; }
+            for (int z = 0; z < 4; ++z) { av[z] = sEC[(q) * lde + ((pb + io[z]))]; bv[z] = sEP[(long)q * n1 + jo[z]]; }
 #pragma unroll
             for (int zi = 0; zi < 4; ++zi)
 #pragma unroll
@@ -1157,9 +1170,13 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
 #pragma unroll
             for (int zi = 0; zi < 4; ++zi) if (i0 + zi < ni && j0 + zj < ntr) E[(p0 + pb + i0 + zi) + ec * (k0 + pb + j0 + zj)] = old[zj * 4 + zi] - acc[zj * 4 + zi];
         } else {
+          // tiles of the lower triangle numbered down the tile columns (consecutive threads: consecutive rows of the column-major Gh)
           const int t = x - ntE;
-          int bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5); while (bi * (bi + 1) / 2 > t) --bi; while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
-          const int bj = t - bi * (bi + 1) / 2, i0 = 4 * bi, j0 = 4 * bj;      // rows i0.. (>= columns j0..)
+          const double w2 = 2.0 * tj + 1.0;
+          int bj = (int)((w2 - sqrt(w2 * w2 - 8.0 * t)) * 0.5);
+          while (bj > 0 && bj * tj - bj * (bj - 1) / 2 > t) --bj;
+          while ((bj + 1) * tj - (bj + 1) * bj / 2 <= t) ++bj;
+          const int bi = bj + (t - (bj * tj - bj * (bj - 1) / 2)), i0 = 4 * bi, j0 = 4 * bj;      // rows i0.. (>= columns j0..)
           int io[4], jo[4];
 #pragma unroll
           for (int z = 0; z < 4; ++z) { io[z] = i0 + z < ntr ? i0 + z : ntr - 1; jo[z] = j0 + z < ntr ? j0 + z : ntr - 1; }

@@ -494,6 +494,8 @@ struct Batch : BatchBase {
       std::fprintf(stderr, "[k_literal b=%d] us: explicit rows %.0f Gram %.0f sweep %.0f kept %.0f handed-through rows %.0f basis products %.0f Z fill %.0f eliminate %.0f store %.0f total %.0f\n", b,
                    (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01, (t[5] - t[4]) * 0.01, (t[6] - t[5]) * 0.01,
                    (t[8] - t[6]) * 0.01, (t[10] - t[8]) * 0.01, (t[11] - t[10]) * 0.01, (t[9] - t[11]) * 0.01, (t[9] - t[0]) * 0.01);
+      std::fprintf(stderr, "[k_literal b=%d] us: the sweep's panels = stage %.0f + core %.0f + rows / columns %.0f + results and trailing pass %.0f\n", b,
+                   t[12] * 0.01, t[13] * 0.01, t[14] * 0.01, t[15] * 0.01);
     }
     return 0;
   }

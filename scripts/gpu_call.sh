@@ -9,6 +9,7 @@
 #   sweep        scripts/sweep_variants.py (streams / streamed) profile     scripts/profile_round.sh (kernel stats + PMC passes of cfg3)
 #   lit_profile  rocprofv3 kernel stats + PMC passes of bench.py --config cfg4 (literal route)
 #   cfg2_profile rocprofv3 kernel stats of bench.py --config cfg2
+#   pause        scripts/pause_probe.py: the first window after a pause (state reads, sleeps) against the median, streamed / resident
 # Outputs land in gpurun_out/$TAG; copy what is to be judged into profiles/ by hand (profiles/README.md lists them).
 cd /root/repo
 TAG=${TAG:-round}
@@ -31,6 +32,7 @@ if has tests; then timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail 
 if has lit_tests; then timeout 1500 python -m pytest tests/test_gpu_literal.py tests/test_gpu_vs_reference.py -m gpu -x -q 2>&1 | tail -12 > $O/pytest_lit.txt; tail -6 $O/pytest_lit.txt; fi
 if has smoke; then python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1; fi
 if has lit_timers; then MSCKF_HIP_LITERAL_TIMERS=1 python scripts/lit_timers.py 2>&1 | tail -14 | tee $O/lit_timers.txt; fi
+if has pause; then python scripts/pause_probe.py 2>&1 | tail -6 | tee $O/pause_probe.txt; fi
 if has bench; then python bench.py > $O/bench.json 2> $O/bench.err; summ bench; fi
 if has cfg4; then python bench.py --config cfg4 --steps 10 --warmup 3 --no-cpu-baseline --no-early-accept-pass --no-other-configs > $O/bench_cfg4.json 2> $O/bench_cfg4.err; summ bench_cfg4; fi
 if has cfgs; then
