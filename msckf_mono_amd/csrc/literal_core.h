@@ -539,21 +539,15 @@ LIT_FN void information_from_rn(const Ctx& c, const Args<HT>& a, int n, int nr) 
         }
       }
       barrier(c);
-      // rows below the block: entry q2 of the row after the pivots q < q2 of the panel
+      // rows below the block: entry q2 of the row after the pivots q < q2 of the panel, in place in LDS (a thread's row is a
+      // column of banks of its own; sixteen values in registers per thread spilled at 1 024 threads per workgroup)
       par_for32(c, mrow - pb, [&](int x) {
-        const int r = pb + x;
-        double y[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) y[q] = q < pb ? sP[q * ldr + r] : 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          if (q >= pb) break;
-          const double yq = y[q] * sD[q];
-#pragma unroll
-          for (int q2 = q + 1; q2 < 16; ++q2) if (q2 < pb) y[q2] -= yq * sP[q * ldr + q2];
+        double* row = sP + pb + x;
+        for (int q = 0; q + 1 < pb; ++q) {
+          const double yq = row[q * ldr] * sD[q];
+          const double* lq = sP + q * ldr;
+          for (int q2 = q + 1; q2 < pb; ++q2) row[q2 * ldr] -= yq * lq[q2];
         }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) if (q < pb) sP[q * ldr + r] = y[q];
       });
       barrier(c);
       // trailing triangle: columns j >= k0 + pb, rows i >= j: Z(i, j) -= sum_q L(i, q) L(j, q) / d_q; tiles numbered down the
@@ -1094,39 +1088,27 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
     tick_acc(c, 13, tprev);
     so.n_reflect += (int)sCnt[0]; so.n_skip_tol += (int)sCnt[1];
     // ---- one thread per row below the panel (its reflector entries) and per column to the right (its entries of R and s)
+    // (in place in LDS: consecutive threads are consecutive words of every array; register arrays of sixteen spilled)
     par_for32(c, (nrow - pb) + ntr, [&](int x) {
-      double y[16], g[16];
       if (x < nrow - pb) {
-        const int rr = pb + x;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) y[q] = q < pb ? sEC[q * lde + rr] : 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          if (q >= pb) break;
-          const double vq = y[q] * sDn[q];             // 0 for a step that did not reflect
-#pragma unroll
-          for (int q2 = q + 1; q2 < 16; ++q2) if (q2 < pb) y[q2] -= vq * sS[q * PB + q2];
-          y[q] = vq;
+        double* row = sEC + pb + x;                        // row[q * lde] = E(p0 + pb + x, k0 + q)
+        for (int q = 0; q < pb; ++q) {
+          const double vq = row[q * lde] * sDn[q];          // 0 for a step that did not reflect
+          const double* sq = sS + q * PB;
+          for (int q2 = q + 1; q2 < pb; ++q2) row[q2 * lde] -= vq * sq[q2];
+          row[q * lde] = vq;
         }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) if (q < pb) sEC[q * lde + rr] = y[q];
       } else {
         const int jj = x - (nrow - pb);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) { y[q] = q < pb ? sEP[(long)q * n1 + jj] : 0.0; g[q] = q < pb ? sGP[(long)q * n1 + jj] : 0.0; }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          if (q >= pb) break;
+        double* yc = sEP + jj; double* gc = sGP + jj;      // yc[q * n1] = E(p0 + q, j), gc[q * n1] = Gh(k0 + q, j)
+        for (int q = 0; q < pb; ++q) {
           const bool rf = sRf[q] != 0.0;
-          const double r = rf ? g[q] * sBi[q] : y[q];
-          const double s = rf ? y[q] - r : 0.0;
-#pragma unroll
-          for (int q2 = q + 1; q2 < 16; ++q2)
-            if (q2 < pb) { g[q2] -= sEC[(q2) * lde + (q)] * r; y[q2] -= sEC[(q) * lde + (q2)] * s; }
-          g[q] = r; y[q] = s;
+          const double yq = yc[(long)q * n1];
+          const double r = rf ? gc[(long)q * n1] * sBi[q] : yq;
+          const double sj = rf ? yq - r : 0.0;
+          for (int q2 = q + 1; q2 < pb; ++q2) { gc[(long)q2 * n1] -= sEC[q2 * lde + q] * r; yc[(long)q2 * n1] -= sEC[q * lde + q2] * sj; }
+          gc[(long)q * n1] = r; yc[(long)q * n1] = sj;
         }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) if (q < pb) { sEP[(long)q * n1 + jj] = y[q]; sGP[(long)q * n1 + jj] = g[q]; }
       }
     });
     barrier(c);

@@ -131,7 +131,7 @@ struct BatchBase {
   virtual int set_aniso(int mode, double tol) = 0;
   virtual int error_flags(int b, int* flags) = 0;
   virtual int copy_from(BatchBase* src) = 0;
-  virtual int lit_info(int b, int* out4) = 0;
+  virtual int lit_info(int b, int* out8) = 0;
 };
 
 constexpr int NSTAGE = 11;   // 0..7: msckf_hip_profile_read; 8 k_lit_pre, 9 k_lit_gamma, 10 k_literal (msckf_hip_profile_read_ex)
@@ -150,14 +150,20 @@ struct Workers {
   // given (msckf_hip_set_host_affinity): the hand-overs between the uploading thread and the slices' enqueue threads are
   // spin waits, and a waiter that the scheduler moves or parks costs a frame's worth of time
   std::vector<int> cpus;
-  static void pin_self(int cpu) {
-    if (cpu < 0) return;
+  // cpu >= 0: pin the calling worker to it (its original mask is saved on the first pin); cpu < 0: back to the original mask
+  static void pin_self(int cpu, cpu_set_t* orig, bool* have_orig) {
+    if (cpu < 0) {
+      if (*have_orig) (void)pthread_setaffinity_np(pthread_self(), sizeof(*orig), orig);
+      return;
+    }
+    if (!*have_orig) { if (pthread_getaffinity_np(pthread_self(), sizeof(*orig), orig) == 0) *have_orig = true; }
     cpu_set_t set; CPU_ZERO(&set); CPU_SET(cpu, &set);
     (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
   }
   void loop(int idx) {
     unsigned long seen = 0;
     int pinned = -2;
+    cpu_set_t orig; bool have_orig = false;
     for (;;) {
       std::function<void(int)> f;
       {
@@ -168,7 +174,7 @@ struct Workers {
         if (idx >= active) continue;
         f = job;
         const int want = idx + 1 < (int)cpus.size() ? cpus[idx + 1] : -1;
-        if (want != pinned) { pin_self(want); pinned = want; }
+        if (want != pinned) { pin_self(want, &orig, &have_orig); pinned = want; }
       }
       f(idx);
       { std::lock_guard<std::mutex> lk(m); if (--pending == 0) cv_done.notify_all(); }
@@ -381,6 +387,20 @@ struct Batch : BatchBase {
     return 0;
   }
   int stage_release() { HIPCHK(hipEventRecord(ev_stage[stage_cur], st)); stage_busy[stage_cur] = true; return 0; }
+  // every slot of the ring at least `bytes` (a commit walks the ring once per frame: without this each slot would be freed and
+  // re-allocated as the frames grow)
+  int stage_reserve(size_t bytes) {
+    for (int k = 0; k < NSTG; ++k) {
+      if (bytes <= h_stage_bytes[k]) continue;
+      if (stage_busy[k]) { HIPCHK(hipEventSynchronize(ev_stage[k])); stage_busy[k] = false; }
+      if (h_stage[k]) HIPCHK(hipHostFree(h_stage[k]));
+      h_stage[k] = nullptr; h_stage_bytes[k] = 0;
+      const size_t nb = std::max<size_t>(bytes, 1 << 12);
+      HIPCHK(hipHostMalloc((void**)&h_stage[k], nb, hipHostMallocDefault));
+      h_stage_bytes[k] = nb;
+    }
+    return 0;
+  }
   void use_single_worklists() {
     d.trk_n = wl_n; d.trk_M = wl_M; d.trk_slots = wl_slots; d.trk_obs = wl_obs; d.trk_off = nullptr;
     d.wl_stride_n = 1; d.wl_stride_f = f_cap; d.wl_stride_o = (long)f_cap * m_cap;
@@ -481,11 +501,11 @@ struct Batch : BatchBase {
     }
     return 0;
   }
-  int lit_info(int b, int* out4) override {
+  int lit_info(int b, int* out8) override {
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
-    if (!d.lit.info) { for (int i = 0; i < 8; ++i) out4[i] = 0; return 0; }
+    if (!d.lit.info) { for (int i = 0; i < 8; ++i) out8[i] = 0; return 0; }
     HIPCHK(hipSetDevice(device));
-    HIPCHK(hipMemcpyAsync(out4, d.lit.info + (size_t)b * 8, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out8, d.lit.info + (size_t)b * 8, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (d.lit.tim) {     // MSCKF_HIP_LITERAL_TIMERS=1 (profiling runs): phase durations of the last launch in microseconds on stderr
       long long t[16];
@@ -664,11 +684,20 @@ struct Batch : BatchBase {
     const bool fuse = fuse_prune && !prof && !overlap_feature && d.joseph == 0;
     if (fuse && f1 - f0 >= 2 && ((f1 - f0 - 1) & 1)) std::swap(d.P, P_spare);
   }
+  // compression route of an update's launches (k_feature publishes B^ only for the information form): the handle's choice,
+  // except that a batch with a trajectory on the literal anisotropic route always takes the information form (that route hands
+  // over an information matrix: Cholesky tail).  Every launch of an update -- the early k_feature of the overlap path too --
+  // asks here.
+  int update_compress(int base) const {
+    int cmp = base;
+    if (compress_route >= 0) cmp = (compress_route && d.trk_B) ? 3 : 0;
+    if (n_lit > 0 && !cmp) cmp = d.compress;
+    return cmp;
+  }
   void launch_update(const Dev<S>& vin, int b0, int nb, hipStream_t q, bool feature_done = false) {
     invalidate_imu(b0, nb);            // the update corrects the IMU state on the device (msckf.h:1376-1383)
     Dev<S> v = vin;
-    if (compress_route >= 0) v.compress = (compress_route && d.trk_B) ? 3 : 0;
-    if (n_lit > 0 && !v.compress) v.compress = d.compress;   // the literal route hands over an information matrix: Cholesky tail
+    v.compress = update_compress(v.compress);
     if (!feature_done) { stage_begin(2, q); launch_feature<S>(v, b0, nb, q); stage_end(2, q); }
     // information form: k_select and the block-diagonal reduction share a launch (both only read k_feature's outputs)
     stage_begin(7, q); if (v.compress) launch_select_diag<S>(v, b0, nb, q); else launch_select<S>(v, b0, nb, q); stage_end(7, q);
@@ -862,6 +891,7 @@ struct Batch : BatchBase {
     Batch<S>* o = dynamic_cast<Batch<S>*>(src);
     if (!o || o->B != B || o->n_cap != n_cap || o->f_cap != f_cap || o->m_cap != m_cap || o->h16 != h16)
       return fail(-EINVAL, "copy_state: handles differ in shape or dtype");
+    if (o->poisoned) return fail(-EIO, "copy_state: the source handle is unusable after a failed run_frames call (its filter states are undefined)");
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamSynchronize(o->st));
     const size_t Bz = B, pl = (size_t)d.ld * d.ld;
@@ -874,6 +904,7 @@ struct Batch : BatchBase {
     compress_route = o->compress_route; d.joseph = o->d.joseph; d.gate_early = o->d.gate_early; nstreams = o->nstreams;
     overlap_feature = o->overlap_feature; d.gain_fused_s = o->d.gain_fused_s; fuse_prune = o->fuse_prune;
     HIPCHK(hipStreamSynchronize(st));
+    std::fill(h_lit.begin(), h_lit.end(), 0); n_lit = 0;   // which trajectories run the literal route is re-derived from the copied parameters
     return set_aniso(o->aniso_mode, o->lit_tol);   // re-derives the per-trajectory noise parameters, allocates the literal route's work space if needed
   }
   int error_flags(int b, int* flags) override {
@@ -1018,11 +1049,10 @@ struct Batch : BatchBase {
     HIPCHK(hipMemcpyAsync(sc_M, h_M.data(), h_M.size() * sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(sc_off, h_off.data(), h_off.size() * sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(sc_drop, h_drop.data(), h_drop.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    {   // size the pinned staging area once, for the largest frame
+    {   // size the pinned staging ring once, for the largest frame
       size_t mx = 0;
       for (int f = 0; f < sc_frames; ++f) mx = std::max(mx, fr_base[f + 1] - fr_base[f]);
-      unsigned char* raw = nullptr;
-      int rc = stage_acquire(mx * (sizeof(int) + 2 * sizeof(S)), &raw);
+      const int rc = stage_reserve(mx * (sizeof(int) + 2 * sizeof(S)));
       if (rc) return rc;
     }
     for (int f = 0; f < sc_frames; ++f) {            // one frame at a time through the pinned staging area (bounded host memory)
@@ -1259,7 +1289,7 @@ int Batch<S>::run_frames(int f0, int f1) {
         (void)hipEventRecord(ev_fa[hh], q);
         (void)hipStreamWaitEvent(sty[hh], ev_fa[hh], 0);
         Dev<S> v2 = v; v2.ncam_bias = 1;
-        if (compress_route >= 0) v2.compress = (compress_route && d.trk_B) ? 3 : 0;
+        v2.compress = update_compress(v2.compress);
         launch_feature<S>(v2, b0, nb, sty[hh]);
         (void)hipEventRecord(ev_fb[hh], sty[hh]);
       }
@@ -1389,7 +1419,8 @@ int Batch<S>::run_frames_streamed(int f0, int f1) {
   // the uploading (calling) thread on its own core for the duration of the call, when a list of cores was given
   cpu_set_t old_mask; bool repin = false;
   if (!workers.cpus.empty() && workers.cpus[0] >= 0 && pthread_getaffinity_np(pthread_self(), sizeof(old_mask), &old_mask) == 0) {
-    Workers::pin_self(workers.cpus[0]); repin = true;
+    cpu_set_t one; CPU_ZERO(&one); CPU_SET(workers.cpus[0], &one);
+    (void)pthread_setaffinity_np(pthread_self(), sizeof(one), &one); repin = true;
   }
   workers.start(nh, slice);
   int rc_up = 0;
@@ -1899,6 +1930,6 @@ int msckf_hip_set_gate_early_accept(msckf_hip_handle h, int on) { if (!h) return
 int msckf_hip_set_anisotropic_noise(msckf_hip_handle h, int mode, double tail_tol) { if (!h) return fail(-EINVAL, "null handle"); return H(h)->set_aniso(mode, tail_tol); }
 int msckf_hip_copy_state(msckf_hip_handle dst, msckf_hip_handle src) { if (!dst || !src) return fail(-EINVAL, "null handle"); return H(dst)->copy_from(H(src)); }
 int msckf_hip_get_error_flags(msckf_hip_handle h, int b, int* flags) { if (!h || !flags) return fail(-EINVAL, "null argument"); return H(h)->error_flags(b, flags); }
-int msckf_hip_literal_info(msckf_hip_handle h, int b, int* out4) { if (!h || !out4) return fail(-EINVAL, "null argument"); return H(h)->lit_info(b, out4); }
+int msckf_hip_literal_info(msckf_hip_handle h, int b, int* out8) { if (!h || !out8) return fail(-EINVAL, "null argument"); return H(h)->lit_info(b, out8); }
 
 }  // extern "C"
