@@ -321,14 +321,32 @@ __global__ __launch_bounds__(64) void k_lit_gamma(Dev<S> d, int b0, int nb, int 
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = lg_v4d{0.0, 0.0, 0.0, 0.0};
   const double* dummy = L.Du;                                // an always-valid word for the lanes whose column a track does not have
+  // the sorted track list and the tracks' slot ranges, 64 per register (four registers: up to 256 stacked tracks are served by
+  // v_readlane; a pair's operands then depend on nothing but registers -- two levels of dependent loads per pair otherwise)
+  int ordv[4], flv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = lane + 64 * k;
+    ordv[k] = e < P ? order[e] : 0;
+    flv[k] = e < P ? d.trk_first[(long)b * f_cap + ordv[k]] : 0;
+  }
+  auto track_of = [&](int e, int& t, int& fl) {
+    if (e < 256) {
+      const int k = e >> 6, l = e & 63;
+      const int ov = k == 0 ? ordv[0] : (k == 1 ? ordv[1] : (k == 2 ? ordv[2] : ordv[3]));
+      const int fv = k == 0 ? flv[0] : (k == 1 ? flv[1] : (k == 2 ? flv[2] : flv[3]));
+      t = wave_bcast(ov, l); fl = wave_bcast(fv, l);
+    } else { t = order[e]; fl = d.trk_first[(long)b * f_cap + t]; }
+  };
+#pragma unroll 2
   for (int e0 = 0; e0 < P; e0 += 2) {
     // the pair of tracks (e0, e0 + 1): ranges, overlap with the tile's rows and columns
     int tt[2], lo[2], hi[2]; bool use[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int e = e0 + u;
-      tt[u] = e < P ? order[e] : 0;
-      const int fl = e < P ? d.trk_first[(long)b * f_cap + tt[u]] : 0;
+      int fl = 0; tt[u] = 0;
+      if (e < P) track_of(e, tt[u], fl);
       lo[u] = 6 * (fl & 63); hi[u] = 6 * ((fl >> 8) & 63) + 5;
       use[u] = e < P && lo[u] < 32 * ti + 32 && hi[u] >= 32 * ti && lo[u] < 32 * tj + 32 && hi[u] >= 32 * tj;
     }

@@ -99,6 +99,9 @@ LIT_FN double lit_rsqrt(double x) { return 1.0 / sqrt(x); }
 LIT_FN double lit_rcp(double x) { return 1.0 / x; }
 // par_for with a 32-bit index (the device divides 32-bit indices ~10x faster than 64-bit ones)
 template <class F> LIT_FN void par_for32(const Ctx&, int n, F f) { for (int i = 0; i < n; ++i) f(i); }
+// st(i, val(i)) for i in [0, n): the device evaluates four items before it stores the first (a store followed by the next
+// item's dependent loads is a memory round trip when the compiler cannot rule out that they alias)
+template <class FV, class FS> LIT_FN void par_map4(const Ctx&, int n, FV val, FS st) { for (int i = 0; i < n; ++i) st(i, val(i)); }
 // a section run by ONE wavefront with wave_sync between its dependent steps (no workgroup barrier inside)
 LIT_FN bool first_wave(const Ctx&) { return true; }
 LIT_FN void wave_sync(const Ctx&) {}
@@ -352,6 +355,15 @@ LIT_FN long long tick_now(const Ctx& c) { return (c.tim && c.tid == 0) ? (long l
 LIT_FN double lit_rsqrt(double x) { return fast_rsqrt(x); }
 LIT_FN double lit_rcp(double x) { return fast_rcp(x); }
 template <class F> LIT_FN void par_for32(const Ctx& c, int n, F f) { for (int i = c.tid; i < n; i += c.nt) f(i); }
+template <class FV, class FS> LIT_FN void par_map4(const Ctx& c, int n, FV val, FS st) {
+  for (int i0 = c.tid; i0 < n; i0 += 4 * c.nt) {
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = i0 + u * c.nt; v[u] = i < n ? val(i) : 0.0; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = i0 + u * c.nt; if (i < n) st(i, v[u]); }
+  }
+}
 LIT_FN bool first_wave(const Ctx& c) { return c.wave == 0; }
 // LDS hand-over between the lanes of one wavefront: the fences keep the compiler from moving reads above writes
 LIT_FN void wave_sync(const Ctx&) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
@@ -376,6 +388,17 @@ template <class P> LIT_FN int compact_list(const Ctx& c, int n, int* out, P pred
   return r;
 }
 #endif
+
+// dst[q2 * ds] -= coef * src[q2 * ss] for q2 in [lo, hi), hi - lo <= 16, both in LDS: every operand is read before the first
+// result is written (a store followed by the next element's loads is a full LDS round trip when the compiler cannot rule
+// out that they alias: 120 of them per thread and panel)
+LIT_FN void lds_axpy16(double* dst, long ds, const double* src, long ss, int lo, int hi, double coef) {
+  double t[16], w[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) { const int q2 = lo + u; const bool on = q2 < hi; t[u] = on ? dst[q2 * ds] : 0.0; w[u] = on ? src[q2 * ss] : 0.0; }
+#pragma unroll
+  for (int u = 0; u < 16; ++u) { const int q2 = lo + u; if (q2 < hi) dst[q2 * ds] = t[u] - coef * w[u]; }
+}
 
 // One trajectory's inputs (what k_feature / k_select left behind) and work space.  HT: scalar type of the Jacobian blocks.
 template <class HT>
@@ -476,7 +499,7 @@ LIT_FN void track_null_space(const Args<HT>& a, int t) {
   T[5] = -tau[2] * T[4] * d12;                       // T(1,2)
 }
 
-template <class HT> LIT_FN void information_from_rn(const Ctx& c, const Args<HT>& a, int n, int nr);
+template <class HT> LIT_FN void information_from_rn(const Ctx& c, const Args<HT>& a, int n, int nr, bool appended = false);
 
 // Tail of both routes: R_n = v' I + (u' - v') G^T G (msckf.h:1366), then Z = [[R_n, .], [[T_H | r_n]^T, 0]] (lower triangle);
 // eliminating the nr pivots of R_n leaves -[T_H | r_n]^T R_n^-1 [T_H | r_n] in the trailing block = -Lam^.
@@ -492,13 +515,14 @@ LIT_FN void information_from_compressed(const Ctx& c, const Args<HT>& a, int n, 
 
 // Z(0:nr, 0:nr) holds the lower triangle of R_n: append [T_H | r_n]^T, eliminate, store Lam^
 template <class HT>
-LIT_FN void information_from_rn(const Ctx& c, const Args<HT>& a, int n, int nr) {
+LIT_FN void information_from_rn(const Ctx& c, const Args<HT>& a, int n, int nr, bool appended) {
   const int rc = a.r_cap, n1 = n + 1;
   const int nz = nr + n1;
   const long ldz = a.ldz;
   double* Z = a.Z;
-  par_for32(c, n1 * nz, [&](int x) {
-    const int j = x / n1, cc = x - j * n1;
+  // appended: the caller wrote [T_H | r_n]^T below R_n itself (rows nr .., columns < nr); the block right of it starts as zero
+  par_for32(c, n1 * (appended ? n1 : nz), [&](int x) {
+    const int jq = x / n1, cc = x - jq * n1, j = appended ? nr + jq : jq;
     Z[(nr + cc) + ldz * j] = j < nr ? a.TH[j + (long)rc * cc] : 0.0;
   });
   barrier(c);
@@ -543,11 +567,7 @@ LIT_FN void information_from_rn(const Ctx& c, const Args<HT>& a, int n, int nr) 
       // column of banks of its own; sixteen values in registers per thread spilled at 1 024 threads per workgroup)
       par_for32(c, mrow - pb, [&](int x) {
         double* row = sP + pb + x;
-        for (int q = 0; q + 1 < pb; ++q) {
-          const double yq = row[q * ldr] * sD[q];
-          const double* lq = sP + q * ldr;
-          for (int q2 = q + 1; q2 < pb; ++q2) row[q2 * ldr] -= yq * lq[q2];
-        }
+        for (int q = 0; q + 1 < pb; ++q) lds_axpy16(row, ldr, sP + q * ldr, 1, q + 1, pb, row[q * ldr] * sD[q]);
       });
       barrier(c);
       // trailing triangle: columns j >= k0 + pb, rows i >= j: Z(i, j) -= sum_q L(i, q) L(j, q) / d_q; tiles numbered down the
@@ -603,10 +623,12 @@ LIT_FN void information_from_rn(const Ctx& c, const Args<HT>& a, int n, int nr) 
   }
   tick(c, 11);
   // ---- Lam^ (lower triangle incl. row n) where the blocked Cholesky reads it
-  par_for32(c, n1 * n1, [&](int x) {
-    const int hi = x / n1, lo = x - hi * n1;
-    if (lo > hi) return;
-    a.Lam[(long)hi * a.ldL + lo] = -Z[(nr + hi) + ldz * (nr + lo)];
+  par_map4(c, n1 * n1, [&](int x) -> double {
+    const int lo = x / n1, hi = x - lo * n1;
+    return lo > hi ? 0.0 : -Z[(nr + hi) + ldz * (nr + lo)];
+  }, [&](int x, double v) {
+    const int lo = x / n1, hi = x - lo * n1;
+    if (lo <= hi) a.Lam[(long)hi * a.ldL + lo] = v;
   });
   barrier(c);
 }
@@ -856,7 +878,7 @@ LIT_FN double lam_in(const Args<HT>& a, int hi, int lo) {   // hi >= lo
 // of Z = [[Bs^T R_o Bs, .], [(Bs^T A)^T, 0]] (information_from_rn).
 LIT_HD long compact_ws_doubles(int n, int m_cap, int r_cap, int /*ldg*/) {
   const long n1 = n + 1, ec = 15 + n;
-  return 2 * ec * n1 + ec * 2L * m_cap + 3 * n1 * n1 + 34 * n1 + ec * ec + ec * (long)n + 15L * n + 4 * ec
+  return 2 * ec * n1 + ec * 2L * m_cap + 3 * n1 * n1 + 35 * n1 + ec * ec + ec * (long)n + 15L * n + 4 * ec
        + 3L * n * n + 2 * ec * (long)n + 2L * n * n + 128;
 }
 
@@ -904,7 +926,7 @@ LIT_FN void explicit_row_products(const Ctx& c, const Args<HT>& a, int e, int n,
   const int nrow = i_hi - i_lo;
   if (nrow <= 0) return;
   const long mc2 = 2L * a.m_cap;
-  par_for(c, (long)nrow * n, [&](long x) { const long j = x / nrow, i = i_lo + (x - j * nrow); Xe[i + ec * j] = 0.0; });
+  par_for32(c, nrow * n, [&](int x) { const int j = x / nrow, i = i_lo + (x - j * nrow); Xe[i + ec * j] = 0.0; });
   // g3_i = Q_f^T (D_u a_i)
   par_for(c, nrow, [&](long ii) {
     const int i = i_lo + (int)ii, t = topt[i], M = a.M[t];
@@ -915,8 +937,8 @@ LIT_FN void explicit_row_products(const Ctx& c, const Args<HT>& a, int e, int n,
     for (int x = 0; x < 3; ++x) G3[i * 3 + x] = g[x];
   });
   barrier(c);
-  par_for(c, (long)nrow * a.m_cap, [&](long x) {
-    const int i = i_lo + (int)(x / a.m_cap), o = (int)(x % a.m_cap), t = topt[i];
+  par_for32(c, nrow * a.m_cap, [&](int x) {
+    const int i = i_lo + x / a.m_cap, o = x % a.m_cap, t = topt[i];
     if (o >= a.M[t]) return;
     const double* V = a.Vf + (long)t * 2 * a.m_cap * 3;
     double Z3[9]; qf_z3(V, a.Tf + (long)t * 9, Z3);
@@ -931,8 +953,8 @@ LIT_FN void explicit_row_products(const Ctx& c, const Args<HT>& a, int e, int n,
     for (int kk = 0; kk < 6; ++kk) Xe[i + ec * (col + kk)] = w0 * hh[kk] + w1 * hh[6 + kk];
   });
   // See: pairs of explicit rows of one track (rows of [i_lo, i_hi) against every explicit row of their track)
-  par_for(c, (long)nrow * e, [&](long x) {
-    const int i = i_lo + (int)(x / e), i2 = (int)(x % e);
+  par_for32(c, nrow * e, [&](int x) {
+    const int i = i_lo + x / e, i2 = x % e;
     const int t = topt[i];
     double sacc = 0;
     if (topt[i2] == t) { const int M = a.M[t]; for (int o = 0; o < M; ++o) sacc += At[i * mc2 + 2 * o] * At[i2 * mc2 + 2 * o]; }
@@ -1094,8 +1116,7 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
         double* row = sEC + pb + x;                        // row[q * lde] = E(p0 + pb + x, k0 + q)
         for (int q = 0; q < pb; ++q) {
           const double vq = row[q * lde] * sDn[q];          // 0 for a step that did not reflect
-          const double* sq = sS + q * PB;
-          for (int q2 = q + 1; q2 < pb; ++q2) row[q2 * lde] -= vq * sq[q2];
+          lds_axpy16(row, lde, sS + q * PB, 1, q + 1, pb, vq);
           row[q * lde] = vq;
         }
       } else {
@@ -1106,7 +1127,8 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
           const double yq = yc[(long)q * n1];
           const double r = rf ? gc[(long)q * n1] * sBi[q] : yq;
           const double sj = rf ? yq - r : 0.0;
-          for (int q2 = q + 1; q2 < pb; ++q2) { gc[(long)q2 * n1] -= sEC[q2 * lde + q] * r; yc[(long)q2 * n1] -= sEC[q * lde + q2] * sj; }
+          lds_axpy16(gc, n1, sEC + q, lde, q + 1, pb, r);               // Gh(k0 + q2, j) -= R(p0 + q, k0 + q2) R(p0 + q, j)
+          lds_axpy16(yc, n1, sEC + q * lde, 1, q + 1, pb, sj);          // E(p0 + q2, j) -= v_q(p0 + q2) s_q(j)
           gc[(long)q * n1] = r; yc[(long)q * n1] = sj;
         }
       }
@@ -1235,7 +1257,7 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
   const int e = m < D ? m : D;                  // explicit rows
   const int msteps = e - 15 > 0 ? e - 15 : 0;
   const bool gram = m > e;
-  const long ec = 15 + n, rc = a.r_cap, mc2 = 2L * a.m_cap;
+  const long ec = 15 + n, mc2 = 2L * a.m_cap;
   double* E = a.W2;                             // [ec x n1] column-major: the explicit rows; ends as R (rows) and the reflectors' explicit parts (below the pivots)
   double* E0 = E + ec * n1;                     // [ec x n1] the explicit rows as they were
   double* At = E0 + ec * n1;                    // [ec][2 m_cap]: a_i = A_j e_(i - row0) for the explicit rows
@@ -1243,7 +1265,7 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
   double* Ac = Gh + (long)n1 * n1;              // [n1 x n1] Ac[j + n1 k] = s_j / (c0 - beta) of step k (column operations of the sweep), j > k
   double* G0s = Ac + (long)n1 * n1;             // [n1 x n1] lower triangle, column-major: Gh as it starts (the Gram matrix of the rows from row 15 down)
   double* Stg = G0s + (long)n1 * n1;            // [2][n1][16] stand-in for the LDS staging of the first 15 rows when the staging area is too small
-  double* Ld = Stg + 32L * n1;                  // [n1] squared column norms
+  double* Ld = Stg + 33L * n1;                  // [n1] squared column norms
   double* See = Ld + n1;                        // [ec x ec] G_E^T G_E (blocks of the tracks that own explicit rows)
   double* Xe = See + ec * ec;                   // [ec x n] G_E^T H_u
   double* Ut = Xe + ec * (long)n;               // [15 x n] See15 E15 / 2 - Xe15
@@ -1270,7 +1292,7 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
     const int r0 = a.row0[t], r1 = r0 + 2 * a.M[t] - 3;
     for (int i = r0; i < r1 && i < e; ++i) topt[i] = (int)t;
   });
-  par_for(c, (long)e * n1, [&](long x) { const long j = x / e, i = x - j * e; E[i + ec * j] = 0.0; E0[i + ec * j] = 0.0; });
+  par_for32(c, e * n1, [&](int x) { const int j = x / e, i = x - j * e; E[i + ec * j] = 0.0; E0[i + ec * j] = 0.0; });
   barrier(c);
   par_for(c, e, [&](long i) {
     const int t = topt[i], q = 3 + (int)i - a.row0[t];
@@ -1281,8 +1303,8 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
     for (int p = 0; p < 3; ++p) { double x = 0; for (int qq = p; qq < 3; ++qq) x += T[p * 3 + qq] * sv[qq]; G3[i * 3 + p] = x; }
   });
   barrier(c);
-  par_for(c, (long)e * a.m_cap, [&](long x) {
-    const int i = (int)(x / a.m_cap), o = (int)(x % a.m_cap), t = topt[i];
+  par_for32(c, e * a.m_cap, [&](int x) {
+    const int i = x / a.m_cap, o = x % a.m_cap, t = topt[i];
     if (o >= a.M[t]) return;
     const int q = 3 + i - a.row0[t];
     const double* V = a.Vf + (long)t * 2 * a.m_cap * 3;
@@ -1308,8 +1330,8 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
   const int e15 = e < 15 ? e : 15;
   explicit_row_products(c, a, e, n, ec, 0, e15, topt, At, See, Xe, G3);
   // Ut = See15 E15 / 2 - Xe15  (zero rows beyond e15)
-  par_for(c, 15L * n, [&](long x) {
-    const int cc = (int)(x / 15), l = (int)(x - 15L * cc);
+  par_for32(c, 15 * n, [&](int x) {
+    const int cc = x / 15, l = x - 15 * cc;
     double s = 0;
     if (l < e15) { for (int l2 = 0; l2 < e15; ++l2) s += See[l + ec * l2] * E[l2 + ec * cc]; s = 0.5 * s - Xe[l + ec * cc]; }
     Ut[l + 15L * cc] = s;
@@ -1318,7 +1340,7 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
   tick(c, 2);
   // ---- Gh = [H_o | r_o]^T [H_o | r_o] minus the first 15 rows (lower triangle; the corner (n, n) is never a pivot), kept a
   // second time (G0s) for the basis products; the first 15 rows staged [column][16]
-  double* sE = 32L * n1 <= c.lds_doubles ? c.lds : Stg;
+  double* sE = 33L * n1 <= c.lds_doubles ? c.lds : Stg;   // (+ n1 / 2 doubles: the basis list of the last phase)
   double* sU = sE + 16L * n1;
   auto stage15 = [&]() {
     par_for32(c, 16 * n1, [&](int x) {
@@ -1329,16 +1351,17 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
     barrier(c);
   };
   stage15();
-  par_for32(c, n1 * n1, [&](int x) {
+  par_map4(c, n1 * n1, [&](int x) -> double {
+    const int lo = x / n1, hi = x - lo * n1;
+    if (hi < lo || (hi == n && lo == n)) return 0.0;
+    double v = lam_in(a, hi, lo);
+    const double* eh = sE + 16 * hi; const double* el = sE + 16 * lo;
+#pragma unroll
+    for (int l = 0; l < 15; ++l) v -= eh[l] * el[l];
+    return v;
+  }, [&](int x, double v) {
     const int lo = x / n1, hi = x - lo * n1;
     if (hi < lo) return;
-    double v = 0.0;
-    if (!(hi == n && lo == n)) {
-      v = lam_in(a, hi, lo);
-      const double* eh = sE + 16 * hi; const double* el = sE + 16 * lo;
-#pragma unroll
-      for (int l = 0; l < 15; ++l) v -= eh[l] * el[l];
-    }
     G0s[hi + (long)n1 * lo] = v;
     if (gram) Gh[hi + (long)n1 * lo] = v;
   });
@@ -1353,7 +1376,7 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
   tick(c, 4);
   // ---- rows of R that are kept (msckf.h:1345-1348): a row with an entry above tol * max|R| in its upper-triangular part
   double rmax = 0;
-  if (a.tol > 0) rmax = wg_max(c, 0, (long)e * n, [&](long x) { const long j = x / e, i = x - j * e; return (j + 15 >= i) ? fabs(E[i + ec * j]) : 0.0; });
+  if (a.tol > 0) rmax = wg_max(c, 0, (long)e * n, [&](long xl) { const int x = (int)xl, j = x / e, i = x - j * e; return (j + 15 >= i) ? fabs(E[i + ec * j]) : 0.0; });
   par_for(c, e, [&](long i) { flag[i] = 0; });
   barrier(c);
   par_for(c, n, [&](long j) {                    // a thread per column (contiguous); every writer of a flag writes 1
@@ -1449,23 +1472,26 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
   {
     const long ldz = a.ldz;
     stage15();
-    par_for32(c, nr * nr, [&](int x) {
+    int* sB = reinterpret_cast<int*>(sU + 16L * n1);      // the basis list beside the staged rows
+    par_for32(c, nr, [&](int k) { sB[k] = bidx[k]; });
+    barrier(c);
+    par_map4(c, nr * nr, [&](int x) -> double {
       const int kb = x / nr, ka = x - kb * nr;
-      if (ka < kb) return;
+      if (ka < kb) return 0.0;
       double val;
       if (ka < na) {                               // (e_i, e_i')
-        const int i = bidx[ka], i2 = bidx[kb];
+        const int i = sB[ka], i2 = sB[kb];
         val = (i == i2 ? a.v_var : 0.0) + dlt * See[i + ec * i2];
       } else if (ka < na + nb) {
-        const int cc = bidx[ka];
+        const int cc = sB[ka];
         const double* ec_ = sE + 16 * cc; const double* uc_ = sU + 16 * cc;
         if (kb < na) {                             // (x'_c, e_i)
-          const int i = bidx[kb];
+          const int i = sB[kb];
           double sacc = Xe[i + ec * cc];
           for (int l = 0; l < e15; ++l) sacc -= See[i + ec * l] * ec_[l];
           val = dlt * sacc;
         } else {                                   // (x'_c, x'_c'), c >= c'
-          const int c2 = bidx[kb];
+          const int c2 = sB[kb];
           const double* e2 = sE + 16 * c2; const double* u2 = sU + 16 * c2;
           double sacc = a.Gam[(long)cc * a.ldGam + c2];
 #pragma unroll
@@ -1473,10 +1499,10 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
           val = a.v_var * G0s[cc + (long)n1 * c2] + dlt * sacc;
         }
       } else {
-        const int ah = ka - na - nb, h = 15 + bidx[ka];
-        if (kb < na) val = dlt * Ph[bidx[kb] + ec * ah];                 // (q_h, e_i)
+        const int ah = ka - na - nb, h = 15 + sB[ka];
+        if (kb < na) val = dlt * Ph[sB[kb] + ec * ah];                 // (q_h, e_i)
         else if (kb < na + nb) {                   // (q_h, x'_c): q_h^T x'_c = R(h, c)
-          const int cc = bidx[kb];
+          const int cc = sB[kb];
           double sacc = Qh[cc + (long)n * ah];
           for (int l = 0; l < e15; ++l) sacc -= sE[16 * cc + l] * Ph[l + ec * ah];
           val = a.v_var * (cc + 15 >= h ? E[h + ec * cc] : 0.0) + dlt * sacc;
@@ -1488,20 +1514,26 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
           val = (ah == a2 ? a.v_var : 0.0) + dlt * sacc;
         }
       }
-      a.Z[ka + ldz * kb] = val;
+      return val;
+    }, [&](int x, double val) {
+      const int kb = x / nr, ka = x - kb * nr;
+      if (ka >= kb) a.Z[ka + ldz * kb] = val;
     });
-    par_for32(c, nr * n1, [&](int x) {
-      const int j = x / nr, k = x - j * nr;
+    par_map4(c, nr * n1, [&](int x) -> double {
+      const int k = x / n1, j = x - k * n1;
       double val;
-      if (k < na) val = E0[bidx[k] + ec * j];
-      else if (k < na + nb) { const int cc = bidx[k]; val = cc >= j ? G0s[cc + (long)n1 * j] : G0s[j + (long)n1 * cc]; }
-      else { const int h = 15 + bidx[k]; val = (j == n || j + 15 >= h) ? E[h + ec * j] : 0.0; }
-      a.TH[k + rc * j] = val;
+      if (k < na) val = E0[sB[k] + ec * j];
+      else if (k < na + nb) { const int cc = sB[k]; val = cc >= j ? G0s[cc + (long)n1 * j] : G0s[j + (long)n1 * cc]; }
+      else { const int h = 15 + sB[k]; val = (j == n || j + 15 >= h) ? E[h + ec * j] : 0.0; }
+      return val;
+    }, [&](int x, double val) {
+      const int k = x / n1, j = x - k * n1;
+      a.Z[(nr + j) + ldz * k] = val;               // [T_H | r_n]^T below R_n, where the elimination wants it
     });
   }
   barrier(c);
   tick(c, 8);
-  information_from_rn(c, a, n, nr);
+  information_from_rn(c, a, n, nr, true);
   tick(c, 9);
 }
 
