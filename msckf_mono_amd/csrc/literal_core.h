@@ -356,13 +356,9 @@ LIT_FN double lit_rsqrt(double x) { return fast_rsqrt(x); }
 LIT_FN double lit_rcp(double x) { return fast_rcp(x); }
 template <class F> LIT_FN void par_for32(const Ctx& c, int n, F f) { for (int i = c.tid; i < n; i += c.nt) f(i); }
 template <class FV, class FS> LIT_FN void par_map4(const Ctx& c, int n, FV val, FS st) {
-  for (int i0 = c.tid; i0 < n; i0 += 4 * c.nt) {
-    double v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { const int i = i0 + u * c.nt; v[u] = i < n ? val(i) : 0.0; }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { const int i = i0 + u * c.nt; if (i < n) st(i, v[u]); }
-  }
+  // (measured: four items per thread in flight -- four inlined copies of the value function -- gained nothing on the Gram
+  // start and the basis products and cost registers: one item at a time)
+  for (int i = c.tid; i < n; i += c.nt) st(i, val(i));
 }
 LIT_FN bool first_wave(const Ctx& c) { return c.wave == 0; }
 // LDS hand-over between the lanes of one wavefront: the fences keep the compiler from moving reads above writes
@@ -389,15 +385,17 @@ template <class P> LIT_FN int compact_list(const Ctx& c, int n, int* out, P pred
 }
 #endif
 
-// dst[q2 * ds] -= coef * src[q2 * ss] for q2 in [lo, hi), hi - lo <= 16, both in LDS: every operand is read before the first
-// result is written (a store followed by the next element's loads is a full LDS round trip when the compiler cannot rule
-// out that they alias: 120 of them per thread and panel)
-LIT_FN void lds_axpy16(double* dst, long ds, const double* src, long ss, int lo, int hi, double coef) {
-  double t[16], w[16];
-#pragma unroll
-  for (int u = 0; u < 16; ++u) { const int q2 = lo + u; const bool on = q2 < hi; t[u] = on ? dst[q2 * ds] : 0.0; w[u] = on ? src[q2 * ss] : 0.0; }
-#pragma unroll
-  for (int u = 0; u < 16; ++u) { const int q2 = lo + u; if (q2 < hi) dst[q2 * ds] = t[u] - coef * w[u]; }
+// dst[q2 * ds] -= coef * src[q2 * ss] for q2 in [lo, hi), both in LDS and never overlapping: four elements are read before the
+// first is written (a store followed by the next element's loads is a full LDS round trip when the compiler cannot rule out
+// that they alias: 120 of them per thread and panel; sixteen at a time spilled at 128 registers per thread)
+LIT_FN void lds_axpy16(double* __restrict__ dst, long ds, const double* __restrict__ src, long ss, int lo, int hi, double coef) {
+  int q2 = lo;
+  for (; q2 + 4 <= hi; q2 += 4) {
+    const double d0 = dst[q2 * ds], d1 = dst[(q2 + 1) * ds], d2 = dst[(q2 + 2) * ds], d3 = dst[(q2 + 3) * ds];
+    const double s0 = src[q2 * ss], s1 = src[(q2 + 1) * ss], s2 = src[(q2 + 2) * ss], s3 = src[(q2 + 3) * ss];
+    dst[q2 * ds] = d0 - coef * s0; dst[(q2 + 1) * ds] = d1 - coef * s1; dst[(q2 + 2) * ds] = d2 - coef * s2; dst[(q2 + 3) * ds] = d3 - coef * s3;
+  }
+  for (; q2 < hi; ++q2) dst[q2 * ds] -= coef * src[q2 * ss];
 }
 
 // One trajectory's inputs (what k_feature / k_select left behind) and work space.  HT: scalar type of the Jacobian blocks.

@@ -31,7 +31,12 @@ for s in $STEPS; do case $s in pytest:*) a=${s#pytest:}; timeout 1800 python -m 
 if has tests; then timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $O/pytest.txt; tail -4 $O/pytest.txt; fi
 if has lit_tests; then timeout 1500 python -m pytest tests/test_gpu_literal.py tests/test_gpu_vs_reference.py -m gpu -x -q 2>&1 | tail -12 > $O/pytest_lit.txt; tail -6 $O/pytest_lit.txt; fi
 if has smoke; then python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1; fi
-if has lit_timers; then MSCKF_HIP_LITERAL_TIMERS=1 python scripts/lit_timers.py 2>&1 | tail -14 | tee $O/lit_timers.txt; fi
+if has lit_timers; then
+  # (with msckf_mono_amd/lib_ab/libmsckf_hip_prev.so present: the previous library first, on the same lease -- leases differ by up to 1.6x)
+  P=msckf_mono_amd/lib_ab/libmsckf_hip_prev.so
+  if [ -f $P ]; then MSCKF_HIP_LIB=$P MSCKF_HIP_LITERAL_TIMERS=1 python scripts/lit_timers.py 2>&1 | grep "k_literal b=0" | sed 's/^/prev /' | tee $O/lit_timers_prev.txt; fi
+  MSCKF_HIP_LITERAL_TIMERS=1 python scripts/lit_timers.py 2>&1 | tail -14 | tee $O/lit_timers.txt
+fi
 if has pause; then python scripts/pause_probe.py 2>&1 | tail -6 | tee $O/pause_probe.txt; fi
 if has bench; then python bench.py > $O/bench.json 2> $O/bench.err; summ bench; fi
 if has cfg4; then python bench.py --config cfg4 --steps 10 --warmup 3 --no-cpu-baseline --no-early-accept-pass --no-other-configs > $O/bench_cfg4.json 2> $O/bench_cfg4.err; summ bench_cfg4; fi
