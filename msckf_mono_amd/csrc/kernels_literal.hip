@@ -386,40 +386,86 @@ __global__ __launch_bounds__(64) void k_lit_gamma(Dev<S> d, int b0, int nb, int 
       }
 }
 
+// The trajectory's context of the four phase kernels / the dense-route kernel; false: nothing to do for this workgroup
 template <class S>
-__global__ __launch_bounds__(1024) void k_literal(Dev<S> d, int b0, int nb, int prepared) {
-  const int bi = blockIdx.x, b = b0 + bi;
-  if (bi >= nb) return;
+__device__ __forceinline__ bool lit_ctx(const Dev<S>& d, int b0, int nb, double* red, double* lds, lit::Ctx& c, int& bi, int& b) {
+  bi = blockIdx.x; b = b0 + bi;
+  if (bi >= nb) return false;
   const S* prm = d.prm + (long)b * PRM_STRIDE;
-  if (prm[PRM_LIT] == S(0)) return;                          // isotropic (or pre-whitened) trajectory: k_gram's Lam^ stands
-  int* st = d.stats + (long)b * STAT_STRIDE;
-  if (st[STAT_MROWS] == 0) return;
+  if (prm[PRM_LIT] == S(0)) return false;                    // isotropic (or pre-whitened) trajectory: k_gram's Lam^ stands
+  const int* st = d.stats + (long)b * STAT_STRIDE;
+  if (st[STAT_MROWS] == 0) return false;
+  c.tid = threadIdx.x; c.nt = blockDim.x; c.lane = threadIdx.x & 63; c.wave = threadIdx.x >> 6; c.nw = blockDim.x >> 6; c.red = red;
+  c.tim = d.lit.tim ? d.lit.tim + (long)b * 16 : nullptr; c.lds = lds; c.lds_doubles = LIT_LDS_DOUBLES;
+  return true;
+}
+
+// The compact route as four launches, one workgroup of 1 024 threads per trajectory each (literal_core.h: compact_rows /
+// _sweep / _basis / _eliminate).  As ONE kernel the compiler ran out of its 128 registers per thread and the panel loops
+// reloaded spilled addresses from scratch memory inside their dependent chains; a launch boundary costs ~5 us.
+template <class S, int PHASE>
+__global__ __launch_bounds__(1024) void k_lit_phase(Dev<S> d, int b0, int nb) {
   __shared__ double red[40];                                 // two reductions at a time (literal_core.h: wg_sum2): 2 x 16 wavefronts
   extern __shared__ double lit_lds[];
-  lit::Ctx c;
-  c.tid = threadIdx.x; c.nt = blockDim.x; c.lane = threadIdx.x & 63; c.wave = threadIdx.x >> 6; c.nw = blockDim.x >> 6; c.red = red; c.tim = d.lit.tim ? d.lit.tim + (long)b * 16 : nullptr; c.lds = lit_lds; c.lds_doubles = LIT_LDS_DOUBLES;
+  lit::Ctx c; int bi, b;
+  if (!lit_ctx(d, b0, nb, red, lit_lds, c, bi, b)) return;
   const lit::Args<S> a = lit_args(d, bi, b);
-  if (c.tim && c.tid == 0) for (int q = 12; q < 16; ++q) c.tim[q] = 0;     // accumulating phase timers of the sweep's panels
-  lit::literal_compress(c, a, d.lit.route, prepared != 0);
-  // the blocked Cholesky adds the split-K copies of Lam^ that k_gram leaves (Dev::lam_part apart): none here
+  const int m = a.row0[a.F];
+  if (m <= 0) return;
+  if (PHASE == 0) {
+    if (c.tim && c.tid == 0) { for (int q = 12; q < 16; ++q) c.tim[q] = 0; }     // accumulating phase timers of the sweep's panels
+    lit::tick(c, 0);
+    lit::compact_rows(c, a, m);
+  } else if (PHASE == 1) lit::compact_sweep(c, a, m);
+  else if (PHASE == 2) lit::compact_basis(c, a, m);
+  else {
+    lit::compact_eliminate(c, a);
+    // the blocked Cholesky adds the split-K copies of Lam^ that k_gram leaves (Dev::lam_part apart): none here
+    if (d.lam_part) {
+      const int n1 = 6 * a.N + 1;
+      for (int cpy = 1; cpy < 4; ++cpy) {
+        double* Lc = d.Lam + cpy * d.lam_part + (long)b * d.ldR * d.ldR;
+        for (int e = threadIdx.x; e < n1 * n1; e += blockDim.x) {
+          const int hi = e / n1, lo = e - hi * n1;
+          if (lo <= hi) Lc[(long)hi * d.ldR + lo] = 0.0;
+        }
+      }
+    }
+  }
+}
+
+// the sweep over the dense stack (MSCKF_HIP_LITERAL_ROUTE=1: the definition, tests and A/B runs)
+template <class S>
+__global__ __launch_bounds__(1024) void k_literal_dense(Dev<S> d, int b0, int nb) {
+  __shared__ double red[40];
+  extern __shared__ double lit_lds[];
+  lit::Ctx c; int bi, b;
+  if (!lit_ctx(d, b0, nb, red, lit_lds, c, bi, b)) return;
+  const lit::Args<S> a = lit_args(d, bi, b);
+  lit::tick(c, 0);
+  const int m = lit::prepare(c, a);
+  if (m <= 0) return;
+  lit::literal_general(c, a, m, a.obs0[a.F]);
   if (d.lam_part) {
-    const int n = 6 * a.N;
+    const int n1 = 6 * a.N + 1;
     for (int cpy = 1; cpy < 4; ++cpy) {
       double* Lc = d.Lam + cpy * d.lam_part + (long)b * d.ldR * d.ldR;
-      for (long e = threadIdx.x; e < (long)(n + 1) * (n + 1); e += blockDim.x) {
-        const int hi = (int)(e / (n + 1)), lo = (int)(e - (long)hi * (n + 1));
+      for (int e = threadIdx.x; e < n1 * n1; e += blockDim.x) {
+        const int hi = e / n1, lo = e - hi * n1;
         if (lo <= hi) Lc[(long)hi * d.ldR + lo] = 0.0;
       }
     }
   }
 }
 
+template <class K> static void lit_lds_attr(K k) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LIT_LDS_DOUBLES * sizeof(double))); }
 void literal_device_setup() {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_literal<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LIT_LDS_DOUBLES * sizeof(double)));
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_literal<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LIT_LDS_DOUBLES * sizeof(double)));
+  lit_lds_attr(k_lit_phase<float, 0>); lit_lds_attr(k_lit_phase<float, 1>); lit_lds_attr(k_lit_phase<float, 2>); lit_lds_attr(k_lit_phase<float, 3>);
+  lit_lds_attr(k_lit_phase<double, 0>); lit_lds_attr(k_lit_phase<double, 1>); lit_lds_attr(k_lit_phase<double, 2>); lit_lds_attr(k_lit_phase<double, 3>);
+  lit_lds_attr(k_literal_dense<float>); lit_lds_attr(k_literal_dense<double>);
 }
 
-// part: 0 all three launches; 1 k_lit_pre, 2 k_lit_gamma, 3 k_literal alone (the stage timers of a profiled run bracket each)
+// part: 0 all launches; 1 k_lit_pre, 2 k_lit_gamma, 3 the four phase kernels (k_lit_phase<., 0..3>) alone (the stage timers of a profiled run bracket each)
 template <class S>
 void launch_literal(const Dev<S>& d, int b0, int nb, hipStream_t st, int part) {
   if (nb <= 0 || !d.lit.W2) return;
@@ -432,8 +478,16 @@ void launch_literal(const Dev<S>& d, int b0, int nb, hipStream_t st, int part) {
     const int T = (d.n6cap + 31) / 32, ntile = T * (T + 1) / 2;
     hipLaunchKernelGGL(k_lit_gamma<S>, dim3(xcd_grid(nb, ntile)), dim3(64), 0, st, d, b0, nb, ntile);
   }
-  if (part == 0 || part == 3)
-    hipLaunchKernelGGL(k_literal<S>, dim3(nb), dim3(1024), LIT_LDS_DOUBLES * sizeof(double), st, d, b0, nb, dense ? 0 : 1);
+  if (part == 0 || part == 3) {
+    const size_t lds = LIT_LDS_DOUBLES * sizeof(double);
+    if (dense) hipLaunchKernelGGL(k_literal_dense<S>, dim3(nb), dim3(1024), lds, st, d, b0, nb);
+    else {
+      hipLaunchKernelGGL((k_lit_phase<S, 0>), dim3(nb), dim3(1024), lds, st, d, b0, nb);
+      hipLaunchKernelGGL((k_lit_phase<S, 1>), dim3(nb), dim3(1024), lds, st, d, b0, nb);
+      hipLaunchKernelGGL((k_lit_phase<S, 2>), dim3(nb), dim3(1024), lds, st, d, b0, nb);
+      hipLaunchKernelGGL((k_lit_phase<S, 3>), dim3(nb), dim3(1024), lds, st, d, b0, nb);
+    }
+  }
 }
 template void launch_literal<float>(const Dev<float>&, int, int, hipStream_t, int);
 template void launch_literal<double>(const Dev<double>&, int, int, hipStream_t, int);

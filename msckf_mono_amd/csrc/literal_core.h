@@ -1031,7 +1031,7 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
   const int n1 = n + 1;
   int PB = 16;
   const long lde = (e - 15 + 4) | 1;                 // the panel's columns [q][row]: rows contiguous (a thread's four rows are one 32-byte read, no bank conflicts)
-  auto need = [&](int pb) -> long { return lde * pb + 2L * pb * n1 + 2L * pb * pb + 8L * pb + 16; };
+  auto need = [&](int pb) -> long { return lde * pb + 2L * pb * n1 + 2L * pb * pb + 9L * pb + 16; };
   while (PB > 2 && need(PB) > c.lds_doubles) PB >>= 1;
   if (need(PB) > c.lds_doubles) return sweep_gram_steps(c, a, e, n, msteps, ec, E, Gh, Ld, Ac, dnv, refl, sv);
   double* sEC = c.lds;                               // [PB][lde]: E(p0 + r, k0 + q) at sEC[q * lde + r]; rows r < PB x the PB columns are the panel's core
@@ -1044,6 +1044,7 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
   double* sTau = sBi + PB;                           // [PB]
   double* sRf = sTau + PB;                           // [PB] 1.0 reflected / 0.0 skipped
   double* sCnt = sRf + PB;                           // [2] counts of the panel
+  double* sLd = sCnt + 2;                            // [PB] squared norms of the panel's columns (a global load per step sat on the core's chain)
   const double tol2 = a.tol * a.tol, t2 = tol2 < 1e-7 ? 1e-7 : tol2;
   SweepOut so = {0, 0};
   long long tprev = tick_now(c);       // phase timers over the panels: slots 12 stage, 13 core, 14 rows / columns, 15 results + trailing pass
@@ -1061,6 +1062,7 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
     par_for32(c, pb * pb, [&](int x) {
       const int q = x / pb, q2 = x - q * pb, hi = q > q2 ? q : q2, lo = q > q2 ? q2 : q;
       sG[q * PB + q2] = Gh[(k0 + hi) + (long)n1 * (k0 + lo)];
+      if (q2 == 0) sLd[q] = Ld[k0 + q];
     });
     barrier(c);
     tick_acc(c, 12, tprev);
@@ -1070,7 +1072,7 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
       for (int q = 0; q < pb; ++q) {
         const double c0 = sEC[(q) * lde + (q)], gq = sG[q * PB + q] > 0.0 ? sG[q * PB + q] : 0.0;
         double tail2 = gq - c0 * c0; tail2 = tail2 > 0.0 ? tail2 : 0.0;
-        double zero2 = t2 * Ld[k0 + q]; zero2 = zero2 > 2.2250738585072014e-308 ? zero2 : 2.2250738585072014e-308;
+        double zero2 = t2 * sLd[q]; zero2 = zero2 > 2.2250738585072014e-308 ? zero2 : 2.2250738585072014e-308;
         const bool reflect = tail2 > zero2;
         wave_sync(c);                                // every lane has read the step's inputs
         if (reflect) {
@@ -1248,41 +1250,83 @@ LIT_FN SweepOut sweep_explicit(const Ctx& c, const Args<HT>& a, int e, int n, in
   return so;
 }
 
+// Work space of the compact route, carved out of a.W2 (and the int scratch behind a.kept); every phase below starts with it:
+//   const int e = m < D ? m : D;                  // explicit rows
+//   double* E = a.W2;                             // [ec x n1] column-major: the explicit rows; ends as R (rows) and the reflectors' explicit parts (below the pivots)
+//   double* E0 = E + ec * n1;                     // [ec x n1] the explicit rows as they were
+//   double* At = E0 + ec * n1;                    // [ec][2 m_cap]: a_i = A_j e_(i - row0) for the explicit rows
+//   double* Gh = At + ec * mc2;                   // [n1 x n1] lower triangle, column-major: Gram matrix of the rows from the pivot row down
+//   double* Ac = Gh + (long)n1 * n1;              // [n1 x n1] Ac[j + n1 k] = s_j / (c0 - beta) of step k (column operations of the sweep), j > k
+//   double* G0s = Ac + (long)n1 * n1;             // [n1 x n1] lower triangle, column-major: Gh as it starts (the Gram matrix of the rows from row 15 down)
+//   double* Stg = G0s + (long)n1 * n1;            // [2][n1][16] stand-in for the LDS staging of the first 15 rows when the staging area is too small
+//   double* Ld = Stg + 33L * n1;                  // [n1] squared column norms
+//   double* See = Ld + n1;                        // [ec x ec] G_E^T G_E (blocks of the tracks that own explicit rows)
+//   double* Xe = See + ec * ec;                   // [ec x n] G_E^T H_u
+//   double* Ut = Xe + ec * (long)n;               // [15 x n] See15 E15 / 2 - Xe15
+//   double* G3 = Ut + 15L * n;                    // [ec][3]
+//   double* W3 = G3 + 3 * ec;                     // [ec] s_j of the step at hand (step-by-step form of the sweep)
+//   double* dnv = W3 + ec;                        // [n1]
+//   double* Yk = dnv + n1 + 63;                   // [n x n] extras: Y(:, j), then Yv = Y dn
+//   double* Gb0 = Yk + (long)n * n;               // [n x n] extras: Gram matrix of the rows below the explicit ones (leading block)
+//   double* Gv = Gb0 + (long)n * n;               // [n x n] extras: Gb0 Yv
+//   double* Th = Gv + (long)n * n;                // [ec x n] extras: t_h, then t~_h
+//   double* Ph = Th + ec * (long)n;               // [ec x n] extras: See t~_h + Xe y_h
+//   double* Yh = Ph + ec * (long)n;               // [n x n] extras: y_h
+//   double* Qh = Yh + (long)n * n;                // [n x n] extras: Xe^T t~_h + Gam y_h
+//   int* flag = a.kept + ks;                      // [e]
+//   int* topt = a.kept + 2 * ks;                  // [e] track of explicit row i
+//   int* refl = a.kept + 3 * ks;                  // [msteps]
+//   int* bidx = a.kept + 4 * ks;                  // [<= e] the basis: kept rows < 15, reflected steps, kept handed-through rows
+//   double* sE = 33L * n1 <= c.lds_doubles ? c.lds : Stg;   // (+ n1 / 2 doubles: the basis list of the last phase)
+#define LIT_COMPACT_LAYOUT \
+  const int n = 6 * a.N, F = a.F, n1 = n + 1, D = 15 + n; \
+  const int e = m < D ? m : D; \
+  const int msteps = e - 15 > 0 ? e - 15 : 0; \
+  const bool gram = m > e; \
+  const long ec = 15 + n, mc2 = 2L * a.m_cap; \
+  double* E = a.W2; \
+  double* E0 = E + ec * n1; \
+  double* At = E0 + ec * n1; \
+  double* Gh = At + ec * mc2; \
+  double* Ac = Gh + (long)n1 * n1; \
+  double* G0s = Ac + (long)n1 * n1; \
+  double* Stg = G0s + (long)n1 * n1; \
+  double* Ld = Stg + 33L * n1; \
+  double* See = Ld + n1; \
+  double* Xe = See + ec * ec; \
+  double* Ut = Xe + ec * (long)n; \
+  double* G3 = Ut + 15L * n; \
+  double* W3 = G3 + 3 * ec; \
+  double* dnv = W3 + ec; \
+  double* Yk = dnv + n1 + 63; \
+  double* Gb0 = Yk + (long)n * n; \
+  double* Gv = Gb0 + (long)n * n; \
+  double* Th = Gv + (long)n * n; \
+  double* Ph = Th + ec * (long)n; \
+  double* Yh = Ph + ec * (long)n; \
+  double* Qh = Yh + (long)n * n; \
+  const int ks = n + 16; \
+  int* flag = a.kept + ks; \
+  int* topt = a.kept + 2 * ks; \
+  int* refl = a.kept + 3 * ks; \
+  int* bidx = a.kept + 4 * ks; \
+  const double dlt = a.u_var - a.v_var; \
+  const int e15 = e < 15 ? e : 15; \
+  double* sE = 33L * n1 <= c.lds_doubles ? c.lds : Stg; \
+  double* sU = sE + 16L * n1; \
+  auto stage15 = [&]() { \
+    par_for32(c, 16 * n1, [&](int x) { \
+      const int j = x >> 4, l = x & 15; \
+      sE[x] = l < e15 ? E0[l + ec * j] : 0.0; \
+      sU[x] = (l < 15 && j < n) ? Ut[l + 15L * j] : 0.0; \
+    }); \
+    barrier(c); \
+  };
+
+// ---- phase A: explicit rows, their products, the Gram matrix the sweep starts from
 template <class HT>
-LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const int mobs) {
-  (void)mobs;
-  const int n = 6 * a.N, F = a.F, n1 = n + 1, D = 15 + n;
-  const int e = m < D ? m : D;                  // explicit rows
-  const int msteps = e - 15 > 0 ? e - 15 : 0;
-  const bool gram = m > e;
-  const long ec = 15 + n, mc2 = 2L * a.m_cap;
-  double* E = a.W2;                             // [ec x n1] column-major: the explicit rows; ends as R (rows) and the reflectors' explicit parts (below the pivots)
-  double* E0 = E + ec * n1;                     // [ec x n1] the explicit rows as they were
-  double* At = E0 + ec * n1;                    // [ec][2 m_cap]: a_i = A_j e_(i - row0) for the explicit rows
-  double* Gh = At + ec * mc2;                   // [n1 x n1] lower triangle, column-major: Gram matrix of the rows from the pivot row down
-  double* Ac = Gh + (long)n1 * n1;              // [n1 x n1] Ac[j + n1 k] = s_j / (c0 - beta) of step k (column operations of the sweep), j > k
-  double* G0s = Ac + (long)n1 * n1;             // [n1 x n1] lower triangle, column-major: Gh as it starts (the Gram matrix of the rows from row 15 down)
-  double* Stg = G0s + (long)n1 * n1;            // [2][n1][16] stand-in for the LDS staging of the first 15 rows when the staging area is too small
-  double* Ld = Stg + 33L * n1;                  // [n1] squared column norms
-  double* See = Ld + n1;                        // [ec x ec] G_E^T G_E (blocks of the tracks that own explicit rows)
-  double* Xe = See + ec * ec;                   // [ec x n] G_E^T H_u
-  double* Ut = Xe + ec * (long)n;               // [15 x n] See15 E15 / 2 - Xe15
-  double* G3 = Ut + 15L * n;                    // [ec][3]
-  double* W3 = G3 + 3 * ec;                     // [ec] s_j of the step at hand (step-by-step form of the sweep)
-  double* dnv = W3 + ec;                        // [n1]
-  double* Yk = dnv + n1 + 63;                   // [n x n] extras: Y(:, j), then Yv = Y dn
-  double* Gb0 = Yk + (long)n * n;               // [n x n] extras: Gram matrix of the rows below the explicit ones (leading block)
-  double* Gv = Gb0 + (long)n * n;               // [n x n] extras: Gb0 Yv
-  double* Th = Gv + (long)n * n;                // [ec x n] extras: t_h, then t~_h
-  double* Ph = Th + ec * (long)n;               // [ec x n] extras: See t~_h + Xe y_h
-  double* Yh = Ph + ec * (long)n;               // [n x n] extras: y_h
-  double* Qh = Yh + (long)n * n;                // [n x n] extras: Xe^T t~_h + Gam y_h
-  const int ks = n + 16;
-  int* flag = a.kept + ks;                      // [e]
-  int* topt = a.kept + 2 * ks;                  // [e] track of explicit row i
-  int* refl = a.kept + 3 * ks;                  // [msteps]
-  int* bidx = a.kept + 4 * ks;                  // [<= e] the basis: kept rows < 15, reflected steps, kept handed-through rows
-  const double dlt = a.u_var - a.v_var;
+LIT_FN void compact_rows(const Ctx& c, const Args<HT>& a, const int m) {
+  LIT_COMPACT_LAYOUT
   tick(c, 1);
   // ---- explicit rows: a_i = Q_f e_(3 + i - row0) and row i of [H_o | r_o] (msckf.h:957, :430)
   par_for(c, F, [&](long t) {
@@ -1325,7 +1369,6 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
     E[i + ec * n] = sr; E0[i + ec * n] = sr;
   });
   barrier(c);
-  const int e15 = e < 15 ? e : 15;
   explicit_row_products(c, a, e, n, ec, 0, e15, topt, At, See, Xe, G3);
   // Ut = See15 E15 / 2 - Xe15  (zero rows beyond e15)
   par_for32(c, 15 * n, [&](int x) {
@@ -1338,16 +1381,6 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
   tick(c, 2);
   // ---- Gh = [H_o | r_o]^T [H_o | r_o] minus the first 15 rows (lower triangle; the corner (n, n) is never a pivot), kept a
   // second time (G0s) for the basis products; the first 15 rows staged [column][16]
-  double* sE = 33L * n1 <= c.lds_doubles ? c.lds : Stg;   // (+ n1 / 2 doubles: the basis list of the last phase)
-  double* sU = sE + 16L * n1;
-  auto stage15 = [&]() {
-    par_for32(c, 16 * n1, [&](int x) {
-      const int j = x >> 4, l = x & 15;
-      sE[x] = l < e15 ? E0[l + ec * j] : 0.0;
-      sU[x] = (l < 15 && j < n) ? Ut[l + 15L * j] : 0.0;
-    });
-    barrier(c);
-  };
   stage15();
   par_map4(c, n1 * n1, [&](int x) -> double {
     const int lo = x / n1, hi = x - lo * n1;
@@ -1365,13 +1398,26 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
   });
   if (gram) par_for32(c, n, [&](int k) { Ld[k] = lam_in(a, k, k); });
   barrier(c);
+}
+
+// ---- phase B: the sweep (msckf.h:1343) for its decisions
+template <class HT>
+LIT_FN void compact_sweep(const Ctx& c, const Args<HT>& a, const int m) {
+  LIT_COMPACT_LAYOUT
   tick(c, 3);
   // ---- the sweep (msckf.h:1343): steps 0..14 meet the zero IMU columns; step 15 + k works on camera column k, pivot row 15 + k
   SweepOut so = {0, 0};
   if (msteps > 0) so = gram ? sweep_gram_blocked(c, a, e, n, msteps, ec, E, Gh, Ld, Ac, dnv, refl, W3)
                             : sweep_explicit(c, a, e, n, msteps, ec, E, Ac, dnv, refl);
+  if (first_thread(c)) { a.info[2] = so.n_reflect; a.info[3] = so.n_skip_tol; }
   barrier(c);
   tick(c, 4);
+}
+
+// ---- phase C: kept rows, the basis of range(Q_1), Z = [[Bs^T R_o Bs, .], [(Bs^T A)^T, .]]
+template <class HT>
+LIT_FN void compact_basis(const Ctx& c, const Args<HT>& a, const int m) {
+  LIT_COMPACT_LAYOUT
   // ---- rows of R that are kept (msckf.h:1345-1348): a row with an entry above tol * max|R| in its upper-triangular part
   double rmax = 0;
   if (a.tol > 0) rmax = wg_max(c, 0, (long)e * n, [&](long xl) { const int x = (int)xl, j = x / e, i = x - j * e; return (j + 15 >= i) ? fabs(E[i + ec * j]) : 0.0; });
@@ -1389,7 +1435,7 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
   const int nb = compact_list(c, msteps, bidx + na, [&](int k) { return refl[k] != 0 && flag[15 + k] != 0; });
   const int nh = compact_list(c, msteps, bidx + na + nb, [&](int k) { return refl[k] == 0 && flag[15 + k] != 0; });   // steps whose row was handed through and kept
   const int nr = na + nb + nh;
-  if (first_thread(c)) { a.info[1] = nr_kept; a.info[2] = so.n_reflect; a.info[3] = so.n_skip_tol; a.info[4] = 3; a.info[5] = e - msteps; a.info[6] = nh; }
+  if (first_thread(c)) { a.info[1] = nr_kept; a.info[4] = 3; a.info[5] = e - msteps; a.info[6] = nh; a.info[7] = nr; }
   barrier(c);
   tick(c, 5);
   // ---- the kept handed-through rows: q_h = H_first .. H_(k_h - 1) e_h as [t ; B0 y] (the reflectors of the steps before k_h,
@@ -1531,8 +1577,25 @@ LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const 
   }
   barrier(c);
   tick(c, 8);
-  information_from_rn(c, a, n, nr, true);
+}
+
+// ---- phase D: elimination of the basis' pivots leaves -Lam^
+template <class HT>
+LIT_FN void compact_eliminate(const Ctx& c, const Args<HT>& a) {
+  information_from_rn(c, a, 6 * a.N, a.info[7], true);
   tick(c, 9);
+}
+
+// The four phases in one call (the host build; the device runs them as four launches -- kernels_literal.hip -- so that each
+// gets registers of its own: as one kernel at 1 024 threads the panel loops reloaded spilled addresses from scratch memory)
+template <class HT>
+LIT_FN void literal_compact(const Ctx& c, const Args<HT>& a, const int m, const int mobs) {
+  (void)mobs;
+  compact_rows(c, a, m);
+  compact_sweep(c, a, m);
+  compact_basis(c, a, m);
+  barrier(c);
+  compact_eliminate(c, a);
 }
 
 // route: 0 (default) = the compact route; 1 = the sweep over the dense stack (needs its work space X, G: tests and A/B runs)

@@ -2,19 +2,23 @@
 bench.py)?  cfg3, 64 trajectories; windows of 20 frames each, median of a run of back-to-back windows as the yardstick, then
 one window after each kind of pause, on the streamed path (uploader + enqueue threads) and on the resident path with one
 stream (no host threads in the timed region at all: whatever is slow there is the device, not the threads)."""
+import json
+import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, "/root/repo")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # as bench.py: the slices' streams + the copy stream on hardware queues of their own
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+QUICK = "--quick" in sys.argv                        # tests/test_gpu_pause.py: the streamed path only, the state-read pause three times
 import bench
 from msckf_mono_amd import capi
 
 K = 20
 c = dict(bench.CONFIGS["cfg3"])
 B, N = c["B"], c["N"]
-NW = 40
+NW = 14 if QUICK else 40
 nfr = N + 5 + K * NW
 trajs = bench.make_trajectories(c, 0, nfr)
 bt = capi.Batch(B, N, c["F"], N, capi.F32)
@@ -54,7 +58,8 @@ def pause_sleep(ms):
     time.sleep(ms * 1e-3)
 
 
-for streams, streamed in ((4, True), (1, False), (4, False)):
+summary = {}
+for streams, streamed in (((4, True),) if QUICK else ((4, True), (1, False), (4, False))):
     bt.set_streams(streams)
     pins = bench.host_cpus_for_rank(0, streams + 1)
     if pins:
@@ -73,12 +78,17 @@ for streams, streamed in ((4, True), (1, False), (4, False)):
         base.append(window(f, streamed)); f += K
     med = float(np.median(base))
     res = {}
-    for name, fn in (("64 state reads", pause_reads), ("sleep 1 ms", lambda: pause_sleep(1)), ("sleep 5 ms", lambda: pause_sleep(5)), ("sleep 50 ms", lambda: pause_sleep(50))):
+    kinds = (("64 state reads", pause_reads), ("64 state reads (2)", pause_reads), ("64 state reads (3)", pause_reads)) if QUICK else \
+            (("64 state reads", pause_reads), ("sleep 1 ms", lambda: pause_sleep(1)), ("sleep 5 ms", lambda: pause_sleep(5)), ("sleep 50 ms", lambda: pause_sleep(50)))
+    for name, fn in kinds:
         fn()
         a = window(f, streamed); f += K
         b2 = window(f, streamed); f += K
         res[name] = (round(a / med, 3), round(b2 / med, 3))
     f_next = f
     print("streams", streams, "streamed", streamed, "median %.0f" % med, "first / second window after the pause (x median):", res, flush=True)
-print(smi())
+    summary["streams=%d,streamed=%d" % (streams, int(streamed))] = {"median": med, "after_pause": res}
+if not QUICK:
+    print(smi())
 bt.close()
+print(json.dumps(summary))

@@ -20,7 +20,7 @@ _ip = C.POINTER(C.c_int)
 @pytest.fixture(scope="module")
 def lit(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("lit") / "liblit_host.so")
-    out = subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unknown-pragmas", "-o", so, os.path.join(ROOT, "tests", "cpp", "literal_host.cpp")],
+    out = subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unknown-pragmas", "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-o", so, os.path.join(ROOT, "tests", "cpp", "literal_host.cpp")],
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     return C.CDLL(so)
