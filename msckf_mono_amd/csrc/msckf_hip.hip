@@ -79,6 +79,8 @@ struct HostTraj {
   std::vector<TrackToResid> to_resid;
   std::vector<PrunedState> pruned;
   std::vector<double> map;   // xyz triples of the last marginalize
+  int map_pending = 0;       // > 0: the last marginalize()'s triangulated points of this many tracks are still on the device
+                             // (read back when somebody asks -- getMap(), pruneRedundantStates(), a copy -- or dropped by the next marginalize())
   int wl_F = 0;              // tracks in the device work-list of this trajectory
 };
 
@@ -101,6 +103,7 @@ struct BatchBase {
   virtual int get_imu(int b, double* o) = 0;
   virtual int set_imu(int b, const double* in) = 0;
   virtual int get_cams(int b, double* o, int cap, int* n) = 0;
+  virtual int get_cams_known(int b, double* o, int n) = 0;   // n known to the caller: cameras + (into the host copy) the IMU state, one wait
   virtual int set_cam(int b, int slot, const double* in) = 0;
   virtual int get_cov(int b, double* P, int ldo) = 0;
   virtual int set_cov(int b, const double* P, int D) = 0;
@@ -134,6 +137,7 @@ struct BatchBase {
   virtual int lit_info(int b, int* out8) = 0;
 };
 
+int resolve_map(BatchBase* B, int b);   // (defined with the host-side bookkeeping below)
 constexpr int NSTAGE = 11;   // 0..7: msckf_hip_profile_read; 8 k_lit_pre, 9 k_lit_gamma, 10 k_literal (msckf_hip_profile_read_ex)
 
 // Persistent enqueue threads of a batch (one per slice of run_frames / run_frames_streamed): a K-frame window is a few
@@ -820,6 +824,21 @@ struct Batch : BatchBase {
     for (int i = 0; i < n; ++i) for (int k = 0; k < 7; ++k) o[7 * i + k] = (double)tmp[(size_t)i * CAM_STRIDE + k];
     return 0;
   }
+  // the single-filter API knows its window size on the host: no count read first, and the IMU state rides along into the host
+  // copy (nothing changes it between an update and the next propagate), so that the getImuState() that follows costs no wait
+  int get_cams_known(int b, double* o, int n) override {
+    POISON_GUARD();
+    if (chk(b) || n < 0 || n > n_cap) return fail(-EINVAL, "index out of range");
+    HIPCHK(hipSetDevice(device));
+    std::vector<S> tmp((size_t)std::max(n, 1) * CAM_STRIDE);
+    if (n) HIPCHK(hipMemcpyAsync(tmp.data(), d.cam + (size_t)b * n_cap * CAM_STRIDE, (size_t)n * CAM_STRIDE * sizeof(S), hipMemcpyDeviceToHost, st));
+    const bool want_imu = !h_imu_ok[b];
+    if (want_imu) HIPCHK(hipMemcpyAsync(h_imu.data() + (size_t)b * IMU_STRIDE, d.imu + (size_t)b * IMU_STRIDE, IMU_STRIDE * sizeof(S), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (want_imu) h_imu_ok[b] = 1;
+    for (int i = 0; i < n; ++i) for (int k = 0; k < 7; ++k) o[7 * i + k] = (double)tmp[(size_t)i * CAM_STRIDE + k];
+    return 0;
+  }
   int set_cam(int b, int slot, const double* in) override {
     if (chk(b) || slot < 0 || slot >= n_cap) return fail(-EINVAL, "index out of range");
     HIPCHK(hipSetDevice(device));
@@ -892,6 +911,7 @@ struct Batch : BatchBase {
     if (!o || o->B != B || o->n_cap != n_cap || o->f_cap != f_cap || o->m_cap != m_cap || o->h16 != h16)
       return fail(-EINVAL, "copy_state: handles differ in shape or dtype");
     if (o->poisoned) return fail(-EIO, "copy_state: the source handle is unusable after a failed run_frames call (its filter states are undefined)");
+    for (int b = 0; b < o->B; ++b) { const int rcm = resolve_map(o, b); if (rcm) return rcm; }   // (work buffers are not copied: points still on the device first)
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamSynchronize(o->st));
     const size_t Bz = B, pl = (size_t)d.ld * d.ld;
@@ -1523,9 +1543,10 @@ int host_add_features(BatchBase* B, int b, const double* meas, const uint64_t* i
   return 0;
 }
 
+int resolve_map(BatchBase* B, int b);
 int host_marginalize(BatchBase* B, int b) {
   HostTraj& t = B->traj[b];
-  t.map.clear();
+  t.map.clear(); t.map_pending = 0;
   if (t.to_resid.empty()) { int z = 0; int rc = B->set_tracks(b, 0, &z, &z, nullptr); return rc ? rc : B->clear_stats(b); }
   const int F = (int)t.to_resid.size();
   std::vector<int> M(F), slots; std::vector<double> obs;
@@ -1538,8 +1559,18 @@ int host_marginalize(BatchBase* B, int b) {
   if (rc) return rc;
   rc = B->marginalize(b, 1);
   if (rc) return rc;
+  t.map_pending = F;      // map_ (msckf.h:371) is read back when it is asked for: no wait for the device inside marginalize()
+  return 0;
+}
+
+// the triangulated points of the last marginalize() (msckf.h:371: map_.push_back(p_f_G)), fetched on demand
+int resolve_map(BatchBase* B, int b) {
+  HostTraj& t = B->traj[b];
+  const int F = t.map_pending;
+  if (F <= 0) return 0;
+  t.map_pending = 0;
   std::vector<double> info((size_t)F * 8);
-  rc = B->track_info(b, info.data(), F);
+  const int rc = B->track_info(b, info.data(), F);
   if (rc < 0) return rc;
   for (int i = 0; i < F; ++i)
     if (info[8 * i] != 0 && info[8 * i + 1] != 0) { t.map.push_back(info[8 * i + 5]); t.map.push_back(info[8 * i + 6]); t.map.push_back(info[8 * i + 7]); }
@@ -1558,8 +1589,7 @@ int host_prune_empty(BatchBase* B, int b) {
   std::vector<int> keep;
   // pruned_states_ keeps the whole camState (msckf.h:714; read by asl_msckf.cpp:409-424): poses come back once, here
   std::vector<double> poses((size_t)num * 7);
-  int ngot = 0;
-  int rc = B->get_cams(b, poses.data(), num, &ngot);
+  int rc = B->get_cams_known(b, poses.data(), num);
   if (rc) return rc;
   for (int i = 0; i <= last_to_remove; ++i) {
     PrunedState ps{t.cams[i].state_id, t.cams[i].time, t.cams[i].last_correlated_id, {0}};
@@ -1621,8 +1651,9 @@ int host_prune_redundant(BatchBase* B, int b) {
   if (t.cams.size() < 20) return 0;                                           // :455
   const int n = (int)t.cams.size();
   std::vector<double> poses((size_t)n * 7);
-  int ngot = 0;
-  int rc = B->get_cams(b, poses.data(), n, &ngot);
+  int rc = resolve_map(B, b);          // this call appends to map_ (:528) and reuses the device work-list
+  if (rc) return rc;
+  rc = B->get_cams_known(b, poses.data(), n);
   if (rc) return rc;
   std::vector<int> rm;
   find_redundant(t, poses, rm);
@@ -1699,7 +1730,7 @@ int host_prune_redundant(BatchBase* B, int b) {
   std::vector<int> keep;
   std::vector<CamMeta> kept;
   if (!rm.empty()) {                                  // poses as corrected by the second update (msckf.h:614 precedes :631)
-    rc = B->get_cams(b, poses.data(), n, &ngot);
+    rc = B->get_cams_known(b, poses.data(), n);
     if (rc) return rc;
   }
   for (int i = 0; i < n; ++i) {
@@ -1840,6 +1871,7 @@ int msckf_hip_get_cam_states(msckf_hip_handle h, int b, double* cam7, int* state
 }
 int msckf_hip_get_map(msckf_hip_handle h, int b, double* xyz, int cap) {
   if (b < 0 || b >= H(h)->B) return fail(-EINVAL, "trajectory index out of range");
+  { const int rc = resolve_map(H(h), b); if (rc) return rc; }
   const auto& m = H(h)->traj[b].map;
   const int n = (int)m.size() / 3;
   if (n > cap) return fail(-E2BIG, "output buffer too small");
