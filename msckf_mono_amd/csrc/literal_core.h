@@ -36,6 +36,7 @@
 #define MSCKF_LITERAL_CORE_H
 
 #include <math.h>
+#include <type_traits>
 
 namespace msckf {
 namespace lit {
@@ -398,6 +399,117 @@ LIT_FN void lds_axpy16(double* __restrict__ dst, long ds, const double* __restri
   for (; q2 < hi; ++q2) dst[q2 * ds] -= coef * src[q2 * ss];
 }
 
+// ---- the panels' per-row / per-column recurrences.  A row below a panel (a column right of it) takes its PB entries through
+// the panel's pivots one after the other: entry q2 changes at every pivot q < q2, so one thread per row walks a chain of
+// PB x (LDS read, FMA, LDS write) round trips (16 us per panel at PB = 16).  On the device a row of 16 lanes takes an item
+// instead, lane = entry: the pivot's value reaches the other lanes by a DPP row_share (no memory, a few cycles), what the
+// step multiplies it with sits in registers -- sixteen dependent FMAs per item.  (PB <= 16; the host build keeps the plain loops.)
+#ifdef LIT_HOST
+// sweep, rows below the panel: E(p0 + r, k0 + q) at sEC[q * lde + r] -> reflector entries v_q(r)
+LIT_FN void panel_rows_sweep(const Ctx&, double* sEC, long lde, const double* sS, int PB, const double* sDn, int pb, int r_lo, int r_hi) {
+  for (int r = r_lo; r < r_hi; ++r) {
+    double* row = sEC + r;
+    for (int q = 0; q < pb; ++q) {
+      const double vq = row[q * lde] * sDn[q];          // 0 for a step that did not reflect
+      for (int q2 = q + 1; q2 < pb; ++q2) row[q2 * lde] -= vq * sS[q * PB + q2];
+      row[q * lde] = vq;
+    }
+  }
+}
+// sweep, columns right of the panel: (E(p0 + q, j), Gh(k0 + q, j)) at (sEP, sGP)[q * n1 + jj] -> (s_q(j), R(p0 + q, j))
+LIT_FN void panel_cols_sweep(const Ctx&, double* sEP, double* sGP, long n1, const double* sEC, long lde, const double* sRf, const double* sBi, int pb, int ntr) {
+  for (int jj = 0; jj < ntr; ++jj) {
+    double* yc = sEP + jj; double* gc = sGP + jj;
+    for (int q = 0; q < pb; ++q) {
+      const bool rf = sRf[q] != 0.0;
+      const double yq = yc[q * n1];
+      const double r = rf ? gc[q * n1] * sBi[q] : yq;
+      const double sj = rf ? yq - r : 0.0;
+      for (int q2 = q + 1; q2 < pb; ++q2) { gc[q2 * n1] -= sEC[q2 * lde + q] * r; yc[q2 * n1] -= sEC[q * lde + q2] * sj; }
+      gc[q * n1] = r; yc[q * n1] = sj;
+    }
+  }
+}
+// elimination, rows below the panel's diagonal block: Z(k0 + r, k0 + q) at sP[q * ldr + r], left unscaled
+LIT_FN void panel_rows_elim(const Ctx&, double* sP, long ldr, const double* sD, int pb, int r_lo, int r_hi) {
+  for (int r = r_lo; r < r_hi; ++r) {
+    double* row = sP + r;
+    for (int q = 0; q + 1 < pb; ++q) {
+      const double yq = row[q * ldr] * sD[q];
+      for (int q2 = q + 1; q2 < pb; ++q2) row[q2 * ldr] -= yq * sP[q * ldr + q2];
+    }
+  }
+}
+#else
+template <int Q> LIT_FN double row_share(double v) { return dpp_x<0x150 + Q>(v); }     // the value of lane Q of this row of 16 lanes
+LIT_FN void panel_rows_sweep(const Ctx& c, double* sEC, long lde, const double* sS, int PB, const double* sDn, int pb, int r_lo, int r_hi) {
+  const int g = c.lane & 15;
+  const bool on = g < pb;
+  double sg[16];                                         // column g of S: s_q(k0 + g), q < g
+#pragma unroll
+  for (int q = 0; q < 16; ++q) sg[q] = (on && q < g) ? sS[q * PB + g] : 0.0;
+  const double dng = on ? sDn[g] : 0.0;
+  for (int r = r_lo + 4 * c.wave + (c.lane >> 4); r < r_hi; r += 4 * c.nw) {
+    double y = on ? sEC[g * lde + r] : 0.0;
+    auto step = [&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      const double vq = row_share<q>(y * dng);
+      y = g == q ? vq : y - vq * sg[q];                  // (sg[q] = 0 for the lanes at or left of the pivot)
+    };
+    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{}); step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+    step(std::integral_constant<int, 8>{}); step(std::integral_constant<int, 9>{}); step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
+    step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{}); step(std::integral_constant<int, 14>{}); step(std::integral_constant<int, 15>{});
+    if (on) sEC[g * lde + r] = y;
+  }
+}
+LIT_FN void panel_cols_sweep(const Ctx& c, double* sEP, double* sGP, long n1, const double* sEC, long lde, const double* sRf, const double* sBi, int pb, int ntr) {
+  const int g = c.lane & 15;
+  const bool on = g < pb;
+  double rg[16], vg[16];                                 // R(p0 + q, k0 + g) and v_q(p0 + g), q < g
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { const bool use = on && q < g; rg[q] = use ? sEC[g * lde + q] : 0.0; vg[q] = use ? sEC[q * lde + g] : 0.0; }
+  const bool rfg = on && sRf[on ? g : 0] != 0.0;
+  const double big = rfg ? sBi[g] : 0.0;
+  for (int jj = 4 * c.wave + (c.lane >> 4); jj < ntr; jj += 4 * c.nw) {
+    double gq = on ? sGP[g * n1 + jj] : 0.0, yq = on ? sEP[g * n1 + jj] : 0.0;
+    auto step = [&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      const double rl = rfg ? gq * big : yq, sl = rfg ? yq - rl : 0.0;     // what this lane would publish as the pivot
+      const double r = row_share<q>(rl), sj = row_share<q>(sl);
+      gq = g == q ? rl : gq - rg[q] * r;
+      yq = g == q ? sl : yq - vg[q] * sj;
+    };
+    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{}); step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+    step(std::integral_constant<int, 8>{}); step(std::integral_constant<int, 9>{}); step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
+    step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{}); step(std::integral_constant<int, 14>{}); step(std::integral_constant<int, 15>{});
+    if (on) { sGP[g * n1 + jj] = gq; sEP[g * n1 + jj] = yq; }
+  }
+}
+LIT_FN void panel_rows_elim(const Ctx& c, double* sP, long ldr, const double* sD, int pb, int r_lo, int r_hi) {
+  const int g = c.lane & 15;
+  const bool on = g < pb;
+  double lg[16];                                         // L(k0 + g, k0 + q), q < g (unscaled)
+#pragma unroll
+  for (int q = 0; q < 16; ++q) lg[q] = (on && q < g) ? sP[q * ldr + g] : 0.0;
+  const double dg = on ? sD[g] : 0.0;
+  for (int r = r_lo + 4 * c.wave + (c.lane >> 4); r < r_hi; r += 4 * c.nw) {
+    double y = on ? sP[g * ldr + r] : 0.0;
+    auto step = [&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      const double yq = row_share<q>(y * dg);
+      y -= yq * lg[q];                                   // (lg[q] = 0 for the lanes at or left of the pivot: they keep their value)
+    };
+    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{}); step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+    step(std::integral_constant<int, 8>{}); step(std::integral_constant<int, 9>{}); step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
+    step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{}); step(std::integral_constant<int, 14>{});
+    if (on) sP[g * ldr + r] = y;
+  }
+}
+#endif
+
 // One trajectory's inputs (what k_feature / k_select left behind) and work space.  HT: scalar type of the Jacobian blocks.
 template <class HT>
 struct Args {
@@ -561,12 +673,8 @@ LIT_FN void information_from_rn(const Ctx& c, const Args<HT>& a, int n, int nr, 
         }
       }
       barrier(c);
-      // rows below the block: entry q2 of the row after the pivots q < q2 of the panel, in place in LDS (a thread's row is a
-      // column of banks of its own; sixteen values in registers per thread spilled at 1 024 threads per workgroup)
-      par_for32(c, mrow - pb, [&](int x) {
-        double* row = sP + pb + x;
-        for (int q = 0; q + 1 < pb; ++q) lds_axpy16(row, ldr, sP + q * ldr, 1, q + 1, pb, row[q * ldr] * sD[q]);
-      });
+      // rows below the block: entry q2 of the row after the pivots q < q2 of the panel
+      panel_rows_elim(c, sP, ldr, sD, pb, pb, mrow);
       barrier(c);
       // trailing triangle: columns j >= k0 + pb, rows i >= j: Z(i, j) -= sum_q L(i, q) L(j, q) / d_q; tiles numbered down the
       // tile columns (consecutive threads: consecutive rows of the column-major Z)
@@ -1110,29 +1218,8 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
     tick_acc(c, 13, tprev);
     so.n_reflect += (int)sCnt[0]; so.n_skip_tol += (int)sCnt[1];
     // ---- one thread per row below the panel (its reflector entries) and per column to the right (its entries of R and s)
-    // (in place in LDS: consecutive threads are consecutive words of every array; register arrays of sixteen spilled)
-    par_for32(c, (nrow - pb) + ntr, [&](int x) {
-      if (x < nrow - pb) {
-        double* row = sEC + pb + x;                        // row[q * lde] = E(p0 + pb + x, k0 + q)
-        for (int q = 0; q < pb; ++q) {
-          const double vq = row[q * lde] * sDn[q];          // 0 for a step that did not reflect
-          lds_axpy16(row, lde, sS + q * PB, 1, q + 1, pb, vq);
-          row[q * lde] = vq;
-        }
-      } else {
-        const int jj = x - (nrow - pb);
-        double* yc = sEP + jj; double* gc = sGP + jj;      // yc[q * n1] = E(p0 + q, j), gc[q * n1] = Gh(k0 + q, j)
-        for (int q = 0; q < pb; ++q) {
-          const bool rf = sRf[q] != 0.0;
-          const double yq = yc[(long)q * n1];
-          const double r = rf ? gc[(long)q * n1] * sBi[q] : yq;
-          const double sj = rf ? yq - r : 0.0;
-          lds_axpy16(gc, n1, sEC + q, lde, q + 1, pb, r);               // Gh(k0 + q2, j) -= R(p0 + q, k0 + q2) R(p0 + q, j)
-          lds_axpy16(yc, n1, sEC + q * lde, 1, q + 1, pb, sj);          // E(p0 + q2, j) -= v_q(p0 + q2) s_q(j)
-          gc[(long)q * n1] = r; yc[(long)q * n1] = sj;
-        }
-      }
-    });
+    panel_rows_sweep(c, sEC, lde, sS, PB, sDn, pb, pb, nrow);
+    panel_cols_sweep(c, sEP, sGP, n1, sEC, lde, sRf, sBi, pb, ntr);
     barrier(c);
     tick_acc(c, 14, tprev);
     // ---- results of the panel, and ONE pass over the trailing parts: E(i, j) -= sum_q v_q(i) s_q(j),  Gh(j, l) -= sum_q R_q(j) R_q(l)
