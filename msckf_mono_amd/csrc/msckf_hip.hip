@@ -290,6 +290,8 @@ struct Batch : BatchBase {
     *p = (T*)q;
     return 0;
   }
+  // (flush_pending: the IMU samples of propagate() calls that have not reached the device yet, see propagate())
+#define DEVICE_ENTER() do { HIPCHK(hipSetDevice(device)); if (pend_b >= 0) { const int rc_p_ = flush_pending(); if (rc_p_) return rc_p_; } } while (0)
   int create() {
     HIPCHK(hipSetDevice(device));
     feature_device_setup(); qr_device_setup(); kalman_device_setup(); gram_device_setup(); literal_device_setup();   // per device: constant tables, dynamic-LDS limits
@@ -491,7 +493,7 @@ struct Batch : BatchBase {
   }
   int set_aniso(int mode, double tol) override {
     if (mode < 0 || mode > 1) return fail(-EINVAL, "mode: 0 the reference's R_n = Q_1^T R_o Q_1 on the device, 1 pre-whitened rows");
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     aniso_mode = mode; lit_tol = tol;
     d.lit.tol = tol >= 0 ? tol : (sizeof(S) == 4 ? 8e-4 : 1e-10);
     d.lit.route = lit_route;
@@ -508,7 +510,7 @@ struct Batch : BatchBase {
   int lit_info(int b, int* out8) override {
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
     if (!d.lit.info) { for (int i = 0; i < 8; ++i) out8[i] = 0; return 0; }
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     HIPCHK(hipMemcpyAsync(out8, d.lit.info + (size_t)b * 8, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (d.lit.tim) {     // MSCKF_HIP_LITERAL_TIMERS=1 (profiling runs): phase durations of the last launch in microseconds on stderr
@@ -527,7 +529,7 @@ struct Batch : BatchBase {
     POISON_GUARD();
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
     if (!(noise[0] > 0) || !(noise[1] > 0)) return fail(-EINVAL, "u_var_prime / v_var_prime must be positive");
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     S prm[PRM_STRIDE] = {0}, st_imu[IMU_STRIDE] = {0};
     for (int i = 0; i < 12; ++i) prm[i] = (S)cam[i];
     prm[PRM_UVAR] = (S)noise[0]; prm[PRM_VVAR] = (S)noise[1];
@@ -598,13 +600,33 @@ struct Batch : BatchBase {
     for (int i = 0; i < 3; ++i) { x[IVN + i] = x[IV + i]; x[IPN + i] = x[IP + i]; }
   }
   void invalidate_imu(int b0, int nb) { for (int b = b0; b < b0 + nb && b < B; ++b) h_imu_ok[b] = 0; }
+  // Single-filter API (the shim's propagate(), one call per IMU sample, msckf.h:101): while the host copy of the IMU state is
+  // valid it answers getImuState(), so the samples need not reach the device one by one -- they wait here and go as ONE copy +
+  // ONE k_propagate launch when anything else touches the device (DEVICE_ENTER at the head of every other entry).  Ten calls per
+  // image were ten pinned-memory copies and ten launches (~6 us of host time each) for the same device-side result.
+  std::vector<double> pend_rd; int pend_b = -1;
+  int flush_pending() {
+    if (pend_b < 0) return 0;
+    const int b = pend_b; pend_b = -1;
+    std::vector<double> rd; rd.swap(pend_rd);
+    HIPCHK(hipSetDevice(device));
+    return propagate_device(b, 1, rd.data(), (int)(rd.size() / RD_STRIDE));
+  }
   int propagate(int b0, int nb, const double* rd, int K, bool mirror) override {
     POISON_GUARD();
     if (chk_range(b0, nb)) return fail(-EINVAL, "trajectory range out of bounds");
     if (K < 0) return fail(-EINVAL, "negative sample count");
-    if (mirror && nb == 1) { if (h_imu_ok[b0]) for (int k = 0; k < K; ++k) host_rk(h_imu.data() + (size_t)b0 * IMU_STRIDE, rd + (size_t)k * RD_STRIDE); }
-    else invalidate_imu(b0, nb);
-    HIPCHK(hipSetDevice(device));
+    if (mirror && nb == 1 && h_imu_ok[b0]) {
+      for (int k = 0; k < K; ++k) host_rk(h_imu.data() + (size_t)b0 * IMU_STRIDE, rd + (size_t)k * RD_STRIDE);
+      if (pend_b >= 0 && pend_b != b0) { const int rc = flush_pending(); if (rc) return rc; }
+      pend_b = b0; pend_rd.insert(pend_rd.end(), rd, rd + (size_t)K * RD_STRIDE);
+      return 0;
+    }
+    if (!(mirror && nb == 1)) invalidate_imu(b0, nb);
+    DEVICE_ENTER();
+    return propagate_device(b0, nb, rd, K);
+  }
+  int propagate_device(int b0, int nb, const double* rd, int K) {
     for (int k0 = 0; k0 < K; k0 += rd_cap) {
       const int kk = std::min(rd_cap, K - k0);
       const size_t cnt = (size_t)nb * kk * RD_STRIDE;
@@ -626,7 +648,7 @@ struct Batch : BatchBase {
   int augment(int b0, int nb) override {
     POISON_GUARD();
     if (chk_range(b0, nb)) return fail(-EINVAL, "trajectory range out of bounds");
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     launch_augment<S>(d, b0, nb, st);
     for (int b = b0; b < b0 + nb; ++b) if (h_ncam[b] < n_cap) h_ncam[b]++;
     HIPCHK(hipGetLastError());
@@ -635,7 +657,7 @@ struct Batch : BatchBase {
   int set_tracks(int b, int F, const int* M, const int* slots, const double* obs) override {
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
     if (F < 0 || F > f_cap) return fail(-E2BIG, "more tracks than f_cap");
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     for (int t = 0; t < F; ++t) if (M[t] > m_cap || M[t] < 0) return fail(-E2BIG, "track longer than m_cap");
     { size_t o = 0; for (int t = 0; t < F; ++t) { if (repeated_slot(slots + o, M[t])) return fail(-EINVAL, "camera slot repeated within a track"); o += M[t]; } }
     // only the F rows in use travel: [F] lengths, [F][m_cap] slots, [F][m_cap][2] coordinates, one pinned block
@@ -673,13 +695,13 @@ struct Batch : BatchBase {
   // last_stats of a marginalize() that had nothing to residualize (the reference returns early, msckf.h:337)
   int clear_stats(int b) override {
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     HIPCHK(hipMemsetAsync(d.stats + (size_t)b * STAT_STRIDE, 0, sizeof(int) * STAT_ERR, st));
     return 0;
   }
   int clear_errors(int b) override {
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     HIPCHK(hipMemsetAsync(d.stats + (size_t)b * STAT_STRIDE + STAT_ERR, 0, sizeof(int), st));
     return 0;
   }
@@ -725,7 +747,7 @@ struct Batch : BatchBase {
   int marginalize(int b0, int nb) override {
     POISON_GUARD();
     if (chk_range(b0, nb)) return fail(-EINVAL, "trajectory range out of bounds");
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     use_single_worklists();
     launch_update(view(b0), b0, nb, st);
     HIPCHK(hipGetLastError());
@@ -733,7 +755,7 @@ struct Batch : BatchBase {
   }
   int set_given_positions(int b, int F, const double* pf3) override {
     if (chk(b) || F > f_cap) return fail(-EINVAL, "bad arguments");
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     std::vector<S> tmp((size_t)std::max(F, 1) * 4, S(0));
     for (int t = 0; t < F; ++t) for (int k = 0; k < 3; ++k) tmp[4 * t + k] = (S)pf3[3 * t + k];
     HIPCHK(hipMemcpyAsync(d_pfin + (size_t)b * f_cap * 4, tmp.data(), tmp.size() * sizeof(S), hipMemcpyHostToDevice, st));
@@ -742,7 +764,7 @@ struct Batch : BatchBase {
   }
   int feature_only(int b, int* status, double* pf3, int cap) override {
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     use_single_worklists();
     const int F = traj[b].wl_F;
     if (F > cap) return fail(-E2BIG, "output buffer too small");
@@ -759,7 +781,7 @@ struct Batch : BatchBase {
   int marginalize_given(int b) override {
     POISON_GUARD();
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     use_single_worklists();
     Dev<S> v = view(b);
     v.mode = 1;
@@ -769,7 +791,7 @@ struct Batch : BatchBase {
   }
   int prune_keep(int b, const std::vector<int>& keep) override {
     POISON_GUARD();
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     const int nk = (int)keep.size();
     if (nk) HIPCHK(hipMemcpyAsync(d.keep + (size_t)b * n_cap, keep.data(), nk * sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d.nkeep + b, &nk, sizeof(int), hipMemcpyHostToDevice, st));
@@ -783,7 +805,7 @@ struct Batch : BatchBase {
   int get_ncam(int b, int* n) override {
     POISON_GUARD();
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     HIPCHK(hipMemcpyAsync(n, d.ncam + b, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return 0;
@@ -793,7 +815,7 @@ struct Batch : BatchBase {
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
     S* tmp = h_imu.data() + (size_t)b * IMU_STRIDE;
     if (!h_imu_ok[b]) {
-      HIPCHK(hipSetDevice(device));
+      DEVICE_ENTER();
       HIPCHK(hipMemcpyAsync(tmp, d.imu + (size_t)b * IMU_STRIDE, IMU_STRIDE * sizeof(S), hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
       h_imu_ok[b] = 1;
@@ -803,7 +825,7 @@ struct Batch : BatchBase {
   }
   int set_imu(int b, const double* in) override {
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     S tmp[IMU_STRIDE] = {0};
     for (int i = 0; i < 29; ++i) tmp[i] = (S)in[i];
     HIPCHK(hipMemcpyAsync(d.imu + (size_t)b * IMU_STRIDE, tmp, sizeof(tmp), hipMemcpyHostToDevice, st));
@@ -829,7 +851,7 @@ struct Batch : BatchBase {
   int get_cams_known(int b, double* o, int n) override {
     POISON_GUARD();
     if (chk(b) || n < 0 || n > n_cap) return fail(-EINVAL, "index out of range");
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     std::vector<S> tmp((size_t)std::max(n, 1) * CAM_STRIDE);
     if (n) HIPCHK(hipMemcpyAsync(tmp.data(), d.cam + (size_t)b * n_cap * CAM_STRIDE, (size_t)n * CAM_STRIDE * sizeof(S), hipMemcpyDeviceToHost, st));
     const bool want_imu = !h_imu_ok[b];
@@ -841,7 +863,7 @@ struct Batch : BatchBase {
   }
   int set_cam(int b, int slot, const double* in) override {
     if (chk(b) || slot < 0 || slot >= n_cap) return fail(-EINVAL, "index out of range");
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     S tmp[CAM_STRIDE] = {0};
     for (int k = 0; k < 7; ++k) tmp[k] = (S)in[k];
     HIPCHK(hipMemcpyAsync(d.cam + ((size_t)b * n_cap + slot) * CAM_STRIDE, tmp, sizeof(tmp), hipMemcpyHostToDevice, st));
@@ -864,7 +886,7 @@ struct Batch : BatchBase {
   int set_cov(int b, const double* P, int D) override {
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
     if (D < 15 || (D - 15) % 6 || (D - 15) / 6 > n_cap) return fail(-EINVAL, "bad covariance dimension");
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     std::vector<S> tmp((size_t)d.ld * d.ld, S(0));
     for (int j = 0; j < D; ++j) for (int i = 0; i < D; ++i) tmp[(size_t)j * d.ld + i] = (S)P[(size_t)j * D + i];
     const int n = (D - 15) / 6;
@@ -876,14 +898,14 @@ struct Batch : BatchBase {
   }
   int get_nres(int b, long long* n) override {
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     HIPCHK(hipMemcpyAsync(n, d.n_resid + b, sizeof(long long), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return 0;
   }
   int set_nres(int b, long long n) override {
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     HIPCHK(hipMemcpyAsync(d.n_resid + b, &n, sizeof(long long), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
     return 0;
@@ -891,7 +913,7 @@ struct Batch : BatchBase {
   int stats(int b, int* out) override {
     POISON_GUARD();
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     int tmp[STAT_STRIDE];
     HIPCHK(hipMemcpyAsync(tmp, d.stats + (size_t)b * STAT_STRIDE, sizeof(tmp), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -911,8 +933,9 @@ struct Batch : BatchBase {
     if (!o || o->B != B || o->n_cap != n_cap || o->f_cap != f_cap || o->m_cap != m_cap || o->h16 != h16)
       return fail(-EINVAL, "copy_state: handles differ in shape or dtype");
     if (o->poisoned) return fail(-EIO, "copy_state: the source handle is unusable after a failed run_frames call (its filter states are undefined)");
+    { const int rcf = o->flush_pending(); if (rcf) return rcf; }
     for (int b = 0; b < o->B; ++b) { const int rcm = resolve_map(o, b); if (rcm) return rcm; }   // (work buffers are not copied: points still on the device first)
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     HIPCHK(hipStreamSynchronize(o->st));
     const size_t Bz = B, pl = (size_t)d.ld * d.ld;
     auto cp = [&](void* dst, const void* sp, size_t bytes) { return hipMemcpyAsync(dst, sp, bytes, hipMemcpyDeviceToDevice, st); };
@@ -929,14 +952,14 @@ struct Batch : BatchBase {
   }
   int error_flags(int b, int* flags) override {
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     HIPCHK(hipMemcpyAsync(flags, d.stats + (size_t)b * STAT_STRIDE + STAT_ERR, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return 0;
   }
   int track_info(int b, double* out, int cap) override {
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     int tmp[STAT_STRIDE];
     HIPCHK(hipMemcpyAsync(tmp, d.stats + (size_t)b * STAT_STRIDE, sizeof(tmp), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -987,7 +1010,7 @@ struct Batch : BatchBase {
   }
   int scen_alloc(int n_frames, int K) override {
     if (n_frames <= 0 || K <= 0) return fail(-EINVAL, "bad scenario size");
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     HIPCHK(hipStreamSynchronize(st));
     free_scenario_device();
     sc_frames = 0; committed = false;
@@ -1039,7 +1062,7 @@ struct Batch : BatchBase {
   // H2D of everything staged.  The host copy is kept, so cells may be patched with scenario_set and committed again.
   int scen_commit() override {
     if (sc_frames <= 0) return fail(-EINVAL, "no scenario allocated");
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     HIPCHK(hipStreamSynchronize(st));
     const size_t Bz = B;
     size_t total = 0;
@@ -1102,7 +1125,7 @@ struct Batch : BatchBase {
   int scen_pin(int f0, int f1) override {
     if (f0 < 0 || f1 > sc_frames || f0 > f1) return fail(-EINVAL, "frame range out of bounds");
     if (!committed) return fail(-EINVAL, "scenario not committed");
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
     const size_t Bz = B;
     size_t need = 0, maxb = sg_bytes;
@@ -1184,7 +1207,7 @@ struct Batch : BatchBase {
     return 0;
   }
   int sync() override {
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     HIPCHK(hipStreamSynchronize(st));
     return 0;
   }
@@ -1219,7 +1242,7 @@ struct Batch : BatchBase {
   // what an event pair with NOTHING between its records measures on this stream (the marker packets themselves): the stage
   // timers of prof_read hold one such pair per launch, so a single-kernel stage reads kernel time + this
   int prof_event_overhead(double* ms) override {
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     hipEvent_t a, b2;
     HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b2));
     HIPCHK(hipStreamSynchronize(st));
@@ -1235,7 +1258,7 @@ struct Batch : BatchBase {
     return 0;
   }
   int prof_read(double* ms, int* cnt, int cap) override {
-    HIPCHK(hipSetDevice(device));
+    DEVICE_ENTER();
     HIPCHK(hipStreamSynchronize(st));
     for (int s = 0; s < NSTAGE; ++s) {
       for (size_t i = 0; i < ev_used[s]; ++i) {
@@ -1254,7 +1277,7 @@ template <class S>
 int Batch<S>::drop_oldest(int b0, int nb, int n) {
   POISON_GUARD();
   if (chk_range(b0, nb)) return fail(-EINVAL, "trajectory range out of bounds");
-  HIPCHK(hipSetDevice(device));
+  DEVICE_ENTER();
   launch_prune<S>(d, b0, nb, st, nullptr, std::max(n, 0));
   for (int b = b0; b < b0 + nb; ++b) h_ncam[b] -= std::max(0, std::min(n, h_ncam[b]));
   HIPCHK(hipGetLastError());
@@ -1266,7 +1289,7 @@ int Batch<S>::run_frames(int f0, int f1) {
   POISON_GUARD();
   if (f0 < 0 || f1 > sc_frames || f0 > f1) return fail(-EINVAL, "frame range out of bounds");
   if (!committed) return fail(-EINVAL, "scenario not committed");
-  HIPCHK(hipSetDevice(device));
+  DEVICE_ENTER();
   // Trajectories are independent, so the batch may be cut into slices that run the same kernel sequence on
   // separate streams: the latency-bound stages of one slice (gain solve, Cholesky, propagate: one workgroup per
   // trajectory) overlap with the chip-filling stages of the others.  Stage profiling forces a single stream.
@@ -1367,7 +1390,7 @@ int Batch<S>::run_frames_streamed(int f0, int f1) {
   POISON_GUARD();
   if (f0 < 0 || f1 > sc_frames || f0 > f1) return fail(-EINVAL, "frame range out of bounds");
   if (!committed) return fail(-EINVAL, "scenario not committed");
-  HIPCHK(hipSetDevice(device));
+  DEVICE_ENTER();
   {
     bool all = sg_blk[0] != nullptr;
     for (int f = f0; f < f1 && all; ++f) all = pinf[f].p != nullptr;
@@ -1503,8 +1526,8 @@ int host_update(BatchBase* B, int b, const double* meas, const uint64_t* ids, in
       TrackToResid r;
       remove_tracked_feature(t, fid, r.slots);
       if (r.slots.size() >= (size_t)t.min_track_length) {
-        r.id = tr.id; r.obs = tr.obs;
-        t.to_resid.push_back(r);
+        r.id = tr.id; r.obs = std::move(tr.obs);        // (the track is erased below: its observations move, they are not copied)
+        t.to_resid.push_back(std::move(r));
       }
       to_remove.push_back(fid);
     }
