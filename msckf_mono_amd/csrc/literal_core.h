@@ -678,13 +678,16 @@ LIT_FN void information_from_rn(const Ctx& c, const Args<HT>& a, int n, int nr, 
       barrier(c);
       // trailing triangle: columns j >= k0 + pb, rows i >= j: Z(i, j) -= sum_q L(i, q) L(j, q) / d_q; tiles numbered down the
       // tile columns (consecutive threads: consecutive rows of the column-major Z)
-      const int j0 = k0 + pb, mt = nz - j0, tt = (mt + 3) / 4;
-      par_for32(c, tt * tt, [&](int t) {
-        // interleaved 4 x 4 sets (see the sweep's trailing pass): rows bi + z tt, columns bj + z' tt, the entries with i >= j
-        const int bj = t / tt, bi = t - bj * tt;
+      const int j0 = k0 + pb, mt = nz - j0, tt = (mt + 3) / 4, ntile = tt * (tt + 1) / 2;
+      par_for32(c, ntile, [&](int t) {
+        const double w2 = 2.0 * tt + 1.0;
+        int bj = (int)((w2 - sqrt(w2 * w2 - 8.0 * t)) * 0.5);
+        while (bj > 0 && bj * tt - bj * (bj - 1) / 2 > t) --bj;
+        while ((bj + 1) * tt - (bj + 1) * bj / 2 <= t) ++bj;
+        const int bi = bj + (t - (bj * tt - bj * (bj - 1) / 2)), i0 = 4 * bi, c0 = 4 * bj;      // rows i0 .. (>= columns c0 ..)
         int io[4], jo[4];
 #pragma unroll
-        for (int z = 0; z < 4; ++z) { io[z] = bi + z * tt < mt ? bi + z * tt : mt - 1; jo[z] = bj + z * tt < mt ? bj + z * tt : mt - 1; }
+        for (int z = 0; z < 4; ++z) { io[z] = i0 + z < mt ? i0 + z : mt - 1; jo[z] = c0 + z < mt ? c0 + z : mt - 1; }
         double acc[16];
 #pragma unroll
         for (int z = 0; z < 16; ++z) acc[z] = 0.0;
@@ -707,10 +710,7 @@ LIT_FN void information_from_rn(const Ctx& c, const Args<HT>& a, int n, int nr, 
 #pragma unroll
         for (int zj = 0; zj < 4; ++zj)
 #pragma unroll
-          for (int zi = 0; zi < 4; ++zi) {
-            const int i = bi + zi * tt, j = bj + zj * tt;
-            if (i < mt && j < mt && i >= j) Z[(j0 + i) + ldz * (j0 + j)] = old[zj * 4 + zi] - acc[zj * 4 + zi];
-          }
+          for (int zi = 0; zi < 4; ++zi) if (i0 + zi < mt && c0 + zj <= i0 + zi) Z[(j0 + i0 + zi) + ldz * (j0 + c0 + zj)] = old[zj * 4 + zi] - acc[zj * 4 + zi];
       });
       barrier(c);
     }
@@ -984,7 +984,7 @@ LIT_FN double lam_in(const Args<HT>& a, int hi, int lo) {   // hi >= lo
 // of Z = [[Bs^T R_o Bs, .], [(Bs^T A)^T, 0]] (information_from_rn).
 LIT_HD long compact_ws_doubles(int n, int m_cap, int r_cap, int /*ldg*/) {
   const long n1 = n + 1, ec = 15 + n;
-  return 2 * ec * n1 + ec * 2L * m_cap + 3 * n1 * n1 + 37 * n1 + ec * ec + ec * (long)n + 15L * n + 4 * ec
+  return 2 * ec * n1 + ec * 2L * m_cap + 3 * n1 * n1 + 35 * n1 + ec * ec + ec * (long)n + 15L * n + 4 * ec
        + 3L * n * n + 2 * ec * (long)n + 2L * n * n + 128;
 }
 
@@ -1232,24 +1232,20 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
     });
     par_for32(c, pb * pb, [&](int x) { const int q = x / pb, q2 = x - q * pb; if (q2 > q) Ac[(k0 + q2) + (long)n1 * (k0 + q)] = sS[q * PB + q2] * sDn[q]; });
     {
-      // a 4 x 4 set of entries per thread, INTERLEAVED: thread (bi, bj) owns rows bi + z ti, columns bj + z' tj -- consecutive
-      // threads are consecutive rows, so that every LDS read is a run of consecutive words (four consecutive rows per thread
-      // put a wavefront's reads four to a bank) and every global access a run of consecutive addresses.  The symmetric part
-      // keeps i >= j: all of the pairs z > z', the pairs z = z' when bi >= bj.
-      const int ni = nrow - pb, ti = (ni + 3) / 4, tj = (ntr + 3) / 4, ntE = ti * tj, ntG = tj * tj;
+      const int ni = nrow - pb, ti = (ni + 3) / 4, tj = (ntr + 3) / 4, ntE = ti * tj, ntG = tj * (tj + 1) / 2;
       par_for32(c, ntE + ntG, [&](int x) {
         double acc[16];
 #pragma unroll
         for (int z = 0; z < 16; ++z) acc[z] = 0.0;
         if (x < ntE) {
-          const int bj = x / ti, bi = x - bj * ti;
+          const int bj = x / ti, bi = x - bj * ti, i0 = 4 * bi, j0 = 4 * bj;
           int io[4], jo[4];
 #pragma unroll
-          for (int z = 0; z < 4; ++z) { io[z] = bi + z * ti < ni ? bi + z * ti : ni - 1; jo[z] = bj + z * tj < ntr ? bj + z * tj : ntr - 1; }
+          for (int z = 0; z < 4; ++z) { io[z] = i0 + z < ni ? i0 + z : ni - 1; jo[z] = j0 + z < ntr ? j0 + z : ntr - 1; }
           for (int q = 0; q < pb; ++q) {
             double av[4], bv[4];
 #pragma unroll
-            for (int z = 0; z < 4; ++z) { av[z] = sEC[q * lde + pb + io[z]]; bv[z] = sEP[(long)q * n1 + jo[z]]; }
+            for (int z = 0; z < 4; ++z) { av[z] = sEC[(q) * lde + ((pb + io[z]))]; bv[z] = sEP[(long)q * n1 + jo[z]]; }
 #pragma unroll
             for (int zi = 0; zi < 4; ++zi)
 #pragma unroll
@@ -1263,12 +1259,18 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
 #pragma unroll
           for (int zj = 0; zj < 4; ++zj)
 #pragma unroll
-            for (int zi = 0; zi < 4; ++zi) if (bi + zi * ti < ni && bj + zj * tj < ntr) E[(p0 + pb + io[zi]) + ec * (k0 + pb + jo[zj])] = old[zj * 4 + zi] - acc[zj * 4 + zi];
+            for (int zi = 0; zi < 4; ++zi) if (i0 + zi < ni && j0 + zj < ntr) E[(p0 + pb + i0 + zi) + ec * (k0 + pb + j0 + zj)] = old[zj * 4 + zi] - acc[zj * 4 + zi];
         } else {
-          const int t = x - ntE, bj = t / tj, bi = t - bj * tj;
+          // tiles of the lower triangle numbered down the tile columns (consecutive threads: consecutive rows of the column-major Gh)
+          const int t = x - ntE;
+          const double w2 = 2.0 * tj + 1.0;
+          int bj = (int)((w2 - sqrt(w2 * w2 - 8.0 * t)) * 0.5);
+          while (bj > 0 && bj * tj - bj * (bj - 1) / 2 > t) --bj;
+          while ((bj + 1) * tj - (bj + 1) * bj / 2 <= t) ++bj;
+          const int bi = bj + (t - (bj * tj - bj * (bj - 1) / 2)), i0 = 4 * bi, j0 = 4 * bj;      // rows i0.. (>= columns j0..)
           int io[4], jo[4];
 #pragma unroll
-          for (int z = 0; z < 4; ++z) { io[z] = bi + z * tj < ntr ? bi + z * tj : ntr - 1; jo[z] = bj + z * tj < ntr ? bj + z * tj : ntr - 1; }
+          for (int z = 0; z < 4; ++z) { io[z] = i0 + z < ntr ? i0 + z : ntr - 1; jo[z] = j0 + z < ntr ? j0 + z : ntr - 1; }
           for (int q = 0; q < pb; ++q) {
             double av[4], bv[4];
 #pragma unroll
@@ -1286,10 +1288,7 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
 #pragma unroll
           for (int zj = 0; zj < 4; ++zj)
 #pragma unroll
-            for (int zi = 0; zi < 4; ++zi) {
-              const int i = bi + zi * tj, j = bj + zj * tj;
-              if (i < ntr && j < ntr && i >= j) Gh[(k0 + pb + i) + (long)n1 * (k0 + pb + j)] = old[zj * 4 + zi] - acc[zj * 4 + zi];
-            }
+            for (int zi = 0; zi < 4; ++zi) if (i0 + zi < ntr && j0 + zj <= i0 + zi) Gh[(k0 + pb + i0 + zi) + (long)n1 * (k0 + pb + j0 + zj)] = old[zj * 4 + zi] - acc[zj * 4 + zi];
         }
       });
     }
@@ -1347,7 +1346,7 @@ LIT_FN SweepOut sweep_explicit(const Ctx& c, const Args<HT>& a, int e, int n, in
 //   double* Ac = Gh + (long)n1 * n1;              // [n1 x n1] Ac[j + n1 k] = s_j / (c0 - beta) of step k (column operations of the sweep), j > k
 //   double* G0s = Ac + (long)n1 * n1;             // [n1 x n1] lower triangle, column-major: Gh as it starts (the Gram matrix of the rows from row 15 down)
 //   double* Stg = G0s + (long)n1 * n1;            // [2][n1][16] stand-in for the LDS staging of the first 15 rows when the staging area is too small
-//   double* Ld = Stg + 35L * n1;                  // [n1] squared column norms
+//   double* Ld = Stg + 33L * n1;                  // [n1] squared column norms
 //   double* See = Ld + n1;                        // [ec x ec] G_E^T G_E (blocks of the tracks that own explicit rows)
 //   double* Xe = See + ec * ec;                   // [ec x n] G_E^T H_u
 //   double* Ut = Xe + ec * (long)n;               // [15 x n] See15 E15 / 2 - Xe15
@@ -1365,7 +1364,7 @@ LIT_FN SweepOut sweep_explicit(const Ctx& c, const Args<HT>& a, int e, int n, in
 //   int* topt = a.kept + 2 * ks;                  // [e] track of explicit row i
 //   int* refl = a.kept + 3 * ks;                  // [msteps]
 //   int* bidx = a.kept + 4 * ks;                  // [<= e] the basis: kept rows < 15, reflected steps, kept handed-through rows
-//   double* sE = 35L * n1 <= c.lds_doubles ? c.lds : Stg;   // rows 0..14 staged [column][17] (an odd stride: consecutive columns on different banks; 16 put every column of a wavefront on two banks); + n1 / 2 doubles: the basis list of the last phase
+//   double* sE = 33L * n1 <= c.lds_doubles ? c.lds : Stg;   // (+ n1 / 2 doubles: the basis list of the last phase)
 #define LIT_COMPACT_LAYOUT \
   const int n = 6 * a.N, F = a.F, n1 = n + 1, D = 15 + n; \
   const int e = m < D ? m : D; \
@@ -1379,7 +1378,7 @@ LIT_FN SweepOut sweep_explicit(const Ctx& c, const Args<HT>& a, int e, int n, in
   double* Ac = Gh + (long)n1 * n1; \
   double* G0s = Ac + (long)n1 * n1; \
   double* Stg = G0s + (long)n1 * n1; \
-  double* Ld = Stg + 35L * n1; \
+  double* Ld = Stg + 33L * n1; \
   double* See = Ld + n1; \
   double* Xe = See + ec * ec; \
   double* Ut = Xe + ec * (long)n; \
@@ -1400,11 +1399,11 @@ LIT_FN SweepOut sweep_explicit(const Ctx& c, const Args<HT>& a, int e, int n, in
   int* bidx = a.kept + 4 * ks; \
   const double dlt = a.u_var - a.v_var; \
   const int e15 = e < 15 ? e : 15; \
-  double* sE = 35L * n1 <= c.lds_doubles ? c.lds : Stg; \
-  double* sU = sE + 17L * n1; \
+  double* sE = 33L * n1 <= c.lds_doubles ? c.lds : Stg; \
+  double* sU = sE + 16L * n1; \
   auto stage15 = [&]() { \
-    par_for32(c, 16 * n1, [&](int x0) { \
-      const int j = x0 >> 4, l = x0 & 15, x = 17 * j + l; \
+    par_for32(c, 16 * n1, [&](int x) { \
+      const int j = x >> 4, l = x & 15; \
       sE[x] = l < e15 ? E0[l + ec * j] : 0.0; \
       sU[x] = (l < 15 && j < n) ? Ut[l + 15L * j] : 0.0; \
     }); \
@@ -1474,7 +1473,7 @@ LIT_FN void compact_rows(const Ctx& c, const Args<HT>& a, const int m) {
     const int lo = x / n1, hi = x - lo * n1;
     if (hi < lo || (hi == n && lo == n)) return 0.0;
     double v = lam_in(a, hi, lo);
-    const double* eh = sE + 17 * hi; const double* el = sE + 17 * lo;
+    const double* eh = sE + 16 * hi; const double* el = sE + 16 * lo;
 #pragma unroll
     for (int l = 0; l < 15; ++l) v -= eh[l] * el[l];
     return v;
@@ -1604,7 +1603,7 @@ LIT_FN void compact_basis(const Ctx& c, const Args<HT>& a, const int m) {
   {
     const long ldz = a.ldz;
     stage15();
-    int* sB = reinterpret_cast<int*>(sU + 17L * n1);      // the basis list beside the staged rows
+    int* sB = reinterpret_cast<int*>(sU + 16L * n1);      // the basis list beside the staged rows
     par_for32(c, nr, [&](int k) { sB[k] = bidx[k]; });
     barrier(c);
     par_map4(c, nr * nr, [&](int x) -> double {
@@ -1616,7 +1615,7 @@ LIT_FN void compact_basis(const Ctx& c, const Args<HT>& a, const int m) {
         val = (i == i2 ? a.v_var : 0.0) + dlt * See[i + ec * i2];
       } else if (ka < na + nb) {
         const int cc = sB[ka];
-        const double* ec_ = sE + 17 * cc; const double* uc_ = sU + 17 * cc;
+        const double* ec_ = sE + 16 * cc; const double* uc_ = sU + 16 * cc;
         if (kb < na) {                             // (x'_c, e_i)
           const int i = sB[kb];
           double sacc = Xe[i + ec * cc];
@@ -1624,7 +1623,7 @@ LIT_FN void compact_basis(const Ctx& c, const Args<HT>& a, const int m) {
           val = dlt * sacc;
         } else {                                   // (x'_c, x'_c'), c >= c'
           const int c2 = sB[kb];
-          const double* e2 = sE + 17 * c2; const double* u2 = sU + 17 * c2;
+          const double* e2 = sE + 16 * c2; const double* u2 = sU + 16 * c2;
           double sacc = a.Gam[(long)cc * a.ldGam + c2];
 #pragma unroll
           for (int l = 0; l < 15; ++l) sacc += ec_[l] * u2[l] + uc_[l] * e2[l];
@@ -1636,7 +1635,7 @@ LIT_FN void compact_basis(const Ctx& c, const Args<HT>& a, const int m) {
         else if (kb < na + nb) {                   // (q_h, x'_c): q_h^T x'_c = R(h, c)
           const int cc = sB[kb];
           double sacc = Qh[cc + (long)n * ah];
-          for (int l = 0; l < e15; ++l) sacc -= sE[17 * cc + l] * Ph[l + ec * ah];
+          for (int l = 0; l < e15; ++l) sacc -= sE[16 * cc + l] * Ph[l + ec * ah];
           val = a.v_var * (cc + 15 >= h ? E[h + ec * cc] : 0.0) + dlt * sacc;
         } else {                                   // (q_h, q_h')
           const int a2 = kb - na - nb;
