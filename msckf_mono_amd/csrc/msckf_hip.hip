@@ -100,6 +100,7 @@ struct BatchBase {
   virtual int prune_keep(int b, const std::vector<int>& keep) = 0;
   virtual int drop_oldest(int b0, int nb, int n) = 0;
   virtual int get_ncam(int b, int* n) = 0;
+  virtual int ncam_host(int b) const = 0;   // the window size from the host's own count (kept through every entry that changes it): no device read
   virtual int get_imu(int b, double* o) = 0;
   virtual int set_imu(int b, const double* in) = 0;
   virtual int get_cams(int b, double* o, int cap, int* n) = 0;
@@ -802,6 +803,7 @@ struct Batch : BatchBase {
     return 0;
   }
   int drop_oldest(int b0, int nb, int n) override;
+  int ncam_host(int b) const override { return (b < 0 || b >= B) ? -EINVAL : h_ncam[b]; }
   int get_ncam(int b, int* n) override {
     POISON_GUARD();
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
@@ -1880,7 +1882,10 @@ int msckf_hip_finish(msckf_hip_handle h, int b) {
   if (b < 0 || b >= H(h)->B) return fail(-EINVAL, "trajectory index out of range");
   return host_finish(H(h), b);
 }
-int msckf_hip_get_num_cam_states(msckf_hip_handle h, int b) { int n = 0; int rc = H(h)->get_ncam(b, &n); return rc ? rc : n; }
+int msckf_hip_get_num_cam_states(msckf_hip_handle h, int b) {   // cam_states_.size(): the host keeps the count (augment, prune, drop and run_frames all update it)
+  const int n = H(h)->ncam_host(b);
+  return n < 0 ? fail(-EINVAL, "trajectory index out of range") : n;
+}
 int msckf_hip_get_imu_state(msckf_hip_handle h, int b, double* imu29) { return H(h)->get_imu(b, imu29); }
 int msckf_hip_get_cam_states(msckf_hip_handle h, int b, double* cam7, int* state_ids, int cap) {
   int n = 0;

@@ -43,6 +43,9 @@ def main():
                 continue
             f, w = res[(k, "FETCH_SIZE")], res[(k, "WRITE_SIZE")]
             key = m.group(1) + (re.search(r"<(\d+)>", k).group(0) if m.group(1) == "k_gemm_mfma" and re.search(r"<(\d+)>", k) else "")
+            if m.group(1) == "k_lit_phase":   # the four phase kernels of the literal anisotropic compression (rows, sweep, basis, elimination)
+                ph = re.search(r"k_lit_phase<\w+, *(\d)>", k)
+                key += "<%s>" % (ph.group(1) if ph else "?")
             if m.group(1) == "k_chol_mfma":   # two instances per frame: the f64 factorization of Lam^ and the f32 gain solve
                 key += "_gram" if "<double" in k else "_gain"
             tr[key] = dict(kernel=k, fetch_kib=f, write_kib=w, bytes_per_launch=(2 * f + w) * 1024,
