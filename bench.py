@@ -246,6 +246,8 @@ def main():
         return run_cfg2(args)
     c = dict(CONFIGS[args.config])
     if args.trajectories > 0:
+        c["workload"] = c["workload"].replace("%d trajectories per GPU" % c["B"], "%d trajectories per GPU" % args.trajectories).replace(
+            "%d batched trajectories per GPU" % c["B"], "%d batched trajectories per GPU" % args.trajectories)
         c["B"] = args.trajectories
     if args.config == "cfg5":          # big windows: one repeat window by default, no CPU legs that take minutes
         args.no_early_accept_pass = True
@@ -585,8 +587,11 @@ def run_other_configs():
     A pass that fails or runs over its limit is reported as such; it never takes the headline line with it."""
     import subprocess
     lit = ["--config", "cfg4", "--steps", "10", "--warmup", "3", "--repeats", "3", "--no-cpu-baseline", "--no-early-accept-pass", "--parity-samples", "2"]
+    # cfg4_literal_640: BASELINE configs[3]'s own share per GPU (5 sequences x 1 024 seeds over 8 GPUs = 640 trajectories): the
+    # literal route's kernels are one workgroup per trajectory, so 128 trajectories leave half of the 256 compute units idle
     specs = [("cfg2", ["--config", "cfg2", "--steps", "20", "--warmup", "5", "--repeats", "3", "--no-cpu-baseline"]),
              ("cfg4_literal", lit), ("cfg4_whitened", lit + ["--aniso-mode", "1"]),
+             ("cfg4_literal_640", ["--config", "cfg4", "--trajectories", "640", "--steps", "6", "--warmup", "2", "--repeats", "3", "--no-cpu-baseline", "--no-early-accept-pass"]),
              ("cfg5", ["--config", "cfg5", "--steps", "5", "--warmup", "2", "--repeats", "2", "--no-cpu-baseline", "--no-early-accept-pass"])]
     res = {}
     for name, extra in specs:
@@ -597,12 +602,14 @@ def run_other_configs():
             rf = j.get("roofline") or {}
             if name == "cfg2":
                 parity = j.get("parity")
+            elif name == "cfg4_literal_640":
+                parity = "as cfg4_literal (the same trajectories' first 128 and 512 more seeds)"
             elif name == "cfg5":
                 parity = "no CPU leg at this size (cpu_baseline_note); held by tests/test_gpu_configs.py and tests/test_gpu_vs_reference.py (-m gpu)"
             else:
                 parity = {k2: j.get(k2) for k2 in ("ate_vs_ref_m", "ate_vs_ref_is", "ate_vs_ref_literal_m", "ate_vs_ref_whitened_m", "ate_vs_ref_note")}
             res[name] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"], "dtype": j["dtype"],
-                         "workload": j["config"]["workload"], "noise": j["config"].get("noise"),
+                         "workload": j["config"]["workload"], "noise": j["config"].get("noise"), "trajectories_per_gpu": j["config"].get("trajectories_per_gpu"),
                          "repeats_median": (j.get("repeats") or {}).get("median"),
                          "roofline": {"kernel": rf.get("kernel"), "frac": rf.get("frac"), "peak": rf.get("peak"), "bound": rf.get("bound"),
                                       "kernel_ms": rf.get("kernel_ms_per_step", rf.get("kernel_ms_per_update")), "stage_ms_per_step": rf.get("stage_ms_per_step", rf.get("stage_ms_per_update"))},
