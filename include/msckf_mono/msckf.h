@@ -10,7 +10,8 @@
 //
 // Differences a caller can observe (all documented in INTEGRATION.md):
 //   * one filter = one batch handle with B = 1; capacities come from MSCKFParams (override with
-//     MSCKF_SHIM_N_CAP / MSCKF_SHIM_F_CAP / MSCKF_SHIM_M_CAP);
+//     MSCKF_SHIM_N_CAP / MSCKF_SHIM_F_CAP / MSCKF_SHIM_M_CAP at compile time; the track capacity per update also at run
+//     time, before the filter is initialized: environment MSCKF_SHIM_F_CAP or MSCKF<S>::setTrackCapacity(n));
 //   * Q_imu / initial_imu_covar are read through their diagonals (every caller passes .asDiagonal());
 //   * u_var_prime != v_var_prime (EuRoC intrinsics): the reference's R_o_j = A_j^T R_j A_j / R_n = Q_1^T R_o Q_1 construction
 //     runs on the device, see include/msckf_hip.h (msckf_hip_set_anisotropic_noise);
@@ -26,6 +27,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../msckf_hip.h"
@@ -71,6 +73,13 @@ class MSCKF {
 
   MSCKF() {}
   ~MSCKF() { if (h_) msckf_hip_destroy(h_); }
+  // tracks one update() may hand to marginalize() (the reference has no such limit: its vectors grow): the compile-time
+  // default MSCKF_SHIM_F_CAP, the environment variable of the same name, or this setter, read when a filter is initialized
+  static int& trackCapacity() {
+    static int cap = [] { const char* e = std::getenv("MSCKF_SHIM_F_CAP"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : (int)MSCKF_SHIM_F_CAP; }();
+    return cap;
+  }
+  static void setTrackCapacity(int n) { if (n > 0) trackCapacity() = n; }
   // value semantics, as the reference object (msckf.h:31-67): a copy owns its own device-side filter
   MSCKF(const MSCKF& o) { copy_from(o); }
   MSCKF& operator=(const MSCKF& o) { if (this != &o) copy_from(o); return *this; }
@@ -85,7 +94,8 @@ class MSCKF {
     if (n_cap <= 0) n_cap = std::min(63, std::max(msckf_params.max_cam_states, std::min(msckf_params.max_track_length, 60)) + 3);
     if (m_cap <= 0) m_cap = std::min(64, std::max(4, std::min(msckf_params.max_track_length, n_cap)));
     n_cap_ = n_cap; m_cap_ = m_cap; sticky_ = 0;
-    rc_ = msckf_hip_create(1, n_cap, MSCKF_SHIM_F_CAP, m_cap, sizeof(_S) == 4 ? MSCKF_HIP_F32 : MSCKF_HIP_F64, 0, &h_);
+    f_cap_ = trackCapacity();
+    rc_ = msckf_hip_create(1, n_cap, f_cap_, m_cap, sizeof(_S) == 4 ? MSCKF_HIP_F32 : MSCKF_HIP_F64, 0, &h_);
     if (report("create")) return;
     double cam[12] = {(double)camera.c_u, (double)camera.c_v, (double)camera.f_u, (double)camera.f_v, (double)camera.b,
                       (double)camera.q_CI.w(), (double)camera.q_CI.x(), (double)camera.q_CI.y(), (double)camera.q_CI.z(),
@@ -143,8 +153,8 @@ class MSCKF {
     return s;
   }
   inline Vec3List getMap() {
-    std::vector<double> xyz(3 * MSCKF_SHIM_F_CAP);
-    int n = msckf_hip_get_map(h_, 0, xyz.data(), MSCKF_SHIM_F_CAP);
+    std::vector<double> xyz(3 * (size_t)f_cap_);
+    int n = msckf_hip_get_map(h_, 0, xyz.data(), f_cap_);
     Vec3List out;
     for (int i = 0; i < n; ++i) { Vector3<_S> p; set3(p, xyz.data() + 3 * i); out.push_back(p); }
     return out;
@@ -209,7 +219,7 @@ class MSCKF {
  private:
   msckf_hip_handle h_ = nullptr;
   Camera<_S> camera_;
-  int rc_ = 0, sticky_ = 0, n_cap_ = 0, m_cap_ = 0;
+  int rc_ = 0, sticky_ = 0, n_cap_ = 0, m_cap_ = 0, f_cap_ = MSCKF_SHIM_F_CAP;
   std::vector<double> buf_;
   std::vector<uint64_t> ids_;
 
@@ -223,9 +233,9 @@ class MSCKF {
   }
   void copy_from(const MSCKF& o) {
     if (h_) { msckf_hip_destroy(h_); h_ = nullptr; }
-    camera_ = o.camera_; rc_ = o.rc_; sticky_ = o.sticky_; n_cap_ = o.n_cap_; m_cap_ = o.m_cap_;
+    camera_ = o.camera_; rc_ = o.rc_; sticky_ = o.sticky_; n_cap_ = o.n_cap_; m_cap_ = o.m_cap_; f_cap_ = o.f_cap_;
     if (!o.h_) return;
-    rc_ = msckf_hip_create(1, n_cap_, MSCKF_SHIM_F_CAP, m_cap_, sizeof(_S) == 4 ? MSCKF_HIP_F32 : MSCKF_HIP_F64, 0, &h_);
+    rc_ = msckf_hip_create(1, n_cap_, f_cap_, m_cap_, sizeof(_S) == 4 ? MSCKF_HIP_F32 : MSCKF_HIP_F64, 0, &h_);
     if (report("create (copy)")) return;
     rc_ = msckf_hip_copy_state(h_, o.h_);
     report("copy_state");

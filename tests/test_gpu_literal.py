@@ -57,6 +57,7 @@ def test_literal_route_double_vs_restatement_every_frame(capi, po, N, F, nf, tra
     o = po.Oracle(po.F64, po.LEAN); o.setTinyRowTol(1e-10); o.initialize(tr.cfg, tr.imu0)
     bt = capi.Batch(1, N, F, max(N, 4), capi.F64); bt.initialize(0, tr.cfg, tr.imu0)
     updates = 0
+    handed = 0
     for k in range(nf):
         H.oracle_frame(o, tr, k, N); H.device_frame(bt, 0, tr, k, N)
         e = _errs(bt, 0, o)
@@ -65,7 +66,12 @@ def test_literal_route_double_vs_restatement_every_frame(capi, po, N, F, nf, tra
             info = bt.literal_info(0)
             assert info["m_rows"] == o.lastStats()["m_rows"] and info["kept_rows"] == o.lastStats()["r_rows"] and info["route"] == 3, (k, info, o.lastStats())
             updates += 1
+            handed = max(handed, info["kept_handed_through_rows"])
     assert updates >= nf - 4
+    # the basis of range(Q_1) then holds Q columns of rows that a dependent column handed through (literal_core.h: q_h), not only
+    # kept unit vectors and reflected columns: these two scenarios must exercise that path
+    if traj in (6, 3):
+        assert handed > 0
     bt.close()
 
 
