@@ -586,12 +586,12 @@ def run_other_configs():
     window, fp16 Jacobian) -> {name: {value, ms_per_step, dtype, workload, roofline: {kernel, frac, peak, bound}, parity, wall_s}}.
     A pass that fails or runs over its limit is reported as such; it never takes the headline line with it."""
     import subprocess
-    lit = ["--config", "cfg4", "--steps", "10", "--warmup", "3", "--repeats", "3", "--no-cpu-baseline", "--no-early-accept-pass", "--parity-samples", "2"]
+    lit = ["--config", "cfg4", "--steps", "10", "--warmup", "6", "--repeats", "3", "--no-cpu-baseline", "--no-early-accept-pass", "--parity-samples", "2"]
     # cfg4_literal_640: BASELINE configs[3]'s own share per GPU (5 sequences x 1 024 seeds over 8 GPUs = 640 trajectories): the
     # literal route's kernels are one workgroup per trajectory, so 128 trajectories leave half of the 256 compute units idle
     specs = [("cfg2", ["--config", "cfg2", "--steps", "20", "--warmup", "5", "--repeats", "3", "--no-cpu-baseline"]),
              ("cfg4_literal", lit), ("cfg4_whitened", lit + ["--aniso-mode", "1"]),
-             ("cfg4_literal_640", ["--config", "cfg4", "--trajectories", "640", "--steps", "6", "--warmup", "2", "--repeats", "3", "--no-cpu-baseline", "--no-early-accept-pass"]),
+             ("cfg4_literal_640", ["--config", "cfg4", "--trajectories", "640", "--steps", "6", "--warmup", "4", "--repeats", "3", "--no-cpu-baseline", "--no-early-accept-pass"]),
              ("cfg5", ["--config", "cfg5", "--steps", "5", "--warmup", "2", "--repeats", "2", "--no-cpu-baseline", "--no-early-accept-pass"])]
     res = {}
     for name, extra in specs:
