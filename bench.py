@@ -192,6 +192,17 @@ def host_cpus_for_rank(local_rank, n):
         return []
 
 
+def device_clocks():
+    """What rocm-smi reports for the shader / memory clocks right after the timed windows (off the timed path; best effort): leases
+    of this pool have run the same binaries up to 1.6x apart, and the line should say on which kind it ran."""
+    import subprocess
+    try:
+        o = subprocess.run(["rocm-smi", "--showclocks"], capture_output=True, text=True, timeout=20).stdout
+        return [ln.strip() for ln in o.splitlines() if ("sclk" in ln or "mclk" in ln or "fclk" in ln)][:8] or None
+    except Exception:
+        return None
+
+
 def self_launch_if_needed(args):
     """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: re-execute as N ranks, one per GPU, on this node."""
     env_world = os.environ.get("WORLD_SIZE")
@@ -385,6 +396,7 @@ def main():
         except Exception:
             h2d_gbs = None
 
+    clocks = device_clocks() if (rank == 0 and not os.environ.get("BENCH_NO_SMI")) else None
     # ---- profiled pass over K further frames: HIP events on the library's stream, per stage (single stream)
     bt.profile_enable(True)
     bt.run_frames(f, f + K)
@@ -555,7 +567,7 @@ def main():
                          "stage_ms_per_step": stage_ms, "stage_ms_per_step_raw_event_pairs": stage_raw, "event_pair_overhead_ms": ev_pair_ms},
             "ranks_seen": ranks_seen, "ranks_bit_identical_for_equal_seeds": ranks_equal,
             "gate_pass_rate": pass_rate, "ate_m": ate, "ate_per_sequence_m": [float(x) for x in ate_seq],
-            "scenario_gen_s": t_gen, "scenario_upload_s": t_up,
+            "scenario_gen_s": t_gen, "scenario_upload_s": t_up, "device_clocks_after_timed_windows": clocks,
             "with_gate_early_accept": None if early_ms is None else {
                 "value": world * B_TRAJ * K / (early_ms * 1e-3 * K), "ms_per_step": early_ms,
                 "note": "same K steps measured again with msckf_hip_set_gate_early_accept(1): exact bound gamma <= |r_o|^2/sigma^2, identical results; not the headline value"},
