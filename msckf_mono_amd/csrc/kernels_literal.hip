@@ -144,7 +144,6 @@ __global__ __launch_bounds__(64) void k_lit_pre(Dev<S> d, int b0, int nb, int it
   // Column-pivoted Householder QR of H_f = -H_x(:, 3:6) (2M x 3), lane o holds rows 2o, 2o + 1 (literal_core.h:
   // track_null_space is the serial statement of the same steps; the pivot rule is the oracle's: largest remaining squared
   // column norm over the rows from the pivot row down, first one wins)
-  const int R2 = 2 * M;
   double x[2][3] = {{0, 0, 0}, {0, 0, 0}};
   double hh[12];
 #pragma unroll
@@ -165,8 +164,7 @@ __global__ __launch_bounds__(64) void k_lit_pre(Dev<S> d, int b0, int nb, int it
   }
   double tau[3] = {0, 0, 0};
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    if (k >= R2) break;
+  for (int k = 0; k < 3; ++k) {                     // (a stacked track has M >= 2: at least four rows, all three steps exist)
     // squared norms of the remaining columns over rows >= k
     const int rk0 = 2 * lane, rk1 = 2 * lane + 1;
     double best = -1.0; int big = k;
@@ -322,7 +320,9 @@ __global__ __launch_bounds__(64) void k_lit_gamma(Dev<S> d, int b0, int nb, int 
     for (int j = 0; j < 2; ++j) acc[i][j] = lg_v4d{0.0, 0.0, 0.0, 0.0};
   const double* dummy = L.Du;                                // an always-valid word for the lanes whose column a track does not have
   // the sorted track list and the tracks' slot ranges, 64 per register (four registers: up to 256 stacked tracks are served by
-  // v_readlane; a pair's operands then depend on nothing but registers -- two levels of dependent loads per pair otherwise)
+  // v_readlane; a pair's operands then depend on nothing but registers -- two levels of dependent loads per pair otherwise).
+  // (Requesting the next pair's operands before this pair's MFMAs did not pay: 0.215 -> 0.238 ms; the kernel is bound by the ~0.9 GB of
+  // operands a launch of 128 trajectories moves out of L2, four loads per four MFMAs, not by one pair's latency.)
   int ordv[4], flv[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -338,7 +338,6 @@ __global__ __launch_bounds__(64) void k_lit_gamma(Dev<S> d, int b0, int nb, int 
       t = wave_bcast(ov, l); fl = wave_bcast(fv, l);
     } else { t = order[e]; fl = d.trk_first[(long)b * f_cap + t]; }
   };
-#pragma unroll 2
   for (int e0 = 0; e0 < P; e0 += 2) {
     // the pair of tracks (e0, e0 + 1): ranges, overlap with the tile's rows and columns
     int tt[2], lo[2], hi[2]; bool use[2];

@@ -26,11 +26,14 @@
 //
 // Two routes compute the same thing.  literal_general builds the dense stack and sweeps the reflectors over it, exactly as
 // written above: O(m n) memory passes per step -- the definition, kept for tests and A/B runs.  literal_compact (default)
-// runs the SAME sequence of Householder steps on a compressed representation (the rows that can become pivot rows
-// explicitly, the rest through their Gram matrix) in O(n^2) per step; see there.
+// uses that Lam^ depends on Q_1 only through range(Q_1): the SAME sequence of Householder steps runs, for its decisions, on a
+// compressed representation (the rows that can become pivot rows explicitly, all rows from the pivot row down through their
+// Gram matrix), and Lam^ follows from a basis of that range that needs no Q; see there.
 //
-// Written once for two compilers: hipcc (kernels_literal.hip: one workgroup per trajectory, phases separated by barriers)
-// and g++ -DLIT_HOST (tests/cpp/literal_host.cpp: the same phases run serially, checked against the oracle on the CPU).
+// Written once for two compilers: hipcc (kernels_literal.hip: one workgroup per trajectory and phase kernel, phases separated
+// by barriers) and g++ -DLIT_HOST (tests/cpp/literal_host.cpp: the same phases run serially, checked against the oracle on
+// the CPU).  Device-only pieces (DPP recurrences, ballot compaction, the chip-wide kernels of kernels_literal.hip) have a
+// serial statement beside them here.
 // All arithmetic in f64 whatever the filter's scalar type.
 #ifndef MSCKF_LITERAL_CORE_H
 #define MSCKF_LITERAL_CORE_H
@@ -65,11 +68,6 @@ LIT_FN bool first_rowlane(const Ctx&) { return true; }
 // before it writes the first: a store followed by the next item's loads is a full memory round trip when the compiler cannot
 // rule out that they alias)
 template <class FU, class FS> LIT_FN void rowlane_update(const Ctx&, long lo, long hi, FU upd, FS st) { for (long i = lo; i < hi; ++i) st(i, upd(i)); }
-// NV sums over a row range at once: f(i, v) adds row i's contribution to v[0..NV)
-template <int NV, class F> LIT_FN void wave_sum_vec(const Ctx&, long lo, long hi, double (&out)[NV], F f) {
-  for (int k = 0; k < NV; ++k) out[k] = 0;
-  for (long i = lo; i < hi; ++i) f(i, out);
-}
 // lower triangle of G^T G (G: mobs x nr, column-major with leading dimension ldg): st(i, j, value) for every j <= i < nr
 template <class ST> LIT_FN void syrk_lower(const Ctx&, const double* G, long ldg, int nr, int mobs, ST st) {
   for (int j = 0; j < nr; ++j)
@@ -79,20 +77,8 @@ template <class ST> LIT_FN void syrk_lower(const Ctx&, const double* G, long ldg
       st(i, j, s);
     }
 }
-// A^T B for A (kd x ma) and B (kd x nb), both column-major with the contraction index along the columns: st(i, j, value)
-template <class ST> LIT_FN void atb(const Ctx&, const double* A, long lda, int ma, const double* B, long ldb, int nb, int kd, ST st) {
-  for (int j = 0; j < nb; ++j)
-    for (int i = 0; i < ma; ++i) {
-      double s = 0;
-      for (int l = 0; l < kd; ++l) s += A[l + lda * i] * B[l + ldb * j];
-      st(i, j, s);
-    }
-}
 LIT_FN bool first_lane(const Ctx&) { return true; }
 LIT_FN bool first_thread(const Ctx&) { return true; }
-template <class ST> LIT_FN void atb_lower(const Ctx& c, const double* A, long lda, int ma, const double* B, long ldb, int kd, ST st) {
-  atb(c, A, lda, ma, B, ldb, ma, kd, [&](int i, int j, double v) { if (i >= j) st(i, j, v); });
-}
 LIT_FN void tick(const Ctx&, int) {}
 LIT_FN void tick_acc(const Ctx&, int, long long&) {}
 LIT_FN long long tick_now(const Ctx&) { return 0; }
@@ -175,14 +161,6 @@ template <class FU, class FS> LIT_FN void rowlane_update(const Ctx& c, long lo, 
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const long i = i0 + 16 * u; if (i < hi) st(i, v[u]); }
   }
-}
-template <int NV, class F> LIT_FN void wave_sum_vec(const Ctx& c, long lo, long hi, double (&out)[NV], F f) {
-  double v[NV];
-#pragma unroll
-  for (int k = 0; k < NV; ++k) v[k] = 0;
-  for (long i = lo + c.lane; i < hi; i += 64) f(i, v);
-#pragma unroll
-  for (int k = 0; k < NV; ++k) out[k] = wave_sum(v[k]);
 }
 // G is read from global memory ONCE: chunks of rows are staged in LDS ([row][column], row stride nr | 1), every thread owns
 // one 4 x 4 tile of the lower triangle (a second pass takes the tiles beyond the thread count) and keeps its sixteen sums in
@@ -287,64 +265,6 @@ template <class ST> LIT_FN void syrk_lower(const Ctx& c, const double* G, long l
   if (nt4 * (nt4 + 1) / 2 <= c.nt) syrk_lower_ts<4>(c, G, ldg, nr, mobs, st);
   else syrk_lower_ts<5>(c, G, ldg, nr, mobs, st);
 }
-// A^T B with chunks of the contraction index staged in LDS ([row][column of A | column of B]), one 4 x 4 tile of the result
-// per thread and pass (the operands are read from global memory once per pass)
-template <int TS, bool LOWER, class ST> LIT_FN void atb_ts(const Ctx& c, const double* A, long lda, int ma, const double* B, long ldb, int nb, int kd, ST st) {
-  const int ta = (ma + TS - 1) / TS, tb = (nb + TS - 1) / TS, ntl = LOWER ? ta * (ta + 1) / 2 : ta * tb, ldl = (ma + nb) | 1;
-  const int rows = c.lds_doubles / ldl;
-  for (int e0 = 0; e0 < ntl; e0 += c.nt) {
-    const int e = e0 + c.tid;
-    int ti = 0, tj = 0;
-    if (e < ntl) {
-      if (LOWER) { ti = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5); while (ti * (ti + 1) / 2 > e) --ti; while ((ti + 1) * (ti + 2) / 2 <= e) ++ti; tj = e - ti * (ti + 1) / 2; }
-      else { ti = e % ta; tj = e / ta; }
-    }
-    double acc[TS * TS];
-#pragma unroll
-    for (int k = 0; k < TS * TS; ++k) acc[k] = 0;
-    for (int l0 = 0; l0 < kd; l0 += rows) {
-      const int nrow = kd - l0 < rows ? kd - l0 : rows;
-      __syncthreads();
-      for (long x = c.tid; x < (long)nrow * ma; x += c.nt) { const int k = (int)(x / nrow), l = (int)(x - (long)k * nrow); c.lds[l * ldl + k] = A[l0 + l + lda * k]; }
-      for (long x = c.tid; x < (long)nrow * nb; x += c.nt) { const int k = (int)(x / nrow), l = (int)(x - (long)k * nrow); c.lds[l * ldl + ma + k] = B[l0 + l + ldb * k]; }
-      __syncthreads();
-      if (e < ntl) {
-        const double* li = c.lds + TS * ti; const double* lj = c.lds + ma + TS * tj;
-        int io[TS], jo[TS];                       // offsets clamped inside the matrices (edge tiles)
-#pragma unroll
-        for (int q = 0; q < TS; ++q) { io[q] = TS * ti + q < ma ? q : ma - 1 - TS * ti; jo[q] = TS * tj + q < nb ? q : nb - 1 - TS * tj; }
-        for (int l = 0; l < nrow; ++l) {
-          const double* ri = li + l * ldl; const double* rj = lj + l * ldl;
-          double xv[TS], yv[TS];
-#pragma unroll
-          for (int q = 0; q < TS; ++q) { xv[q] = ri[io[q]]; yv[q] = rj[jo[q]]; }
-#pragma unroll
-          for (int qi = 0; qi < TS; ++qi)
-#pragma unroll
-            for (int qj = 0; qj < TS; ++qj) acc[qi * TS + qj] += xv[qi] * yv[qj];
-        }
-      }
-    }
-    if (e < ntl)
-#pragma unroll
-      for (int qi = 0; qi < TS; ++qi)
-#pragma unroll
-        for (int qj = 0; qj < TS; ++qj) { const int i = TS * ti + qi, j = TS * tj + qj; if (i < ma && j < nb && (!LOWER || i >= j)) st(i, j, acc[qi * TS + qj]); }
-  }
-  __syncthreads();
-}
-// 4 x 4 tiles per thread, 5 x 5 when that saves a pass over the operands (every pass re-stages A and B); atb_lower: only the
-// entries (i, j), i >= j, of a square result (half the tiles)
-template <class ST> LIT_FN void atb(const Ctx& c, const double* A, long lda, int ma, const double* B, long ldb, int nb, int kd, ST st) {
-  const int t4 = ((ma + 3) / 4) * ((nb + 3) / 4), t5 = ((ma + 4) / 5) * ((nb + 4) / 5);
-  if ((t4 + c.nt - 1) / c.nt <= (t5 + c.nt - 1) / c.nt) atb_ts<4, false>(c, A, lda, ma, B, ldb, nb, kd, st);
-  else atb_ts<5, false>(c, A, lda, ma, B, ldb, nb, kd, st);
-}
-template <class ST> LIT_FN void atb_lower(const Ctx& c, const double* A, long lda, int ma, const double* B, long ldb, int kd, ST st) {
-  const int a4 = (ma + 3) / 4, a5 = (ma + 4) / 5, t4 = a4 * (a4 + 1) / 2, t5 = a5 * (a5 + 1) / 2;
-  if ((t4 + c.nt - 1) / c.nt <= (t5 + c.nt - 1) / c.nt) atb_ts<4, true>(c, A, lda, ma, B, ldb, ma, kd, st);
-  else atb_ts<5, true>(c, A, lda, ma, B, ldb, ma, kd, st);
-}
 LIT_FN bool first_lane(const Ctx& c) { return c.lane == 0; }
 LIT_FN bool first_thread(const Ctx& c) { return c.tid == 0; }
 LIT_FN void tick(const Ctx& c, int slot) { if (c.tim && c.tid == 0) c.tim[slot] = (long long)wall_clock64(); }
@@ -385,19 +305,6 @@ template <class P> LIT_FN int compact_list(const Ctx& c, int n, int* out, P pred
   return r;
 }
 #endif
-
-// dst[q2 * ds] -= coef * src[q2 * ss] for q2 in [lo, hi), both in LDS and never overlapping: four elements are read before the
-// first is written (a store followed by the next element's loads is a full LDS round trip when the compiler cannot rule out
-// that they alias: 120 of them per thread and panel; sixteen at a time spilled at 128 registers per thread)
-LIT_FN void lds_axpy16(double* __restrict__ dst, long ds, const double* __restrict__ src, long ss, int lo, int hi, double coef) {
-  int q2 = lo;
-  for (; q2 + 4 <= hi; q2 += 4) {
-    const double d0 = dst[q2 * ds], d1 = dst[(q2 + 1) * ds], d2 = dst[(q2 + 2) * ds], d3 = dst[(q2 + 3) * ds];
-    const double s0 = src[q2 * ss], s1 = src[(q2 + 1) * ss], s2 = src[(q2 + 2) * ss], s3 = src[(q2 + 3) * ss];
-    dst[q2 * ds] = d0 - coef * s0; dst[(q2 + 1) * ds] = d1 - coef * s1; dst[(q2 + 2) * ds] = d2 - coef * s2; dst[(q2 + 3) * ds] = d3 - coef * s3;
-  }
-  for (; q2 < hi; ++q2) dst[q2 * ds] -= coef * src[q2 * ss];
-}
 
 // ---- the panels' per-row / per-column recurrences.  A row below a panel (a column right of it) takes its PB entries through
 // the panel's pivots one after the other: entry q2 changes at every pivot q < q2, so one thread per row walks a chain of
