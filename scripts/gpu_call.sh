@@ -7,7 +7,7 @@
 #   bench        default bench.py (cfg3, the driver's line)     cfgs        cfg2, cfg4 (literal + whitened), cfg5 as their own lines
 #   cfg4         bench.py --config cfg4 (literal route) only    lit_timers  phase timers of k_literal at B = 8 and 128 (cfg4 geometry)
 #   sweep        scripts/sweep_variants.py (streams / streamed) profile     scripts/profile_round.sh (kernel stats + PMC passes of cfg3)
-#   lit_profile  rocprofv3 kernel stats + PMC passes of bench.py --config cfg4 (literal route)
+#   lit_profile  rocprofv3 kernel stats + PMC passes of bench.py --config cfg4 (literal route)    lit_stats  the kernel stats alone (all launches + last six)
 #   cfg2_profile rocprofv3 kernel stats of bench.py --config cfg2
 #   pause        scripts/pause_probe.py: the first window after a pause (state reads, sleeps) against the median, streamed / resident
 # Outputs land in gpurun_out/$TAG; copy what is to be judged into profiles/ by hand (profiles/README.md lists them).
@@ -49,12 +49,21 @@ if has cfgs; then
 fi
 if has sweep; then python scripts/sweep_variants.py --steps 20 --windows 5 "streams=4,streamed=0" "streams=4,streamed=1" "streams=1,streamed=0" > $O/sweep.txt 2>&1; cut -c1-250 $O/sweep.txt; fi
 if has profile; then TAG=$TAG PMC_COMMIT=${PMC_COMMIT:-unknown} bash scripts/profile_round.sh > $O/profile_round.log 2>&1; head -12 $O/kernel_stats_tail20.md; fi
+if has lit_stats; then    # kernel trace of cfg4 on the literal route only (no PMC passes): all launches and the last six (steady state) per kernel
+  cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --kernel-trace --stats -d /tmp/q0 -o r -- python /root/repo/bench.py --config cfg4 --steps 6 --warmup 2 --no-cpu-baseline --no-early-accept-pass --no-upload-pass --no-other-configs --repeats 1 --streams 1 > /tmp/c0.log 2>&1
+  python /root/repo/scripts/rocpd_summary.py $(find /tmp/q0 -name "*.db" | head -1) /root/repo/$O/kernel_stats_cfg4_literal.md > /dev/null
+  ROCPD_TAIL=6 python /root/repo/scripts/rocpd_summary.py $(find /tmp/q0 -name "*.db" | head -1) /root/repo/$O/kernel_stats_cfg4_literal_tail6.md > /dev/null
+  head -14 /root/repo/$O/kernel_stats_cfg4_literal_tail6.md
+  cd /root/repo
+fi
 if has lit_profile || has cfg2_profile; then
   cd /tmp && export TMPDIR=/tmp
   if has lit_profile; then
     C4="--config cfg4 --steps 6 --warmup 2 --no-cpu-baseline --no-early-accept-pass --no-upload-pass --no-other-configs --repeats 1 --streams 1"
     rocprofv3 --kernel-trace --stats -d /tmp/q1 -o r -- python /root/repo/bench.py $C4 > /tmp/c1.log 2>&1
     python /root/repo/scripts/rocpd_summary.py $(find /tmp/q1 -name "*.db" | head -1) /root/repo/$O/kernel_stats_cfg4_literal.md > /dev/null
+    ROCPD_TAIL=6 python /root/repo/scripts/rocpd_summary.py $(find /tmp/q1 -name "*.db" | head -1) /root/repo/$O/kernel_stats_cfg4_literal_tail6.md > /dev/null
     rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/q2 -o r -- python /root/repo/bench.py $C4 > /tmp/c2.log 2>&1
     rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/q3 -o r -- python /root/repo/bench.py $C4 > /tmp/c3.log 2>&1
     rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD --kernel-trace -d /tmp/q4 -o r -- python /root/repo/bench.py $C4 > /tmp/c4.log 2>&1
