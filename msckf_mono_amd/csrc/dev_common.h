@@ -49,6 +49,7 @@ enum { STAT_ERR_NCAP = 1, STAT_ERR_PIVOT = 2 };
 
 // work space of the literal anisotropic compression (kernels_literal.hip / literal_core.h), per trajectory; null when no
 // trajectory of the batch uses it
+constexpr int LIT_TIM_SLOTS = 24;   // 0..11 phase stamps, 12..15 the sweep's panels (sums), 16..22 the handed-through rows' steps
 struct LitBufs {
   double* X = nullptr; double* tau = nullptr; double* Vf = nullptr; double* Tf = nullptr; double* TH = nullptr; double* G = nullptr; double* Z = nullptr; double* W2 = nullptr;
   int* row0 = nullptr; int* obs0 = nullptr; int* otrk = nullptr; int* kept = nullptr; int* info = nullptr;
@@ -56,7 +57,7 @@ struct LitBufs {
   double* Gam = nullptr;      // [B][ldR][ldR] lower triangle, (hi, lo) at hi * ldR + lo: sum over the stacked tracks of (u-rows of the projected Jacobian)^T (the same)
   double* Du = nullptr;       // [B][n_cap][24] per camera slot: upper triangle of sum h_u^T h_u (21)
   int serial = 0;             // MSCKF_HIP_LITERAL_SERIAL=1: k_lit_pre's per-track part on one lane with literal_core.h's serial reference (A/B runs)
-  long long* tim = nullptr;   // [B][16] phase stamps of k_literal (100 MHz wall clock), only with MSCKF_HIP_LITERAL_TIMERS=1
+  long long* tim = nullptr;   // [B][LIT_TIM_SLOTS] phase stamps of k_literal (100 MHz wall clock), only with MSCKF_HIP_LITERAL_TIMERS=1
   int ldx = 0, r_cap = 0, ldg = 0, ldz = 0, kept_stride = 0;
   long w2_stride = 0;
   int route = 0;     // 0: the compact route; 1: the sweep over the dense stack (X, G allocated only then)

@@ -395,7 +395,7 @@ __device__ __forceinline__ bool lit_ctx(const Dev<S>& d, int b0, int nb, double*
   const int* st = d.stats + (long)b * STAT_STRIDE;
   if (st[STAT_MROWS] == 0) return false;
   c.tid = threadIdx.x; c.nt = blockDim.x; c.lane = threadIdx.x & 63; c.wave = threadIdx.x >> 6; c.nw = blockDim.x >> 6; c.red = red;
-  c.tim = d.lit.tim ? d.lit.tim + (long)b * 16 : nullptr; c.lds = lds; c.lds_doubles = LIT_LDS_DOUBLES;
+  c.tim = d.lit.tim ? d.lit.tim + (long)b * LIT_TIM_SLOTS : nullptr; c.lds = lds; c.lds_doubles = LIT_LDS_DOUBLES;
   return true;
 }
 

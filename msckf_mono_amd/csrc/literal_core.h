@@ -92,6 +92,7 @@ template <class FV, class FS> LIT_FN void par_map4(const Ctx&, int n, FV val, FS
 // a section run by ONE wavefront with wave_sync between its dependent steps (no workgroup barrier inside)
 LIT_FN bool first_wave(const Ctx&) { return true; }
 LIT_FN void wave_sync(const Ctx&) {}
+LIT_FN void wave_mem_sync(const Ctx&) {}
 // out[0 .. count) = the i in [0, n) with pred(i), ascending; returns count (uniform)
 template <class P> LIT_FN int compact_list(const Ctx&, int n, int* out, P pred) { int cnt = 0; for (int i = 0; i < n; ++i) if (pred(i)) out[cnt++] = i; return cnt; }
 #else
@@ -284,6 +285,9 @@ template <class FV, class FS> LIT_FN void par_map4(const Ctx& c, int n, FV val, 
 LIT_FN bool first_wave(const Ctx& c) { return c.wave == 0; }
 // LDS hand-over between the lanes of one wavefront: the fences keep the compiler from moving reads above writes
 LIT_FN void wave_sync(const Ctx&) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+// GLOBAL-memory hand-over between the lanes of one wavefront (a lane reads what another lane of its wavefront stored): the
+// stores are released to the device's coherence point and the loads that follow do not come out of a stale first-level line
+LIT_FN void wave_mem_sync(const Ctx&) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 // stream compaction by the first wavefront (ballot + prefix popcount, 64 candidates per round); the count reaches the other
 // wavefronts through c.red.  A thread-0 loop (load flag, store index, next load) paid a memory round trip per candidate.
 template <class P> LIT_FN int compact_list(const Ctx& c, int n, int* out, P pred) {
@@ -892,7 +896,7 @@ LIT_FN double lam_in(const Args<HT>& a, int hi, int lo) {   // hi >= lo
 LIT_HD long compact_ws_doubles(int n, int m_cap, int r_cap, int /*ldg*/) {
   const long n1 = n + 1, ec = 15 + n;
   return 2 * ec * n1 + ec * 2L * m_cap + 3 * n1 * n1 + 35 * n1 + ec * ec + ec * (long)n + 15L * n + 4 * ec
-       + 3L * n * n + 2 * ec * (long)n + 2L * n * n + 128;
+       + 3L * n * n + 2 * ec * (long)n + 2L * n * n + 55L * (2 * ec + m_cap) + 128;
 }
 
 // row r of Q_f = (I - V T V^T)(:, 0:3) of a track, Z3 = T V(0:3, :)^T
@@ -977,6 +981,217 @@ LIT_FN void explicit_row_products(const Ctx& c, const Args<HT>& a, int e, int n,
 }
 
 // One step of the sweep's per-column bookkeeping, shared by the three forms of the sweep
+
+// C(i, j) = sum_(klo(i) <= k < khi(j0)) fa(i, k) fb(k, j), i < M, j < N: a thread per (i, four consecutive j = j0 .. j0 + 3), i fastest
+// (fa coalesced over i, fb the same address in every lane of an i-run), four k in flight -- the plain loop per element waits
+// out a memory round trip per term (Gram of the start x column operations of a 160-step prefix: 0.6 ms)
+template <class FL, class FH, class FA, class FB, class ST>
+LIT_FN void par_gemm4(const Ctx& c, int M, int N, FL klo, FH khi, FA fa, FB fb, ST st) {
+  const int nq = (N + 3) / 4;
+  par_for(c, (long)M * nq, [&](long x) {
+    const int q = (int)(x / M), i = (int)(x - (long)q * M), j0 = 4 * q;
+    const int k1 = khi(j0);
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    int k = klo(i);
+    for (; k + 4 <= k1; k += 4) {
+      double av[4], bv[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        av[u] = fa(i, k + u);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) bv[u][v] = fb(k + u, j0 + v);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] += av[u] * bv[u][v];
+    }
+    for (; k < k1; ++k) {
+      const double av = fa(i, k);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[v] += av * fb(k, j0 + v);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) if (j0 + v < N) st(i, j0 + v, acc[v]);
+  });
+}
+
+// The reflectors of the steps before k_h, last one first, on [t ; y] (q_h = [t ; B0 y]); a wavefront per handed-through row.
+// t and y live in memory: every step is load -> reduce -> store -> next load (3.4 us a step: 0.55 ms for a row 160 steps in)
+template <class HT>
+LIT_FN void reflector_chain_mem(const Ctx& c, const Args<HT>& a, int ah, int kh, int kmax, int e, int n, long ec, const double* E, const double* Gv, const double* Yk, const int* refl, double* t, double* y) {
+  (void)ah;
+  lane_for(c, 0, e, [&](long i) { t[i] = i == 15 + kh ? 1.0 : 0.0; });
+  lane_for(c, 0, n, [&](long l) { y[l] = 0.0; });
+  for (int j = kh - 1; j >= 0; --j) {
+    if (!refl[j]) continue;
+    const int pj = 15 + j;
+    const double* ej = E + ec * j;
+    const double d1 = wave_sum_range(c, 0, e, [&](long i) { return i < pj ? 0.0 : (i == pj ? t[i] : ej[i] * t[i]); });
+    const double d2 = wave_sum_range(c, 0, kmax, [&](long l) { return Gv[l + (long)n * j] * y[l]; });
+    const double al = a.tau[j] * (d1 + d2);
+    lane_for(c, 0, e, [&](long i) { if (i >= pj) t[i] -= al * (i == pj ? 1.0 : ej[i]); });
+    lane_for(c, 0, kmax, [&](long l) { if (l <= j) y[l] -= al * Yk[l + (long)n * j]; });
+  }
+}
+#ifndef LIT_HOST
+// ... in registers (lane l holds entries l, l + 64, l + 128, l + 192), the next reflector's columns loaded while this one's
+// dot product reduces: one reduction per step is what is left of the chain
+template <class HT>
+LIT_FN void reflector_chain_regs(const Ctx& c, const Args<HT>& a, int kh, int kmax, int e, int n, long ec, const double* E, const double* Gv, const double* Yk, const int* refl, double* t, double* y) {
+  double tr[4], yr[4], ev[4], gv[4], yk[4], evn[4], gvn[4], ykn[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { tr[u] = (c.lane + 64 * u) == 15 + kh ? 1.0 : 0.0; yr[u] = 0.0; ev[u] = gv[u] = yk[u] = evn[u] = gvn[u] = ykn[u] = 0.0; }
+  auto next_refl = [&](int j) { while (j >= 0 && !refl[j]) --j; return j; };
+  auto load = [&](int j, double (&ev_)[4], double (&gv_)[4], double (&yk_)[4]) {
+    const int pj = 15 + j;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = c.lane + 64 * u;
+      ev_[u] = (i < e && i > pj) ? E[i + ec * j] : (i == pj ? 1.0 : 0.0);
+      gv_[u] = i < kmax ? Gv[i + (long)n * j] : 0.0;
+      yk_[u] = i <= j ? Yk[i + (long)n * j] : 0.0;
+    }
+  };
+  int j = next_refl(kh - 1);
+  if (j >= 0) load(j, ev, gv, yk);
+  while (j >= 0) {
+    const int jn = next_refl(j - 1);
+    if (jn >= 0) load(jn, evn, gvn, ykn);
+    double d = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) d += ev[u] * tr[u] + gv[u] * yr[u];
+    const double al = a.tau[j] * wave_sum(d);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { tr[u] -= al * ev[u]; yr[u] -= al * yk[u]; ev[u] = evn[u]; gv[u] = gvn[u]; yk[u] = ykn[u]; }
+    j = jn;
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { const int i = c.lane + 64 * u; if (i < e) t[i] = tr[u]; if (i < n) y[i] = yr[u]; }
+}
+#endif
+template <class HT>
+LIT_FN void reflector_chain(const Ctx& c, const Args<HT>& a, int ah, int kh, int kmax, int e, int n, long ec, const double* E, const double* Gv, const double* Yk, const int* refl, double* t, double* y) {
+#ifndef LIT_HOST
+  if (e <= 256 && n <= 256) { reflector_chain_regs(c, a, kh, kmax, e, n, ec, E, Gv, Yk, refl, t, y); return; }
+#endif
+  reflector_chain_mem(c, a, ah, kh, kmax, e, n, ec, E, Gv, Yk, refl, t, y);
+}
+
+// sum_(k < len) pa[k sa] pb[k sb], four terms in flight (the plain loop waits out a memory round trip per term)
+LIT_FN double dot_strided(const double* pa, long sa, const double* pb, long sb, int len) {
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int k = 0;
+  for (; k + 4 <= len; k += 4) {
+    const double a0 = pa[k * sa], a1 = pa[(k + 1) * sa], a2 = pa[(k + 2) * sa], a3 = pa[(k + 3) * sa];
+    const double b0 = pb[k * sb], b1 = pb[(k + 1) * sb], b2 = pb[(k + 2) * sb], b3 = pb[(k + 3) * sb];
+    s0 += a0 * b0; s1 += a1 * b1; s2 += a2 * b2; s3 += a3 * b3;
+  }
+  for (; k < len; ++k) s0 += pa[k * sa] * pb[k * sb];
+  return (s0 + s1) + (s2 + s3);
+}
+// Ph = See t~ + Xe y and Qh = Xe^T t~ + Gam y for the nh handed-through rows (t~ = Th, y = Yh) WITHOUT the full See / Xe (a pass
+// over every explicit row: 0.35 ms on every launch that had one such row among its trajectories).  Per track t that owns
+// explicit rows, with g = sum_i a_i[u-rows] t~(i) (a_i = row i of A_t^T), z = H_x y, P = I - Q_f Q_f^T:
+//     (See t~)(i) = a_i[u]^T g,   (Xe y)(i) = a_i[u]^T (P z)[u],   Xe^T t~ = H_x^T P [g on the u-rows ; 0 on the v-rows]
+// in passes over (row, observation of those tracks) pairs -- a workgroup's worth of threads each -- eight rows at a time.
+// GS: [6 nEc] rows 2o, 2o + 1 of Q_f | eight x [6 nEc] g, z0 -> (P u)_2o, z1 -> (P u)_2o+1, Q_f^T u and Q_f^T z at the
+// track's first two observations | [nEc] ints: track, slot (when the staging area is too small for them); nEc = 2 ec + m_cap observations at most (a track of M has 2 M - 3 >= M / 2 rows)
+template <class HT>
+LIT_FN void extras_products(const Ctx& c, const Args<HT>& a, int e, int n, long ec, int nh, int kmax, const int* topt, const double* At, const double* Th, const double* Yh, double* Ph, double* Qh, double* GS) {
+  const long mc2 = 2L * a.m_cap, nEc = 2 * ec + a.m_cap;
+  const int t0 = topt[0], t1 = topt[e - 1], ob = a.obs0[t0], nE = a.obs0[t1] + a.M[t1] - ob;
+  double* QF = GS;
+  double* CH = GS + 6 * nEc;
+  // observation -> track, slot, first observation of the track: in the staging area when it fits (read in every inner loop below)
+  int* obs_t = 3 * nEc <= 2L * c.lds_doubles ? reinterpret_cast<int*>(c.lds) : reinterpret_cast<int*>(GS + 54 * nEc);
+  int* obs_s = obs_t + nEc;
+  par_for(c, t1 - t0 + 1, [&](long tl) {
+    const int t = t0 + (int)tl;
+    if (!(a.status[t] & a.inc_bit)) return;
+    const int og0 = a.obs0[t] - ob, so = first_obs(a, t);
+    for (int o = 0; o < a.M[t]; ++o) { obs_t[og0 + o] = t; obs_s[og0 + o] = a.slots[so + o]; }
+  });
+  barrier(c);
+  par_for(c, nE, [&](long og) {
+    const int t = obs_t[og], o = (int)og - (a.obs0[t] - ob);
+    const double* V = a.Vf + (long)t * 2 * a.m_cap * 3;
+    double Z3[9], q0[3], q1[3]; qf_z3(V, a.Tf + (long)t * 9, Z3);
+    qf_row(V, Z3, 2 * o, q0); qf_row(V, Z3, 2 * o + 1, q1);
+    for (int k = 0; k < 3; ++k) { QF[6 * og + k] = q0[k]; QF[6 * og + 3 + k] = q1[k]; }
+  });
+  barrier(c);
+  for (int h0 = 0; h0 < nh; h0 += 8) {
+    const int nc = nh - h0 < 8 ? nh - h0 : 8;
+    // g, z per (row, observation)
+    par_for(c, (long)nc * nE, [&](long x) {
+      const int hc = (int)(x / nE), og = (int)(x - (long)hc * nE), ah = h0 + hc;
+      const int t = obs_t[og], o = og - (a.obs0[t] - ob), r0 = a.row0[t];
+      int r1 = r0 + 2 * a.M[t] - 3; r1 = r1 < e ? r1 : e;
+      const double* tt = Th + ec * ah; const double* yy = Yh + (long)n * ah;
+      const double g = dot_strided(At + r0 * mc2 + 2 * o, mc2, tt + r0, 1, r1 - r0);
+      const HT* hx = a.Hx + ((long)t * a.m_cap + o) * 12;
+      const int col = 6 * obs_s[og];
+      double z0 = 0, z1 = 0;
+      for (int kk = 0; kk < 6; ++kk) { const double yv = yy[col + kk]; z0 += (double)hx[kk] * yv; z1 += (double)hx[6 + kk] * yv; }
+      double* ch = CH + 6 * nEc * hc;
+      ch[og] = g; ch[nEc + og] = z0; ch[2 * nEc + og] = z1;
+    });
+    barrier(c);
+    // Q_f^T u, Q_f^T z per (row, track): a wavefront each
+    wave_for(c, 0, (long)nc * (t1 - t0 + 1), [&](long x) {
+      const int hc = (int)(x / (t1 - t0 + 1)), t = t0 + (int)(x - (long)hc * (t1 - t0 + 1));
+      if (!(a.status[t] & a.inc_bit)) return;
+      const int og0 = a.obs0[t] - ob, M = a.M[t];
+      double* ch = CH + 6 * nEc * hc;
+      double cu[3], cz[3];                         // (the stores after all six sums: the loads of the six are then issued together)
+      for (int k = 0; k < 3; ++k) {
+        cu[k] = wave_sum_range(c, 0, M, [&](long o) { return QF[6 * (og0 + o) + k] * ch[og0 + o]; });
+        cz[k] = wave_sum_range(c, 0, M, [&](long o) { return QF[6 * (og0 + o) + k] * ch[nEc + og0 + o] + QF[6 * (og0 + o) + 3 + k] * ch[2 * nEc + og0 + o]; });
+      }
+      if (first_lane(c)) for (int k = 0; k < 3; ++k) { ch[(3 + k) * nEc + og0] = cu[k]; ch[(3 + k) * nEc + og0 + 1] = cz[k]; }
+    });
+    barrier(c);
+    // (P u) rows 2o, 2o + 1 and g + (P z)_2o
+    par_for(c, (long)nc * nE, [&](long x) {
+      const int hc = (int)(x / nE), og = (int)(x - (long)hc * nE);
+      const int t = obs_t[og], og0 = a.obs0[t] - ob;
+      double* ch = CH + 6 * nEc * hc;
+      double su = 0, sv = 0, sz = 0;
+      for (int k = 0; k < 3; ++k) {
+        const double cu = ch[(3 + k) * nEc + og0], cz = ch[(3 + k) * nEc + og0 + 1];
+        su += QF[6 * og + k] * cu; sv += QF[6 * og + 3 + k] * cu; sz += QF[6 * og + k] * cz;
+      }
+      const double g = ch[og], z0 = ch[nEc + og];
+      ch[nEc + og] = g - su; ch[2 * nEc + og] = -sv; ch[og] = g + z0 - sz;
+    });
+    barrier(c);
+    par_for(c, (long)nc * e, [&](long x) {
+      const int hc = (int)(x / e), i = (int)(x - (long)hc * e), ah = h0 + hc;
+      const int t = topt[i], og0 = a.obs0[t] - ob, M = a.M[t];
+      const double* ch = CH + 6 * nEc * hc;
+      Ph[i + ec * ah] = dot_strided(At + i * mc2, 2, ch + og0, 1, M);
+    });
+    par_for(c, (long)nc * n, [&](long x) {
+      const int hc = (int)(x / n), cc = (int)(x - (long)hc * n), ah = h0 + hc, sl = cc / 6, kk = cc - 6 * sl;
+      const double* ch = CH + 6 * nEc * hc;
+      double sacc = 0;
+      for (int og = 0; og < nE; ++og) {
+        if (obs_s[og] != sl) continue;
+        const int t = obs_t[og], o = og - (a.obs0[t] - ob);
+        const HT* hx = a.Hx + ((long)t * a.m_cap + o) * 12;
+        sacc += (double)hx[kk] * ch[nEc + og] + (double)hx[6 + kk] * ch[2 * nEc + og];
+      }
+      const double* yy = Yh + (long)n * ah;
+      const int lsplit = cc < kmax ? cc : kmax;     // Gam(cc, l): row cc up to the diagonal, column cc below it
+      sacc += dot_strided(a.Gam + (long)cc * a.ldGam, 1, yy, 1, lsplit);
+      if (kmax > lsplit) sacc += dot_strided(a.Gam + (long)lsplit * a.ldGam + cc, a.ldGam, yy + lsplit, 1, kmax - lsplit);
+      Qh[cc + (long)n * ah] = sacc;
+    });
+    barrier(c);
+  }
+}
+
 struct SweepOut { int n_reflect, n_skip_tol; };
 
 // ---- the sweep when rows exist below the explicit ones, step by step (the definition of the blocked form; runs when the
@@ -1267,6 +1482,7 @@ LIT_FN SweepOut sweep_explicit(const Ctx& c, const Args<HT>& a, int e, int n, in
 //   double* Ph = Th + ec * (long)n;               // [ec x n] extras: See t~_h + Xe y_h
 //   double* Yh = Ph + ec * (long)n;               // [n x n] extras: y_h
 //   double* Qh = Yh + (long)n * n;                // [n x n] extras: Xe^T t~_h + Gam y_h
+//   double* GS = Qh + (long)n * n;                // [55 (2 ec + m_cap)] extras: per observation of the tracks that own explicit rows (extras_products)
 //   int* flag = a.kept + ks;                      // [e]
 //   int* topt = a.kept + 2 * ks;                  // [e] track of explicit row i
 //   int* refl = a.kept + 3 * ks;                  // [msteps]
@@ -1299,6 +1515,7 @@ LIT_FN SweepOut sweep_explicit(const Ctx& c, const Args<HT>& a, int e, int n, in
   double* Ph = Th + ec * (long)n; \
   double* Yh = Ph + ec * (long)n; \
   double* Qh = Yh + (long)n * n; \
+  double* GS = Qh + (long)n * n; \
   const int ks = n + 16; \
   int* flag = a.kept + ks; \
   int* topt = a.kept + 2 * ks; \
@@ -1438,72 +1655,82 @@ LIT_FN void compact_basis(const Ctx& c, const Args<HT>& a, const int m) {
   if (nh > 0) {
     const int* hk = bidx + na + nb;               // steps k_h, ascending
     const int kmax = hk[nh - 1];                  // reflectors 0 .. kmax - 1 can act
-    // Y(r, j) = [r == j] - sum_(i < j) Y(r, i) A(i, j): a row's entries follow from the row's earlier ones
-    par_for(c, kmax, [&](long r) {
-      for (int j = (int)r; j < kmax; ++j) {
-        double s = j == r ? 1.0 : 0.0;
-        if (refl[j]) for (int i = (int)r; i < j; ++i) if (refl[i]) s -= Yk[r + (long)n * i] * Ac[j + (long)n1 * i];
-        Yk[r + (long)n * j] = refl[j] ? s : 0.0;
-      }
-    });
-    par_for(c, (long)kmax * kmax, [&](long x) {
-      const int lo = (int)(x / kmax), hi = (int)(x - (long)lo * kmax);
-      if (hi < lo) return;
-      double s = 0;
-      if (gram) { s = lam_in(a, hi, lo); for (int i = 0; i < e; ++i) s -= E0[i + ec * hi] * E0[i + ec * lo]; }
-      Gb0[hi + (long)n * lo] = s; Gb0[lo + (long)n * hi] = s;
-    });
+    // Y(r, j) = [r == j] - sum_(i < j) Y(r, i) A(i, j), sixteen columns at a time: the part of the sum over the columns before
+    // the block as a product for all rows at once, the part inside the block per row in registers.  (A thread per row walking
+    // all its columns: k^2 / 2 dependent round trips, 3.9 ms for a handed-through row 160 steps in.)
+    for (int J0 = 0; J0 < kmax; J0 += 16) {
+      const int jn = kmax - J0 < 16 ? kmax - J0 : 16;
+      if (J0 > 0)
+        par_gemm4(c, J0, jn, [&](int r) { return r; }, [&](int) { return J0; },
+                  [&](int r, int i) { return Yk[r + (long)n * i]; },
+                  [&](int i, int jj) { return refl[i] ? Ac[(J0 + jj) + (long)n1 * i] : 0.0; },
+                  [&](int r, int jj, double v) { Yk[r + (long)n * (J0 + jj)] = -v; });
+      double* Ab = c.lds_doubles >= 256 ? c.lds : Stg;      // the block's own A, zero where a step did not reflect
+      par_for(c, 256, [&](long x) { const int ii = (int)(x >> 4), jj = (int)(x & 15); Ab[x] = (ii < jj && jj < jn && refl[J0 + ii]) ? Ac[(J0 + jj) + (long)n1 * (J0 + ii)] : 0.0; });
+      barrier(c);
+      par_for(c, J0 + jn, [&](long r) {
+        double yv[16];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+          const int j = J0 + jj;
+          double sv = 0.0;
+          if (jj < jn && j >= r) {
+            sv = r < J0 ? Yk[r + (long)n * j] : (j == r ? 1.0 : 0.0);
+#pragma unroll
+            for (int ii = 0; ii < jj; ++ii) sv -= yv[ii] * Ab[ii * 16 + jj];
+            if (!refl[j]) sv = 0.0;
+            Yk[r + (long)n * j] = sv;
+          }
+          yv[jj] = sv;
+        }
+      });
+      barrier(c);
+    }
+    tick(c, 16);
+    // Gb0 = B0^T B0 (the rows that were never explicit) = Lam_in - E0^T E0 over the first kmax columns
+    if (gram && kmax <= 8)        // (a short prefix: a wavefront per entry beats staging the rows for three threads' worth of tiles)
+      wave_for(c, 0, (long)kmax * kmax, [&](long x) {
+        const int lo = (int)(x / kmax), hi = (int)(x - (long)lo * kmax);
+        if (hi < lo) return;
+        const double v = wave_sum_range(c, 0, e, [&](long i) { return E0[i + ec * hi] * E0[i + ec * lo]; });
+        if (first_lane(c)) { const double g = lam_in(a, hi, lo) - v; Gb0[hi + (long)n * lo] = g; Gb0[lo + (long)n * hi] = g; }
+      });
+    else if (gram) syrk_lower(c, E0, ec, kmax, e, [&](int hi, int lo, double v) { const double g = lam_in(a, hi, lo) - v; Gb0[hi + (long)n * lo] = g; Gb0[lo + (long)n * hi] = g; });
+    else par_for(c, (long)kmax * kmax, [&](long x) { const int lo = (int)(x / kmax), hi = (int)(x - (long)lo * kmax); Gb0[hi + (long)n * lo] = 0.0; });
     barrier(c);
+    tick(c, 17);
     par_for(c, (long)kmax * kmax, [&](long x) { const int j = (int)(x / kmax), r = (int)(x - (long)j * kmax); if (r <= j) Yk[r + (long)n * j] *= dnv[j]; });   // Yv
     barrier(c);
-    par_for(c, (long)kmax * kmax, [&](long x) {
-      const int j = (int)(x / kmax), r = (int)(x - (long)j * kmax);
-      double s = 0;
-      for (int l = 0; l <= j; ++l) s += Gb0[r + (long)n * l] * Yk[l + (long)n * j];
-      Gv[r + (long)n * j] = s;
-    });
-    par_for(c, (long)e * nh, [&](long x) { const int ah = (int)(x / e), i = (int)(x - (long)ah * e); Th[i + ec * ah] = i == 15 + hk[ah] ? 1.0 : 0.0; });
-    par_for(c, (long)n * nh, [&](long x) { Yh[x] = 0.0; });
+    par_gemm4(c, kmax, kmax, [&](int) { return 0; }, [&](int j0) { return j0 + 4 < kmax ? j0 + 4 : kmax; },
+              [&](int r, int l) { return Gb0[r + (long)n * l]; },
+              [&](int l, int j) { return (l <= j && j < kmax) ? Yk[l + (long)n * j] : 0.0; },
+              [&](int r, int j, double v) { Gv[r + (long)n * j] = v; });
     barrier(c);
-    wave_for(c, 0, nh, [&](long ah) {
-      double* t = Th + ec * ah; double* y = Yh + (long)n * ah;
-      for (int j = hk[ah] - 1; j >= 0; --j) {
-        if (!refl[j]) continue;
-        const int pj = 15 + j;
-        const double* ej = E + ec * j;
-        const double d1 = wave_sum_range(c, 0, e, [&](long i) { return i < pj ? 0.0 : (i == pj ? t[i] : ej[i] * t[i]); });
-        const double d2 = wave_sum_range(c, 0, kmax, [&](long l) { return Gv[l + (long)n * j] * y[l]; });
-        const double al = a.tau[j] * (d1 + d2);
-        lane_for(c, 0, e, [&](long i) { if (i >= pj) t[i] -= al * (i == pj ? 1.0 : ej[i]); });
-        lane_for(c, 0, kmax, [&](long l) { if (l <= j) y[l] -= al * Yk[l + (long)n * j]; });
-      }
-    });
+    tick(c, 18);
+    wave_for(c, 0, nh, [&](long ah) { reflector_chain(c, a, (int)ah, hk[ah], kmax, e, n, ec, E, Gv, Yk, refl, Th + ec * ah, Yh + (long)n * ah); });
     barrier(c);
-    // t~ = t - E0 y ; the full See / Xe (the first 15 rows exist already)
+    tick(c, 19);
+    // t~ = t - E0 y
     par_for(c, (long)e * nh, [&](long x) {
       const int ah = (int)(x / e), i = (int)(x - (long)ah * e);
-      double s = Th[i + ec * ah];
-      for (int l = 0; l < kmax; ++l) s -= E0[i + ec * l] * Yh[l + (long)n * ah];
-      Th[i + ec * ah] = s;
-    });
-    explicit_row_products(c, a, e, n, ec, e15, e, topt, At, See, Xe, G3);
-    barrier(c);
-    par_for(c, (long)e * nh, [&](long x) {
-      const int ah = (int)(x / e), i = (int)(x - (long)ah * e), t = topt[i];
-      double s = 0;
-      const int r0 = a.row0[t]; int r1 = r0 + 2 * a.M[t] - 3; r1 = r1 < e ? r1 : e;
-      for (int i2 = r0; i2 < r1; ++i2) s += See[i + ec * i2] * Th[i2 + ec * ah];
-      for (int l = 0; l < kmax; ++l) s += Xe[i + ec * l] * Yh[l + (long)n * ah];
-      Ph[i + ec * ah] = s;
-    });
-    par_for(c, (long)n * nh, [&](long x) {
-      const int ah = (int)(x / n), cc = (int)(x - (long)ah * n);
-      double s = 0;
-      for (int i = 0; i < e; ++i) s += Xe[i + ec * cc] * Th[i + ec * ah];
-      for (int l = 0; l < kmax; ++l) { const int hi = cc > l ? cc : l, lo = cc > l ? l : cc; s += a.Gam[(long)hi * a.ldGam + lo] * Yh[l + (long)n * ah]; }
-      Qh[cc + (long)n * ah] = s;
+      double sacc = Th[i + ec * ah];
+      for (int l = 0; l < kmax; ++l) sacc -= E0[i + ec * l] * Yh[l + (long)n * ah];
+      Th[i + ec * ah] = sacc;
     });
     barrier(c);
+    tick(c, 20);
+    extras_products(c, a, e, n, ec, nh, kmax, topt, At, Th, Yh, Ph, Qh, GS);
+    tick(c, 21);
+    // (q_h, q_h') products of the Z fill below: a wavefront per pair
+    wave_for(c, 0, (long)nh * nh, [&](long x) {
+      const int ah = (int)(x / nh), a2 = (int)(x - (long)ah * nh);
+      if (a2 > ah) return;
+      const double s1 = wave_sum_range(c, 0, e, [&](long i) { return Th[i + ec * a2] * Ph[i + ec * ah]; });
+      const double s2 = wave_sum_range(c, 0, n, [&](long l) { return Yh[l + (long)n * a2] * Qh[l + (long)n * ah]; });
+      if (first_lane(c)) Gb0[a2 + (long)n * ah] = s1 + s2;
+    });
+    barrier(c);
+    tick(c, 22);
   }
   tick(c, 6);
   // ---- Z(0:nr, 0:nr) = Bs^T R_o Bs (lower triangle) and TH = Bs^T A for the basis [e_i | x'_c | q_h]
@@ -1513,14 +1740,15 @@ LIT_FN void compact_basis(const Ctx& c, const Args<HT>& a, const int m) {
     int* sB = reinterpret_cast<int*>(sU + 16L * n1);      // the basis list beside the staged rows
     par_for32(c, nr, [&](int k) { sB[k] = bidx[k]; });
     barrier(c);
-    par_map4(c, nr * nr, [&](int x) -> double {
-      const int kb = x / nr, ka = x - kb * nr;
+    const int nab = na + nb;
+    par_map4(c, nab * nab, [&](int x) -> double {
+      const int kb = x / nab, ka = x - kb * nab;
       if (ka < kb) return 0.0;
       double val;
       if (ka < na) {                               // (e_i, e_i')
         const int i = sB[ka], i2 = sB[kb];
         val = (i == i2 ? a.v_var : 0.0) + dlt * See[i + ec * i2];
-      } else if (ka < na + nb) {
+      } else {
         const int cc = sB[ka];
         const double* ec_ = sE + 16 * cc; const double* uc_ = sU + 16 * cc;
         if (kb < na) {                             // (x'_c, e_i)
@@ -1536,26 +1764,29 @@ LIT_FN void compact_basis(const Ctx& c, const Args<HT>& a, const int m) {
           for (int l = 0; l < 15; ++l) sacc += ec_[l] * u2[l] + uc_[l] * e2[l];
           val = a.v_var * G0s[cc + (long)n1 * c2] + dlt * sacc;
         }
-      } else {
-        const int ah = ka - na - nb, h = 15 + sB[ka];
-        if (kb < na) val = dlt * Ph[sB[kb] + ec * ah];                 // (q_h, e_i)
-        else if (kb < na + nb) {                   // (q_h, x'_c): q_h^T x'_c = R(h, c)
-          const int cc = sB[kb];
-          double sacc = Qh[cc + (long)n * ah];
-          for (int l = 0; l < e15; ++l) sacc -= sE[16 * cc + l] * Ph[l + ec * ah];
-          val = a.v_var * (cc + 15 >= h ? E[h + ec * cc] : 0.0) + dlt * sacc;
-        } else {                                   // (q_h, q_h')
-          const int a2 = kb - na - nb;
-          double sacc = 0;
-          for (int i = 0; i < e; ++i) sacc += Th[i + ec * a2] * Ph[i + ec * ah];
-          for (int l = 0; l < n; ++l) sacc += Yh[l + (long)n * a2] * Qh[l + (long)n * ah];
-          val = (ah == a2 ? a.v_var : 0.0) + dlt * sacc;
-        }
       }
       return val;
     }, [&](int x, double val) {
-      const int kb = x / nr, ka = x - kb * nr;
+      const int kb = x / nab, ka = x - kb * nab;
       if (ka >= kb) a.Z[ka + ldz * kb] = val;
+    });
+    // the handed-through rows' part in a pass of its own (inside the pass above, every wavefront walked their branch -- loops over
+    // global memory -- for the one or two lanes that had such an entry: +45 us on a launch with one such trajectory)
+    par_for(c, (long)nh * nr, [&](long x) {
+      const int ah = (int)(x / nr), kb = (int)(x - (long)ah * nr), ka = nab + ah, h = 15 + sB[ka];
+      if (kb > ka) return;
+      double val;
+      if (kb < na) val = dlt * Ph[sB[kb] + ec * ah];                   // (q_h, e_i)
+      else if (kb < nab) {                         // (q_h, x'_c): q_h^T x'_c = R(h, c)
+        const int cc = sB[kb];
+        double sacc = Qh[cc + (long)n * ah];
+        for (int l = 0; l < e15; ++l) sacc -= sE[16 * cc + l] * Ph[l + ec * ah];
+        val = a.v_var * (cc + 15 >= h ? E[h + ec * cc] : 0.0) + dlt * sacc;
+      } else {                                     // (q_h, q_h'): Th^T Ph + Yh^T Qh, left in Gb0 by the block above
+        const int a2 = kb - nab;
+        val = (ah == a2 ? a.v_var : 0.0) + dlt * Gb0[a2 + (long)n * ah];
+      }
+      a.Z[ka + ldz * kb] = val;
     });
     par_map4(c, nr * n1, [&](int x) -> double {
       const int k = x / n1, j = x - k * n1;

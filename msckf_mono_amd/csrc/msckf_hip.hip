@@ -488,7 +488,7 @@ struct Batch : BatchBase {
     rc |= dalloc(&L.info, Bz * 8);
     rc |= dalloc(&L.BD, Bz * f_cap * 6 * (size_t)d.ldR); rc |= dalloc(&L.Gam, Bz * (size_t)d.ldR * d.ldR); rc |= dalloc(&L.Du, Bz * n_cap * 24);
     if (const char* e = getenv("MSCKF_HIP_LITERAL_SERIAL")) L.serial = atoi(e);
-    if (const char* e = getenv("MSCKF_HIP_LITERAL_TIMERS")) if (atoi(e)) rc |= dalloc(&L.tim, Bz * 16);
+    if (const char* e = getenv("MSCKF_HIP_LITERAL_TIMERS")) if (atoi(e)) rc |= dalloc(&L.tim, Bz * LIT_TIM_SLOTS);
     if (rc) { L.W2 = nullptr; return fail(-ENOMEM, "work space of the literal anisotropic route (msckf_hip_set_anisotropic_noise(h, 1, 0) selects pre-whitening)"); }
     return 0;
   }
@@ -515,14 +515,17 @@ struct Batch : BatchBase {
     HIPCHK(hipMemcpyAsync(out8, d.lit.info + (size_t)b * 8, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (d.lit.tim) {     // MSCKF_HIP_LITERAL_TIMERS=1 (profiling runs): phase durations of the last launch in microseconds on stderr
-      long long t[16];
-      HIPCHK(hipMemcpyAsync(t, d.lit.tim + (size_t)b * 16, sizeof(t), hipMemcpyDeviceToHost, st));
+      long long t[LIT_TIM_SLOTS];
+      HIPCHK(hipMemcpyAsync(t, d.lit.tim + (size_t)b * LIT_TIM_SLOTS, sizeof(t), hipMemcpyDeviceToHost, st));
       HIPCHK(hipStreamSynchronize(st));
       std::fprintf(stderr, "[k_literal b=%d] us: explicit rows %.0f Gram %.0f sweep %.0f kept %.0f handed-through rows %.0f basis products %.0f Z fill %.0f eliminate %.0f store %.0f total %.0f\n", b,
                    (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01, (t[5] - t[4]) * 0.01, (t[6] - t[5]) * 0.01,
                    (t[8] - t[6]) * 0.01, (t[10] - t[8]) * 0.01, (t[11] - t[10]) * 0.01, (t[9] - t[11]) * 0.01, (t[9] - t[0]) * 0.01);
       std::fprintf(stderr, "[k_literal b=%d] us: the sweep's panels = stage %.0f + core %.0f + rows / columns %.0f + results and trailing pass %.0f\n", b,
                    t[12] * 0.01, t[13] * 0.01, t[14] * 0.01, t[15] * 0.01);
+      if (out8[6] > 0)
+        std::fprintf(stderr, "[k_literal b=%d] us: the %d kept handed-through rows = column operations %.0f + Gram of the start %.0f + its products %.0f + reflectors %.0f + t~ %.0f + products with the explicit rows, Gam y %.0f + pair products %.0f\n", b, out8[6],
+                     (t[16] - t[5]) * 0.01, (t[17] - t[16]) * 0.01, (t[18] - t[17]) * 0.01, (t[19] - t[18]) * 0.01, (t[20] - t[19]) * 0.01, (t[21] - t[20]) * 0.01, (t[22] - t[21]) * 0.01);
     }
     return 0;
   }

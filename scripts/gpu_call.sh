@@ -36,6 +36,7 @@ if has lit_timers; then
   P=msckf_mono_amd/lib_ab/libmsckf_hip_prev.so
   if [ -f $P ]; then MSCKF_HIP_LIB=$P MSCKF_HIP_LITERAL_TIMERS=1 python scripts/lit_timers.py 2>&1 | grep "k_literal b=0" | sed 's/^/prev /' | tee $O/lit_timers_prev.txt; fi
   MSCKF_HIP_LITERAL_TIMERS=1 python scripts/lit_timers.py 2>&1 | tail -14 | tee $O/lit_timers.txt
+  if has lit_timers_all; then MSCKF_HIP_LITERAL_TIMERS=1 python scripts/lit_timers.py --all > $O/lit_timers_all.txt 2>&1; fi
 fi
 if has pause; then python scripts/pause_probe.py 2>&1 | tail -6 | tee $O/pause_probe.txt; fi
 if has bench; then python bench.py > $O/bench.json 2> $O/bench.err; summ bench; fi

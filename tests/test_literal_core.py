@@ -184,3 +184,46 @@ def test_blocked_elimination_is_independent_of_the_panel_width(lit, po, monkeypa
             ref = L_c
         else:
             assert np.linalg.norm(L_c - ref) <= 1e-11 * np.linalg.norm(ref), stage
+
+
+def _without_slots(M, inc, slots, hx, r, drop):
+    """the same tracks without their observations in the camera slots `drop` (tracks left with fewer than 3 leave the stack)"""
+    M = M.copy(); slots = slots.copy(); hx = hx.copy(); r = r.copy(); inc = np.array(inc).copy()
+    for t in range(len(M)):
+        keep = [o for o in range(M[t]) if slots[t, o] not in drop]
+        k = len(keep)
+        slots[t, :k] = slots[t, keep]; hx[t, :k] = hx[t, keep]
+        rr = r[t].copy()
+        for q, o in enumerate(keep):
+            r[t, 2 * q:2 * q + 2] = rr[2 * o:2 * o + 2]
+        M[t] = k
+        if k < 3:
+            inc[t] = 0
+    return M, inc, slots, hx, r
+
+
+@pytest.mark.parametrize("drop", [(20,), (5, 27), (1,)])
+def test_handed_through_rows_deep_in_the_sweep(lit, po, monkeypatch, drop):
+    """A camera state that no stacked track observes has six zero columns: their steps reflect nothing, their rows are handed
+    through and kept (the later columns have entries there), and their columns of Q are the unit vectors under all the
+    reflectors before them -- 6 x slot steps deep.  The compact route builds those columns from the column operations of the
+    sweep in blocks of sixteen (literal_core.h: compact_basis, par_gemm4, reflector_chain, extras_products); the sweep over the
+    dense stack is the definition.  Also with the staging area too small for anything (every stand-in path)."""
+    N, F, nf = 30, 200, 32
+    cfg = sc.filter_config(N, isotropic=False)
+    tr = sc.Trajectory(4, 0, N, F, nf, cfg=cfg, path_id=0)
+    o = po.Oracle(po.F64, po.GRAM); o.setWhiten(True); o.setCapture(True); o.initialize(tr.cfg, tr.imu0)
+    u, v = tr.cfg["u_var_prime"], tr.cfg["v_var_prime"]
+    for k in range(nf):
+        H.oracle_frame(o, tr, k, N)
+    Fk, M, ps, sl, hx, r = _track_inputs(o, cap_m=64)
+    su, sv = np.sqrt(u), np.sqrt(v)
+    hx[:, :, 0:6] *= su; hx[:, :, 6:12] *= sv; r[:, 0::2] *= su; r[:, 1::2] *= sv
+    M2, inc2, sl2, hx2, r2 = _without_slots(M, ps, sl, hx, r, set(drop))
+    L_g, ig, _ = host_compress(lit, N, M2, inc2, sl2, hx2, r2, u, v, 1e-10, route=1)
+    for stage in (None, "100"):
+        if stage:
+            monkeypatch.setenv("LIT_HOST_STAGE", stage)
+        L_c, ic, _ = host_compress(lit, N, M2, inc2, sl2, hx2, r2, u, v, 1e-10, route=0)
+        assert ic[6] >= 6 and ic[1] == ig[1] and ic[2] == ig[2], (drop, ic, ig)       # six (or more) kept handed-through rows
+        assert np.linalg.norm(L_c - L_g) / np.linalg.norm(L_g) < 1e-9, (drop, stage)
