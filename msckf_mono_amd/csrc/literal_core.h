@@ -1035,16 +1035,18 @@ LIT_FN void reflector_chain_mem(const Ctx& c, const Args<HT>& a, int ah, int kh,
   }
 }
 #ifndef LIT_HOST
-// ... in registers (lane l holds entries l, l + 64, l + 128, l + 192), the next reflector's columns loaded while this one's
-// dot product reduces: one reduction per step is what is left of the chain
+// ... in registers (lane l holds entries l, l + 64, l + 128, l + 192), the next reflector's columns and tau loaded while this
+// one's dot product reduces, the step after that looked up in the list of reflected steps (rl, ascending, nrl entries) one
+// iteration ahead: one reduction per step is what is left of the chain.  (Walking refl[] for the next reflected step put a
+// dependent load in front of every step's loads: 1 us a step.)
 template <class HT>
-LIT_FN void reflector_chain_regs(const Ctx& c, const Args<HT>& a, int kh, int kmax, int e, int n, long ec, const double* E, const double* Gv, const double* Yk, const int* refl, double* t, double* y) {
-  double tr[4], yr[4], ev[4], gv[4], yk[4], evn[4], gvn[4], ykn[4];
+LIT_FN void reflector_chain_regs(const Ctx& c, const Args<HT>& a, int kh, int kmax, int e, int n, long ec, const double* E, const double* Gv, const double* Yk, const int* rl, int nrl, double* t, double* y) {
+  double tr[4], yr[4], ev[4], gv[4], yk[4], evn[4], gvn[4], ykn[4], tau = 0, taun = 0;
 #pragma unroll
   for (int u = 0; u < 4; ++u) { tr[u] = (c.lane + 64 * u) == 15 + kh ? 1.0 : 0.0; yr[u] = 0.0; ev[u] = gv[u] = yk[u] = evn[u] = gvn[u] = ykn[u] = 0.0; }
-  auto next_refl = [&](int j) { while (j >= 0 && !refl[j]) --j; return j; };
-  auto load = [&](int j, double (&ev_)[4], double (&gv_)[4], double (&yk_)[4]) {
+  auto load = [&](int j, double (&ev_)[4], double (&gv_)[4], double (&yk_)[4], double& tau_) {
     const int pj = 15 + j;
+    tau_ = a.tau[j];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = c.lane + 64 * u;
@@ -1053,28 +1055,30 @@ LIT_FN void reflector_chain_regs(const Ctx& c, const Args<HT>& a, int kh, int km
       yk_[u] = i <= j ? Yk[i + (long)n * j] : 0.0;
     }
   };
-  int j = next_refl(kh - 1);
-  if (j >= 0) load(j, ev, gv, yk);
+  int idx = (int)wave_sum_range(c, 0, nrl, [&](long q) { return rl[q] < kh ? 1.0 : 0.0; }) - 1;    // reflected steps before k_h: rl[0 .. idx]
+  int j = idx >= 0 ? rl[idx] : -1, jn = idx >= 1 ? rl[idx - 1] : -1;
+  if (j >= 0) load(j, ev, gv, yk, tau);
   while (j >= 0) {
-    const int jn = next_refl(j - 1);
-    if (jn >= 0) load(jn, evn, gvn, ykn);
+    const int jnn = idx >= 2 ? rl[idx - 2] : -1;
+    if (jn >= 0) load(jn, evn, gvn, ykn, taun);
     double d = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) d += ev[u] * tr[u] + gv[u] * yr[u];
-    const double al = a.tau[j] * wave_sum(d);
+    const double al = tau * wave_sum(d);
 #pragma unroll
     for (int u = 0; u < 4; ++u) { tr[u] -= al * ev[u]; yr[u] -= al * yk[u]; ev[u] = evn[u]; gv[u] = gvn[u]; yk[u] = ykn[u]; }
-    j = jn;
+    tau = taun; j = jn; jn = jnn; --idx;
   }
 #pragma unroll
   for (int u = 0; u < 4; ++u) { const int i = c.lane + 64 * u; if (i < e) t[i] = tr[u]; if (i < n) y[i] = yr[u]; }
 }
 #endif
 template <class HT>
-LIT_FN void reflector_chain(const Ctx& c, const Args<HT>& a, int ah, int kh, int kmax, int e, int n, long ec, const double* E, const double* Gv, const double* Yk, const int* refl, double* t, double* y) {
+LIT_FN void reflector_chain(const Ctx& c, const Args<HT>& a, int ah, int kh, int kmax, int e, int n, long ec, const double* E, const double* Gv, const double* Yk, const int* refl, const int* rl, int nrl, double* t, double* y) {
 #ifndef LIT_HOST
-  if (e <= 256 && n <= 256) { reflector_chain_regs(c, a, kh, kmax, e, n, ec, E, Gv, Yk, refl, t, y); return; }
+  if (e <= 256 && n <= 256) { reflector_chain_regs(c, a, kh, kmax, e, n, ec, E, Gv, Yk, rl, nrl, t, y); return; }
 #endif
+  (void)rl; (void)nrl;
   reflector_chain_mem(c, a, ah, kh, kmax, e, n, ec, E, Gv, Yk, refl, t, y);
 }
 
@@ -1487,6 +1491,7 @@ LIT_FN SweepOut sweep_explicit(const Ctx& c, const Args<HT>& a, int e, int n, in
 //   int* topt = a.kept + 2 * ks;                  // [e] track of explicit row i
 //   int* refl = a.kept + 3 * ks;                  // [msteps]
 //   int* bidx = a.kept + 4 * ks;                  // [<= e] the basis: kept rows < 15, reflected steps, kept handed-through rows
+//   (a.kept + 5 * ks: the reflected steps before the last kept handed-through row, for the reflector chains of compact_basis)
 //   double* sE = 33L * n1 <= c.lds_doubles ? c.lds : Stg;   // (+ n1 / 2 doubles: the basis list of the last phase)
 #define LIT_COMPACT_LAYOUT \
   const int n = 6 * a.N, F = a.F, n1 = n + 1, D = 15 + n; \
@@ -1658,12 +1663,15 @@ LIT_FN void compact_basis(const Ctx& c, const Args<HT>& a, const int m) {
     // Y(r, j) = [r == j] - sum_(i < j) Y(r, i) A(i, j), sixteen columns at a time: the part of the sum over the columns before
     // the block as a product for all rows at once, the part inside the block per row in registers.  (A thread per row walking
     // all its columns: k^2 / 2 dependent round trips, 3.9 ms for a handed-through row 160 steps in.)
+    // (rows of A of the steps that did not reflect were never written: zero, so that the products below need no test)
+    par_for(c, (long)kmax * n1, [&](long x) { const int i = (int)(x / n1); if (!refl[i]) Ac[x] = 0.0; });
+    barrier(c);
     for (int J0 = 0; J0 < kmax; J0 += 16) {
       const int jn = kmax - J0 < 16 ? kmax - J0 : 16;
       if (J0 > 0)
         par_gemm4(c, J0, jn, [&](int r) { return r; }, [&](int) { return J0; },
                   [&](int r, int i) { return Yk[r + (long)n * i]; },
-                  [&](int i, int jj) { return refl[i] ? Ac[(J0 + jj) + (long)n1 * i] : 0.0; },
+                  [&](int i, int jj) { return Ac[(J0 + jj) + (long)n1 * i]; },
                   [&](int r, int jj, double v) { Yk[r + (long)n * (J0 + jj)] = -v; });
       double* Ab = c.lds_doubles >= 256 ? c.lds : Stg;      // the block's own A, zero where a step did not reflect
       par_for(c, 256, [&](long x) { const int ii = (int)(x >> 4), jj = (int)(x & 15); Ab[x] = (ii < jj && jj < jn && refl[J0 + ii]) ? Ac[(J0 + jj) + (long)n1 * (J0 + ii)] : 0.0; });
@@ -1699,15 +1707,21 @@ LIT_FN void compact_basis(const Ctx& c, const Args<HT>& a, const int m) {
     else par_for(c, (long)kmax * kmax, [&](long x) { const int lo = (int)(x / kmax), hi = (int)(x - (long)lo * kmax); Gb0[hi + (long)n * lo] = 0.0; });
     barrier(c);
     tick(c, 17);
-    par_for(c, (long)kmax * kmax, [&](long x) { const int j = (int)(x / kmax), r = (int)(x - (long)j * kmax); if (r <= j) Yk[r + (long)n * j] *= dnv[j]; });   // Yv
+    {                             // Yv = Y diag(dn), zero below the diagonal and in the columns up to the next multiple of four
+      const int k4 = (kmax + 3) & ~3, kc = k4 < n ? k4 : n;
+      par_for(c, (long)kc * kc, [&](long x) { const int j = (int)(x / kc), r = (int)(x - (long)j * kc); Yk[r + (long)n * j] = (r <= j && j < kmax) ? Yk[r + (long)n * j] * dnv[j] : 0.0; });
+    }
     barrier(c);
     par_gemm4(c, kmax, kmax, [&](int) { return 0; }, [&](int j0) { return j0 + 4 < kmax ? j0 + 4 : kmax; },
               [&](int r, int l) { return Gb0[r + (long)n * l]; },
-              [&](int l, int j) { return (l <= j && j < kmax) ? Yk[l + (long)n * j] : 0.0; },
+              [&](int l, int j) { return Yk[l + (long)n * (j < n ? j : n - 1)]; },
               [&](int r, int j, double v) { Gv[r + (long)n * j] = v; });
     barrier(c);
     tick(c, 18);
-    wave_for(c, 0, nh, [&](long ah) { reflector_chain(c, a, (int)ah, hk[ah], kmax, e, n, ec, E, Gv, Yk, refl, Th + ec * ah, Yh + (long)n * ah); });
+    int* rlist = a.kept + 5 * ks;                 // the reflected steps below kmax, ascending
+    const int nrl = compact_list(c, kmax, rlist, [&](int k) { return refl[k] != 0; });
+    barrier(c);
+    wave_for(c, 0, nh, [&](long ah) { reflector_chain(c, a, (int)ah, hk[ah], kmax, e, n, ec, E, Gv, Yk, refl, rlist, nrl, Th + ec * ah, Yh + (long)n * ah); });
     barrier(c);
     tick(c, 19);
     // t~ = t - E0 y
