@@ -49,7 +49,7 @@ enum { STAT_ERR_NCAP = 1, STAT_ERR_PIVOT = 2 };
 
 // work space of the literal anisotropic compression (kernels_literal.hip / literal_core.h), per trajectory; null when no
 // trajectory of the batch uses it
-constexpr int LIT_TIM_SLOTS = 24;   // 0..11 phase stamps, 12..15 the sweep's panels (sums), 16..22 the handed-through rows' steps
+constexpr int LIT_TIM_SLOTS = 24;   // 0..11 phase stamps (7: basis staged), 12..15 the sweep's panels (sums), 16..22 the handed-through rows' steps, 23: Z's main pass done
 struct LitBufs {
   double* X = nullptr; double* tau = nullptr; double* Vf = nullptr; double* Tf = nullptr; double* TH = nullptr; double* G = nullptr; double* Z = nullptr; double* W2 = nullptr;
   int* row0 = nullptr; int* obs0 = nullptr; int* otrk = nullptr; int* kept = nullptr; int* info = nullptr;

@@ -1639,9 +1639,11 @@ LIT_FN void compact_basis(const Ctx& c, const Args<HT>& a, const int m) {
   if (a.tol > 0) rmax = wg_max(c, 0, (long)e * n, [&](long xl) { const int x = (int)xl, j = x / e, i = x - j * e; return (j + 15 >= i) ? fabs(E[i + ec * j]) : 0.0; });
   par_for(c, e, [&](long i) { flag[i] = 0; });
   barrier(c);
-  par_for(c, n, [&](long j) {                    // a thread per column (contiguous); every writer of a flag writes 1
-    const int i_hi = (int)j + 15 < e - 1 ? (int)j + 15 : e - 1;
-    for (int i = 0; i <= i_hi; ++i) { const double v = fabs(E[i + ec * j]); if (a.tol > 0 ? (v > a.tol * rmax) : (v != 0.0)) flag[i] = 1; }
+  par_for(c, (long)e * n, [&](long xl) {         // an entry per thread (a thread per column walked 195 rows one load at a time); every writer of a flag writes 1
+    const int x = (int)xl, j = x / e, i = x - j * e;
+    if (j + 15 < i) return;
+    const double v = fabs(E[i + ec * j]);
+    if (a.tol > 0 ? (v > a.tol * rmax) : (v != 0.0)) flag[i] = 1;
   });
   barrier(c);
   const int nr_kept = compact_list(c, e, a.kept, [&](int i) { return flag[i] != 0; });
@@ -1754,6 +1756,7 @@ LIT_FN void compact_basis(const Ctx& c, const Args<HT>& a, const int m) {
     int* sB = reinterpret_cast<int*>(sU + 16L * n1);      // the basis list beside the staged rows
     par_for32(c, nr, [&](int k) { sB[k] = bidx[k]; });
     barrier(c);
+    tick(c, 7);
     const int nab = na + nb;
     par_map4(c, nab * nab, [&](int x) -> double {
       const int kb = x / nab, ka = x - kb * nab;
@@ -1784,6 +1787,8 @@ LIT_FN void compact_basis(const Ctx& c, const Args<HT>& a, const int m) {
       const int kb = x / nab, ka = x - kb * nab;
       if (ka >= kb) a.Z[ka + ldz * kb] = val;
     });
+    barrier(c);
+    tick(c, 23);
     // the handed-through rows' part in a pass of its own (inside the pass above, every wavefront walked their branch -- loops over
     // global memory -- for the one or two lanes that had such an entry: +45 us on a launch with one such trajectory)
     par_for(c, (long)nh * nr, [&](long x) {

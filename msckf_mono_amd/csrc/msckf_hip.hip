@@ -243,7 +243,10 @@ struct Batch : BatchBase {
   // single-call staging on device
   S* d_rd = nullptr; int rd_cap = 0;               // [B][rd_cap][7]
   S* d_pfin = nullptr;                              // [B][f_cap][4] stored feature positions (mode 1)
-  int* wl_n = nullptr; int* wl_M = nullptr; int* wl_slots = nullptr; S* wl_obs = nullptr;  // [B]...[B][f_cap][m_cap]
+  // single-call work-lists: per trajectory ONE block of ints [n, 0, 0, 0 | M[f4] | slots[f_cap][m_cap]] (wl_ib ints; one copy per
+  // set_tracks instead of three) and the observations [2 wl_ib] (the kernels index both with the same stride)
+  int* wl_i = nullptr; long wl_ib = 0; int wl_f4 = 0; S* wl_obs = nullptr;
+  S* h_rb = nullptr;           // page-locked landing area of the single-filter state read (get_cams_known): [n_cap][CAM_STRIDE] + [IMU_STRIDE]
   // scenario.  Work-lists are COMPACT: a cell (frame, trajectory) holds sum M_j (slot, observation) entries, track t of the
   // cell starts at off[cell][t] counted from the frame's first entry (Dev::trk_off) -- not [f_cap][m_cap] padded rows (1.9x
   // the payload at cfg3's track lengths, on the host, in HBM and in every per-frame upload).
@@ -354,7 +357,9 @@ struct Batch : BatchBase {
     rc |= dalloc(&d.gain_bar, Bz * 32);   // 0: the S GEMM as a launch of its own (A/B runs)
     rd_cap = 64;
     rc |= dalloc(&d_rd, Bz * rd_cap * RD_STRIDE);
-    rc |= dalloc(&wl_n, Bz); rc |= dalloc(&wl_M, TF); rc |= dalloc(&wl_slots, TF * m_cap); rc |= dalloc(&wl_obs, TF * m_cap * 2);
+    HIPCHK(hipHostMalloc((void**)&h_rb, ((size_t)n_cap * CAM_STRIDE + IMU_STRIDE) * sizeof(S), hipHostMallocDefault));
+    wl_f4 = (f_cap + 3) & ~3; wl_ib = (4 + wl_f4 + (long)f_cap * m_cap + 3) & ~3L;
+    rc |= dalloc(&wl_i, Bz * wl_ib); rc |= dalloc(&wl_obs, Bz * wl_ib * 2);
     if (rc) return rc;
     use_single_worklists();
     if (feature_lds_bytes(m_cap, sizeof(S)) > 160 * 1024) return fail(-EINVAL, "m_cap too large for the feature kernel's LDS budget");
@@ -366,6 +371,7 @@ struct Batch : BatchBase {
     hipSetDevice(device);
     if (st) hipStreamSynchronize(st);
     for (void* p : allocs) hipFree(p);
+    if (h_rb) hipHostFree(h_rb);
     for (int s = 0; s < NSTAGE; ++s) for (auto& e : ev_pool[s]) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (int i = 1; i < MAXS; ++i) { if (stx[i]) hipStreamDestroy(stx[i]); if (ev_join[i]) hipEventDestroy(ev_join[i]); }
     for (int i = 0; i < MAXS; ++i) { if (sty[i]) hipStreamDestroy(sty[i]); if (ev_fa[i]) hipEventDestroy(ev_fa[i]); if (ev_fb[i]) hipEventDestroy(ev_fb[i]); }
@@ -409,8 +415,8 @@ struct Batch : BatchBase {
     return 0;
   }
   void use_single_worklists() {
-    d.trk_n = wl_n; d.trk_M = wl_M; d.trk_slots = wl_slots; d.trk_obs = wl_obs; d.trk_off = nullptr;
-    d.wl_stride_n = 1; d.wl_stride_f = f_cap; d.wl_stride_o = (long)f_cap * m_cap;
+    d.trk_n = wl_i; d.trk_M = wl_i + 4; d.trk_slots = wl_i + 4 + wl_f4; d.trk_obs = wl_obs; d.trk_off = nullptr;
+    d.wl_stride_n = wl_ib; d.wl_stride_f = wl_ib; d.wl_stride_o = wl_ib;
   }
   // Dev view whose work-list pointers start at trajectory b0 (kernels index work-lists by b - b0)
   Dev<S> view(int b0) const {
@@ -521,8 +527,8 @@ struct Batch : BatchBase {
       std::fprintf(stderr, "[k_literal b=%d] us: explicit rows %.0f Gram %.0f sweep %.0f kept %.0f handed-through rows %.0f basis products %.0f Z fill %.0f eliminate %.0f store %.0f total %.0f\n", b,
                    (t[2] - t[1]) * 0.01, (t[3] - t[2]) * 0.01, (t[4] - t[3]) * 0.01, (t[5] - t[4]) * 0.01, (t[6] - t[5]) * 0.01,
                    (t[8] - t[6]) * 0.01, (t[10] - t[8]) * 0.01, (t[11] - t[10]) * 0.01, (t[9] - t[11]) * 0.01, (t[9] - t[0]) * 0.01);
-      std::fprintf(stderr, "[k_literal b=%d] us: the sweep's panels = stage %.0f + core %.0f + rows / columns %.0f + results and trailing pass %.0f\n", b,
-                   t[12] * 0.01, t[13] * 0.01, t[14] * 0.01, t[15] * 0.01);
+      std::fprintf(stderr, "[k_literal b=%d] us: the sweep's panels = stage %.0f + core %.0f + rows / columns %.0f + results and trailing pass %.0f; basis products = staging %.0f + Z %.0f + rest %.0f\n", b,
+                   t[12] * 0.01, t[13] * 0.01, t[14] * 0.01, t[15] * 0.01, (t[7] - t[6]) * 0.01, (t[23] - t[7]) * 0.01, (t[8] - t[23]) * 0.01);
       if (out8[6] > 0)
         std::fprintf(stderr, "[k_literal b=%d] us: the %d kept handed-through rows = column operations %.0f + Gram of the start %.0f + its products %.0f + reflectors %.0f + t~ %.0f + products with the explicit rows, Gam y %.0f + pair products %.0f\n", b, out8[6],
                      (t[16] - t[5]) * 0.01, (t[17] - t[16]) * 0.01, (t[18] - t[17]) * 0.01, (t[19] - t[18]) * 0.01, (t[20] - t[19]) * 0.01, (t[21] - t[20]) * 0.01, (t[22] - t[21]) * 0.01);
@@ -554,7 +560,7 @@ struct Batch : BatchBase {
     h_ncam[b] = 0;
     HIPCHK(hipMemsetAsync(d.n_resid + b, 0, sizeof(long long), st));
     HIPCHK(hipMemsetAsync(d.stats + (size_t)b * STAT_STRIDE, 0, sizeof(int) * STAT_STRIDE, st));
-    HIPCHK(hipMemsetAsync(wl_n + b, 0, sizeof(int), st));
+    HIPCHK(hipMemsetAsync(wl_i + (size_t)b * wl_ib, 0, sizeof(int), st));
     HIPCHK(hipStreamSynchronize(st));
     HostTraj& t = traj[b];
     t = HostTraj();
@@ -609,12 +615,12 @@ struct Batch : BatchBase {
   // ONE k_propagate launch when anything else touches the device (DEVICE_ENTER at the head of every other entry).  Ten calls per
   // image were ten pinned-memory copies and ten launches (~6 us of host time each) for the same device-side result.
   std::vector<double> pend_rd; int pend_b = -1;
-  int flush_pending() {
+  int flush_pending(bool then_augment = false) {
     if (pend_b < 0) return 0;
     const int b = pend_b; pend_b = -1;
     std::vector<double> rd; rd.swap(pend_rd);
     HIPCHK(hipSetDevice(device));
-    return propagate_device(b, 1, rd.data(), (int)(rd.size() / RD_STRIDE));
+    return propagate_device(b, 1, rd.data(), (int)(rd.size() / RD_STRIDE), then_augment);
   }
   int propagate(int b0, int nb, const double* rd, int K, bool mirror) override {
     POISON_GUARD();
@@ -630,7 +636,8 @@ struct Batch : BatchBase {
     DEVICE_ENTER();
     return propagate_device(b0, nb, rd, K);
   }
-  int propagate_device(int b0, int nb, const double* rd, int K) {
+  // then_augment: augmentState follows for the same trajectories -- k_propagate's fused variant on the last chunk (as run_frames)
+  int propagate_device(int b0, int nb, const double* rd, int K, bool then_augment = false) {
     for (int k0 = 0; k0 < K; k0 += rd_cap) {
       const int kk = std::min(rd_cap, K - k0);
       const size_t cnt = (size_t)nb * kk * RD_STRIDE;
@@ -644,7 +651,7 @@ struct Batch : BatchBase {
       HIPCHK(hipMemcpyAsync(d_rd, tmp, cnt * sizeof(S), hipMemcpyHostToDevice, st));
       rc = stage_release();
       if (rc) return rc;
-      launch_propagate<S>(d, b0, nb, d_rd, (long)kk * RD_STRIDE, kk, st);
+      launch_propagate<S>(d, b0, nb, d_rd, (long)kk * RD_STRIDE, kk, st, then_augment && k0 + kk >= K);
       HIPCHK(hipGetLastError());
     }
     return 0;
@@ -652,8 +659,14 @@ struct Batch : BatchBase {
   int augment(int b0, int nb) override {
     POISON_GUARD();
     if (chk_range(b0, nb)) return fail(-EINVAL, "trajectory range out of bounds");
-    DEVICE_ENTER();
-    launch_augment<S>(d, b0, nb, st);
+    HIPCHK(hipSetDevice(device));
+    if (pend_b >= 0 && pend_b == b0 && nb == 1 && !pend_rd.empty()) {     // the image's IMU samples are still here: one launch for both
+      const int rc = flush_pending(true);
+      if (rc) return rc;
+    } else {
+      DEVICE_ENTER();
+      launch_augment<S>(d, b0, nb, st);
+    }
     for (int b = b0; b < b0 + nb; ++b) if (h_ncam[b] < n_cap) h_ncam[b]++;
     HIPCHK(hipGetLastError());
     return 0;
@@ -664,16 +677,16 @@ struct Batch : BatchBase {
     DEVICE_ENTER();
     for (int t = 0; t < F; ++t) if (M[t] > m_cap || M[t] < 0) return fail(-E2BIG, "track longer than m_cap");
     { size_t o = 0; for (int t = 0; t < F; ++t) { if (repeated_slot(slots + o, M[t])) return fail(-EINVAL, "camera slot repeated within a track"); o += M[t]; } }
-    // only the F rows in use travel: [F] lengths, [F][m_cap] slots, [F][m_cap][2] coordinates, one pinned block
-    const size_t nM = (size_t)F, nS = (size_t)F * m_cap, nO = (size_t)F * m_cap * 2;
-    const size_t offS = ((nM * sizeof(int) + 15) / 16) * 16, offO = offS + ((nS * sizeof(int) + 15) / 16) * 16;
+    // only the F rows in use travel, as the device holds them: [n, 0, 0, 0 | M[f4] | F rows of slots] in one copy, F rows of
+    // coordinates in a second one, both out of one pinned block
+    const size_t nI = 4 + (size_t)wl_f4 + (size_t)F * m_cap, nO = (size_t)F * m_cap * 2;
+    const size_t offO = ((nI * sizeof(int) + 15) / 16) * 16;
     unsigned char* raw = nullptr;
-    int rc = stage_acquire(offO + nO * sizeof(S) + sizeof(int), &raw);
+    int rc = stage_acquire(offO + nO * sizeof(S) + 16, &raw);
     if (rc) return rc;
-    int* hM = reinterpret_cast<int*>(raw); int* hS = reinterpret_cast<int*>(raw + offS); S* hO = reinterpret_cast<S*>(raw + offO);
-    int* hF = reinterpret_cast<int*>(raw + offO + nO * sizeof(S));
+    int* hI = reinterpret_cast<int*>(raw); int* hM = hI + 4; int* hS = hI + 4 + wl_f4; S* hO = reinterpret_cast<S*>(raw + offO);
     std::memset(raw, 0, offO + nO * sizeof(S));
-    *hF = F;
+    hI[0] = F;
     size_t o = 0;
     for (int t = 0; t < F; ++t) {
       hM[t] = M[t];
@@ -685,12 +698,8 @@ struct Batch : BatchBase {
       }
       o += M[t];
     }
-    HIPCHK(hipMemcpyAsync(wl_n + b, hF, sizeof(int), hipMemcpyHostToDevice, st));
-    if (F) {
-      HIPCHK(hipMemcpyAsync(wl_M + (size_t)b * f_cap, hM, nM * sizeof(int), hipMemcpyHostToDevice, st));
-      HIPCHK(hipMemcpyAsync(wl_slots + (size_t)b * f_cap * m_cap, hS, nS * sizeof(int), hipMemcpyHostToDevice, st));
-      HIPCHK(hipMemcpyAsync(wl_obs + (size_t)b * f_cap * m_cap * 2, hO, nO * sizeof(S), hipMemcpyHostToDevice, st));
-    }
+    HIPCHK(hipMemcpyAsync(wl_i + (size_t)b * wl_ib, hI, (F ? nI : 4) * sizeof(int), hipMemcpyHostToDevice, st));
+    if (F) HIPCHK(hipMemcpyAsync(wl_obs + (size_t)b * wl_ib * 2, hO, nO * sizeof(S), hipMemcpyHostToDevice, st));
     rc = stage_release();
     if (rc) return rc;
     traj[b].wl_F = F;
@@ -797,9 +806,17 @@ struct Batch : BatchBase {
     POISON_GUARD();
     DEVICE_ENTER();
     const int nk = (int)keep.size();
-    if (nk) HIPCHK(hipMemcpyAsync(d.keep + (size_t)b * n_cap, keep.data(), nk * sizeof(int), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d.nkeep + b, &nk, sizeof(int), hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));
+    // the list goes through the pinned ring like every other input: no wait for the stream in the middle of the image's chain
+    // (the update before it, k_prune and the state read after it are one uninterrupted queue)
+    unsigned char* raw = nullptr;
+    int rc = stage_acquire(((size_t)nk + 1) * sizeof(int), &raw);
+    if (rc) return rc;
+    int* hk = reinterpret_cast<int*>(raw);
+    hk[0] = nk; for (int i = 0; i < nk; ++i) hk[1 + i] = keep[i];
+    if (nk) HIPCHK(hipMemcpyAsync(d.keep + (size_t)b * n_cap, hk + 1, nk * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d.nkeep + b, hk, sizeof(int), hipMemcpyHostToDevice, st));
+    rc = stage_release();
+    if (rc) return rc;
     launch_prune<S>(d, b, 1, st);
     h_ncam[b] = nk;
     HIPCHK(hipGetLastError());
@@ -857,12 +874,12 @@ struct Batch : BatchBase {
     POISON_GUARD();
     if (chk(b) || n < 0 || n > n_cap) return fail(-EINVAL, "index out of range");
     DEVICE_ENTER();
-    std::vector<S> tmp((size_t)std::max(n, 1) * CAM_STRIDE);
-    if (n) HIPCHK(hipMemcpyAsync(tmp.data(), d.cam + (size_t)b * n_cap * CAM_STRIDE, (size_t)n * CAM_STRIDE * sizeof(S), hipMemcpyDeviceToHost, st));
+    S* tmp = h_rb; S* tim = h_rb + (size_t)n_cap * CAM_STRIDE;        // (page-locked: a pageable destination goes through the runtime's own staging copy)
+    if (n) HIPCHK(hipMemcpyAsync(tmp, d.cam + (size_t)b * n_cap * CAM_STRIDE, (size_t)n * CAM_STRIDE * sizeof(S), hipMemcpyDeviceToHost, st));
     const bool want_imu = !h_imu_ok[b];
-    if (want_imu) HIPCHK(hipMemcpyAsync(h_imu.data() + (size_t)b * IMU_STRIDE, d.imu + (size_t)b * IMU_STRIDE, IMU_STRIDE * sizeof(S), hipMemcpyDeviceToHost, st));
+    if (want_imu) HIPCHK(hipMemcpyAsync(tim, d.imu + (size_t)b * IMU_STRIDE, IMU_STRIDE * sizeof(S), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (want_imu) h_imu_ok[b] = 1;
+    if (want_imu) { std::copy(tim, tim + IMU_STRIDE, h_imu.begin() + (size_t)b * IMU_STRIDE); h_imu_ok[b] = 1; }
     for (int i = 0; i < n; ++i) for (int k = 0; k < 7; ++k) o[7 * i + k] = (double)tmp[(size_t)i * CAM_STRIDE + k];
     return 0;
   }
