@@ -982,6 +982,20 @@ LIT_FN void explicit_row_products(const Ctx& c, const Args<HT>& a, int e, int n,
 
 // One step of the sweep's per-column bookkeeping, shared by the three forms of the sweep
 
+
+// 4 x 4 tiles of the lower triangle of an N x N index space, a thread per tile: f(i0, j0), i0 >= j0 multiples of four.  Where an
+// entry is a short inner product of two staged vectors, a tile reads 8 vectors for 16 entries instead of 32 -- the entry-wise
+// passes over the basis products and the Gram start were bound by their LDS reads (60 / 30 doubles per entry)
+template <class F> LIT_FN void par_tiles_lower4(const Ctx& c, int N, F f) {
+  const int nt = (N + 3) / 4;
+  par_for(c, (long)nt * (nt + 1) / 2, [&](long el) {
+    const int e = (int)el;
+    int ti = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > e) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= e) ++ti;
+    f(4 * ti, 4 * (e - ti * (ti + 1) / 2));
+  });
+}
 // C(i, j) = sum_(klo(i) <= k < khi(j0)) fa(i, k) fb(k, j), i < M, j < N: a thread per (i, four consecutive j = j0 .. j0 + 3), i fastest
 // (fa coalesced over i, fb the same address in every lane of an i-run), four k in flight -- the plain loop per element waits
 // out a memory round trip per term (Gram of the start x column operations of a 160-step prefix: 0.6 ms)
@@ -1598,6 +1612,40 @@ LIT_FN void compact_rows(const Ctx& c, const Args<HT>& a, const int m) {
   // ---- Gh = [H_o | r_o]^T [H_o | r_o] minus the first 15 rows (lower triangle; the corner (n, n) is never a pivot), kept a
   // second time (G0s) for the basis products; the first 15 rows staged [column][16]
   stage15();
+  const int ldt = (n1 + 7) & ~3;                   // the same rows [l][column] for the tiles (four columns: one 32-byte read; zero beyond n1)
+  if (33L * n1 + 15L * ldt <= c.lds_doubles) {
+    double* sEt = sU + 16L * n1;
+    par_for32(c, 15 * ldt, [&](int x) { const int l = x / ldt, j = x - l * ldt; sEt[x] = (l < e15 && j < n1) ? E0[l + ec * j] : 0.0; });
+    barrier(c);
+    par_tiles_lower4(c, n1, [&](int i0, int j0) {
+      double acc[4][4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[p][q] = 0.0;
+#pragma unroll 1
+      for (int l = 0; l < 15; ++l) {               // (unrolled, the compiler requests all 15 rows' vectors at once: 580 B of scratch per lane)
+        const double* r = sEt + l * ldt;
+        double ei[4], ej[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { ei[p] = r[i0 + p]; ej[p] = r[j0 + p]; }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[p][q] += ei[p] * ej[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int hi = i0 + p, lo = j0 + q;
+          if (hi >= n1 || lo > hi) continue;
+          const double v = (hi == n && lo == n) ? 0.0 : lam_in(a, hi, lo) - acc[p][q];
+          G0s[hi + (long)n1 * lo] = v;
+          if (gram) Gh[hi + (long)n1 * lo] = v;
+        }
+    });
+  } else
   par_map4(c, n1 * n1, [&](int x) -> double {
     const int lo = x / n1, hi = x - lo * n1;
     if (hi < lo || (hi == n && lo == n)) return 0.0;
@@ -1758,7 +1806,19 @@ LIT_FN void compact_basis(const Ctx& c, const Args<HT>& a, const int m) {
     barrier(c);
     tick(c, 7);
     const int nab = na + nb;
-    par_map4(c, nab * nab, [&](int x) -> double {
+    const int ldb = (nb + 7) & ~3;                  // the staged rows of the basis' columns, gathered, [l][k] (zero beyond nb)
+    const bool tiles = 33L * n1 + 104 + 30L * ldb <= c.lds_doubles;
+    double* sEg = sU + 16L * n1 + 104; double* sUg = sEg + 15L * ldb;
+    if (tiles) {
+      par_for32(c, 15 * ldb, [&](int x) {
+        const int l = x / ldb, k = x - l * ldb;
+        const int cc = k < nb ? sB[na + k] : 0;
+        sEg[x] = k < nb ? sE[16 * cc + l] : 0.0; sUg[x] = k < nb ? sU[16 * cc + l] : 0.0;
+      });
+      barrier(c);
+    }
+    // entries with an e_i in them -- and all of them when the staging area has no room for the tiles' copy
+    par_map4(c, tiles ? nab * na : nab * nab, [&](int x) -> double {
       const int kb = x / nab, ka = x - kb * nab;
       if (ka < kb) return 0.0;
       double val;
@@ -1786,6 +1846,34 @@ LIT_FN void compact_basis(const Ctx& c, const Args<HT>& a, const int m) {
     }, [&](int x, double val) {
       const int kb = x / nab, ka = x - kb * nab;
       if (ka >= kb) a.Z[ka + ldz * kb] = val;
+    });
+    // (x'_c, x'_c'), c >= c': v' G^0(c, c') + (u' - v') (Gam(c, c') + sum_l E(l, c) U~(l, c') + U~(l, c) E(l, c'))
+    if (tiles) par_tiles_lower4(c, nb, [&](int i0, int j0) {
+      double acc[4][4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[p][q] = 0.0;
+#pragma unroll 1
+      for (int l = 0; l < 15; ++l) {
+        const double* er = sEg + l * ldb; const double* ur = sUg + l * ldb;
+        double ei[4], ui[4], ej[4], uj[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { ei[p] = er[i0 + p]; ui[p] = ur[i0 + p]; ej[p] = er[j0 + p]; uj[p] = ur[j0 + p]; }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[p][q] += ei[p] * uj[q] + ui[p] * ej[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int ka = i0 + p, kb = j0 + q;
+          if (ka >= nb || kb > ka) continue;
+          const int cc = sB[na + ka], c2 = sB[na + kb];
+          a.Z[(na + ka) + ldz * (na + kb)] = a.v_var * G0s[cc + (long)n1 * c2] + dlt * (a.Gam[(long)cc * a.ldGam + c2] + acc[p][q]);
+        }
     });
     barrier(c);
     tick(c, 23);
