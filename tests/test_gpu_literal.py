@@ -186,6 +186,57 @@ def test_literal_route_cfg3_window_float(capi, po):
     bt.close()
 
 
+def _frame_without_slot(fr, slot):
+    """the frame's work-list without its observations in one camera slot (tracks left with fewer than three leave the list)"""
+    M, sl, ob = [], [], []
+    o = 0
+    for m in fr["M"]:
+        keep = [o + i for i in range(int(m)) if fr["slots"][o + i] != slot]
+        o += int(m)
+        if len(keep) >= 3:
+            M.append(len(keep)); sl.extend(int(fr["slots"][i]) for i in keep); ob.extend(fr["obs"][i] for i in keep)
+    out = dict(fr)
+    out["M"] = np.array(M, dtype=fr["M"].dtype); out["slots"] = np.array(sl, dtype=fr["slots"].dtype); out["obs"] = np.array(ob, dtype=fr["obs"].dtype).reshape(-1, 2)
+    return out
+
+
+@pytest.mark.parametrize("slot,double", [(20, False), (6, False), (20, True)])
+def test_literal_route_handed_through_rows_deep_in_the_sweep(capi, po, slot, double):
+    """A camera state that none of the update's tracks observes: six zero columns 6 x slot steps into the sweep, whose rows are
+    handed through and kept -- the part of the compact route that builds columns of Q (literal_core.h: blocked column
+    operations, par_gemm4, the register-resident reflector chain, extras_products; the host build of the same code is held
+    against the dense sweep in tests/test_literal_core.py).  30-camera window, 200 tracks, teacher-forced, against the
+    restatement: float at 1e-3 like test_literal_route_cfg3_window_float, double at 1e-6."""
+    N, F, nf = 30, 200, 33
+    tr = _aniso(N, F, nf, 0, cfgid=3)
+    prec, dprec, tol, bar = (po.F64, capi.F64, 1e-10, 1e-6) if double else (po.F32, capi.F32, 8e-4, 1e-3)
+    fast = po.Oracle(prec, po.GRAM); fast.setWhiten(True); fast.initialize(tr.cfg, tr.imu0)
+    bt = capi.Batch(1, N, F, 32, dprec); bt.initialize(0, tr.cfg, tr.imu0)
+    for k in range(nf - 2):
+        H.oracle_frame(fast, tr, k, N)
+    o = po.Oracle(prec, po.LEAN); o.setTinyRowTol(tol); o.initialize(tr.cfg, tr.imu0)
+    while o.getNumCamStates() < fast.getNumCamStates():
+        o.augmentState(o.getNumCamStates(), 0.0)
+    _force(o, fast)
+    for _ in range(fast.getNumCamStates()):
+        bt.augment_range(0, 1)
+    n = 0
+    for k in range(nf - 2, nf):
+        tr.frames[k] = _frame_without_slot(tr.frames[k], slot)
+        H.copy_oracle_to_device(o, bt, 0)
+        H.oracle_frame(o, tr, k, N); H.device_frame(bt, 0, tr, k, N)
+        if o.lastStats()["n_motion_rejected"]:
+            continue
+        e = _errs(bt, 0, o)
+        assert H.worst(e) < bar, (k, e)
+        info = bt.literal_info(0)
+        assert info["m_rows"] == o.lastStats()["m_rows"] > 4000 and abs(info["kept_rows"] - o.lastStats()["r_rows"]) <= (0 if double else 2) and info["route"] == 3
+        assert info["kept_handed_through_rows"] >= 6, info
+        n += 1
+    assert n >= 1
+    bt.close()
+
+
 def test_literal_route_inside_run_frames_equals_the_single_call_path(capi, po):
     """the resident-scenario path (compact work-lists, slices, prune on the downdate) runs the same literal compression: same
     bits as frame-by-frame calls"""
