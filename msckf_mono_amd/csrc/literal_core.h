@@ -1210,6 +1210,70 @@ LIT_FN void extras_products(const Ctx& c, const Args<HT>& a, int e, int n, long 
   }
 }
 
+
+#ifndef LIT_HOST
+// The 16 x 16 core of the sweep's panels on ONE wavefront with the block in REGISTERS: lane j < 16 holds column j of the panel's
+// rows and of its Gram block (sixteen entries each), a pivot's values reach the other lanes by v_readlane -- no LDS round trip
+// and no wave_sync between the pivots (the LDS form: ~1 800 cycles a pivot, three hand-overs through LDS each; this one ~1 000,
+// the rsqrt / rcp chain and thirty broadcasts).  Same arithmetic, entry by entry, as the loop it replaces (sweep_gram_blocked
+// keeps that one for the host build and for panels narrower than sixteen).  Not inlined: inside the phase kernel its 64
+// registers of block pushed the panel loops' addresses into scratch memory.  (The elimination's diagonal block the same
+// way: no gain -- that routine's panels are bound by their staging and trailing passes -- and left as it was.)
+// C(j, r) = sEC[j * lde + r], G(r, j) = sG[r * 16 + j] (both triangles); results back where the loop leaves them
+__device__ __attribute__((noinline)) void sweep_core_regs(const Ctx& c, double* sEC, long lde, double* sG, double* sS, double* sDn, double* sBi, double* sTau, double* sRf, double* sCnt, const double* sLd, int pb, double t2) {
+  const int j = c.lane & 15;
+  const bool mine = c.lane < 16 && j < pb;
+  double Cc[16], Gc[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { Cc[r] = (mine && r < pb) ? sEC[j * lde + r] : 0.0; Gc[r] = (mine && r < pb) ? sG[r * 16 + j] : 0.0; }
+  const double ldj = mine ? sLd[j] : 0.0;
+  int nref = 0, nskt = 0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    if (q < pb) {
+      const double c0 = wave_bcast(Cc[q], q), gq0 = wave_bcast(Gc[q], q), ldq = wave_bcast(ldj, q);
+      const double gq = gq0 > 0.0 ? gq0 : 0.0;
+      double tail2 = gq - c0 * c0; tail2 = tail2 > 0.0 ? tail2 : 0.0;
+      double zero2 = t2 * ldq; zero2 = zero2 > 2.2250738585072014e-308 ? zero2 : 2.2250738585072014e-308;
+      const bool reflect = tail2 > zero2;
+      double sq = 0.0;
+      if (reflect) {
+        ++nref;
+        const double g2 = c0 * c0 + tail2, rs = lit_rsqrt(g2);
+        const double binv = c0 >= 0.0 ? -rs : rs, beta = g2 * binv;
+        const double dn = lit_rcp(c0 - beta);
+        if (c.lane == 0) { sDn[q] = dn; sBi[q] = binv; sTau[q] = (beta - c0) * binv; sRf[q] = 1.0; }
+        if (mine && j >= q) { const double rr = j == q ? beta : Gc[q] * binv; sq = Cc[q] - rr; Cc[q] = rr; }
+        if (c.lane == q) {
+#pragma unroll
+          for (int r = q + 1; r < 16; ++r) Cc[r] *= dn;
+        }
+      } else {
+        if (tail2 > 2.2250738585072014e-308) ++nskt;
+        if (c.lane == 0) { sDn[q] = 0.0; sBi[q] = 0.0; sTau[q] = 0.0; sRf[q] = 0.0; }
+        if (c.lane == q) {
+#pragma unroll
+          for (int r = q + 1; r < 16; ++r) Cc[r] = 0.0;
+        }
+      }
+      if (mine && j >= q) sS[q * 16 + j] = sq;
+      const double rown = Cc[q];                     // R(p0 + q, k0 + j): row q of this lane's column, final from here on
+#pragma unroll
+      for (int r = q + 1; r < 16; ++r) {
+        const double vr = wave_bcast(Cc[r], q);      // column q, row r (the reflector's entry, 0 when the step was skipped)
+        const double rr = wave_bcast(rown, r);       // row q of column r
+        if (j > q) { Cc[r] -= vr * sq; Gc[r] -= rr * rown; }
+      }
+    }
+  }
+  if (mine) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) if (r < pb) { sEC[j * lde + r] = Cc[r]; sG[r * 16 + j] = Gc[r]; }
+  }
+  if (c.lane == 0) { sCnt[0] = (double)nref; sCnt[1] = (double)nskt; }
+}
+#endif
+
 struct SweepOut { int n_reflect, n_skip_tol; };
 
 // ---- the sweep when rows exist below the explicit ones, step by step (the definition of the blocked form; runs when the
@@ -1315,6 +1379,10 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
     barrier(c);
     tick_acc(c, 12, tprev);
     // ---- core: the panel's columns against each other, one wavefront
+#ifndef LIT_HOST
+    if (PB == 16) { if (first_wave(c)) sweep_core_regs(c, sEC, lde, sG, sS, sDn, sBi, sTau, sRf, sCnt, sLd, pb, t2); }
+    else
+#endif
     if (first_wave(c)) {
       int nref = 0, nskt = 0;
       for (int q = 0; q < pb; ++q) {
