@@ -590,6 +590,35 @@ LIT_FN void information_from_rn(const Ctx& c, const Args<HT>& a, int n, int nr, 
       // trailing triangle: columns j >= k0 + pb, rows i >= j: Z(i, j) -= sum_q L(i, q) L(j, q) / d_q; tiles numbered down the
       // tile columns (consecutive threads: consecutive rows of the column-major Z)
       const int j0 = k0 + pb, mt = nz - j0, tt = (mt + 3) / 4, ntile = tt * (tt + 1) / 2;
+#ifndef LIT_HOST
+      // ... on the f64 matrix cores where the panel is full: a 16 x 16 block of the triangle per wavefront and step, its two
+      // operands straight out of the staged panel ([pivot][row]: the MFMA's k along the pivots) -- two LDS reads per lane and
+      // k-step instead of the tiles' eight per entry and panel (the tile pass was bound by them and by its global round trip)
+      if (pb == 16) {
+        const int tb = (mt + 15) / 16, nblk = tb * (tb + 1) / 2;
+        const int lr = c.lane & 15, lk = c.lane >> 4;
+        const double* below = sP + pb;                  // below[q * ldr + i]: Z(j0 + i, k0 + q)
+        for (int t = c.wave; t < nblk; t += c.nw) {
+          const double w2 = 2.0 * tb + 1.0;
+          int bj = (int)((w2 - sqrt(w2 * w2 - 8.0 * t)) * 0.5);
+          while (bj > 0 && bj * tb - bj * (bj - 1) / 2 > t) --bj;
+          while ((bj + 1) * tb - (bj + 1) * bj / 2 <= t) ++bj;
+          const int bi = bj + (t - (bj * tb - bj * (bj - 1) / 2));
+          const int ii = 16 * bi + lr;                  // row of Z (the B operand's index, the result's column index)
+          double old[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const int jj = 16 * bj + lk + 4 * r; old[r] = (ii < mt && jj <= ii) ? Z[(j0 + ii) + ldz * (j0 + jj)] : 0.0; }
+          lit_v4d acc = lit_v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const int q = 4 * kk + lk;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(below[q * ldr + 16 * bj + lr] * sD[q], below[q * ldr + ii], acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const int jj = 16 * bj + lk + 4 * r; if (ii < mt && jj <= ii) Z[(j0 + ii) + ldz * (j0 + jj)] = old[r] - acc[r]; }
+        }
+      } else
+#endif
       par_for32(c, ntile, [&](int t) {
         const double w2 = 2.0 * tt + 1.0;
         int bj = (int)((w2 - sqrt(w2 * w2 - 8.0 * t)) * 0.5);
@@ -1441,6 +1470,42 @@ LIT_FN SweepOut sweep_gram_blocked(const Ctx& c, const Args<HT>& a, int e, int n
     par_for32(c, pb * pb, [&](int x) { const int q = x / pb, q2 = x - q * pb; if (q2 > q) Ac[(k0 + q2) + (long)n1 * (k0 + q)] = sS[q * PB + q2] * sDn[q]; });
     {
       const int ni = nrow - pb, ti = (ni + 3) / 4, tj = (ntr + 3) / 4, ntE = ti * tj, ntG = tj * (tj + 1) / 2;
+#ifndef LIT_HOST
+      // ... on the f64 matrix cores where the panel is full (as the elimination's trailing pass, information_from_rn): 16 x 16
+      // blocks per wavefront, operands straight out of the staged panel -- [step][row] and [step][column] are the MFMA's k-major
+      // layouts as they stand; the result's contiguous index (the row of E, the row of Gh) rides on the B operand
+      if (pb == 16) {
+        const int bE = (ni + 15) / 16, bT = (ntr + 15) / 16, nbE = bE * bT, nbG = bT * (bT + 1) / 2;
+        const int lr = c.lane & 15, lk = c.lane >> 4;
+        for (int t = c.wave; t < nbE + nbG; t += c.nw) {
+          const bool isE = t < nbE;
+          int bi, bj;
+          if (isE) { bj = t / bE; bi = t - bj * bE; }
+          else {
+            const int tg = t - nbE;
+            const double w2 = 2.0 * bT + 1.0;
+            bj = (int)((w2 - sqrt(w2 * w2 - 8.0 * tg)) * 0.5);
+            while (bj > 0 && bj * bT - bj * (bj - 1) / 2 > tg) --bj;
+            while ((bj + 1) * bT - (bj + 1) * bj / 2 <= tg) ++bj;
+            bi = bj + (tg - (bj * bT - bj * (bj - 1) / 2));
+          }
+          const int ii = 16 * bi + lr, ilim = isE ? ni : ntr;
+          double* dst = isE ? E + (p0 + pb + ii) + ec * (k0 + pb) : Gh + (k0 + pb + ii) + (long)n1 * (k0 + pb);
+          const long ldd = isE ? ec : (long)n1;
+          double old[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const int jj = 16 * bj + lk + 4 * r; old[r] = (ii < ilim && jj < ntr && (isE || jj <= ii)) ? dst[ldd * jj] : 0.0; }
+          const double* pa = isE ? sEP + 16 * bj + lr : sGP + 16 * bj + lr;           // A: the result's column index (the step's s / R entries)
+          const double* pb_ = isE ? sEC + pb + ii : sGP + ii;                       // B: the result's row index
+          const long sa = n1, sb = isE ? lde : (long)n1;
+          lit_v4d acc = lit_v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) { const int q = 4 * kk + lk; acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[sa * q], pb_[sb * q], acc, 0, 0, 0); }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const int jj = 16 * bj + lk + 4 * r; if (ii < ilim && jj < ntr && (isE || jj <= ii)) dst[ldd * jj] = old[r] - acc[r]; }
+        }
+      } else
+#endif
       par_for32(c, ntE + ntG, [&](int x) {
         double acc[16];
 #pragma unroll
