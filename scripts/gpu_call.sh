@@ -5,7 +5,9 @@
 #   pytest:<args> pytest with the given arguments (one token: use commas for spaces)
 #   smoke        __graft_entry__.smoke()
 #   bench        default bench.py (cfg3, the driver's line)     cfgs        cfg2, cfg4 (literal + whitened), cfg5 as their own lines
-#   cfg4         bench.py --config cfg4 (literal route) only    lit_timers  phase timers of k_literal at B = 8 and 128 (cfg4 geometry)
+#   cfg4         bench.py --config cfg4 (literal route) only    lit_timers  phase timers of k_literal at B = 8 and 128 (cfg4 geometry), the
+#                previous library (msckf_mono_amd/lib_ab/libmsckf_hip_prev.so, when there) first; with lit_timers_all also per frame the
+#                slowest trajectory of every phase and the step timers of every trajectory with kept handed-through rows
 #   sweep        scripts/sweep_variants.py (streams / streamed) profile     scripts/profile_round.sh (kernel stats + PMC passes of cfg3)
 #   lit_profile  rocprofv3 kernel stats + PMC passes of bench.py --config cfg4 (literal route)    lit_stats  the kernel stats alone (all launches + last six)
 #   cfg2_profile rocprofv3 kernel stats of bench.py --config cfg2

@@ -1,6 +1,7 @@
 """Phase timers of k_literal (MSCKF_HIP_LITERAL_TIMERS=1) at BASELINE configs[3]'s geometry (30-camera window, 200 tracks,
 anisotropic noise): wall time of single frames of a resident scenario at 8 and 128 trajectories, the phase table of two
-trajectories on stderr."""
+trajectories on stderr.  --all: 24 more frames at 128 trajectories, per frame the slowest trajectory of phase 2 (a launch lasts
+as long as its slowest workgroup) and the step timers of every trajectory that has kept handed-through rows."""
 import sys
 import time
 
