@@ -96,6 +96,7 @@ struct Dev {
   int ncam_bias; int* ncam_upd;
   int* nres_upd;   // [B] n_resid at the start of the update in flight (k_feature -> k_select_diag)
   int gate_early;   // exact early accept of the chi-square gate by the bound |r_o|^2 / sigma^2 (k_feature), off by default
+  int feat_pair;    // float filters, information form: k_feature_pair (two tracks per wavefront) instead of k_feature; MSCKF_HIP_FEATURE_PAIR=0 for A/B runs
   // per-track products of k_feature
   int* trk_status; S* trk_pf; S* trk_gamma; S* trk_Hx; S* trk_V; S* trk_Zf; S* trk_ro; int* trk_first;
   // dtype MSCKF_HIP_F16H_F32P (BASELINE.json configs[4]: fp16 Jacobian / fp32 covariance): the 2 x 6 measurement Jacobian

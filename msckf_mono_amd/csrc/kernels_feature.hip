@@ -177,7 +177,7 @@ __device__ __forceinline__ bool gate_chol(const S* sG, S* sC, int lane, int R2, 
     const int kk_hi = min(8, R2 - 8 * kb);
     for (int kk = 0; kk < kk_hi; ++kk) {
       const S dkk = wave_bcast(A[kb][kb], kk * 9);
-      if (!(dkk > S(0))) { spd = false; break; }
+      spd = spd && dkk > S(0);                        // (no early exit: a non-positive pivot only poisons entries nobody reads; the caller drops the result)
       // L is never needed itself: the update is A(i, j) -= A(i, k) A(j, k) / d -- one reciprocal (hardware seed; double:
       // + Newton) and one scaled operand instead of rsqrt + Newton and two scaled operands
       const S dinv2 = sizeof(S) == 4 ? (S)__builtin_amdgcn_rcpf((float)dkk) : fast_rcp(dkk);
@@ -187,8 +187,9 @@ __device__ __forceinline__ bool gate_chol(const S* sG, S* sC, int lane, int R2, 
       for (int a2 = kb; a2 < NB; ++a2) li[a2] = lane_gather(A[a2][kb], src_i);
 #pragma unroll
       for (int b2 = kb; b2 < NB; ++b2) lj[b2] = lane_gather(A[b2][kb], src_j);
-      li[kb] = tx > kk ? li[kb] : S(0);
-      lj[kb] = ty > kk ? lj[kb] : S(0);
+      // No masks on the diagonal block's multipliers: a lane with tx <= kk or ty <= kk holds an entry of a row or column that is
+      // finished (or of the block's unused upper triangle) -- nothing reads those again, live entries (row, column > k) only
+      // ever meet multipliers of live rows (kernels_chol.hip's diagonal block dropped its masks the same way)
 #pragma unroll
       for (int a2 = kb; a2 < NB; ++a2) li[a2] *= dinv2;
 #pragma unroll
@@ -196,7 +197,6 @@ __device__ __forceinline__ bool gate_chol(const S* sG, S* sC, int lane, int R2, 
 #pragma unroll
         for (int b2 = kb; b2 <= a2; ++b2) A[a2][b2] -= li[a2] * lj[b2];
     }
-    if (!spd) break;
   }
   __syncthreads();
   // the 4 x 4 corner (rows / columns 2M .. 2M+3) sits in the last two block rows / columns in use; NB may exceed the blocks
@@ -248,6 +248,80 @@ __device__ __forceinline__ S gate_gamma_from_corner(const S* c) {
     } else if (c22 > tol) g -= b2 * b2 / c22;
   }
   return g > S(0) ? g : S(0);
+}
+
+// gate_chol for float filters and at most 8 x 8 blocks, with HALF the LDS-crossbar traffic.  The crossbar (ds_bpermute: ~4 LDS
+// cycles per wavefront instruction, ONE crossbar per compute unit for its sixteen wavefronts) is what bounds gate_chol: 2 (NB - kb)
+// exchanges per pivot, 3.5 M per launch of the benchmark = 23 us of the compute units' LDS time.  Here the lane grid is laid out
+// the other way round -- lane = 8 tx + ty, element (8 a + tx, 8 b + ty) -- so that the pivot column's entry of a lane's ROW sits in
+// the lane's own group of 8 (position kk): the row-side multiplier is a DPP broadcast inside the group (quad broadcast + one
+// masked row shift, vector ALU only; kk is a template parameter because DPP controls are immediates), and only the column-side
+// multiplier L(8 b + ty, k), which lives in lane 8 ty + kk, still crosses the LDS crossbar.  Same arithmetic, same masks-free
+// updates as gate_chol.  The packed triangle is read with consecutive lanes on consecutive words.
+template <int KK> __device__ __forceinline__ float grp8_bcast_scaled(float v, float s) {
+  constexpr int q = KK & 3, QP = q | (q << 2) | (q << 4) | (q << 6);
+  const int t = __float_as_int(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), QP, 0xF, 0xF, true)) * s);   // every quad: its lane q, scaled (one v_mul_f32_dpp)
+  // the group's other quad takes it over: lanes 4..7 of a group from 0..3 (row_shr:4, banks 1 and 3) or 0..3 from 4..7 (row_shl:4, banks 0 and 2)
+  return __int_as_float(KK < 4 ? __builtin_amdgcn_update_dpp(t, t, 0x114, 0xF, 0xA, false) : __builtin_amdgcn_update_dpp(t, t, 0x104, 0xF, 0x5, false));
+}
+template <int NB, int KB, int KK>
+__device__ __forceinline__ void gate_pivot_dpp(float (&A)[NB][NB], bool& spd, const int srcj4) {
+  const float dkk = wave_bcast(A[KB][KB], KK * 9);
+  spd = spd && dkk > 0.0f;
+  const float dinv = __builtin_amdgcn_rcpf(dkk);
+  float li[NB], lj[NB];
+#pragma unroll
+  for (int b2 = KB; b2 < NB; ++b2) lj[b2] = lane_gather(A[b2][KB], srcj4 + 4 * KK);
+#pragma unroll
+  for (int a2 = KB; a2 < NB; ++a2) li[a2] = grp8_bcast_scaled<KK>(A[a2][KB], dinv);
+#pragma unroll
+  for (int a2 = KB; a2 < NB; ++a2)
+#pragma unroll
+    for (int b2 = KB; b2 <= a2; ++b2) A[a2][b2] -= li[a2] * lj[b2];
+}
+template <int NB, int KB>
+__device__ __forceinline__ void gate_block_dpp(float (&A)[NB][NB], bool& spd, const int srcj4, const int R2) {
+  const int kk_hi = R2 - 8 * KB;                       // pivots of this diagonal block (wave-uniform)
+  if (kk_hi > 0) gate_pivot_dpp<NB, KB, 0>(A, spd, srcj4);
+  if (kk_hi > 1) gate_pivot_dpp<NB, KB, 1>(A, spd, srcj4);
+  if (kk_hi > 2) gate_pivot_dpp<NB, KB, 2>(A, spd, srcj4);
+  if (kk_hi > 3) gate_pivot_dpp<NB, KB, 3>(A, spd, srcj4);
+  if (kk_hi > 4) gate_pivot_dpp<NB, KB, 4>(A, spd, srcj4);
+  if (kk_hi > 5) gate_pivot_dpp<NB, KB, 5>(A, spd, srcj4);
+  if (kk_hi > 6) gate_pivot_dpp<NB, KB, 6>(A, spd, srcj4);
+  if (kk_hi > 7) gate_pivot_dpp<NB, KB, 7>(A, spd, srcj4);
+  if constexpr (KB + 1 < NB) gate_block_dpp<NB, KB + 1>(A, spd, srcj4, R2);
+}
+template <int NB>
+__device__ __forceinline__ bool gate_chol_dpp(const float* sG, float* sC, int lane, int R2, float sig2) {
+  bool spd = true;
+  const int tx = lane >> 3, ty = lane & 7, nr = R2 + 4;
+  float A[NB][NB];
+#pragma unroll
+  for (int a2 = 0; a2 < NB; ++a2) {
+    const int i = 8 * a2 + tx, rb = TRI(i, 0);
+#pragma unroll
+    for (int b2 = 0; b2 <= a2; ++b2) {
+      const int j = 8 * b2 + ty;
+      float val = 0;
+      if (i < nr && j < nr && !(i >= R2 && j >= R2)) {
+        val = sG[a2 > b2 ? rb + j : SYM(i, j)];
+        if (i == j) val += sig2;
+      }
+      A[a2][b2] = val;
+    }
+  }
+  gate_block_dpp<NB, 0>(A, spd, ty << 5, R2);         // column-side source lane 8 ty + kk, as a byte index
+  __syncthreads();
+#pragma unroll
+  for (int a2 = (NB >= 3 ? NB - 3 : 0); a2 < NB; ++a2)
+#pragma unroll
+    for (int b2 = (NB >= 3 ? NB - 3 : 0); b2 <= a2; ++b2) {
+      const int qi = 8 * a2 + tx - R2, qj = 8 * b2 + ty - R2;
+      if (qi >= 0 && qi < 4 && qj >= 0 && qj <= qi) sC[qi * 4 + qj] = A[a2][b2];
+    }
+  __syncthreads();
+  return spd;
 }
 
 // LONG: tracks of more than 30 observations (2M + 4 > 64) keep the gate's Cholesky in registers too (up to 16 x 16 blocks
@@ -794,6 +868,537 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
   }
 }
 
+// ---------------------------------------------------------------- k_feature_pair: TWO tracks per wavefront
+// Float filters on the information-form route (the headline configuration; cfg5's tracks of up to 30 observations).
+// k_feature gives a track a whole wavefront with lane = observation: at the benchmark's track lengths (3 .. 29, 16 on
+// average) three lanes in four idle through triangulation, Jacobian and B^ -- the kernel is bound by VALU issue, and that
+// part is 58 % of its instructions.  Here a wavefront takes two tracks, one per half (lanes 0-31 / 32-63, lane = observation
+// within the half), and every reduction / broadcast of that part runs inside a half (DPP inside rows of 16 + one
+// v_permlane16_swap across the two rows; broadcasts through ds_bpermute), the Levenberg-Marquardt loops predicated per half.
+// Which two: the trajectory's tracks are ranked by length (counting sort redone by every wavefront from the 4 lengths a
+// lane loads: ~100 instructions) and wavefront w takes ranks w and n-1-w -- the shortest with the longest -- so that
+//   * every wavefront of the launch has the same amount of work (M_a + M_b ~ const: no tail of long-track wavefronts),
+//   * both gate matrices fit the LDS one long track needs (tri(2 M_a + 4) + tri(2 M_b + 4) <= S_cap; a pair that does not
+//     fit -- a frame of maximum-length tracks -- assembles and factors its two matrices one after the other in the same space).
+// The gate products G = H_x P_cc H_x^T of both tracks are enumerated together over the 64 lanes (pairs of observations),
+// the two Cholesky factorizations run one after the other on the full 8 x 8 lane grid (gate_chol, as in k_feature).
+// Same arithmetic per track as k_feature<float> (sums over a half instead of the wavefront: identical terms, the zeros
+// of the idle lanes fall elsewhere in the tree); decisions and gamma agree to rounding (tests/test_gpu_parity.py A/B).
+constexpr int GS = 32;   // lanes per track
+// LDS hand-over inside ONE wavefront (its LDS operations complete in order; the fences stop the compiler from moving reads above writes)
+__device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+#ifdef MSCKF_ABLATE
+// phase timers of the -DMSCKF_ABLATE build (scripts/feat_phases.py): shader-clock cycles per phase summed over ALL wavefronts
+// [0 pairing, 1 loads + checkMotion + first cost, 2 Levenberg-Marquardt, 3 Jacobian + B^ + publish, 4 G assembly, 5 factorizations, 6 tail, 7 wavefronts]
+__device__ unsigned long long g_featp_cycles[8];
+// g_feat_dbg & 0x100000: timers on (they cost: eight device-scope atomics per wavefront); g_feat_dbg & (0x400 << slot): the
+// wavefront returns after phase `slot` (timing of a truncated kernel: results are garbage)
+#define FP_TICK(slot) do { if ((fdbg & 0x100000) && lane == 0) { const long long t_ = clock64(); atomicAdd(&g_featp_cycles[slot], (unsigned long long)(t_ - tlast)); tlast = clock64(); } \
+                           if (fdbg & (0x400 << (slot))) return; } while (0)
+#else
+#define FP_TICK(slot) do { } while (0)
+#endif
+
+__device__ __forceinline__ float x16_sum(float v) {   // v[lane] + v[lane ^ 16]
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ double x16_sum(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)(b & 0xffffffffull), hi = (unsigned)(b >> 32);
+  const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double a = __longlong_as_double((long long)(((unsigned long long)rh[0] << 32) | rl[0]));
+  const double c = __longlong_as_double((long long)(((unsigned long long)rh[1] << 32) | rl[1]));
+  return a + c;
+}
+// sum over the lane's half of the wavefront; every lane of the half gets the same bits
+template <class T> __device__ __forceinline__ T half_sum(T v) {
+  v += dpp_x<DPP_QUAD_X1>(v); v += dpp_x<DPP_QUAD_X2>(v); v += dpp_x<DPP_HALF_MIRROR>(v); v += dpp_x<DPP_ROW_MIRROR>(v);
+  return x16_sum(v);
+}
+__device__ __forceinline__ float half_max(float v) {
+  float t;
+  t = dpp_x<DPP_QUAD_X1>(v); v = t > v ? t : v; t = dpp_x<DPP_QUAD_X2>(v); v = t > v ? t : v;
+  t = dpp_x<DPP_HALF_MIRROR>(v); v = t > v ? t : v; t = dpp_x<DPP_ROW_MIRROR>(v); v = t > v ? t : v;
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float a = __uint_as_float(r[0]), c = __uint_as_float(r[1]);
+  return a > c ? a : c;
+}
+__device__ __forceinline__ int half_min_i(int v) {
+  int t;
+  t = dpp_x<DPP_QUAD_X1>(v); v = t < v ? t : v; t = dpp_x<DPP_QUAD_X2>(v); v = t < v ? t : v;
+  t = dpp_x<DPP_HALF_MIRROR>(v); v = t < v ? t : v; t = dpp_x<DPP_ROW_MIRROR>(v); v = t < v ? t : v;
+  const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+  return min((int)r[0], (int)r[1]);
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_feature_pair(Dev<float> d, int b0, int nb, int lm, int m_lo, int m_hi, int s_cap, int items) {
+  typedef float S;
+  int bi, w;
+  if (!xcd_item(nb, items, bi, w)) return;
+  const int b = b0 + bi, lane = threadIdx.x;
+  const int F = d.trk_n[(long)bi * d.wl_stride_n];
+#ifdef MSCKF_ABLATE
+  const int fdbg = g_feat_dbg;
+  long long tlast = clock64();
+#endif
+  if (w == 0 && lane == 0) d.nres_upd[b] = (int)(d.n_resid[b] > 1000 ? 1000 : d.n_resid[b]);
+  if (2 * w >= F) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  S* sG = reinterpret_cast<S*>(smem_raw);              // [s_cap]: the packed gate matrices of the two tracks
+  S* sC = sG + s_cap;                                  // [16]: the corner left by gate_chol
+  int* sSlot = reinterpret_cast<int*>(sC + 16);        // [2][lm]
+  int* sHist = reinterpret_cast<int*>(sG);             // [64], prologue only
+  const int m_cap = d.m_cap;
+  const int* Mlist = d.trk_M + (long)bi * d.wl_stride_f;
+
+  // ---- which two tracks: ranks w and nv - 1 - w of the trajectory's tracks of this launch's bin, by length (stable)
+  constexpr int NC = 8;                                // F <= 512 (launch_feature checks)
+  int Mv[NC];
+  sHist[lane] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int t = 64 * c + lane;
+    int M = -1;
+    if (64 * c < F) {
+      if (t < F) {
+        M = Mlist[t];
+        if (M <= m_lo || M > m_hi) M = -1;             // another launch's bin
+        else if (M < 2 || M > m_cap || M > GS) {       // cannot be residualized (checkMotion :982 returns false)
+          if (w == 0) { const long tb = (long)b * d.f_cap + t; d.trk_status[tb] = 0; d.trk_gamma[tb] = 0; d.trk_first[tb] = 0; }
+          M = -1;
+        }
+      }
+      if (M >= 0) atomicAdd(&sHist[M], 1);
+    }
+    Mv[c] = M;
+  }
+  __syncthreads();
+  int tA, tB, nv;
+  {
+    const int c0 = sHist[lane];
+    int scan = c0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(scan, o, 64); if (lane >= o) scan += up; }
+    nv = wave_bcast(scan, 63);
+    if (2 * w >= nv) return;
+    int tsel[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int p = s ? nv - 1 - w : w;
+      const unsigned long long mb = __ballot(scan > p);
+      const int Mb = __builtin_ctzll(mb);              // the length whose bin holds rank p
+      int r = p - (wave_bcast(scan, Mb) - wave_bcast(c0, Mb));
+      int found = -1;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        if (64 * c < F && found < 0) {
+          const unsigned long long m = __ballot(Mv[c] == Mb);
+          const int n = __popcll(m);
+          if (r < n) {
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+            const unsigned long long hit = __ballot(Mv[c] == Mb && rank == r);
+            found = 64 * c + __builtin_ctzll(hit);
+          } else r -= n;
+        }
+      }
+      tsel[s] = found;
+    }
+    tA = tsel[0]; tB = tsel[1];
+  }
+  __syncthreads();                                     // sHist is sG
+  FP_TICK(0);
+  const bool hasB = (nv - 1 - w) != w;
+  const int g = lane >> 5, gl = lane & (GS - 1), gbase4 = (lane & GS) << 2;
+  const bool has = g == 0 || hasB;
+  const int t = g ? tB : tA;
+  const long tb = (long)b * d.f_cap + t;               // per-track output index
+  const int M = has ? Mlist[t] : 0;
+  const long wo = wl_first(d, bi, t);
+  const S* prm = d.prm + (long)b * PRM_STRIDE;
+  const S* imu = d.imu + (long)b * IMU_STRIDE;
+  const int ld = d.ld;
+  const bool act = gl < M;
+  int status = 0;
+  // (requested here, long before their use: a load issued behind the output stores at the end would wait for all of them --
+  // loads and stores share one in-order counter)
+  const S thresh = S(c_chi2[M < 98 ? M : 98]);   // table[dof+1], dof = M-1   (:433, :1117)
+  const int ncam_now = d.ncam_bias ? d.ncam_upd[b] : d.ncam[b];
+  // value of the half's lane i (i may differ between the halves)
+  auto hget = [&](S v, int i) -> S { return __int_as_float(__builtin_amdgcn_ds_bpermute(gbase4 + (i << 2), __float_as_int(v))); };
+
+  // ---- load this lane's camera state and observation
+  const int slot = act ? d.trk_slots[wo + gl] : 0;
+  const S* cs = d.cam + ((long)b * d.n_cap + slot) * CAM_STRIDE;
+  const Q4<S> qc = ldq(cs);
+  const V3<S> pcg = ld3(cs + 4);
+  const S zx = act ? d.trk_obs[2 * (wo + gl)] : S(0), zy = act ? d.trk_obs[2 * (wo + gl) + 1] : S(0);
+  const M3<S> C = q2rot(qc);
+  const V3<S> gv = ld3(imu + IG);
+  if (gl < lm) sSlot[g * lm + gl] = act ? slot : -1;
+  const int slot_lo = half_min_i(act ? slot : 0x7fffffff), slot_hi = -half_min_i(act ? -slot : 0x7fffffff);
+  // first camera of the track (lane 0 of the half) broadcast
+  M3<S> C0; V3<S> p0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C0.m[i][j] = hget(C.m[i][j], 0);
+  p0 = mk3(hget(pcg.x, 0), hget(pcg.y, 0), hget(pcg.z, 0));
+  const S z0x = hget(zx, 0), z0y = hget(zy, 0);
+
+  // ---- checkMotion :980-1025
+  {
+    V3<S> dir = mk3(z0x, z0y, S(1));
+    dir = (S(1) / dsqrt(dot3(dir, dir))) * dir;
+    dir = multv(C0, dir);
+    const V3<S> tr = pcg - p0;
+    const S par = dot3(tr, dir);
+    const V3<S> orth = tr - (par * dir);
+    S nrm = (act && gl > 0) ? dsqrt(dot3(orth, orth)) : S(0);
+    nrm = half_max(nrm);
+    if (nrm > prm[PRM_TRANS]) status |= ST_MOTION_OK;
+  }
+
+  // ---- initializePosition :1147-1285 (Levenberg-Marquardt on inverse depth, sums over the half), predicated per half
+  Pose<S> T;
+  T.R = mulmt(C, C0);
+  T.t = mulv(C, p0 - pcg);
+  S sa, sb, srho;   // solution (alpha, beta, rho)
+  {
+    S depth;
+    {
+      const V3<S> m = mulv(T.R, mk3(z0x, z0y, S(1)));
+      const S A0 = m.x - zx * m.z, A1 = m.y - zy * m.z;
+      const S b0v = zx * T.t.z - T.t.x, b1v = zy * T.t.z - T.t.y;
+      depth = (S(1) / (A0 * A0 + A1 * A1)) * (A0 * b0v + A1 * b1v);
+      depth = hget(depth, M > 0 ? M - 1 : 0);
+    }
+    const S ix = z0x * depth, iy = z0y * depth, iz = depth;
+    sa = ix / iz; sb = iy / iz; srho = S(1) / iz;
+  }
+  const bool given = d.mode == 1;   // stored feature position supplied by the host (pruneRedundantStates)
+  S lambda = S(1e-3), delta_norm = 0;
+  S total_cost = half_sum(act ? tri_cost(T, sa, sb, srho, zx, zy) : S(0));
+  FP_TICK(1);
+  bool reduced = false;
+  int inner = 0, outer = 0;
+  bool oact = has && !given;                           // this half's outer loop is still running
+  while (__any(oact)) {
+    S Ab[9];  // a00 a01 a02 a11 a12 a22 b0 b1 b2
+    {
+      const V3<S> h = mulv(T.R, mk3(sa, sb, S(1))) + (srho * T.t);
+      S W[3][3];
+      for (int i = 0; i < 3; ++i) { W[i][0] = T.R.m[i][0]; W[i][1] = T.R.m[i][1]; }
+      W[0][2] = T.t.x; W[1][2] = T.t.y; W[2][2] = T.t.z;
+      S J[2][3];
+      const S iz = lm_rcp(h.z), xz = h.x * iz, yz = h.y * iz;
+      for (int j = 0; j < 3; ++j) {
+        J[0][j] = iz * (W[0][j] - xz * W[2][j]);
+        J[1][j] = iz * (W[1][j] - yz * W[2][j]);
+      }
+      const S r0 = xz - zx, r1 = yz - zy;
+      const S e = lm_sqrt(r0 * r0 + r1 * r1);
+      const S wgt = (e <= S(0.01)) ? S(1) : S(0.005) * lm_rcp(e);
+      const S w2 = (wgt == S(1)) ? S(1) : wgt * wgt;
+      const S m = act ? w2 : S(0);
+      Ab[0] = m * (J[0][0] * J[0][0] + J[1][0] * J[1][0]);
+      Ab[1] = m * (J[0][0] * J[0][1] + J[1][0] * J[1][1]);
+      Ab[2] = m * (J[0][0] * J[0][2] + J[1][0] * J[1][2]);
+      Ab[3] = m * (J[0][1] * J[0][1] + J[1][1] * J[1][1]);
+      Ab[4] = m * (J[0][1] * J[0][2] + J[1][1] * J[1][2]);
+      Ab[5] = m * (J[0][2] * J[0][2] + J[1][2] * J[1][2]);
+      Ab[6] = m * (J[0][0] * r0 + J[1][0] * r1);
+      Ab[7] = m * (J[0][1] * r0 + J[1][1] * r1);
+      Ab[8] = m * (J[0][2] * r0 + J[1][2] * r1);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Ab[i] = half_sum(Ab[i]);
+    // the damping ladder lambda, 10 lambda, ... (clamped at 1e12): lane c of the half solves the c-th rung (k_feature)
+    S lam_c = lambda;
+#pragma unroll
+    for (int t2 = 0; t2 < 11; ++t2) { const S up = lam_c * 10 < S(1e12) ? lam_c * 10 : S(1e12); if (t2 < gl) lam_c = up; }
+    S dlc[3];
+    ldlt3(Ab, lam_c, Ab + 6, dlc);
+    int cand = 0;
+    bool iact = oact;                                  // this half's inner loop is still running
+    while (__any(iact)) {
+      const S dl0 = hget(dlc[0], cand), dl1 = hget(dlc[1], cand), dl2 = hget(dlc[2], cand);
+      const S lam_now = hget(lam_c, cand), lam_next = hget(lam_c, cand + 1);
+      const S na = sa - dl0, nb2 = sb - dl1, nr = srho - dl2;
+      const S dn = lm_sqrt(dl0 * dl0 + dl1 * dl1 + dl2 * dl2);
+      // a step that changes none of the three parameters gives bit for bit the cost already held: not evaluated (k_feature)
+      const bool changed = iact && !(na == sa && nb2 == sb && nr == srho);
+      S new_cost = total_cost;
+      if (__any(changed)) {
+        const S sc = half_sum(act ? tri_cost(T, na, nb2, nr, zx, zy) : S(0));
+        new_cost = changed ? sc : total_cost;
+      }
+      const bool better = iact && new_cost < total_cost;
+      const S l10th = lam_now * S(0.1);
+      const S lam_acc = l10th > S(1e-10) ? l10th : S(1e-10);
+      sa = better ? na : sa; sb = better ? nb2 : sb; srho = better ? nr : srho; total_cost = better ? new_cost : total_cost;
+      if (iact) {
+        delta_norm = dn;
+        reduced = better;
+        lambda = better ? lam_acc : lam_next;          // lam_next = min(10 * rung, 1e12)
+        ++cand;
+        iact = inner < 10 && !reduced;
+        ++inner;
+      }
+    }
+    if (oact) {
+      inner = 0;
+      oact = outer < 10 && delta_norm > S(5e-7);
+      ++outer;
+    }
+  }
+  FP_TICK(2);
+  const V3<S> fin = mk3(sa / srho, sb / srho, S(1) / srho);
+  {
+    const V3<S> pos = mulv(T.R, fin) + T.t;
+    const unsigned long long badm = __ballot(act && pos.z <= S(0));
+    const bool any_bad = ((g ? (unsigned)(badm >> 32) : (unsigned)badm)) != 0u;
+    const S ncost = total_cost / (S(2) * S(M) * S(M));
+    if (!any_bad && !(ncost > prm[PRM_GN])) status |= ST_TRI_VALID;
+  }
+  V3<S> pf = multv(C0, fin) + p0;   // :1282
+  if (given) {
+    if (has) pf = ld3(d.trk_pfin + tb * 4);
+    status |= ST_MOTION_OK | ST_TRI_VALID;
+  }
+
+  // ---- calcResidual :960-978 and calcMeasJacobian :915-950 for this lane's observation
+  S hx[2][6], r[2];   // H_f = -H_x[:, 3:6] (:949), not kept separately
+  {
+    const V3<S> pc = mulv(C, pf - pcg);
+    const S X = pc.x, Y = pc.y, Z = pc.z;
+    r[0] = zx - X / Z; r[1] = zy - Y / Z;
+    S Ji[2][3];
+    Ji[0][0] = S(1) * (S(1) / Z); Ji[0][1] = 0; Ji[0][2] = (-X / Z) * (S(1) / Z);
+    Ji[1][0] = 0; Ji[1][1] = S(1) * (S(1) / Z); Ji[1][2] = (-Y / Z) * (S(1) / Z);
+    const M3<S> sk = skew3(pc);
+    S A[2][6];
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 3; ++j) {
+        S a = 0, bb = 0;
+        for (int k = 0; k < 3; ++k) { a += Ji[i][k] * sk.m[k][j]; bb += Ji[i][k] * C.m[k][j]; }
+        A[i][j] = a; A[i][3 + j] = -bb;
+      }
+    const V3<S> uh = mulv(C, gv);
+    const V3<S> ut = mulv(skew3(pf - pcg), gv);
+    const S u[6] = {uh.x, uh.y, uh.z, ut.x, ut.y, ut.z};
+    S uu = 0;
+    for (int k = 0; k < 6; ++k) uu += u[k] * u[k];
+    for (int i = 0; i < 2; ++i) {
+      S Au = 0;
+      for (int k = 0; k < 6; ++k) Au += A[i][k] * u[k];
+      for (int k = 0; k < 6; ++k) {
+        const S h = act ? A[i][k] - Au * (S(1) / uu) * u[k] : S(0);
+        hx[i][k] = h;
+      }
+    }
+    if (!act) { r[0] = 0; r[1] = 0; }
+    const S wu = prm[PRM_WU], wv = prm[PRM_WV];
+    r[0] *= wu; r[1] *= wv;
+    for (int k = 0; k < 6; ++k) { hx[0][k] *= wu; hx[1][k] *= wv; }
+    if (d.h16) {   // fp16 Jacobian (dtype MSCKF_HIP_F16H_F32P): rounded here, every consumer below sees the rounded blocks
+      for (int i = 0; i < 2; ++i) for (int k = 0; k < 6; ++k) hx[i][k] = (S)__half2float(__float2half_rn((float)hx[i][k]));
+    }
+  }
+
+  // H_f^T H_f = L L^T (3 x 3, f64) and c = L^-1 H_f^T r: nine f64 sums over the half (k_feature's float-filter form of B^)
+  struct Lq { double i00, l10, l20, i11, l21, i22, cq[3]; };
+  auto normal_eq = [&]() -> Lq {
+    Lq q;
+    const double f0[3] = {-(double)hx[0][3], -(double)hx[0][4], -(double)hx[0][5]}, f1[3] = {-(double)hx[1][3], -(double)hx[1][4], -(double)hx[1][5]};
+    const double s00 = half_sum(f0[0] * f0[0] + f1[0] * f1[0]), s01 = half_sum(f0[0] * f0[1] + f1[0] * f1[1]), s02 = half_sum(f0[0] * f0[2] + f1[0] * f1[2]);
+    const double s11 = half_sum(f0[1] * f0[1] + f1[1] * f1[1]), s12 = half_sum(f0[1] * f0[2] + f1[1] * f1[2]), s22 = half_sum(f0[2] * f0[2] + f1[2] * f1[2]);
+    const double r0 = (double)r[0], r1 = (double)r[1];
+    const double t0 = half_sum(f0[0] * r0 + f1[0] * r1), t1 = half_sum(f0[1] * r0 + f1[1] * r1), t2 = half_sum(f0[2] * r0 + f1[2] * r1);
+    const double tiny = 1e-300;
+    q.i00 = fast_rsqrt(s00 > tiny ? s00 : tiny); q.l10 = s01 * q.i00; q.l20 = s02 * q.i00;
+    const double p11 = s11 - q.l10 * q.l10; q.i11 = fast_rsqrt(p11 > tiny ? p11 : tiny); q.l21 = (s12 - q.l20 * q.l10) * q.i11;
+    const double p22 = s22 - q.l20 * q.l20 - q.l21 * q.l21; q.i22 = fast_rsqrt(p22 > tiny ? p22 : tiny);
+    q.cq[0] = t0 * q.i00; q.cq[1] = (t1 - q.l10 * q.cq[0]) * q.i11; q.cq[2] = (t2 - q.l20 * q.cq[0] - q.l21 * q.cq[1]) * q.i22;
+    return q;
+  };
+  FP_TICK(3);
+  // ---- optional exact early accept of the gate (k_feature): gamma <= |r_o|^2 / sigma^2
+  const int row0 = 2 * gl;
+  S gamma = 0;
+  bool early = false, spd = true;
+  if (d.gate_early) {
+    const Lq q = normal_eq();
+    const S rn = half_sum(r[0] * r[0] + r[1] * r[1]);
+    const S rr_ro = rn - (S)(q.cq[0] * q.cq[0] + q.cq[1] * q.cq[1] + q.cq[2] * q.cq[2]);
+    const S ub = rr_ro / prm[PRM_SIG2G];
+    if (ub < S(0.5) * thresh) { early = true; gamma = ub; status |= ST_GATE_BOUND; }
+  }
+
+  // ---- the gate: G = H_x P_cc H_x^T of both tracks from 6 x 6 blocks of P, the four riding rows, gate_chol per track
+  // (the 2 x 6 Jacobian blocks stay in their lanes' registers: a pair's two blocks come through the LDS crossbar,
+  // ds_bpermute -- 2.9 KB of LDS per wavefront less, which is what holds sixteen wavefronts on a compute unit)
+  const int MA = wave_bcast(M, 0), MB = wave_bcast(M, GS);
+  const bool needA = !wave_bcast((int)early, 0), needB = hasB && !wave_bcast((int)early, GS);
+  const int szA = (2 * MA + 4) * (2 * MA + 5) / 2, szB = (2 * MB + 4) * (2 * MB + 5) / 2;
+  const int npass = (needA && needB && szA + szB > s_cap) ? 2 : 1;
+  const S* P = d.P + (long)b * ld * ld;
+  const S sig2 = prm[PRM_SIG2G];
+  for (int pass = 0; pass < npass; ++pass) {
+    const bool selA = needA && (npass == 1 || pass == 0), selB = needB && (npass == 1 || pass == 1);
+    const int offB = selA ? szA : 0;
+    const int npA = selA ? MA * (MA + 1) / 2 : 0, npB = selB ? MB * (MB + 1) / 2 : 0;
+    const float invWA = 1.0f / (float)(MA | 1), invWB = 1.0f / (float)(MB | 1);
+    for (int p0 = 0; p0 < npA + npB; p0 += 64) {
+      // pairs (a, bq), a <= bq, of the track `sel`, enumerated as a folded rectangle (k_feature).  Every lane runs every
+      // round (ds_bpermute returns zero for a source lane that is switched off); a lane without a pair redoes the last one
+      // and does not store
+      const bool pvalid = p0 + lane < npA + npB;
+      const int p = pvalid ? p0 + lane : npA + npB - 1;
+      const bool sel = p >= npA;
+      const int pq = sel ? p - npA : p, Mq = sel ? MB : MA, Wd = Mq | 1;
+      const int k = (int)(((float)pq + 0.5f) * (sel ? invWB : invWA)), c = pq - k * Wd;
+      const bool first = c < Mq - k;
+      const int a = first ? k : ((Mq & 1) ? Mq - k : Mq - 1 - k);
+      const int bq = a + (first ? c : c - (Mq - k));
+      const int* sl = sSlot + (sel ? lm : 0);
+      const int la4 = ((sel ? GS : 0) + a) << 2, lb4 = ((sel ? GS : 0) + bq) << 2;
+      S* G = sG + (sel ? offB : 0);
+      const int sa2 = sl[a], sb2 = sl[bq];
+      // P(6 s_a + i, 6 s_b + j) through its mirror image (P is bit-symmetric): consecutive lanes read consecutive 24-byte runs
+      const S* Pt = P + (long)(15 + 6 * sa2) * ld + 15 + 6 * sb2;   // element (i, j) at Pt[i * ld + j]
+      S pv[6][6];
+      typedef S s2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const S* col = Pt + (long)i * ld;
+        const s2 m12 = *reinterpret_cast<const s2*>(col + 1), m34 = *reinterpret_cast<const s2*>(col + 3);
+        pv[0][i] = col[0]; pv[1][i] = m12.x; pv[2][i] = m12.y; pv[3][i] = m34.x; pv[4][i] = m34.y; pv[5][i] = col[5];
+      }
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      f2 ha[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ha[i] = f2{lane_gather(hx[0][i], la4), lane_gather(hx[1][i], la4)};
+      S hb[2][6];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) hb[i][j] = lane_gather(hx[i][j], lb4);
+      f2 Tt[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        f2 tt = f2{0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tt += ha[i] * pv[j][i];
+        Tt[j] = tt;
+      }
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        f2 gg = f2{0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < 6; ++j) gg += Tt[j] * hb[cc][j];
+        if (pvalid) G[TRI(2 * bq + cc, 2 * a)] = gg.x;                  // a <= bq: row 2bq+cc >= column 2a+rr
+        if (pvalid && (a != bq || 1 <= cc)) G[TRI(2 * bq + cc, 2 * a + 1)] = gg.y;
+      }
+    }
+    // the four rows that ride along: r^T and the three columns of H_f (rows 2M .. 2M+3 of the packed triangle)
+    if (act && (g ? selB : selA)) {
+      S* G = sG + (g ? offB : 0);
+      const int R2 = 2 * M;
+      for (int s2i = 0; s2i < 2; ++s2i) {
+        const int row = row0 + s2i;
+        G[TRI(R2, row)] = r[s2i];
+        for (int q = 0; q < 3; ++q) G[TRI(R2 + 1 + q, row)] = -hx[s2i][3 + q];
+      }
+    }
+    __syncthreads();
+    FP_TICK(4);
+    for (int s = 0; s < 2; ++s) {
+      if (!(s ? selB : selA)) continue;
+      const S* G = sG + (s ? offB : 0);
+      const int R2 = 2 * (s ? MB : MA), nbr = (R2 + 4 + 7) >> 3;   // 8 x 8 blocks in use (wave-uniform)
+      bool ok;
+      switch (nbr) {
+        case 1: ok = gate_chol_dpp<1>(G, sC, lane, R2, sig2); break;
+        case 2: ok = gate_chol_dpp<2>(G, sC, lane, R2, sig2); break;
+        case 3: ok = gate_chol_dpp<3>(G, sC, lane, R2, sig2); break;
+        case 4: ok = gate_chol_dpp<4>(G, sC, lane, R2, sig2); break;
+        case 5: ok = gate_chol_dpp<5>(G, sC, lane, R2, sig2); break;
+        case 6: ok = gate_chol_dpp<6>(G, sC, lane, R2, sig2); break;
+        case 7: ok = gate_chol_dpp<7>(G, sC, lane, R2, sig2); break;
+        default: ok = gate_chol_dpp<8>(G, sC, lane, R2, sig2); break;
+      }
+      const S gm = ok ? gate_gamma_from_corner<S>(sC) : S(0);
+      if (g == s) { spd = ok; gamma = gm; }
+      __syncthreads();                                 // sC is rewritten by the other track's factorization
+    }
+  }
+  FP_TICK(5);
+  if (spd && gamma < thresh) status |= ST_GATE_PASS;
+
+  // ---- publish status, gamma, slot range and the triangulated point
+  if (has && gl == 0) {
+    d.trk_status[tb] = status;
+    d.trk_gamma[tb] = gamma;
+    d.trk_first[tb] = slot_lo | (slot_hi << 8);   // first and last camera slot of the track (TRK_FIRST / TRK_LAST)
+    S* opf = d.trk_pf + tb * 4;
+    opf[0] = pf.x; opf[1] = pf.y; opf[2] = pf.z; opf[3] = 0;
+  }
+
+  // ---- B = L^-1 H_f^T [H_x | r] (f64, k_feature's float-filter form) and every per-track output, at the very END: the output
+  // stores (~35 per lane) share the loads' in-order counter, and anything loaded behind them -- the gate's blocks of P, a
+  // spilled register -- waited for all of them to drain (the kernel published H_x and B^ before the gate to shorten B^'s 36
+  // registers' lives: 14 us of the launch went into those waits)
+  {
+    const Lq q = normal_eq();
+    double Bq[3][6];
+    const double f0[3] = {-(double)hx[0][3], -(double)hx[0][4], -(double)hx[0][5]}, f1[3] = {-(double)hx[1][3], -(double)hx[1][4], -(double)hx[1][5]};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const double h0 = (double)hx[0][k], h1 = (double)hx[1][k];
+      const double g0 = f0[0] * h0 + f1[0] * h1, g1 = f0[1] * h0 + f1[1] * h1, g2 = f0[2] * h0 + f1[2] * h1;
+      const double b0v = g0 * q.i00, b1v = (g1 - q.l10 * b0v) * q.i11;
+      Bq[0][k] = b0v; Bq[1][k] = b1v; Bq[2][k] = (g2 - q.l20 * b0v - q.l21 * b1v) * q.i22;
+    }
+    // slot -> observation map of the half through LDS (the gate matrices are done with): one pass of stores, nothing is
+    // written twice, no wait between a fill and a scatter
+    int* sInv = reinterpret_cast<int*>(sG) + g * 64;
+    sInv[gl] = -1; sInv[gl + GS] = -1;
+    wave_lds_sync();
+    if (act) sInv[slot] = gl;
+    wave_lds_sync();
+    double* oB = d.trk_B + tb * 3 * (long)d.ldR;
+    signed char* oI = d.trk_inv + tb * d.n_cap;
+    if (has) {
+      for (int e = gl; e < d.n_cap; e += GS) oI[e] = (signed char)sInv[e];
+      if (slot_hi - slot_lo + 1 != M) {                // zeros where a slot inside the track's range is unobserved
+        const int c_n = 6 * (slot_hi - slot_lo + 1);
+        for (int e = gl; e < 3 * c_n; e += GS) { const int qr = e / c_n, cc = e - qr * c_n; if (sInv[slot_lo + cc / 6] < 0) oB[(long)qr * d.ldR + 6 * slot_lo + cc] = 0.0; }
+      }
+    }
+    if (act) {
+      if (d.h16) { __half* oH = d.trk_Hx16 + (tb * m_cap) * 12; for (int i = 0; i < 2; ++i) for (int k = 0; k < 6; ++k) oH[gl * 12 + i * 6 + k] = __float2half_rn((float)hx[i][k]); }
+      else { S* oHx = d.trk_Hx + (tb * m_cap) * 12; for (int i = 0; i < 2; ++i) for (int k = 0; k < 6; ++k) oHx[gl * 12 + i * 6 + k] = hx[i][k]; }
+      for (int qr = 0; qr < 3; ++qr) for (int k = 0; k < 6; ++k) oB[(long)qr * d.ldR + 6 * slot + k] = Bq[qr][k];
+      d.trk_rw[tb * 2 * m_cap + 2 * gl] = r[0]; d.trk_rw[tb * 2 * m_cap + 2 * gl + 1] = r[1];
+    }
+    if (has && gl < 3) oB[(long)gl * d.ldR + 6 * ncam_now] = gl == 0 ? q.cq[0] : (gl == 1 ? q.cq[1] : q.cq[2]);
+  }
+  FP_TICK(6);
+#ifdef MSCKF_ABLATE
+  if ((fdbg & 0x100000) && lane == 0) atomicAdd(&g_featp_cycles[7], 1ull);
+#endif
+}
+
+size_t feature_pair_lds_bytes(int lm, int& s_cap) {
+  const int r2 = 2 * lm + 4;
+  s_cap = r2 * (r2 + 1) / 2 + 12 * 13 / 2;            // the longest track + a 4-observation partner
+  if (s_cap < 64) s_cap = 64;                          // the prologue's histogram lives there
+  return ((size_t)s_cap + 16) * sizeof(float) + 2 * (size_t)lm * sizeof(int) + 16;
+}
+
 // One wavefront per trajectory: resolves the order-dependent part of marginalize (:352-399) -- checkMotion is
 // skipped while fewer than 4 tracks have ever been residualized (Q4, msckf.h:354) -- and lays the gated-in
 // tracks' rows out for the compression stage: tracks are counting-sorted by their first camera slot (stable,
@@ -1072,6 +1677,7 @@ void feature_device_setup() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature<double, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature<double, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_pair), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 template <class S>
@@ -1079,6 +1685,18 @@ void launch_feature(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0) return;
   const dim3 grid(xcd_grid(nb, d.f_cap));
   constexpr int ALL_LO = -0x7fffffff, ALL_HI = 0x7fffffff, M_REG = 30;   // 2 * 30 + 4 = 64: the register-resident gate factorization
+  // float filters on the information-form route: tracks of up to 30 observations two per wavefront (k_feature_pair)
+  bool pair = false;
+  if constexpr (sizeof(S) == 4) {
+    if (d.feat_pair && d.compress && d.f_cap <= 512) {
+      pair = true;
+      const int lm = d.m_cap < M_REG ? d.m_cap : M_REG, items = (d.f_cap + 1) / 2;
+      int s_cap = 0;
+      const size_t lds = feature_pair_lds_bytes(lm, s_cap);
+      hipLaunchKernelGGL(k_feature_pair, dim3(xcd_grid(nb, items)), dim3(64), lds, st, d, b0, nb, lm, ALL_LO, d.m_cap <= M_REG ? ALL_HI : M_REG, s_cap, items);
+      if (d.m_cap <= M_REG) return;
+    }
+  }
   if (d.m_cap <= M_REG) {
     // (measured and rejected, round 4: the tracks of at most 12 / 16 / 20 observations in a launch of their own with the LDS sized
     // for them -- five wavefronts per SIMD instead of four for those: 183 k -> 172 k updates/s on one stream, 201 k -> 199 k in four
@@ -1088,7 +1706,7 @@ void launch_feature(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   }
   // long windows: tracks binned by length, one launch per bin over the same grid (a workgroup whose track belongs to another
   // bin returns at once).  Occupancy is set by the LDS of the bin's longest track, not of the window's
-  hipLaunchKernelGGL((k_feature<S, false>), grid, dim3(64), feature_lds_bytes(M_REG, sizeof(S)), st, d, b0, nb, M_REG, ALL_LO, M_REG);
+  if (!pair) hipLaunchKernelGGL((k_feature<S, false>), grid, dim3(64), feature_lds_bytes(M_REG, sizeof(S)), st, d, b0, nb, M_REG, ALL_LO, M_REG);
   const int mid = (M_REG + d.m_cap + 1) / 2;
   if (d.m_cap - M_REG >= 16) {
     hipLaunchKernelGGL((k_feature<S, true>), grid, dim3(64), feature_lds_bytes(mid, sizeof(S)), st, d, b0, nb, mid, M_REG, mid);
@@ -1097,6 +1715,10 @@ void launch_feature(const Dev<S>& d, int b0, int nb, hipStream_t st) {
 }
 #ifdef MSCKF_ABLATE
 void feat_debug_set(int val) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_feat_dbg), &val, sizeof(int)); }
+void featp_cycles_read(unsigned long long* out8, int reset) {
+  (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_featp_cycles), sizeof(unsigned long long) * 8);
+  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_featp_cycles), z, sizeof(z)); }
+}
 #endif
 
 template <class S>

@@ -354,6 +354,7 @@ struct Batch : BatchBase {
     rc |= dalloc(&d.keep, Bz * n_cap); rc |= dalloc(&d.nkeep, Bz); rc |= dalloc(&d.ncam_upd, Bz); rc |= dalloc(&d.nres_upd, Bz);
     rc |= dalloc(&d_pfin, TF * 4); d.trk_pfin = d_pfin; d.mode = 0; d.joseph = 0; d.ncam_bias = 0;
     { const char* e = getenv("MSCKF_HIP_FUSED_S"); d.gain_fused_s = e ? atoi(e) : 2; }
+    { const char* e = getenv("MSCKF_HIP_FEATURE_PAIR"); d.feat_pair = e ? atoi(e) : 1; }
     rc |= dalloc(&d.gain_bar, Bz * 32);   // 0: the S GEMM as a launch of its own (A/B runs)
     rd_cap = 64;
     rc |= dalloc(&d_rd, Bz * rd_cap * RD_STRIDE);
@@ -1815,7 +1816,7 @@ BatchBase* H(msckf_hip_handle h) { return reinterpret_cast<BatchBase*>(h); }
 }  // namespace
 
 #ifdef MSCKF_ABLATE
-namespace msckf { void qr_debug_set(int idx, int val); void feat_debug_set(int val); extern int g_gram_dbg; void chol_cycles_read(unsigned long long* out16, int reset); void chol_sub_read(unsigned long long* out32, int reset); void chol_debug_set(int v); void prop_cycles_read(unsigned long long* out8, int reset); void gram_cycles_read(unsigned long long* out40, int reset); void gemm_cycles_read(unsigned long long* out16, int reset); void gemm_trace_read(unsigned long long* out); }
+namespace msckf { void qr_debug_set(int idx, int val); void feat_debug_set(int val); void featp_cycles_read(unsigned long long* out8, int reset); extern int g_gram_dbg; void chol_cycles_read(unsigned long long* out16, int reset); void chol_sub_read(unsigned long long* out32, int reset); void chol_debug_set(int v); void prop_cycles_read(unsigned long long* out8, int reset); void gram_cycles_read(unsigned long long* out40, int reset); void gemm_cycles_read(unsigned long long* out16, int reset); void gemm_trace_read(unsigned long long* out); }
 #endif
 
 extern "C" {
@@ -1831,6 +1832,7 @@ void msckf_hip_debug_set(int idx, int val) {
 void msckf_hip_debug_chol_cycles(unsigned long long* out16, int reset) { msckf::chol_cycles_read(out16, reset); }
 void msckf_hip_debug_chol_sub(unsigned long long* out32, int reset) { msckf::chol_sub_read(out32, reset); }
 void msckf_hip_debug_prop_cycles(unsigned long long* out8, int reset) { msckf::prop_cycles_read(out8, reset); }
+void msckf_hip_debug_featp_cycles(unsigned long long* out8, int reset) { msckf::featp_cycles_read(out8, reset); }
 void msckf_hip_debug_gram_cycles(unsigned long long* out40, int reset) { msckf::gram_cycles_read(out40, reset); }
 void msckf_hip_debug_gemm_cycles(unsigned long long* out16, int reset) { msckf::gemm_cycles_read(out16, reset); }
 void msckf_hip_debug_gemm_trace(unsigned long long* out) { msckf::gemm_trace_read(out); }

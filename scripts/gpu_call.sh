@@ -11,6 +11,7 @@
 #   sweep        scripts/sweep_variants.py (streams / streamed) profile     scripts/profile_round.sh (kernel stats + PMC passes of cfg3)
 #   lit_profile  rocprofv3 kernel stats + PMC passes of bench.py --config cfg4 (literal route)    lit_stats  the kernel stats alone (all launches + last six)
 #   cfg2_profile rocprofv3 kernel stats of bench.py --config cfg2
+#   ab_env       bench.py (cfg3, short) with AB_ENV set against the default, alternating on the same lease (AB_ARGS: extra bench.py flags)
 #   pause        scripts/pause_probe.py: the first window after a pause (state reads, sleeps) against the median, streamed / resident
 # Outputs land in gpurun_out/$TAG; copy what is to be judged into profiles/ by hand (profiles/README.md lists them).
 cd /root/repo
@@ -41,6 +42,25 @@ if has lit_timers; then
   if has lit_timers_all; then MSCKF_HIP_LITERAL_TIMERS=1 python scripts/lit_timers.py --all > $O/lit_timers_all.txt 2>&1; fi
 fi
 if has pause; then python scripts/pause_probe.py 2>&1 | tail -6 | tee $O/pause_probe.txt; fi
+if has ab_env; then   # A/B inside one lease: AB_ENV="VAR=val" (the alternative) against the default, alternating, twice each
+  BA="--steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-early-accept-pass --repeats 6 ${AB_ARGS:-}"
+  for i in 1 2; do
+    env $AB_ENV python bench.py $BA > $O/bench_alt$i.json 2> $O/bench_alt$i.err; summ bench_alt$i
+    python bench.py $BA > $O/bench_def$i.json 2> $O/bench_def$i.err; summ bench_def$i
+  done
+fi
+if has feat_pmc; then   # instruction / issue counters of the per-track kernel only (two PMC passes), default library and with AB_ENV set
+  cd /tmp && export TMPDIR=/tmp
+  CM="--steps 6 --warmup 2 --no-cpu-baseline --no-early-accept-pass --no-upload-pass --no-other-configs --repeats 1 --streams 1"
+  for v in def alt; do
+    E=""; if [ $v = alt ]; then E="$AB_ENV"; fi
+    env $E rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVES --kernel-trace -d /tmp/f1$v -o r -- python /root/repo/bench.py $CM > /tmp/f1$v.log 2>&1
+    env $E rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE --kernel-trace -d /tmp/f2$v -o r -- python /root/repo/bench.py $CM > /tmp/f2$v.log 2>&1
+    rm -f /root/repo/$O/feat_pmc_$v.md
+    python /root/repo/scripts/rocpd_pmc.py /root/repo/$O/feat_pmc_$v.md $(find /tmp/f1$v /tmp/f2$v -name "*.db") | grep -i "k_feature" | cut -c1-200
+  done
+  cd /root/repo
+fi
 if has bench; then python bench.py > $O/bench.json 2> $O/bench.err; summ bench; fi
 if has cfg4; then python bench.py --config cfg4 --steps 10 --warmup 3 --no-cpu-baseline --no-early-accept-pass --no-other-configs > $O/bench_cfg4.json 2> $O/bench_cfg4.err; summ bench_cfg4; fi
 if has cfgs; then
