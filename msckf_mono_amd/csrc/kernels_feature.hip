@@ -938,36 +938,52 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   int bi, w;
   if (!xcd_item(nb, items, bi, w)) return;
   const int b = b0 + bi, lane = threadIdx.x;
-  const int F = d.trk_n[(long)bi * d.wl_stride_n];
 #ifdef MSCKF_ABLATE
   const int fdbg = g_feat_dbg;
   long long tlast = clock64();
+  if (fdbg & 0x200) return;                            // launch floor
 #endif
-  if (w == 0 && lane == 0) d.nres_upd[b] = (int)(d.n_resid[b] > 1000 ? 1000 : d.n_resid[b]);
-  if (2 * w >= F) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   S* sG = reinterpret_cast<S*>(smem_raw);              // [s_cap]: the packed gate matrices of the two tracks
   S* sC = sG + s_cap;                                  // [16]: the corner left by gate_chol
   int* sSlot = reinterpret_cast<int*>(sC + 16);        // [2][lm]
   int* sHist = reinterpret_cast<int*>(sG);             // [64], prologue only
-  const int m_cap = d.m_cap;
+  const int m_cap = d.m_cap, f_cap = d.f_cap;
   const int* Mlist = d.trk_M + (long)bi * d.wl_stride_f;
 
-  // ---- which two tracks: ranks w and nv - 1 - w of the trajectory's tracks of this launch's bin, by length (stable)
+  // ---- which two tracks: ranks w and nv - 1 - w of the trajectory's tracks of this launch's bin, by length (stable).
+  // Everything the ranking needs is requested at once -- the track count, the lengths and the list offsets of up to 512
+  // tracks (clamped addresses: nothing waits for the count) -- one memory round trip instead of four dependent ones
+  // (count -> lengths -> chosen track's length -> its offset).
   constexpr int NC = 8;                                // F <= 512 (launch_feature checks)
-  int Mv[NC];
+  int Mv[NC], Ov[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    Mv[c] = -1; Ov[c] = 0;
+    if (64 * c < f_cap) {
+      const int tt = min(64 * c + lane, f_cap - 1);
+      Mv[c] = Mlist[tt];
+      if (d.trk_off) Ov[c] = d.trk_off[(long)bi * d.wl_stride_f + tt];
+    }
+  }
+  const int F = d.trk_n[(long)bi * d.wl_stride_n];
+  if (w == 0 && lane == 0) d.nres_upd[b] = (int)(d.n_resid[b] > 1000 ? 1000 : d.n_resid[b]);
   sHist[lane] = 0;
-  __syncthreads();
+  wave_lds_sync();
+  if (2 * w >= F) return;
+#ifdef MSCKF_ABLATE
+  if (fdbg & 0x80000) { if (Mv[0] + Ov[0] == -12345) d.trk_gamma[0] = 0; return; }   // the first round trip only
+#endif
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const int t = 64 * c + lane;
     int M = -1;
     if (64 * c < F) {
       if (t < F) {
-        M = Mlist[t];
+        M = Mv[c];
         if (M <= m_lo || M > m_hi) M = -1;             // another launch's bin
         else if (M < 2 || M > m_cap || M > GS) {       // cannot be residualized (checkMotion :982 returns false)
-          if (w == 0) { const long tb = (long)b * d.f_cap + t; d.trk_status[tb] = 0; d.trk_gamma[tb] = 0; d.trk_first[tb] = 0; }
+          if (w == 0) { const long tb = (long)b * f_cap + t; d.trk_status[tb] = 0; d.trk_gamma[tb] = 0; d.trk_first[tb] = 0; }
           M = -1;
         }
       }
@@ -975,23 +991,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
     Mv[c] = M;
   }
-  __syncthreads();
-  int tA, tB, nv;
+  wave_lds_sync();
+  int tA, tB, nv, MA, MB, woA, woB;
   {
     const int c0 = sHist[lane];
+    // inclusive prefix over the 64 bins on the DPP network (four shifts inside the rows of 16, two row broadcasts)
     int scan = c0;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(scan, o, 64); if (lane >= o) scan += up; }
+    scan += __builtin_amdgcn_update_dpp(0, scan, 0x111, 0xF, 0xF, true);
+    scan += __builtin_amdgcn_update_dpp(0, scan, 0x112, 0xF, 0xF, true);
+    scan += __builtin_amdgcn_update_dpp(0, scan, 0x114, 0xF, 0xF, true);
+    scan += __builtin_amdgcn_update_dpp(0, scan, 0x118, 0xF, 0xF, true);
+    scan += dppm_i<DPP_ROW_BCAST15, 0xA>(scan);
+    scan += dppm_i<DPP_ROW_BCAST31, 0xC>(scan);
     nv = wave_bcast(scan, 63);
     if (2 * w >= nv) return;
-    int tsel[2];
+    int tsel[2], msel[2], osel[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int p = s ? nv - 1 - w : w;
       const unsigned long long mb = __ballot(scan > p);
       const int Mb = __builtin_ctzll(mb);              // the length whose bin holds rank p
       int r = p - (wave_bcast(scan, Mb) - wave_bcast(c0, Mb));
-      int found = -1;
+      int found = -1, off = 0;
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         if (64 * c < F && found < 0) {
@@ -999,24 +1020,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           const int n = __popcll(m);
           if (r < n) {
             const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-            const unsigned long long hit = __ballot(Mv[c] == Mb && rank == r);
-            found = 64 * c + __builtin_ctzll(hit);
+            const int hl = __builtin_ctzll(__ballot(Mv[c] == Mb && rank == r));
+            found = 64 * c + hl; off = wave_bcast(Ov[c], hl);
           } else r -= n;
         }
       }
-      tsel[s] = found;
+      tsel[s] = found; msel[s] = Mb; osel[s] = off;
     }
-    tA = tsel[0]; tB = tsel[1];
+    tA = tsel[0]; tB = tsel[1]; MA = msel[0]; MB = msel[1]; woA = osel[0]; woB = osel[1];
   }
-  __syncthreads();                                     // sHist is sG
+  wave_lds_sync();                                     // sHist is sG
   FP_TICK(0);
   const bool hasB = (nv - 1 - w) != w;
+  if (!hasB) MB = 0;
   const int g = lane >> 5, gl = lane & (GS - 1), gbase4 = (lane & GS) << 2;
   const bool has = g == 0 || hasB;
   const int t = g ? tB : tA;
-  const long tb = (long)b * d.f_cap + t;               // per-track output index
-  const int M = has ? Mlist[t] : 0;
-  const long wo = wl_first(d, bi, t);
+  const long tb = (long)b * f_cap + t;                 // per-track output index
+  const int M = g ? MB : MA;
+  const long wo = d.trk_off ? (long)(g ? woB : woA) : (long)bi * d.wl_stride_o + (long)t * m_cap;
   const S* prm = d.prm + (long)b * PRM_STRIDE;
   const S* imu = d.imu + (long)b * IMU_STRIDE;
   const int ld = d.ld;
@@ -1240,10 +1262,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   // ---- the gate: G = H_x P_cc H_x^T of both tracks from 6 x 6 blocks of P, the four riding rows, gate_chol per track
   // (the 2 x 6 Jacobian blocks stay in their lanes' registers: a pair's two blocks come through the LDS crossbar,
   // ds_bpermute -- 2.9 KB of LDS per wavefront less, which is what holds sixteen wavefronts on a compute unit)
-  const int MA = wave_bcast(M, 0), MB = wave_bcast(M, GS);
   const bool needA = !wave_bcast((int)early, 0), needB = hasB && !wave_bcast((int)early, GS);
   const int szA = (2 * MA + 4) * (2 * MA + 5) / 2, szB = (2 * MB + 4) * (2 * MB + 5) / 2;
+#ifdef MSCKF_ABLATE
+  const int npass = (needA && needB && (szA + szB > s_cap || (fdbg & 0x40000))) ? 2 : 1;
+#else
   const int npass = (needA && needB && szA + szB > s_cap) ? 2 : 1;
+#endif
   const S* P = d.P + (long)b * ld * ld;
   const S sig2 = prm[PRM_SIG2G];
   for (int pass = 0; pass < npass; ++pass) {
