@@ -277,7 +277,7 @@ def main():
     R2 = min(R, 3) if streamed else 0                       # resident-input windows beside the streamed ones
     extra = R2 + 1 + (0 if (args.gate_early_accept or args.no_early_accept_pass) else 1)
     W2 = max(W, 3)                           # untimed frames after the state reads that follow the first window (see below)
-    n_frames = fill + W + W2 + K * (R + extra)   # [fill | warmup | window 0 | re-warm | R - 1 timed windows | R2 resident windows | profiled | early-accept window]
+    n_frames = fill + W + W2 + K * (R + 1 + extra)   # [fill | warmup | window 0 | one window straight after the state reads | re-warm | R - 1 timed windows | R2 resident windows | profiled | early-accept window]
     rendezvous_only = bool(os.environ.get("BENCH_RENDEZVOUS_ONLY"))   # test hook, see below
     t_gen = time.time()
     trajs = [] if rendezvous_only else make_trajectories(c, rank, n_frames)
@@ -359,7 +359,7 @@ def main():
     f = fill + W
     run_timed_path = bt.run_frames_streamed if streamed else bt.run_frames
     if streamed:                     # page-lock the frames that will be streamed (set-up, like every other allocation)
-        bt.scenario_pin(0, f + K * R + W2)
+        bt.scenario_pin(0, f + K * (R + 1) + W2)
     run_timed_path(0, fill)          # window fill (untimed), on the path that is timed: the staging ring wraps several times
     run_timed_path(fill, f)          # W warm-up steps (untimed)
     bt.sync()
@@ -374,6 +374,9 @@ def main():
     # such a pause ran at 0.4 - 0.8 of the median (BENCH_r04: windows[1], [2]; not reproducible on others: scripts/pause_probe.py
     # reads 0.98 - 0.99 after state reads or sleeps of 1 .. 50 ms).  The repeat windows measure the steady state, so they start
     # after W2 untimed frames, like the first window after its warm-up; `value` (window 0) is not affected either way.
+    # (rounds 1-4 timed their repeat windows straight after the reads; ONE such window is still recorded, outside the median, so
+    # that the two conventions stay comparable: repeats.first_after_reads)
+    el_after_reads = timed(f, f + K, streamed=streamed); f += K
     run_timed_path(f, f + W2); bt.sync(); f += W2
     rep = [elapsed]
     for _ in range(R - 1):           # further windows of the same size: spread of the measurement
@@ -489,7 +492,8 @@ def main():
         # the REFERENCE's algorithm (dense gate products, Householder compression), not the instructions executed.
         kernels = {
             "k_feature": dict(ms=stage_ms["feature"], flops=fl["feature"], bound="valu", peak=PEAK_F32_TFLOPS,
-                              why="one wavefront per track, lane = observation: VALU-issue bound (0 MFMA), f32 vector peak"),
+                              why="k_feature_pair: two tracks per wavefront (shortest with longest), lane = observation within a half; vector ALU + LDS "
+                                  "crossbar (the gate's register-resident Cholesky exchanges its pivot column through ds_bpermute), 0 MFMA, f32 vector peak"),
             "k_gram": dict(ms=stage_ms["compress_stage1"], flops=fl["gram"], bound="mfma", peak=PEAK_F64_TFLOPS,
                            why="SYRK of the projected blocks on v_mfma_f64_16x16x4 (information form: its own FLOP, ~20x fewer than the "
                                "reference's Householder QR of the stack): bound by load latency, not by the matrix cores"),
@@ -499,7 +503,7 @@ def main():
             "k_propagate": dict(ms=stage_ms["propagate"], flops=fl["propagate"], bound="valu", peak=PEAK_F32_TFLOPS,
                                 why="sequential 15x15 chain per trajectory: latency bound"),
         }
-        if lit_on:      # the three launches of the literal anisotropic compression, each with its own event pair in the profiled pass
+        if lit_on:      # the literal anisotropic compression's six launches (k_lit_pre, k_lit_gamma, four k_lit_phase) as three stages, each with its own event pair in the profiled pass
             kernels["k_literal"] = dict(ms=stage_ms["literal"], flops=ex["literal"], bound="valu", peak=PEAK_F64_TFLOPS,
                                         why="one workgroup per trajectory: explicit rows, the Householder sweep for its decisions in LDS panels of 16, "
                                             "the basis products and the blocked elimination of R_n -- f64 vector arithmetic on 128 of 256 compute units, "
@@ -524,17 +528,24 @@ def main():
             "config": {"workload": c["workload"], "name": args.config,
                        "cam_window": N_WIN, "tracks_per_update": F_TRK, "trajectories_per_gpu": B_TRAJ, "imu_per_update": K_IMU,
                        "parallelism": "replicated trajectories, %d per rank" % B_TRAJ,
-                       "noise": "isotropic (f_u = f_v)" if c["iso"] else ("anisotropic (EuRoC f_u != f_v): " + ("the reference's R_o_j = A_j^T R_j A_j / HouseholderQR / R_n = Q_1^T R_o Q_1 on the device (kernels_literal.hip)" if args.aniso_mode == 0 else "rows pre-whitened by 1/sigma (GLS)")),
+                       "noise": "isotropic (f_u = f_v)" if c["iso"] else ("anisotropic (EuRoC f_u != f_v): " + ("the reference's R_o_j = A_j^T R_j A_j / HouseholderQR / R_n = Q_1^T R_o Q_1 on the device (kernels_literal.hip), zero-tail tolerance 8e-4 "
+                                                                                                      "(the exact-arithmetic limit of Eigen's makeHouseholder rule; the reference's letter rule = tolerance 0 is selectable: msckf_hip_set_anisotropic_noise(h, 0, 0))" if args.aniso_mode == 0 else "rows pre-whitened by 1/sigma (GLS)")),
                        "sequences": nseq, "gate_early_accept": bool(args.gate_early_accept), "streams": args.streams,
                        "host_affinity": pin_cpus or None},
             "inputs": ("uploaded per frame inside the timed region (SURVEY.md 8d): page-locked host memory -> staging ring on a copy stream, "
                        "compact work-lists, %d sets" % args.ring) if streamed else "resident in HBM before the timed region (--no-upload-pass)",
             "upload": None if not streamed else {"bytes_per_step_per_gpu": int(up_bytes), "ring": args.ring,
                                                  "hand_over": "host" if args.upload_mode == 0 else "device events", "h2d_GBps_pinned_64MB": h2d_gbs},
+            # the spread of the measurement where the driver's record shows it (nested keys end up under extra_keys there):
+            # value_suspect = window 0 fell below 0.93 x the median of the run's windows (a slow window, DESIGN.md 9, reached `value`)
+            "repeats_median": float(np.median(rep_vals)), "repeats_min_over_median": float(np.min(rep_vals) / np.median(rep_vals)),
+            "value_over_repeats_median": float(rep_vals[0] / np.median(rep_vals)), "value_suspect": bool(rep_vals[0] < 0.93 * np.median(rep_vals)),
             "repeats": {"windows": len(rep_vals), "steps_each": K, "values": rep_vals, "median": float(np.median(rep_vals)),
                         "min": float(np.min(rep_vals)), "max": float(np.max(rep_vals)),
+                        "first_after_reads": updates / el_after_reads,
                         "note": "value = windows[0] (the contract's K timed steps); the others are the same measurement on later frames, after the "
-                                "state reads that follow window 0 and %d untimed frames (a pause of the device is not part of a steady-state window)" % W2},
+                                "state reads that follow window 0 and %d untimed frames (a pause of the device is not part of a steady-state window); "
+                                "first_after_reads = one more window timed straight after those reads, without the untimed frames (rounds 1-4's convention), not in the median" % W2},
             "resident_inputs": None if not res_vals else {
                 "values": res_vals, "median": float(np.median(res_vals)), "ms_per_step": 1e3 * float(np.median(res_rep)) / K,
                 "streamed_over_resident": float(np.median(rep_vals) / np.median(res_vals)),

@@ -215,8 +215,10 @@ int msckf_hip_set_feature_overlap(msckf_hip_handle h, int on);
  * R_o_j = A_j^T R_j A_j / HouseholderQR in column order / R_n = Q_1^T R_o Q_1 on the device (msckf.h:423-431, 1343-1366;
  * f64: the Householder sweep for its decisions, the result as a projection onto range(Q_1), kernels_literal.hip), handed to the
  * update as the information matrix [T_H | r_n]^T R_n^-1 [T_H | r_n]; mode 1 rows pre-whitened by 1/sigma (generalized least squares).  tail_tol: zero-tail tolerance of mode 0, < 0 = default (1e-10 double, 8e-4 float), 0 = the reference's
- * rule to the letter.  Applies to every trajectory of the handle, initialized or not.  -ENOMEM when the work space (about
- * sixteen (6 n_cap)^2 matrices of doubles per trajectory) does not fit. */
+ * rule to the letter.  Applies to every trajectory of the handle, initialized or not.  -ENOMEM when the work space does not fit
+ * (per trajectory about sixteen (6 n_cap)^2 matrices of doubles, the (2 * 6 n_cap + 16)^2 elimination matrix, and per TRACK six rows of
+ * ldR doubles -- f_cap * 6 * ldR * 8 bytes, 1.8 MB at 200 tracks and a 30-camera window); -ENOTSUP on a device that does not grant
+ * the route's kernels their 94 KB of LDS per workgroup (gfx950 does). */
 int msckf_hip_set_anisotropic_noise(msckf_hip_handle h, int mode, double tail_tol);
 /* last marginalize of trajectory b on the literal route: out[0..5] = stacked rows m, kept rows r of R (msckf.h:1347),
  * Householder steps that reflected, steps whose non-zero tail fell under tail_tol, route taken (3: the sequence of steps on

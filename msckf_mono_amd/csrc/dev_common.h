@@ -420,6 +420,7 @@ void qr_device_setup();
 void kalman_device_setup();
 void gram_device_setup();
 void literal_device_setup();
+bool literal_lds_available();   // false when the device refused the phase kernels' dynamic LDS (94 KB per workgroup)
 long lit_ws_doubles(int n6, int m_cap, int r_cap);   // per-trajectory scratch of k_literal (doubles)
 
 }  // namespace msckf

@@ -457,12 +457,20 @@ __global__ __launch_bounds__(1024) void k_literal_dense(Dev<S> d, int b0, int nb
   }
 }
 
-template <class K> static void lit_lds_attr(K k) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LIT_LDS_DOUBLES * sizeof(double))); }
+// The phase kernels ask for LIT_LDS_DOUBLES * 8 = 94 KB of dynamic LDS per workgroup: granted on gfx950 (160 KB per compute unit), not on
+// a part with 64 KB.  The result of every attribute call is kept: a device that refuses gets -ENOTSUP from the literal route's
+// allocation (msckf_hip.hip: lit_alloc) instead of launches that fail one update later.
+static bool g_lit_lds_ok = true;
+template <class K> static void lit_lds_attr(K k) {
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LIT_LDS_DOUBLES * sizeof(double))) != hipSuccess) { (void)hipGetLastError(); g_lit_lds_ok = false; }
+}
 void literal_device_setup() {
+  g_lit_lds_ok = true;
   lit_lds_attr(k_lit_phase<float, 0>); lit_lds_attr(k_lit_phase<float, 1>); lit_lds_attr(k_lit_phase<float, 2>); lit_lds_attr(k_lit_phase<float, 3>);
   lit_lds_attr(k_lit_phase<double, 0>); lit_lds_attr(k_lit_phase<double, 1>); lit_lds_attr(k_lit_phase<double, 2>); lit_lds_attr(k_lit_phase<double, 3>);
   lit_lds_attr(k_literal_dense<float>); lit_lds_attr(k_literal_dense<double>);
 }
+bool literal_lds_available() { return g_lit_lds_ok; }
 
 // part: 0 all launches; 1 k_lit_pre, 2 k_lit_gamma, 3 the four phase kernels (k_lit_phase<., 0..3>) alone (the stage timers of a profiled run bracket each)
 template <class S>

@@ -477,6 +477,7 @@ struct Batch : BatchBase {
   // work space of kernels_literal.hip (a few (6 n_cap)^2 matrices per trajectory); only allocated when a trajectory has
   // u_var' != v_var' on the literal route
   int lit_alloc() {
+    if (!literal_lds_available()) return fail(-ENOTSUP, "this device does not grant the 94 KB of LDS per workgroup the literal anisotropic route needs (msckf_hip_set_anisotropic_noise(h, 1, 0) selects pre-whitening)");
     LitBufs& L = d.lit;
     const size_t Bz = B, n1 = (size_t)d.n6cap + 1;
     L.ldx = ((f_cap * std::max(2 * m_cap - 3, 1) + 7) / 8) * 8;
@@ -620,16 +621,18 @@ struct Batch : BatchBase {
     if (pend_b < 0) return 0;
     const int b = pend_b; pend_b = -1;
     std::vector<double> rd; rd.swap(pend_rd);
-    HIPCHK(hipSetDevice(device));
-    return propagate_device(b, 1, rd.data(), (int)(rd.size() / RD_STRIDE), then_augment);
+    if (hipSetDevice(device) != hipSuccess) { h_imu_ok[b] = 0; return fail(-EIO, "hipSetDevice failed"); }
+    const int rc = propagate_device(b, 1, rd.data(), (int)(rd.size() / RD_STRIDE), then_augment);
+    if (rc) h_imu_ok[b] = 0;   // the samples are gone and the device never saw them: the host copy is ahead of the filter, drop it (getImuState() re-reads the device)
+    return rc;
   }
   int propagate(int b0, int nb, const double* rd, int K, bool mirror) override {
     POISON_GUARD();
     if (chk_range(b0, nb)) return fail(-EINVAL, "trajectory range out of bounds");
     if (K < 0) return fail(-EINVAL, "negative sample count");
     if (mirror && nb == 1 && h_imu_ok[b0]) {
+      if (pend_b >= 0 && pend_b != b0) { const int rc = flush_pending(); if (rc) return rc; }   // first: a failure here must not leave b0's host copy advanced with nothing queued
       for (int k = 0; k < K; ++k) host_rk(h_imu.data() + (size_t)b0 * IMU_STRIDE, rd + (size_t)k * RD_STRIDE);
-      if (pend_b >= 0 && pend_b != b0) { const int rc = flush_pending(); if (rc) return rc; }
       pend_b = b0; pend_rd.insert(pend_rd.end(), rd, rd + (size_t)K * RD_STRIDE);
       return 0;
     }
@@ -824,7 +827,7 @@ struct Batch : BatchBase {
     return 0;
   }
   int drop_oldest(int b0, int nb, int n) override;
-  int ncam_host(int b) const override { return (b < 0 || b >= B) ? -EINVAL : h_ncam[b]; }
+  int ncam_host(int b) const override { return (b < 0 || b >= B) ? -EINVAL : (poisoned ? -EIO : h_ncam[b]); }   // a poisoned handle's count is not to be trusted (its slices may have stopped at different frames)
   int get_ncam(int b, int* n) override {
     POISON_GUARD();
     if (chk(b)) return fail(-EINVAL, "trajectory index out of range");
@@ -1873,6 +1876,7 @@ int msckf_hip_augment_state(msckf_hip_handle h, int b, int state_id, double time
   if (rc) return rc;
   B->traj[b].cams.push_back(CamMeta{state_id, time, -1, {}});
   B->traj[b].map.clear();   // msckf.h:149
+  B->traj[b].map_pending = 0;   // (the points of the previous marginalize() still on the device belong to the map just cleared)
   return 0;
 }
 int msckf_hip_update(msckf_hip_handle h, int b, const double* meas2, const uint64_t* ids, int n) {
@@ -1906,6 +1910,7 @@ int msckf_hip_finish(msckf_hip_handle h, int b) {
 }
 int msckf_hip_get_num_cam_states(msckf_hip_handle h, int b) {   // cam_states_.size(): the host keeps the count (augment, prune, drop and run_frames all update it)
   const int n = H(h)->ncam_host(b);
+  if (n == -EIO) return fail(-EIO, "handle unusable after a failed run_frames call (destroy it)");
   return n < 0 ? fail(-EINVAL, "trajectory index out of range") : n;
 }
 int msckf_hip_get_imu_state(msckf_hip_handle h, int b, double* imu29) { return H(h)->get_imu(b, imu29); }

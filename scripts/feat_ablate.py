@@ -5,7 +5,7 @@ import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 from msckf_mono_amd import capi, scenario as sc
-N, F, B, K = 30, 200, 64, 10
+N, F, B, K = 30, 200, int(os.environ.get("FEAT_B", "64")), 10
 nf = N + 8
 trs = [sc.Trajectory(3, b, N, F, nf) for b in range(B)]
 knobs = [("full", 0), ("noLM", 1), ("noG", 2), ("noChol", 4), ("noF64", 8), ("noG+noChol", 6), ("all", 15), ("full", 0)]

@@ -273,8 +273,8 @@ def test_fp16_jacobian_dtype(capi, po):
     (1) the rounding is active and bounded: against the plain float filter on the same inputs, per update, attitude /
     position / velocity move by < 3e-3, the covariance and the accelerometer bias by < 3e-2, the gyro bias by < 1e-1
     (measured at the 10-camera window: 1e-4, 5e-5, 2e-4, 9e-4, 3e-3, 5e-2; at the 60-camera window P moves by 1.0e-2); (2) cfg5 geometry (60-camera window, 500 tracks): the same envelope
-    against the float oracle -- SURVEY 8d quotes 1e-2 for this configuration, "reported, not gated" -- with equal gate
-    decisions."""
+    against the float oracle with equal gate decisions, AND SURVEY 8d's 1e-2 on q, v, p, camera poses and the IMU block of the covariance as
+    a gate, 1.5e-2 on the full covariance (measured 1.0e-2) (the survey says "reported, not gated"; the biases keep the envelope: their floor is the fp16 significand)."""
     def envelope(e):
         assert max(e["q"], e["p"], e["v"], e["cam_q"], e["cam_p"]) < 3e-3 and max(e["P"], e["Pii"], e["ba"]) < 3e-2 and e["bg"] < 1e-1, e
     N, F, nf = 10, 50, 20
@@ -313,6 +313,11 @@ def test_fp16_jacobian_dtype(capi, po):
         assert so["n_passed"] == sd["n_passed"] > 400, (so, sd)
         e = H.state_errors(bt.imu_state(b2), o.getImuState(), bt.cam_states(b2)[0], o.getCamStates()[0], bt.covariance(b2), o.getCovariance())
         envelope(e)
+        # SURVEY 8d's bar for this configuration, as a gate: 1e-2 against the float oracle on attitude, velocity, position
+        # (IMU and camera states) and on the covariance (full and IMU block)
+        for key in ("q", "v", "p", "cam_q", "cam_p", "Pii"):
+            assert e[key] < 1e-2, (b2, key, e)
+        assert e["P"] < 1.5e-2, (b2, e)     # measured 1.02e-2 / 0.98e-2 on the two trajectories: the full covariance sits AT the survey's figure, not under it
     bt.close()
 
 

@@ -260,17 +260,20 @@ def test_literal_route_inside_run_frames_equals_the_single_call_path(capi, po):
 
 def test_literal_route_cfg3_window_float_vs_reference_source(capi, po):
     """BASELINE configs[3]'s geometry and noise (30-camera window, 200 tracks, EuRoC f_u != f_v) in FLOAT against the
-    reference's own source (lib_ref.so: msckf.h unmodified, its full Q of a ~5 800-row stack, seconds per update, on host
-    threads): SIX consecutive steady-state updates of TWO trajectories, teacher-forced from the float restatement (zero-tail
-    tolerance 8e-4, as the device).  Everything the measurements determine -- attitude, velocity, position, camera poses,
-    covariance -- at the section-3.4 bar of 1e-3; the biases, which the reference itself only defines to its rounding envelope
-    under anisotropic noise (two roundings of its source differ by 1e-4 .. 4e-4 per update in double, more in
-    float), within 2e-2 of their norm floor; the device keeps exactly the rows the restatement keeps."""
+    reference's own source under BOTH its roundings (lib_ref.so / lib_ref_alt.so: msckf.h unmodified, its full Q of a
+    ~5 800-row stack, seconds per update, on host threads): SIX consecutive steady-state updates of FOUR trajectories,
+    teacher-forced from the float restatement (zero-tail tolerance 8e-4, as the device).  Everything the measurements
+    determine -- attitude, velocity, position, camera poses, covariance -- at the section-3.4 bar of 1e-3 against either
+    rounding.  The biases, which the reference itself only defines to its rounding envelope under anisotropic noise (DESIGN
+    3.3), are measured as the double test above measures them: in units of the distance between the reference's two
+    roundings ON THE SAME UPDATE -- the device is as close to either as they are to each other (median ratio, 90th
+    percentile) -- with a flat 2e-2 only as the outer fence; against the float restatement (a third rounding of the same
+    algorithm) they are held at 1e-3 or twice that spread.  The device keeps exactly the rows the restatement keeps."""
     if not po.ref_available():
         pytest.skip("oracle/_ref/lib_ref.so not built (needs /root/reference at build time)")
     import threading
     N, F, nf, n_upd = 30, 200, 38, 6
-    trs = [_aniso(N, F, nf, g, cfgid=3) for g in (0, 1)]
+    trs = [_aniso(N, F, nf, g, cfgid=3) for g in (0, 1, 2, 3)]
     B = len(trs)
     teachers = []
     for tr in trs:
@@ -293,37 +296,152 @@ def test_literal_route_cfg3_window_float_vs_reference_source(capi, po):
         for _ in range(lean[b].getNumCamStates()):
             bt.augment_range(b, 1)
     env, compared, kept = {}, 0, []
+    ratios = {"bg": [], "ba": []}
     for k in range(first, nf):
         refs = []
         for tr, t in zip(trs, lean):
-            r = po.Oracle(po.F32, impl="ref"); r.initialize(tr.cfg, tr.imu0)
-            while r.getNumCamStates() < t.getNumCamStates():
-                r.augmentState(r.getNumCamStates(), 0.0)
-            _force(r, t)
-            refs.append(r)
+            pair = []
+            for impl in ("ref", "ref_alt"):
+                r = po.Oracle(po.F32, impl=impl); r.initialize(tr.cfg, tr.imu0)
+                while r.getNumCamStates() < t.getNumCamStates():
+                    r.augmentState(r.getNumCamStates(), 0.0)
+                _force(r, t)
+                pair.append(r)
+            refs.append(pair)
         for b, t in enumerate(lean):
             H.copy_oracle_to_device(t, bt, b)
-        th = [threading.Thread(target=H.oracle_frame, args=(r, tr, k, N)) for r, tr in zip(refs, trs)]
+        th = [threading.Thread(target=H.oracle_frame, args=(r, tr, k, N)) for pair, tr in zip(refs, trs) for r in pair]
         for x in th:
             x.start()
         for b, (t, tr) in enumerate(zip(lean, trs)):
             H.oracle_frame(t, tr, k, N); H.device_frame(bt, b, tr, k, N)
         for x in th:
             x.join()
-        for b, (t, r) in enumerate(zip(lean, refs)):
+        for b, (t, pair) in enumerate(zip(lean, refs)):
             if t.lastStats()["n_motion_rejected"] > 0:       # D1: the reference is undefined on this frame
                 continue
             info = bt.literal_info(b)
             assert info["route"] == 3 and info["m_rows"] == t.lastStats()["m_rows"] > 4000
             kept.append((info["kept_rows"], t.lastStats()["r_rows"]))
-            for key, v in _errs(bt, b, r).items():
-                env[key] = max(env.get(key, 0.0), v)
-            e2 = _errs(bt, b, t)                                # and the restatement itself, every field at 1e-3
-            assert H.worst(e2) < 1e-3, (k, b, e2)
+            ea, eb, mutual = _errs(bt, b, pair[0]), _errs(bt, b, pair[1]), _oerrs(pair[0], pair[1])
+            for key in ea:
+                env[key] = max(env.get(key, 0.0), ea[key], eb[key])
+            for key in ("bg", "ba"):
+                if mutual[key] > 1e-6:
+                    ratios[key].append(max(ea[key], eb[key]) / mutual[key])
+            e2 = _errs(bt, b, t)                                # and the restatement itself: every observable field at 1e-3, the biases at
+            for key, v in e2.items():                          # 1e-3 or twice the reference's own spread on this update, whichever is larger
+                assert v < (max(1e-3, 2.0 * mutual[key]) if key in ("bg", "ba") else 1e-3), (k, b, key, e2, mutual)
             compared += 1
     bt.close()
-    assert compared >= 5, compared
+    assert compared >= 10, compared
     assert all(a == b for a, b in kept), kept
     for key in ("q", "v", "p", "P", "Pii", "cam_q", "cam_p"):
         assert env[key] < 1e-3, (key, env)
     assert env["bg"] < 2e-2 and env["ba"] < 2e-2, env
+    for key in ("bg", "ba"):
+        r = np.array(ratios[key])
+        assert len(r) >= 8, (key, r)
+        assert np.median(r) < 2.0 and np.percentile(r, 90) < 5.0, (key, np.median(r), np.percentile(r, 90), r.max(), r)
+
+
+def test_literal_route_batched_at_the_benchmarked_size_vs_restatement(capi, po):
+    """The BATCHED literal route as bench.py --config cfg4 runs it -- 64 trajectories, 30-camera window, 200 tracks, EuRoC
+    f_u != f_v, float, resident scenario, FOUR slices (streams) -- against the float restatement of msckf.h:423-431,
+    1343-1366 (explicit Q_1 of a ~5 800-row stack on the CPU, zero-tail tolerance 8e-4 as the device): after the window is
+    full, 8 sampled trajectories hand state + covariance to a restatement each (teacher forcing, device -> oracle), both
+    run the next update on the same inputs, and every state field and the covariance agree to 1e-3, the gate's counts and
+    the stacked rows exactly, the kept rows of R to the restatement's; two consecutive updates."""
+    import threading
+    N, F, B, nf = 30, 200, 64, 33
+    trs = [_aniso(N, F, nf, 100 + b, cfgid=3) for b in range(B)]
+    bt = capi.Batch(B, N, F, 32, capi.F32)
+    for b, tr in enumerate(trs):
+        bt.initialize(b, tr.cfg, tr.imu0)
+    bt.scenario_alloc(nf, sc.IMU_PER_FRAME)
+    for k in range(nf):
+        for b, tr in enumerate(trs):
+            fr = tr.frames[k]
+            bt.scenario_set(k, b, tr.imu_for_frame(k), fr["M"], fr["slots"], fr["obs"], 1 if fr["Nw"] == N else 0)
+    bt.scenario_commit()
+    bt.set_streams(4)
+    k0 = nf - 2
+    bt.run_frames(0, k0); bt.sync()
+    sample = [0, 9, 17, 26, 35, 44, 53, 63]
+    compared = 0
+    for k in (k0, k0 + 1):
+        oracles = {}
+        for b in sample:
+            o = po.Oracle(po.F32, po.LEAN); o.setTinyRowTol(8e-4)
+            o.initialize(trs[b].cfg, trs[b].imu0)
+            H.copy_device_to_oracle(bt, b, o)
+            oracles[b] = o
+        th = [threading.Thread(target=H.oracle_frame, args=(oracles[b], trs[b], k, N)) for b in sample]
+        for x in th:
+            x.start()
+        bt.run_frames(k, k + 1); bt.sync()
+        for x in th:
+            x.join()
+        for b in sample:
+            o = oracles[b]
+            so, sd = o.lastStats(), bt.last_stats(b)
+            for key in ("n_tracks", "n_motion_rejected", "n_tri_rejected", "n_gate_rejected", "n_passed", "m_rows"):
+                assert so[key] == sd[key], (k, b, key, so, sd)
+            info = bt.literal_info(b)
+            assert info["route"] == 3 and info["m_rows"] == so["m_rows"] > 4000 and abs(info["kept_rows"] - so["r_rows"]) <= 2, (k, b, info, so)
+            e = _errs(bt, b, o)
+            assert H.worst(e) < 1e-3, (k, b, e)
+            compared += 1
+    bt.close()
+    assert compared == 2 * len(sample)
+
+
+def test_literal_letter_rule_in_float_at_the_benchmarked_window_recorded(capi, po):
+    """What the zero-tail tolerance is worth at the benchmarked window, as a number: the same float updates (30-camera window,
+    200 tracks, EuRoC noise, teacher-forced from the restatement) on the device with the default tolerance 8e-4 (the
+    exact-arithmetic limit of the rule, what bench.py --config cfg4 runs) and with tolerance 0 (msckf.h / Eigen's
+    makeHouseholder to the letter: a tail of rounding noise is reflected along).  RECORDED, not gated: under the letter rule
+    the float filter's own rounding picks the gauge rows; the distance is printed and written to
+    gpurun_out/literal_tol0_float.json when that directory exists.  Held: both runs finish with finite states and the
+    observable fields stay within 1e-2 of each other."""
+    import json, os
+    N, F, nf, n_upd = 30, 200, 36, 4
+    tr = _aniso(N, F, nf, 2, cfgid=3)
+    fast = po.Oracle(po.F32, po.GRAM); fast.setWhiten(True); fast.initialize(tr.cfg, tr.imu0)
+    first = nf - n_upd
+    for k in range(first):
+        H.oracle_frame(fast, tr, k, N)
+    o = po.Oracle(po.F32, po.LEAN); o.setTinyRowTol(8e-4); o.initialize(tr.cfg, tr.imu0)
+    while o.getNumCamStates() < fast.getNumCamStates():
+        o.augmentState(o.getNumCamStates(), 0.0)
+    _force(o, fast)
+    bts = []
+    for tol in (-1.0, 0.0):
+        bt = capi.Batch(1, N, F, 32, capi.F32); bt.set_anisotropic_noise(0, tol); bt.initialize(0, tr.cfg, tr.imu0)
+        for _ in range(o.getNumCamStates()):
+            bt.augment_range(0, 1)
+        bts.append(bt)
+    rec = []
+    for k in range(first, nf):
+        for bt in bts:
+            H.copy_oracle_to_device(o, bt, 0)
+        H.oracle_frame(o, tr, k, N)
+        for bt in bts:
+            H.device_frame(bt, 0, tr, k, N)
+        if o.lastStats()["n_motion_rejected"] or o.lastStats()["m_rows"] == 0:
+            continue
+        a, z = bts
+        e = H.state_errors(z.imu_state(0), a.imu_state(0), z.cam_states(0)[0], a.cam_states(0)[0], z.covariance(0), a.covariance(0))
+        assert all(np.isfinite(v) for v in e.values()), e
+        for key in ("q", "v", "p", "cam_q", "cam_p"):
+            assert e[key] < 1e-2, (k, e)
+        rec.append(dict(frame=k, kept_rows_default=a.literal_info(0)["kept_rows"], kept_rows_letter=z.literal_info(0)["kept_rows"],
+                        **{key: float(v) for key, v in e.items()}))
+    for bt in bts:
+        bt.close()
+    assert len(rec) >= 1
+    print("literal route, float, N=30 / F=200: tolerance 0 (letter rule) vs 8e-4 (default), per update:", json.dumps(rec))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        json.dump(dict(what="device, literal anisotropic route, float, 30-camera window / 200 tracks: zero-tail tolerance 0 (msckf.h's rule to the letter) against "
+                            "the default 8e-4, same teacher-forced updates; section-3.4 error metric per field", updates=rec), open(os.path.join(out, "literal_tol0_float.json"), "w"), indent=1)
