@@ -137,6 +137,18 @@ int msckf_hip_propagate_range(msckf_hip_handle h, int b0, int nb, const double* 
 int msckf_hip_augment_range(msckf_hip_handle h, int b0, int nb);
 int msckf_hip_marginalize_range(msckf_hip_handle h, int b0, int nb);
 int msckf_hip_drop_oldest_range(msckf_hip_handle h, int b0, int nb, int n_drop);
+/* The ASL runner's per-image cycle (datasets/asl_msckf.cpp:269-294: augmentState, update, addFeatures, marginalize,
+ * pruneRedundantStates :289, pruneEmptyStates) for trajectories b0 .. b0 + nb - 1 IN LOCKSTEP: the feature bookkeeping of every
+ * trajectory (msckf.h:215-332, 453-534, 685-717, 1049-1098) runs on the host as in the per-filter entries, every device stage is one
+ * launch sequence over the range and every read-back (poses for findRedundantCamStates, triangulated points, pruned states' poses)
+ * one copy + one wait for the whole range.  Same results per trajectory as msckf_hip_augment_state / _update / _add_features /
+ * _marginalize / _prune_redundant_states / _prune_empty_states called filter by filter, bit for bit.  IMU samples go in beforehand
+ * through msckf_hip_propagate_range.  state_ids[nb], times[nb] (may be null): augmentState's arguments; upd_* / new_*: update()'s
+ * and addFeatures()'s arguments of the trajectories, concatenated (upd_n[i] / new_n[i] entries each; normalized coordinates, 2 per id).
+ * flags: 1 = pruneRedundantStates, 2 = pruneEmptyStates. */
+int msckf_hip_image_cycle_range(msckf_hip_handle h, int b0, int nb, const int* state_ids, const double* times,
+                                const double* upd_meas2, const uint64_t* upd_ids, const int* upd_n,
+                                const double* new_meas2, const uint64_t* new_ids, const int* new_n, int flags);
 
 /* ---- batched path: HBM-resident scenario (inputs uploaded once, then frames run without host syncs) ---- */
 int msckf_hip_scenario_alloc(msckf_hip_handle h, int n_frames, int K);

@@ -34,6 +34,7 @@ SYMBOLS = [
     "msckf_hip_scenario_pin", "msckf_hip_set_upload_ring", "msckf_hip_clear_error_flags",
     "msckf_hip_set_compression", "msckf_hip_set_covariance_update", "msckf_hip_set_feature_overlap", "msckf_hip_get_pruned_states", "msckf_hip_get_cam_meta", "msckf_hip_get_tracked_feature_ids",
     "msckf_hip_set_anisotropic_noise", "msckf_hip_literal_info", "msckf_hip_get_error_flags", "msckf_hip_copy_state", "msckf_hip_set_host_affinity",
+    "msckf_hip_image_cycle_range",
 ]
 
 
@@ -243,6 +244,21 @@ class Batch:
 
     def drop_oldest_range(self, b0, nb, n):
         _chk(self.L.msckf_hip_drop_oldest_range(self.h, b0, nb, int(n)))
+
+    def image_cycle_range(self, b0, nb, state_ids, times, cur, new, prune_redundant=True, prune_empty=True):
+        """The ASL runner's per-image cycle (asl_msckf.cpp:269-294) for trajectories b0 .. b0 + nb - 1 in lockstep:
+        augmentState, update, addFeatures, marginalize, [pruneRedundantStates], [pruneEmptyStates].
+        cur[i] / new[i] = (measurements [n][2], feature ids [n]) of trajectory b0 + i, as update() / addFeatures() take them."""
+        def cat(parts):
+            n = np.array([len(p[1]) for p in parts], dtype=np.int32)
+            m = np.concatenate([np.asarray(p[0], dtype=np.float64).reshape(-1, 2) for p in parts]) if n.sum() else np.zeros((0, 2))
+            i = np.concatenate([np.asarray(p[1], dtype=np.uint64).reshape(-1) for p in parts]) if n.sum() else np.zeros(0, dtype=np.uint64)
+            return np.ascontiguousarray(m, dtype=np.float64), np.ascontiguousarray(i, dtype=np.uint64), n
+        um, ui, un = cat(cur); nm, ni, nn = cat(new)
+        sid, psid = _i(np.asarray(state_ids).reshape(nb)); tt, ptt = _d(np.asarray(times, dtype=np.float64).reshape(nb))
+        _chk(self.L.msckf_hip_image_cycle_range(self.h, b0, nb, psid, ptt, um.ctypes.data_as(_dp), ui.ctypes.data_as(_up), un.ctypes.data_as(_ip),
+                                                nm.ctypes.data_as(_dp), ni.ctypes.data_as(_up), nn.ctypes.data_as(_ip),
+                                                (1 if prune_redundant else 0) | (2 if prune_empty else 0)))
 
     def scenario_alloc(self, n_frames, K):
         _chk(self.L.msckf_hip_scenario_alloc(self.h, n_frames, K))

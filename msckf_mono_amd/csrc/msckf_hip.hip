@@ -17,6 +17,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <unordered_map>
+#include <unordered_set>
 
 #include "../../include/msckf_hip.h"
 #include <atomic>
@@ -98,6 +100,12 @@ struct BatchBase {
   virtual int feature_only(int b, int* status, double* pf3, int cap) = 0;  // checkMotion + triangulation of the work-list
   virtual int marginalize_given(int b) = 0;                               // second update of pruneRedundantStates
   virtual int prune_keep(int b, const std::vector<int>& keep) = 0;
+  // range forms for the batched image cycle (host_image_cycle): one copy / one launch for trajectories b0 .. b0 + nb - 1
+  virtual int cams_range(int b0, int nb, double* poses7) = 0;                                  // [nb][n_cap][7], one read + one wait
+  virtual int feature_only_range(int b0, int nb, int* status, double* pf3, bool launch) = 0;   // [nb][f_cap], [nb][f_cap][3]; launch = false: only read what the last launch left
+  virtual int set_given_range(int b0, int nb, const double* pf3) = 0;                          // [nb][f_cap][3]
+  virtual int marginalize_given_range(int b0, int nb) = 0;
+  virtual int prune_keep_range(int b0, int nb, const std::vector<std::vector<int>>& keep) = 0; // keep[i]: ascending slots of trajectory b0 + i
   virtual int drop_oldest(int b0, int nb, int n) = 0;
   virtual int get_ncam(int b, int* n) = 0;
   virtual int ncam_host(int b) const = 0;   // the window size from the host's own count (kept through every entry that changes it): no device read
@@ -826,6 +834,81 @@ struct Batch : BatchBase {
     HIPCHK(hipGetLastError());
     return 0;
   }
+  // ---- range forms (host_image_cycle)
+  int cams_range(int b0, int nb, double* poses7) override {
+    POISON_GUARD();
+    if (chk_range(b0, nb)) return fail(-EINVAL, "trajectory range out of bounds");
+    DEVICE_ENTER();
+    const size_t per = (size_t)n_cap * CAM_STRIDE;
+    std::vector<S> tmp(per * nb);
+    HIPCHK(hipMemcpyAsync(tmp.data(), d.cam + (size_t)b0 * per, tmp.size() * sizeof(S), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < nb; ++i)
+      for (int c = 0; c < n_cap; ++c)
+        for (int k = 0; k < 7; ++k) poses7[((size_t)i * n_cap + c) * 7 + k] = (double)tmp[(size_t)i * per + (size_t)c * CAM_STRIDE + k];
+    return 0;
+  }
+  int feature_only_range(int b0, int nb, int* status, double* pf3, bool launch) override {
+    POISON_GUARD();
+    if (chk_range(b0, nb)) return fail(-EINVAL, "trajectory range out of bounds");
+    DEVICE_ENTER();
+    if (launch) { use_single_worklists(); launch_feature<S>(view(b0), b0, nb, st); HIPCHK(hipGetLastError()); }
+    std::vector<int> stt((size_t)nb * f_cap); std::vector<S> pf((size_t)nb * f_cap * 4);
+    HIPCHK(hipMemcpyAsync(stt.data(), d.trk_status + (size_t)b0 * f_cap, stt.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(pf.data(), d.trk_pf + (size_t)b0 * f_cap * 4, pf.size() * sizeof(S), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (size_t t = 0; t < stt.size(); ++t) { status[t] = stt[t]; for (int k = 0; k < 3; ++k) pf3[3 * t + k] = (double)pf[4 * t + k]; }
+    return 0;
+  }
+  int set_given_range(int b0, int nb, const double* pf3) override {
+    if (chk_range(b0, nb)) return fail(-EINVAL, "trajectory range out of bounds");
+    DEVICE_ENTER();
+    const size_t cnt = (size_t)nb * f_cap * 4;
+    unsigned char* raw = nullptr;
+    int rc = stage_acquire(cnt * sizeof(S), &raw);
+    if (rc) return rc;
+    S* tmp = reinterpret_cast<S*>(raw);
+    for (size_t t = 0; t < (size_t)nb * f_cap; ++t) { for (int k = 0; k < 3; ++k) tmp[4 * t + k] = (S)pf3[3 * t + k]; tmp[4 * t + 3] = S(0); }
+    HIPCHK(hipMemcpyAsync(d_pfin + (size_t)b0 * f_cap * 4, tmp, cnt * sizeof(S), hipMemcpyHostToDevice, st));
+    return stage_release();
+  }
+  int marginalize_given_range(int b0, int nb) override {
+    POISON_GUARD();
+    if (chk_range(b0, nb)) return fail(-EINVAL, "trajectory range out of bounds");
+    DEVICE_ENTER();
+    use_single_worklists();
+    Dev<S> v = view(b0);
+    v.mode = 1;
+    launch_update(v, b0, nb, st);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  int prune_keep_range(int b0, int nb, const std::vector<std::vector<int>>& keep) override {
+    POISON_GUARD();
+    if (chk_range(b0, nb) || (int)keep.size() != nb) return fail(-EINVAL, "trajectory range out of bounds");
+    DEVICE_ENTER();
+    // [nb][n_cap] slots + [nb] counts through the pinned ring, two copies, one launch (a trajectory that keeps everything is a no-op there)
+    const size_t nI = (size_t)nb * n_cap + nb;
+    unsigned char* raw = nullptr;
+    int rc = stage_acquire(nI * sizeof(int), &raw);
+    if (rc) return rc;
+    int* hk = reinterpret_cast<int*>(raw); int* hn = hk + (size_t)nb * n_cap;
+    std::memset(hk, 0, nI * sizeof(int));
+    for (int i = 0; i < nb; ++i) {
+      const int nk = (int)keep[i].size();
+      if (nk > n_cap) return fail(-EINVAL, "keep list longer than n_cap");
+      hn[i] = nk;
+      for (int k = 0; k < nk; ++k) hk[(size_t)i * n_cap + k] = keep[i][k];
+    }
+    HIPCHK(hipMemcpyAsync(d.keep + (size_t)b0 * n_cap, hk, (size_t)nb * n_cap * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d.nkeep + b0, hn, nb * sizeof(int), hipMemcpyHostToDevice, st));
+    rc = stage_release();
+    if (rc) return rc;
+    launch_prune<S>(d, b0, nb, st);
+    for (int i = 0; i < nb; ++i) h_ncam[b0 + i] = (int)keep[i].size();
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   int drop_oldest(int b0, int nb, int n) override;
   int ncam_host(int b) const override { return (b < 0 || b >= B) ? -EINVAL : (poisoned ? -EIO : h_ncam[b]); }   // a poisoned handle's count is not to be trusted (its slices may have stopped at different frames)
   int get_ncam(int b, int* n) override {
@@ -1531,46 +1614,82 @@ void remove_tracked_feature(HostTraj& t, uint64_t fid, std::vector<int>& slots) 
   }
 }
 
+// update(), msckf.h:215-300, with the reference's results and none of its quadratic searches.  The reference looks every tracked
+// feature up in the incoming ids by linear search (:226), removes an ended feature from every camera state's list by linear
+// search + erase (removeTrackedFeature :1469-1485) and erases the ended tracks one by one (:283-298): O(tracked x incoming) +
+// O(ended x cameras x tracked) per image -- 43 us of the single filter's 286 us at 50 features per image (round-5 verdict), tens of
+// milliseconds per filter at the benchmark's 200.  Here: one hash table of the incoming ids (first occurrence, as std::find
+// returns), one table "feature -> camera slots that list it" built from the lists as they stand after this image's
+// registrations, ONE stable filter pass per camera list and per track list.  Every list ends in the order the reference leaves it.
 int host_update(BatchBase* B, int b, const double* meas, const uint64_t* ids, int n) {
   HostTraj& t = B->traj[b];
   if (!t.initialized) return fail(-EINVAL, "trajectory not initialized");
   if (t.cams.empty()) return fail(-EINVAL, "update() before augmentState() (msckf.h:238 dereferences cam_states_.end()-1)");
   t.to_resid.clear();
-  std::vector<uint64_t> to_remove;
-  size_t id_iter = 0;
-  for (uint64_t fid : t.tracked_ids) {
-    const uint64_t* it = std::find(ids, ids + n, fid);
-    const bool valid = it != ids + n;
-    Track& tr = t.tracks[id_iter];
+  std::unordered_map<uint64_t, int> first;
+  first.reserve((size_t)n * 2 + 16);
+  for (int k = 0; k < n; ++k) first.emplace(ids[k], k);                      // keeps the first occurrence (std::find, :226)
+  // pass 1 (:224-247): register this image's observation; which tracks end here
+  const size_t nt = t.tracked_ids.size();
+  std::vector<char> ended(nt, 0);
+  size_t n_ended = 0;
+  for (size_t i = 0; i < nt; ++i) {
+    const uint64_t fid = t.tracked_ids[i];
+    Track& tr = t.tracks[i];
+    const auto it = first.find(fid);
+    const bool valid = it != first.end();
     if (valid) {
-      const size_t k = (size_t)(it - ids);
+      const size_t k = (size_t)it->second;
       tr.obs.push_back(meas[2 * k]); tr.obs.push_back(meas[2 * k + 1]);
       t.cams.back().tracked.push_back(fid);
       tr.cam_ids.push_back(t.cams.back().state_id);
     }
-    if (!valid || tr.obs.size() / 2 >= (size_t)t.max_track_length) {
-      TrackToResid r;
-      remove_tracked_feature(t, fid, r.slots);
-      if (r.slots.size() >= (size_t)t.min_track_length) {
-        r.id = tr.id; r.obs = std::move(tr.obs);        // (the track is erased below: its observations move, they are not copied)
-        t.to_resid.push_back(std::move(r));
-      }
-      to_remove.push_back(fid);
-    }
-    id_iter++;
+    if (!valid || tr.obs.size() / 2 >= (size_t)t.max_track_length) { ended[i] = 1; ++n_ended; }
   }
-  for (uint64_t fid : to_remove) {
-    for (size_t i = 0; i < t.tracks.size(); ++i)
-      if (t.tracks[i].id == fid) {
-        const int last_id = t.tracks[i].cam_ids.back();
-        for (int idx : t.tracks[i].cam_ids)
-          for (auto& cs : t.cams)
-            if (cs.tracked.empty() && cs.state_id == idx) cs.last_correlated_id = last_id;
-        t.tracks.erase(t.tracks.begin() + i);
-        break;
-      }
-    auto c = std::find(t.tracked_ids.begin(), t.tracked_ids.end(), fid);
-    if (c != t.tracked_ids.end()) t.tracked_ids.erase(c);
+  if (!n_ended) return 0;
+  // pass 2 (:249-265 + removeTrackedFeature): the camera slots that list an ended feature, in camera order
+  std::unordered_map<uint64_t, std::vector<int>> where;
+  where.reserve(n_ended * 2 + 16);
+  for (size_t i = 0; i < nt; ++i) if (ended[i]) where.emplace(t.tracked_ids[i], std::vector<int>());
+  for (size_t c = 0; c < t.cams.size(); ++c) {
+    auto& lst = t.cams[c].tracked;
+    size_t w = 0;
+    for (size_t r = 0; r < lst.size(); ++r) {
+      const auto it = where.find(lst[r]);
+      if (it != where.end() && (it->second.empty() || it->second.back() != (int)c)) { it->second.push_back((int)c); continue; }   // first occurrence in this list leaves it
+      lst[w++] = lst[r];
+    }
+    lst.resize(w);
+  }
+  for (size_t i = 0; i < nt; ++i) {
+    if (!ended[i]) continue;
+    Track& tr = t.tracks[i];
+    std::vector<int>& slots = where[t.tracked_ids[i]];
+    if (slots.size() >= (size_t)t.min_track_length) {
+      TrackToResid r;
+      r.id = tr.id; r.obs = std::move(tr.obs); r.slots = std::move(slots);   // (the track is erased below: its observations move, they are not copied)
+      t.to_resid.push_back(std::move(r));
+    }
+  }
+  // pass 3 (:283-298): last_correlated_id of the camera states an ended track leaves empty, then the tracks themselves
+  std::unordered_map<int, size_t> cam_of;
+  for (size_t c = 0; c < t.cams.size(); ++c) cam_of.emplace(t.cams[c].state_id, c);
+  for (size_t i = 0; i < nt; ++i) {
+    if (!ended[i] || t.tracks[i].cam_ids.empty()) continue;
+    const int last_id = t.tracks[i].cam_ids.back();
+    for (int idx : t.tracks[i].cam_ids) {
+      const auto it = cam_of.find(idx);
+      if (it != cam_of.end() && t.cams[it->second].tracked.empty()) t.cams[it->second].last_correlated_id = last_id;
+    }
+  }
+  {
+    size_t w = 0;
+    for (size_t i = 0; i < nt; ++i) {
+      if (ended[i]) continue;
+      if (w != i) { t.tracks[w] = std::move(t.tracks[i]); t.tracked_ids[w] = t.tracked_ids[i]; }
+      ++w;
+    }
+    t.tracks.resize(w); t.tracked_ids.resize(w);
   }
   return 0;
 }
@@ -1579,14 +1698,15 @@ int host_add_features(BatchBase* B, int b, const double* meas, const uint64_t* i
   HostTraj& t = B->traj[b];
   if (!t.initialized) return fail(-EINVAL, "trajectory not initialized");
   if (t.cams.empty()) return fail(-EINVAL, "addFeatures() before augmentState() (msckf.h:320)");
+  std::unordered_set<uint64_t> known(t.tracked_ids.begin(), t.tracked_ids.end());
   for (int i = 0; i < n; ++i) {
-    if (std::find(t.tracked_ids.begin(), t.tracked_ids.end(), ids[i]) != t.tracked_ids.end())
+    if (!known.insert(ids[i]).second)
       return fail(-EEXIST, "added new feature that was already being tracked");   // msckf.h:328-329 prints and returns
     Track tr; tr.id = ids[i];
     tr.obs.push_back(meas[2 * i]); tr.obs.push_back(meas[2 * i + 1]);
     t.cams.back().tracked.push_back(ids[i]);
     tr.cam_ids.push_back(t.cams.back().state_id);
-    t.tracks.push_back(tr);
+    t.tracks.push_back(std::move(tr));
     t.tracked_ids.push_back(ids[i]);
   }
   return 0;
@@ -1815,6 +1935,268 @@ int host_finish(BatchBase* B, int b) {
   return host_marginalize(B, b);
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// One image of the ASL runner's loop (asl_msckf.cpp:269-294) for trajectories b0 .. b0 + nb - 1 of a batch IN LOCKSTEP:
+//   augmentState -> update -> addFeatures -> marginalize -> [pruneRedundantStates] -> [pruneEmptyStates]
+// The bookkeeping of every trajectory (msckf.h:215-332, 453-534, 685-717, 1049-1098) runs on the host exactly as in the
+// per-filter entries above -- same functions --, the device work of a stage goes out as ONE launch sequence over the range
+// (the kernels index trajectories; a run of trajectories with nothing to do is skipped) and what a stage needs back -- poses for
+// findRedundantCamStates, triangulated points of not-yet-initialized features, poses of the states about to be pruned --
+// comes back in one read and one wait per stage for the whole range, instead of one per filter.
+// Same arithmetic per trajectory as the per-filter calls (tests/test_gpu_parity.py: bit for bit).
+// -------------------------------------------------------------------------------------------------
+template <class Fn> static int for_runs(const std::vector<char>& on, int b0, Fn fn) {
+  const int nb = (int)on.size();
+  for (int i = 0; i < nb;) {
+    if (!on[i]) { ++i; continue; }
+    int j = i;
+    while (j < nb && on[j]) ++j;
+    const int rc = fn(b0 + i, j - i);
+    if (rc) return rc;
+    i = j;
+  }
+  return 0;
+}
+
+int host_image_cycle(BatchBase* B, int b0, int nb, const int* state_ids, const double* times,
+                     const double* upd_meas, const uint64_t* upd_ids, const int* upd_n,
+                     const double* new_meas, const uint64_t* new_ids, const int* new_n, int flags) {
+  if (b0 < 0 || nb <= 0 || b0 + nb > B->B) return fail(-EINVAL, "trajectory range out of bounds");
+  const int n_cap = B->n_cap, f_cap = B->f_cap;
+  for (int i = 0; i < nb; ++i) {
+    const HostTraj& t = B->traj[b0 + i];
+    if (!t.initialized) return fail(-EINVAL, "trajectory not initialized");
+    if ((int)t.cams.size() >= n_cap) return fail(-EOVERFLOW, "camera-state capacity n_cap exceeded");
+  }
+  // ---- augmentState :148-212
+  int rc = B->augment(b0, nb);
+  if (rc) return rc;
+  for (int i = 0; i < nb; ++i) {
+    HostTraj& t = B->traj[b0 + i];
+    t.cams.push_back(CamMeta{state_ids[i], times ? times[i] : 0.0, -1, {}});
+    t.map.clear(); t.map_pending = 0;
+  }
+  // ---- update :215-300, addFeatures :302-332 (host)
+  {
+    size_t ou = 0, on = 0;
+    for (int i = 0; i < nb; ++i) {
+      rc = host_update(B, b0 + i, upd_meas + 2 * ou, upd_ids + ou, upd_n[i]);
+      if (rc) return rc;
+      rc = host_add_features(B, b0 + i, new_meas + 2 * on, new_ids + on, new_n[i]);
+      if (rc) return rc;
+      ou += (size_t)upd_n[i]; on += (size_t)new_n[i];
+    }
+  }
+  // ---- marginalize :336-449
+  std::vector<char> has(nb, 0);
+  {
+    std::vector<int> M, slots; std::vector<double> obs;
+    for (int i = 0; i < nb; ++i) {
+      HostTraj& t = B->traj[b0 + i];
+      const int F = (int)t.to_resid.size();
+      if (F > f_cap) return fail(-E2BIG, "more tracks to residualize than f_cap");
+      M.assign(F, 0); slots.clear(); obs.clear();
+      for (int k = 0; k < F; ++k) {
+        M[k] = (int)t.to_resid[k].slots.size();
+        slots.insert(slots.end(), t.to_resid[k].slots.begin(), t.to_resid[k].slots.end());
+        obs.insert(obs.end(), t.to_resid[k].obs.begin(), t.to_resid[k].obs.end());
+      }
+      int z = 0;
+      rc = F ? B->set_tracks(b0 + i, F, M.data(), slots.data(), obs.data()) : B->set_tracks(b0 + i, 0, &z, &z, nullptr);
+      if (rc) return rc;
+      if (!F) { rc = B->clear_stats(b0 + i); if (rc) return rc; }
+      has[i] = F > 0;
+      t.map_pending = F;
+    }
+    rc = for_runs(has, b0, [&](int s0, int n) { return B->marginalize(s0, n); });
+    if (rc) return rc;
+  }
+  // ---- pruneRedundantStates :453-682
+  if (flags & 1) {
+    std::vector<char> act(nb, 0);
+    bool any = false;
+    for (int i = 0; i < nb; ++i) { act[i] = B->traj[b0 + i].cams.size() >= 20; any |= act[i] != 0; }   // :455
+    if (any) {
+      std::vector<int> status((size_t)nb * f_cap);
+      std::vector<double> pf((size_t)nb * f_cap * 3), poses((size_t)nb * n_cap * 7);
+      // what resolve_map() fetches per filter: the points of the marginalize just launched (the work-lists are reused below)
+      rc = B->feature_only_range(b0, nb, status.data(), pf.data(), false);
+      if (rc) return rc;
+      rc = B->cams_range(b0, nb, poses.data());
+      if (rc) return rc;
+      std::vector<std::vector<int>> rm(nb);
+      std::vector<std::vector<size_t>> cand(nb);
+      std::vector<char> has_cand(nb, 0), has_upd(nb, 0);
+      auto involved_of = [&](int i, const Track& tr) {
+        std::vector<int> inv;
+        for (int cam_id : rm[i]) if (std::find(tr.cam_ids.begin(), tr.cam_ids.end(), cam_id) != tr.cam_ids.end()) inv.push_back(cam_id);
+        return inv;
+      };
+      for (int i = 0; i < nb; ++i) {
+        if (!act[i]) continue;
+        HostTraj& t = B->traj[b0 + i];
+        const int F = t.map_pending; t.map_pending = 0;
+        for (int k = 0; k < F; ++k) {
+          const int sx = status[(size_t)i * f_cap + k];
+          if (((sx & ST_MOTION_SKIPPED) || (sx & ST_MOTION_OK)) && (sx & ST_TRI_VALID)) t.map.insert(t.map.end(), &pf[((size_t)i * f_cap + k) * 3], &pf[((size_t)i * f_cap + k) * 3] + 3);
+        }
+        const int n = (int)t.cams.size();
+        std::vector<double> pz(&poses[(size_t)i * n_cap * 7], &poses[(size_t)i * n_cap * 7] + (size_t)n * 7);
+        find_redundant(t, pz, rm[i]);
+        // first loop :466-534
+        for (size_t k = 0; k < t.tracks.size(); ++k) {
+          Track& tr = t.tracks[k];
+          std::vector<int> inv = involved_of(i, tr);
+          if (inv.empty()) continue;
+          if (inv.size() == 1) { erase_involved(tr, inv); continue; }
+          if (!tr.initialized) cand[i].push_back(k);
+        }
+        if ((int)cand[i].size() > f_cap) return fail(-E2BIG, "more candidate features than f_cap");
+        if (!cand[i].empty()) {
+          std::vector<int> M, slots; std::vector<double> obs;
+          for (size_t ci : cand[i]) {
+            const Track& tr = t.tracks[ci];
+            int m = 0;
+            for (int p2 = 0; p2 < n; ++p2) {
+              auto it = std::find(tr.cam_ids.begin(), tr.cam_ids.end(), t.cams[p2].state_id);
+              if (it == tr.cam_ids.end()) continue;
+              const size_t k = (size_t)(it - tr.cam_ids.begin());
+              slots.push_back(p2); obs.push_back(tr.obs[2 * k]); obs.push_back(tr.obs[2 * k + 1]); ++m;
+            }
+            M.push_back(m);
+          }
+          rc = B->set_tracks(b0 + i, (int)cand[i].size(), M.data(), slots.data(), obs.data());
+          if (rc) return rc;
+          has_cand[i] = 1;
+        }
+      }
+      // checkMotion + initializePosition of the not-yet-initialized features, every trajectory's in one launch per run
+      {
+        bool anyc = false;
+        for (int i = 0; i < nb; ++i) anyc |= has_cand[i] != 0;
+        if (anyc) {
+          // (feature_only_range launches over the runs; the read-back covers the whole range once)
+          rc = for_runs(has_cand, b0, [&](int s0, int n) { return B->feature_only_range(s0, n, status.data() + (size_t)(s0 - b0) * f_cap, pf.data() + (size_t)(s0 - b0) * f_cap * 3, true); });
+          if (rc) return rc;
+          for (int i = 0; i < nb; ++i) {
+            if (!has_cand[i]) continue;
+            HostTraj& t = B->traj[b0 + i];
+            for (size_t c = 0; c < cand[i].size(); ++c) {
+              Track& tr = t.tracks[cand[i][c]];
+              const int sx = status[(size_t)i * f_cap + c];
+              const double* pc = &pf[((size_t)i * f_cap + c) * 3];
+              const bool ok = (sx & ST_MOTION_OK) && (sx & ST_TRI_VALID);
+              if (!ok) erase_involved(tr, involved_of(i, tr));                      // :496-524
+              else { tr.initialized = true; for (int k = 0; k < 3; ++k) tr.p_f_G[k] = pc[k]; t.map.insert(t.map.end(), pc, pc + 3); }
+            }
+          }
+        }
+      }
+      // second loop :545-607: the work-lists of the second update
+      std::vector<std::vector<size_t>> used(nb);
+      std::vector<double> pfin((size_t)nb * f_cap * 3, 0.0);
+      for (int i = 0; i < nb; ++i) {
+        if (!act[i]) continue;
+        HostTraj& t = B->traj[b0 + i];
+        const int n = (int)t.cams.size();
+        auto slot_of = [&](int cam_id) { for (int q = 0; q < n; ++q) if (t.cams[q].state_id == cam_id) return q; return -1; };
+        std::vector<int> M, slots; std::vector<double> obs;
+        for (size_t k = 0; k < t.tracks.size(); ++k) {
+          Track& tr = t.tracks[k];
+          std::vector<int> inv = involved_of(i, tr);
+          if (inv.empty()) continue;
+          for (int cam_id : inv) {
+            const size_t q = (size_t)(std::find(tr.cam_ids.begin(), tr.cam_ids.end(), cam_id) - tr.cam_ids.begin());
+            slots.push_back(slot_of(cam_id)); obs.push_back(tr.obs[2 * q]); obs.push_back(tr.obs[2 * q + 1]);
+          }
+          for (int q = 0; q < 3; ++q) pfin[((size_t)i * f_cap + M.size()) * 3 + q] = tr.p_f_G[q];
+          M.push_back((int)inv.size());
+          used[i].push_back(k);
+          if ((int)M.size() > f_cap) return fail(-E2BIG, "more features than f_cap");
+        }
+        if (!M.empty()) {
+          rc = B->set_tracks(b0 + i, (int)M.size(), M.data(), slots.data(), obs.data());
+          if (rc) return rc;
+          has_upd[i] = 1;
+        }
+      }
+      {
+        bool anyu = false;
+        for (int i = 0; i < nb; ++i) anyu |= has_upd[i] != 0;
+        if (anyu) {
+          rc = B->set_given_range(b0, nb, pfin.data());
+          if (rc) return rc;
+          rc = for_runs(has_upd, b0, [&](int s0, int n) { return B->marginalize_given_range(s0, n); });
+          if (rc) return rc;
+        }
+      }
+      for (int i = 0; i < nb; ++i) {
+        HostTraj& t = B->traj[b0 + i];
+        for (size_t k : used[i]) erase_involved(t.tracks[k], involved_of(i, t.tracks[k]));
+      }
+      // prune the removed camera states :616-681 (poses as corrected by the second update: :614 precedes :631)
+      bool anyrm = false;
+      for (int i = 0; i < nb; ++i) anyrm |= !rm[i].empty();
+      if (anyrm) {
+        rc = B->cams_range(b0, nb, poses.data());
+        if (rc) return rc;
+        std::vector<std::vector<int>> keep(nb);
+        for (int i = 0; i < nb; ++i) {
+          HostTraj& t = B->traj[b0 + i];
+          const int n = (int)t.cams.size();
+          std::vector<CamMeta> kept;
+          for (int q = 0; q < n; ++q) {
+            if (!rm[i].empty() && std::find(rm[i].begin(), rm[i].end(), t.cams[q].state_id) != rm[i].end()) {
+              PrunedState ps{t.cams[q].state_id, t.cams[q].time, t.cams[q].last_correlated_id, {0}};
+              std::copy(&poses[((size_t)i * n_cap + q) * 7], &poses[((size_t)i * n_cap + q) * 7] + 7, ps.pose);
+              t.pruned.push_back(ps);
+            } else { keep[i].push_back(q); kept.push_back(t.cams[q]); }
+          }
+          if ((int)keep[i].size() != n) t.cams = kept;
+        }
+        rc = B->prune_keep_range(b0, nb, keep);
+        if (rc) return rc;
+      }
+    }
+  }
+  // ---- pruneEmptyStates :685-761
+  if (flags & 2) {
+    std::vector<int> last(nb, -1);
+    bool any = false;
+    for (int i = 0; i < nb; ++i) {
+      const HostTraj& t = B->traj[b0 + i];
+      const int max_states = t.max_cam_states, num = (int)t.cams.size();
+      if (num < max_states || !t.cams.front().tracked.empty()) continue;
+      int last_to_remove = num - max_states - 1;
+      for (int q = 1; q < num - max_states; q++)
+        if (!t.cams[q].tracked.empty()) { last_to_remove = q - 1; break; }
+      last[i] = last_to_remove;
+      any |= last_to_remove >= 0;
+    }
+    if (any) {
+      std::vector<double> poses((size_t)nb * n_cap * 7);
+      rc = B->cams_range(b0, nb, poses.data());    // pruned_states_ keeps the whole camState (msckf.h:714)
+      if (rc) return rc;
+      std::vector<std::vector<int>> keep(nb);
+      for (int i = 0; i < nb; ++i) {
+        HostTraj& t = B->traj[b0 + i];
+        const int num = (int)t.cams.size();
+        for (int q = 0; q <= last[i]; ++q) {
+          PrunedState ps{t.cams[q].state_id, t.cams[q].time, t.cams[q].last_correlated_id, {0}};
+          std::copy(&poses[((size_t)i * n_cap + q) * 7], &poses[((size_t)i * n_cap + q) * 7] + 7, ps.pose);
+          t.pruned.push_back(ps);
+        }
+        for (int q = last[i] + 1; q < num; ++q) keep[i].push_back(q);
+        if (last[i] >= 0) t.cams.erase(t.cams.begin(), t.cams.begin() + last[i] + 1);
+      }
+      rc = B->prune_keep_range(b0, nb, keep);
+      if (rc) return rc;
+    }
+  }
+  return 0;
+}
+
 BatchBase* H(msckf_hip_handle h) { return reinterpret_cast<BatchBase*>(h); }
 }  // namespace
 
@@ -1898,6 +2280,14 @@ int msckf_hip_prune_empty_states(msckf_hip_handle h, int b) {
   if (b < 0 || b >= H(h)->B) return fail(-EINVAL, "trajectory index out of range");
   StageRange r("msckf_prune_empty_states");
   return host_prune_empty(H(h), b);
+}
+int msckf_hip_image_cycle_range(msckf_hip_handle h, int b0, int nb, const int* state_ids, const double* times,
+                                const double* upd_meas2, const uint64_t* upd_ids, const int* upd_n,
+                                const double* new_meas2, const uint64_t* new_ids, const int* new_n, int flags) {
+  if (!h) return fail(-EINVAL, "null handle");
+  if (!state_ids || !upd_n || !new_n) return fail(-EINVAL, "null argument");
+  StageRange r("msckf_image_cycle_range");
+  return host_image_cycle(H(h), b0, nb, state_ids, times, upd_meas2, upd_ids, upd_n, new_meas2, new_ids, new_n, flags);
 }
 int msckf_hip_prune_redundant_states(msckf_hip_handle h, int b) {
   if (b < 0 || b >= H(h)->B) return fail(-EINVAL, "trajectory index out of range");

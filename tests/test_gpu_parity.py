@@ -177,6 +177,71 @@ def test_prune_redundant_states_vs_oracle(capi, po):
     assert np.array_equal(pf[:, 7:9], pr[:, 7:9]) and np.allclose(pf[:, :7], pr[:, :7], atol=1e-7)
 
 
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_batched_image_cycle_with_prune_redundant_equals_per_filter_calls_and_oracle(capi, po, prec):
+    """msckf_hip_image_cycle_range: the ASL runner's per-image cycle (asl_msckf.cpp:269-294, pruneRedundantStates :289 included)
+    for a BATCH of trajectories in lockstep -- host bookkeeping per trajectory, every device stage one launch sequence over
+    the range, every read-back one copy for the range.  (1) bit for bit the per-filter API (augmentState / update /
+    addFeatures / marginalize / pruneRedundantStates / pruneEmptyStates called filter by filter on a second handle): state,
+    camera states and their ids, covariance, pruned states, after every image; (2) against the oracle running the same
+    cycle: 1e-6 in double after every image, free-running; in float the two free-running filters are compared at the end (2e-2)
+    when they selected the same keyframes."""
+    N, F, nf, B = 26, 12, 40, 5
+    cd, pd, tol = (capi.F64, po.F64, 1e-6) if prec == "f64" else (capi.F32, po.F32, 1e-3)
+    cfg = sc.filter_config(N)
+    cfg["max_cam_states"] = 20
+    cfg["redundancy_distance_thresh"] = 0.25
+    cfg["redundancy_angle_thresh"] = 0.25
+    trs = [sc.Trajectory(2, 70 + b, N, F, nf, cfg=cfg) for b in range(B)]
+    sts = [tr.stream() for tr in trs]
+    one, big = capi.Batch(B, 40, 128, 40, cd), capi.Batch(B, 40, 128, 40, cd)
+    oracles = []
+    for b, tr in enumerate(trs):
+        one.initialize(b, tr.cfg, tr.imu0); big.initialize(b, tr.cfg, tr.imu0)
+        o = po.Oracle(pd, po.LEAN); o.initialize(tr.cfg, tr.imu0); oracles.append(o)
+    pruned_any = 0
+    for k in range(nf):
+        # per filter, as the shim calls them
+        for b, tr in enumerate(trs):
+            one.propagate_range(b, 1, tr.imu_for_frame(k))
+            one.augment_state(b, k, tr.frame_times[k])
+            one.update(b, sts[b][k]["cur"][0], sts[b][k]["cur"][1])
+            one.add_features(b, sts[b][k]["new"][0], sts[b][k]["new"][1])
+            one.marginalize(b)
+            one.prune_redundant_states(b)
+            one.prune_empty_states(b)
+        # the batch in lockstep
+        big.propagate_range(0, B, np.stack([tr.imu_for_frame(k) for tr in trs]))
+        big.image_cycle_range(0, B, [k] * B, [tr.frame_times[k] for tr in trs], [sts[b][k]["cur"] for b in range(B)], [sts[b][k]["new"] for b in range(B)])
+        for b, tr in enumerate(trs):
+            o = oracles[b]
+            o.propagate(tr.imu_for_frame(k)); o.augmentState(k, tr.frame_times[k])
+            o.update(sts[b][k]["cur"][0], sts[b][k]["cur"][1]); o.addFeatures(sts[b][k]["new"][0], sts[b][k]["new"][1])
+            o.marginalize(); n_before = o.getNumCamStates(); o.pruneRedundantStates(); pruned_any += o.getNumCamStates() < n_before; o.pruneEmptyStates()
+            assert big.num_cam_states(b) == one.num_cam_states(b), (k, b)
+            assert np.array_equal(big.cam_states(b)[1], one.cam_states(b)[1]), (k, b)
+            if prec == "f64":
+                assert big.num_cam_states(b) == o.getNumCamStates() and np.array_equal(big.cam_states(b)[1], o.getCamStates()[1]), (k, b)
+            assert np.array_equal(big.imu_state(b), one.imu_state(b)), (k, b)
+            assert np.array_equal(big.cam_states(b)[0], one.cam_states(b)[0]), (k, b)
+            assert np.array_equal(big.covariance(b), one.covariance(b)), (k, b)
+            if prec == "f64":
+                e = _errs(big, b, o)
+                assert H.worst(e) < tol, (k, b, e)
+    assert pruned_any >= B          # every trajectory pruned redundant states at least once
+    for b in range(B):
+        assert np.array_equal(big.pruned_state_ids(b), one.pruned_state_ids(b))
+        assert np.array_equal(big.pruned_states(b), one.pruned_states(b))
+        if prec == "f64":
+            assert np.array_equal(big.pruned_state_ids(b), oracles[b].getPrunedIds())
+        elif np.array_equal(big.cam_states(b)[1], oracles[b].getCamStates()[1]):
+            # float, free-running against a free-running float oracle over 40 images: as long as both selected the same
+            # keyframes (threshold decisions on float poses may flip) the filters stay together
+            e = _errs(big, b, oracles[b])
+            assert H.worst(e) < 2e-2, (b, e)
+    one.close(); big.close()
+
+
 def test_batched_range_equals_single(capi):
     """B trajectories in one launch give bit-identical results to B separate single-trajectory batches of
     the same geometry (same kernels, same chunking)."""
