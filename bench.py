@@ -249,12 +249,17 @@ def main():
     ap.add_argument("--cov-form", type=int, default=0, help="msckf_hip_set_covariance_update form (A/B runs; 0 = square-root gain, blocked solve (default), 1 Joseph, 2 square-root gain, register-resident solve)")
     ap.add_argument("--no-pin", action="store_true", help="leave the uploading / enqueue threads where the scheduler puts them (default: one core each on the GPU's NUMA node)")
     ap.add_argument("--aniso-mode", type=int, default=0, help="u_var' != v_var' (cfg4): 0 the reference's literal R_n = Q_1^T R_o Q_1 on the device (default), 1 rows pre-whitened (GLS)")
+    ap.add_argument("--prune-redundant", action="store_true",
+                    help="cfg4: run the ASL runner's per-image cycle (asl_msckf.cpp:269-294, pruneRedundantStates :289 included) for the batch in "
+                         "lockstep through msckf_hip_image_cycle_range (host bookkeeping per trajectory, batched device stages) instead of the resident scenario")
     ap.add_argument("--gate-early-accept", action="store_true",
                     help="exact early accept of the chi-square gate (msckf_hip_set_gate_early_accept); OFF for the headline number")
     args = ap.parse_args()
     self_launch_if_needed(args)
     if args.config == "cfg2":
         return run_cfg2(args)
+    if args.prune_redundant:
+        return run_cycle(args)
     c = dict(CONFIGS[args.config])
     if args.trajectories > 0:
         c["workload"] = c["workload"].replace("%d trajectories per GPU" % c["B"], "%d trajectories per GPU" % args.trajectories).replace(
@@ -615,7 +620,9 @@ def run_other_configs():
     specs = [("cfg2", ["--config", "cfg2", "--steps", "20", "--warmup", "5", "--repeats", "3", "--no-cpu-baseline"]),
              ("cfg4_literal", lit), ("cfg4_whitened", lit + ["--aniso-mode", "1"]),
              ("cfg4_literal_640", ["--config", "cfg4", "--trajectories", "640", "--steps", "6", "--warmup", "4", "--repeats", "3", "--no-cpu-baseline", "--no-early-accept-pass"]),
-             ("cfg5", ["--config", "cfg5", "--steps", "5", "--warmup", "2", "--repeats", "2", "--no-cpu-baseline", "--no-early-accept-pass"])]
+             ("cfg5", ["--config", "cfg5", "--steps", "5", "--warmup", "2", "--repeats", "2", "--no-cpu-baseline", "--no-early-accept-pass"]),
+             # the runner's cycle with pruneRedundantStates for the batch in lockstep (host bookkeeping + batched device stages)
+             ("cfg4_runner_cycle_prune_redundant", ["--config", "cfg4", "--prune-redundant", "--steps", "6", "--warmup", "2"])]
     res = {}
     for name, extra in specs:
         t0 = time.time()
@@ -627,6 +634,8 @@ def run_other_configs():
                 parity = j.get("parity")
             elif name == "cfg4_literal_640":
                 parity = "as cfg4_literal (the same trajectories' first 128 and 512 more seeds)"
+            elif name == "cfg4_runner_cycle_prune_redundant":
+                parity = j.get("parity")
             elif name == "cfg5":
                 parity = "no CPU leg at this size (cpu_baseline_note); held by tests/test_gpu_configs.py and tests/test_gpu_vs_reference.py (-m gpu)"
             else:
@@ -641,6 +650,99 @@ def run_other_configs():
         except Exception as ex_:
             res[name] = {"error": repr(ex_)[:300], "wall_s": time.time() - t0}
     return res
+
+
+def run_cycle(args):
+    """BASELINE.json configs[3] as the ASL runner runs it: per image augmentState -> update -> addFeatures -> marginalize ->
+    pruneRedundantStates (asl_msckf.cpp:289) -> pruneEmptyStates, for ALL trajectories of the batch in lockstep through
+    msckf_hip_image_cycle_range -- the feature bookkeeping of update() / addFeatures() / pruneRedundantStates on the host per
+    trajectory (spread over host threads), every device stage one launch sequence for the batch, every read-back (poses for
+    findRedundantCamStates, pruned states' poses) one copy for the batch.  Inputs are feature ids + normalized coordinates per
+    image, as the front-end hands them to the filter (msckf_mono_amd/scenario.py: Trajectory.stream()).  `value` = filter
+    updates per second of that loop, inputs converted beforehand (the timed region is propagate_range + image_cycle_range per
+    image).  Parity: two sampled trajectories run again filter by filter through the per-filter entries -- bit-identical."""
+    c = dict(CONFIGS[args.config])
+    if args.trajectories > 0:
+        c["B"] = args.trajectories
+    N, F, B = c["N"], c["F"], c["B"]
+    K, W = args.steps, args.warmup
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.gpus > 1:
+        raise SystemExit("bench.py --prune-redundant: 1 GPU")
+    t0 = time.time()
+    nf = N + W + K
+    trajs = make_trajectories(c, 0, nf)
+    streams = [tr.stream() for tr in trajs]
+    t_gen = time.time() - t0
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    from msckf_mono_amd import capi
+
+    def frame_inputs(k, idx):
+        rd = np.ascontiguousarray(np.stack([trajs[b].imu_for_frame(k) for b in idx]), dtype=np.float64)
+        return rd, capi.Batch.pack_image_inputs(len(idx), [k] * len(idx), [trajs[b].frame_times[k] for b in idx],
+                                                [streams[b][k]["cur"] for b in idx], [streams[b][k]["new"] for b in idx])
+
+    def fresh(idx):
+        bt = capi.Batch(len(idx), N + 2, max(F + 32, 64), N + 2, capi.F32)
+        bt.set_anisotropic_noise(args.aniso_mode)
+        for i, b in enumerate(idx):
+            bt.initialize(i, trajs[b].cfg, trajs[b].imu0)
+        return bt
+
+    allb = list(range(B))
+    bt = fresh(allb)
+    pre = [frame_inputs(k, allb) for k in range(nf)]     # conversions outside the timed region
+    n_pruned0 = 0
+    for k in range(N + W):
+        rd, packed = pre[k]
+        bt.propagate_range(0, B, rd); bt.image_cycle_range_packed(0, B, packed)
+    bt.sync(); torch.cuda.synchronize()
+    n_pruned0 = sum(len(bt.pruned_state_ids(b)) for b in (0, B // 2, B - 1))
+    win = []
+    t_all = time.perf_counter()
+    for k in range(N + W, nf):
+        t1 = time.perf_counter()
+        rd, packed = pre[k]
+        bt.propagate_range(0, B, rd); bt.image_cycle_range_packed(0, B, packed)
+        win.append(time.perf_counter() - t1)
+    bt.sync(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_all
+    # the same K images once more with the library's stage timers (HIP events around the device stages): what the device part costs
+    bt.profile_enable(True)
+    ncam = [bt.num_cam_states(b) for b in allb]
+    state = {b: (bt.imu_state(b).copy(), bt.covariance(b).copy()) for b in (0, B - 1)}
+    prof = bt.profile_read(); bt.profile_enable(False)
+    n_pruned = sum(len(bt.pruned_state_ids(b)) for b in (0, B // 2, B - 1))
+    bt.close()
+    # ---- parity: the first and the last trajectory again, filter by filter through the per-filter entries
+    same = True
+    for b in (0, B - 1):
+        one = fresh([b])
+        for k in range(nf):
+            one.propagate_range(0, 1, trajs[b].imu_for_frame(k))
+            one.augment_state(0, k, trajs[b].frame_times[k])
+            one.update(0, streams[b][k]["cur"][0], streams[b][k]["cur"][1]); one.add_features(0, streams[b][k]["new"][0], streams[b][k]["new"][1])
+            one.marginalize(0); one.prune_redundant_states(0); one.prune_empty_states(0)
+        same = same and bool(np.array_equal(one.imu_state(0), state[b][0]) and np.array_equal(one.covariance(0), state[b][1]))
+        one.close()
+    value = B * K / elapsed
+    out = {
+        "metric": "filter updates/sec (%d-cam window, %d feats)" % (N, F), "value": value, "unit": "updates/s", "n_gpus": 1, "steps": K, "warmup": W,
+        "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": c["workload"] + "; the ASL runner's per-image cycle WITH pruneRedundantStates (asl_msckf.cpp:269-294) for the batch in lockstep "
+                                               "(msckf_hip_image_cycle_range: update() / addFeatures() bookkeeping on the host per trajectory, device stages batched)",
+                   "name": args.config, "cam_window": N, "tracks_per_update": F, "trajectories_per_gpu": B, "prune_redundant": True,
+                   "noise": "anisotropic (EuRoC f_u != f_v), literal route" if args.aniso_mode == 0 else "anisotropic, rows pre-whitened",
+                   "host_threads": min(os.cpu_count() or 1, 32)},
+        "window_size_at_end": {"min": int(min(ncam)), "max": int(max(ncam))}, "pruned_states_of_3_sampled_trajectories": [int(n_pruned0), int(n_pruned)],
+        "per_image_ms": {"median": 1e3 * float(np.median(win)), "min": 1e3 * float(np.min(win)), "max": 1e3 * float(np.max(win))},
+        "note": "host-bound: the list surgery of update() for ~3 000 live features per trajectory and image runs on the host (as in the reference), "
+                "the device waits for it; the resident-scenario path (bench.py --config cfg4) measures the device alone",
+        "parity": {"per_filter_calls_bit_identical": same, "trajectories": [0, B - 1]},
+        "roofline": None, "cpu_baseline": None, "scenario_gen_s": t_gen,
+    }
+    print(json.dumps(out))
 
 
 def run_cfg2(args):

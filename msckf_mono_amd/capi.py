@@ -249,14 +249,21 @@ class Batch:
         """The ASL runner's per-image cycle (asl_msckf.cpp:269-294) for trajectories b0 .. b0 + nb - 1 in lockstep:
         augmentState, update, addFeatures, marginalize, [pruneRedundantStates], [pruneEmptyStates].
         cur[i] / new[i] = (measurements [n][2], feature ids [n]) of trajectory b0 + i, as update() / addFeatures() take them."""
+        self.image_cycle_range_packed(b0, nb, self.pack_image_inputs(nb, state_ids, times, cur, new), prune_redundant, prune_empty)
+
+    @staticmethod
+    def pack_image_inputs(nb, state_ids, times, cur, new):
+        """the arguments of msckf_hip_image_cycle_range as contiguous arrays (a caller that replays images converts once, outside its loop)"""
         def cat(parts):
             n = np.array([len(p[1]) for p in parts], dtype=np.int32)
             m = np.concatenate([np.asarray(p[0], dtype=np.float64).reshape(-1, 2) for p in parts]) if n.sum() else np.zeros((0, 2))
             i = np.concatenate([np.asarray(p[1], dtype=np.uint64).reshape(-1) for p in parts]) if n.sum() else np.zeros(0, dtype=np.uint64)
             return np.ascontiguousarray(m, dtype=np.float64), np.ascontiguousarray(i, dtype=np.uint64), n
-        um, ui, un = cat(cur); nm, ni, nn = cat(new)
-        sid, psid = _i(np.asarray(state_ids).reshape(nb)); tt, ptt = _d(np.asarray(times, dtype=np.float64).reshape(nb))
-        _chk(self.L.msckf_hip_image_cycle_range(self.h, b0, nb, psid, ptt, um.ctypes.data_as(_dp), ui.ctypes.data_as(_up), un.ctypes.data_as(_ip),
+        return (np.ascontiguousarray(np.asarray(state_ids).reshape(nb), dtype=np.int32), np.ascontiguousarray(np.asarray(times, dtype=np.float64).reshape(nb))) + cat(cur) + cat(new)
+
+    def image_cycle_range_packed(self, b0, nb, packed, prune_redundant=True, prune_empty=True):
+        sid, tt, um, ui, un, nm, ni, nn = packed
+        _chk(self.L.msckf_hip_image_cycle_range(self.h, b0, nb, sid.ctypes.data_as(_ip), tt.ctypes.data_as(_dp), um.ctypes.data_as(_dp), ui.ctypes.data_as(_up), un.ctypes.data_as(_ip),
                                                 nm.ctypes.data_as(_dp), ni.ctypes.data_as(_up), nn.ctypes.data_as(_ip),
                                                 (1 if prune_redundant else 0) | (2 if prune_empty else 0)))
 

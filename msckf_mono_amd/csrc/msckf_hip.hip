@@ -17,6 +17,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <chrono>
 #include <unordered_map>
 #include <unordered_set>
 
@@ -101,6 +102,8 @@ struct BatchBase {
   virtual int marginalize_given(int b) = 0;                               // second update of pruneRedundantStates
   virtual int prune_keep(int b, const std::vector<int>& keep) = 0;
   // range forms for the batched image cycle (host_image_cycle): one copy / one launch for trajectories b0 .. b0 + nb - 1
+  struct WorkList { std::vector<int> M, slots; std::vector<double> obs; };                     // one trajectory's tracks to residualize (set_tracks' arguments)
+  virtual int set_tracks_range(int b0, int nb, const std::vector<WorkList>& wl) = 0;           // every trajectory's list in one pinned block, two copies
   virtual int cams_range(int b0, int nb, double* poses7) = 0;                                  // [nb][n_cap][7], one read + one wait
   virtual int feature_only_range(int b0, int nb, int* status, double* pf3, bool launch) = 0;   // [nb][f_cap], [nb][f_cap][3]; launch = false: only read what the last launch left
   virtual int set_given_range(int b0, int nb, const double* pf3) = 0;                          // [nb][f_cap][3]
@@ -715,6 +718,57 @@ struct Batch : BatchBase {
     rc = stage_release();
     if (rc) return rc;
     traj[b].wl_F = F;
+    return 0;
+  }
+  int set_tracks_range(int b0, int nb, const std::vector<BatchBase::WorkList>& wl) override {
+    if (chk_range(b0, nb) || (int)wl.size() != nb) return fail(-EINVAL, "trajectory range out of bounds");
+    DEVICE_ENTER();
+    for (int i = 0; i < nb; ++i) {
+      const int F = (int)wl[i].M.size();
+      if (F > f_cap) return fail(-E2BIG, "more tracks than f_cap");
+      size_t o = 0;
+      for (int t = 0; t < F; ++t) {
+        const int m = wl[i].M[t];
+        if (m > m_cap || m < 0) return fail(-E2BIG, "track longer than m_cap");
+        if (repeated_slot(wl[i].slots.data() + o, m)) return fail(-EINVAL, "camera slot repeated within a track");
+        for (int k = 0; k < m; ++k) if (wl[i].slots[o + k] < 0 || wl[i].slots[o + k] >= n_cap) return fail(-EINVAL, "camera slot out of range");
+        o += m;
+      }
+    }
+    // the device's padded single-call layout for the whole range: [nb][wl_ib] ints ([n, 0, 0, 0 | M[f4] | f_cap rows of slots]) and
+    // [nb][wl_ib * 2] coordinates, out of one pinned block, two copies
+    const size_t nI = (size_t)nb * wl_ib, nO = (size_t)nb * wl_ib * 2;
+    const size_t offO = ((nI * sizeof(int) + 15) / 16) * 16;
+    unsigned char* raw = nullptr;
+    int rc = stage_acquire(offO + nO * sizeof(S) + 16, &raw);
+    if (rc) return rc;
+    int* hI = reinterpret_cast<int*>(raw); S* hO = reinterpret_cast<S*>(raw + offO);
+    const long ib = wl_ib; const int f4 = wl_f4, mc = m_cap;
+    parallel_for(nb, [&](int i) {
+      int* I = hI + (size_t)i * ib; S* O = hO + (size_t)i * ib * 2;
+      const int F = (int)wl[i].M.size();
+      std::memset(I, 0, (size_t)(4 + f4 + (size_t)F * mc) * sizeof(int));
+      std::memset(O, 0, (size_t)F * mc * 2 * sizeof(S));
+      I[0] = F;
+      int* hM = I + 4; int* hS = I + 4 + f4;
+      size_t o = 0;
+      for (int t = 0; t < F; ++t) {
+        const int m = wl[i].M[t];
+        hM[t] = m;
+        for (int k = 0; k < m; ++k) {
+          hS[(size_t)t * mc + k] = wl[i].slots[o + k];
+          O[((size_t)t * mc + k) * 2] = (S)wl[i].obs[2 * (o + k)];
+          O[((size_t)t * mc + k) * 2 + 1] = (S)wl[i].obs[2 * (o + k) + 1];
+        }
+        o += m;
+      }
+      return 0;
+    });
+    HIPCHK(hipMemcpyAsync(wl_i + (size_t)b0 * wl_ib, hI, nI * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(wl_obs + (size_t)b0 * wl_ib * 2, hO, nO * sizeof(S), hipMemcpyHostToDevice, st));
+    rc = stage_release();
+    if (rc) return rc;
+    for (int i = 0; i < nb; ++i) traj[b0 + i].wl_F = (int)wl[i].M.size();
     return 0;
   }
   // last_stats of a marginalize() that had nothing to residualize (the reference returns early, msckf.h:337)
@@ -1946,6 +2000,22 @@ int host_finish(BatchBase* B, int b) {
 // comes back in one read and one wait per stage for the whole range, instead of one per filter.
 // Same arithmetic per trajectory as the per-filter calls (tests/test_gpu_parity.py: bit for bit).
 // -------------------------------------------------------------------------------------------------
+// the bookkeeping of the trajectories of a range is independent: spread over host threads (created per call: tens of microseconds
+// against milliseconds of list surgery at the benchmark's 200 tracks per image); fn(i) returns 0 or an error code
+template <class Fn> static int parallel_for(int n, Fn fn) {
+  unsigned hw = std::thread::hardware_concurrency();
+  int nt = (int)std::min<unsigned>(hw ? hw : 1u, 32u);
+  if (const char* e = getenv("MSCKF_HIP_HOST_THREADS")) nt = std::max(1, atoi(e));
+  nt = std::min(nt, n);
+  if (nt <= 1) { for (int i = 0; i < n; ++i) { const int rc = fn(i); if (rc) return rc; } return 0; }
+  std::atomic<int> next(0), err(0);
+  auto work = [&]() { for (;;) { const int i = next.fetch_add(1); if (i >= n || err.load()) return; const int rc = fn(i); if (rc) err.store(rc); } };
+  std::vector<std::thread> th;
+  for (int k = 1; k < nt; ++k) th.emplace_back(work);
+  work();
+  for (auto& x : th) x.join();
+  return err.load();
+}
 template <class Fn> static int for_runs(const std::vector<char>& on, int b0, Fn fn) {
   const int nb = (int)on.size();
   for (int i = 0; i < nb;) {
@@ -1969,6 +2039,10 @@ int host_image_cycle(BatchBase* B, int b0, int nb, const int* state_ids, const d
     if (!t.initialized) return fail(-EINVAL, "trajectory not initialized");
     if ((int)t.cams.size() >= n_cap) return fail(-EOVERFLOW, "camera-state capacity n_cap exceeded");
   }
+  static const bool tim = getenv("MSCKF_HIP_CYCLE_TIMERS") != nullptr;
+  double tph[8] = {0}; auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tl = now();
+  auto tick = [&](int k) { if (tim) { const double t2 = now(); tph[k] += t2 - tl; tl = t2; } };
   // ---- augmentState :148-212
   int rc = B->augment(b0, nb);
   if (rc) return rc;
@@ -1977,41 +2051,48 @@ int host_image_cycle(BatchBase* B, int b0, int nb, const int* state_ids, const d
     t.cams.push_back(CamMeta{state_ids[i], times ? times[i] : 0.0, -1, {}});
     t.map.clear(); t.map_pending = 0;
   }
+  tick(0);
   // ---- update :215-300, addFeatures :302-332 (host)
   {
-    size_t ou = 0, on = 0;
-    for (int i = 0; i < nb; ++i) {
-      rc = host_update(B, b0 + i, upd_meas + 2 * ou, upd_ids + ou, upd_n[i]);
-      if (rc) return rc;
-      rc = host_add_features(B, b0 + i, new_meas + 2 * on, new_ids + on, new_n[i]);
-      if (rc) return rc;
-      ou += (size_t)upd_n[i]; on += (size_t)new_n[i];
-    }
+    std::vector<size_t> ou(nb + 1, 0), on(nb + 1, 0);
+    for (int i = 0; i < nb; ++i) { ou[i + 1] = ou[i] + (size_t)upd_n[i]; on[i + 1] = on[i] + (size_t)new_n[i]; }
+    rc = parallel_for(nb, [&](int i) {
+      int r2 = host_update(B, b0 + i, upd_meas + 2 * ou[i], upd_ids + ou[i], upd_n[i]);
+      if (!r2) r2 = host_add_features(B, b0 + i, new_meas + 2 * on[i], new_ids + on[i], new_n[i]);
+      return r2;
+    });
+    if (rc) return rc;
   }
+  tick(1);
   // ---- marginalize :336-449
   std::vector<char> has(nb, 0);
   {
-    std::vector<int> M, slots; std::vector<double> obs;
-    for (int i = 0; i < nb; ++i) {
-      HostTraj& t = B->traj[b0 + i];
+    std::vector<BatchBase::WorkList> wl(nb);
+    parallel_for(nb, [&](int i) {
+      const HostTraj& t = B->traj[b0 + i];
       const int F = (int)t.to_resid.size();
-      if (F > f_cap) return fail(-E2BIG, "more tracks to residualize than f_cap");
-      M.assign(F, 0); slots.clear(); obs.clear();
+      wl[i].M.assign(F, 0);
       for (int k = 0; k < F; ++k) {
-        M[k] = (int)t.to_resid[k].slots.size();
-        slots.insert(slots.end(), t.to_resid[k].slots.begin(), t.to_resid[k].slots.end());
-        obs.insert(obs.end(), t.to_resid[k].obs.begin(), t.to_resid[k].obs.end());
+        wl[i].M[k] = (int)t.to_resid[k].slots.size();
+        wl[i].slots.insert(wl[i].slots.end(), t.to_resid[k].slots.begin(), t.to_resid[k].slots.end());
+        wl[i].obs.insert(wl[i].obs.end(), t.to_resid[k].obs.begin(), t.to_resid[k].obs.end());
       }
-      int z = 0;
-      rc = F ? B->set_tracks(b0 + i, F, M.data(), slots.data(), obs.data()) : B->set_tracks(b0 + i, 0, &z, &z, nullptr);
-      if (rc) return rc;
+      return 0;
+    });
+    tick(2);
+    rc = B->set_tracks_range(b0, nb, wl);
+    if (rc) return rc;
+    for (int i = 0; i < nb; ++i) {
+      const int F = (int)wl[i].M.size();
       if (!F) { rc = B->clear_stats(b0 + i); if (rc) return rc; }
       has[i] = F > 0;
-      t.map_pending = F;
+      B->traj[b0 + i].map_pending = F;
     }
+    tick(3);
     rc = for_runs(has, b0, [&](int s0, int n) { return B->marginalize(s0, n); });
     if (rc) return rc;
   }
+  tick(4);
   // ---- pruneRedundantStates :453-682
   if (flags & 1) {
     std::vector<char> act(nb, 0);
@@ -2044,6 +2125,7 @@ int host_image_cycle(BatchBase* B, int b0, int nb, const int* state_ids, const d
         const int n = (int)t.cams.size();
         std::vector<double> pz(&poses[(size_t)i * n_cap * 7], &poses[(size_t)i * n_cap * 7] + (size_t)n * 7);
         find_redundant(t, pz, rm[i]);
+        if (rm[i].empty()) continue;                   // no camera state to remove: both loops over the tracks find nothing involved
         // first loop :466-534
         for (size_t k = 0; k < t.tracks.size(); ++k) {
           Track& tr = t.tracks[k];
@@ -2097,7 +2179,7 @@ int host_image_cycle(BatchBase* B, int b0, int nb, const int* state_ids, const d
       std::vector<std::vector<size_t>> used(nb);
       std::vector<double> pfin((size_t)nb * f_cap * 3, 0.0);
       for (int i = 0; i < nb; ++i) {
-        if (!act[i]) continue;
+        if (!act[i] || rm[i].empty()) continue;
         HostTraj& t = B->traj[b0 + i];
         const int n = (int)t.cams.size();
         auto slot_of = [&](int cam_id) { for (int q = 0; q < n; ++q) if (t.cams[q].state_id == cam_id) return q; return -1; };
@@ -2160,6 +2242,7 @@ int host_image_cycle(BatchBase* B, int b0, int nb, const int* state_ids, const d
       }
     }
   }
+  tick(5);
   // ---- pruneEmptyStates :685-761
   if (flags & 2) {
     std::vector<int> last(nb, -1);
@@ -2194,6 +2277,8 @@ int host_image_cycle(BatchBase* B, int b0, int nb, const int* state_ids, const d
       if (rc) return rc;
     }
   }
+  tick(6);
+  if (tim) fprintf(stderr, "cycle nb=%d ms: augment %.2f update+add %.2f lists %.2f upload %.2f launch %.2f redundant %.2f empty %.2f\n", nb, tph[0], tph[1], tph[2], tph[3], tph[4], tph[5], tph[6]);
   return 0;
 }
 
