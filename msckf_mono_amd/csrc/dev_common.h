@@ -413,7 +413,7 @@ template <class S> void launch_literal(const Dev<S>& d, int b0, int nb, hipStrea
 template <class S> bool launch_chol_gram(const Dev<S>& d, int b0, int nb, hipStream_t st);
 bool launch_chol_gain(const Dev<float>& d, int b0, int nb, hipStream_t st);
 template <class S> bool launch_chol_gain_large(const Dev<S>& d, int b0, int nb, hipStream_t st);
-size_t feature_lds_bytes(int m_cap, size_t scalar);
+size_t feature_lds_bytes(int m_cap, size_t scalar, bool staged = false);
 // one-time per-device setup of each kernel file (constant tables, dynamic-LDS limits); msckf_hip_create calls them
 void feature_device_setup();
 void qr_device_setup();

@@ -212,6 +212,77 @@ __device__ __forceinline__ bool gate_chol(const S* sG, S* sC, int lane, int R2, 
   return spd;
 }
 
+// gate_chol for the long tracks of a float filter (31 .. 62 observations: 2M + 4 up to 128, NB up to 16 blocks of 8), WITHOUT the
+// whole packed matrix in LDS.  A 60-observation track's triangle is 31 KB -- four wavefronts per compute unit, and the long
+// bin of cfg5's tracks was bound by exactly that (k_feature<LONG> 4.4 of the frame's 12 ms).  The lane grid takes the matrix
+// from a staging area anyway, so it takes it sixteen columns at a time: `assemble(c0)` fills rows c0 .. 2M+3 of columns
+// c0 .. c0+15 ([row - c0][17]: 8.4 KB at most), the two block columns are picked up into the registers, the next sixteen
+// columns reuse the space.  Same entries, same pivot loops as gate_chol.
+template <int NB, class Asm>
+__device__ __forceinline__ bool gate_chol_staged(float* sCol, float* sC, int lane, int R2, float sig2, Asm&& assemble) {
+  typedef float S;
+  bool spd = true;
+  const int tx = lane & 7, ty = lane >> 3, nr = R2 + 4;
+  S A[NB][NB];
+#pragma unroll
+  for (int cb = 0; cb < NB; cb += 2) {
+    const int c0 = 8 * cb;
+    if (c0 < nr) assemble(c0);
+    __syncthreads();
+#pragma unroll
+    for (int bo = 0; bo < 2; ++bo) {
+      const int b2 = cb + bo;
+      if (b2 < NB) {
+        const int j = 8 * b2 + ty;
+#pragma unroll
+        for (int a2 = 0; a2 < NB; ++a2) {
+          if (a2 < b2) continue;
+          const int i = 8 * a2 + tx;
+          S val = 0;
+          if (i < nr && j < nr && !(i >= R2 && j >= R2)) {
+            const int hi = (a2 > b2 || i >= j) ? i : j, lo = (a2 > b2 || i >= j) ? j : i;
+            val = sCol[(hi - c0) * 17 + (lo - c0)];
+            if (i == j) val += sig2;
+          }
+          A[a2][b2] = val;
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    const int kk_hi = min(8, R2 - 8 * kb);
+    for (int kk = 0; kk < kk_hi; ++kk) {
+      const S dkk = wave_bcast(A[kb][kb], kk * 9);
+      spd = spd && dkk > S(0);
+      const S dinv2 = (S)__builtin_amdgcn_rcpf((float)dkk);
+      const int src_i = (kk * 8 + tx) << 2, src_j = (kk * 8 + ty) << 2;
+      S li[NB], lj[NB];
+#pragma unroll
+      for (int a2 = kb; a2 < NB; ++a2) li[a2] = lane_gather(A[a2][kb], src_i);
+#pragma unroll
+      for (int b2 = kb; b2 < NB; ++b2) lj[b2] = lane_gather(A[b2][kb], src_j);
+#pragma unroll
+      for (int a2 = kb; a2 < NB; ++a2) li[a2] *= dinv2;
+#pragma unroll
+      for (int a2 = kb; a2 < NB; ++a2)
+#pragma unroll
+        for (int b2 = kb; b2 <= a2; ++b2) A[a2][b2] -= li[a2] * lj[b2];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int a2 = (NB >= 3 ? NB - 3 : 0); a2 < NB; ++a2)
+#pragma unroll
+    for (int b2 = (NB >= 3 ? NB - 3 : 0); b2 <= a2; ++b2) {
+      const int qi = 8 * a2 + tx - R2, qj = 8 * b2 + ty - R2;
+      if (qi >= 0 && qi < 4 && qj >= 0 && qj <= qi) sC[qi * 4 + qj] = A[a2][b2];
+    }
+  __syncthreads();
+  return spd;
+}
+
 // gamma = y^T y - b^T C^-1 b from the corner -[y^T y, . ; b, C] left by the factorization (c[qi * 4 + qj], qj <= qi).  C is
 // 3 x 3 symmetric positive definite (H_f has full column rank for a triangulable feature); a direction H_f says nothing
 // about (pivot below rounding of C's diagonal) contributes nothing.
@@ -327,7 +398,7 @@ __device__ __forceinline__ bool gate_chol_dpp(const float* sG, float* sC, int la
 // LONG: tracks of more than 30 observations (2M + 4 > 64) keep the gate's Cholesky in registers too (up to 16 x 16 blocks
 // per lane); a separate instantiation, so that the short-track kernel keeps its register budget.
 template <class S, bool LONG>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (sizeof(S) == 4 ? 4 : 2), sizeof(S) == 4 && !LONG ? 4 : 2))) void k_feature(Dev<S> d, int b0, int nb, int lm, int m_lo, int m_hi) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (sizeof(S) == 4 ? 4 : 2), sizeof(S) == 4 && !LONG ? 4 : 2))) void k_feature(Dev<S> d, int b0, int nb, int lm, int m_lo, int m_hi, int staged) {
   // all tracks of a trajectory on one XCD (xcd_item): the gate's 6 x 6 blocks of P then come out of an L2 that holds 1/8 of
   // the batch's covariances (the (track, trajectory) grid spread every trajectory over all eight: 68 MB fetched per launch for
   // 9.7 MB of covariance; now 17 MB).  Measured and rejected: a PERSISTENT form of this kernel -- one residency
@@ -351,8 +422,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
   // observations: with long windows launch_feature bins the tracks by length (this launch takes m_lo < M <= m_hi), so that
   // a short track does not hold the 31 KB a 60-observation track needs (5 wavefronts per CU)
   S* sG = reinterpret_cast<S*>(smem_raw);              // [(2 lm + 4)(2 lm + 5) / 2]
-  S* sHx = sG + (2 * lm + 4) * (2 * lm + 5) / 2;       // [lm][12]
-  S* sC = sHx;                                         // [16]: the corner
+  S* sHx = sG + (staged ? (2 * lm + 4) * 17 : (2 * lm + 4) * (2 * lm + 5) / 2);       // [lm][12]  (staged: sixteen columns of the gate matrix at a time, gate_chol_staged)
+  S* sC = sHx;                                         // [16]: the corner (gate_chol_staged writes it after its last assemble: H_x is done with by then)
   const int xlen = lm * 12 > 16 ? lm * 12 : 16;
   int* sSlot = reinterpret_cast<int*>(sHx + xlen);
 
@@ -736,6 +807,75 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
   __syncthreads();
   const int R2 = 2 * M;
   const S* P = d.P + (long)b * ld * ld;
+  bool done_staged = false;
+  if constexpr (LONG && sizeof(S) == 4) {
+    if (staged) {
+      done_staged = true;
+      S* sCol = sG;
+      auto assemble = [&](int c0) {
+        const int a0 = c0 >> 1, a1 = min(M, a0 + 8);       // observations whose two columns fall into [c0, c0 + 16)
+        if (a0 < M) {
+          const int na = a1 - a0, cnt = na * M - (a0 + a1 - 1) * na / 2;   // pairs (a, bq): a in [a0, a1), bq in [a, M)
+          for (int p = lane; p < cnt; p += 64) {
+            int a = a0, q = p;
+#pragma unroll
+            for (int s8 = 0; s8 < 7; ++s8) { const int len = M - a; if (q >= len) { q -= len; ++a; } }
+            const int bq = a + q;
+            const int sa2 = sSlot[a], sb2 = sSlot[bq];
+            const S* Pt = P + (long)(15 + 6 * sa2) * ld + 15 + 6 * sb2;   // P through its mirror image (k_feature's packed form above)
+            S pv[6][6];
+            typedef S s2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+              const S* col = Pt + (long)i * ld;
+              const s2 m12 = *reinterpret_cast<const s2*>(col + 1), m34 = *reinterpret_cast<const s2*>(col + 3);
+              pv[0][i] = col[0]; pv[1][i] = m12.x; pv[2][i] = m12.y; pv[3][i] = m34.x; pv[4][i] = m34.y; pv[5][i] = col[5];
+            }
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2 ha[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ha[i] = f2{(float)sHx[a * 12 + i], (float)sHx[a * 12 + 6 + i]};
+            f2 Tt[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+              f2 t = f2{0.0f, 0.0f};
+#pragma unroll
+              for (int i = 0; i < 6; ++i) t += ha[i] * (float)pv[j][i];
+              Tt[j] = t;
+            }
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+              f2 g = f2{0.0f, 0.0f};
+#pragma unroll
+              for (int j = 0; j < 6; ++j) g += Tt[j] * (float)sHx[bq * 12 + cc * 6 + j];
+              S* dst = sCol + (2 * bq + cc - c0) * 17 + (2 * a - c0);
+              dst[0] = (S)g.x;
+              if (a != bq || 1 <= cc) dst[1] = (S)g.y;
+            }
+          }
+        }
+        if (act) {                                       // the four riding rows of this lane's two columns
+#pragma unroll
+          for (int s2i = 0; s2i < 2; ++s2i) {
+            const int row = row0 + s2i;
+            if (row >= c0 && row < c0 + 16) {
+              sCol[(R2 - c0) * 17 + row - c0] = r[s2i];
+#pragma unroll
+              for (int q = 0; q < 3; ++q) sCol[(R2 + 1 + q - c0) * 17 + row - c0] = hf[s2i][q];
+            }
+          }
+        }
+      };
+      const S sig2s = prm[PRM_SIG2G];
+      const int nbr = (R2 + 4 + 7) >> 3;
+      if (nbr <= 10) spd = gate_chol_staged<10>(sCol, sC, lane, R2, sig2s, assemble);
+      else if (nbr <= 12) spd = gate_chol_staged<12>(sCol, sC, lane, R2, sig2s, assemble);
+      else if (nbr <= 14) spd = gate_chol_staged<14>(sCol, sC, lane, R2, sig2s, assemble);
+      else spd = gate_chol_staged<16>(sCol, sC, lane, R2, sig2s, assemble);
+      if (spd) gamma = gate_gamma_from_corner<S>(sC);
+    }
+  }
+  if (!done_staged) {
   {
     // pairs (a, bq), a <= bq, enumerated as a rectangle of M/2 (rounded up) rows of width M | 1: row k of the rectangle
     // holds row k of the triangle (M - k pairs) followed by row M - 1 - k (M even) or M - k (M odd) -- two integer
@@ -853,6 +993,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LONG ? 1 : (
     __syncthreads();
   }
   if (spd && !(fdbg & 4)) gamma = gate_gamma_from_corner<S>(sC);
+  }   // !done_staged
   }   // !early
   if (spd && gamma < thresh) status |= ST_GATE_PASS;
 
@@ -1689,10 +1830,10 @@ __global__ __launch_bounds__(256) void k_select_diag(Dev<S> d, int b0, int nb, i
   }
 }
 
-size_t feature_lds_bytes(int m_cap, size_t scalar) {
+size_t feature_lds_bytes(int m_cap, size_t scalar, bool staged) {
   const size_t r2 = 2 * (size_t)m_cap + 4;
   const size_t x = std::max<size_t>((size_t)m_cap * 12, 16);
-  return (r2 * (r2 + 1) / 2 + x) * scalar + (size_t)m_cap * sizeof(int) + 16;
+  return ((staged ? r2 * 17 : r2 * (r2 + 1) / 2) + x) * scalar + (size_t)m_cap * sizeof(int) + 16;
 }
 
 // one-time, per-device setup (called from msckf_hip_create after hipSetDevice): chi-square table, LDS limits
@@ -1726,17 +1867,24 @@ void launch_feature(const Dev<S>& d, int b0, int nb, hipStream_t st) {
     // (measured and rejected, round 4: the tracks of at most 12 / 16 / 20 observations in a launch of their own with the LDS sized
     // for them -- five wavefronts per SIMD instead of four for those: 183 k -> 172 k updates/s on one stream, 201 k -> 199 k in four
     // slices; the second launch's tail costs more than the occupancy gives.  cfg5's windows are another matter, below)
-    hipLaunchKernelGGL((k_feature<S, false>), grid, dim3(64), feature_lds_bytes(d.m_cap, sizeof(S)), st, d, b0, nb, d.m_cap, ALL_LO, ALL_HI);
+    hipLaunchKernelGGL((k_feature<S, false>), grid, dim3(64), feature_lds_bytes(d.m_cap, sizeof(S)), st, d, b0, nb, d.m_cap, ALL_LO, ALL_HI, 0);
     return;
   }
   // long windows: tracks binned by length, one launch per bin over the same grid (a workgroup whose track belongs to another
   // bin returns at once).  Occupancy is set by the LDS of the bin's longest track, not of the window's
-  if (!pair) hipLaunchKernelGGL((k_feature<S, false>), grid, dim3(64), feature_lds_bytes(M_REG, sizeof(S)), st, d, b0, nb, M_REG, ALL_LO, M_REG);
+  if (!pair) hipLaunchKernelGGL((k_feature<S, false>), grid, dim3(64), feature_lds_bytes(M_REG, sizeof(S)), st, d, b0, nb, M_REG, ALL_LO, M_REG, 0);
+  // float filters, tracks of 31 .. 62 observations: the gate matrix goes through LDS sixteen columns at a time (gate_chol_staged) -- the
+  // launch's LDS no longer depends on the square of the longest track, and ONE launch takes every long track (the two bins by length
+  // existed for the LDS of the packed triangle: 31 KB at 60 observations)
+  const bool staged = sizeof(S) == 4 && d.m_cap <= 62 && d.feat_pair;
+  // (measured and rejected: the tracks of 31 .. 46 observations in a launch of their own whose instance holds 12 x 12 blocks at most --
+  // 168 registers, three wavefronts per SIMD instead of two: 4.70 -> 4.67 ms at cfg5, the second launch's tail takes what the occupancy gives)
+  if (staged) { hipLaunchKernelGGL((k_feature<S, true>), grid, dim3(64), feature_lds_bytes(d.m_cap, sizeof(S), true), st, d, b0, nb, d.m_cap, M_REG, ALL_HI, 1); return; }
   const int mid = (M_REG + d.m_cap + 1) / 2;
   if (d.m_cap - M_REG >= 16) {
-    hipLaunchKernelGGL((k_feature<S, true>), grid, dim3(64), feature_lds_bytes(mid, sizeof(S)), st, d, b0, nb, mid, M_REG, mid);
-    hipLaunchKernelGGL((k_feature<S, true>), grid, dim3(64), feature_lds_bytes(d.m_cap, sizeof(S)), st, d, b0, nb, d.m_cap, mid, ALL_HI);
-  } else hipLaunchKernelGGL((k_feature<S, true>), grid, dim3(64), feature_lds_bytes(d.m_cap, sizeof(S)), st, d, b0, nb, d.m_cap, M_REG, ALL_HI);
+    hipLaunchKernelGGL((k_feature<S, true>), grid, dim3(64), feature_lds_bytes(mid, sizeof(S)), st, d, b0, nb, mid, M_REG, mid, 0);
+    hipLaunchKernelGGL((k_feature<S, true>), grid, dim3(64), feature_lds_bytes(d.m_cap, sizeof(S)), st, d, b0, nb, d.m_cap, mid, ALL_HI, 0);
+  } else hipLaunchKernelGGL((k_feature<S, true>), grid, dim3(64), feature_lds_bytes(d.m_cap, sizeof(S)), st, d, b0, nb, d.m_cap, M_REG, ALL_HI, 0);
 }
 #ifdef MSCKF_ABLATE
 void feat_debug_set(int val) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_feat_dbg), &val, sizeof(int)); }
