@@ -1074,7 +1074,7 @@ __device__ __forceinline__ int half_min_i(int v) {
   return min((int)r[0], (int)r[1]);
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_feature_pair(Dev<float> d, int b0, int nb, int lm, int m_lo, int m_hi, int s_cap, int items) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_feature_pair(Dev<float> d, int b0, int nb, int lm, int m_lo, int m_hi, int s_cap, int items, int single) {
   typedef float S;
   int bi, w;
   if (!xcd_item(nb, items, bi, w)) return;
@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   if (w == 0 && lane == 0) d.nres_upd[b] = (int)(d.n_resid[b] > 1000 ? 1000 : d.n_resid[b]);
   sHist[lane] = 0;
   wave_lds_sync();
-  if (2 * w >= F) return;
+  if ((single ? w : 2 * w) >= F) return;
 #ifdef MSCKF_ABLATE
   if (fdbg & 0x80000) { if (Mv[0] + Ov[0] == -12345) d.trk_gamma[0] = 0; return; }   // the first round trip only
 #endif
@@ -1145,11 +1145,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     scan += dppm_i<DPP_ROW_BCAST15, 0xA>(scan);
     scan += dppm_i<DPP_ROW_BCAST31, 0xC>(scan);
     nv = wave_bcast(scan, 63);
-    if (2 * w >= nv) return;
+    if ((single ? w : 2 * w) >= nv) return;
     int tsel[2], msel[2], osel[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const int p = s ? nv - 1 - w : w;
+      const int p = single ? (nv - 1 - w) : (s ? nv - 1 - w : w);   // single: one track per wavefront, longest first
       const unsigned long long mb = __ballot(scan > p);
       const int Mb = __builtin_ctzll(mb);              // the length whose bin holds rank p
       int r = p - (wave_bcast(scan, Mb) - wave_bcast(c0, Mb));
@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   }
   wave_lds_sync();                                     // sHist is sG
   FP_TICK(0);
-  const bool hasB = (nv - 1 - w) != w;
+  const bool hasB = !single && (nv - 1 - w) != w;
   if (!hasB) MB = 0;
   const int g = lane >> 5, gl = lane & (GS - 1), gbase4 = (lane & GS) << 2;
   const bool has = g == 0 || hasB;
@@ -1856,10 +1856,13 @@ void launch_feature(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if constexpr (sizeof(S) == 4) {
     if (d.feat_pair && d.compress && d.f_cap <= 512) {
       pair = true;
-      const int lm = d.m_cap < M_REG ? d.m_cap : M_REG, items = (d.f_cap + 1) / 2;
+      // a launch that does not fill the chip anyway (a slice of run_frames: 16 trajectories) takes ONE track per wavefront -- the kernel's
+      // latency is then its slowest wavefront's, and a wavefront with a single track has half the gate work (feat_pair & 2 forces pairs)
+      const int single = (d.feat_pair == 3 || (d.feat_pair == 1 && (long)nb * d.f_cap <= 4096)) ? 1 : 0;
+      const int lm = d.m_cap < M_REG ? d.m_cap : M_REG, items = single ? d.f_cap : (d.f_cap + 1) / 2;
       int s_cap = 0;
       const size_t lds = feature_pair_lds_bytes(lm, s_cap);
-      hipLaunchKernelGGL(k_feature_pair, dim3(xcd_grid(nb, items)), dim3(64), lds, st, d, b0, nb, lm, ALL_LO, d.m_cap <= M_REG ? ALL_HI : M_REG, s_cap, items);
+      hipLaunchKernelGGL(k_feature_pair, dim3(xcd_grid(nb, items)), dim3(64), lds, st, d, b0, nb, lm, ALL_LO, d.m_cap <= M_REG ? ALL_HI : M_REG, s_cap, items, single);
       if (d.m_cap <= M_REG) return;
     }
   }
