@@ -1668,33 +1668,61 @@ void remove_tracked_feature(HostTraj& t, uint64_t fid, std::vector<int>& slots) 
   }
 }
 
+// key -> int table without a heap node per key (open addressing, power-of-two capacity, one instance per host thread reused
+// from call to call): the bookkeeping below makes a few hundred to a few thousand look-ups per image and trajectory, and a
+// std::unordered_map's allocations were most of their cost
+struct FlatIndex {
+  std::vector<uint64_t> key; std::vector<int> val; unsigned shift = 64; size_t mask = 0;
+  void reset(size_t n) {
+    size_t cap = 16; unsigned lg = 4;
+    while (cap < 2 * n + 2) { cap <<= 1; ++lg; }
+    if (key.size() < cap) key.resize(cap);
+    val.assign(cap, -1);
+    mask = cap - 1; shift = 64 - lg;
+  }
+  size_t slot(uint64_t k) const { return (size_t)((k * 0x9E3779B97F4A7C15ull) >> shift) & mask; }
+  // keeps the FIRST value given for a key (std::find returns the first occurrence); returns the value held
+  int insert_first(uint64_t k, int v) {
+    for (size_t s = slot(k);; s = (s + 1) & mask) {
+      if (val[s] < 0) { key[s] = k; val[s] = v; return v; }
+      if (key[s] == k) return val[s];
+    }
+  }
+  int find(uint64_t k) const {
+    for (size_t s = slot(k);; s = (s + 1) & mask) {
+      if (val[s] < 0) return -1;
+      if (key[s] == k) return val[s];
+    }
+  }
+};
+
 // update(), msckf.h:215-300, with the reference's results and none of its quadratic searches.  The reference looks every tracked
 // feature up in the incoming ids by linear search (:226), removes an ended feature from every camera state's list by linear
 // search + erase (removeTrackedFeature :1469-1485) and erases the ended tracks one by one (:283-298): O(tracked x incoming) +
 // O(ended x cameras x tracked) per image -- 43 us of the single filter's 286 us at 50 features per image (round-5 verdict), tens of
-// milliseconds per filter at the benchmark's 200.  Here: one hash table of the incoming ids (first occurrence, as std::find
-// returns), one table "feature -> camera slots that list it" built from the lists as they stand after this image's
+// milliseconds per filter at the benchmark's 200.  Here: one table of the incoming ids (first occurrence, as std::find
+// returns), one table "ended feature -> camera slots that list it" built from the lists as they stand after this image's
 // registrations, ONE stable filter pass per camera list and per track list.  Every list ends in the order the reference leaves it.
 int host_update(BatchBase* B, int b, const double* meas, const uint64_t* ids, int n) {
   HostTraj& t = B->traj[b];
   if (!t.initialized) return fail(-EINVAL, "trajectory not initialized");
   if (t.cams.empty()) return fail(-EINVAL, "update() before augmentState() (msckf.h:238 dereferences cam_states_.end()-1)");
   t.to_resid.clear();
-  std::unordered_map<uint64_t, int> first;
-  first.reserve((size_t)n * 2 + 16);
-  for (int k = 0; k < n; ++k) first.emplace(ids[k], k);                      // keeps the first occurrence (std::find, :226)
+  static thread_local FlatIndex first, where;
+  first.reset((size_t)n);
+  for (int k = 0; k < n; ++k) first.insert_first(ids[k], k);                  // keeps the first occurrence (std::find, :226)
   // pass 1 (:224-247): register this image's observation; which tracks end here
   const size_t nt = t.tracked_ids.size();
-  std::vector<char> ended(nt, 0);
+  static thread_local std::vector<char> ended;
+  ended.assign(nt, 0);
   size_t n_ended = 0;
   for (size_t i = 0; i < nt; ++i) {
     const uint64_t fid = t.tracked_ids[i];
     Track& tr = t.tracks[i];
-    const auto it = first.find(fid);
-    const bool valid = it != first.end();
+    const int k = first.find(fid);
+    const bool valid = k >= 0;
     if (valid) {
-      const size_t k = (size_t)it->second;
-      tr.obs.push_back(meas[2 * k]); tr.obs.push_back(meas[2 * k + 1]);
+      tr.obs.push_back(meas[2 * (size_t)k]); tr.obs.push_back(meas[2 * (size_t)k + 1]);
       t.cams.back().tracked.push_back(fid);
       tr.cam_ids.push_back(t.cams.back().state_id);
     }
@@ -1702,39 +1730,42 @@ int host_update(BatchBase* B, int b, const double* meas, const uint64_t* ids, in
   }
   if (!n_ended) return 0;
   // pass 2 (:249-265 + removeTrackedFeature): the camera slots that list an ended feature, in camera order
-  std::unordered_map<uint64_t, std::vector<int>> where;
-  where.reserve(n_ended * 2 + 16);
-  for (size_t i = 0; i < nt; ++i) if (ended[i]) where.emplace(t.tracked_ids[i], std::vector<int>());
+  where.reset(n_ended);
+  std::vector<std::vector<int>> slots_of(n_ended);
+  {
+    int e = 0;
+    for (size_t i = 0; i < nt; ++i) if (ended[i]) where.insert_first(t.tracked_ids[i], e++);
+  }
   for (size_t c = 0; c < t.cams.size(); ++c) {
     auto& lst = t.cams[c].tracked;
     size_t w = 0;
     for (size_t r = 0; r < lst.size(); ++r) {
-      const auto it = where.find(lst[r]);
-      if (it != where.end() && (it->second.empty() || it->second.back() != (int)c)) { it->second.push_back((int)c); continue; }   // first occurrence in this list leaves it
+      const int e = where.find(lst[r]);
+      if (e >= 0 && (slots_of[e].empty() || slots_of[e].back() != (int)c)) { slots_of[e].push_back((int)c); continue; }   // first occurrence in this list leaves it
       lst[w++] = lst[r];
     }
     lst.resize(w);
   }
-  for (size_t i = 0; i < nt; ++i) {
-    if (!ended[i]) continue;
-    Track& tr = t.tracks[i];
-    std::vector<int>& slots = where[t.tracked_ids[i]];
-    if (slots.size() >= (size_t)t.min_track_length) {
-      TrackToResid r;
-      r.id = tr.id; r.obs = std::move(tr.obs); r.slots = std::move(slots);   // (the track is erased below: its observations move, they are not copied)
-      t.to_resid.push_back(std::move(r));
+  {
+    int e = 0;
+    for (size_t i = 0; i < nt; ++i) {
+      if (!ended[i]) continue;
+      Track& tr = t.tracks[i];
+      std::vector<int>& slots = slots_of[e++];
+      if (slots.size() >= (size_t)t.min_track_length) {
+        TrackToResid r;
+        r.id = tr.id; r.obs = std::move(tr.obs); r.slots = std::move(slots);   // (the track is erased below: its observations move, they are not copied)
+        t.to_resid.push_back(std::move(r));
+      }
     }
   }
   // pass 3 (:283-298): last_correlated_id of the camera states an ended track leaves empty, then the tracks themselves
-  std::unordered_map<int, size_t> cam_of;
-  for (size_t c = 0; c < t.cams.size(); ++c) cam_of.emplace(t.cams[c].state_id, c);
   for (size_t i = 0; i < nt; ++i) {
     if (!ended[i] || t.tracks[i].cam_ids.empty()) continue;
     const int last_id = t.tracks[i].cam_ids.back();
-    for (int idx : t.tracks[i].cam_ids) {
-      const auto it = cam_of.find(idx);
-      if (it != cam_of.end() && t.cams[it->second].tracked.empty()) t.cams[it->second].last_correlated_id = last_id;
-    }
+    for (int idx : t.tracks[i].cam_ids)
+      for (auto& cs : t.cams)
+        if (cs.state_id == idx) { if (cs.tracked.empty()) cs.last_correlated_id = last_id; break; }
   }
   {
     size_t w = 0;
@@ -1752,10 +1783,13 @@ int host_add_features(BatchBase* B, int b, const double* meas, const uint64_t* i
   HostTraj& t = B->traj[b];
   if (!t.initialized) return fail(-EINVAL, "trajectory not initialized");
   if (t.cams.empty()) return fail(-EINVAL, "addFeatures() before augmentState() (msckf.h:320)");
-  std::unordered_set<uint64_t> known(t.tracked_ids.begin(), t.tracked_ids.end());
+  static thread_local FlatIndex known;
+  known.reset(t.tracked_ids.size() + (size_t)n);
+  for (size_t i = 0; i < t.tracked_ids.size(); ++i) known.insert_first(t.tracked_ids[i], (int)i);
   for (int i = 0; i < n; ++i) {
-    if (!known.insert(ids[i]).second)
+    if (known.find(ids[i]) >= 0)
       return fail(-EEXIST, "added new feature that was already being tracked");   // msckf.h:328-329 prints and returns
+    known.insert_first(ids[i], (int)t.tracked_ids.size());
     Track tr; tr.id = ids[i];
     tr.obs.push_back(meas[2 * i]); tr.obs.push_back(meas[2 * i + 1]);
     t.cams.back().tracked.push_back(ids[i]);
