@@ -407,6 +407,10 @@ template <class S> void launch_compress(const Dev<S>& d, int b0, int nb, hipStre
 // phase: 0 = both, 1 = Gram accumulation only, 2 = Cholesky only, 3 = SYRK only (the block-diagonal part came with launch_select_diag)
 template <class S> void launch_gram(const Dev<S>& d, int b0, int nb, hipStream_t st, int phase);
 template <class S> void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st);
+// kernels_kalman.hip: Gram matrix, both factorizations, gain, state injection and covariance downdate of a SMALL window (n_max = 6 x cameras) in one
+// launch, one workgroup per trajectory; false when the window does not fit its LDS (the caller then takes the usual chain)
+template <class S> bool launch_update_small(const Dev<S>& d, int b0, int nb, hipStream_t st, int n_max);
+size_t update_small_lds_bytes(int n_max, int f_cap, size_t scalar);
 template <class S> void launch_literal(const Dev<S>& d, int b0, int nb, hipStream_t st, int part = 0);   // kernels_literal.hip: Lam^ of the literal anisotropic compression (part: 0 all, 1 k_lit_pre, 2 k_lit_gamma, 3 k_literal)
 // blocked matrix-core Cholesky (kernels_chol.hip): [T | r_n] = chol(Lam^) for the information form; S = L L^T with
 // [PHt ; r_n^T] appended (W, dx) for the float Kalman stage.  Return false when the window does not fit the kernel.

@@ -146,8 +146,8 @@ template <int OP> __device__ __forceinline__ float opb_fix(const KView<float>& v
 // State injection from a finished dx (msckf.h:1373-1391, buildUpdateQuat :851-872), for one trajectory, by the threads of one
 // workgroup: the square-root gain form runs it inside the first tile's workgroup of the covariance downdate (one launch less).
 template <class S>
-__device__ __forceinline__ void inject_from_dx(const Dev<S>& d, int b, int tid, int nthreads) {
-  const S* dx = d.dx + (long)b * d.ld;
+__device__ __forceinline__ void inject_from_dx(const Dev<S>& d, int b, int tid, int nthreads, const S* dx_in = nullptr) {
+  const S* dx = dx_in ? dx_in : d.dx + (long)b * d.ld;
   S* imu = d.imu + (long)b * IMU_STRIDE;
   // every load of a thread is issued before its first store (a store to imu / cam may alias dx as far as the compiler knows:
   // interleaved, each += became its own load -> wait -> store round trip, ~12 in a row on the thread that also owns a GEMM tile)
@@ -947,6 +947,383 @@ static void launch_gain_w(const Dev<S>& d, int b0, int nb, hipStream_t st) {
 static bool gain_blocked(const Dev<float>& d, int b0, int nb, hipStream_t st) { return launch_chol_gain(d, b0, nb, st); }
 static bool gain_blocked(const Dev<double>&, int, int, hipStream_t) { return false; }
 
+// ---------------------------------------------------------------- k_update_small: the whole update of a SMALL window in one launch
+// Single filters with short windows (BASELINE.json configs[1]: 10 cameras, D = 75 .. 81) ran their update as a chain of six
+// launches after k_select_diag -- k_gram, k_chol_mfma, two GEMMs, k_gain_w, the downdate GEMM, each a latency chain of its own
+// plus a launch boundary: 104 us of kernels for 1.5 MFLOP.  Everything fits ONE workgroup's LDS at these sizes:
+//   A  Lam^ = blockdiag(sum h^T h | sum h^T r) - sum_j [B_j | c_j]^T [B_j | c_j]      (msckf.h:404-431 in information form, f64)
+//   B  [T | r_n] = chol(Lam^)     a pivot below 64 eps x its original diagonal is a gauge direction: zero row (kernels_chol.hip's rule)
+//   C  PHt = P[:, 15:] T^T        D  S = T PHt[15:, :] + sigma^2 I                                                      (:1369)
+//   E  S = L L^T with the rows [PHt ; r_n^T] riding along: they come out as W = PHt L^-T and z^T = (L^-1 r_n)^T           (:1370)
+//   G  dx = W z, state injection (:1373-1391)     H  P <- P - W W^T
+// The products (A, C, D, H) run on the matrix cores in 16 x 16 tiles (v_mfma_*_16x16x4, operands straight from LDS); the two
+// factorizations keep the matrix in REGISTERS -- a wavefront task is 64 rows x 8 columns, lane = row -- and per pivot only the
+// pivot's column crosses LDS: the owners publish it unscaled together with 1 / sqrt(pivot), one barrier, every task updates
+// its columns right of the pivot (x -= (c_i d^2) c_j: one per-lane read, eight wave-uniform reads, eight FMAs).  P[:, 15:] is
+// fetched into LDS once, while A runs.  First form of the kernel (scalar loops over LDS, 512 threads): ~200 us.
+#ifdef MSCKF_ABLATE
+// phase timers of the -DMSCKF_ABLATE build (scripts/us_phases.py): shader-clock cycles of thread 0 per phase of k_update_small, summed over launches
+// [0 A Gram, 1 P to LDS + loads of B, 2 B chol(Lam^), 3 C PHt, 4 D S, 5 E loads, 6 E chol(S) + W, 7 G dx, 8 H downdate, 9 injection, 15 launches]
+__device__ unsigned long long g_us_cycles[16];
+void us_cycles_read(unsigned long long* out16, int reset) {
+  (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_us_cycles), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_us_cycles), z, sizeof(z)); }
+}
+#define US_TICK(slot) do { if (tid == 0 && blockIdx.x == 0) { const long long t_ = clock64(); atomicAdd(&g_us_cycles[slot], (unsigned long long)(t_ - us_t)); us_t = t_; } } while (0)
+#else
+#define US_TICK(slot) do {} while (0)
+#endif
+typedef double us_d4 __attribute__((ext_vector_type(4)));
+typedef float us_f4 __attribute__((ext_vector_type(4)));
+template <class T> struct UsM;
+template <> struct UsM<double> {
+  typedef us_d4 V;
+  static __device__ __forceinline__ V mma(double a, double b, V c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
+  static __device__ __forceinline__ double clamp() { return 1e-300; }    // a non-positive pivot (reported): its rsqrt squared stays finite
+};
+template <> struct UsM<float> {
+  typedef us_f4 V;
+  static __device__ __forceinline__ V mma(float a, float b, V c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }
+  static __device__ __forceinline__ float clamp() { return 1e-30f; }
+};
+constexpr int US_UMAX = 2;     // tasks per wavefront of the factorizations
+constexpr int US_SEG_E = 12;   // columns per task of chol(S) with its D + 1 riding rows (10 cameras: 3 row chunks x 5 segments = 15 tasks); chol(Lam^): SEGB = 4 (61 rows: one chunk, 15 tasks) or 8
+// scalars of the PHt / W block [15 + n_max][n_max | 1]: it also stages 24 rows of B^ (doubles, 16 ceil((n_max + 1) / 16) + 1 columns) in
+// phase A, the larger need for the first few frames of a window; and of the P staging block [n_max][(15 + n_max) | 1], later S [n_max][n_max | 1]
+__host__ __device__ inline size_t update_small_ph_elems(int n_max, size_t scalar) {
+  const size_t w = (size_t)(15 + n_max) * (n_max | 1), nb1 = 16 * (((size_t)n_max + 1 + 15) / 16) + 1, stg = (24 * nb1 * sizeof(double) + scalar - 1) / scalar;
+  return ((w > stg ? w : stg) + 3) & ~(size_t)3;
+}
+// (phase A keeps two ints per included track there: f_cap of them at most)
+__host__ __device__ inline size_t update_small_pt_elems(int n_max, int f_cap, size_t scalar) {
+  const size_t a = (size_t)n_max * ((15 + n_max) | 1), b = (size_t)n_max * (n_max | 1), c = ((size_t)f_cap * 2 * sizeof(int) + scalar - 1) / scalar;
+  const size_t m = a > b ? (a > c ? a : c) : (b > c ? b : c);
+  return (m + 3) & ~(size_t)3;
+}
+// one 16 x 16 tile of sum_k a(16 ti + m, k) b(k, 16 tj + c), k in [k0, k1) in steps of 4 (the functors return zero out of range)
+template <class T, class FA, class FB>
+__device__ __forceinline__ typename UsM<T>::V us_tile(int ti, int tj, int k0, int k1, int lane, FA&& fa, FB&& fb) {
+  typename UsM<T>::V acc = {0, 0, 0, 0};
+  const int m = lane & 15, g = lane >> 4;
+  for (int k = k0; k < k1; k += 4) acc = UsM<T>::mma(fa(16 * ti + m, k + g), fb(k + g, 16 * tj + m), acc);
+  return acc;
+}
+// Right-looking Cholesky of the leading n x n block of a tall matrix (R rows) held in registers, rows n .. R-1 riding along.
+// Task t = w + 16 u of wavefront w: column segment cs = t % ncs (columns SEG cs .. SEG cs + SEG - 1), row chunk t / ncs (row 64 rc +
+// lane).  sCol[(k & 1) * cstride + i]: column k, unscaled, as its owners left it; slot R of it: 1 / sqrt(pivot k) (0: skipped).
+// store(i, k, L(i, k)) is called for the entries i >= k of the finished column k by the task that owns it.
+// What a step costs is the number of instructions its slowest wavefront issues between two barriers (one wavefront issues an
+// instruction every ~6 cycles here), so: every LDS read of the step in one round trip; no masks -- registers of finished
+// columns (j <= k), of columns beyond n and of rows beyond R are dead and may take garbage; the pivot's tolerance waits in a
+// register of its row's lane; the column to publish is picked by a wave-uniform register index.
+template <class T, int SEG, bool SEMIDEF, class Store>
+__device__ __forceinline__ void us_chol_tall(T (&x)[US_UMAX][SEG], const int n, const int R, const int ncs, const int ntask, const int w, const int lane,
+                                             T* sCol, const int cstride, const double* sD0, int* sFlag, Store&& store) {
+  int cs_u[US_UMAX], i_u[US_UMAX]; bool on[US_UMAX]; T told[US_UMAX];
+#pragma unroll
+  for (int u = 0; u < US_UMAX; ++u) {
+    const int t = w + 16 * u; on[u] = t < ntask; cs_u[u] = t % ncs; i_u[u] = 64 * (t / ncs) + lane;
+    told[u] = SEMIDEF ? T(64.0 * 2.220446049250313e-16) * (T)sD0[min(i_u[u], n)] : T(0);
+  }
+  // column j1 (register jj of task u) as it stands, with its pivot's reciprocal square root
+  auto publish = [&](int u, const T v, int j1) __attribute__((always_inline)) {
+    T* col = sCol + (j1 & 1) * cstride;
+    if (i_u[u] < R) col[i_u[u]] = v;
+    if (i_u[u] == j1) {
+      T piv = v; bool skip = false;
+      if (SEMIDEF) { skip = !(piv > told[u]); if (skip) atomicAdd(&sFlag[0], 1); }
+      else { if (!(piv > T(0))) sFlag[1] = 1; piv = piv > UsM<T>::clamp() ? piv : UsM<T>::clamp(); }
+      col[R] = skip ? T(0) : fast_rsqrt(piv);
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < US_UMAX; ++u) if (on[u] && cs_u[u] == 0) publish(u, x[u][0], 0);
+  __syncthreads();
+  for (int k = 0; k < n; ++k) {
+    const T* col = sCol + (k & 1) * cstride;
+    const int kc = k / SEG;
+#pragma unroll
+    for (int u = 0; u < US_UMAX; ++u) {
+      if (!on[u] || cs_u[u] < kc) continue;                  // wave-uniform: every column of the task is finished
+      const int i = i_u[u];
+      const int j0 = SEG * cs_u[u];
+      const T dinv = col[R];
+      const T ci = col[min(i, R - 1)];
+      T cj[SEG];
+#pragma unroll
+      for (int jj = 0; jj < SEG; ++jj) cj[jj] = col[j0 + jj];        // wave-uniform addresses (SEG ncs <= cstride)
+      const T li = ci * dinv;                                // L(i, k)
+      if (cs_u[u] == kc && (unsigned)(i - k) < (unsigned)(R - k)) store(i, k, li);
+      const T li2 = li * dinv;
+#pragma unroll
+      for (int jj = 0; jj < SEG; ++jj) x[u][jj] -= li2 * cj[jj];
+      const int jj1 = __builtin_amdgcn_readfirstlane(k + 1 - j0);
+      if (k + 1 < n && jj1 >= 0 && jj1 < SEG) {
+        T v = x[u][0];
+#pragma unroll
+        for (int jj = 1; jj < SEG; ++jj) v = jj == jj1 ? x[u][jj] : v;
+        publish(u, v, k + 1);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <class S, int US_SEG_B>
+__global__ __launch_bounds__(1024) void k_update_small(Dev<S> d, int b0, int n_max) {
+  typedef typename UsM<S>::V VS;
+  typedef typename UsM<double>::V VD;
+  const int b = b0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int* st = d.stats + (long)b * STAT_STRIDE;
+  const int mrows_ = st[STAT_MROWS], npass = st[STAT_PASSED], N = d.ncam[b];
+  // run_frames: the frame's prune rides on the downdate (Dev::Pout, as in the tile GEMM's OP_DOWN): P - W W^T goes straight to its
+  // pruned position in the other buffer; a trajectory without an update still has its covariance moved there
+  const bool fused_prune = d.Pout != nullptr;
+  const bool upd = mrows_ != 0;
+  if (!upd && !fused_prune) return;
+  int nd_ = 0;
+  if (fused_prune) { nd_ = d.fuse_drop[blockIdx.x]; nd_ = nd_ < 0 ? 0 : (nd_ > N ? N : nd_); }
+  const int n = 6 * N, n1 = n + 1, D = 15 + n, ld = d.ld, ldR = d.ldR, f_cap = d.f_cap;
+  const int LL = (n_max + 1) | 1, LS = n_max | 1, Dm = 15 + n_max, Dp = Dm | 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* sL = reinterpret_cast<double*>(smem_raw);                 // [(n_max+1)][LL] lower: Lam^ -> L (T = L^T, row n = r_n^T), upper zero after B
+  double* sD0 = sL + (size_t)(n_max + 1) * LL;                      // [n_max+2] original diagonal (pivot tolerance)
+  double* sColD = sD0 + n_max + 2;                                  // [2][cstride] published columns (doubles in B, S in E)
+  const int cstride = 2 * n_max + 20;
+  S* sPT = reinterpret_cast<S*>(sColD + 2 * cstride);               // [n_max][Dp] P(r, 15 + c) at [c][r]; later S at [i][LS]
+  S* sPH = sPT + update_small_pt_elems(n_max, f_cap, sizeof(S));                      // [Dm][LS] PHt -> W   (phase A: staging of B^ rows, doubles)
+  S* sZ = sPH + update_small_ph_elems(n_max, sizeof(S));            // [n_max+2] z = L^-1 r_n
+  S* sdx = sZ + n_max + 2;                                          // [Dm]
+  int* sFlag = reinterpret_cast<int*>(sdx + Dm + 1);                // skipped pivots, bad pivot
+#ifdef MSCKF_ABLATE
+  long long us_t = clock64();
+  if (tid == 0 && blockIdx.x == 0) atomicAdd(&g_us_cycles[15], 1ull);
+#endif
+  if (upd) {
+    if (tid < 2) sFlag[tid] = 0;
+    for (int e = tid; e < (n_max + 1) * LL; e += 1024) sL[e] = 0.0;   // (its upper triangle is never written: C and D read zeros there)
+    // P[:, 15:] on its way into registers (consecutive threads along a row of P: P is symmetric, row 15 + c = column 15 + c)
+    const S* P = d.P + (long)b * ld * ld;
+    constexpr int EPP = 7;                                            // 1024 * 7 >= 87 * 72
+    S pst[EPP];
+#pragma unroll
+    for (int q = 0; q < EPP; ++q) {
+      const int e = tid + 1024 * q, c = e / D, r = e - c * D;
+      pst[q] = P[(long)(15 + min(c, n - 1)) * ld + r];
+    }
+    // ---- A: Lam^ (lower tiles incl. row n): a wavefront per 16 x 16 tile, the B^ rows of the included tracks staged eight tracks at a time
+    const double* Dg = d.Dg + (long)b * d.n_cap * DG_STRIDE;
+    const int* order = d.trk_order + (long)b * f_cap;
+    const int nt1 = (n1 + 15) >> 4;                                   // tiles per side of Lam^ (<= 5: 15 lower tiles)
+    int ati = 0, atj = 0; bool atile = false;
+    { int t = 0; for (int i = 0; i < nt1; ++i) for (int j = 0; j <= i; ++j, ++t) if (t == w) { ati = i; atj = j; atile = true; } }
+    VD lacc = {0, 0, 0, 0};
+    double dgt[4];                                                    // the tile's block-diagonal terms: loads issued now, used at the end of the phase
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * ati + UsM<double>::row(lane, r), j = 16 * atj + (lane & 15);
+      dgt[r] = (atile && i <= n && j <= i && !(i == n && j == n)) ? lam_diag_term(Dg, n, d.n_cap, i, j) : 0.0;
+    }
+    {
+      double* sB = reinterpret_cast<double*>(sPH);                    // [24][16 nt1 + 1]
+      const int nb1 = 16 * nt1 + 1;
+      // the included tracks' row addresses and slot ranges once, through LDS (the P staging block is free until the end of this
+      // phase): the staging loop below then is ONE level of global loads per round instead of three dependent ones
+      int* sTrk = reinterpret_cast<int*>(sPT);                        // [npass][2]: track, first | last << 8
+      for (int e = tid; e < npass; e += 1024) { const int t = order[e]; sTrk[2 * e] = t; sTrk[2 * e + 1] = d.trk_first[(long)b * f_cap + t]; }
+      for (int t0 = 0; t0 < npass; t0 += 8) {
+        __syncthreads();
+        const int nt = min(8, npass - t0);
+        // (24 x 81 entries at most: two per thread, both loads in flight before the first is stored)
+        double sv[2]; int se[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int e = tid + 1024 * h, row = e / nb1, c = e - row * nb1, tl = row / 3, q = row - 3 * tl;
+          double v = 0.0;
+          if (e < 24 * nb1 && tl < nt && c < n1) {
+            const int t = sTrk[2 * (t0 + tl)], fl = sTrk[2 * (t0 + tl) + 1], first = fl & 63, last = (fl >> 8) & 63;
+            // k_feature writes a track's rows only inside its slot range and at column n: everything else reads as zero
+            if (c == n || (c >= 6 * first && c < 6 * (last + 1))) v = d.trk_B[((long)b * f_cap + t) * 3 * ldR + (long)q * ldR + c];
+          }
+          sv[h] = v; se[h] = e;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) if (se[h] < 24 * nb1) sB[se[h]] = sv[h];
+        __syncthreads();
+        if (atile) {
+          const int m = lane & 15, g = lane >> 4;
+#pragma unroll
+          for (int k = 0; k < 24; k += 4) lacc = UsM<double>::mma(sB[(k + g) * nb1 + 16 * ati + m], sB[(k + g) * nb1 + 16 * atj + m], lacc);
+        }
+      }
+    }
+    __syncthreads();
+    if (atile) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * ati + UsM<double>::row(lane, r), j = 16 * atj + (lane & 15);
+        if (i <= n && j <= i) {
+          const double v = dgt[r] - lacc[r];
+          sL[i * LL + j] = v;
+          if (i == j) sD0[i] = v;
+        }
+      }
+    }
+    US_TICK(0);
+    // P into LDS (the loads have had phase A to arrive)
+#pragma unroll
+    for (int q = 0; q < EPP; ++q) {
+      const int e = tid + 1024 * q, c = e / D, r = e - c * D;
+      if (c < n) sPT[c * Dp + r] = pst[q];
+    }
+    __syncthreads();
+    // ---- B: [T | r_n] = chol(Lam^): rows 0 .. n (row n rides), in registers; the finished columns go back to sL (whose upper triangle is zero)
+    {
+      double x[US_UMAX][US_SEG_B];
+      const int ncs = (n + US_SEG_B - 1) / US_SEG_B, R = n1, ntask = ncs * ((R + 63) >> 6);
+#pragma unroll
+      for (int u = 0; u < US_UMAX; ++u) {
+        const int t = w + 16 * u, cs = t % ncs, i = 64 * (t / ncs) + lane;
+#pragma unroll
+        for (int jj = 0; jj < US_SEG_B; ++jj) { const int j = US_SEG_B * cs + jj; x[u][jj] = (t < ntask && i < R && j < n && j <= i) ? sL[i * LL + j] : 0.0; }
+      }
+      __syncthreads();
+      US_TICK(1);
+      us_chol_tall<double, US_SEG_B, true>(x, n, R, ncs, ntask, w, lane, sColD, cstride, sD0, sFlag, [&](int i, int k, double v) { sL[i * LL + k] = v; });
+    }
+    US_TICK(2);
+    if (tid == 0) st[STAT_RROWS] = n - sFlag[0];
+    // ---- C: PHt = P[:, 15:] T^T = Pc L: tile (ti, tj) sums over c >= 16 tj (L is lower triangular)
+    {
+      const int ntr = (D + 15) >> 4, ntc = (n + 15) >> 4;
+      for (int t = w; t < ntr * ntc; t += 16) {
+        const int ti = t / ntc, tj = t - ti * ntc;
+        const VS acc = us_tile<S>(ti, tj, 16 * tj, n, lane,
+                                  [&](int r, int c) -> S { return (r < D && c < n) ? sPT[c * Dp + r] : S(0); },
+                                  [&](int c, int k) -> S { return (c < n && k < n) ? (S)sL[c * LL + k] : S(0); });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int i = 16 * ti + UsM<S>::row(lane, r), k = 16 * tj + (lane & 15); if (i < D && k < n) sPH[i * LS + k] = acc[r]; }
+      }
+    }
+    __syncthreads();
+    US_TICK(3);
+    // ---- D: S = T PHt[15:, :] + sigma^2 I, lower tiles, into the P staging block as [i][LS]
+    const S sig2 = d.prm[(long)b * PRM_STRIDE + PRM_SIG2];
+    S* sS = sPT;
+    {
+      const int ntc = (n + 15) >> 4;
+      int t = 0;
+      for (int ti = 0; ti < ntc; ++ti)
+        for (int tj = 0; tj <= ti; ++tj, ++t) {
+          if ((t & 15) != w) continue;
+          const VS acc = us_tile<S>(ti, tj, 16 * ti, n, lane,
+                                    [&](int i, int c) -> S { return (i < n && c < n) ? (S)sL[c * LL + i] : S(0); },
+                                    [&](int c, int j) -> S { return (c < n && j < n) ? sPH[(15 + c) * LS + j] : S(0); });
+          // (sS aliases the P staging block, which phase C has finished reading; this phase reads sL and sPH only)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const int i = 16 * ti + UsM<S>::row(lane, r), j = 16 * tj + (lane & 15); if (i < n && j <= i) sS[i * LS + j] = acc[r] + (i == j ? sig2 : S(0)); }
+        }
+    }
+    __syncthreads();
+    US_TICK(4);
+    // ---- E: S = L L^T in registers, rows n .. n + D - 1 = PHt and row n + D = r_n^T riding: W replaces PHt in place, z in sZ
+    {
+      S x[US_UMAX][US_SEG_E];
+      const int ncs = (n + US_SEG_E - 1) / US_SEG_E, R = n + D + 1, ntask = ncs * ((R + 63) >> 6);
+#pragma unroll
+      for (int u = 0; u < US_UMAX; ++u) {
+        const int t = w + 16 * u, cs = t % ncs, i = 64 * (t / ncs) + lane;
+#pragma unroll
+        for (int jj = 0; jj < US_SEG_E; ++jj) {
+          const int j = US_SEG_E * cs + jj;
+          S v = S(0);
+          if (t < ntask && j < n) {
+            if (i < n) v = j <= i ? sS[i * LS + j] : S(0);
+            else if (i < n + D) v = sPH[(i - n) * LS + j];
+            else if (i == n + D) v = (S)sL[n * LL + j];
+          }
+          x[u][jj] = v;
+        }
+      }
+      __syncthreads();
+      US_TICK(5);
+      S* sColS = reinterpret_cast<S*>(sColD);
+      us_chol_tall<S, US_SEG_E, false>(x, n, R, ncs, ntask, w, lane, sColS, cstride, sD0, sFlag,
+                                       [&](int i, int k, S v) { if (i >= n + D) sZ[k] = v; else if (i >= n) sPH[(i - n) * LS + k] = v; });
+    }
+    US_TICK(6);
+    if (tid == 0 && sFlag[1]) atomicOr(&st[STAT_ERR], STAT_ERR_PIVOT);
+    // ---- G: dx = W z, injected into the state
+    for (int r = tid; r < D; r += 1024) {
+      S a = 0;
+      for (int k = 0; k < n; ++k) a += sPH[r * LS + k] * sZ[k];
+      sdx[r] = a;
+      d.dx[(long)b * ld + r] = a;
+    }
+  }
+  US_TICK(7);
+  // ---- H: P <- P - W W^T, lower tiles on the matrix cores, both triangles written from the same value.  With the frame's prune
+  // riding along, rows / columns of the nd_ oldest camera states vanish and later ones move up by 6 nd_, into the other buffer
+  {
+    const S* Pr = d.P + (long)b * ld * ld;
+    S* Po = (fused_prune ? d.Pout : d.P) + (long)b * ld * ld;
+    const int ntr = (D + 15) >> 4, cut = 15 + 6 * nd_, kend = upd ? n : 0;
+    int t = 0;
+    for (int ti = 0; ti < ntr; ++ti)
+      for (int tj = 0; tj <= ti; ++tj, ++t) {
+        if ((t & 15) != w) continue;
+        S pv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int i = min(16 * ti + UsM<S>::row(lane, r), D - 1), j = min(16 * tj + (lane & 15), D - 1); pv[r] = Pr[(long)j * ld + i]; }
+        const VS acc = us_tile<S>(ti, tj, 0, kend, lane,
+                                  [&](int i, int k) -> S { return (i < D && k < n) ? sPH[i * LS + k] : S(0); },
+                                  [&](int k, int j) -> S { return (j < D && k < n) ? sPH[j * LS + k] : S(0); });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * ti + UsM<S>::row(lane, r), j = 16 * tj + (lane & 15);
+          const bool keep = (i < 15 || i >= cut) && (j < 15 || j >= cut);
+          if (i < D && j <= i && keep) {
+            const int di = i < 15 ? i : i - 6 * nd_, dj = j < 15 ? j : j - 6 * nd_;
+            const S v = pv[r] - acc[r];
+            Po[(long)dj * ld + di] = v; Po[(long)di * ld + dj] = v;
+          }
+        }
+      }
+  }
+  __syncthreads();
+  US_TICK(8);
+  if (upd && tid < 256) inject_from_dx<S>(d, b, tid, 256, sdx);
+  if (fused_prune) {
+    __syncthreads();   // the camera states just corrected are compacted by other threads
+    prune_bookkeeping<S>(d, b, tid, N, N - nd_, nd_, 0);
+  }
+  US_TICK(9);
+}
+
+static bool update_small_ok = false;   // the 160 KB attribute was granted (kalman_device_setup)
+size_t update_small_lds_bytes(int n_max, int f_cap, size_t scalar) {
+  const size_t n1 = (size_t)n_max + 1, LL = n1 | 1, Dm = 15 + (size_t)n_max, cstride = 2 * (size_t)n_max + 20;
+  return (n1 * LL + n1 + 1 + 2 * cstride) * sizeof(double) + (update_small_pt_elems(n_max, f_cap, scalar) + update_small_ph_elems(n_max, scalar) + n_max + 2 + Dm + 1) * scalar + 64;
+}
+template <class S>
+bool launch_update_small(const Dev<S>& d, int b0, int nb, hipStream_t st, int n_max) {
+  if (nb <= 0) return true;
+  const size_t lds = update_small_lds_bytes(n_max, d.f_cap, sizeof(S));
+  // tasks of the factorizations: ceil(n / 12) x ceil((2 n + 16) / 64) and ceil(n / 4) x ceil((n + 1) / 64) <= 32; tiles of Lam^: <= 15 of the 16 wavefronts
+  const int ncs = (n_max + US_SEG_E - 1) / US_SEG_E, nrc = (2 * n_max + 16 + 63) / 64, nt1 = (n_max + 1 + 15) / 16;
+  const int nrcb = (n_max + 1 + 63) / 64;
+  const bool b4 = ((n_max + 3) / 4) * nrcb <= 16 * US_UMAX, b8 = ((n_max + 7) / 8) * nrcb <= 16 * US_UMAX;
+  if (!update_small_ok || lds > 156 * 1024 || ncs * nrc > 16 * US_UMAX || !(b4 || b8) || nt1 * (nt1 + 1) / 2 > 16 || (15 + n_max) * n_max > 1024 * 7) return false;
+  if (b4) hipLaunchKernelGGL((k_update_small<S, 4>), dim3(nb), dim3(1024), lds, st, d, b0, n_max);
+  else hipLaunchKernelGGL((k_update_small<S, 8>), dim3(nb), dim3(1024), lds, st, d, b0, n_max);
+  return true;
+}
+template bool launch_update_small<float>(const Dev<float>&, int, int, hipStream_t, int);
+template bool launch_update_small<double>(const Dev<double>&, int, int, hipStream_t, int);
+
 template <class S>
 void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if (nb <= 0) return;
@@ -1001,6 +1378,11 @@ void launch_kalman(const Dev<S>& d, int b0, int nb, hipStream_t st) {
 void kalman_device_setup() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_inv<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_inv<double, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  update_small_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_update_small<float, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(k_update_small<double, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(k_update_small<float, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(k_update_small<double, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+  (void)hipGetLastError();
 }
 
 template void launch_kalman<float>(const Dev<float>&, int, int, hipStream_t);

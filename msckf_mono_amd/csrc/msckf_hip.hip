@@ -232,6 +232,7 @@ struct Batch : BatchBase {
   hipStream_t sty[MAXS] = {nullptr}; hipEvent_t ev_fa[MAXS] = {nullptr}, ev_fb[MAXS] = {nullptr};
   S* P_spare = nullptr;   // second covariance buffer: target of a downdate that carries the frame's prune (Dev::Pout)
   int fuse_prune = 1;     // run_frames: prune rides on the downdate (MSCKF_HIP_FUSE_PRUNE=0: separate k_prune_inplace launch)
+  int small_update = 84;     // windows of at most this many camera columns (6 x cameras) take the one-launch update k_update_small; MSCKF_HIP_SMALL_UPDATE=0 switches it off
   int overlap_feature = 0;   // measured on MI355X at cfg3: 100 k -> 82 k updates/s with the overlap on (k_feature floods the CUs the
                              // latency-bound propagate/augment workgroups need); kept selectable, off by default
   int compress_route = -1;   // -1 default, 0 Householder TSQR, != 0 information form + blocked matrix-core Cholesky
@@ -366,6 +367,7 @@ struct Batch : BatchBase {
     rc |= dalloc(&d_pfin, TF * 4); d.trk_pfin = d_pfin; d.mode = 0; d.joseph = 0; d.ncam_bias = 0;
     { const char* e = getenv("MSCKF_HIP_FUSED_S"); d.gain_fused_s = e ? atoi(e) : 2; }
     { const char* e = getenv("MSCKF_HIP_FEATURE_PAIR"); d.feat_pair = e ? atoi(e) : 1; }
+    { const char* e = getenv("MSCKF_HIP_SMALL_UPDATE"); if (e) small_update = atoi(e); }
     rc |= dalloc(&d.gain_bar, Bz * 32);   // 0: the S GEMM as a launch of its own (A/B runs)
     rd_cap = 64;
     rc |= dalloc(&d_rd, Bz * rd_cap * RD_STRIDE);
@@ -799,13 +801,27 @@ struct Batch : BatchBase {
     if (n_lit > 0 && !cmp) cmp = d.compress;
     return cmp;
   }
-  void launch_update(const Dev<S>& vin, int b0, int nb, hipStream_t q, bool feature_done = false) {
+  // ncam_ahead: run_frames advances its host mirror of the window sizes after the frame's launches (the frame's augmentState is
+  // not in h_ncam yet when its update is enqueued).  Which route a frame takes depends on the window sizes only -- never on how a
+  // frame range is cut into calls or on the API used (bit-identical results either way)
+  void launch_update(const Dev<S>& vin, int b0, int nb, hipStream_t q, bool feature_done = false, int ncam_ahead = 0) {
     invalidate_imu(b0, nb);            // the update corrects the IMU state on the device (msckf.h:1376-1383)
     Dev<S> v = vin;
     v.compress = update_compress(v.compress);
     if (!feature_done) { stage_begin(2, q); launch_feature<S>(v, b0, nb, q); stage_end(2, q); }
     // information form: k_select and the block-diagonal reduction share a launch (both only read k_feature's outputs)
     stage_begin(7, q); if (v.compress) launch_select_diag<S>(v, b0, nb, q); else launch_select<S>(v, b0, nb, q); stage_end(7, q);
+    // short windows (single filters, BASELINE configs[1]): everything after the selection in ONE launch (k_update_small)
+    if (small_update && v.compress && n_lit == 0 && d.joseph == 0) {
+      int nmax = 0;
+      for (int b = b0; b < b0 + nb; ++b) nmax = std::max(nmax, 6 * std::min(h_ncam[b] + ncam_ahead, n_cap));
+      if (nmax > 0 && nmax <= small_update) {
+        stage_begin(5, q);
+        const bool ok = launch_update_small<S>(v, b0, nb, q, nmax);
+        stage_end(5, q);
+        if (ok) return;
+      }
+    }
     if (v.compress) {
       // anisotropic pixel noise, literal route: the information matrix of the reference's (T_H, r_n, R_n) replaces H_o^T H_o
       // for those trajectories (kernels_literal.hip)
@@ -1508,7 +1524,7 @@ int Batch<S>::run_frames(int f0, int f1) {
       if (early) (void)hipStreamWaitEvent(q, ev_fb[hh], 0);
       v.ncam_defer = 0;
       if (fuse) { v.Pout = spare; v.fuse_drop = (const int*)(sc_drop + cell0 + b0); }
-      { StageRange r(fuse ? "msckf_marginalize+msckf_prune_empty_states" : "msckf_marginalize"); launch_update(v, b0, nb, q, early); }
+      { StageRange r(fuse ? "msckf_marginalize+msckf_prune_empty_states" : "msckf_marginalize"); launch_update(v, b0, nb, q, early, 1); }
       if (fuse) { std::swap(curP, spare); pending = true; }
       else {
         StageRange r("msckf_prune_empty_states");
@@ -1605,7 +1621,7 @@ int Batch<S>::run_frames_streamed(int f0, int f1) {
       if (prof) { stage_begin(1, q); launch_augment<S>(v, b0, nb, q); stage_end(1, q); }
       v.ncam_defer = 0;
       if (fuse) { v.Pout = spare; v.fuse_drop = (const int*)(reinterpret_cast<int*>(blk + pk_drop) + b0); }
-      launch_update(v, b0, nb, q);
+      launch_update(v, b0, nb, q, false, 1);
       if (fuse) { std::swap(curP, spare); pending = true; }
       else {
         stage_begin(6, q);
@@ -2320,7 +2336,7 @@ BatchBase* H(msckf_hip_handle h) { return reinterpret_cast<BatchBase*>(h); }
 }  // namespace
 
 #ifdef MSCKF_ABLATE
-namespace msckf { void qr_debug_set(int idx, int val); void feat_debug_set(int val); void featp_cycles_read(unsigned long long* out8, int reset); extern int g_gram_dbg; void chol_cycles_read(unsigned long long* out16, int reset); void chol_sub_read(unsigned long long* out32, int reset); void chol_debug_set(int v); void prop_cycles_read(unsigned long long* out8, int reset); void gram_cycles_read(unsigned long long* out40, int reset); void gemm_cycles_read(unsigned long long* out16, int reset); void gemm_trace_read(unsigned long long* out); }
+namespace msckf { void qr_debug_set(int idx, int val); void feat_debug_set(int val); void featp_cycles_read(unsigned long long* out8, int reset); extern int g_gram_dbg; void chol_cycles_read(unsigned long long* out16, int reset); void chol_sub_read(unsigned long long* out32, int reset); void chol_debug_set(int v); void prop_cycles_read(unsigned long long* out8, int reset); void gram_cycles_read(unsigned long long* out40, int reset); void gemm_cycles_read(unsigned long long* out16, int reset); void gemm_trace_read(unsigned long long* out); void us_cycles_read(unsigned long long* out16, int reset); }
 #endif
 
 extern "C" {
@@ -2340,6 +2356,7 @@ void msckf_hip_debug_featp_cycles(unsigned long long* out8, int reset) { msckf::
 void msckf_hip_debug_gram_cycles(unsigned long long* out40, int reset) { msckf::gram_cycles_read(out40, reset); }
 void msckf_hip_debug_gemm_cycles(unsigned long long* out16, int reset) { msckf::gemm_cycles_read(out16, reset); }
 void msckf_hip_debug_gemm_trace(unsigned long long* out) { msckf::gemm_trace_read(out); }
+void msckf_hip_debug_us_cycles(unsigned long long* out16, int reset) { msckf::us_cycles_read(out16, reset); }
 #endif
 
 const char* msckf_hip_last_error(void) { return g_err.c_str(); }
