@@ -1074,7 +1074,11 @@ __device__ __forceinline__ int half_min_i(int v) {
   return min((int)r[0], (int)r[1]);
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_feature_pair(Dev<float> d, int b0, int nb, int lm, int m_lo, int m_hi, int s_cap, int items, int single) {
+// Three wavefronts per SIMD (168 registers): at four (128) the kernel spilled 34 live values to scratch -- 56 MB of the launch's
+// 96 MB of writes at 64 trajectories, ~70 scratch instructions per wavefront; at three it spills 5.  One stream of 64
+// trajectories: 82.6 -> 84.6 us; four slices of 16 (the bench): 185-189 k -> 192-193 k updates/s on the same lease.  (Both builds
+// side by side, picked by launch size, measured 95 us for the large launches -- dropped.)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_feature_pair(Dev<float> d, int b0, int nb, int lm, int m_lo, int m_hi, int s_cap, int items, int single) {
   typedef float S;
   int bi, w;
   if (!xcd_item(nb, items, bi, w)) return;
@@ -1545,10 +1549,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       }
     }
     if (act) {
+      // 16-byte stores (a lane's 48 bytes of H_x / of a B^ row are contiguous and 16-byte aligned: ldR and m_cap * 12 are multiples
+      // of 4 elements): 3 + 9 + 1 store instructions per lane instead of 12 + 18 + 2, whole 16-byte sectors reach the L2
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      typedef double d2v __attribute__((ext_vector_type(2)));
+      typedef float f2v __attribute__((ext_vector_type(2)));
       if (d.h16) { __half* oH = d.trk_Hx16 + (tb * m_cap) * 12; for (int i = 0; i < 2; ++i) for (int k = 0; k < 6; ++k) oH[gl * 12 + i * 6 + k] = __float2half_rn((float)hx[i][k]); }
-      else { S* oHx = d.trk_Hx + (tb * m_cap) * 12; for (int i = 0; i < 2; ++i) for (int k = 0; k < 6; ++k) oHx[gl * 12 + i * 6 + k] = hx[i][k]; }
-      for (int qr = 0; qr < 3; ++qr) for (int k = 0; k < 6; ++k) oB[(long)qr * d.ldR + 6 * slot + k] = Bq[qr][k];
-      d.trk_rw[tb * 2 * m_cap + 2 * gl] = r[0]; d.trk_rw[tb * 2 * m_cap + 2 * gl + 1] = r[1];
+      else {
+        f4v* oHx = reinterpret_cast<f4v*>(d.trk_Hx + (tb * m_cap) * 12 + gl * 12);
+        oHx[0] = f4v{hx[0][0], hx[0][1], hx[0][2], hx[0][3]}; oHx[1] = f4v{hx[0][4], hx[0][5], hx[1][0], hx[1][1]}; oHx[2] = f4v{hx[1][2], hx[1][3], hx[1][4], hx[1][5]};
+      }
+#pragma unroll
+      for (int qr = 0; qr < 3; ++qr) {
+        d2v* ob = reinterpret_cast<d2v*>(oB + (long)qr * d.ldR + 6 * slot);
+        ob[0] = d2v{Bq[qr][0], Bq[qr][1]}; ob[1] = d2v{Bq[qr][2], Bq[qr][3]}; ob[2] = d2v{Bq[qr][4], Bq[qr][5]};
+      }
+      *reinterpret_cast<f2v*>(d.trk_rw + tb * 2 * m_cap + 2 * gl) = f2v{r[0], r[1]};
     }
     if (has && gl < 3) oB[(long)gl * d.ldR + 6 * ncam_now] = gl == 0 ? q.cq[0] : (gl == 1 ? q.cq[1] : q.cq[2]);
   }

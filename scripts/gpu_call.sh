@@ -92,7 +92,7 @@ if has lit_profile || has cfg2_profile; then
     rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD --kernel-trace -d /tmp/q4 -o r -- python /root/repo/bench.py $C4 > /tmp/c4.log 2>&1
     rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_ACTIVE_INST_LDS --kernel-trace -d /tmp/q5 -o r -- python /root/repo/bench.py $C4 > /tmp/c5.log 2>&1
     mkdir -p /root/repo/$O/lit
-    PMC_TAG=$TAG PMC_COMMIT=${PMC_COMMIT:-unknown} PMC_CSRC_HASH=$(python -c 'import bench; print(bench.csrc_hash())') python /root/repo/scripts/rocpd_pmc.py /root/repo/$O/lit/pmc_cfg4_literal.md $(find /tmp/q2 /tmp/q3 /tmp/q4 /tmp/q5 -name "*.db") > /dev/null
+    PMC_TAG=$TAG PMC_COMMIT=${PMC_COMMIT:-unknown} PMC_CSRC_HASH=$(cd /root/repo && python -c 'import bench; print(bench.csrc_hash())') python /root/repo/scripts/rocpd_pmc.py /root/repo/$O/lit/pmc_cfg4_literal.md $(find /tmp/q2 /tmp/q3 /tmp/q4 /tmp/q5 -name "*.db") > /dev/null
     cp /root/repo/$O/lit/pmc_cfg4_literal.md /root/repo/$O/pmc_cfg4_literal.md
     if [ -f /root/repo/$O/pmc_traffic.json ]; then python /root/repo/scripts/pmc_merge.py /root/repo/$O/pmc_traffic.json /root/repo/$O/lit/pmc_traffic.json; fi
     head -16 /root/repo/$O/kernel_stats_cfg4_literal.md
