@@ -643,7 +643,7 @@ enum { TR_GRAM = 0, TR_S21 = 1, TR_W = 2 };
 // compiler must not move the reads above the writes -- per-thread addresses differ, so only the fences order them
 #define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 template <class T, class SO, int NP, int TMODE>
-__global__ __launch_bounds__(256) void k_trsm_rows(Dev<SO> d, int b0, int nb, int nwg) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_trsm_rows(Dev<SO> d, int b0, int nb, int nwg) {
   typedef typename Mf<T>::V V;
   constexpr int LP = 17;
   // the row blocks of a trajectory all read its factor L: on one XCD (xcd_item), whose private L2 then fetches it once
@@ -657,14 +657,19 @@ __global__ __launch_bounds__(256) void k_trsm_rows(Dev<SO> d, int b0, int nb, in
   const int ncols = TMODE == TR_W ? nfull : min(nfull, CH_SPLIT);      // columns of L that exist
   const int R0 = TMODE == TR_W ? 16 * i : CH_SPLIT + 16 * i;           // first row of the block (TR_W: row of [PHt ; r_n^T])
   const int row_end = TMODE == TR_GRAM ? nfull + 1 : (TMODE == TR_S21 ? nfull : D + 1);   // rows that exist
-  if (TMODE == TR_GRAM) { if (R0 >= d.ldR) return; } else if (R0 >= row_end) return;
+  // (a wavefront without a block keeps taking part in the staging of L and its barriers: `active` instead of a return)
+  bool active = TMODE == TR_GRAM ? R0 < d.ldR : R0 < row_end;
   double* Lam = TMODE == TR_GRAM ? d.Lam + (long)b * d.ldR * d.ldR : nullptr;
   SO* Sm = TMODE != TR_GRAM ? d.Smat + (long)b * d.n6cap * d.n6cap : nullptr;
   SO* Rt = d.Rbuf + ((long)b * d.nchunk) * (long)d.n6cap * d.ldR;
   __shared__ T sT[4][16][LP];
-  if (TMODE == TR_GRAM && R0 >= row_end) {               // nothing below the split in this block: zero columns of T_H
+  // round 6: the block column L(q, p), q > p, of the panel in LDS, fetched once per WORKGROUP with whole 64-byte rows; every
+  // wavefront of the four takes its MFMA operands from there.  (Before: every wavefront fetched every operand itself, a 4-byte
+  // load per lane scattered over sixteen rows, one per MFMA: the W solve of a 60-camera window ran at 9 % of the f32 MFMA rate.)
+  __shared__ T sLc[(NP - 1) * 16][LP];
+  if (TMODE == TR_GRAM && active && R0 >= row_end) {     // nothing below the split in this block: zero columns of T_H
     for (int e = lane; e < 16 * CH_SPLIT; e += 64) { const int k = e >> 4, c = e & 15; if (k < nfull) Rt[(long)k * d.ldR + R0 + c] = SO(0); }
-    return;
+    active = false;
   }
   auto xin = [&](int row, int col) -> T {                // X(row, col), row = absolute row of this mode's operand
     if (TMODE == TR_GRAM) return (T)lam_hat(Lam, nullptr, d.ldR, nfull, d.n_cap, row, col);
@@ -677,14 +682,26 @@ __global__ __launch_bounds__(256) void k_trsm_rows(Dev<SO> d, int b0, int nb, in
     if (TMODE == TR_GRAM) return (T)Lam[(long)(16 * q + r) * d.ldR + 16 * p + c];
     return (T)Sm[(long)(16 * q + r) * d.n6cap + 16 * p + c];
   };
+  const int lrow_max = (TMODE == TR_GRAM ? d.ldR : d.n6cap) - 1;   // last row of L's storage (rows past the matrix multiply columns that are never stored)
   V acc[NP];
 #pragma unroll
   for (int q = 0; q < NP; ++q)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[q][r] = xin(R0 + Mf<T>::row(lane, r), 16 * q + (lane & 15));
+    for (int r = 0; r < 4; ++r) acc[q][r] = active ? xin(R0 + Mf<T>::row(lane, r), 16 * q + (lane & 15)) : T(0);
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     if (16 * p >= ncols) continue;
+    // the panel's block column into LDS: rows 16 (p + 1) .. of the columns 16 p .. 16 p + 15 (sixteen threads per 64-byte row)
+    if (p + 1 < NP) {
+      __syncthreads();                                   // the previous panel's operands have been read
+      const int NRW = (NP - 1 - p) * 16;
+      for (int e0 = 0; e0 < NRW * 16; e0 += 256) {
+        const int e = e0 + tid, r = e >> 4, c = e & 15;
+        if (e < NRW * 16 && 16 * (p + 1) + (r & ~15) < ncols) sLc[r][c] = lblk(p + 1, p, min(r, lrow_max - 16 * (p + 1)), c);
+      }
+      __syncthreads();
+    }
+    if (!active) continue;
     // Y = X_p M_p
 #pragma unroll
     for (int r = 0; r < 4; ++r) sT[w][Mf<T>::row(lane, r)][lane & 15] = acc[p][r];
@@ -725,7 +742,7 @@ __global__ __launch_bounds__(256) void k_trsm_rows(Dev<SO> d, int b0, int nb, in
     for (int q = p + 1; q < NP; ++q) {
       if (16 * q >= ncols) continue;
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) acc[q] = Mf<T>::mma(a[s4], lblk(q, p, lane & 15, 4 * s4 + (lane >> 4)), acc[q]);
+      for (int s4 = 0; s4 < 4; ++s4) acc[q] = Mf<T>::mma(a[s4], sLc[(q - p - 1) * 16 + (lane & 15)][4 * s4 + (lane >> 4)], acc[q]);
     }
     WAVE_LDS_SYNC();
     __builtin_amdgcn_sched_barrier(0);   // keep the next panels' loads of L out of this one (the scheduler otherwise hoists them all: spills)
