@@ -821,7 +821,15 @@ bool launch_chol_gain(const Dev<float>& d, int b0, int nb, hipStream_t st) {
   // rows per part = 16 NA - 1; D = 15 + 6 n_cap <= NPART (16 NA - 1)
   if (nbn <= 4) { gain_launch<4, 2, 3>(d, b0, nb, st); return true; }          // D <= 79 <= 3 * 31
   if (nbn <= 8) { gain_launch<8, 3, 3>(d, b0, nb, st); return true; }          // D <= 143 <= 3 * 47
-  if (nbn <= 12) { gain_launch<12, 4, 4>(d, b0, nb, st); return true; }        // D <= 207 <= 4 * 63
+  if (nbn <= 12) {                                                             // D <= 207 <= 4 * 63 = 2 * 111 - ...
+    // four parts per trajectory fill the chip at 64 trajectories; from a batch of 96 on, two parts (each redoes the factorization: half the
+    // workgroups, one round of them instead of two).  Rows are independent and S's blocks are formed by the same instruction
+    // sequence whichever part owns them: same bits either way.  MSCKF_HIP_GAIN_PARTS=2|4 forces one (A/B runs).
+    static const int force = [] { const char* e = getenv("MSCKF_HIP_GAIN_PARTS"); return e ? atoi(e) : 0; }();
+    const bool two = force ? force == 2 : d.B >= 96;   // (the whole batch: its slices run these launches side by side)
+    if (two && 15 + 6 * d.n_cap <= 2 * 111) gain_launch<12, 7, 2>(d, b0, nb, st); else gain_launch<12, 4, 4>(d, b0, nb, st);
+    return true;
+  }
   return false;
 }
 
