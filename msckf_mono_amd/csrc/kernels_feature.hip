@@ -1872,9 +1872,12 @@ void launch_feature(const Dev<S>& d, int b0, int nb, hipStream_t st) {
   if constexpr (sizeof(S) == 4) {
     if (d.feat_pair && d.compress && d.f_cap <= 512) {
       pair = true;
-      // a launch that does not fill the chip anyway (a slice of run_frames: 16 trajectories) takes ONE track per wavefront -- the kernel's
-      // latency is then its slowest wavefront's, and a wavefront with a single track has half the gate work (feat_pair & 2 forces pairs)
-      const int single = (d.feat_pair == 3 || (d.feat_pair == 1 && (long)nb * d.f_cap <= 4096)) ? 1 : 0;
+      // a small launch (a filter or a few: at most 1 024 tracks) takes ONE track per wavefront -- the kernel's latency is then its
+      // slowest wavefront's, and a wavefront with a single track has half the gate work.  A slice of run_frames (16 trajectories, 3 200
+      // tracks) keeps the pairs: alone the single form is 1.5 us faster (40 -> 38.5 us), but with the other slices' kernels beside it
+      // twice the wavefronts cost more than that -- 191-194 k -> 201-202 k updates/s (medians 193-195 k -> 203-205 k), three
+      // alternating runs on one lease.  feat_pair 2 forces pairs, 3 forces the single form.
+      const int single = (d.feat_pair == 3 || (d.feat_pair == 1 && (long)nb * d.f_cap <= 1024)) ? 1 : 0;
       const int lm = d.m_cap < M_REG ? d.m_cap : M_REG, items = single ? d.f_cap : (d.f_cap + 1) / 2;
       int s_cap = 0;
       const size_t lds = feature_pair_lds_bytes(lm, s_cap);
