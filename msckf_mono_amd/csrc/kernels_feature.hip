@@ -1074,11 +1074,12 @@ __device__ __forceinline__ int half_min_i(int v) {
   return min((int)r[0], (int)r[1]);
 }
 
-// Three wavefronts per SIMD (168 registers): at four (128) the kernel spilled 34 live values to scratch -- 56 MB of the launch's
-// 96 MB of writes at 64 trajectories, ~70 scratch instructions per wavefront; at three it spills 5.  One stream of 64
-// trajectories: 82.6 -> 84.6 us; four slices of 16 (the bench): 185-189 k -> 192-193 k updates/s on the same lease.  (Both builds
-// side by side, picked by launch size, measured 95 us for the large launches -- dropped.)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_feature_pair(Dev<float> d, int b0, int nb, int lm, int m_lo, int m_hi, int s_cap, int items, int single) {
+// Register budget: four wavefronts per SIMD (128 registers), at which 34 live values per lane sit in scratch -- 56 MB of the launch's
+// 96 MB of writes at 64 trajectories, ~70 scratch instructions per wavefront.  Three wavefronts (168 registers, 5 spilled, 49 MB of
+// writes) were the better build while the slices ran the one-track form (185-189 k -> 192-193 k updates/s); with pairs in the slices
+// four are again (medians 203.8 / 204.6 k -> 207.2 / 208.6 k, one stream of 64: 84.3 -> 82.3 us; alternating runs on one lease).
+// (Both builds side by side, picked by launch size: the 128-register one then reads 95 us for the large launches, warm or not.)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_feature_pair(Dev<float> d, int b0, int nb, int lm, int m_lo, int m_hi, int s_cap, int items, int single) {
   typedef float S;
   int bi, w;
   if (!xcd_item(nb, items, bi, w)) return;
