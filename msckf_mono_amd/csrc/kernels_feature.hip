@@ -1074,12 +1074,13 @@ __device__ __forceinline__ int half_min_i(int v) {
   return min((int)r[0], (int)r[1]);
 }
 
-// Register budget: four wavefronts per SIMD (128 registers), at which 34 live values per lane sit in scratch -- 56 MB of the launch's
-// 96 MB of writes at 64 trajectories, ~70 scratch instructions per wavefront.  Three wavefronts (168 registers, 5 spilled, 49 MB of
-// writes) were the better build while the slices ran the one-track form (185-189 k -> 192-193 k updates/s); with pairs in the slices
-// four are again (medians 203.8 / 204.6 k -> 207.2 / 208.6 k, one stream of 64: 84.3 -> 82.3 us; alternating runs on one lease).
-// (Both builds side by side, picked by launch size: the 128-register one then reads 95 us for the large launches, warm or not.)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_feature_pair(Dev<float> d, int b0, int nb, int lm, int m_lo, int m_hi, int s_cap, int items, int single) {
+// Register budget: three wavefronts per SIMD (168 registers, 5 values per lane in scratch).  At four (128 registers) 34 live values
+// per lane sit in scratch: 56 MB of the launch's 96 MB of writes at 64 trajectories (166 MB of traffic per launch instead of 64),
+// ~70 scratch instructions per wavefront.  Throughput: the three-wavefront build was ahead while the slices ran the one-track form
+// (185-189 k -> 192-193 k updates/s), with pairs in the slices the four-wavefront build is (medians 203.8 / 204.6 k vs 207.2 /
+// 208.6 k, alternating runs on one lease: 1.5 %, inside what leases differ by) -- the build that moves a third of the bytes ships.
+// (Both side by side, picked by launch size: the 128-register one then reads 95 us for the large launches, warm or not.)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_feature_pair(Dev<float> d, int b0, int nb, int lm, int m_lo, int m_hi, int s_cap, int items, int single) {
   typedef float S;
   int bi, w;
   if (!xcd_item(nb, items, bi, w)) return;
