@@ -292,6 +292,35 @@ def test_information_form_equals_householder_route(capi, prec):
     assert res[3][3]["r_rows"] < res[0][3]["r_rows"] == 6 * N            # gauge directions skipped
 
 
+@pytest.mark.parametrize("prec,N,F", [("f64", 10, 50), ("f32", 10, 50), ("f64", 12, 40), ("f32", 13, 40), ("f64", 4, 16)])
+def test_one_launch_update_of_short_windows_equals_the_chain(capi, prec, N, F, monkeypatch):
+    """Windows of at most 14 cameras take everything after k_select_diag in ONE launch (k_update_small, kernels_kalman.hip:
+    Gram matrix, both factorizations, gain, injection and downdate of msckf.h:404-431, 1338-1418 out of one workgroup's LDS)
+    instead of the chain k_gram / k_chol_mfma / GEMMs / gain solve / downdate.  Same update, other arithmetic order: free-running
+    over N + 10 frames the two must agree to rounding (double 1e-9 -- the 10-camera window is BASELINE configs[1]'s -- float
+    1e-4), with the same gate decisions and row counts.  MSCKF_HIP_SMALL_UPDATE=0 at create time selects the chain."""
+    nf = N + 10
+    tr = sc.Trajectory(2, 21, N, F, nf)
+    cd = capi.F64 if prec == "f64" else capi.F32
+    res = {}
+    for small in ("84", "0"):
+        monkeypatch.setenv("MSCKF_HIP_SMALL_UPDATE", small)
+        bt = capi.Batch(1, N, F, max(N, 4), cd)
+        bt.initialize(0, tr.cfg, tr.imu0)
+        stats = []
+        for k in range(nf):
+            H.device_frame(bt, 0, tr, k, N)
+            stats.append(bt.last_stats(0, strict=False))
+        res[small] = (bt.imu_state(0), bt.cam_states(0)[0], bt.covariance(0), stats)
+        bt.close()
+    a, c = res["84"], res["0"]
+    e = H.state_errors(a[0], c[0], a[1], c[1], a[2], c[2])
+    assert H.worst(e) < (1e-9 if prec == "f64" else 1e-4), e
+    assert np.array_equal(a[2], a[2].T)
+    strip = lambda st: [{k: v for k, v in s.items() if k != "r_rows"} for s in st]      # r_rows: pivots above a rounding-level tolerance
+    assert strip(a[3]) == strip(c[3]) and sum(s["n_passed"] for s in a[3]) > 0
+
+
 @pytest.mark.parametrize("prec,N,F", [("f64", 8, 24), ("f64", 26, 60), ("f32", 12, 40), ("f32", 30, 120), ("f64", 36, 80), ("f32", 44, 100), ("f64", 60, 120), ("f32", 32, 80), ("f32", 33, 80)])
 def test_square_root_gain_form_equals_joseph_form(capi, prec, N, F):
     """Covariance update of measurementUpdate (msckf.h:1368-1418): the default square-root gain form (W = P T_H^T L^-T,
